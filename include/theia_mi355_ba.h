@@ -1,0 +1,334 @@
+/*
+ * theia_mi355_ba.h -- C ABI of the MI355X-native bundle-adjustment engine.
+ *
+ * This is the drop-in boundary for TheiaSfM's full-reconstruction bundle
+ * adjustment.  Theia has no FFI / plugin registry for this path: the seam is
+ * the C++ API
+ *     BundleAdjustReconstruction / BundleAdjustPartialReconstruction
+ *         (reference: src/theia/sfm/bundle_adjustment/bundle_adjustment.h:136-155)
+ *     class BundleAdjuster { AddView, AddTrack, Optimize }
+ *         (reference: src/theia/sfm/bundle_adjustment/bundle_adjuster.h:60-77)
+ * whose Optimize() is hard-wired to ceres::Solve
+ *         (reference: src/theia/sfm/bundle_adjustment/bundle_adjuster.cc:205).
+ * The entry points below are what a maintainer would bind in place of that
+ * ceres::Solve call: the host side flattens the Reconstruction into the SoA
+ * arrays of tmi_ba_problem, calls tmi_ba_solve(), and copies the in/out arrays
+ * back (see INTEGRATION.md for the binding, include/theia/ for the host shim).
+ *
+ * Plain C, plain pointers and sizes.  No torch / Eigen / Ceres types.
+ * All floating point is IEEE fp64, all indices int32 (observation count int64).
+ * The library never keeps a caller pointer past the return of a call, never
+ * aborts and never throws across this boundary: every entry point returns a
+ * tmi_ba_status.
+ */
+#ifndef THEIA_MI355_BA_H_
+#define THEIA_MI355_BA_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TMI_BA_VERSION_MAJOR 0
+#define TMI_BA_VERSION_MINOR 1
+
+/* ---- status codes ------------------------------------------------------ */
+typedef enum tmi_ba_status {
+  TMI_BA_OK = 0,
+  TMI_BA_ERR_INVALID_ARGUMENT = 1, /* null pointer, bad index, bad enum      */
+  TMI_BA_ERR_NO_DEVICE = 2,        /* no gfx950 device visible               */
+  TMI_BA_ERR_DEVICE = 3,           /* a HIP runtime call failed              */
+  TMI_BA_ERR_OUT_OF_MEMORY = 4,
+  TMI_BA_ERR_UNSUPPORTED = 5,      /* problem shape the device path lacks    */
+  TMI_BA_ERR_EVALUATION_FAILED = 6,/* residual undefined at the start point  */
+  TMI_BA_ERR_LINEAR_SOLVER = 7,    /* reduced system could not be solved     */
+  TMI_BA_ERR_COLLECTIVE = 8        /* the all-reduce callback reported error */
+} tmi_ba_status;
+
+/* ---- enums mirrored from the reference ---------------------------------- */
+
+/* CameraIntrinsicsModelType,
+ * reference: src/theia/sfm/camera/camera_intrinsics_model_type.h:45-52.
+ * Parameter order inside one intrinsics group:
+ *   PINHOLE (7)                  [f, ar, skew, px, py, k1, k2]
+ *       reference: pinhole_camera_model.h:86-94
+ *   PINHOLE_RADIAL_TANGENTIAL(10)[f, ar, skew, px, py, k1, k2, k3, t1, t2]
+ *       reference: pinhole_radial_tangential_camera_model.h:91-102
+ *   FISHEYE (9)                  [f, ar, skew, px, py, k1, k2, k3, k4]
+ *       reference: fisheye_camera_model.h:67-77
+ *   FOV (5)                      [f, ar, px, py, omega]
+ *       reference: fov_camera_model.h:69-75
+ *   DIVISION_UNDISTORTION (5)    [f, ar, px, py, k]
+ *       reference: division_undistortion_camera_model.h:76-82            */
+typedef enum tmi_ba_camera_model {
+  TMI_BA_PINHOLE = 0,
+  TMI_BA_PINHOLE_RADIAL_TANGENTIAL = 1,
+  TMI_BA_FISHEYE = 2,
+  TMI_BA_FOV = 3,
+  TMI_BA_DIVISION_UNDISTORTION = 4
+} tmi_ba_camera_model;
+#define TMI_BA_MAX_INTRINSICS 10
+#define TMI_BA_EXTRINSICS_SIZE 6 /* [C(3), angle_axis(3)], camera.h:195-200 */
+
+/* LossFunctionType,
+ * reference: src/theia/sfm/bundle_adjustment/create_loss_function.h:51-58 */
+typedef enum tmi_ba_loss {
+  TMI_BA_LOSS_TRIVIAL = 0,
+  TMI_BA_LOSS_HUBER = 1,
+  TMI_BA_LOSS_SOFTLONE = 2,
+  TMI_BA_LOSS_CAUCHY = 3,
+  TMI_BA_LOSS_ARCTAN = 4,
+  TMI_BA_LOSS_TUKEY = 5
+} tmi_ba_loss;
+
+/* ceres::LinearSolverType values Theia passes through
+ * (reference: bundle_adjustment.h:86; bundle_adjustment.cc:86,100 force
+ * DENSE_QR for single view / single track problems).  The device path solves
+ * the reduced camera system exactly (blocked dense Cholesky of the explicit
+ * Schur complement) for DENSE_QR/DENSE_SCHUR/SPARSE_SCHUR and with
+ * preconditioned conjugate gradients for ITERATIVE_SCHUR/CGNR.             */
+typedef enum tmi_ba_linear_solver {
+  TMI_BA_DENSE_QR = 1,
+  TMI_BA_DENSE_SCHUR = 3,
+  TMI_BA_SPARSE_SCHUR = 4,
+  TMI_BA_ITERATIVE_SCHUR = 5,
+  TMI_BA_CGNR = 6
+} tmi_ba_linear_solver;
+
+/* ceres::PreconditionerType (bundle_adjustment.h:87).  The device path has
+ * SCHUR_JACOBI (block diagonal of the reduced camera matrix); JACOBI maps to
+ * it, the cluster preconditioners are accepted and mapped to SCHUR_JACOBI.  */
+typedef enum tmi_ba_preconditioner {
+  TMI_BA_PRECOND_IDENTITY = 0,
+  TMI_BA_PRECOND_JACOBI = 1,
+  TMI_BA_PRECOND_SCHUR_JACOBI = 2,
+  TMI_BA_PRECOND_CLUSTER_JACOBI = 3,
+  TMI_BA_PRECOND_CLUSTER_TRIDIAGONAL = 4
+} tmi_ba_preconditioner;
+
+/* OptimizeIntrinsicsType bit flags, reference: bundle_adjustment.h:65-76 */
+enum {
+  TMI_BA_INTRINSICS_NONE = 0x00,
+  TMI_BA_INTRINSICS_FOCAL_LENGTH = 0x01,
+  TMI_BA_INTRINSICS_ASPECT_RATIO = 0x02,
+  TMI_BA_INTRINSICS_SKEW = 0x04,
+  TMI_BA_INTRINSICS_PRINCIPAL_POINTS = 0x08,
+  TMI_BA_INTRINSICS_RADIAL_DISTORTION = 0x10,
+  TMI_BA_INTRINSICS_TANGENTIAL_DISTORTION = 0x20,
+  TMI_BA_INTRINSICS_ALL = 0x3f
+};
+
+/* camera_flags bits: which half of the 6 extrinsics is held constant
+ * (reference: bundle_adjuster.cc:304-334; both bits = SetCameraExtrinsicsConstant,
+ * which is also what AddTrack does to cameras that were not added through
+ * AddView, bundle_adjuster.cc:156-168).                                     */
+enum {
+  TMI_BA_CAMERA_POSITION_CONSTANT = 0x1,
+  TMI_BA_CAMERA_ORIENTATION_CONSTANT = 0x2
+};
+
+/* ---- the flattened problem ---------------------------------------------- */
+/* Caller-owned structure-of-arrays view of the residual set
+ *   {(view, track): view estimated, track estimated, view observes track}
+ * that BundleAdjuster::AddView/AddTrack build (bundle_adjuster.cc:102-180).
+ * Arrays marked in/out are overwritten with the optimised values when the
+ * solve produced a usable solution (Ceres semantics: CONVERGENCE or
+ * NO_CONVERGENCE, bundle_adjuster.cc:218) and left untouched otherwise.     */
+typedef struct tmi_ba_problem {
+  /* cameras (one per optimised or anchoring view) */
+  int32_t num_cameras;
+  double* extrinsics;            /* in/out [6*num_cameras]                   */
+  const int32_t* camera_group;   /* [num_cameras] intrinsics group index     */
+  const uint8_t* camera_flags;   /* [num_cameras] TMI_BA_CAMERA_* bits       */
+
+  /* shared intrinsics groups (reference: reconstruction.h:93-106; one Ceres
+   * parameter block per group because Camera holds a shared_ptr, camera.h:247) */
+  int32_t num_groups;
+  const int32_t* group_model;    /* [num_groups] tmi_ba_camera_model         */
+  const int32_t* group_offset;   /* [num_groups+1] offsets into intrinsics   */
+  double* intrinsics;            /* in/out [group_offset[num_groups]]        */
+  const uint8_t* intrinsics_constant; /* same length; 1 = held constant
+                                    (GetSubsetFromOptimizeIntrinsicsType and
+                                    the whole-block rule bundle_adjuster.cc:242-287) */
+
+  /* tracks: homogeneous 3-D points (reference: track.h:66-67) */
+  int32_t num_points;
+  double* points;                /* in/out [4*num_points]                    */
+  const uint8_t* point_constant; /* [num_points] 1 = SetTrackConstant        */
+
+  /* observations: Feature = pixel (x, y) (reference: feature.h) */
+  int64_t num_observations;
+  const int32_t* obs_camera;     /* [num_observations]                       */
+  const int32_t* obs_point;      /* [num_observations]                       */
+  const double* obs_xy;          /* [2*num_observations]                     */
+} tmi_ba_problem;
+
+/* ---- options: BundleAdjustmentOptions field for field -------------------- */
+/* reference: src/theia/sfm/bundle_adjustment/bundle_adjustment.h:78-122.
+ * intrinsics_to_optimize / constant_camera_* live in the flattened problem
+ * (intrinsics_constant, camera_flags); tmi_ba_intrinsics_constant_mask()
+ * below converts the bitmask.                                               */
+typedef struct tmi_ba_options {
+  int32_t loss_function_type;        /* tmi_ba_loss, default TRIVIAL         */
+  double robust_loss_width;          /* 2.0                                   */
+  int32_t linear_solver_type;        /* tmi_ba_linear_solver, SPARSE_SCHUR    */
+  int32_t preconditioner_type;       /* tmi_ba_preconditioner, SCHUR_JACOBI   */
+  int32_t verbose;                   /* 0                                     */
+  int32_t num_threads;               /* accepted, unused by the device path   */
+  int32_t max_num_iterations;        /* 100                                   */
+  double max_solver_time_in_seconds; /* 3600                                  */
+  int32_t use_inner_iterations;      /* accepted; the device path runs plain
+                                        LM (no inner iterations), see DESIGN  */
+  double function_tolerance;         /* 1e-6                                  */
+  double gradient_tolerance;         /* 1e-10                                 */
+  double parameter_tolerance;        /* 1e-8                                  */
+  double max_trust_region_radius;    /* 1e12                                  */
+
+  /* Ceres defaults Theia does not override; exposed so the
+   * benchmark and the tests can pin them.                                    */
+  double initial_trust_region_radius; /* 1e4                                  */
+  double min_trust_region_radius;     /* 1e-32                                */
+  double min_relative_decrease;       /* 1e-3                                 */
+  double min_lm_diagonal;             /* 1e-6                                 */
+  double max_lm_diagonal;             /* 1e32                                 */
+  double eta;                         /* 0.1  (PCG forcing, q-tolerance)      */
+  int32_t max_linear_solver_iterations; /* 500                                */
+  int32_t min_linear_solver_iterations; /* 0                                  */
+  int32_t max_num_consecutive_invalid_steps; /* 5                             */
+  int32_t jacobi_scaling;             /* 1                                    */
+
+  /* extensions of the device path */
+  int32_t point_dof;       /* 4 = reference-exact homogeneous points (no
+                              parameterization, bundle_adjuster.cc:379-385);
+                              3 = hold w fixed (the north-star 2x3 blocks)   */
+  int32_t device;          /* HIP device ordinal; -1 = current device        */
+  int32_t profile_kernels; /* 1 = bracket every kernel class with HIP events
+                              and report per-class times in the summary      */
+  int32_t residual_precision; /* 64 (fp64). 32 reserved for the fp32 path    */
+} tmi_ba_options;
+
+/* ---- summary: BundleAdjustmentSummary + device-path extras --------------- */
+/* reference: bundle_adjustment.h:125-133 */
+#define TMI_BA_NUM_KERNEL_CLASSES 12
+typedef struct tmi_ba_summary {
+  int32_t success;               /* IsSolutionUsable()                       */
+  double initial_cost;           /* 1/2 sum rho(|r|^2)                       */
+  double final_cost;
+  double setup_time_in_seconds;  /* flatten-side preprocessing + upload      */
+  double solve_time_in_seconds;  /* the LM loop, device-resident inputs      */
+
+  int32_t status;                /* tmi_ba_status                            */
+  int32_t termination;           /* 0 convergence, 1 no convergence (limits),
+                                    2 failure                                */
+  int32_t num_iterations;        /* LM iterations run (accepted + rejected)  */
+  int32_t num_successful_steps;
+  int32_t num_unsuccessful_steps;
+  int64_t num_linear_solver_iterations; /* PCG iterations over the solve     */
+  double final_rmse;             /* sqrt(sum |r|^2 / num_obs), un-robustified */
+  double initial_rmse;
+  int32_t num_reduced_blocks;    /* camera blocks of the reduced system      */
+  int32_t reduced_block_dim;     /* D (uniform, zero padded)                 */
+  int64_t num_schur_blocks;      /* structurally non-zero D x D blocks of S,
+                                    upper triangle incl. diagonal            */
+  int64_t num_schur_pairs;       /* observation pairs feeding off-diagonal S */
+  /* per kernel class (index = tmi_ba_kernel_class): launches and total
+   * device time from HIP events; filled when options.profile_kernels != 0   */
+  int64_t kernel_launches[TMI_BA_NUM_KERNEL_CLASSES];
+  double kernel_seconds[TMI_BA_NUM_KERNEL_CLASSES];
+  char message[192];
+} tmi_ba_summary;
+
+typedef enum tmi_ba_kernel_class {
+  TMI_BA_K_LINEARIZE = 0,      /* residuals + Jacobian blocks per observation */
+  TMI_BA_K_POINT_ELIMINATE = 1,/* per-track V, g_p, (V+D)^-1, Y = W L^-T     */
+  TMI_BA_K_CAMERA_DIAG = 2,    /* per-camera U, g~, diagonal S block          */
+  TMI_BA_K_SCHUR_OFFDIAG = 3,  /* off-diagonal S blocks from pair lists       */
+  TMI_BA_K_PRECONDITIONER = 4, /* invert diagonal blocks                      */
+  TMI_BA_K_SPMV = 5,           /* q = S p (PCG)                               */
+  TMI_BA_K_PCG_VECTOR = 6,     /* PCG dots / axpys / preconditioner apply     */
+  TMI_BA_K_CHOLESKY = 7,       /* dense reduced-system factor + solve         */
+  TMI_BA_K_BACK_SUBSTITUTE = 8,/* delta_p, model cost change                  */
+  TMI_BA_K_UPDATE_COST = 9,    /* x+ = x + delta, trial cost                  */
+  TMI_BA_K_REDUCE = 10,        /* small reductions / bookkeeping              */
+  TMI_BA_K_ALLREDUCE = 11      /* time spent inside the all-reduce callback   */
+} tmi_ba_kernel_class;
+
+/* ---- multi-GPU hook ------------------------------------------------------- */
+/* When the tracks are sharded over several processes (one per GPU) each rank
+ * builds the reduced camera system from its own tracks; the engine then calls
+ * this hook once per LM iteration on the concatenated device buffer
+ *   [S blocks | U diagonal | reduced gradient | cost terms]
+ * and once (a few doubles) for the trial cost.  The hook must sum `count`
+ * doubles in place across ranks (RCCL all-reduce over xGMI in practice) on
+ * `stream` or synchronise it itself.  Return 0 on success.                  */
+typedef int (*tmi_ba_allreduce_fn)(void* device_buffer, int64_t count,
+                                   void* hip_stream, void* user);
+
+/* ---- entry points --------------------------------------------------------- */
+typedef struct tmi_ba_solver tmi_ba_solver; /* opaque, device-resident problem */
+
+/* Library / device discovery. */
+int32_t tmi_ba_version(void);           /* major*1000 + minor                 */
+int32_t tmi_ba_device_count(void);      /* gfx950 devices visible, <0 = error */
+const char* tmi_ba_status_string(int32_t status);
+
+/* Fill `opts` with the reference defaults (bundle_adjustment.h:78-122 plus
+ * the Ceres defaults of SURVEY App. B). */
+void tmi_ba_options_init(tmi_ba_options* opts);
+
+/* Number of intrinsic parameters of a camera model (kIntrinsicsSize), or -1. */
+int32_t tmi_ba_intrinsics_size(int32_t camera_model);
+
+/* GetSubsetFromOptimizeIntrinsicsType for one model
+ * (reference: pinhole_camera_model.cc:132-162 and the four siblings):
+ * writes 1 into mask[i] for every parameter held constant under the
+ * OptimizeIntrinsicsType bitmask.  mask has tmi_ba_intrinsics_size() entries. */
+int32_t tmi_ba_intrinsics_constant_mask(int32_t camera_model,
+                                        int32_t intrinsics_to_optimize,
+                                        uint8_t* mask);
+
+/* One-shot: upload, solve, download.  The replacement for ceres::Solve at
+ * bundle_adjuster.cc:205.  Re-entrant; serialises per device.               */
+int32_t tmi_ba_solve(tmi_ba_problem* problem, const tmi_ba_options* options,
+                     tmi_ba_summary* summary);
+
+/* Resident form (used by the benchmark so the timed region starts with the
+ * inputs already in HBM, and by pipelines that run BA -> filter -> BA):
+ *   create   : validate, build the static structure (track-major and
+ *              camera-major orders, Schur block structure, pair lists),
+ *              upload.  `rank`/`world` select the contiguous shard of tracks
+ *              this process owns (0/1 for single GPU).
+ *   solve    : run LM on the resident parameters (may be called repeatedly).
+ *   reset    : restore the parameters uploaded at create time.
+ *   download : copy the current parameters into the caller's in/out arrays.  */
+int32_t tmi_ba_solver_create(const tmi_ba_problem* problem,
+                             const tmi_ba_options* options, int32_t rank,
+                             int32_t world, tmi_ba_solver** out);
+int32_t tmi_ba_solver_set_allreduce(tmi_ba_solver* s, tmi_ba_allreduce_fn fn,
+                                    void* user);
+int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* options,
+                            tmi_ba_summary* summary);
+int32_t tmi_ba_solver_reset(tmi_ba_solver* s);
+int32_t tmi_ba_solver_download(tmi_ba_solver* s, tmi_ba_problem* problem);
+/* The HIP stream the engine launches on (so callers can record their own
+ * events on it). */
+void* tmi_ba_solver_stream(tmi_ba_solver* s);
+void tmi_ba_solver_destroy(tmi_ba_solver* s);
+
+/* Per-observation evaluation on the device, exposed for parity tests:
+ * residuals [2*N], the reduced camera Jacobian blocks [2*D*N] (row major
+ * 2 x D, columns = free extrinsics then free intrinsics of the observing
+ * camera) and point Jacobian blocks [2*point_dof*N], in the caller's
+ * observation order, without loss correction or Jacobi scaling.
+ * valid[i] = 0 where the reference functor returns false
+ * (reprojection_error.h:75-77).  Any output pointer may be NULL.            */
+int32_t tmi_ba_solver_evaluate(tmi_ba_solver* s, double* residuals,
+                               double* jac_camera, double* jac_point,
+                               uint8_t* valid, int32_t* block_dim);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+#endif /* THEIA_MI355_BA_H_ */

@@ -1,0 +1,1520 @@
+/*
+ * ORACLE -- TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+ * See ba_oracle.h for scope, provenance and pinning status.
+ */
+#include "ba_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "jet.h"
+
+/* ---- instantiate the residual template for double and for jets ---------- */
+#define T double
+#define FN(name) name##_d
+#define CST(c) (c)
+#define ADD(a, b) ((a) + (b))
+#define SUB(a, b) ((a) - (b))
+#define MUL(a, b) ((a) * (b))
+#define DIV(a, b) ((a) / (b))
+#define NEG(a) (-(a))
+#define SQRT(a) sqrt(a)
+#define COS(a) cos(a)
+#define SIN(a) sin(a)
+#define TAN(a) tan(a)
+#define ATAN(a) atan(a)
+#define ATAN2(a, b) atan2(a, b)
+#define ABS(a) fabs(a)
+#define VAL(a) (a)
+#include "reprojection_tmpl.h"
+#undef T
+#undef FN
+#undef CST
+#undef ADD
+#undef SUB
+#undef MUL
+#undef DIV
+#undef NEG
+#undef SQRT
+#undef COS
+#undef SIN
+#undef TAN
+#undef ATAN
+#undef ATAN2
+#undef ABS
+#undef VAL
+
+#define T jet
+#define FN(name) name##_j
+#define CST(c) jet_const(c)
+#define ADD(a, b) jet_add(a, b)
+#define SUB(a, b) jet_sub(a, b)
+#define MUL(a, b) jet_mul(a, b)
+#define DIV(a, b) jet_div(a, b)
+#define NEG(a) jet_neg(a)
+#define SQRT(a) jet_sqrt(a)
+#define COS(a) jet_cos(a)
+#define SIN(a) jet_sin(a)
+#define TAN(a) jet_tan(a)
+#define ATAN(a) jet_atan(a)
+#define ATAN2(a, b) jet_atan2(a, b)
+#define ABS(a) jet_abs(a)
+#define VAL(x_) ((x_).a)
+#include "reprojection_tmpl.h"
+#undef T
+#undef FN
+#undef CST
+#undef ADD
+#undef SUB
+#undef MUL
+#undef DIV
+#undef NEG
+#undef SQRT
+#undef COS
+#undef SIN
+#undef TAN
+#undef ATAN
+#undef ATAN2
+#undef ABS
+#undef VAL
+
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+int32_t oracle_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+static int model_size(int model) {
+  /* kIntrinsicsSize: pinhole_camera_model.h:84, pinhole_radial_tangential_
+   * camera_model.h:89, fisheye_camera_model.h:65, fov_camera_model.h:67,
+   * division_undistortion_camera_model.h:74 */
+  static const int n[5] = {7, 10, 9, 5, 5};
+  return (model >= 0 && model < 5) ? n[model] : -1;
+}
+
+/* ---- GetSubsetFromOptimizeIntrinsicsType --------------------------------- */
+/* reference: pinhole_camera_model.cc:132-162,
+ * pinhole_radial_tangential_camera_model.cc:150-185,
+ * fisheye_camera_model.cc:142-175, fov_camera_model.cc:124-149,
+ * division_undistortion_camera_model.cc:126-150. */
+int32_t oracle_intrinsics_constant_mask(int32_t model, int32_t bits, uint8_t* mask) {
+  const int n = model_size(model);
+  if (n < 0 || !mask) return -1;
+  memset(mask, 0, (size_t)n);
+  if (bits == TMI_BA_INTRINSICS_ALL) return n;
+  const int no_f = !(bits & TMI_BA_INTRINSICS_FOCAL_LENGTH);
+  const int no_ar = !(bits & TMI_BA_INTRINSICS_ASPECT_RATIO);
+  const int no_skew = !(bits & TMI_BA_INTRINSICS_SKEW);
+  const int no_pp = !(bits & TMI_BA_INTRINSICS_PRINCIPAL_POINTS);
+  const int no_rad = !(bits & TMI_BA_INTRINSICS_RADIAL_DISTORTION);
+  const int no_tan = !(bits & TMI_BA_INTRINSICS_TANGENTIAL_DISTORTION);
+  switch (model) {
+    case 0: /* [f, ar, skew, px, py, k1, k2] */
+      mask[0] = no_f; mask[1] = no_ar; mask[2] = no_skew;
+      mask[3] = mask[4] = no_pp; mask[5] = mask[6] = no_rad;
+      break;
+    case 1: /* [f, ar, skew, px, py, k1, k2, k3, t1, t2] */
+      mask[0] = no_f; mask[1] = no_ar; mask[2] = no_skew;
+      mask[3] = mask[4] = no_pp; mask[5] = mask[6] = mask[7] = no_rad;
+      mask[8] = mask[9] = no_tan;
+      break;
+    case 2: /* [f, ar, skew, px, py, k1..k4] */
+      mask[0] = no_f; mask[1] = no_ar; mask[2] = no_skew;
+      mask[3] = mask[4] = no_pp;
+      mask[5] = mask[6] = mask[7] = mask[8] = no_rad;
+      break;
+    default: /* FOV / division: [f, ar, px, py, w|k] (no skew term) */
+      mask[0] = no_f; mask[1] = no_ar; mask[2] = mask[3] = no_pp; mask[4] = no_rad;
+      break;
+  }
+  return n;
+}
+
+/* ---- projection helpers --------------------------------------------------- */
+void oracle_camera_to_pixel(int32_t model, const double* K, const double* pt, double* px) {
+  camera_to_pixel_d(model, K, pt, px);
+}
+
+/* UndistortPoint of each model + PixelToCameraCoordinates (used only to
+ * restate the reference round-trip tests).
+ * reference: pinhole_camera_model.h:212-239,259-296;
+ * pinhole_radial_tangential_camera_model.h:221-248,293-355;
+ * fisheye_camera_model.h:189-216,269-335; fov_camera_model.h:184-209,262-306;
+ * division_undistortion_camera_model.h:226-254,291-310. */
+static void undistort_iterative(int model, const double* K, const double d[2], double u[2]) {
+  u[0] = d[0];
+  u[1] = d[1];
+  for (int it = 0; it < 100; ++it) { /* kNumUndistortionIterations */
+    const double p0 = u[0], p1 = u[1];
+    const double r_sq = u[0] * u[0] + u[1] * u[1];
+    if (model == 0) {
+      const double dd = 1.0 + r_sq * (K[5] + K[6] * r_sq);
+      u[0] = d[0] / dd;
+      u[1] = d[1] / dd;
+    } else if (model == 1) {
+      const double rd = 1.0 + K[5] * r_sq + K[6] * r_sq * r_sq + K[7] * r_sq * r_sq * r_sq;
+      const double tx = K[9] * (r_sq + 2.0 * u[0] * u[0]) + 2.0 * K[8] * u[0] * u[1];
+      const double ty = K[8] * (r_sq + 2.0 * u[1] * u[1]) + 2.0 * K[9] * u[0] * u[1];
+      u[0] = (d[0] - tx) / rd;
+      u[1] = (d[1] - ty) / rd;
+    } else { /* fisheye */
+      const double r = sqrt(r_sq);
+      if (r < 1e-8) {
+        u[0] = d[0];
+        u[1] = d[1];
+        return;
+      }
+      const double theta = atan2(r, 1.0);
+      const double t2 = theta * theta;
+      const double theta_d = theta * (1.0 + K[5] * t2 + K[6] * t2 * t2 + K[7] * t2 * t2 * t2 +
+                                      K[8] * t2 * t2 * t2 * t2);
+      u[0] = r * d[0] / theta_d;
+      u[1] = r * d[1] / theta_d;
+    }
+    if (fabs(u[0] - p0) < 1e-10 && fabs(u[1] - p1) < 1e-10) break;
+  }
+}
+
+void oracle_pixel_to_camera(int32_t model, const double* K, const double* px, double* pt) {
+  double d[2], u[2];
+  if (model <= 2) {
+    const double fy = K[0] * K[1];
+    d[1] = (px[1] - K[4]) / fy;
+    d[0] = (px[0] - K[3] - d[1] * K[2]) / K[0];
+    undistort_iterative(model, K, d, u);
+    pt[0] = u[0];
+    pt[1] = u[1];
+  } else if (model == 3) {
+    const double fy = K[0] * K[1];
+    d[0] = (px[0] - K[2]) / K[0];
+    d[1] = (px[1] - K[3]) / fy;
+    const double omega = K[4];
+    const double r_d_sq = d[0] * d[0] + d[1] * d[1];
+    double r_u;
+    if (omega < 1e-3) {
+      r_u = (omega * omega * r_d_sq) / 3.0 - omega * omega / 12.0 + 1.0;
+    } else if (r_d_sq < 1e-3) {
+      r_u = (omega * (omega * omega * r_d_sq + 3.0)) / (6.0 * tan(omega / 2.0));
+    } else {
+      const double r_d = sqrt(r_d_sq);
+      r_u = tan(r_d * omega) / (2.0 * r_d * tan(omega / 2.0));
+    }
+    pt[0] = r_u * d[0];
+    pt[1] = r_u * d[1];
+  } else {
+    const double fy = K[0] * K[1];
+    d[0] = px[0] - K[2];
+    d[1] = px[1] - K[3];
+    const double r_d_sq = d[0] * d[0] + d[1] * d[1];
+    const double undistortion = 1.0 / (1.0 + K[4] * r_d_sq);
+    pt[0] = d[0] * undistortion / K[0];
+    pt[1] = d[1] * undistortion / fy;
+  }
+  pt[2] = 1.0;
+}
+
+/* batched forms so the reference's grid tests can be restated cheaply */
+void oracle_camera_to_pixel_batch(int32_t model, const double* K, const double* pts, int64_t n,
+                                  double* px) {
+  for (int64_t i = 0; i < n; ++i) camera_to_pixel_d(model, K, pts + 3 * i, px + 2 * i);
+}
+void oracle_pixel_to_camera_batch(int32_t model, const double* K, const double* px, int64_t n,
+                                  double* pts) {
+  for (int64_t i = 0; i < n; ++i) oracle_pixel_to_camera(model, K, px + 2 * i, pts + 3 * i);
+}
+
+/* Camera::ProjectPoint, reference camera.cc:204-213 */
+double oracle_project_point(int32_t model, const double* ext, const double* K,
+                            const double* X, double* pixel) {
+  const double adjusted[3] = {X[0] - X[3] * ext[0], X[1] - X[3] * ext[1], X[2] - X[3] * ext[2]};
+  double rotated[3];
+  angle_axis_rotate_point_d(ext + 3, adjusted, rotated);
+  camera_to_pixel_d(model, K, rotated, pixel);
+  return rotated[2] / X[3];
+}
+
+/* ---- robust losses --------------------------------------------------------- */
+/* ceres/loss_function.cc (Ceres 1.14) restated; constructed by
+ * CreateLossFunction, reference create_loss_function.cc:42-71.
+ * TukeyLoss uses the 1.x normalisation rho(0)'=1/2 (SURVEY App. B notes the
+ * constant is version dependent). */
+void oracle_loss(int32_t type, double a, double s, double rho[3]) {
+  switch (type) {
+    case TMI_BA_LOSS_HUBER: {
+      const double b = a * a;
+      if (s > b) {
+        const double r = sqrt(s);
+        rho[0] = 2.0 * a * r - b;
+        rho[1] = fmax(DBL_MIN, a / r);
+        rho[2] = -rho[1] / (2.0 * s);
+      } else {
+        rho[0] = s; rho[1] = 1.0; rho[2] = 0.0;
+      }
+      break;
+    }
+    case TMI_BA_LOSS_SOFTLONE: {
+      const double b = a * a, c = 1.0 / b;
+      const double sum = 1.0 + s * c;
+      const double tmp = sqrt(sum);
+      rho[0] = 2.0 * b * (tmp - 1.0);
+      rho[1] = fmax(DBL_MIN, 1.0 / tmp);
+      rho[2] = -(c * rho[1]) / (2.0 * sum);
+      break;
+    }
+    case TMI_BA_LOSS_CAUCHY: {
+      const double b = a * a, c = 1.0 / b;
+      const double sum = 1.0 + s * c;
+      const double inv = 1.0 / sum;
+      rho[0] = b * log(sum);
+      rho[1] = fmax(DBL_MIN, inv);
+      rho[2] = -c * (inv * inv);
+      break;
+    }
+    case TMI_BA_LOSS_ARCTAN: {
+      const double b = 1.0 / (a * a);
+      const double sum = 1.0 + s * s * b;
+      const double inv = 1.0 / sum;
+      rho[0] = a * atan2(s, a);
+      rho[1] = fmax(DBL_MIN, inv);
+      rho[2] = -2.0 * s * b * (inv * inv);
+      break;
+    }
+    case TMI_BA_LOSS_TUKEY: {
+      const double a_squared = a * a;
+      if (s <= a_squared) {
+        const double value = 1.0 - s / a_squared;
+        const double value_sq = value * value;
+        rho[0] = a_squared / 6.0 * (1.0 - value_sq * value);
+        rho[1] = 0.5 * value_sq;
+        rho[2] = -1.0 / a_squared * value;
+      } else {
+        rho[0] = a_squared / 6.0; rho[1] = 0.0; rho[2] = 0.0;
+      }
+      break;
+    }
+    default:
+      rho[0] = s; rho[1] = 1.0; rho[2] = 0.0;
+  }
+}
+
+/* ---- evaluation of one observation with jets -------------------------------- */
+static int eval_obs_jet(int model, const double* ext, const double* K, int nk, const double* X,
+                        const double* feat, double r[2], double J[2][JN]) {
+  jet e[6], k[TMI_BA_MAX_INTRINSICS], x[4], res[2];
+  for (int i = 0; i < 6; ++i) e[i] = jet_var(ext[i], i);
+  for (int i = 0; i < nk; ++i) k[i] = jet_var(K[i], 6 + i);
+  for (int i = nk; i < TMI_BA_MAX_INTRINSICS; ++i) k[i] = jet_const(0.0);
+  for (int i = 0; i < 4; ++i) x[i] = jet_var(X[i], 16 + i);
+  if (!reprojection_error_j(model, e, k, x, feat, res)) return 0;
+  r[0] = res[0].a;
+  r[1] = res[1].a;
+  memcpy(J[0], res[0].v, sizeof(double) * JN);
+  memcpy(J[1], res[1].v, sizeof(double) * JN);
+  return 1;
+}
+
+int32_t oracle_ba_evaluate(const tmi_ba_problem* P, double* residuals, double* jac_full,
+                           uint8_t* valid) {
+  if (!P) return TMI_BA_ERR_INVALID_ARGUMENT;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < P->num_observations; ++i) {
+    const int c = P->obs_camera[i], p = P->obs_point[i];
+    const int g = P->camera_group[c];
+    const int model = P->group_model[g];
+    const double* K = P->intrinsics + P->group_offset[g];
+    double r[2] = {0, 0}, J[2][JN];
+    memset(J, 0, sizeof(J));
+    const int ok = eval_obs_jet(model, P->extrinsics + 6 * c, K, model_size(model),
+                                P->points + 4 * p, P->obs_xy + 2 * i, r, J);
+    if (residuals) {
+      residuals[2 * i] = r[0];
+      residuals[2 * i + 1] = r[1];
+    }
+    if (jac_full) memcpy(jac_full + 2 * JN * i, J, sizeof(J));
+    if (valid) valid[i] = (uint8_t)ok;
+  }
+  return TMI_BA_OK;
+}
+
+int64_t oracle_ba_cost(const tmi_ba_problem* P, const tmi_ba_options* O, double* cost,
+                       double* rmse) {
+  double c = 0.0, ss = 0.0;
+  int64_t bad = 0;
+  const int lt = O ? O->loss_function_type : 0;
+  const double lw = O ? O->robust_loss_width : 1.0;
+#pragma omp parallel for schedule(static) reduction(+ : c, ss, bad)
+  for (int64_t i = 0; i < P->num_observations; ++i) {
+    const int cam = P->obs_camera[i], p = P->obs_point[i];
+    const int g = P->camera_group[cam];
+    double r[2];
+    if (!reprojection_error_d(P->group_model[g], P->extrinsics + 6 * cam,
+                              P->intrinsics + P->group_offset[g], P->points + 4 * p,
+                              P->obs_xy + 2 * i, r)) {
+      ++bad;
+      continue;
+    }
+    const double s = r[0] * r[0] + r[1] * r[1];
+    double rho[3];
+    oracle_loss(lt, lw, s, rho);
+    c += 0.5 * rho[0];
+    ss += s;
+  }
+  if (cost) *cost = c;
+  if (rmse) *rmse = P->num_observations ? sqrt(ss / (double)P->num_observations) : 0.0;
+  return bad;
+}
+
+/* ---- open-addressing map (block key -> block index) -------------------------- */
+typedef struct {
+  int64_t* keys;
+  int64_t* vals;
+  int64_t cap;
+  int64_t n;
+} hmap;
+static uint64_t hmix(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+  return x;
+}
+static void hmap_init(hmap* h, int64_t cap) {
+  int64_t c = 64;
+  while (c < cap) c <<= 1;
+  h->cap = c;
+  h->n = 0;
+  h->keys = (int64_t*)malloc(sizeof(int64_t) * c);
+  h->vals = (int64_t*)malloc(sizeof(int64_t) * c);
+  for (int64_t i = 0; i < c; ++i) h->keys[i] = -1;
+}
+static void hmap_free(hmap* h) { free(h->keys); free(h->vals); }
+static int64_t hmap_get(const hmap* h, int64_t key) {
+  int64_t i = (int64_t)(hmix((uint64_t)key) & (uint64_t)(h->cap - 1));
+  while (h->keys[i] != -1) {
+    if (h->keys[i] == key) return h->vals[i];
+    i = (i + 1) & (h->cap - 1);
+  }
+  return -1;
+}
+static void hmap_put_raw(hmap* h, int64_t key, int64_t val) {
+  int64_t i = (int64_t)(hmix((uint64_t)key) & (uint64_t)(h->cap - 1));
+  while (h->keys[i] != -1) i = (i + 1) & (h->cap - 1);
+  h->keys[i] = key;
+  h->vals[i] = val;
+  h->n++;
+}
+static void hmap_put(hmap* h, int64_t key, int64_t val) {
+  if (2 * (h->n + 1) > h->cap) {
+    hmap nh;
+    hmap_init(&nh, h->cap * 2);
+    for (int64_t i = 0; i < h->cap; ++i)
+      if (h->keys[i] != -1) hmap_put_raw(&nh, h->keys[i], h->vals[i]);
+    hmap_free(h);
+    *h = nh;
+  }
+  hmap_put_raw(h, key, val);
+}
+
+/* ---- solver state ------------------------------------------------------------- */
+#define MAXC 16 /* max camera-side columns per observation: 6 + 10 */
+
+typedef struct {
+  const tmi_ba_problem* P;
+  const tmi_ba_options* O;
+  int Nc, G, Np, dp;
+  int64_t No;
+  /* working parameters */
+  double *ext, *intr, *pts;
+  /* free-column maps */
+  int *n_ext, *ext_idx;   /* [Nc], [Nc*6] */
+  int *n_intr, *intr_idx; /* [G], [G*10]  */
+  int* grp_private;       /* [G] 1 if exactly one camera uses the group */
+  /* reduced blocks */
+  int nrb, nr;
+  int *rb_dim, *rb_off;
+  int *cam_rb, *grp_rb; /* -1 = none */
+  /* observations sorted by point */
+  int64_t* order;  /* sorted position -> caller index */
+  int64_t* pt_ptr; /* [Np+1] */
+  /* per observation (sorted order) */
+  double *r, *Jc, *Jp; /* 2, 2*MAXC, 2*4 per obs */
+  double* Ep;          /* Jp (V+D)^-1, 2*4 per obs */
+  /* scaling and LM diagonal */
+  double *scale_c, *scale_p; /* [nr], [Np*dp] */
+  double *diag_c, *diag_p;   /* squared column norms of the scaled Jacobian */
+  /* per point */
+  double *Vinv, *gp, *tp; /* dp*dp, dp, dp */
+  /* reduced system */
+  hmap bmap;
+  int64_t nblk;
+  int* blk_i;
+  int* blk_j;
+  int64_t* blk_off;
+  int64_t* row_ptr; /* CSR over blocks by block row */
+  int64_t* row_blk;
+  double* S;
+  int64_t S_len;
+  double *gc, *rhs, *yc, *yp;
+  double* dense; /* nr*nr when an exact solve is requested */
+  int64_t pcg_iters;
+} ost;
+
+static int obs_parts(const ost* s, int c, int* rb0, int* n0, int* rb1, int* n1) {
+  const int g = s->P->camera_group[c];
+  *rb0 = s->cam_rb[c];
+  *n0 = (*rb0 >= 0) ? s->rb_dim[*rb0] : 0;
+  *rb1 = s->grp_private[g] ? -1 : s->grp_rb[g];
+  *n1 = (*rb1 >= 0) ? s->rb_dim[*rb1] : 0;
+  return *n0 + *n1;
+}
+
+/* Evaluate all observations.  with_jac: fill r (robustified), Jc, Jp (robustified,
+ * Jacobi-scaled if apply_scale).  Returns cost via *cost, sum of squared raw
+ * residuals via *ss, and the number of invalid observations. */
+static int64_t evaluate(ost* s, int with_jac, int apply_scale, double* cost, double* ss_out) {
+  const tmi_ba_problem* P = s->P;
+  double c = 0.0, ss = 0.0;
+  int64_t bad = 0;
+  const int lt = s->O->loss_function_type;
+  const double lw = s->O->robust_loss_width;
+#pragma omp parallel for schedule(static) reduction(+ : c, ss, bad)
+  for (int64_t k = 0; k < s->No; ++k) {
+    const int64_t i = s->order[k];
+    const int cam = P->obs_camera[i], p = P->obs_point[i];
+    const int g = P->camera_group[cam];
+    const int model = P->group_model[g];
+    const double* K = s->intr + P->group_offset[g];
+    double r[2];
+    if (!with_jac) {
+      if (!reprojection_error_d(model, s->ext + 6 * cam, K, s->pts + 4 * p, P->obs_xy + 2 * i,
+                                r)) {
+        ++bad;
+        continue;
+      }
+      const double sq = r[0] * r[0] + r[1] * r[1];
+      double rho[3];
+      oracle_loss(lt, lw, sq, rho);
+      c += 0.5 * rho[0];
+      ss += sq;
+      continue;
+    }
+    double J[2][JN];
+    double* Jc = s->Jc + 2 * MAXC * k;
+    double* Jp = s->Jp + 8 * k;
+    memset(Jc, 0, sizeof(double) * 2 * MAXC);
+    memset(Jp, 0, sizeof(double) * 8);
+    if (!eval_obs_jet(model, s->ext + 6 * cam, K, model_size(model), s->pts + 4 * p,
+                      P->obs_xy + 2 * i, r, J)) {
+      ++bad;
+      s->r[2 * k] = s->r[2 * k + 1] = 0.0;
+      continue;
+    }
+    const double sq = r[0] * r[0] + r[1] * r[1];
+    double rho[3];
+    oracle_loss(lt, lw, sq, rho);
+    c += 0.5 * rho[0];
+    ss += sq;
+    /* gather the free columns: [ext free | intr free] (merged block) or
+     * [ext free] then [intr free] (shared group = second block) */
+    int col = 0;
+    if (s->cam_rb[cam] >= 0 || !s->grp_private[g]) {
+      for (int a = 0; a < s->n_ext[cam]; ++a, ++col) {
+        Jc[col] = J[0][s->ext_idx[6 * cam + a]];
+        Jc[MAXC + col] = J[1][s->ext_idx[6 * cam + a]];
+      }
+    }
+    if (s->grp_private[g] ? (s->cam_rb[cam] >= 0) : (s->grp_rb[g] >= 0)) {
+      for (int a = 0; a < s->n_intr[g]; ++a, ++col) {
+        Jc[col] = J[0][6 + s->intr_idx[10 * g + a]];
+        Jc[MAXC + col] = J[1][6 + s->intr_idx[10 * g + a]];
+      }
+    }
+    if (!P->point_constant || !P->point_constant[p]) {
+      for (int a = 0; a < s->dp; ++a) {
+        Jp[a] = J[0][16 + a];
+        Jp[4 + a] = J[1][16 + a];
+      }
+    }
+    /* ceres/corrector.cc restated (Triggs' correction): the Jacobian is
+     * corrected first, with the UNcorrected residual, then the residual */
+    {
+      const double sqrt_rho1 = sqrt(rho[1]);
+      double alpha_sq_norm = 0.0, residual_scaling = sqrt_rho1;
+      if (!(sq == 0.0 || rho[2] <= 0.0)) {
+        const double D = 1.0 + 2.0 * sq * rho[2] / rho[1];
+        const double alpha = 1.0 - sqrt(D);
+        residual_scaling = sqrt_rho1 / (1.0 - alpha);
+        alpha_sq_norm = alpha / sq;
+      }
+      if (lt != TMI_BA_LOSS_TRIVIAL) {
+        for (int a = 0; a < col; ++a) {
+          const double rtj = Jc[a] * r[0] + Jc[MAXC + a] * r[1];
+          Jc[a] = sqrt_rho1 * (Jc[a] - alpha_sq_norm * r[0] * rtj);
+          Jc[MAXC + a] = sqrt_rho1 * (Jc[MAXC + a] - alpha_sq_norm * r[1] * rtj);
+        }
+        for (int a = 0; a < s->dp; ++a) {
+          const double rtj = Jp[a] * r[0] + Jp[4 + a] * r[1];
+          Jp[a] = sqrt_rho1 * (Jp[a] - alpha_sq_norm * r[0] * rtj);
+          Jp[4 + a] = sqrt_rho1 * (Jp[4 + a] - alpha_sq_norm * r[1] * rtj);
+        }
+        r[0] *= residual_scaling;
+        r[1] *= residual_scaling;
+      }
+    }
+    if (apply_scale) {
+      int rb0, n0, rb1, n1;
+      obs_parts(s, cam, &rb0, &n0, &rb1, &n1);
+      for (int a = 0; a < n0; ++a) {
+        const double sc = s->scale_c[s->rb_off[rb0] + a];
+        Jc[a] *= sc;
+        Jc[MAXC + a] *= sc;
+      }
+      for (int a = 0; a < n1; ++a) {
+        const double sc = s->scale_c[s->rb_off[rb1] + a];
+        Jc[n0 + a] *= sc;
+        Jc[MAXC + n0 + a] *= sc;
+      }
+      for (int a = 0; a < s->dp; ++a) {
+        const double sc = s->scale_p[(int64_t)p * s->dp + a];
+        Jp[a] *= sc;
+        Jp[4 + a] *= sc;
+      }
+    }
+    s->r[2 * k] = r[0];
+    s->r[2 * k + 1] = r[1];
+  }
+  *cost = c;
+  if (ss_out) *ss_out = ss;
+  return bad;
+}
+
+/* squared column norms of the current (possibly scaled) Jacobian */
+static void column_sqnorms(ost* s, double* dc, double* dpn) {
+  memset(dc, 0, sizeof(double) * (size_t)s->nr);
+  memset(dpn, 0, sizeof(double) * (size_t)s->Np * s->dp);
+  for (int p = 0; p < s->Np; ++p) {
+    for (int64_t k = s->pt_ptr[p]; k < s->pt_ptr[p + 1]; ++k) {
+      const int cam = s->P->obs_camera[s->order[k]];
+      int rb0, n0, rb1, n1;
+      obs_parts(s, cam, &rb0, &n0, &rb1, &n1);
+      const double* Jc = s->Jc + 2 * MAXC * k;
+      const double* Jp = s->Jp + 8 * k;
+      for (int a = 0; a < n0; ++a)
+        dc[s->rb_off[rb0] + a] += Jc[a] * Jc[a] + Jc[MAXC + a] * Jc[MAXC + a];
+      for (int a = 0; a < n1; ++a)
+        dc[s->rb_off[rb1] + a] += Jc[n0 + a] * Jc[n0 + a] + Jc[MAXC + n0 + a] * Jc[MAXC + n0 + a];
+      for (int a = 0; a < s->dp; ++a)
+        dpn[(int64_t)p * s->dp + a] += Jp[a] * Jp[a] + Jp[4 + a] * Jp[4 + a];
+    }
+  }
+}
+
+/* gradient J^T r (of the current Jacobian) -> gc [nr], gp [Np*dp] */
+static void gradient(ost* s, double* gc, double* gp) {
+  memset(gc, 0, sizeof(double) * (size_t)s->nr);
+  memset(gp, 0, sizeof(double) * (size_t)s->Np * s->dp);
+  for (int p = 0; p < s->Np; ++p) {
+    for (int64_t k = s->pt_ptr[p]; k < s->pt_ptr[p + 1]; ++k) {
+      const int cam = s->P->obs_camera[s->order[k]];
+      int rb0, n0, rb1, n1;
+      obs_parts(s, cam, &rb0, &n0, &rb1, &n1);
+      const double* Jc = s->Jc + 2 * MAXC * k;
+      const double* Jp = s->Jp + 8 * k;
+      const double r0 = s->r[2 * k], r1 = s->r[2 * k + 1];
+      for (int a = 0; a < n0; ++a) gc[s->rb_off[rb0] + a] += Jc[a] * r0 + Jc[MAXC + a] * r1;
+      for (int a = 0; a < n1; ++a)
+        gc[s->rb_off[rb1] + a] += Jc[n0 + a] * r0 + Jc[MAXC + n0 + a] * r1;
+      for (int a = 0; a < s->dp; ++a) gp[(int64_t)p * s->dp + a] += Jp[a] * r0 + Jp[4 + a] * r1;
+    }
+  }
+}
+
+static int64_t block_lookup(const ost* s, int bi, int bj) {
+  return hmap_get(&s->bmap, ((int64_t)bi << 32) | (int64_t)(uint32_t)bj);
+}
+
+static void block_insert(ost* s, int bi, int bj, int64_t* cap) {
+  const int64_t key = ((int64_t)bi << 32) | (int64_t)(uint32_t)bj;
+  if (hmap_get(&s->bmap, key) >= 0) return;
+  if (s->nblk == *cap) {
+    *cap *= 2;
+    s->blk_i = (int*)realloc(s->blk_i, sizeof(int) * (size_t)*cap);
+    s->blk_j = (int*)realloc(s->blk_j, sizeof(int) * (size_t)*cap);
+    s->blk_off = (int64_t*)realloc(s->blk_off, sizeof(int64_t) * (size_t)*cap);
+  }
+  s->blk_i[s->nblk] = bi;
+  s->blk_j[s->nblk] = bj;
+  s->blk_off[s->nblk] = s->S_len;
+  s->S_len += (int64_t)s->rb_dim[bi] * s->rb_dim[bj];
+  hmap_put(&s->bmap, key, s->nblk);
+  s->nblk++;
+}
+
+/* structure of the reduced camera matrix: every pair of reduced blocks that
+ * share a track, plus the diagonal and the ext/intrinsics cross blocks */
+static void build_structure(ost* s) {
+  int64_t cap = 1024;
+  s->blk_i = (int*)malloc(sizeof(int) * (size_t)cap);
+  s->blk_j = (int*)malloc(sizeof(int) * (size_t)cap);
+  s->blk_off = (int64_t*)malloc(sizeof(int64_t) * (size_t)cap);
+  s->nblk = 0;
+  s->S_len = 0;
+  hmap_init(&s->bmap, 1024);
+  for (int b = 0; b < s->nrb; ++b) block_insert(s, b, b, &cap);
+  int* rbs = (int*)malloc(sizeof(int) * 2 * 65536);
+  int rbs_cap = 2 * 65536;
+  for (int p = 0; p < s->Np; ++p) {
+    const int64_t k0 = s->pt_ptr[p], k1 = s->pt_ptr[p + 1];
+    if (2 * (k1 - k0) > rbs_cap) {
+      rbs_cap = (int)(2 * (k1 - k0));
+      rbs = (int*)realloc(rbs, sizeof(int) * (size_t)rbs_cap);
+    }
+    int n = 0;
+    for (int64_t k = k0; k < k1; ++k) {
+      int rb0, n0, rb1, n1;
+      obs_parts(s, s->P->obs_camera[s->order[k]], &rb0, &n0, &rb1, &n1);
+      if (rb0 >= 0) rbs[n++] = rb0;
+      if (rb1 >= 0) rbs[n++] = rb1;
+    }
+    for (int a = 0; a < n; ++a)
+      for (int b = 0; b < n; ++b) block_insert(s, rbs[a], rbs[b], &cap);
+  }
+  free(rbs);
+  /* CSR by block row */
+  s->row_ptr = (int64_t*)calloc((size_t)s->nrb + 1, sizeof(int64_t));
+  s->row_blk = (int64_t*)malloc(sizeof(int64_t) * (size_t)s->nblk);
+  for (int64_t b = 0; b < s->nblk; ++b) s->row_ptr[s->blk_i[b] + 1]++;
+  for (int i = 0; i < s->nrb; ++i) s->row_ptr[i + 1] += s->row_ptr[i];
+  int64_t* fill = (int64_t*)malloc(sizeof(int64_t) * (size_t)s->nrb);
+  memcpy(fill, s->row_ptr, sizeof(int64_t) * (size_t)s->nrb);
+  for (int64_t b = 0; b < s->nblk; ++b) s->row_blk[fill[s->blk_i[b]]++] = b;
+  free(fill);
+  s->S = (double*)malloc(sizeof(double) * (size_t)s->S_len);
+}
+
+/* small SPD inverse via Cholesky (n <= 4).  Returns 0 if not positive definite. */
+static int spd_inverse(int n, const double* A, double* Ainv) {
+  double L[16];
+  for (int j = 0; j < n; ++j) {
+    double d = A[j * n + j];
+    for (int k = 0; k < j; ++k) d -= L[j * n + k] * L[j * n + k];
+    if (!(d > 0.0)) return 0;
+    L[j * n + j] = sqrt(d);
+    for (int i = j + 1; i < n; ++i) {
+      double v = A[i * n + j];
+      for (int k = 0; k < j; ++k) v -= L[i * n + k] * L[j * n + k];
+      L[i * n + j] = v / L[j * n + j];
+    }
+  }
+  /* invert L, then Ainv = L^-T L^-1 */
+  double Li[16];
+  memset(Li, 0, sizeof(Li));
+  for (int j = 0; j < n; ++j) {
+    Li[j * n + j] = 1.0 / L[j * n + j];
+    for (int i = j + 1; i < n; ++i) {
+      double v = 0.0;
+      for (int k = j; k < i; ++k) v -= L[i * n + k] * Li[k * n + j];
+      Li[i * n + j] = v / L[i * n + i];
+    }
+  }
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) {
+      double v = 0.0;
+      for (int k = (i > j ? i : j); k < n; ++k) v += Li[k * n + i] * Li[k * n + j];
+      Ainv[i * n + j] = v;
+    }
+  return 1;
+}
+
+/* Build S = U + Dc - W (V + Dp)^-1 W^T and rhs = gc - W (V+Dp)^-1 gp.
+ * Dc, Dp = clamp(diag)/radius.  Returns 0 on a singular point block. */
+static int build_reduced(ost* s, double radius) {
+  const int dp = s->dp;
+  const double lo = s->O->min_lm_diagonal, hi = s->O->max_lm_diagonal;
+  int ok = 1;
+  /* phase 1: per point (V + Dp)^-1, t_p, E_i = Jp_i (V+Dp)^-1 */
+#pragma omp parallel for schedule(dynamic, 256)
+  for (int p = 0; p < s->Np; ++p) {
+    double V[16], g[4];
+    memset(V, 0, sizeof(V));
+    memset(g, 0, sizeof(g));
+    for (int64_t k = s->pt_ptr[p]; k < s->pt_ptr[p + 1]; ++k) {
+      const double* Jp = s->Jp + 8 * k;
+      for (int a = 0; a < dp; ++a) {
+        for (int b = 0; b < dp; ++b) V[a * dp + b] += Jp[a] * Jp[b] + Jp[4 + a] * Jp[4 + b];
+        g[a] += Jp[a] * s->r[2 * k] + Jp[4 + a] * s->r[2 * k + 1];
+      }
+    }
+    for (int a = 0; a < dp; ++a) {
+      double d = s->diag_p[(int64_t)p * dp + a];
+      d = fmin(fmax(d, lo), hi);
+      V[a * dp + a] += d / radius;
+    }
+    double* Vi = s->Vinv + (int64_t)p * dp * dp;
+    if (!spd_inverse(dp, V, Vi)) {
+#pragma omp atomic write
+      ok = 0;
+      continue;
+    }
+    for (int a = 0; a < dp; ++a) {
+      s->gp[(int64_t)p * dp + a] = g[a];
+      double t = 0.0;
+      for (int b = 0; b < dp; ++b) t += Vi[a * dp + b] * g[b];
+      s->tp[(int64_t)p * dp + a] = t;
+    }
+    for (int64_t k = s->pt_ptr[p]; k < s->pt_ptr[p + 1]; ++k) {
+      const double* Jp = s->Jp + 8 * k;
+      double* E = s->Ep + 8 * k;
+      for (int row = 0; row < 2; ++row)
+        for (int b = 0; b < dp; ++b) {
+          double v = 0.0;
+          for (int a = 0; a < dp; ++a) v += Jp[4 * row + a] * Vi[a * dp + b];
+          E[4 * row + b] = v;
+        }
+    }
+  }
+  if (!ok) return 0;
+  memset(s->S, 0, sizeof(double) * (size_t)s->S_len);
+  memset(s->rhs, 0, sizeof(double) * (size_t)s->nr);
+  /* phase 2: accumulate, each thread owns the block rows bi % T == t */
+#pragma omp parallel
+  {
+#ifdef _OPENMP
+    const int T_ = omp_get_num_threads(), t_ = omp_get_thread_num();
+#else
+    const int T_ = 1, t_ = 0;
+#endif
+    for (int p = 0; p < s->Np; ++p) {
+      const int64_t k0 = s->pt_ptr[p], k1 = s->pt_ptr[p + 1];
+      const double* tp = s->tp + (int64_t)p * dp;
+      for (int64_t ki = k0; ki < k1; ++ki) {
+        const int cam_i = s->P->obs_camera[s->order[ki]];
+        int rb[2], n[2], c0[2];
+        obs_parts(s, cam_i, &rb[0], &n[0], &rb[1], &n[1]);
+        c0[0] = 0;
+        c0[1] = n[0];
+        const double* Ji = s->Jc + 2 * MAXC * ki;
+        const double* Jpi = s->Jp + 8 * ki;
+        const double* Ei = s->Ep + 8 * ki;
+        /* reduced residual r~ = r - Jp t_p */
+        double rt[2] = {s->r[2 * ki], s->r[2 * ki + 1]};
+        for (int a = 0; a < dp; ++a) {
+          rt[0] -= Jpi[a] * tp[a];
+          rt[1] -= Jpi[4 + a] * tp[a];
+        }
+        for (int pi = 0; pi < 2; ++pi) {
+          if (rb[pi] < 0 || (rb[pi] % T_) != t_) continue;
+          const int ni = n[pi];
+          const double* Ai0 = Ji + c0[pi];
+          const double* Ai1 = Ji + MAXC + c0[pi];
+          double* rhs = s->rhs + s->rb_off[rb[pi]];
+          for (int a = 0; a < ni; ++a) rhs[a] += Ai0[a] * rt[0] + Ai1[a] * rt[1];
+          /* U: this observation's own blocks (pi, pj) */
+          for (int pj = 0; pj < 2; ++pj) {
+            if (rb[pj] < 0) continue;
+            double* B = s->S + s->blk_off[block_lookup(s, rb[pi], rb[pj])];
+            const int nj = n[pj];
+            const double* Aj0 = Ji + c0[pj];
+            const double* Aj1 = Ji + MAXC + c0[pj];
+            for (int a = 0; a < ni; ++a)
+              for (int b = 0; b < nj; ++b) B[a * nj + b] += Ai0[a] * Aj0[b] + Ai1[a] * Aj1[b];
+          }
+          /* Schur: - A_i^T (E_i Jp_j^T) A_j over every observation j of the track */
+          for (int64_t kj = k0; kj < k1; ++kj) {
+            const int cam_j = s->P->obs_camera[s->order[kj]];
+            int rbj[2], nj_[2], cj0[2];
+            obs_parts(s, cam_j, &rbj[0], &nj_[0], &rbj[1], &nj_[1]);
+            cj0[0] = 0;
+            cj0[1] = nj_[0];
+            const double* Jj = s->Jc + 2 * MAXC * kj;
+            const double* Jpj = s->Jp + 8 * kj;
+            double M[4] = {0, 0, 0, 0};
+            for (int a = 0; a < dp; ++a) {
+              M[0] += Ei[a] * Jpj[a];
+              M[1] += Ei[a] * Jpj[4 + a];
+              M[2] += Ei[4 + a] * Jpj[a];
+              M[3] += Ei[4 + a] * Jpj[4 + a];
+            }
+            for (int pj = 0; pj < 2; ++pj) {
+              if (rbj[pj] < 0) continue;
+              const int nj = nj_[pj];
+              const double* Aj0 = Jj + cj0[pj];
+              const double* Aj1 = Jj + MAXC + cj0[pj];
+              double* B = s->S + s->blk_off[block_lookup(s, rb[pi], rbj[pj])];
+              for (int b = 0; b < nj; ++b) {
+                const double t0 = M[0] * Aj0[b] + M[1] * Aj1[b];
+                const double t1 = M[2] * Aj0[b] + M[3] * Aj1[b];
+                for (int a = 0; a < ni; ++a) B[a * nj + b] -= Ai0[a] * t0 + Ai1[a] * t1;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  /* LM diagonal on the camera blocks */
+  for (int b = 0; b < s->nrb; ++b) {
+    double* B = s->S + s->blk_off[block_lookup(s, b, b)];
+    const int n = s->rb_dim[b];
+    for (int a = 0; a < n; ++a) {
+      double d = s->diag_c[s->rb_off[b] + a];
+      d = fmin(fmax(d, lo), hi);
+      B[a * n + a] += d / radius;
+    }
+  }
+  return 1;
+}
+
+static void spmv(const ost* s, const double* x, double* y) {
+#pragma omp parallel for schedule(dynamic, 8)
+  for (int i = 0; i < s->nrb; ++i) {
+    const int ni = s->rb_dim[i];
+    double acc[MAXC];
+    for (int a = 0; a < ni; ++a) acc[a] = 0.0;
+    for (int64_t q = s->row_ptr[i]; q < s->row_ptr[i + 1]; ++q) {
+      const int64_t b = s->row_blk[q];
+      const int j = s->blk_j[b], nj = s->rb_dim[j];
+      const double* B = s->S + s->blk_off[b];
+      const double* xj = x + s->rb_off[j];
+      for (int a = 0; a < ni; ++a) {
+        double v = 0.0;
+        for (int c = 0; c < nj; ++c) v += B[a * nj + c] * xj[c];
+        acc[a] += v;
+      }
+    }
+    for (int a = 0; a < ni; ++a) y[s->rb_off[i] + a] = acc[a];
+  }
+}
+
+static double dot(const double* a, const double* b, int n) {
+  double v = 0.0;
+  for (int i = 0; i < n; ++i) v += a[i] * b[i];
+  return v;
+}
+
+/* dense SPD inverse of a small block via Cholesky (n <= MAXC) into Minv */
+static int block_inverse(int n, const double* A, double* Ainv) {
+  double L[MAXC * MAXC];
+  for (int j = 0; j < n; ++j) {
+    double d = A[j * n + j];
+    for (int k = 0; k < j; ++k) d -= L[j * n + k] * L[j * n + k];
+    if (!(d > 0.0)) return 0;
+    L[j * n + j] = sqrt(d);
+    for (int i = j + 1; i < n; ++i) {
+      double v = A[i * n + j];
+      for (int k = 0; k < j; ++k) v -= L[i * n + k] * L[j * n + k];
+      L[i * n + j] = v / L[j * n + j];
+    }
+  }
+  for (int c = 0; c < n; ++c) {
+    double y[MAXC];
+    for (int i = 0; i < n; ++i) {
+      double v = (i == c) ? 1.0 : 0.0;
+      for (int k = 0; k < i; ++k) v -= L[i * n + k] * y[k];
+      y[i] = v / L[i * n + i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+      double v = y[i];
+      for (int k = i + 1; k < n; ++k) v -= L[k * n + i] * Ainv[k * n + c];
+      Ainv[i * n + c] = v / L[i * n + i];
+    }
+  }
+  return 1;
+}
+
+/* ceres/conjugate_gradients_solver.cc (Ceres 1.14) restated, applied to the
+ * explicit reduced system with the SCHUR_JACOBI preconditioner (inverse of
+ * the diagonal blocks of S).  r_tolerance = -1, q_tolerance = eta
+ * (LevenbergMarquardtStrategy::ComputeStep).  Returns 1 ok, 0 failure. */
+static int solve_pcg(ost* s) {
+  const int n = s->nr;
+  double* x = s->yc;
+  double* r = (double*)malloc(sizeof(double) * (size_t)n * 4);
+  double *z = r + n, *pvec = r + 2 * n, *tmp = r + 3 * n;
+  double* Minv = (double*)malloc(sizeof(double) * (size_t)s->nrb * MAXC * MAXC);
+  int ok = 1;
+  for (int b = 0; b < s->nrb; ++b) {
+    const int nb = s->rb_dim[b];
+    const double* B = s->S + s->blk_off[block_lookup(s, b, b)];
+    if (s->O->preconditioner_type == TMI_BA_PRECOND_IDENTITY) {
+      double* M = Minv + (int64_t)b * MAXC * MAXC;
+      for (int a = 0; a < nb * nb; ++a) M[a] = 0.0;
+      for (int a = 0; a < nb; ++a) M[a * nb + a] = 1.0;
+    } else if (!block_inverse(nb, B, Minv + (int64_t)b * MAXC * MAXC)) {
+      ok = 0;
+    }
+  }
+  if (!ok) {
+    free(r);
+    free(Minv);
+    return 0;
+  }
+  const double* bref = s->rhs;
+  memset(x, 0, sizeof(double) * (size_t)n);
+  memcpy(r, bref, sizeof(double) * (size_t)n); /* r = b - A*0 */
+  const double norm_b = sqrt(dot(bref, bref, n));
+  const double tol_r = -1.0 * norm_b; /* r_tolerance = -1: disabled */
+  (void)tol_r;
+  double rho = 1.0;
+  double Q0 = -1.0 * 0.0; /* x = 0 */
+  const int max_it = s->O->max_linear_solver_iterations;
+  const int min_it = s->O->min_linear_solver_iterations;
+  const double q_tol = s->O->eta;
+  int it;
+  for (it = 1;; ++it) {
+    /* z = M^-1 r */
+    for (int b = 0; b < s->nrb; ++b) {
+      const int nb = s->rb_dim[b], off = s->rb_off[b];
+      const double* M = Minv + (int64_t)b * MAXC * MAXC;
+      for (int a = 0; a < nb; ++a) {
+        double v = 0.0;
+        for (int c = 0; c < nb; ++c) v += M[a * nb + c] * r[off + c];
+        z[off + a] = v;
+      }
+    }
+    const double last_rho = rho;
+    rho = dot(r, z, n);
+    if (rho == 0.0 || !isfinite(rho)) { ok = 0; break; }
+    if (it == 1) {
+      memcpy(pvec, z, sizeof(double) * (size_t)n);
+    } else {
+      const double beta = rho / last_rho;
+      if (beta == 0.0 || !isfinite(beta)) { ok = 0; break; }
+      for (int i = 0; i < n; ++i) pvec[i] = z[i] + beta * pvec[i];
+    }
+    double* q = z;
+    spmv(s, pvec, q);
+    const double pq = dot(pvec, q, n);
+    if (pq <= 0.0 || !isfinite(pq)) break; /* LINEAR_SOLVER_NO_CONVERGENCE: x is kept */
+    const double alpha = rho / pq;
+    if (!isfinite(alpha)) { ok = 0; break; }
+    for (int i = 0; i < n; ++i) x[i] += alpha * pvec[i];
+    if (it % 10 == 0) { /* residual_reset_period */
+      spmv(s, x, tmp);
+      for (int i = 0; i < n; ++i) r[i] = bref[i] - tmp[i];
+    } else {
+      for (int i = 0; i < n; ++i) r[i] -= alpha * q[i];
+    }
+    /* Q1 = x'Ax - 2 b'x = -x'(b + r) */
+    double Q1 = 0.0;
+    for (int i = 0; i < n; ++i) Q1 -= x[i] * (bref[i] + r[i]);
+    const double zeta = it * (Q1 - Q0) / Q1;
+    if (zeta < q_tol && it >= min_it) break;
+    Q0 = Q1;
+    if (it >= max_it) break;
+  }
+  s->pcg_iters += it;
+  free(r);
+  free(Minv);
+  return ok;
+}
+
+/* dense Cholesky solve of the reduced system (DENSE_SCHUR / SPARSE_SCHUR /
+ * DENSE_QR all solve the same normal equations exactly) */
+static int solve_dense(ost* s) {
+  const int n = s->nr;
+  if (!s->dense) s->dense = (double*)malloc(sizeof(double) * (size_t)n * n);
+  double* A = s->dense;
+  memset(A, 0, sizeof(double) * (size_t)n * n);
+  for (int64_t b = 0; b < s->nblk; ++b) {
+    const int bi = s->blk_i[b], bj = s->blk_j[b];
+    const int ni = s->rb_dim[bi], nj = s->rb_dim[bj];
+    const double* B = s->S + s->blk_off[b];
+    for (int a = 0; a < ni; ++a)
+      for (int c = 0; c < nj; ++c)
+        A[(int64_t)(s->rb_off[bi] + a) * n + s->rb_off[bj] + c] = B[a * nj + c];
+  }
+  /* row-major lower Cholesky (Cholesky-Crout, dot products over rows) */
+  for (int j = 0; j < n; ++j) {
+    double* Aj = A + (int64_t)j * n;
+    double d = Aj[j];
+    for (int k = 0; k < j; ++k) d -= Aj[k] * Aj[k];
+    if (!(d > 0.0) || !isfinite(d)) return 0;
+    const double ljj = sqrt(d);
+    Aj[j] = ljj;
+#pragma omp parallel for schedule(static) if (n - j > 256)
+    for (int i = j + 1; i < n; ++i) {
+      double* Ai = A + (int64_t)i * n;
+      double v = Ai[j];
+      for (int k = 0; k < j; ++k) v -= Ai[k] * Aj[k];
+      Ai[j] = v / ljj;
+    }
+  }
+  double* y = s->yc;
+  for (int i = 0; i < n; ++i) {
+    double v = s->rhs[i];
+    const double* Ai = A + (int64_t)i * n;
+    for (int k = 0; k < i; ++k) v -= Ai[k] * y[k];
+    y[i] = v / Ai[i];
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double v = y[i];
+    for (int k = i + 1; k < n; ++k) v -= A[(int64_t)k * n + i] * y[k];
+    y[i] = v / A[(int64_t)i * n + i];
+  }
+  return 1;
+}
+
+/* back substitution y_p = (V+Dp)^-1 (g_p - W^T y_c) and the model cost change
+ *   -(J d).(r + J d / 2) with d = -y  (TrustRegionMinimizer) */
+static double back_substitute(ost* s) {
+  const int dp = s->dp;
+  double mcc = 0.0;
+#pragma omp parallel for schedule(dynamic, 256) reduction(+ : mcc)
+  for (int p = 0; p < s->Np; ++p) {
+    double v[4] = {0, 0, 0, 0};
+    for (int a = 0; a < dp; ++a) v[a] = s->gp[(int64_t)p * dp + a];
+    for (int64_t k = s->pt_ptr[p]; k < s->pt_ptr[p + 1]; ++k) {
+      const int cam = s->P->obs_camera[s->order[k]];
+      int rb0, n0, rb1, n1;
+      obs_parts(s, cam, &rb0, &n0, &rb1, &n1);
+      const double* Jc = s->Jc + 2 * MAXC * k;
+      const double* Jp = s->Jp + 8 * k;
+      double u0 = 0.0, u1 = 0.0;
+      for (int a = 0; a < n0; ++a) {
+        u0 += Jc[a] * s->yc[s->rb_off[rb0] + a];
+        u1 += Jc[MAXC + a] * s->yc[s->rb_off[rb0] + a];
+      }
+      for (int a = 0; a < n1; ++a) {
+        u0 += Jc[n0 + a] * s->yc[s->rb_off[rb1] + a];
+        u1 += Jc[MAXC + n0 + a] * s->yc[s->rb_off[rb1] + a];
+      }
+      for (int a = 0; a < dp; ++a) v[a] -= Jp[a] * u0 + Jp[4 + a] * u1;
+    }
+    const double* Vi = s->Vinv + (int64_t)p * dp * dp;
+    double* yp = s->yp + (int64_t)p * dp;
+    for (int a = 0; a < dp; ++a) {
+      double t = 0.0;
+      for (int b = 0; b < dp; ++b) t += Vi[a * dp + b] * v[b];
+      yp[a] = t;
+    }
+    /* model residual m = J d = -(Jc yc + Jp yp) per observation */
+    for (int64_t k = s->pt_ptr[p]; k < s->pt_ptr[p + 1]; ++k) {
+      const int cam = s->P->obs_camera[s->order[k]];
+      int rb0, n0, rb1, n1;
+      obs_parts(s, cam, &rb0, &n0, &rb1, &n1);
+      const double* Jc = s->Jc + 2 * MAXC * k;
+      const double* Jp = s->Jp + 8 * k;
+      double m0 = 0.0, m1 = 0.0;
+      for (int a = 0; a < n0; ++a) {
+        m0 += Jc[a] * s->yc[s->rb_off[rb0] + a];
+        m1 += Jc[MAXC + a] * s->yc[s->rb_off[rb0] + a];
+      }
+      for (int a = 0; a < n1; ++a) {
+        m0 += Jc[n0 + a] * s->yc[s->rb_off[rb1] + a];
+        m1 += Jc[MAXC + n0 + a] * s->yc[s->rb_off[rb1] + a];
+      }
+      for (int a = 0; a < dp; ++a) {
+        m0 += Jp[a] * yp[a];
+        m1 += Jp[4 + a] * yp[a];
+      }
+      m0 = -m0;
+      m1 = -m1;
+      mcc -= m0 * (s->r[2 * k] + 0.5 * m0) + m1 * (s->r[2 * k + 1] + 0.5 * m1);
+    }
+  }
+  return mcc;
+}
+
+static void free_state(ost* s) {
+  free(s->ext); free(s->intr); free(s->pts);
+  free(s->n_ext); free(s->ext_idx); free(s->n_intr); free(s->intr_idx); free(s->grp_private);
+  free(s->rb_dim); free(s->rb_off); free(s->cam_rb); free(s->grp_rb);
+  free(s->order); free(s->pt_ptr);
+  free(s->r); free(s->Jc); free(s->Jp); free(s->Ep);
+  free(s->scale_c); free(s->scale_p); free(s->diag_c); free(s->diag_p);
+  free(s->Vinv); free(s->gp); free(s->tp);
+  if (s->bmap.keys) hmap_free(&s->bmap);
+  free(s->blk_i); free(s->blk_j); free(s->blk_off); free(s->row_ptr); free(s->row_blk);
+  free(s->S); free(s->gc); free(s->rhs); free(s->yc); free(s->yp); free(s->dense);
+}
+
+static int validate(const tmi_ba_problem* P) {
+  if (!P || P->num_cameras < 0 || P->num_groups < 0 || P->num_points < 0 ||
+      P->num_observations < 0)
+    return 0;
+  if (P->num_cameras && (!P->extrinsics || !P->camera_group)) return 0;
+  if (P->num_groups && (!P->group_model || !P->group_offset || !P->intrinsics)) return 0;
+  if (P->num_points && !P->points) return 0;
+  if (P->num_observations && (!P->obs_camera || !P->obs_point || !P->obs_xy)) return 0;
+  for (int c = 0; c < P->num_cameras; ++c)
+    if (P->camera_group[c] < 0 || P->camera_group[c] >= P->num_groups) return 0;
+  for (int g = 0; g < P->num_groups; ++g) {
+    const int n = model_size(P->group_model[g]);
+    if (n < 0 || P->group_offset[g + 1] - P->group_offset[g] != n) return 0;
+  }
+  for (int64_t i = 0; i < P->num_observations; ++i)
+    if (P->obs_camera[i] < 0 || P->obs_camera[i] >= P->num_cameras || P->obs_point[i] < 0 ||
+        P->obs_point[i] >= P->num_points)
+      return 0;
+  return 1;
+}
+
+static double state_norm(const ost* s) {
+  /* ||x|| over every coordinate of every non-constant parameter block */
+  double v = 0.0;
+  for (int c = 0; c < s->Nc; ++c)
+    if (s->n_ext[c] > 0)
+      for (int a = 0; a < 6; ++a) v += s->ext[6 * c + a] * s->ext[6 * c + a];
+  for (int g = 0; g < s->G; ++g)
+    if (s->n_intr[g] > 0)
+      for (int a = s->P->group_offset[g]; a < s->P->group_offset[g + 1]; ++a)
+        v += s->intr[a] * s->intr[a];
+  for (int p = 0; p < s->Np; ++p)
+    if (!s->P->point_constant || !s->P->point_constant[p])
+      for (int a = 0; a < 4; ++a) v += s->pts[4 * (int64_t)p + a] * s->pts[4 * (int64_t)p + a];
+  return sqrt(v);
+}
+
+int32_t oracle_ba_solve(tmi_ba_problem* P, const tmi_ba_options* O, tmi_ba_summary* sum) {
+  if (!O || !sum) return TMI_BA_ERR_INVALID_ARGUMENT;
+  memset(sum, 0, sizeof(*sum));
+  sum->termination = 2;
+  if (!validate(P)) {
+    sum->status = TMI_BA_ERR_INVALID_ARGUMENT;
+    snprintf(sum->message, sizeof(sum->message), "invalid problem");
+    return sum->status;
+  }
+  const double t_start = now_s();
+  ost S_;
+  ost* s = &S_;
+  memset(s, 0, sizeof(*s));
+  s->P = P;
+  s->O = O;
+  s->Nc = P->num_cameras;
+  s->G = P->num_groups;
+  s->Np = P->num_points;
+  s->No = P->num_observations;
+  s->dp = (O->point_dof == 3) ? 3 : 4;
+  const int dp = s->dp;
+  const int n_intr_total = s->G ? P->group_offset[s->G] : 0;
+  s->ext = (double*)malloc(sizeof(double) * 6 * (size_t)(s->Nc + 1));
+  s->intr = (double*)malloc(sizeof(double) * (size_t)(n_intr_total + 1));
+  s->pts = (double*)malloc(sizeof(double) * 4 * (size_t)(s->Np + 1));
+  memcpy(s->ext, P->extrinsics, sizeof(double) * 6 * (size_t)s->Nc);
+  memcpy(s->intr, P->intrinsics, sizeof(double) * (size_t)n_intr_total);
+  memcpy(s->pts, P->points, sizeof(double) * 4 * (size_t)s->Np);
+
+  /* free-column maps (SubsetParameterization semantics,
+   * bundle_adjuster.cc:242-334) */
+  s->n_ext = (int*)calloc((size_t)s->Nc + 1, sizeof(int));
+  s->ext_idx = (int*)calloc(6 * (size_t)s->Nc + 1, sizeof(int));
+  s->n_intr = (int*)calloc((size_t)s->G + 1, sizeof(int));
+  s->intr_idx = (int*)calloc(10 * (size_t)s->G + 1, sizeof(int));
+  s->grp_private = (int*)calloc((size_t)s->G + 1, sizeof(int));
+  int* grp_count = (int*)calloc((size_t)s->G + 1, sizeof(int));
+  for (int c = 0; c < s->Nc; ++c) {
+    const int f = P->camera_flags ? P->camera_flags[c] : 0;
+    int n = 0;
+    if (!(f & TMI_BA_CAMERA_POSITION_CONSTANT))
+      for (int a = 0; a < 3; ++a) s->ext_idx[6 * c + n++] = a;
+    if (!(f & TMI_BA_CAMERA_ORIENTATION_CONSTANT))
+      for (int a = 3; a < 6; ++a) s->ext_idx[6 * c + n++] = a;
+    s->n_ext[c] = n;
+    grp_count[P->camera_group[c]]++;
+  }
+  for (int g = 0; g < s->G; ++g) {
+    int n = 0;
+    for (int a = P->group_offset[g]; a < P->group_offset[g + 1]; ++a)
+      if (!P->intrinsics_constant || !P->intrinsics_constant[a])
+        s->intr_idx[10 * g + n++] = a - P->group_offset[g];
+    s->n_intr[g] = n;
+    s->grp_private[g] = (grp_count[g] == 1);
+  }
+  free(grp_count);
+  /* reduced blocks: one merged [ext | intr] block per camera whose group is
+   * private, else an extrinsics block per camera plus one block per shared
+   * group */
+  s->cam_rb = (int*)malloc(sizeof(int) * (size_t)(s->Nc + 1));
+  s->grp_rb = (int*)malloc(sizeof(int) * (size_t)(s->G + 1));
+  s->rb_dim = (int*)malloc(sizeof(int) * (size_t)(s->Nc + s->G + 1));
+  s->rb_off = (int*)malloc(sizeof(int) * (size_t)(s->Nc + s->G + 2));
+  s->nrb = 0;
+  s->nr = 0;
+  for (int c = 0; c < s->Nc; ++c) {
+    const int g = P->camera_group[c];
+    const int d = s->n_ext[c] + (s->grp_private[g] ? s->n_intr[g] : 0);
+    if (d > 0) {
+      s->cam_rb[c] = s->nrb;
+      s->rb_dim[s->nrb] = d;
+      s->rb_off[s->nrb] = s->nr;
+      s->nr += d;
+      s->nrb++;
+    } else {
+      s->cam_rb[c] = -1;
+    }
+  }
+  for (int g = 0; g < s->G; ++g) {
+    if (!s->grp_private[g] && s->n_intr[g] > 0) {
+      s->grp_rb[g] = s->nrb;
+      s->rb_dim[s->nrb] = s->n_intr[g];
+      s->rb_off[s->nrb] = s->nr;
+      s->nr += s->n_intr[g];
+      s->nrb++;
+    } else {
+      s->grp_rb[g] = -1;
+    }
+  }
+  s->rb_off[s->nrb] = s->nr;
+
+  /* sort observations by point (counting sort, stable) */
+  s->order = (int64_t*)malloc(sizeof(int64_t) * (size_t)(s->No + 1));
+  s->pt_ptr = (int64_t*)calloc((size_t)s->Np + 2, sizeof(int64_t));
+  for (int64_t i = 0; i < s->No; ++i) s->pt_ptr[P->obs_point[i] + 1]++;
+  for (int p = 0; p < s->Np; ++p) s->pt_ptr[p + 1] += s->pt_ptr[p];
+  {
+    int64_t* fill = (int64_t*)malloc(sizeof(int64_t) * (size_t)(s->Np + 1));
+    memcpy(fill, s->pt_ptr, sizeof(int64_t) * (size_t)s->Np);
+    for (int64_t i = 0; i < s->No; ++i) s->order[fill[P->obs_point[i]]++] = i;
+    free(fill);
+  }
+  s->r = (double*)calloc(2 * (size_t)s->No + 2, sizeof(double));
+  s->Jc = (double*)calloc(2 * MAXC * (size_t)s->No + 2, sizeof(double));
+  s->Jp = (double*)calloc(8 * (size_t)s->No + 2, sizeof(double));
+  s->Ep = (double*)calloc(8 * (size_t)s->No + 2, sizeof(double));
+  s->scale_c = (double*)malloc(sizeof(double) * (size_t)(s->nr + 1));
+  s->scale_p = (double*)malloc(sizeof(double) * ((size_t)s->Np * dp + 1));
+  s->diag_c = (double*)malloc(sizeof(double) * (size_t)(s->nr + 1));
+  s->diag_p = (double*)malloc(sizeof(double) * ((size_t)s->Np * dp + 1));
+  s->Vinv = (double*)malloc(sizeof(double) * ((size_t)s->Np * dp * dp + 1));
+  s->gp = (double*)malloc(sizeof(double) * ((size_t)s->Np * dp + 1));
+  s->tp = (double*)malloc(sizeof(double) * ((size_t)s->Np * dp + 1));
+  s->gc = (double*)malloc(sizeof(double) * (size_t)(s->nr + 1));
+  s->rhs = (double*)malloc(sizeof(double) * (size_t)(s->nr + 1));
+  s->yc = (double*)calloc((size_t)s->nr + 1, sizeof(double));
+  s->yp = (double*)calloc((size_t)s->Np * dp + 1, sizeof(double));
+  for (int i = 0; i < s->nr; ++i) s->scale_c[i] = 1.0;
+  for (int64_t i = 0; i < (int64_t)s->Np * dp; ++i) s->scale_p[i] = 1.0;
+  build_structure(s);
+  sum->num_reduced_blocks = s->nrb;
+  sum->reduced_block_dim = 0;
+  for (int b = 0; b < s->nrb; ++b)
+    if (s->rb_dim[b] > sum->reduced_block_dim) sum->reduced_block_dim = s->rb_dim[b];
+  sum->num_schur_blocks = (s->nblk + s->nrb) / 2;
+  sum->setup_time_in_seconds = now_s() - t_start;
+  const double t_solve = now_s();
+
+  const int iterative =
+      (O->linear_solver_type == TMI_BA_ITERATIVE_SCHUR || O->linear_solver_type == TMI_BA_CGNR);
+
+  /* ---- iteration zero (TrustRegionMinimizer::IterationZero) ---- */
+  double cost, ss;
+  int64_t bad = evaluate(s, 1, 0, &cost, &ss);
+  if (bad) {
+    sum->status = TMI_BA_ERR_EVALUATION_FAILED;
+    snprintf(sum->message, sizeof(sum->message),
+             "residual evaluation failed at the start point (%lld observations)", (long long)bad);
+    free_state(s);
+    return sum->status;
+  }
+  sum->initial_cost = cost;
+  sum->initial_rmse = s->No ? sqrt(ss / (double)s->No) : 0.0;
+  /* gradient of the unscaled problem */
+  double* gfull_p = (double*)malloc(sizeof(double) * ((size_t)s->Np * dp + 1));
+  gradient(s, s->gc, gfull_p);
+  double gmax = 0.0;
+  for (int i = 0; i < s->nr; ++i) gmax = fmax(gmax, fabs(s->gc[i]));
+  for (int64_t i = 0; i < (int64_t)s->Np * dp; ++i) gmax = fmax(gmax, fabs(gfull_p[i]));
+  if (O->jacobi_scaling) {
+    /* jacobian_scaling = 1 / (1 + sqrt(squared column norm)), computed once */
+    column_sqnorms(s, s->diag_c, s->diag_p);
+    for (int i = 0; i < s->nr; ++i) s->scale_c[i] = 1.0 / (1.0 + sqrt(s->diag_c[i]));
+    for (int64_t i = 0; i < (int64_t)s->Np * dp; ++i)
+      s->scale_p[i] = 1.0 / (1.0 + sqrt(s->diag_p[i]));
+    evaluate(s, 1, 1, &cost, &ss);
+  }
+  double x_norm = state_norm(s);
+  double radius = O->initial_trust_region_radius;
+  double decrease_factor = 2.0;
+  int reuse_diagonal = 0;
+  int invalid_run = 0;
+  int iter = 0;
+  int termination = 1; /* NO_CONVERGENCE unless stated */
+  const char* why = "maximum number of iterations reached";
+  double* cand_ext = (double*)malloc(sizeof(double) * 6 * (size_t)(s->Nc + 1));
+  double* cand_intr = (double*)malloc(sizeof(double) * (size_t)(n_intr_total + 1));
+  double* cand_pts = (double*)malloc(sizeof(double) * 4 * (size_t)(s->Np + 1));
+
+  if (gmax <= O->gradient_tolerance) {
+    termination = 0;
+    why = "gradient tolerance reached at the start point";
+  } else {
+    for (;;) {
+      if (iter >= O->max_num_iterations) break;
+      if (now_s() - t_start >= O->max_solver_time_in_seconds) {
+        why = "maximum solver time reached";
+        break;
+      }
+      ++iter;
+      if (!reuse_diagonal) column_sqnorms(s, s->diag_c, s->diag_p);
+      int step_ok = build_reduced(s, radius);
+      if (step_ok) step_ok = iterative ? solve_pcg(s) : solve_dense(s);
+      double model_cost_change = 0.0;
+      if (step_ok) {
+        model_cost_change = back_substitute(s);
+        if (!(model_cost_change > 0.0)) step_ok = 0;
+      }
+      if (!step_ok) {
+        /* HandleInvalidStep */
+        if (++invalid_run >= O->max_num_consecutive_invalid_steps) {
+          termination = 2;
+          why = "too many consecutive invalid steps";
+          break;
+        }
+        radius /= decrease_factor;
+        decrease_factor *= 2.0;
+        reuse_diagonal = 1;
+        sum->num_unsuccessful_steps++;
+        if (radius < O->min_trust_region_radius) {
+          termination = 0;
+          why = "minimum trust region radius reached";
+          break;
+        }
+        continue;
+      }
+      invalid_run = 0;
+      /* candidate = x + scale .* (-y) on the free coordinates */
+      memcpy(cand_ext, s->ext, sizeof(double) * 6 * (size_t)s->Nc);
+      memcpy(cand_intr, s->intr, sizeof(double) * (size_t)n_intr_total);
+      memcpy(cand_pts, s->pts, sizeof(double) * 4 * (size_t)s->Np);
+      double step_sq = 0.0;
+      for (int c = 0; c < s->Nc; ++c) {
+        const int rb = s->cam_rb[c];
+        if (rb < 0) continue;
+        const int g = P->camera_group[c];
+        int col = 0;
+        for (int a = 0; a < s->n_ext[c]; ++a, ++col) {
+          const double d = -s->yc[s->rb_off[rb] + col] * s->scale_c[s->rb_off[rb] + col];
+          cand_ext[6 * c + s->ext_idx[6 * c + a]] += d;
+          step_sq += d * d;
+        }
+        if (s->grp_private[g])
+          for (int a = 0; a < s->n_intr[g]; ++a, ++col) {
+            const double d = -s->yc[s->rb_off[rb] + col] * s->scale_c[s->rb_off[rb] + col];
+            cand_intr[P->group_offset[g] + s->intr_idx[10 * g + a]] += d;
+            step_sq += d * d;
+          }
+      }
+      for (int g = 0; g < s->G; ++g) {
+        const int rb = s->grp_rb[g];
+        if (rb < 0) continue;
+        for (int a = 0; a < s->n_intr[g]; ++a) {
+          const double d = -s->yc[s->rb_off[rb] + a] * s->scale_c[s->rb_off[rb] + a];
+          cand_intr[P->group_offset[g] + s->intr_idx[10 * g + a]] += d;
+          step_sq += d * d;
+        }
+      }
+      for (int p = 0; p < s->Np; ++p) {
+        if (P->point_constant && P->point_constant[p]) continue;
+        for (int a = 0; a < dp; ++a) {
+          const double d = -s->yp[(int64_t)p * dp + a] * s->scale_p[(int64_t)p * dp + a];
+          cand_pts[4 * (int64_t)p + a] += d;
+          step_sq += d * d;
+        }
+      }
+      /* evaluate the candidate cost */
+      double *sv_e = s->ext, *sv_i = s->intr, *sv_p = s->pts;
+      s->ext = cand_ext;
+      s->intr = cand_intr;
+      s->pts = cand_pts;
+      double cand_cost, cand_ss;
+      const int64_t cbad = evaluate(s, 0, 0, &cand_cost, &cand_ss);
+      s->ext = sv_e;
+      s->intr = sv_i;
+      s->pts = sv_p;
+      if (cbad) cand_cost = DBL_MAX;
+      /* ParameterToleranceReached */
+      const double step_norm = sqrt(step_sq);
+      if (step_norm <= O->parameter_tolerance * (x_norm + O->parameter_tolerance)) {
+        termination = 0;
+        why = "parameter tolerance reached";
+        break;
+      }
+      /* FunctionToleranceReached */
+      const double cost_change = cost - cand_cost;
+      if (fabs(cost_change) <= O->function_tolerance * cost) {
+        termination = 0;
+        why = "function tolerance reached";
+        break;
+      }
+      const double relative_decrease = cost_change / model_cost_change;
+      if (relative_decrease > O->min_relative_decrease) {
+        /* HandleSuccessfulStep */
+        memcpy(s->ext, cand_ext, sizeof(double) * 6 * (size_t)s->Nc);
+        memcpy(s->intr, cand_intr, sizeof(double) * (size_t)n_intr_total);
+        memcpy(s->pts, cand_pts, sizeof(double) * 4 * (size_t)s->Np);
+        x_norm = state_norm(s);
+        double c2;
+        evaluate(s, 1, 1, &c2, &ss);
+        cost = c2;
+        /* gradient of the unscaled problem: g_j = (J_scaled^T r)_j / scale_j */
+        gradient(s, s->gc, gfull_p);
+        gmax = 0.0;
+        for (int i = 0; i < s->nr; ++i) gmax = fmax(gmax, fabs(s->gc[i] / s->scale_c[i]));
+        for (int64_t i = 0; i < (int64_t)s->Np * dp; ++i)
+          gmax = fmax(gmax, fabs(gfull_p[i] / s->scale_p[i]));
+        sum->num_successful_steps++;
+        radius = radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * relative_decrease - 1.0, 3));
+        radius = fmin(O->max_trust_region_radius, radius);
+        decrease_factor = 2.0;
+        reuse_diagonal = 0;
+        if (gmax <= O->gradient_tolerance) {
+          termination = 0;
+          why = "gradient tolerance reached";
+          break;
+        }
+      } else {
+        radius /= decrease_factor;
+        decrease_factor *= 2.0;
+        reuse_diagonal = 1;
+        sum->num_unsuccessful_steps++;
+      }
+      if (radius < O->min_trust_region_radius) {
+        termination = 0;
+        why = "minimum trust region radius reached";
+        break;
+      }
+      if (O->verbose)
+        fprintf(stderr, "[oracle] it %3d cost %.10e radius %.3e pcg %lld\n", iter, cost, radius,
+                (long long)s->pcg_iters);
+    }
+  }
+  free(gfull_p);
+  free(cand_ext);
+  free(cand_intr);
+  free(cand_pts);
+
+  sum->termination = termination;
+  sum->num_iterations = iter;
+  sum->num_linear_solver_iterations = s->pcg_iters;
+  sum->final_cost = cost;
+  sum->success = (termination != 2);
+  sum->status = (termination == 2) ? TMI_BA_ERR_LINEAR_SOLVER : TMI_BA_OK;
+  snprintf(sum->message, sizeof(sum->message), "%s", why);
+  if (sum->success) {
+    memcpy(P->extrinsics, s->ext, sizeof(double) * 6 * (size_t)s->Nc);
+    memcpy(P->intrinsics, s->intr, sizeof(double) * (size_t)n_intr_total);
+    memcpy(P->points, s->pts, sizeof(double) * 4 * (size_t)s->Np);
+  }
+  {
+    double c3, rm;
+    oracle_ba_cost(P, O, &c3, &rm);
+    sum->final_rmse = rm;
+  }
+  sum->solve_time_in_seconds = now_s() - t_solve;
+  free_state(s);
+  return sum->status;
+}

@@ -1,0 +1,87 @@
+/*
+ * ORACLE -- TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker / the reported CPU baseline.
+ *
+ * CPU restatement of the reference's bundle-adjustment path:
+ *   - residual functor + 5 camera models: restated from /root/reference
+ *     (citations on every function in reprojection_tmpl.h);
+ *   - Jacobians by forward-mode dual numbers, as Ceres autodiff does
+ *     (create_reprojection_error_cost_function.h:60-89) -- an independent
+ *     check of the device path's analytic Jacobians;
+ *   - the numerics behind ceres::Solve (bundle_adjuster.cc:205): Ceres Solver
+ *     is an EXTERNAL dependency absent from /root/reference, un-vendored and
+ *     un-pinned (CMakeLists.txt:152; API usage bounds it to 1.12 <= v < 2.2).
+ *     Its published trust-region Levenberg-Marquardt / Schur / PCG algorithm
+ *     is restated from the Ceres 1.14 sources' documented behaviour (SURVEY
+ *     App. B).
+ *
+ * PINNING STATUS: the projection functions are pinned by the reference's own
+ * round-trip tests (pinhole_camera_model_test.cc:218-298 and siblings,
+ * restated in tests/test_oracle_camera_models.py) and by the known-answer
+ * cost/RMSE of the reference fixture data/sfm/fountain11.bin
+ * (tests/golden/).  The LM / Schur / PCG layer is "PARITY UNPINNED": the
+ * reference holds no test that pins BundleAdjustReconstruction output
+ * numerically and neither Ceres nor the reference can be built
+ * here (Eigen, Ceres, glog, gflags, SuiteSparse absent).
+ *
+ * The problem / options / summary structs are the public ones from
+ * include/theia_mi355_ba.h so the same flattened inputs feed both sides.
+ */
+#ifndef ORACLE_BA_ORACLE_H_
+#define ORACLE_BA_ORACLE_H_
+
+#include "../include/theia_mi355_ba.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Ceres-semantics LM on the CPU.  In/out arrays of `problem` are updated when
+ * the solution is usable.  Returns a tmi_ba_status. */
+int32_t oracle_ba_solve(tmi_ba_problem* problem, const tmi_ba_options* options,
+                        tmi_ba_summary* summary);
+
+/* Per-observation evaluation with dual numbers at the problem's current
+ * parameters, in the caller's observation order:
+ *   residuals [2N]; jac_full [2*20*N] row-major 2x20 with columns
+ *   [ext(6) | intrinsics(10, zero padded) | point(4)]; valid [N].
+ * Any output may be NULL. */
+int32_t oracle_ba_evaluate(const tmi_ba_problem* problem, double* residuals,
+                           double* jac_full, uint8_t* valid);
+
+/* 1/2 sum rho(|r|^2) and un-robustified RMSE at the current parameters.
+ * Returns number of invalid observations (cost excludes them). */
+int64_t oracle_ba_cost(const tmi_ba_problem* problem, const tmi_ba_options* options,
+                       double* cost, double* rmse);
+
+/* Camera::ProjectPoint (reference camera.cc:204-213): pixel and depth. */
+double oracle_project_point(int32_t model, const double* extrinsics,
+                            const double* intrinsics, const double* point4,
+                            double* pixel2);
+
+/* CameraToPixelCoordinates / PixelToCameraCoordinates of one model, used to
+ * restate the reference's round-trip tests. */
+void oracle_camera_to_pixel(int32_t model, const double* intrinsics,
+                            const double* point3, double* pixel2);
+void oracle_pixel_to_camera(int32_t model, const double* intrinsics,
+                            const double* pixel2, double* point3);
+
+void oracle_camera_to_pixel_batch(int32_t model, const double* intrinsics, const double* points3,
+                                  int64_t n, double* pixels2);
+void oracle_pixel_to_camera_batch(int32_t model, const double* intrinsics, const double* pixels2,
+                                  int64_t n, double* points3);
+
+/* Loss function rho[3] = {rho, rho', rho''} (ceres/loss_function.cc). */
+void oracle_loss(int32_t type, double width, double s, double rho[3]);
+
+/* GetSubsetFromOptimizeIntrinsicsType restated (same contract as
+ * tmi_ba_intrinsics_constant_mask). */
+int32_t oracle_intrinsics_constant_mask(int32_t model, int32_t bitmask, uint8_t* mask);
+
+int32_t oracle_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,136 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY (see ba_oracle.h).
+
+ctypes binding of oracle/liboracle_ba.so for tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg.  The product package never imports this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from theiasfm_amd import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle_ba.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    if force or not os.path.exists(_LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.oracle_ba_solve.argtypes = [C.POINTER(abi.CProblem), C.POINTER(abi.COptions),
+                                      C.POINTER(abi.CSummary)]
+        L.oracle_ba_solve.restype = C.c_int32
+        L.oracle_ba_evaluate.argtypes = [C.POINTER(abi.CProblem), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_ba_evaluate.restype = C.c_int32
+        L.oracle_ba_cost.argtypes = [C.POINTER(abi.CProblem), C.POINTER(abi.COptions),
+                                     C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.oracle_ba_cost.restype = C.c_int64
+        L.oracle_project_point.argtypes = [C.c_int32] + [C.c_void_p] * 4
+        L.oracle_project_point.restype = C.c_double
+        L.oracle_camera_to_pixel.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_pixel_to_camera.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_camera_to_pixel_batch.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.oracle_pixel_to_camera_batch.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.oracle_loss.argtypes = [C.c_int32, C.c_double, C.c_double, C.c_void_p]
+        L.oracle_intrinsics_constant_mask.argtypes = [C.c_int32, C.c_int32, C.c_void_p]
+        L.oracle_intrinsics_constant_mask.restype = C.c_int32
+        L.oracle_num_threads.restype = C.c_int32
+        _lib = L
+    return _lib
+
+
+def solve(problem: abi.Problem, options: abi.COptions):
+    """Runs the CPU LM on a copy-free view of `problem` (updated in place)."""
+    cp = problem.as_c()
+    s = abi.CSummary()
+    st = lib().oracle_ba_solve(C.byref(cp), C.byref(options), C.byref(s))
+    return st, s
+
+
+def evaluate(problem: abi.Problem):
+    """residuals [N,2], dual-number Jacobians [N,2,20], valid [N]."""
+    n = problem.num_observations
+    r = np.zeros((n, 2))
+    J = np.zeros((n, 2, 20))
+    v = np.zeros(n, dtype=np.uint8)
+    cp = problem.as_c()
+    lib().oracle_ba_evaluate(C.byref(cp), r.ctypes.data, J.ctypes.data, v.ctypes.data)
+    return r, J, v
+
+
+def cost(problem: abi.Problem, options: abi.COptions | None = None):
+    c, rm = C.c_double(), C.c_double()
+    cp = problem.as_c()
+    o = options if options is not None else abi.default_options()
+    bad = lib().oracle_ba_cost(C.byref(cp), C.byref(o), C.byref(c), C.byref(rm))
+    return c.value, rm.value, bad
+
+
+def camera_to_pixel(model, K, pt):
+    K = np.ascontiguousarray(K, dtype=np.float64)
+    pt = np.ascontiguousarray(pt, dtype=np.float64)
+    out = np.zeros(2)
+    lib().oracle_camera_to_pixel(model, K.ctypes.data, pt.ctypes.data, out.ctypes.data)
+    return out
+
+
+def pixel_to_camera(model, K, px):
+    K = np.ascontiguousarray(K, dtype=np.float64)
+    px = np.ascontiguousarray(px, dtype=np.float64)
+    out = np.zeros(3)
+    lib().oracle_pixel_to_camera(model, K.ctypes.data, px.ctypes.data, out.ctypes.data)
+    return out
+
+
+def camera_to_pixel_batch(model, K, pts):
+    K = np.ascontiguousarray(K, dtype=np.float64)
+    pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 3)
+    out = np.zeros((pts.shape[0], 2))
+    lib().oracle_camera_to_pixel_batch(model, K.ctypes.data, pts.ctypes.data, pts.shape[0],
+                                       out.ctypes.data)
+    return out
+
+
+def pixel_to_camera_batch(model, K, px):
+    K = np.ascontiguousarray(K, dtype=np.float64)
+    px = np.ascontiguousarray(px, dtype=np.float64).reshape(-1, 2)
+    out = np.zeros((px.shape[0], 3))
+    lib().oracle_pixel_to_camera_batch(model, K.ctypes.data, px.ctypes.data, px.shape[0],
+                                       out.ctypes.data)
+    return out
+
+
+def project_point(model, ext, K, X):
+    ext, K, X = (np.ascontiguousarray(a, dtype=np.float64) for a in (ext, K, X))
+    out = np.zeros(2)
+    d = lib().oracle_project_point(model, ext.ctypes.data, K.ctypes.data, X.ctypes.data,
+                                   out.ctypes.data)
+    return out, d
+
+
+def loss(kind, width, s):
+    out = np.zeros(3)
+    lib().oracle_loss(kind, width, s, out.ctypes.data)
+    return out
+
+
+def intrinsics_constant_mask(model, bits):
+    out = np.zeros(abi.INTRINSICS_SIZE[model], dtype=np.uint8)
+    lib().oracle_intrinsics_constant_mask(model, bits, out.ctypes.data)
+    return out
+
+
+def num_threads() -> int:
+    return lib().oracle_num_threads()

@@ -1,0 +1,277 @@
+"""Seeded synthetic bundle-adjustment problems at the BASELINE.json sizes.
+
+No BAL / 1DSfM file exists in the container, so the benchmark and
+the parity tests run on synthetic reconstructions with the named camera /
+track / observation counts.  The scene is generated directly in the
+reference's conventions:
+
+  * camera = [position C(3), angle-axis w(3)] with q = R(w) (X - C)
+    (reference: src/theia/sfm/camera/reprojection_error.h:62-83, camera.h:195-200),
+    the camera looks along +z of its own frame;
+  * PINHOLE intrinsics [f, ar, skew, px, py, k1, k2] (pinhole_camera_model.h:86-94),
+    BAL-like: own intrinsics group per view, principal point (0, 0)
+    (Bundler/BAL -> Theia convention);
+  * homogeneous points with w = 1 (track.h:66-67).
+
+Config 1 follows the recipe of the reference's own synthetic test scenes
+(sfm/global_pose_estimation/nonlinear_position_estimator_test.cc:66-74,166-200):
+positions 10*U(-1,1)^3, angle-axis 0.2*U(-1,1)^3, f = 800, pp = (500, 500),
+points U(-1,1)^3 + (0,0,20), every view observes every track.
+
+The larger configs are a "landmark" scene: cameras on a jittered ring looking
+at a ball of points; each track is seen by k cameras drawn from a window of
+the ring (k - 2 ~ Geometric so that mean k = N_obs / N_pts, window width
+heavy-tailed), which gives a banded-plus-tail co-visibility structure whose
+reduced camera matrix fill is controlled by ``spread``.
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy.spatial.transform import Rotation
+
+from . import abi
+from .abi import Problem
+
+# (cameras, points, observations) of BASELINE.json configs[0..3]
+CONFIG_SIZES = {
+    "tiny": (3, 100, 300),
+    "ladybug49": (49, 7776, 31843),
+    "alamo": (570, 140000, 900000),
+    "venice1778": (1778, 993923, 5001946),
+}
+
+
+# ---- numpy projection (generator side only) ----------------------------------
+def _distort(model: int, K: np.ndarray, q: np.ndarray) -> np.ndarray:
+    """Vectorised CameraToPixelCoordinates for observations that all use `model`.
+    K: [n, size], q: [n, 3] camera-frame points.  Used to synthesise pixels."""
+    if model == abi.FISHEYE:
+        x, y, z = q[:, 0], q[:, 1], q[:, 2]
+        r = np.sqrt(x * x + y * y)
+        th = np.arctan2(r, np.abs(z))
+        t2 = th * th
+        thd = th * (1 + K[:, 5] * t2 + K[:, 6] * t2**2 + K[:, 7] * t2**3 + K[:, 8] * t2**4)
+        s = np.where(r * r < 1e-8, 1.0, thd / np.maximum(r, 1e-300)) * np.where(z < 0, -1.0, 1.0)
+        s = np.where(r * r < 1e-8, 1.0, s)
+        dx, dy = s * x, s * y
+        return np.stack([K[:, 0] * dx + K[:, 2] * dy + K[:, 3], K[:, 0] * K[:, 1] * dy + K[:, 4]], 1)
+    nx, ny = q[:, 0] / q[:, 2], q[:, 1] / q[:, 2]
+    r2 = nx * nx + ny * ny
+    if model == abi.PINHOLE:
+        d = 1 + r2 * (K[:, 5] + K[:, 6] * r2)
+        dx, dy = nx * d, ny * d
+        return np.stack([K[:, 0] * dx + K[:, 2] * dy + K[:, 3], K[:, 0] * K[:, 1] * dy + K[:, 4]], 1)
+    if model == abi.PINHOLE_RADIAL_TANGENTIAL:
+        rd = 1 + K[:, 5] * r2 + K[:, 6] * r2**2 + K[:, 7] * r2**3
+        tx = K[:, 9] * (r2 + 2 * nx * nx) + 2 * K[:, 8] * nx * ny
+        ty = K[:, 8] * (r2 + 2 * ny * ny) + 2 * K[:, 9] * nx * ny
+        dx, dy = nx * rd + tx, ny * rd + ty
+        return np.stack([K[:, 0] * dx + K[:, 2] * dy + K[:, 3], K[:, 0] * K[:, 1] * dy + K[:, 4]], 1)
+    if model == abi.FOV:
+        w = K[:, 4]
+        ru = np.sqrt(r2)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            rd = np.where(
+                w < 1e-3, w * w * r2 / 3 - w * w / 12 + 1,
+                np.where(r2 < 1e-3,
+                         -2 * np.tan(w / 2) * (4 * r2 * np.tan(w / 2) ** 2 - 3) / (3 * w),
+                         np.arctan(2 * ru * np.tan(w / 2)) / (ru * w)))
+        return np.stack([K[:, 0] * rd * nx + K[:, 2], K[:, 0] * K[:, 1] * rd * ny + K[:, 3]], 1)
+    # division undistortion
+    ux, uy = K[:, 0] * nx, K[:, 0] * K[:, 1] * ny
+    ru2 = ux * ux + uy * uy
+    k = K[:, 4]
+    denom = 2 * k * ru2
+    inner = 1 - 4 * k * ru2
+    with np.errstate(divide="ignore", invalid="ignore"):
+        sc = np.where((np.abs(denom) < np.finfo(float).eps) | (inner < 0), 1.0,
+                      (1 - np.sqrt(np.maximum(inner, 0))) / denom)
+    return np.stack([ux * sc + K[:, 2], uy * sc + K[:, 3]], 1)
+
+
+def project(problem: Problem, obs_index=None) -> np.ndarray:
+    """Pixels of every observation at the problem's current parameters."""
+    cam = problem.obs_camera if obs_index is None else problem.obs_camera[obs_index]
+    pt = problem.obs_point if obs_index is None else problem.obs_point[obs_index]
+    Rm = Rotation.from_rotvec(problem.extrinsics[:, 3:6]).as_matrix()
+    X = problem.points[pt]
+    a = X[:, :3] - X[:, 3:4] * problem.extrinsics[cam, :3]
+    q = np.einsum("nij,nj->ni", Rm[cam], a)
+    out = np.empty((cam.shape[0], 2))
+    grp = problem.camera_group[cam]
+    models = problem.group_model[grp]
+    for m in np.unique(models):
+        sel = np.nonzero(models == m)[0]
+        n = abi.INTRINSICS_SIZE[m]
+        K = problem.intrinsics[problem.group_offset[grp[sel]][:, None] + np.arange(n)[None, :]]
+        out[sel] = _distort(int(m), K, q[sel])
+    return out
+
+
+# ---- visibility -------------------------------------------------------------
+def _track_lengths(rng, n_cameras, n_points, n_obs):
+    mean_k = n_obs / n_points
+    if mean_k >= n_cameras:
+        return np.full(n_points, n_cameras, dtype=np.int64)
+    p = 1.0 / max(mean_k - 1.0, 1.0 + 1e-9)
+    k = 1 + rng.geometric(min(p, 1.0), n_points).astype(np.int64)
+    k = np.clip(k, 2, n_cameras)
+    # steer the total to exactly n_obs
+    for _ in range(64):
+        diff = int(n_obs - k.sum())
+        if diff == 0:
+            break
+        if diff > 0:
+            cand = np.nonzero(k < n_cameras)[0]
+            pick = rng.choice(cand, size=min(diff, cand.size), replace=False)
+            k[pick] += 1
+        else:
+            cand = np.nonzero(k > 2)[0]
+            pick = rng.choice(cand, size=min(-diff, cand.size), replace=False)
+            k[pick] -= 1
+    if k.sum() != n_obs:
+        raise ValueError("cannot realise the requested observation count")
+    return k
+
+
+def _visibility(rng, n_cameras, n_points, n_obs, spread):
+    k = _track_lengths(rng, n_cameras, n_points, n_obs)
+    # window width w = m*k cameras, m heavy tailed, w <= n_cameras
+    m_max = np.maximum(n_cameras // k, 1)
+    m = np.rint(spread * n_cameras / k * rng.lognormal(0.0, 0.9, n_points)).astype(np.int64)
+    m = np.clip(m, 1, m_max)
+    start = rng.integers(0, n_cameras, n_points)
+    pt = np.repeat(np.arange(n_points, dtype=np.int64), k)
+    first = np.cumsum(k) - k
+    j = np.arange(n_obs, dtype=np.int64) - np.repeat(first, k)
+    mm = np.repeat(m, k)
+    off = j * mm + (rng.random(n_obs) * mm).astype(np.int64)
+    cam = (np.repeat(start, k) + off) % n_cameras
+    return cam.astype(np.int32), pt.astype(np.int32), k
+
+
+# ---- scenes -----------------------------------------------------------------
+def _look_at(C, target, up=np.array([0.0, 1.0, 0.0])):
+    z = target - C
+    z /= np.linalg.norm(z, axis=1, keepdims=True)
+    x = np.cross(np.broadcast_to(up, z.shape), z)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    y = np.cross(z, x)
+    Rm = np.stack([x, y, z], axis=1)  # rows are the camera axes in world coordinates
+    return Rotation.from_matrix(Rm).as_rotvec()
+
+
+def make_problem(n_cameras: int, n_points: int, n_obs: int, seed: int, *,
+                 scene: str = "ring", spread: float = 0.12, pixel_noise: float = 0.5,
+                 perturb: float = 1.0, models=None, shared_group_size: int = 1,
+                 intrinsics_to_optimize: int = abi.INTRINSICS_DEFAULT) -> Problem:
+    """Build a seeded synthetic problem.
+
+    scene "allsee": the reference test recipe (config 1), every view sees every track.
+    scene "ring":   landmark scene with windowed visibility (configs 2-4).
+    models: optional list of (camera_model, fraction); default all PINHOLE.
+    shared_group_size: >1 makes consecutive cameras share an intrinsics group.
+    perturb: scale of the initial perturbation away from the generating
+             parameters (1.0 = SURVEY 8d: points/positions 0.25 % of the scene
+             depth, angle-axis 0.005 rad)."""
+    rng = np.random.default_rng(seed)
+    if scene == "allsee":
+        C = 10.0 * rng.uniform(-1, 1, (n_cameras, 3))
+        aa = 0.2 * rng.uniform(-1, 1, (n_cameras, 3))
+        X = rng.uniform(-1, 1, (n_points, 3))
+        # keep the cloud in front of every camera: depth offset as in the
+        # reference recipe, scaled with the camera spread
+        X[:, 2] += 20.0 + 10.0
+        cam = np.tile(np.arange(n_cameras, dtype=np.int32), n_points)
+        pt = np.repeat(np.arange(n_points, dtype=np.int32), n_cameras)
+        if n_obs != n_cameras * n_points:
+            raise ValueError("allsee scene needs n_obs == n_cameras * n_points")
+        depth = 20.0
+        f = np.full(n_cameras, 800.0)
+        pp = np.full((n_cameras, 2), 500.0)
+        k1 = np.zeros(n_cameras)
+        k2 = np.zeros(n_cameras)
+    elif scene == "ring":
+        radius = 100.0
+        phi = (np.arange(n_cameras) + rng.uniform(-0.3, 0.3, n_cameras)) * (2 * np.pi / n_cameras)
+        rr = radius * (1.0 + rng.uniform(-0.08, 0.08, n_cameras))
+        C = np.stack([rr * np.cos(phi), radius * rng.uniform(-0.15, 0.15, n_cameras),
+                      rr * np.sin(phi)], 1)
+        target = radius * 0.1 * rng.normal(size=(n_cameras, 3))
+        aa = _look_at(C, target)
+        X = radius * 0.3 * rng.uniform(-1, 1, (n_points, 3))
+        cam, pt, _ = _visibility(rng, n_cameras, n_points, n_obs, spread)
+        depth = radius
+        f = rng.uniform(600, 900, n_cameras)
+        pp = np.zeros((n_cameras, 2))
+        k1 = rng.uniform(-0.1, 0.0, n_cameras)
+        k2 = rng.uniform(0.0, 0.02, n_cameras)
+    else:
+        raise ValueError(scene)
+
+    # intrinsics groups
+    if shared_group_size > 1:
+        camera_group = (np.arange(n_cameras) // shared_group_size).astype(np.int32)
+    else:
+        camera_group = np.arange(n_cameras, dtype=np.int32)
+    n_groups = int(camera_group.max()) + 1 if n_cameras else 0
+    group_model = np.zeros(n_groups, dtype=np.int32)
+    if models:
+        edges = np.cumsum([fr for _, fr in models])
+        u = rng.random(n_groups)
+        for g in range(n_groups):
+            group_model[g] = models[int(np.searchsorted(edges, u[g] * edges[-1]))][0]
+    sizes = np.array([abi.INTRINSICS_SIZE[m] for m in group_model], dtype=np.int32)
+    group_offset = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    intr = np.zeros(int(group_offset[-1]))
+    rep = np.zeros(n_groups, dtype=np.int64)  # representative camera of each group
+    rep[camera_group[::-1]] = np.arange(n_cameras)[::-1]
+    for g in range(n_groups):
+        o, m, c = group_offset[g], group_model[g], rep[g]
+        if m in (abi.PINHOLE, abi.PINHOLE_RADIAL_TANGENTIAL, abi.FISHEYE):
+            intr[o:o + 5] = [f[c], 1.0, 0.0, pp[c, 0], pp[c, 1]]
+            if m == abi.PINHOLE:
+                intr[o + 5:o + 7] = [k1[c], k2[c]]
+            elif m == abi.PINHOLE_RADIAL_TANGENTIAL:
+                intr[o + 5:o + 10] = [k1[c], k2[c], 0.1 * k2[c], 1e-3 * rng.normal(), 1e-3 * rng.normal()]
+            else:
+                intr[o + 5:o + 9] = [0.3 * k1[c], 0.3 * k2[c], 0.0, 0.0]
+        elif m == abi.FOV:
+            intr[o:o + 5] = [f[c], 1.0, pp[c, 0], pp[c, 1], rng.uniform(0.05, 0.4)]
+        else:
+            intr[o:o + 5] = [f[c], 1.0, pp[c, 0], pp[c, 1], rng.uniform(-2e-7, 0.0)]
+
+    points = np.concatenate([X, np.ones((n_points, 1))], 1)
+    prob = Problem(
+        extrinsics=np.concatenate([C, aa], 1), camera_group=camera_group,
+        camera_flags=np.zeros(n_cameras, np.uint8), group_model=group_model,
+        group_offset=group_offset, intrinsics=intr,
+        intrinsics_constant=np.zeros(intr.shape[0], np.uint8), points=points,
+        point_constant=np.zeros(n_points, np.uint8), obs_camera=cam, obs_point=pt,
+        obs_xy=np.zeros((cam.shape[0], 2)))
+    prob.set_intrinsics_to_optimize(intrinsics_to_optimize)
+
+    # exact projections + pixel noise
+    xy = project(prob)
+    xy += pixel_noise * rng.normal(size=xy.shape)
+    prob.obs_xy = np.ascontiguousarray(xy)
+    prob.meta["truth"] = dict(extrinsics=prob.extrinsics.copy(), intrinsics=prob.intrinsics.copy(),
+                              points=prob.points.copy())
+    # initial perturbation
+    s = 0.0025 * depth * perturb
+    prob.points[:, :3] += s * rng.normal(size=(n_points, 3))
+    prob.extrinsics[:, :3] += s * rng.normal(size=(n_cameras, 3))
+    prob.extrinsics[:, 3:] += 0.005 * perturb * rng.normal(size=(n_cameras, 3))
+    prob.meta.update(dict(seed=seed, scene=scene, spread=spread))
+    return prob
+
+
+def config(name: str, **kw) -> Problem:
+    """The BASELINE.json configurations by name."""
+    nc, npt, nobs = CONFIG_SIZES[name]
+    if name == "tiny":
+        return make_problem(nc, npt, nobs, seed=1, scene="allsee", **kw)
+    seeds = {"ladybug49": 49, "alamo": 570, "venice1778": 1778}
+    spreads = {"ladybug49": 0.35, "alamo": 0.15, "venice1778": 0.12}
+    kw.setdefault("spread", spreads[name])
+    return make_problem(nc, npt, nobs, seed=seeds[name], scene="ring", **kw)
