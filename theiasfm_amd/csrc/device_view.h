@@ -1,0 +1,129 @@
+// Plain-pointer view of one resident problem in HBM, passed by value to every
+// kernel.  Layout notes (all fp64 unless stated):
+//
+//  parameters        ext[Nc][6]  intr[sum sizes]  pts[Np_pad][4]
+//  track-major SELL  element e = slice_ptr[s] + 64 j + t  (track 64 s + t, its j-th obs)
+//    pm_r   [2][No_pad]      robustified residual
+//    pm_A   [2 D][No_pad]    plane 2*col+row: reduced camera Jacobian (scaled, robustified)
+//    pm_Jp  [2 DP][No_pad]   plane 2*col+row: point Jacobian
+//  camera-major (slot = obs_cpos[e], contiguous per reduced block)
+//    cm_Y   [Nslots][YS]     Y = A^T Jp L^-T  (D x DP row-major, YS = D*DP rounded up to even)
+//    cm_A   [Nslots][AS]     A row 0 (D), A row 1 (D), r~(2), r(2);  AS = 2 D + 4
+//  reduced system
+//    red    [nub*D*D | Nrb*D*D | Nrb*D | Nrb*D | Nrb*D | 8]   the all-reduce buffer:
+//           upper blocks, raw diagonal blocks, U diagonal, reduced gradient g~,
+//           camera gradient g_c, scalars
+//    S      [nnzb][D*D]      BSR values, both triangles, LM diagonal added
+#pragma once
+#include <cstdint>
+
+namespace tmi {
+
+struct DeviceView {
+  int Nc, G, Np_pad, nslices, Nrb, D, DP;
+  int No_pad;
+  int Nslots;
+  int nub, nnzb;
+  long long npairs;
+
+  // parameters (current and candidate)
+  double* ext;
+  double* intr;
+  double* pts;
+  double* ext_c;
+  double* intr_c;
+  double* pts_c;
+
+  // static structure
+  const int* slice_ptr;
+  const int* pt_k;
+  const unsigned char* pt_const;
+  const int* obs_cam;
+  const double* obs_xy;  // [No_pad][2]
+  const int* obs_cpos;
+  const int* cam_grp;
+  const int* cam_rb;
+  const unsigned* cam_mask;
+  const int* grp_model;
+  const int* grp_off;
+  const int* rb_cam;
+  const signed char* rb_cols;  // [Nrb][D]
+  const int* cam_ptr;
+  const int* row_ptr;
+  const int* col_idx;
+  const int* diag_pos;
+  const int* ub_pos;
+  const int* ub_pos_t;
+  const long long* pair_ptr;
+  const int* pair_i;
+  const int* pair_j;
+  const int* ub_order;
+
+  // work arrays
+  double* pm_r;
+  double* pm_A;
+  double* pm_Jp;
+  double* cm_Y;
+  double* cm_A;
+  double* scale_c;  // [Nrb][D]
+  double* scale_p;  // [Np_pad][DP]
+  double* Vinv;     // [DP(DP+1)/2][Np_pad]  planes, symmetric inverse of V + Dp
+  double* gp;       // [DP][Np_pad]
+  double* diag_p;   // [DP][Np_pad] squared column norms of the point Jacobian
+  double* yp;       // [DP][Np_pad]
+  double* red;      // all-reduce buffer
+  double* S;        // BSR values
+  double* Minv;     // [Nrb][D*D] inverse diagonal blocks
+  double* rhs;      // [Nrb*D]
+  double* yc;       // [Nrb*D]
+  double* cg_r;
+  double* cg_z;
+  double* cg_p;
+  double* cg_q;
+  double* cg_t;
+  double* partial;  // per-workgroup partial sums (several lanes of scalars)
+  double* scal;     // device scalars
+  int* flags;       // device flags (invalid residual, singular block, ...)
+};
+
+// offsets into `red`
+struct RedLayout {
+  long long ub, diag, udiag, gt, gc, scalars, total;
+};
+inline RedLayout red_layout(long long nub, int Nrb, int D) {
+  RedLayout L;
+  L.ub = 0;
+  L.diag = L.ub + nub * D * D;
+  L.udiag = L.diag + (long long)Nrb * D * D;
+  L.gt = L.udiag + (long long)Nrb * D;
+  L.gc = L.gt + (long long)Nrb * D;
+  L.scalars = L.gc + (long long)Nrb * D;
+  L.total = L.scalars + 8;
+  return L;
+}
+
+// slots in DeviceView::scal
+enum {
+  SC_COST = 0,      // 1/2 sum rho at the linearisation point
+  SC_SS = 1,        // sum of squared raw residuals
+  SC_CAND_COST = 2,
+  SC_CAND_SS = 3,
+  SC_MCC = 4,       // model cost change
+  SC_STEP_SQ = 5,
+  SC_XNORM_SQ = 6,
+  SC_GMAX = 7,
+  SC_RHO = 8,       // PCG scalars
+  SC_LAST_RHO = 9,
+  SC_PQ = 10,
+  SC_ALPHA = 11,
+  SC_Q0 = 12,
+  SC_Q1 = 13,
+  SC_ZETA = 14,
+  SC_BNORM = 15,
+  SC_GMAX_P = 16,
+  SC_COUNT = 32
+};
+// DeviceView::flags
+enum { FL_INVALID = 0, FL_SINGULAR_POINT = 1, FL_SINGULAR_BLOCK = 2, FL_PCG_FAIL = 3, FL_COUNT = 8 };
+
+}  // namespace tmi

@@ -1,0 +1,1007 @@
+// Host driver + C ABI of the MI355X bundle-adjustment engine.
+//
+// tmi_ba_solver_solve() is the replacement for the ceres::Solve call at
+// src/theia/sfm/bundle_adjustment/bundle_adjuster.cc:205: a trust-region
+// Levenberg-Marquardt loop with Ceres' semantics (restated from
+// Ceres 1.14's TrustRegionMinimizer / LevenbergMarquardtStrategy /
+// ConjugateGradientsSolver since Ceres itself is an external dependency of the
+// reference) whose every numeric phase is a HIP kernel from kernels.h.  The
+// host only sequences launches and takes the accept / reject decisions from a
+// handful of scalars read back once per iteration (once per PCG iteration
+// inside the linear solve).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/theia_mi355_ba.h"
+#include "dense_cholesky.h"
+#include "kernels.h"
+#include "structure.h"
+
+namespace tmi {
+
+static double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+#define TMI_HIP(call)                                                                  \
+  do {                                                                                 \
+    hipError_t e_ = (call);                                                            \
+    if (e_ != hipSuccess) {                                                            \
+      char buf_[256];                                                                  \
+      snprintf(buf_, sizeof(buf_), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+               __FILE__, __LINE__);                                                    \
+      s->error = buf_;                                                                 \
+      return (e_ == hipErrorOutOfMemory) ? TMI_BA_ERR_OUT_OF_MEMORY : TMI_BA_ERR_DEVICE; \
+    }                                                                                  \
+  } while (0)
+
+// ---- per (D, DP) launch table --------------------------------------------------
+struct Launch {
+  void (*linearize)(const DeviceView&, hipStream_t, int, double, int);
+  void (*cost)(const DeviceView&, hipStream_t, const double*, const double*, const double*, int,
+               double, int, int, double*);
+  void (*point_scale)(const DeviceView&, hipStream_t, int);
+  void (*camera_scale)(const DeviceView&, hipStream_t, const int*);
+  void (*point_eliminate)(const DeviceView&, hipStream_t, double, double, double, int, double*);
+  void (*camera_diag)(const DeviceView&, hipStream_t, RedLayout);
+  void (*schur_offdiag)(const DeviceView&, hipStream_t, RedLayout);
+  void (*expand)(const DeviceView&, hipStream_t, RedLayout, double, double, double);
+  void (*precond)(const DeviceView&, hipStream_t, int);
+  void (*spmv)(const DeviceView&, hipStream_t, const double*, double*);
+  void (*pcg_a)(const DeviceView&, hipStream_t, int, int);
+  void (*back_substitute)(const DeviceView&, hipStream_t, double*, int, double*);
+  void (*update_points)(const DeviceView&, hipStream_t, int, double*);
+  void (*update_cameras)(const DeviceView&, hipStream_t, double*);
+  void (*camera_gmax)(const DeviceView&, hipStream_t, const double*, double*);
+  void (*dense_gather)(const DeviceView&, hipStream_t, double*, int);
+};
+
+template <int D, int DP>
+Launch make_launch() {
+  Launch L;
+  L.linearize = [](const DeviceView& v, hipStream_t st, int lt, double lw, int nb) {
+    hipLaunchKernelGGL((linearize_kernel<D, DP>), dim3(nb), dim3(256), 0, st, v, lt, lw, nb);
+  };
+  L.cost = [](const DeviceView& v, hipStream_t st, const double* e, const double* i, const double* p,
+              int lt, double lw, int fl, int nb, double* partial) {
+    hipLaunchKernelGGL((cost_kernel<DP>), dim3(nb), dim3(256), 0, st, v, e, i, p, lt, lw, fl, nb, partial);
+  };
+  L.point_scale = [](const DeviceView& v, hipStream_t st, int nb) {
+    hipLaunchKernelGGL((point_scale_kernel<DP>), dim3(nb), dim3(256), 0, st, v);
+  };
+  L.camera_scale = [](const DeviceView& v, hipStream_t st, const int* slot_obs) {
+    if (v.Nrb) hipLaunchKernelGGL((camera_scale_kernel<D>), dim3(v.Nrb), dim3(64), 0, st, v, slot_obs);
+  };
+  L.point_eliminate = [](const DeviceView& v, hipStream_t st, double ir, double lo, double hi, int nb,
+                         double* pm) {
+    hipLaunchKernelGGL((point_eliminate_kernel<D, DP>), dim3(nb), dim3(256), 0, st, v, ir, lo, hi, nb, pm);
+  };
+  L.camera_diag = [](const DeviceView& v, hipStream_t st, RedLayout R) {
+    if (v.Nrb) hipLaunchKernelGGL((camera_diag_kernel<D, DP>), dim3(v.Nrb), dim3(64), 0, st, v, R);
+  };
+  L.schur_offdiag = [](const DeviceView& v, hipStream_t st, RedLayout R) {
+    if (v.nub)
+      hipLaunchKernelGGL((schur_offdiag_kernel<D, DP>), dim3((v.nub + 3) / 4), dim3(256), 0, st, v, R);
+  };
+  L.expand = [](const DeviceView& v, hipStream_t st, RedLayout R, double ir, double lo, double hi) {
+    const long long n1 = (long long)v.nub * D * D;
+    if (n1)
+      hipLaunchKernelGGL((expand_offdiag_kernel<D>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0,
+                         st, v, R);
+    const int n2 = v.Nrb * D * D;
+    if (n2)
+      hipLaunchKernelGGL((expand_diag_kernel<D>), dim3((n2 + 255) / 256), dim3(256), 0, st, v, R, ir,
+                         lo, hi);
+  };
+  L.precond = [](const DeviceView& v, hipStream_t st, int identity) {
+    if (v.Nrb) hipLaunchKernelGGL((precond_invert_kernel<D>), dim3(v.Nrb), dim3(64), 0, st, v, identity);
+  };
+  L.spmv = [](const DeviceView& v, hipStream_t st, const double* x, double* y) {
+    if (v.Nrb) hipLaunchKernelGGL((spmv_kernel<D>), dim3(v.Nrb), dim3(256), 0, st, v, x, y);
+  };
+  L.pcg_a = [](const DeviceView& v, hipStream_t st, int n, int it) {
+    hipLaunchKernelGGL((pcg_a_kernel<D>), dim3(1), dim3(1024), 0, st, v, n, it);
+  };
+  L.back_substitute = [](const DeviceView& v, hipStream_t st, double* pm_u, int nb, double* partial) {
+    hipLaunchKernelGGL((back_substitute_kernel<D, DP>), dim3(nb), dim3(256), 0, st, v, pm_u, nb, partial);
+  };
+  L.update_points = [](const DeviceView& v, hipStream_t st, int nb, double* partial) {
+    hipLaunchKernelGGL((update_points_kernel<DP>), dim3(nb), dim3(256), 0, st, v, nb, partial);
+  };
+  L.update_cameras = [](const DeviceView& v, hipStream_t st, double* out) {
+    hipLaunchKernelGGL((update_cameras_kernel<D>), dim3(1), dim3(1024), 0, st, v, out);
+  };
+  L.camera_gmax = [](const DeviceView& v, hipStream_t st, const double* gc, double* out) {
+    hipLaunchKernelGGL((camera_gmax_kernel<D>), dim3(1), dim3(1024), 0, st, v, gc, out);
+  };
+  L.dense_gather = [](const DeviceView& v, hipStream_t st, double* A, int n) {
+    const long long total = (long long)v.nnzb * D * D;
+    if (total)
+      hipLaunchKernelGGL((dense_gather_kernel<D>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                         st, v, A, n);
+  };
+  return L;
+}
+
+static bool get_launch(int D, int DP, Launch* out) {
+#define TMI_CASE(d, p)       \
+  if (D == d && DP == p) {   \
+    *out = make_launch<d, p>(); \
+    return true;             \
+  }
+  TMI_CASE(6, 3) TMI_CASE(6, 4) TMI_CASE(9, 3) TMI_CASE(9, 4)
+  TMI_CASE(12, 3) TMI_CASE(12, 4) TMI_CASE(16, 3) TMI_CASE(16, 4)
+#undef TMI_CASE
+  return false;
+}
+
+}  // namespace tmi
+
+using namespace tmi;
+
+// ---- the opaque solver ----------------------------------------------------------
+struct tmi_ba_solver {
+  Structure st;
+  Launch launch;
+  DeviceView v;
+  RedLayout RL;
+  int DP = 4;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::vector<void*> allocs;
+  // pinned host scalars
+  double* h_scal = nullptr;
+  int* h_flags = nullptr;
+  // initial parameters (for reset) in device order
+  std::vector<double> ext0, intr0, pts0;
+  int n_intr = 0;
+  // extra device arrays not in the view
+  int* d_slot_obs = nullptr;
+  double* d_pm_u = nullptr;
+  double* d_partial_max = nullptr;
+  double* d_dense = nullptr;  // n_r x n_r when an exact solve is requested
+  int nblocks_slices = 0;     // grid of the per-track kernels
+  int nblocks_points = 0;
+  tmi_ba_allreduce_fn allreduce = nullptr;
+  void* allreduce_user = nullptr;
+  // profiling
+  unsigned prof_mask = 0;
+  struct Ev { int cls; hipEvent_t a, b; };
+  std::vector<Ev> events;
+  size_t ev_used = 0;
+  int64_t launches[TMI_BA_NUM_KERNEL_CLASSES] = {0};
+  std::string error;
+  double setup_seconds = 0.0;
+};
+
+namespace {
+
+std::mutex g_device_mutex;  // serialise solves per process (tmi_ba_solve is re-entrant)
+
+template <class T>
+int dev_alloc(tmi_ba_solver* s, T** p, size_t n) {
+  *p = nullptr;
+  if (n == 0) n = 1;
+  TMI_HIP(hipMalloc((void**)p, n * sizeof(T)));
+  s->allocs.push_back((void*)*p);
+  return TMI_BA_OK;
+}
+template <class T>
+int dev_upload(tmi_ba_solver* s, T** p, const std::vector<T>& h) {
+  int rc = dev_alloc(s, p, h.size());
+  if (rc) return rc;
+  if (!h.empty()) TMI_HIP(hipMemcpy(*p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  return TMI_BA_OK;
+}
+
+struct Timed {
+  tmi_ba_solver* s;
+  int cls;
+  bool on;
+  tmi_ba_solver::Ev* ev = nullptr;
+  Timed(tmi_ba_solver* s_, int cls_) : s(s_), cls(cls_) {
+    s->launches[cls]++;
+    on = (s->prof_mask >> cls) & 1u;
+    if (on) {
+      if (s->ev_used == s->events.size()) {
+        tmi_ba_solver::Ev e;
+        e.cls = cls;
+        hipEventCreate(&e.a);
+        hipEventCreate(&e.b);
+        s->events.push_back(e);
+      }
+      ev = &s->events[s->ev_used++];
+      ev->cls = cls;
+      hipEventRecord(ev->a, s->stream);
+    }
+  }
+  ~Timed() {
+    if (on) hipEventRecord(ev->b, s->stream);
+  }
+};
+
+int readback(tmi_ba_solver* s) {
+  TMI_HIP(hipMemcpyAsync(s->h_scal, s->v.scal, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  TMI_HIP(hipMemcpyAsync(s->h_flags, s->v.flags, FL_COUNT * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+  TMI_HIP(hipStreamSynchronize(s->stream));
+  return TMI_BA_OK;
+}
+
+int do_allreduce(tmi_ba_solver* s, double* buf, int64_t count) {
+  if (!s->allreduce || s->st.world <= 1) return TMI_BA_OK;
+  Timed t(s, TMI_BA_K_ALLREDUCE);
+  const int rc = s->allreduce((void*)buf, count, (void*)s->stream, s->allreduce_user);
+  if (rc != 0) {
+    s->error = "all-reduce callback failed";
+    return TMI_BA_ERR_COLLECTIVE;
+  }
+  return TMI_BA_OK;
+}
+
+void set_message(tmi_ba_summary* sum, const char* m) { snprintf(sum->message, sizeof(sum->message), "%s", m); }
+
+}  // namespace
+
+// ---- C ABI -------------------------------------------------------------------------
+extern "C" {
+
+int32_t tmi_ba_version(void) { return TMI_BA_VERSION_MAJOR * 1000 + TMI_BA_VERSION_MINOR; }
+
+int32_t tmi_ba_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+  return n;
+}
+
+const char* tmi_ba_status_string(int32_t st) {
+  switch (st) {
+    case TMI_BA_OK: return "ok";
+    case TMI_BA_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case TMI_BA_ERR_NO_DEVICE: return "no HIP device";
+    case TMI_BA_ERR_DEVICE: return "HIP runtime error";
+    case TMI_BA_ERR_OUT_OF_MEMORY: return "out of device memory";
+    case TMI_BA_ERR_UNSUPPORTED: return "unsupported problem shape";
+    case TMI_BA_ERR_EVALUATION_FAILED: return "residual evaluation failed at the start point";
+    case TMI_BA_ERR_LINEAR_SOLVER: return "linear solver failure";
+    case TMI_BA_ERR_COLLECTIVE: return "collective failure";
+    default: return "unknown status";
+  }
+}
+
+void tmi_ba_options_init(tmi_ba_options* o) {
+  if (!o) return;
+  memset(o, 0, sizeof(*o));
+  // BundleAdjustmentOptions, bundle_adjustment.h:78-122
+  o->loss_function_type = TMI_BA_LOSS_TRIVIAL;
+  o->robust_loss_width = 2.0;
+  o->linear_solver_type = TMI_BA_SPARSE_SCHUR;
+  o->preconditioner_type = TMI_BA_PRECOND_SCHUR_JACOBI;
+  o->verbose = 0;
+  o->num_threads = 1;
+  o->max_num_iterations = 100;
+  o->max_solver_time_in_seconds = 3600.0;
+  o->use_inner_iterations = 1;
+  o->function_tolerance = 1e-6;
+  o->gradient_tolerance = 1e-10;
+  o->parameter_tolerance = 1e-8;
+  o->max_trust_region_radius = 1e12;
+  // Ceres defaults Theia does not override
+  o->initial_trust_region_radius = 1e4;
+  o->min_trust_region_radius = 1e-32;
+  o->min_relative_decrease = 1e-3;
+  o->min_lm_diagonal = 1e-6;
+  o->max_lm_diagonal = 1e32;
+  o->eta = 0.1;
+  o->max_linear_solver_iterations = 500;
+  o->min_linear_solver_iterations = 0;
+  o->max_num_consecutive_invalid_steps = 5;
+  o->jacobi_scaling = 1;
+  o->point_dof = 4;
+  o->device = -1;
+  o->profile_kernels = 0;
+  o->residual_precision = 64;
+}
+
+int32_t tmi_ba_intrinsics_size(int32_t model) {
+  static const int n[5] = {7, 10, 9, 5, 5};
+  return (model >= 0 && model < 5) ? n[model] : -1;
+}
+
+// GetSubsetFromOptimizeIntrinsicsType: pinhole_camera_model.cc:132-162,
+// pinhole_radial_tangential_camera_model.cc:150-185, fisheye_camera_model.cc:142-175,
+// fov_camera_model.cc:124-149, division_undistortion_camera_model.cc:126-150.
+int32_t tmi_ba_intrinsics_constant_mask(int32_t model, int32_t bits, uint8_t* mask) {
+  const int n = tmi_ba_intrinsics_size(model);
+  if (n < 0 || !mask) return -1;
+  memset(mask, 0, (size_t)n);
+  if (bits == TMI_BA_INTRINSICS_ALL) return n;
+  const uint8_t cf = !(bits & TMI_BA_INTRINSICS_FOCAL_LENGTH);
+  const uint8_t ca = !(bits & TMI_BA_INTRINSICS_ASPECT_RATIO);
+  const uint8_t cs = !(bits & TMI_BA_INTRINSICS_SKEW);
+  const uint8_t cp = !(bits & TMI_BA_INTRINSICS_PRINCIPAL_POINTS);
+  const uint8_t cr = !(bits & TMI_BA_INTRINSICS_RADIAL_DISTORTION);
+  const uint8_t ct = !(bits & TMI_BA_INTRINSICS_TANGENTIAL_DISTORTION);
+  if (model <= TMI_BA_FISHEYE) {
+    mask[0] = cf; mask[1] = ca; mask[2] = cs; mask[3] = cp; mask[4] = cp;
+    for (int i = 5; i < n; ++i) mask[i] = cr;
+    if (model == TMI_BA_PINHOLE_RADIAL_TANGENTIAL) { mask[8] = ct; mask[9] = ct; }
+  } else {
+    mask[0] = cf; mask[1] = ca; mask[2] = cp; mask[3] = cp; mask[4] = cr;
+  }
+  return n;
+}
+
+void tmi_ba_solver_destroy(tmi_ba_solver* s) {
+  if (!s) return;
+  hipSetDevice(s->device);
+  if (s->stream) hipStreamSynchronize(s->stream);
+  for (auto& e : s->events) {
+    hipEventDestroy(e.a);
+    hipEventDestroy(e.b);
+  }
+  for (void* p : s->allocs) hipFree(p);
+  if (s->h_scal) hipHostFree(s->h_scal);
+  if (s->h_flags) hipHostFree(s->h_flags);
+  if (s->stream) hipStreamDestroy(s->stream);
+  delete s;
+}
+
+static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_options* O, int rank,
+                       int world) {
+  const double t0 = now_s();
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    s->error = "no HIP device visible (the device path has no CPU fallback)";
+    return TMI_BA_ERR_NO_DEVICE;
+  }
+  if (O->device >= 0) {
+    if (O->device >= ndev) {
+      s->error = "options.device out of range";
+      return TMI_BA_ERR_INVALID_ARGUMENT;
+    }
+    s->device = O->device;
+  } else {
+    TMI_HIP(hipGetDevice(&s->device));
+  }
+  TMI_HIP(hipSetDevice(s->device));
+  if (O->point_dof != 3 && O->point_dof != 4) {
+    s->error = "point_dof must be 3 or 4";
+    return TMI_BA_ERR_INVALID_ARGUMENT;
+  }
+  if (O->residual_precision != 64 && O->residual_precision != 0) {
+    s->error = "only the fp64 residual path is implemented";
+    return TMI_BA_ERR_UNSUPPORTED;
+  }
+  s->DP = O->point_dof;
+  int rc = build_structure(P, rank, world, &s->st);
+  if (rc) {
+    s->error = s->st.error;
+    return rc;
+  }
+  Structure& st = s->st;
+  if (!get_launch(st.D, s->DP, &s->launch)) {
+    s->error = "no kernel instantiation for this block size";
+    return TMI_BA_ERR_UNSUPPORTED;
+  }
+  TMI_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  TMI_HIP(hipHostMalloc((void**)&s->h_scal, SC_COUNT * sizeof(double), hipHostMallocDefault));
+  TMI_HIP(hipHostMalloc((void**)&s->h_flags, FL_COUNT * sizeof(int), hipHostMallocDefault));
+
+  const int D = st.D, DP = s->DP;
+  DeviceView& v = s->v;
+  memset(&v, 0, sizeof(v));
+  v.Nc = st.Nc; v.G = st.G; v.Np_pad = st.Np_pad; v.nslices = st.nslices; v.Nrb = st.Nrb;
+  v.D = D; v.DP = DP; v.No_pad = (int)st.No_pad; v.Nslots = (int)st.Nslots;
+  v.nub = (int)st.nub; v.nnzb = (int)st.nnzb; v.npairs = st.npairs;
+  s->RL = red_layout(st.nub, st.Nrb, D);
+  s->n_intr = st.G ? P->group_offset[st.G] : 0;
+
+  // parameters in device order
+  s->ext0.assign(P->extrinsics, P->extrinsics + (size_t)6 * st.Nc);
+  s->intr0.assign(P->intrinsics, P->intrinsics + s->n_intr);
+  s->pts0.assign((size_t)4 * st.Np_pad, 0.0);
+  for (int lp = 0; lp < st.Np_pad; ++lp) {
+    const int p = st.pt_orig[lp];
+    for (int a = 0; a < 4; ++a) s->pts0[(size_t)4 * lp + a] = (p >= 0) ? P->points[(size_t)4 * p + a] : (a == 3 ? 1.0 : 0.0);
+  }
+#define UP(field, vec)                                            \
+  do {                                                            \
+    rc = dev_upload(s, const_cast<std::remove_const<std::remove_pointer<decltype(v.field)>::type>::type**>(&v.field), vec); \
+    if (rc) return rc;                                            \
+  } while (0)
+  {
+    double *d_ext, *d_intr, *d_pts;
+    if ((rc = dev_upload(s, &d_ext, s->ext0))) return rc;
+    if ((rc = dev_upload(s, &d_intr, s->intr0))) return rc;
+    if ((rc = dev_upload(s, &d_pts, s->pts0))) return rc;
+    v.ext = d_ext; v.intr = d_intr; v.pts = d_pts;
+    if ((rc = dev_upload(s, &d_ext, s->ext0))) return rc;
+    if ((rc = dev_upload(s, &d_intr, s->intr0))) return rc;
+    if ((rc = dev_upload(s, &d_pts, s->pts0))) return rc;
+    v.ext_c = d_ext; v.intr_c = d_intr; v.pts_c = d_pts;
+  }
+  std::vector<int> cam_grp(P->camera_group, P->camera_group + st.Nc);
+  std::vector<int> grp_model(P->group_model, P->group_model + st.G);
+  std::vector<int> grp_off(P->group_offset, P->group_offset + st.G + 1);
+  std::vector<signed char> rb_cols(st.rb_cols.begin(), st.rb_cols.end());
+  std::vector<long long> pair_ptr(st.pair_ptr.begin(), st.pair_ptr.end());
+  {
+    int* p; unsigned* pu; unsigned char* pc; signed char* ps; long long* pl; double* pd;
+#define UPI(dst, vec) if ((rc = dev_upload(s, &p, vec))) return rc; dst = p;
+    UPI(v.slice_ptr, st.slice_ptr) UPI(v.pt_k, st.pt_k) UPI(v.obs_cam, st.obs_cam)
+    UPI(v.obs_cpos, st.obs_cpos) UPI(v.cam_grp, cam_grp) UPI(v.cam_rb, st.cam_rb)
+    UPI(v.grp_model, grp_model) UPI(v.grp_off, grp_off) UPI(v.rb_cam, st.rb_cam)
+    UPI(v.cam_ptr, st.cam_ptr) UPI(v.row_ptr, st.row_ptr) UPI(v.col_idx, st.col_idx)
+    UPI(v.diag_pos, st.diag_pos) UPI(v.ub_pos, st.ub_pos) UPI(v.ub_pos_t, st.ub_pos_t)
+    UPI(v.pair_i, st.pair_i) UPI(v.pair_j, st.pair_j) UPI(v.ub_order, st.ub_order)
+#undef UPI
+    if ((rc = dev_upload(s, &pu, st.cam_mask))) return rc; v.cam_mask = pu;
+    if ((rc = dev_upload(s, &pc, st.pt_const))) return rc; v.pt_const = pc;
+    if ((rc = dev_upload(s, &ps, rb_cols))) return rc; v.rb_cols = ps;
+    if ((rc = dev_upload(s, &pl, pair_ptr))) return rc; v.pair_ptr = pl;
+    if ((rc = dev_upload(s, &pd, st.obs_xy))) return rc; v.obs_xy = pd;
+  }
+#undef UP
+  // slot -> track-major element
+  {
+    std::vector<int> slot_obs((size_t)st.Nslots, 0);
+    for (int64_t e = 0; e < st.No_pad; ++e)
+      if (st.obs_cpos[e] >= 0) slot_obs[st.obs_cpos[e]] = (int)e;
+    if ((rc = dev_upload(s, &s->d_slot_obs, slot_obs))) return rc;
+  }
+  const size_t N = (size_t)st.No_pad, NP = (size_t)st.Np_pad;
+  const int YS = ys_of(D, DP), AS = as_of(D), NS = sym_size(DP);
+  const int n_r = st.Nrb * D;
+  s->nblocks_slices = (st.nslices + kSlicesPerBlock - 1) / kSlicesPerBlock;
+  if (s->nblocks_slices < 1) s->nblocks_slices = 1;
+  s->nblocks_points = (st.Np_pad + 255) / 256;
+  if (s->nblocks_points < 1) s->nblocks_points = 1;
+  const int nbmax = std::max(s->nblocks_slices, s->nblocks_points);
+#define AL(ptr, n) if ((rc = dev_alloc(s, &ptr, (size_t)(n)))) return rc;
+  AL(v.pm_r, 2 * N) AL(v.pm_A, 2 * D * N) AL(v.pm_Jp, 2 * DP * N) AL(s->d_pm_u, 2 * N)
+  AL(v.cm_Y, (size_t)st.Nslots * YS) AL(v.cm_A, (size_t)st.Nslots * AS)
+  AL(v.scale_c, std::max(n_r, 1)) AL(v.scale_p, NP * DP)
+  AL(v.Vinv, NP * NS) AL(v.gp, NP * DP) AL(v.diag_p, NP * DP) AL(v.yp, NP * DP)
+  AL(v.red, s->RL.total) AL(v.S, (size_t)st.nnzb * D * D) AL(v.Minv, (size_t)std::max(st.Nrb, 1) * D * D)
+  AL(v.rhs, std::max(n_r, 1)) AL(v.yc, std::max(n_r, 1)) AL(v.cg_r, std::max(n_r, 1))
+  AL(v.cg_z, std::max(n_r, 1)) AL(v.cg_p, std::max(n_r, 1)) AL(v.cg_q, std::max(n_r, 1))
+  AL(v.cg_t, std::max(n_r, 1)) AL(v.partial, (size_t)4 * nbmax) AL(s->d_partial_max, nbmax)
+  AL(v.scal, SC_COUNT) AL(v.flags, FL_COUNT)
+#undef AL
+  TMI_HIP(hipMemsetAsync(v.scal, 0, SC_COUNT * sizeof(double), s->stream));
+  TMI_HIP(hipMemsetAsync(v.flags, 0, FL_COUNT * sizeof(int), s->stream));
+  TMI_HIP(hipMemsetAsync(v.yc, 0, std::max(n_r, 1) * sizeof(double), s->stream));
+  TMI_HIP(hipMemsetAsync(v.red, 0, s->RL.total * sizeof(double), s->stream));
+  TMI_HIP(hipMemsetAsync(v.cm_Y, 0, (size_t)std::max<int64_t>(st.Nslots, 1) * YS * sizeof(double), s->stream));
+  TMI_HIP(hipMemsetAsync(v.cm_A, 0, (size_t)std::max<int64_t>(st.Nslots, 1) * AS * sizeof(double), s->stream));
+  TMI_HIP(hipStreamSynchronize(s->stream));
+  s->setup_seconds = now_s() - t0;
+  return TMI_BA_OK;
+}
+
+int32_t tmi_ba_solver_create(const tmi_ba_problem* P, const tmi_ba_options* O, int32_t rank,
+                             int32_t world, tmi_ba_solver** out) {
+  if (!out) return TMI_BA_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (!P || !O) return TMI_BA_ERR_INVALID_ARGUMENT;
+  tmi_ba_solver* s = new tmi_ba_solver();
+  const int rc = create_impl(s, P, O, rank, world);
+  if (rc != TMI_BA_OK) {
+    if (O->verbose) fprintf(stderr, "[tmi_ba] create failed: %s\n", s->error.c_str());
+    // keep the message reachable through a failed handle is not possible; print when verbose
+    static thread_local std::string last_error;
+    last_error = s->error;
+    tmi_ba_solver_destroy(s);
+    return rc;
+  }
+  *out = s;
+  return TMI_BA_OK;
+}
+
+int32_t tmi_ba_solver_set_allreduce(tmi_ba_solver* s, tmi_ba_allreduce_fn fn, void* user) {
+  if (!s) return TMI_BA_ERR_INVALID_ARGUMENT;
+  s->allreduce = fn;
+  s->allreduce_user = user;
+  return TMI_BA_OK;
+}
+
+void* tmi_ba_solver_stream(tmi_ba_solver* s) { return s ? (void*)s->stream : nullptr; }
+
+int32_t tmi_ba_solver_reset(tmi_ba_solver* s) {
+  if (!s) return TMI_BA_ERR_INVALID_ARGUMENT;
+  TMI_HIP(hipSetDevice(s->device));
+  TMI_HIP(hipMemcpyAsync(s->v.ext, s->ext0.data(), s->ext0.size() * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  TMI_HIP(hipMemcpyAsync(s->v.intr, s->intr0.data(), s->intr0.size() * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  TMI_HIP(hipMemcpyAsync(s->v.pts, s->pts0.data(), s->pts0.size() * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  TMI_HIP(hipStreamSynchronize(s->stream));
+  return TMI_BA_OK;
+}
+
+int32_t tmi_ba_solver_download(tmi_ba_solver* s, tmi_ba_problem* P) {
+  if (!s || !P) return TMI_BA_ERR_INVALID_ARGUMENT;
+  if (P->num_cameras != s->st.Nc || P->num_points != s->st.Np_total) return TMI_BA_ERR_INVALID_ARGUMENT;
+  TMI_HIP(hipSetDevice(s->device));
+  std::vector<double> pts((size_t)4 * s->st.Np_pad);
+  TMI_HIP(hipMemcpyAsync(P->extrinsics, s->v.ext, (size_t)6 * s->st.Nc * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  if (s->n_intr)
+    TMI_HIP(hipMemcpyAsync(P->intrinsics, s->v.intr, (size_t)s->n_intr * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  if (!pts.empty())
+    TMI_HIP(hipMemcpyAsync(pts.data(), s->v.pts, pts.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  TMI_HIP(hipStreamSynchronize(s->stream));
+  for (int lp = 0; lp < s->st.Np_pad; ++lp) {
+    const int p = s->st.pt_orig[lp];
+    if (p < 0) continue;
+    for (int a = 0; a < 4; ++a) P->points[(size_t)4 * p + a] = pts[(size_t)4 * lp + a];
+  }
+  return TMI_BA_OK;
+}
+
+// ---- the linear solve of one LM iteration ------------------------------------------
+// returns TMI_BA_OK; *usable = 0 for LINEAR_SOLVER_FAILURE
+static int solve_reduced_pcg(tmi_ba_solver* s, const tmi_ba_options* O, int* usable, int64_t* iters) {
+  DeviceView& v = s->v;
+  const int n = v.Nrb * v.D;
+  const double* b = v.red + s->RL.gt;
+  *usable = 1;
+  if (n == 0) return TMI_BA_OK;
+  {
+    Timed t(s, TMI_BA_K_PCG_VECTOR);
+    hipLaunchKernelGGL(pcg_begin_kernel, dim3(1), dim3(1024), 0, s->stream, v, b, n);
+  }
+  int it;
+  for (it = 1;; ++it) {
+    {
+      Timed t(s, TMI_BA_K_PCG_VECTOR);
+      s->launch.pcg_a(v, s->stream, n, it);
+    }
+    {
+      Timed t(s, TMI_BA_K_SPMV);
+      s->launch.spmv(v, s->stream, v.cg_p, v.cg_q);
+    }
+    const bool reset = (it % 10 == 0);  // residual_reset_period
+    {
+      Timed t(s, TMI_BA_K_PCG_VECTOR);
+      hipLaunchKernelGGL(pcg_b_kernel, dim3(1), dim3(1024), 0, s->stream, v, b, n, it, reset ? 1 : 0);
+    }
+    if (reset) {
+      {
+        Timed t(s, TMI_BA_K_SPMV);
+        s->launch.spmv(v, s->stream, v.yc, v.cg_t);
+      }
+      Timed t(s, TMI_BA_K_PCG_VECTOR);
+      hipLaunchKernelGGL(pcg_b_kernel, dim3(1), dim3(1024), 0, s->stream, v, b, n, it, 2);
+    }
+    int rc = readback(s);
+    if (rc) return rc;
+    if (s->h_flags[FL_PCG_FAIL]) {
+      *usable = 0;
+      break;
+    }
+    if (!(s->h_scal[SC_PQ] > 0.0)) break;  // LINEAR_SOLVER_NO_CONVERGENCE, x kept
+    if (s->h_scal[SC_ZETA] < O->eta && it >= O->min_linear_solver_iterations) break;
+    if (it >= O->max_linear_solver_iterations) break;
+  }
+  *iters += it;
+  return TMI_BA_OK;
+}
+
+static int solve_reduced_dense(tmi_ba_solver* s, int* usable) {
+  DeviceView& v = s->v;
+  const int n = v.Nrb * v.D;
+  *usable = 1;
+  if (n == 0) return TMI_BA_OK;
+  if (!s->d_dense) {
+    int rc = dev_alloc(s, &s->d_dense, (size_t)n * n);
+    if (rc) return rc;
+  }
+  Timed t(s, TMI_BA_K_CHOLESKY);
+  TMI_HIP(hipMemsetAsync(s->d_dense, 0, (size_t)n * n * sizeof(double), s->stream));
+  s->launch.dense_gather(v, s->stream, s->d_dense, n);
+  dense_cholesky_solve(s->d_dense, n, v.red + s->RL.gt, v.yc, v.flags + FL_SINGULAR_BLOCK, s->stream);
+  return TMI_BA_OK;
+}
+
+int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_summary* sum) {
+  if (!s || !O || !sum) return TMI_BA_ERR_INVALID_ARGUMENT;
+  memset(sum, 0, sizeof(*sum));
+  sum->termination = 2;
+  if (O->point_dof != s->DP) {
+    sum->status = TMI_BA_ERR_INVALID_ARGUMENT;
+    set_message(sum, "point_dof differs from the value the solver was created with");
+    return sum->status;
+  }
+  std::lock_guard<std::mutex> lock(g_device_mutex);
+  auto fail = [&](int rc) {
+    sum->status = rc;
+    sum->success = 0;
+    sum->termination = 2;
+    set_message(sum, s->error.empty() ? tmi_ba_status_string(rc) : s->error.c_str());
+    return rc;
+  };
+  if (hipSetDevice(s->device) != hipSuccess) {
+    s->error = "hipSetDevice failed";
+    return fail(TMI_BA_ERR_DEVICE);
+  }
+  const double t_start = now_s();
+  DeviceView& v = s->v;
+  Structure& st = s->st;
+  const RedLayout& RL = s->RL;
+  const int D = st.D;
+  const int n_r = st.Nrb * D;
+  const int nbs = s->nblocks_slices, nbp = s->nblocks_points;
+  hipStream_t stream = s->stream;
+  s->prof_mask = (O->profile_kernels == 1) ? 0xffffffffu : (unsigned)O->profile_kernels;
+  s->ev_used = 0;
+  memset(s->launches, 0, sizeof(s->launches));
+  sum->num_reduced_blocks = st.Nrb;
+  sum->reduced_block_dim = D;
+  sum->num_schur_blocks = st.nub + st.Nrb;
+  sum->num_schur_pairs = st.npairs;
+  sum->setup_time_in_seconds = s->setup_seconds;
+  int rc;
+#define CK(x) if ((rc = (x)) != TMI_BA_OK) return fail(rc)
+#define CKH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { s->error = std::string(#call) + ": " + hipGetErrorString(e_); return fail(TMI_BA_ERR_DEVICE); } } while (0)
+
+  const int lt = O->loss_function_type;
+  const double lw = O->robust_loss_width;
+  const bool iterative = (O->linear_solver_type == TMI_BA_ITERATIVE_SCHUR || O->linear_solver_type == TMI_BA_CGNR);
+  double* d_sc = v.red + RL.scalars;  // 8 device scalars that get all-reduced
+
+  // ---- iteration zero ---------------------------------------------------------------
+  CKH(hipMemsetAsync(v.flags, 0, FL_COUNT * sizeof(int), stream));
+  CKH(hipMemsetAsync(v.yc, 0, std::max(n_r, 1) * sizeof(double), stream));
+  hipLaunchKernelGGL(fill_kernel, dim3((n_r + 255) / 256 + 1), dim3(256), 0, stream, v.scale_c, (long long)n_r, 1.0);
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)(((long long)st.Np_pad * s->DP + 255) / 256 + 1)), dim3(256), 0, stream, v.scale_p, (long long)st.Np_pad * s->DP, 1.0);
+  auto linearize = [&]() {
+    {
+      Timed t(s, TMI_BA_K_LINEARIZE);
+      s->launch.linearize(v, stream, lt, lw, nbs);
+    }
+    Timed t(s, TMI_BA_K_REDUCE);
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(2), dim3(256), 0, stream, v.partial, nbs, d_sc);
+  };
+  linearize();
+  // d_sc[0] = cost, d_sc[1] = ss, d_sc[2] = #ranks with an invalid residual
+  {
+    int rc2 = readback(s);
+    if (rc2) return fail(rc2);
+    const double inv = s->h_flags[FL_INVALID] ? 1.0 : 0.0;
+    CKH(hipMemcpyAsync(d_sc + 2, &inv, sizeof(double), hipMemcpyHostToDevice, stream));
+    CKH(hipStreamSynchronize(stream));
+  }
+  CK(do_allreduce(s, d_sc, 8));
+  double hsc[8];
+  CKH(hipMemcpyAsync(hsc, d_sc, sizeof(hsc), hipMemcpyDeviceToHost, stream));
+  CKH(hipStreamSynchronize(stream));
+  const int64_t No_global_hint = st.No;  // per-rank; RMSE uses the global count below
+  (void)No_global_hint;
+  if (hsc[2] > 0.0) {
+    s->error = "residual evaluation failed at the start point (a track lies on a camera centre)";
+    return fail(TMI_BA_ERR_EVALUATION_FAILED);
+  }
+  double cost = hsc[0];
+  // global observation count for the RMSE
+  double n_obs_global = (double)st.No;
+  if (st.world > 1) {
+    double tmp[8] = {(double)st.No, 0, 0, 0, 0, 0, 0, 0};
+    CKH(hipMemcpyAsync(d_sc, tmp, sizeof(tmp), hipMemcpyHostToDevice, stream));
+    CK(do_allreduce(s, d_sc, 8));
+    CKH(hipMemcpyAsync(tmp, d_sc, sizeof(tmp), hipMemcpyDeviceToHost, stream));
+    CKH(hipStreamSynchronize(stream));
+    n_obs_global = tmp[0];
+  }
+  sum->initial_cost = cost;
+  sum->initial_rmse = n_obs_global > 0 ? std::sqrt(hsc[1] / n_obs_global) : 0.0;
+  double final_ss = hsc[1];
+
+  if (O->jacobi_scaling) {
+    {
+      Timed t(s, TMI_BA_K_REDUCE);
+      s->launch.point_scale(v, stream, nbs);
+      s->launch.camera_scale(v, stream, s->d_slot_obs);
+    }
+    CK(do_allreduce(s, v.scale_c, n_r));
+    {
+      Timed t(s, TMI_BA_K_REDUCE);
+      if (n_r) hipLaunchKernelGGL(camera_scale_finish_kernel, dim3((n_r + 255) / 256), dim3(256), 0, stream, v.scale_c, n_r);
+    }
+    linearize();
+  }
+  // |x| of the start point: camera part through update_cameras with y = 0
+  double xnorm_cam_sq = 0.0, xnorm_pts_sq = 0.0;
+  {
+    Timed t(s, TMI_BA_K_UPDATE_COST);
+    CKH(hipMemcpyAsync(v.ext_c, v.ext, (size_t)6 * st.Nc * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    if (s->n_intr) CKH(hipMemcpyAsync(v.intr_c, v.intr, (size_t)s->n_intr * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    s->launch.update_cameras(v, stream, v.scal + SC_STEP_SQ);
+    hipLaunchKernelGGL(points_norm_kernel, dim3(nbp), dim3(256), 0, stream, v, v.pts, nbp, v.partial);
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, stream, v.partial, nbp, d_sc);
+  }
+  CK(do_allreduce(s, d_sc, 8));
+  CKH(hipMemcpyAsync(hsc, d_sc, sizeof(hsc), hipMemcpyDeviceToHost, stream));
+  CK(readback(s));
+  xnorm_cam_sq = s->h_scal[SC_STEP_SQ + 1];
+  xnorm_pts_sq = hsc[0];
+  double x_norm = std::sqrt(xnorm_cam_sq + xnorm_pts_sq);
+
+  const double t_loop = now_s();
+  double radius = O->initial_trust_region_radius;
+  double decrease_factor = 2.0;
+  int invalid_run = 0;
+  int iter = 0;
+  int termination = 1;
+  const char* why = "maximum number of iterations reached";
+  int64_t pcg_iters = 0;
+  bool need_gradient_check = true;  // after the first build and after every accepted step
+
+  for (;;) {
+    if (iter >= O->max_num_iterations) break;
+    if (now_s() - t_start >= O->max_solver_time_in_seconds) {
+      why = "maximum solver time reached";
+      break;
+    }
+    ++iter;
+    const double inv_radius = 1.0 / radius;
+    CKH(hipMemsetAsync(v.flags, 0, FL_COUNT * sizeof(int), stream));
+    {
+      Timed t(s, TMI_BA_K_POINT_ELIMINATE);
+      s->launch.point_eliminate(v, stream, inv_radius, O->min_lm_diagonal, O->max_lm_diagonal, nbs, s->d_partial_max);
+    }
+    {
+      Timed t(s, TMI_BA_K_CAMERA_DIAG);
+      s->launch.camera_diag(v, stream, RL);
+    }
+    {
+      Timed t(s, TMI_BA_K_SCHUR_OFFDIAG);
+      s->launch.schur_offdiag(v, stream, RL);
+    }
+    CK(do_allreduce(s, v.red, RL.scalars));
+    {
+      Timed t(s, TMI_BA_K_REDUCE);
+      s->launch.expand(v, stream, RL, inv_radius, O->min_lm_diagonal, O->max_lm_diagonal);
+    }
+    if (need_gradient_check) {
+      Timed t(s, TMI_BA_K_REDUCE);
+      hipLaunchKernelGGL(reduce_max_kernel, dim3(1), dim3(256), 0, stream, s->d_partial_max, nbs, v.scal + SC_GMAX_P);
+      s->launch.camera_gmax(v, stream, v.red + RL.gc, v.scal + SC_GMAX);
+    }
+    int usable = 1;
+    if (iterative) {
+      {
+        Timed t(s, TMI_BA_K_PRECONDITIONER);
+        s->launch.precond(v, stream, O->preconditioner_type == TMI_BA_PRECOND_IDENTITY);
+      }
+      CK(solve_reduced_pcg(s, O, &usable, &pcg_iters));
+    } else {
+      CK(solve_reduced_dense(s, &usable));
+      CK(readback(s));
+    }
+    if (s->h_flags[FL_SINGULAR_POINT] || s->h_flags[FL_SINGULAR_BLOCK]) usable = 0;
+    if (need_gradient_check) {
+      // gradient tolerance: every rank votes, the vote is summed
+      double vote[8] = {0};
+      const double gmax_local = std::fmax(s->h_scal[SC_GMAX], s->h_scal[SC_GMAX_P]);
+      vote[0] = (gmax_local > O->gradient_tolerance) ? 1.0 : 0.0;
+      if (st.world > 1) {
+        CKH(hipMemcpyAsync(d_sc, vote, sizeof(vote), hipMemcpyHostToDevice, stream));
+        CK(do_allreduce(s, d_sc, 8));
+        CKH(hipMemcpyAsync(vote, d_sc, sizeof(vote), hipMemcpyDeviceToHost, stream));
+        CKH(hipStreamSynchronize(stream));
+      }
+      need_gradient_check = false;
+      if (vote[0] == 0.0) {
+        termination = 0;
+        why = "gradient tolerance reached";
+        --iter;
+        break;
+      }
+    }
+    double model_cost_change = 0.0, step_sq = 0.0, cand_cost = 0.0, cand_ss = 0.0;
+    double cand_xc_sq = 0.0, cand_xp_sq = 0.0;
+    bool cand_invalid = false;
+    if (usable) {
+      {
+        Timed t(s, TMI_BA_K_BACK_SUBSTITUTE);
+        s->launch.back_substitute(v, stream, s->d_pm_u, nbs, v.partial);
+        hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, stream, v.partial, nbs, d_sc + 0);
+      }
+      {
+        Timed t(s, TMI_BA_K_UPDATE_COST);
+        CKH(hipMemcpyAsync(v.ext_c, v.ext, (size_t)6 * st.Nc * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        if (s->n_intr) CKH(hipMemcpyAsync(v.intr_c, v.intr, (size_t)s->n_intr * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        s->launch.update_cameras(v, stream, v.scal + SC_STEP_SQ);
+        s->launch.update_points(v, stream, nbp, v.partial);
+        hipLaunchKernelGGL(reduce_sum_kernel, dim3(2), dim3(256), 0, stream, v.partial, nbp, d_sc + 1);
+        s->launch.cost(v, stream, v.ext_c, v.intr_c, v.pts_c, lt, lw, FL_INVALID, nbs, v.partial);
+        hipLaunchKernelGGL(reduce_sum_kernel, dim3(2), dim3(256), 0, stream, v.partial, nbs, d_sc + 3);
+      }
+      // d_sc: [mcc, step_sq_points, |x+|^2 points, cand_cost, cand_ss, invalid votes]
+      CK(readback(s));
+      {
+        const double inv = s->h_flags[FL_INVALID] ? 1.0 : 0.0;
+        CKH(hipMemcpyAsync(d_sc + 5, &inv, sizeof(double), hipMemcpyHostToDevice, stream));
+      }
+      CK(do_allreduce(s, d_sc, 8));
+      CKH(hipMemcpyAsync(hsc, d_sc, sizeof(hsc), hipMemcpyDeviceToHost, stream));
+      CKH(hipStreamSynchronize(stream));
+      model_cost_change = hsc[0];
+      step_sq = hsc[1] + s->h_scal[SC_STEP_SQ];
+      cand_xp_sq = hsc[2];
+      cand_xc_sq = s->h_scal[SC_STEP_SQ + 1];
+      cand_cost = hsc[3];
+      cand_ss = hsc[4];
+      cand_invalid = hsc[5] > 0.0;
+      if (!(model_cost_change > 0.0)) usable = 0;
+    }
+    if (!usable) {
+      // HandleInvalidStep
+      sum->num_unsuccessful_steps++;
+      if (++invalid_run >= O->max_num_consecutive_invalid_steps) {
+        termination = 2;
+        why = "too many consecutive invalid steps";
+        break;
+      }
+      radius /= decrease_factor;
+      decrease_factor *= 2.0;
+      if (radius < O->min_trust_region_radius) {
+        termination = 0;
+        why = "minimum trust region radius reached";
+        break;
+      }
+      continue;
+    }
+    invalid_run = 0;
+    if (cand_invalid) cand_cost = 1.7976931348623157e308;
+    const double step_norm = std::sqrt(step_sq);
+    if (step_norm <= O->parameter_tolerance * (x_norm + O->parameter_tolerance)) {
+      termination = 0;
+      why = "parameter tolerance reached";
+      break;
+    }
+    const double cost_change = cost - cand_cost;
+    if (std::fabs(cost_change) <= O->function_tolerance * cost) {
+      termination = 0;
+      why = "function tolerance reached";
+      break;
+    }
+    const double relative_decrease = cost_change / model_cost_change;
+    if (relative_decrease > O->min_relative_decrease) {
+      std::swap(v.ext, v.ext_c);
+      std::swap(v.intr, v.intr_c);
+      std::swap(v.pts, v.pts_c);
+      cost = cand_cost;
+      final_ss = cand_ss;
+      x_norm = std::sqrt(cand_xc_sq + cand_xp_sq);
+      sum->num_successful_steps++;
+      radius = radius / std::fmax(1.0 / 3.0, 1.0 - std::pow(2.0 * relative_decrease - 1.0, 3));
+      radius = std::fmin(O->max_trust_region_radius, radius);
+      decrease_factor = 2.0;
+      linearize();
+      need_gradient_check = true;
+    } else {
+      sum->num_unsuccessful_steps++;
+      radius /= decrease_factor;
+      decrease_factor *= 2.0;
+    }
+    if (radius < O->min_trust_region_radius) {
+      termination = 0;
+      why = "minimum trust region radius reached";
+      break;
+    }
+    if (O->verbose && st.rank == 0)
+      fprintf(stderr, "[tmi_ba] it %3d cost %.10e radius %.3e pcg %lld\n", iter, cost, radius, (long long)pcg_iters);
+  }
+  CKH(hipStreamSynchronize(stream));
+  const double t_end = now_s();
+  (void)t_loop;
+
+  sum->termination = termination;
+  sum->num_iterations = iter;
+  sum->num_linear_solver_iterations = pcg_iters;
+  sum->final_cost = cost;
+  sum->final_rmse = n_obs_global > 0 ? std::sqrt(final_ss / n_obs_global) : 0.0;
+  sum->success = (termination != 2);
+  sum->status = (termination == 2) ? TMI_BA_ERR_LINEAR_SOLVER : TMI_BA_OK;
+  sum->solve_time_in_seconds = t_end - t_start;
+  set_message(sum, why);
+  for (int c = 0; c < TMI_BA_NUM_KERNEL_CLASSES; ++c) sum->kernel_launches[c] = s->launches[c];
+  for (size_t i = 0; i < s->ev_used; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s->events[i].a, s->events[i].b) == hipSuccess)
+      sum->kernel_seconds[s->events[i].cls] += 1e-3 * ms;
+  }
+  return sum->status;
+#undef CK
+#undef CKH
+}
+
+int32_t tmi_ba_solve(tmi_ba_problem* P, const tmi_ba_options* O, tmi_ba_summary* sum) {
+  if (!P || !O || !sum) return TMI_BA_ERR_INVALID_ARGUMENT;
+  tmi_ba_solver* s = nullptr;
+  memset(sum, 0, sizeof(*sum));
+  const int rc = tmi_ba_solver_create(P, O, 0, 1, &s);
+  if (rc != TMI_BA_OK) {
+    sum->status = rc;
+    sum->termination = 2;
+    set_message(sum, tmi_ba_status_string(rc));
+    return rc;
+  }
+  const int rc2 = tmi_ba_solver_solve(s, O, sum);
+  if (sum->success) tmi_ba_solver_download(s, P);
+  tmi_ba_solver_destroy(s);
+  return rc2;
+}
+
+int32_t tmi_ba_solver_evaluate(tmi_ba_solver* s, double* residuals, double* jac_camera,
+                               double* jac_point, uint8_t* valid, int32_t* block_dim) {
+  if (!s) return TMI_BA_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lock(g_device_mutex);
+  TMI_HIP(hipSetDevice(s->device));
+  DeviceView& v = s->v;
+  Structure& st = s->st;
+  const int D = st.D, DP = s->DP;
+  const int n_r = st.Nrb * D;
+  hipStream_t stream = s->stream;
+  if (block_dim) *block_dim = D;
+  TMI_HIP(hipMemsetAsync(v.flags, 0, FL_COUNT * sizeof(int), stream));
+  hipLaunchKernelGGL(fill_kernel, dim3((n_r + 255) / 256 + 1), dim3(256), 0, stream, v.scale_c, (long long)n_r, 1.0);
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)(((long long)st.Np_pad * DP + 255) / 256 + 1)), dim3(256), 0, stream, v.scale_p, (long long)st.Np_pad * DP, 1.0);
+  // poison the residual planes so that invalid observations can be told apart
+  s->launch.linearize(v, stream, 0, 1.0, s->nblocks_slices);
+  const size_t N = (size_t)st.No_pad;
+  std::vector<double> r(2 * N), A((size_t)2 * D * N), Jp((size_t)2 * DP * N);
+  TMI_HIP(hipMemcpyAsync(r.data(), v.pm_r, r.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+  TMI_HIP(hipMemcpyAsync(A.data(), v.pm_A, A.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+  TMI_HIP(hipMemcpyAsync(Jp.data(), v.pm_Jp, Jp.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+  TMI_HIP(hipStreamSynchronize(stream));
+  for (size_t e = 0; e < N; ++e) {
+    const int64_t i = st.obs_orig[e];
+    if (i < 0) continue;
+    if (residuals) {
+      residuals[2 * i] = r[e];
+      residuals[2 * i + 1] = r[N + e];
+    }
+    if (jac_camera)
+      for (int a = 0; a < D; ++a) {
+        jac_camera[(size_t)2 * D * i + a] = A[(size_t)(2 * a) * N + e];
+        jac_camera[(size_t)2 * D * i + D + a] = A[(size_t)(2 * a + 1) * N + e];
+      }
+    if (jac_point)
+      for (int a = 0; a < DP; ++a) {
+        jac_point[(size_t)2 * DP * i + a] = Jp[(size_t)(2 * a) * N + e];
+        jac_point[(size_t)2 * DP * i + DP + a] = Jp[(size_t)(2 * a + 1) * N + e];
+      }
+    if (valid) valid[i] = 1;
+  }
+  if (valid) {
+    // an invalid observation wrote zeros everywhere; flag it from the functor's own predicate
+    std::vector<double> ext((size_t)6 * st.Nc), pts((size_t)4 * st.Np_pad);
+    TMI_HIP(hipMemcpy(ext.data(), v.ext, ext.size() * sizeof(double), hipMemcpyDeviceToHost));
+    TMI_HIP(hipMemcpy(pts.data(), v.pts, pts.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int sl = 0; sl < st.nslices; ++sl)
+      for (int t = 0; t < 64; ++t) {
+        const int lp = sl * 64 + t;
+        for (int j = 0; j < st.pt_k[lp]; ++j) {
+          const size_t e = (size_t)st.slice_ptr[sl] + (size_t)j * 64 + t;
+          const int64_t i = st.obs_orig[e];
+          const int c = st.obs_cam[e];
+          double sq = 0.0;
+          for (int a = 0; a < 3; ++a) {
+            const double d = pts[(size_t)4 * lp + a] - pts[(size_t)4 * lp + 3] * ext[(size_t)6 * c + a];
+            sq += d * d;
+          }
+          valid[i] = sq < 1e-8 ? 0 : 1;
+        }
+      }
+  }
+  return TMI_BA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,1019 @@
+// HIP kernels of the bundle-adjustment engine (gfx950, wave64, fp64).
+// One Levenberg-Marquardt iteration is
+//   linearize -> point_eliminate -> camera_diag + schur_offdiag -> [all-reduce]
+//   -> expand_S + precond_invert -> PCG (pcg_a / spmv / pcg_b) or dense Cholesky
+//   -> back_substitute -> update -> cost
+// Every kernel is HBM-bound gather/stream work; the only contraction
+// (S_ij = -sum_pairs Y_i Y_j^T, inner dimension 3 x #common tracks) runs on
+// the fp64 matrix cores (v_mfma_f64_16x16x4_f64).
+//
+// Mathematics: SURVEY App. A/B; the reference call site these replace is
+// ceres::Solve at src/theia/sfm/bundle_adjustment/bundle_adjuster.cc:205.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "camera_models.h"
+#include "device_view.h"
+
+namespace tmi {
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+constexpr int kWave = 64;
+constexpr int kSlicesPerBlock = 4;  // 256 threads
+
+__host__ __device__ constexpr int sym_idx(int a, int b, int n) {
+  // index of (a, b), a <= b, in a row-wise packed upper triangle of an n x n matrix
+  return a * n - a * (a - 1) / 2 + (b - a);
+}
+__host__ __device__ constexpr int sym_size(int n) { return n * (n + 1) / 2; }
+__host__ __device__ constexpr int ys_of(int D, int DP) { return (D * DP + 1) & ~1; }
+__host__ __device__ constexpr int as_of(int D) { return 2 * D + 4; }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Sum NV per-thread values over a 256-thread workgroup and store them at
+// partial[v * nblocks + blockIdx.x] (fixed order => reproducible).
+template <int NV>
+__device__ __forceinline__ void block_sum_store(const double (&v)[NV], double* partial, int nblocks) {
+  __shared__ double sh[NV][kSlicesPerBlock];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const double s = wave_sum(v[i]);
+    if (lane == 0) sh[i][w] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < kSlicesPerBlock; ++k) s += sh[threadIdx.x][k];
+    partial[(size_t)threadIdx.x * nblocks + blockIdx.x] = s;
+  }
+}
+
+// dst[v] = sum_{i<n} src[v*n + i]   (grid = #values, block = 256)
+__global__ void reduce_sum_kernel(const double* __restrict__ src, int n, double* __restrict__ dst) {
+  __shared__ double sh[256];
+  const double* s = src + (size_t)blockIdx.x * n;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += s[i];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) dst[blockIdx.x] = sh[0];
+}
+__global__ void reduce_max_kernel(const double* __restrict__ src, int n, double* __restrict__ dst) {
+  __shared__ double sh[256];
+  const double* s = src + (size_t)blockIdx.x * n;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) acc = fmax(acc, s[i]);
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) dst[blockIdx.x] = sh[0];
+}
+
+__global__ void fill_kernel(double* p, long long n, double v) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// ------------------------------------------------------------------------------
+// linearize: residual + Jacobian blocks per observation (kernel class 0).
+// Thread (slice s, lane t) walks the observations of track 64 s + t.
+// Replaces the N_obs AutoDiffCostFunction evaluations of hot loop 1
+// (reprojection_error.h:51-95 under Jets) with analytic Jacobians, applies the
+// loss correction (ceres corrector.cc) and the Jacobi column scaling, and
+// writes the reduced blocks as SoA planes.  cost/ss partials -> partial[0..2).
+// ------------------------------------------------------------------------------
+struct LinearizeArgs {
+  int loss_type;
+  double loss_width;
+  int point_dof_mask;  // unused
+};
+
+template <int D, int DP>
+__global__ __launch_bounds__(256) void linearize_kernel(DeviceView v, int loss_type, double loss_width,
+                                                        int nblocks) {
+  const int lane = threadIdx.x & 63;
+  const int s = blockIdx.x * kSlicesPerBlock + (threadIdx.x >> 6);
+  double acc[2] = {0.0, 0.0};
+  if (s < v.nslices) {
+    const int lp = s * 64 + lane;
+    const int k = v.pt_k[lp];
+    const int base = v.slice_ptr[s] + lane;
+    const int K = (v.slice_ptr[s + 1] - v.slice_ptr[s]) >> 6;
+    const size_t N = (size_t)v.No_pad;
+    double X[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) X[i] = v.pts[(size_t)lp * 4 + i];
+    const bool pconst = v.pt_const[lp] != 0;
+    double sp[DP];
+#pragma unroll
+    for (int a = 0; a < DP; ++a) sp[a] = v.scale_p[(size_t)lp * DP + a];
+    for (int j = 0; j < K; ++j) {
+      if (j >= k) continue;
+      const size_t e = (size_t)base + (size_t)j * 64;
+      const int cam = v.obs_cam[e];
+      const int grp = v.cam_grp[cam];
+      const int model = v.grp_model[grp];
+      const double* Kp = v.intr + v.grp_off[grp];
+      const int nk = v.grp_off[grp + 1] - v.grp_off[grp];
+      double Kv[10], E[6];
+#pragma unroll
+      for (int i = 0; i < 10; ++i) Kv[i] = (i < nk) ? Kp[i] : 0.0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) E[i] = v.ext[(size_t)cam * 6 + i];
+      const double fx = v.obs_xy[2 * e], fy = v.obs_xy[2 * e + 1];
+      double r[2], Jext[2][6], Jint[2][10], Jpt[2][4];
+      const bool ok = reprojection_error<true>(model, E, Kv, X, fx, fy, r, Jext, Jint, Jpt);
+      const unsigned mask = v.cam_mask[cam];
+      const int rb = v.cam_rb[cam];
+      if (!ok) {
+        v.flags[FL_INVALID] = 1;
+        for (int d = 0; d < 2 * D; ++d) v.pm_A[(size_t)d * N + e] = 0.0;
+        for (int d = 0; d < 2 * DP; ++d) v.pm_Jp[(size_t)d * N + e] = 0.0;
+        v.pm_r[e] = 0.0;
+        v.pm_r[N + e] = 0.0;
+        continue;
+      }
+      const double sq = r[0] * r[0] + r[1] * r[1];
+      double sqrt_rho1 = 1.0, asn = 0.0, rscale = 1.0;
+      if (loss_type != 0) {
+        double rho[3];
+        loss_eval(loss_type, loss_width, sq, rho);
+        acc[0] += 0.5 * rho[0];
+        sqrt_rho1 = sqrt(rho[1]);
+        rscale = sqrt_rho1;
+        if (!(sq == 0.0 || rho[2] <= 0.0)) {
+          const double Dd = 1.0 + 2.0 * sq * rho[2] / rho[1];
+          const double alpha = 1.0 - sqrt(Dd);
+          rscale = sqrt_rho1 / (1.0 - alpha);
+          asn = alpha / sq;
+        }
+      } else {
+        acc[0] += 0.5 * sq;
+      }
+      acc[1] += sq;
+      // reduced camera block: free columns of [ext(6) | intr(10)], compacted
+      int dst = 0;
+      const double* sc = v.scale_c + (size_t)(rb < 0 ? 0 : rb) * D;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        if (mask & (1u << c)) {
+          double j0 = (c < 6) ? Jext[0][c < 6 ? c : 0] : Jint[0][c >= 6 ? c - 6 : 0];
+          double j1 = (c < 6) ? Jext[1][c < 6 ? c : 0] : Jint[1][c >= 6 ? c - 6 : 0];
+          if (loss_type != 0) {
+            const double rtj = j0 * r[0] + j1 * r[1];
+            j0 = sqrt_rho1 * (j0 - asn * r[0] * rtj);
+            j1 = sqrt_rho1 * (j1 - asn * r[1] * rtj);
+          }
+          const double scl = sc[dst];
+          v.pm_A[(size_t)(2 * dst) * N + e] = j0 * scl;
+          v.pm_A[(size_t)(2 * dst + 1) * N + e] = j1 * scl;
+          ++dst;
+        }
+      }
+      for (int d = 2 * dst; d < 2 * D; ++d) v.pm_A[(size_t)d * N + e] = 0.0;
+#pragma unroll
+      for (int a = 0; a < DP; ++a) {
+        double j0 = pconst ? 0.0 : Jpt[0][a], j1 = pconst ? 0.0 : Jpt[1][a];
+        if (loss_type != 0) {
+          const double rtj = j0 * r[0] + j1 * r[1];
+          j0 = sqrt_rho1 * (j0 - asn * r[0] * rtj);
+          j1 = sqrt_rho1 * (j1 - asn * r[1] * rtj);
+        }
+        v.pm_Jp[(size_t)(2 * a) * N + e] = j0 * sp[a];
+        v.pm_Jp[(size_t)(2 * a + 1) * N + e] = j1 * sp[a];
+      }
+      v.pm_r[e] = r[0] * rscale;
+      v.pm_r[N + e] = r[1] * rscale;
+    }
+  }
+  block_sum_store<2>(acc, v.partial, nblocks);
+}
+
+// cost only, at a given parameter set (kernel class 9): hot loop 1, residual-only.
+template <int DP>
+__global__ __launch_bounds__(256) void cost_kernel(DeviceView v, const double* __restrict__ ext,
+                                                   const double* __restrict__ intr,
+                                                   const double* __restrict__ pts, int loss_type,
+                                                   double loss_width, int flag_slot, int nblocks,
+                                                   double* partial) {
+  const int lane = threadIdx.x & 63;
+  const int s = blockIdx.x * kSlicesPerBlock + (threadIdx.x >> 6);
+  double acc[2] = {0.0, 0.0};
+  if (s < v.nslices) {
+    const int lp = s * 64 + lane;
+    const int k = v.pt_k[lp];
+    const int base = v.slice_ptr[s] + lane;
+    const int K = (v.slice_ptr[s + 1] - v.slice_ptr[s]) >> 6;
+    double X[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) X[i] = pts[(size_t)lp * 4 + i];
+    for (int j = 0; j < K; ++j) {
+      if (j >= k) continue;
+      const size_t e = (size_t)base + (size_t)j * 64;
+      const int cam = v.obs_cam[e];
+      const int grp = v.cam_grp[cam];
+      const double* Kp = intr + v.grp_off[grp];
+      const int nk = v.grp_off[grp + 1] - v.grp_off[grp];
+      double Kv[10], E[6];
+#pragma unroll
+      for (int i = 0; i < 10; ++i) Kv[i] = (i < nk) ? Kp[i] : 0.0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) E[i] = ext[(size_t)cam * 6 + i];
+      double r[2];
+      double (*nul6)[6] = nullptr;
+      double Jint[2][10];
+      double (*nul4)[4] = nullptr;
+      const bool ok = reprojection_error<false>(v.grp_model[grp], E, Kv, X, v.obs_xy[2 * e],
+                                                v.obs_xy[2 * e + 1], r, nul6, Jint, nul4);
+      if (!ok) {
+        v.flags[flag_slot] = 1;
+        continue;
+      }
+      const double sq = r[0] * r[0] + r[1] * r[1];
+      if (loss_type != 0) {
+        double rho[3];
+        loss_eval(loss_type, loss_width, sq, rho);
+        acc[0] += 0.5 * rho[0];
+      } else {
+        acc[0] += 0.5 * sq;
+      }
+      acc[1] += sq;
+    }
+  }
+  block_sum_store<2>(acc, partial, nblocks);
+}
+
+// ------------------------------------------------------------------------------
+// Jacobi scaling (Ceres jacobi_scaling): 1 / (1 + ||column||), computed once
+// from the unscaled Jacobian at the start point.
+// ------------------------------------------------------------------------------
+template <int DP>
+__global__ __launch_bounds__(256) void point_scale_kernel(DeviceView v) {
+  const int lane = threadIdx.x & 63;
+  const int s = blockIdx.x * kSlicesPerBlock + (threadIdx.x >> 6);
+  if (s >= v.nslices) return;
+  const int lp = s * 64 + lane;
+  const int k = v.pt_k[lp];
+  const size_t base = (size_t)v.slice_ptr[s] + lane;
+  const size_t N = (size_t)v.No_pad;
+  double n2[DP];
+#pragma unroll
+  for (int a = 0; a < DP; ++a) n2[a] = 0.0;
+  for (int j = 0; j < k; ++j) {
+    const size_t e = base + (size_t)j * 64;
+#pragma unroll
+    for (int a = 0; a < DP; ++a) {
+      const double j0 = v.pm_Jp[(size_t)(2 * a) * N + e], j1 = v.pm_Jp[(size_t)(2 * a + 1) * N + e];
+      n2[a] += j0 * j0 + j1 * j1;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < DP; ++a) v.scale_p[(size_t)lp * DP + a] = 1.0 / (1.0 + sqrt(n2[a]));
+}
+
+// one wave per reduced block; slot_obs maps a camera-major slot to its
+// track-major element
+template <int D>
+__global__ __launch_bounds__(64) void camera_scale_kernel(DeviceView v, const int* __restrict__ slot_obs) {
+  const int rb = blockIdx.x;
+  const size_t N = (size_t)v.No_pad;
+  double n2[D];
+#pragma unroll
+  for (int a = 0; a < D; ++a) n2[a] = 0.0;
+  for (int s = v.cam_ptr[rb] + threadIdx.x; s < v.cam_ptr[rb + 1]; s += 64) {
+    const size_t e = (size_t)slot_obs[s];
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      const double j0 = v.pm_A[(size_t)(2 * a) * N + e], j1 = v.pm_A[(size_t)(2 * a + 1) * N + e];
+      n2[a] += j0 * j0 + j1 * j1;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    const double t = wave_sum(n2[a]);
+    if (threadIdx.x == 0) v.scale_c[(size_t)rb * D + a] = t;
+  }
+}
+// With several ranks the per-camera sums are all-reduced between the two
+// kernels; scale_c holds the squared norm in between.
+__global__ void camera_scale_finish_kernel(double* scale_c, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) scale_c[i] = 1.0 / (1.0 + sqrt(scale_c[i]));
+}
+
+// ------------------------------------------------------------------------------
+// point_eliminate (kernel class 1): per track V = sum Jp^T Jp, g_p, LM damping,
+// Cholesky of the DP x DP block in registers, t_p = (V+Dp)^-1 g_p; then per
+// observation Y = A^T (Jp L^-T) and the reduced residual r~ = r - Jp t_p, written
+// to the camera-major records.  This is the e-block half of Ceres'
+// SchurEliminator (hot loop 2) restricted to what the camera side needs.
+// partial: [gmax_p] (max) per block.
+// ------------------------------------------------------------------------------
+template <int D, int DP>
+__global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, double inv_radius,
+                                                              double lm_lo, double lm_hi, int nblocks,
+                                                              double* partial_max) {
+  constexpr int NS = sym_size(DP);
+  constexpr int YS = ys_of(D, DP);
+  constexpr int AS = as_of(D);
+  const int lane = threadIdx.x & 63;
+  const int s = blockIdx.x * kSlicesPerBlock + (threadIdx.x >> 6);
+  double gmax = 0.0;
+  if (s < v.nslices) {
+    const int lp = s * 64 + lane;
+    const int k = v.pt_k[lp];
+    const size_t base = (size_t)v.slice_ptr[s] + lane;
+    const size_t N = (size_t)v.No_pad;
+    const size_t NP = (size_t)v.Np_pad;
+    if (k > 0) {
+      double V[NS], g[DP];
+#pragma unroll
+      for (int i = 0; i < NS; ++i) V[i] = 0.0;
+#pragma unroll
+      for (int a = 0; a < DP; ++a) g[a] = 0.0;
+      for (int j = 0; j < k; ++j) {
+        const size_t e = base + (size_t)j * 64;
+        double J0[DP], J1[DP];
+#pragma unroll
+        for (int a = 0; a < DP; ++a) {
+          J0[a] = v.pm_Jp[(size_t)(2 * a) * N + e];
+          J1[a] = v.pm_Jp[(size_t)(2 * a + 1) * N + e];
+        }
+        const double r0 = v.pm_r[e], r1 = v.pm_r[N + e];
+#pragma unroll
+        for (int a = 0; a < DP; ++a) {
+#pragma unroll
+          for (int b = a; b < DP; ++b) V[sym_idx(a, b, DP)] += J0[a] * J0[b] + J1[a] * J1[b];
+          g[a] += J0[a] * r0 + J1[a] * r1;
+        }
+      }
+      // LM damping and Cholesky V + Dp = L L^T (L lower, packed by rows into Lm[a][b], b <= a)
+      double Lm[DP][DP];
+      bool pd = true;
+#pragma unroll
+      for (int a = 0; a < DP; ++a) {
+        const double d = V[sym_idx(a, a, DP)];
+        v.diag_p[(size_t)a * NP + lp] = d;
+        V[sym_idx(a, a, DP)] = d + fmin(fmax(d, lm_lo), lm_hi) * inv_radius;
+        v.gp[(size_t)a * NP + lp] = g[a];
+        gmax = fmax(gmax, fabs(g[a] / v.scale_p[(size_t)lp * DP + a]));
+      }
+#pragma unroll
+      for (int j = 0; j < DP; ++j) {
+        double d = V[sym_idx(j, j, DP)];
+#pragma unroll
+        for (int m = 0; m < j; ++m) d -= Lm[j][m] * Lm[j][m];
+        if (!(d > 0.0)) {
+          pd = false;
+          d = 1.0;
+        }
+        const double l = sqrt(d);
+        Lm[j][j] = l;
+        const double il = 1.0 / l;
+#pragma unroll
+        for (int i = j + 1; i < DP; ++i) {
+          double t = V[sym_idx(j, i, DP)];
+#pragma unroll
+          for (int m = 0; m < j; ++m) t -= Lm[i][m] * Lm[j][m];
+          Lm[i][j] = t * il;
+        }
+      }
+      if (!pd) v.flags[FL_SINGULAR_POINT] = 1;
+      // Li = L^-1 (lower)
+      double Li[DP][DP];
+#pragma unroll
+      for (int j = 0; j < DP; ++j) {
+        Li[j][j] = 1.0 / Lm[j][j];
+#pragma unroll
+        for (int i = j + 1; i < DP; ++i) {
+          double t = 0.0;
+#pragma unroll
+          for (int m = j; m < i; ++m) t -= Lm[i][m] * Li[m][j];
+          Li[i][j] = t / Lm[i][i];
+        }
+      }
+      // Vinv = Li^T Li (symmetric), t_p = Vinv g
+      double Vi[NS], tp[DP];
+#pragma unroll
+      for (int a = 0; a < DP; ++a)
+#pragma unroll
+        for (int b = a; b < DP; ++b) {
+          double t = 0.0;
+#pragma unroll
+          for (int m = b; m < DP; ++m) t += Li[m][a] * Li[m][b];
+          Vi[sym_idx(a, b, DP)] = t;
+          v.Vinv[(size_t)sym_idx(a, b, DP) * NP + lp] = t;
+        }
+#pragma unroll
+      for (int a = 0; a < DP; ++a) {
+        double t = 0.0;
+#pragma unroll
+        for (int b = 0; b < DP; ++b) t += Vi[a <= b ? sym_idx(a, b, DP) : sym_idx(b, a, DP)] * g[b];
+        tp[a] = t;
+      }
+      for (int j = 0; j < k; ++j) {
+        const size_t e = base + (size_t)j * 64;
+        const int cpos = v.obs_cpos[e];
+        if (cpos < 0) continue;
+        double J0[DP], J1[DP], Q0[DP], Q1[DP];
+#pragma unroll
+        for (int a = 0; a < DP; ++a) {
+          J0[a] = v.pm_Jp[(size_t)(2 * a) * N + e];
+          J1[a] = v.pm_Jp[(size_t)(2 * a + 1) * N + e];
+        }
+        const double r0 = v.pm_r[e], r1 = v.pm_r[N + e];
+        double rt0 = r0, rt1 = r1;
+#pragma unroll
+        for (int a = 0; a < DP; ++a) {
+          rt0 -= J0[a] * tp[a];
+          rt1 -= J1[a] * tp[a];
+        }
+        // Q_row = Li * Jp_row^T
+#pragma unroll
+        for (int b = 0; b < DP; ++b) {
+          double q0 = 0.0, q1 = 0.0;
+#pragma unroll
+          for (int a = 0; a <= b; ++a) {
+            q0 += Li[b][a] * J0[a];
+            q1 += Li[b][a] * J1[a];
+          }
+          Q0[b] = q0;
+          Q1[b] = q1;
+        }
+        double* yrec = v.cm_Y + (size_t)cpos * YS;
+        double* arec = v.cm_A + (size_t)cpos * AS;
+        double Yv[YS];
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+          const double a0 = v.pm_A[(size_t)(2 * a) * N + e], a1 = v.pm_A[(size_t)(2 * a + 1) * N + e];
+          arec[a] = a0;
+          arec[D + a] = a1;
+#pragma unroll
+          for (int b = 0; b < DP; ++b) Yv[a * DP + b] = a0 * Q0[b] + a1 * Q1[b];
+        }
+        if (YS > D * DP) Yv[YS - 1] = 0.0;
+#pragma unroll
+        for (int i = 0; i < YS; i += 2) *reinterpret_cast<double2*>(yrec + i) = make_double2(Yv[i], Yv[i + 1]);
+        arec[2 * D] = rt0;
+        arec[2 * D + 1] = rt1;
+        arec[2 * D + 2] = r0;
+        arec[2 * D + 3] = r1;
+      }
+    }
+  }
+  // block max of the point gradient
+  __shared__ double shm[kSlicesPerBlock];
+  const double wm = wave_max(gmax);
+  if (lane == 0) shm[threadIdx.x >> 6] = wm;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double m = shm[0];
+    for (int i = 1; i < kSlicesPerBlock; ++i) m = fmax(m, shm[i]);
+    partial_max[blockIdx.x] = m;
+  }
+  (void)nblocks;
+}
+
+// ------------------------------------------------------------------------------
+// camera_diag (kernel class 2): one wavefront per reduced block walks that
+// camera's camera-major records and reduces, in registers + wave shuffles,
+//   S_cc(raw) = sum A^T A - Y Y^T,  U diag = sum diag(A^T A),
+//   g~ = sum A^T r~  (reduced gradient),  g_c = sum A^T r  (camera gradient).
+// ------------------------------------------------------------------------------
+template <int D, int DP>
+__global__ __launch_bounds__(64) void camera_diag_kernel(DeviceView v, RedLayout L) {
+  constexpr int NS = sym_size(D);
+  constexpr int YS = ys_of(D, DP);
+  constexpr int AS = as_of(D);
+  const int rb = blockIdx.x;
+  double Ss[NS], Ud[D], gt[D], gc[D];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) Ss[i] = 0.0;
+#pragma unroll
+  for (int a = 0; a < D; ++a) Ud[a] = gt[a] = gc[a] = 0.0;
+  for (int s = v.cam_ptr[rb] + threadIdx.x; s < v.cam_ptr[rb + 1]; s += 64) {
+    const double* arec = v.cm_A + (size_t)s * AS;
+    const double* yrec = v.cm_Y + (size_t)s * YS;
+    double A0[D], A1[D], Y[YS];
+#pragma unroll
+    for (int i = 0; i < D; i += 1) {
+      A0[i] = arec[i];
+      A1[i] = arec[D + i];
+    }
+    const double rt0 = arec[2 * D], rt1 = arec[2 * D + 1], r0 = arec[2 * D + 2], r1 = arec[2 * D + 3];
+#pragma unroll
+    for (int i = 0; i < YS; i += 2) {
+      const double2 t = *reinterpret_cast<const double2*>(yrec + i);
+      Y[i] = t.x;
+      Y[i + 1] = t.y;
+    }
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+#pragma unroll
+      for (int b = a; b < D; ++b) {
+        double t = A0[a] * A0[b] + A1[a] * A1[b];
+#pragma unroll
+        for (int c = 0; c < DP; ++c) t -= Y[a * DP + c] * Y[b * DP + c];
+        Ss[sym_idx(a, b, D)] += t;
+      }
+      Ud[a] += A0[a] * A0[a] + A1[a] * A1[a];
+      gt[a] += A0[a] * rt0 + A1[a] * rt1;
+      gc[a] += A0[a] * r0 + A1[a] * r1;
+    }
+  }
+  double* diag = v.red + L.diag + (size_t)rb * D * D;
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+#pragma unroll
+    for (int b = a; b < D; ++b) {
+      const double t = wave_sum(Ss[sym_idx(a, b, D)]);
+      if (threadIdx.x == 0) {
+        diag[a * D + b] = t;
+        diag[b * D + a] = t;
+      }
+    }
+    const double u = wave_sum(Ud[a]), g1 = wave_sum(gt[a]), g2 = wave_sum(gc[a]);
+    if (threadIdx.x == 0) {
+      v.red[L.udiag + (size_t)rb * D + a] = u;
+      v.red[L.gt + (size_t)rb * D + a] = g1;
+      v.red[L.gc + (size_t)rb * D + a] = g2;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------
+// schur_offdiag (kernel class 3): S_ij = - sum_{tracks seen by both} Y_i Y_j^T.
+// One wavefront per structurally non-zero upper block; the pair list is a flat
+// K = DP * #pairs contraction fed to v_mfma_f64_16x16x4_f64:
+//   A[i][k] = Y_i[i][k % DP] of pair k / DP,  B[k][j] = Y_j[j][k % DP].
+// Lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15]; the 16 x 16 result
+// has row = (l >> 4) + 4 reg, col = l & 15 (f64 MFMA layout).  No atomics, the
+// summation order is the pair list's (bit-reproducible).
+// ------------------------------------------------------------------------------
+template <int D, int DP>
+__global__ __launch_bounds__(256) void schur_offdiag_kernel(DeviceView v, RedLayout L) {
+  constexpr int YS = ys_of(D, DP);
+  const int lane = threadIdx.x & 63;
+  const long long ui = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ui >= v.nub) return;
+  const int u = v.ub_order[ui];
+  const long long p0 = v.pair_ptr[u];
+  const int Ktot = (int)(v.pair_ptr[u + 1] - p0) * DP;
+  const int i = lane & 15, kk = lane >> 4;
+  v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+  const bool row_ok = i < D;
+  for (int k0 = 0; k0 < Ktot; k0 += 8) {
+    // two MFMA steps per trip: more loads in flight per wave
+    double a[2], b[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = k0 + 4 * h + kk;
+      a[h] = 0.0;
+      b[h] = 0.0;
+      if (row_ok && k < Ktot) {
+        const int pr = k / DP;
+        const int c = k - pr * DP;
+        const int si = v.pair_i[p0 + pr], sj = v.pair_j[p0 + pr];
+        a[h] = v.cm_Y[(size_t)si * YS + i * DP + c];
+        b[h] = v.cm_Y[(size_t)sj * YS + i * DP + c];
+      }
+    }
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], acc, 0, 0, 0);
+  }
+  double* out = v.red + L.ub + (size_t)u * D * D;
+  const int col = lane & 15;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = (lane >> 4) + 4 * r;
+    if (row < D && col < D) out[row * D + col] = -acc[r];
+  }
+}
+
+// ------------------------------------------------------------------------------
+// expand_S (part of class 3's epilogue, timed as TMI_BA_K_REDUCE): scatter the
+// (all-reduced) upper blocks into both triangles of the BSR matrix and add the
+// LM diagonal clamp(U_aa) / radius to the diagonal blocks; padding rows get 1.
+// ------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void expand_offdiag_kernel(DeviceView v, RedLayout L) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long long)v.nub * D * D) return;
+  const long long u = e / (D * D);
+  const int w = (int)(e - u * (D * D));
+  const int a = w / D, b = w - a * D;
+  const double val = v.red[L.ub + e];
+  v.S[(size_t)v.ub_pos[u] * D * D + a * D + b] = val;
+  v.S[(size_t)v.ub_pos_t[u] * D * D + b * D + a] = val;
+}
+template <int D>
+__global__ __launch_bounds__(256) void expand_diag_kernel(DeviceView v, RedLayout L, double inv_radius,
+                                                          double lm_lo, double lm_hi) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= v.Nrb * D * D) return;
+  const int rb = e / (D * D);
+  const int w = e - rb * (D * D);
+  const int a = w / D, b = w - a * D;
+  double val = v.red[L.diag + e];
+  if (a == b) {
+    if (v.rb_cols[(size_t)rb * D + a] < 0) {
+      val = 1.0;
+    } else {
+      const double d = v.red[L.udiag + (size_t)rb * D + a];
+      val += fmin(fmax(d, lm_lo), lm_hi) * inv_radius;
+    }
+  }
+  v.S[(size_t)v.diag_pos[rb] * D * D + a * D + b] = val;
+}
+
+// ------------------------------------------------------------------------------
+// precond_invert (kernel class 4): SCHUR_JACOBI = inverse of the diagonal
+// blocks of S, one wavefront per block, matrix staged in LDS.
+// ------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(64) void precond_invert_kernel(DeviceView v, int identity) {
+  __shared__ double M[D * D];
+  __shared__ int bad;
+  const int rb = blockIdx.x;
+  const int t = threadIdx.x;
+  const double* src = v.S + (size_t)v.diag_pos[rb] * D * D;
+  for (int e = t; e < D * D; e += 64) M[e] = src[e];
+  if (t == 0) bad = 0;
+  __syncthreads();
+  double* out = v.Minv + (size_t)rb * D * D;
+  if (identity) {
+    for (int e = t; e < D * D; e += 64) out[e] = (e / D == e % D) ? 1.0 : 0.0;
+    return;
+  }
+  for (int j = 0; j < D; ++j) {
+    if (t == 0) {
+      const double d = M[j * D + j];
+      if (!(d > 0.0)) {
+        bad = 1;
+        M[j * D + j] = 1.0;
+      } else {
+        M[j * D + j] = sqrt(d);
+      }
+    }
+    __syncthreads();
+    if (t > j && t < D) M[t * D + j] /= M[j * D + j];
+    __syncthreads();
+    // trailing update: (i, m), j < m <= i
+    for (int e = t; e < D * D; e += 64) {
+      const int i = e / D, m = e - i * D;
+      if (m > j && m <= i) M[e] -= M[i * D + j] * M[m * D + j];
+    }
+    __syncthreads();
+  }
+  if (t < D) {
+    // column t of (L L^T)^-1
+    double y[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      double s = (i == t) ? 1.0 : 0.0;
+      for (int m = 0; m < i; ++m) s -= M[i * D + m] * y[m];
+      y[i] = s / M[i * D + i];
+    }
+#pragma unroll
+    for (int i = D - 1; i >= 0; --i) {
+      double s = y[i];
+      for (int m = i + 1; m < D; ++m) s -= M[m * D + i] * y[m];
+      y[i] = s / M[i * D + i];
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) out[i * D + t] = y[i];
+  }
+  if (t == 0 && bad) v.flags[FL_SINGULAR_BLOCK] = 1;
+}
+
+// ------------------------------------------------------------------------------
+// spmv (kernel class 5): q = S p on the BSR matrix, the PCG hot kernel (hot
+// loop 3).  One 256-thread workgroup per block row; lane = g * D + r owns row r
+// of every (4 G)-th block so the wave streams G contiguous D x D blocks per trip
+// (all fetched bytes used); partial rows are combined through LDS in a fixed
+// order.  Purely HBM-bound: 8 D^2 bytes per block per product.
+// ------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void spmv_kernel(DeviceView v, const double* __restrict__ x,
+                                                   double* __restrict__ y) {
+  constexpr int G = 64 / D;
+  __shared__ double part[4][G][D];
+  const int row = blockIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int g = lane / D, r = lane - g * D;
+  double acc = 0.0;
+  if (g < G) {
+    const int b0 = v.row_ptr[row], b1 = v.row_ptr[row + 1];
+    for (int b = b0 + w * G + g; b < b1; b += 4 * G) {
+      const double* blk = v.S + (size_t)b * D * D + r * D;
+      const double* xv = x + (size_t)v.col_idx[b] * D;
+      double t = 0.0;
+#pragma unroll
+      for (int c = 0; c < D; ++c) t += blk[c] * xv[c];
+      acc += t;
+    }
+    part[w][g][r] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x < D) {
+    double s = 0.0;
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww)
+#pragma unroll
+      for (int gg = 0; gg < G; ++gg) s += part[ww][gg][threadIdx.x];
+    y[(size_t)row * D + threadIdx.x] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------
+// PCG vector kernels (class 6), single 1024-thread workgroup each so that dot
+// products, the scalar recurrences and the vector updates of one half-step
+// share a launch and need no host round trip.  Restates
+// ceres/conjugate_gradients_solver.cc (1.14).
+// ------------------------------------------------------------------------------
+__device__ __forceinline__ double block1024_sum(double v, double* sh) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const double s = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) sh[w] = s;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) t += sh[i];
+  return t;
+}
+
+// x = 0, r = b, Q0 = 0, rho = 1
+__global__ __launch_bounds__(1024) void pcg_begin_kernel(DeviceView v, const double* __restrict__ b, int n) {
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    v.yc[i] = 0.0;
+    v.cg_r[i] = b[i];
+  }
+  if (threadIdx.x == 0) {
+    v.scal[SC_RHO] = 1.0;
+    v.scal[SC_Q0] = 0.0;
+    v.flags[FL_PCG_FAIL] = 0;
+  }
+}
+
+// z = M^-1 r; rho = r.z; p = z (+ beta p)
+template <int D>
+__global__ __launch_bounds__(1024) void pcg_a_kernel(DeviceView v, int n, int it) {
+  __shared__ double sh[16];
+  double local = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const int rb = i / D, a = i - rb * D;
+    const double* M = v.Minv + (size_t)rb * D * D + a * D;
+    const double* rr = v.cg_r + (size_t)rb * D;
+    double z = 0.0;
+#pragma unroll
+    for (int c = 0; c < D; ++c) z += M[c] * rr[c];
+    v.cg_z[i] = z;
+    local += z * v.cg_r[i];
+  }
+  const double rho = block1024_sum(local, sh);
+  const double last_rho = v.scal[SC_RHO];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    v.scal[SC_LAST_RHO] = last_rho;
+    v.scal[SC_RHO] = rho;
+    if (rho == 0.0 || !isfinite(rho)) v.flags[FL_PCG_FAIL] = 1;
+  }
+  const double beta = rho / last_rho;
+  if (it > 1 && (beta == 0.0 || !isfinite(beta)) && threadIdx.x == 0) v.flags[FL_PCG_FAIL] = 1;
+  for (int i = threadIdx.x; i < n; i += 1024)
+    v.cg_p[i] = (it == 1) ? v.cg_z[i] : v.cg_z[i] + beta * v.cg_p[i];
+}
+
+// pq = p.q; alpha = rho / pq; x += alpha p; r -= alpha q (unless reset);
+// Q1 = -x.(b + r); zeta = it (Q1 - Q0) / Q1
+// stage 0: everything; stage 1 (residual reset): update x only, stop before r;
+// stage 2: r = b - t (t = S x), then Q1, zeta.
+__global__ __launch_bounds__(1024) void pcg_b_kernel(DeviceView v, const double* __restrict__ b, int n,
+                                                     int it, int stage) {
+  __shared__ double sh[16];
+  double alpha = 0.0;
+  if (stage != 2) {
+    double local = 0.0;
+    for (int i = threadIdx.x; i < n; i += 1024) local += v.cg_p[i] * v.cg_q[i];
+    const double pq = block1024_sum(local, sh);
+    if (pq <= 0.0 || !isfinite(pq)) {
+      // LINEAR_SOLVER_NO_CONVERGENCE: keep x, report zeta = -1 (stop)
+      if (threadIdx.x == 0) {
+        v.scal[SC_PQ] = pq;
+        v.scal[SC_ZETA] = -1.0;
+      }
+      return;
+    }
+    alpha = v.scal[SC_RHO] / pq;
+    if (threadIdx.x == 0) {
+      v.scal[SC_PQ] = pq;
+      v.scal[SC_ALPHA] = alpha;
+      if (!isfinite(alpha)) v.flags[FL_PCG_FAIL] = 1;
+    }
+    for (int i = threadIdx.x; i < n; i += 1024) {
+      v.yc[i] += alpha * v.cg_p[i];
+      if (stage == 0) v.cg_r[i] -= alpha * v.cg_q[i];
+    }
+    if (stage == 1) return;
+  } else {
+    for (int i = threadIdx.x; i < n; i += 1024) v.cg_r[i] = b[i] - v.cg_t[i];
+  }
+  double local = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) local -= v.yc[i] * (b[i] + v.cg_r[i]);
+  const double Q1 = block1024_sum(local, sh);
+  if (threadIdx.x == 0) {
+    const double Q0 = v.scal[SC_Q0];
+    v.scal[SC_Q1] = Q1;
+    v.scal[SC_ZETA] = it * (Q1 - Q0) / Q1;
+    v.scal[SC_Q0] = Q1;
+  }
+}
+
+// ------------------------------------------------------------------------------
+// back_substitute (kernel class 8): y_p = (V+Dp)^-1 (g_p - W^T y_c) per track and
+// the model cost change -(J d).(r + J d / 2), d = -y (TrustRegionMinimizer).
+// ------------------------------------------------------------------------------
+template <int D, int DP>
+__global__ __launch_bounds__(256) void back_substitute_kernel(DeviceView v, double* __restrict__ pm_u,
+                                                              int nblocks, double* partial) {
+  constexpr int NS = sym_size(DP);
+  const int lane = threadIdx.x & 63;
+  const int s = blockIdx.x * kSlicesPerBlock + (threadIdx.x >> 6);
+  double acc[1] = {0.0};
+  if (s < v.nslices) {
+    const int lp = s * 64 + lane;
+    const int k = v.pt_k[lp];
+    const size_t base = (size_t)v.slice_ptr[s] + lane;
+    const size_t N = (size_t)v.No_pad;
+    const size_t NP = (size_t)v.Np_pad;
+    if (k > 0) {
+      double w[DP];
+#pragma unroll
+      for (int a = 0; a < DP; ++a) w[a] = v.gp[(size_t)a * NP + lp];
+      for (int j = 0; j < k; ++j) {
+        const size_t e = base + (size_t)j * 64;
+        const int rb = v.cam_rb[v.obs_cam[e]];
+        double u0 = 0.0, u1 = 0.0;
+        if (rb >= 0) {
+          const double* yc = v.yc + (size_t)rb * D;
+#pragma unroll
+          for (int a = 0; a < D; ++a) {
+            const double ya = yc[a];
+            u0 += v.pm_A[(size_t)(2 * a) * N + e] * ya;
+            u1 += v.pm_A[(size_t)(2 * a + 1) * N + e] * ya;
+          }
+        }
+        pm_u[e] = u0;
+        pm_u[N + e] = u1;
+#pragma unroll
+        for (int a = 0; a < DP; ++a)
+          w[a] -= v.pm_Jp[(size_t)(2 * a) * N + e] * u0 + v.pm_Jp[(size_t)(2 * a + 1) * N + e] * u1;
+      }
+      double Vi[NS], yp[DP];
+#pragma unroll
+      for (int i = 0; i < NS; ++i) Vi[i] = v.Vinv[(size_t)i * NP + lp];
+#pragma unroll
+      for (int a = 0; a < DP; ++a) {
+        double t = 0.0;
+#pragma unroll
+        for (int b = 0; b < DP; ++b) t += Vi[a <= b ? sym_idx(a, b, DP) : sym_idx(b, a, DP)] * w[b];
+        yp[a] = t;
+        v.yp[(size_t)a * NP + lp] = t;
+      }
+      for (int j = 0; j < k; ++j) {
+        const size_t e = base + (size_t)j * 64;
+        double m0 = pm_u[e], m1 = pm_u[N + e];
+#pragma unroll
+        for (int a = 0; a < DP; ++a) {
+          m0 += v.pm_Jp[(size_t)(2 * a) * N + e] * yp[a];
+          m1 += v.pm_Jp[(size_t)(2 * a + 1) * N + e] * yp[a];
+        }
+        m0 = -m0;
+        m1 = -m1;
+        acc[0] -= m0 * (v.pm_r[e] + 0.5 * m0) + m1 * (v.pm_r[N + e] + 0.5 * m1);
+      }
+    }
+  }
+  block_sum_store<1>(acc, partial, nblocks);
+}
+
+// ------------------------------------------------------------------------------
+// update (kernel class 9): candidate = x - scale .* y on the free coordinates.
+// Points: one thread per track, partial sums [step^2, |x+|^2] for the tracks.
+// Cameras: single workgroup (the camera part is replicated on every rank).
+// ------------------------------------------------------------------------------
+template <int DP>
+__global__ __launch_bounds__(256) void update_points_kernel(DeviceView v, int nblocks, double* partial) {
+  const int lp = blockIdx.x * 256 + threadIdx.x;
+  double acc[2] = {0.0, 0.0};
+  if (lp < v.Np_pad) {
+    const size_t NP = (size_t)v.Np_pad;
+    const bool live = v.pt_k[lp] > 0 && !v.pt_const[lp];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      double x = v.pts[(size_t)lp * 4 + a];
+      if (live && a < DP) {
+        const double d = -v.yp[(size_t)a * NP + lp] * v.scale_p[(size_t)lp * DP + a];
+        x += d;
+        acc[0] += d * d;
+      }
+      v.pts_c[(size_t)lp * 4 + a] = x;
+      if (live) acc[1] += x * x;
+    }
+  }
+  block_sum_store<2>(acc, partial, nblocks);
+}
+
+// |x|^2 over the live tracks of a parameter set
+__global__ __launch_bounds__(256) void points_norm_kernel(DeviceView v, const double* __restrict__ pts,
+                                                          int nblocks, double* partial) {
+  const int lp = blockIdx.x * 256 + threadIdx.x;
+  double acc[1] = {0.0};
+  if (lp < v.Np_pad && v.pt_k[lp] > 0 && !v.pt_const[lp]) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) acc[0] += pts[(size_t)lp * 4 + a] * pts[(size_t)lp * 4 + a];
+  }
+  block_sum_store<1>(acc, partial, nblocks);
+}
+
+// ext_c / intr_c already hold copies of ext / intr.  out[0] = step^2 (cameras),
+// out[1] = |x+|^2 over every coordinate of every non-constant camera block.
+template <int D>
+__global__ __launch_bounds__(1024) void update_cameras_kernel(DeviceView v, double* out) {
+  __shared__ double sh[16];
+  double step = 0.0;
+  const int n = v.Nrb * D;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const int code = v.rb_cols[i];
+    if (code < 0) continue;
+    const int rb = i / D;
+    const int cam = v.rb_cam[rb];
+    const double d = -v.yc[i] * v.scale_c[i];
+    if (code < 6)
+      v.ext_c[(size_t)cam * 6 + code] += d;
+    else
+      v.intr_c[v.grp_off[v.cam_grp[cam]] + code - 6] += d;
+    step += d * d;
+  }
+  const double s2 = block1024_sum(step, sh);
+  __threadfence_block();
+  __syncthreads();
+  double xn = 0.0;
+  for (int rb = threadIdx.x; rb < v.Nrb; rb += 1024) {
+    const int cam = v.rb_cam[rb];
+    const unsigned m = v.cam_mask[cam];
+    if (m & 0x3f)
+      for (int a = 0; a < 6; ++a) xn += v.ext_c[(size_t)cam * 6 + a] * v.ext_c[(size_t)cam * 6 + a];
+    if (m >> 6) {
+      const int g = v.cam_grp[cam];
+      for (int a = v.grp_off[g]; a < v.grp_off[g + 1]; ++a) xn += v.intr_c[a] * v.intr_c[a];
+    }
+  }
+  const double x2 = block1024_sum(xn, sh);
+  if (threadIdx.x == 0) {
+    out[0] = s2;
+    out[1] = x2;
+  }
+}
+
+// max_i |g_c[i] / scale_c[i]| over the free camera columns (single workgroup)
+template <int D>
+__global__ __launch_bounds__(1024) void camera_gmax_kernel(DeviceView v, const double* __restrict__ gc,
+                                                           double* out) {
+  __shared__ double sh[16];
+  double m = 0.0;
+  const int n = v.Nrb * D;
+  for (int i = threadIdx.x; i < n; i += 1024)
+    if (v.rb_cols[i] >= 0) m = fmax(m, fabs(gc[i] / v.scale_c[i]));
+  const double wm = wave_max(m);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = wm;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = sh[0];
+    for (int i = 1; i < 16; ++i) t = fmax(t, sh[i]);
+    out[0] = t;
+  }
+}
+
+}  // namespace tmi

@@ -1,0 +1,394 @@
+// Host-side structure builder (see structure.h).  Plain C++17, no device code.
+//
+// Residual-set semantics come from the flattened problem the host shim
+// produces (bundle_adjuster.cc:102-180); block constancy follows
+// SetCameraExtrinsicsParameterization / SetCameraIntrinsicsParameterization
+// (bundle_adjuster.cc:223-287): constant coordinates simply have no column.
+#include "structure.h"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+namespace tmi {
+namespace {
+
+int model_size(int m) {
+  static const int n[5] = {7, 10, 9, 5, 5};
+  return (m >= 0 && m < 5) ? n[m] : -1;
+}
+
+struct KeyMap {  // open addressing: uint64 key -> int value
+  std::vector<uint64_t> keys;
+  std::vector<int> vals;
+  uint64_t mask = 0;
+  int64_t n = 0;
+  static uint64_t mix(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return x;
+  }
+  void init(uint64_t cap) {
+    uint64_t c = 1024;
+    while (c < cap) c <<= 1;
+    keys.assign(c, ~0ULL);
+    vals.assign(c, -1);
+    mask = c - 1;
+    n = 0;
+  }
+  void grow() {
+    std::vector<uint64_t> ok;
+    std::vector<int> ov;
+    ok.swap(keys);
+    ov.swap(vals);
+    init((mask + 1) * 2);
+    for (size_t i = 0; i < ok.size(); ++i)
+      if (ok[i] != ~0ULL) put(ok[i], ov[i]);
+  }
+  // returns true if inserted
+  bool put(uint64_t k, int v) {
+    if (2 * (uint64_t)(n + 1) > mask + 1) grow();
+    uint64_t i = mix(k) & mask;
+    while (keys[i] != ~0ULL) {
+      if (keys[i] == k) return false;
+      i = (i + 1) & mask;
+    }
+    keys[i] = k;
+    vals[i] = v;
+    ++n;
+    return true;
+  }
+  int* find(uint64_t k) {
+    uint64_t i = mix(k) & mask;
+    while (keys[i] != ~0ULL) {
+      if (keys[i] == k) return &vals[i];
+      i = (i + 1) & mask;
+    }
+    return nullptr;
+  }
+};
+
+int pad_dim(int d) {
+  if (d <= 6) return 6;
+  if (d <= 9) return 9;
+  if (d <= 12) return 12;
+  return 16;
+}
+
+}  // namespace
+
+int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S) {
+  Structure& s = *S;
+  if (!P || world < 1 || rank < 0 || rank >= world) {
+    s.error = "null problem or bad rank/world";
+    return TMI_BA_ERR_INVALID_ARGUMENT;
+  }
+  if (P->num_cameras < 0 || P->num_groups < 0 || P->num_points < 0 || P->num_observations < 0 ||
+      (P->num_cameras && (!P->extrinsics || !P->camera_group)) ||
+      (P->num_groups && (!P->group_model || !P->group_offset || !P->intrinsics)) ||
+      (P->num_points && !P->points) ||
+      (P->num_observations && (!P->obs_camera || !P->obs_point || !P->obs_xy))) {
+    s.error = "null array or negative size in tmi_ba_problem";
+    return TMI_BA_ERR_INVALID_ARGUMENT;
+  }
+  s.rank = rank;
+  s.world = world;
+  s.Nc = P->num_cameras;
+  s.G = P->num_groups;
+  s.Np_total = P->num_points;
+  const int64_t No_all = P->num_observations;
+  for (int c = 0; c < s.Nc; ++c)
+    if (P->camera_group[c] < 0 || P->camera_group[c] >= s.G) {
+      s.error = "camera_group out of range";
+      return TMI_BA_ERR_INVALID_ARGUMENT;
+    }
+  for (int g = 0; g < s.G; ++g) {
+    const int n = model_size(P->group_model[g]);
+    if (n < 0 || P->group_offset[g + 1] - P->group_offset[g] != n) {
+      s.error = "bad camera model or group_offset";
+      return TMI_BA_ERR_INVALID_ARGUMENT;
+    }
+  }
+  for (int64_t i = 0; i < No_all; ++i)
+    if (P->obs_camera[i] < 0 || P->obs_camera[i] >= s.Nc || P->obs_point[i] < 0 ||
+        P->obs_point[i] >= s.Np_total) {
+      s.error = "observation index out of range";
+      return TMI_BA_ERR_INVALID_ARGUMENT;
+    }
+
+  // ---- reduced camera blocks --------------------------------------------------
+  std::vector<int> grp_count(s.G, 0);
+  for (int c = 0; c < s.Nc; ++c) grp_count[P->camera_group[c]]++;
+  std::vector<uint32_t> grp_free(s.G, 0);
+  for (int g = 0; g < s.G; ++g) {
+    const int o = P->group_offset[g], n = P->group_offset[g + 1] - o;
+    for (int a = 0; a < n; ++a)
+      if (!P->intrinsics_constant || !P->intrinsics_constant[o + a]) grp_free[g] |= 1u << a;
+    if (grp_free[g] && grp_count[g] > 1) {
+      s.error =
+          "free intrinsics shared by several cameras are not supported by the device path yet "
+          "(give each view its own group or hold the shared intrinsics constant)";
+      return TMI_BA_ERR_UNSUPPORTED;
+    }
+  }
+  s.cam_mask.assign(s.Nc, 0);
+  s.cam_rb.assign(s.Nc, -1);
+  int maxdim = 0;
+  for (int c = 0; c < s.Nc; ++c) {
+    const int f = P->camera_flags ? P->camera_flags[c] : 0;
+    uint32_t m = 0;
+    if (!(f & TMI_BA_CAMERA_POSITION_CONSTANT)) m |= 0x07;
+    if (!(f & TMI_BA_CAMERA_ORIENTATION_CONSTANT)) m |= 0x38;
+    m |= grp_free[P->camera_group[c]] << 6;
+    s.cam_mask[c] = m;
+    const int d = __builtin_popcount(m);
+    if (d > 0) {
+      s.cam_rb[c] = s.Nrb++;
+      s.rb_cam.push_back(c);
+      s.rb_dim.push_back(d);
+      maxdim = std::max(maxdim, d);
+    }
+  }
+  s.D = pad_dim(std::max(maxdim, 1));
+  s.rb_cols.assign((size_t)s.Nrb * s.D, -1);
+  for (int rb = 0; rb < s.Nrb; ++rb) {
+    int col = 0;
+    const uint32_t m = s.cam_mask[s.rb_cam[rb]];
+    for (int b = 0; b < 16; ++b)
+      if (m & (1u << b)) s.rb_cols[(size_t)rb * s.D + col++] = (int8_t)b;
+  }
+
+  // ---- tracks: lengths, order by descending length, shard ------------------------
+  std::vector<int> klen(s.Np_total, 0);
+  for (int64_t i = 0; i < No_all; ++i) klen[P->obs_point[i]]++;
+  int kmax = 0;
+  for (int p = 0; p < s.Np_total; ++p) kmax = std::max(kmax, klen[p]);
+  // CSR of observations by track (caller order preserved inside a track)
+  std::vector<int64_t> tptr(s.Np_total + 1, 0);
+  for (int p = 0; p < s.Np_total; ++p) tptr[p + 1] = tptr[p] + klen[p];
+  std::vector<int64_t> tobs(No_all);
+  {
+    std::vector<int64_t> fill(tptr.begin(), tptr.end() - 1);
+    for (int64_t i = 0; i < No_all; ++i) tobs[fill[P->obs_point[i]]++] = i;
+  }
+  // inside a track: ascending camera index (deterministic, and what the pair
+  // enumeration below assumes); reject a view observing a track twice
+  for (int p = 0; p < s.Np_total; ++p) {
+    auto b = tobs.begin() + tptr[p], e = tobs.begin() + tptr[p + 1];
+    std::sort(b, e, [&](int64_t x, int64_t y) {
+      return P->obs_camera[x] != P->obs_camera[y] ? P->obs_camera[x] < P->obs_camera[y] : x < y;
+    });
+    for (auto it = b; it != e && it + 1 != e; ++it)
+      if (P->obs_camera[*it] == P->obs_camera[*(it + 1)]) {
+        s.error = "a track is observed twice by the same view";
+        return TMI_BA_ERR_INVALID_ARGUMENT;
+      }
+  }
+  // counting sort by descending length; tracks without observations take no part
+  std::vector<int> order;
+  order.reserve(s.Np_total);
+  {
+    // bucket b = kmax - k  (b = 0 holds the longest tracks)
+    std::vector<int> pos(kmax + 2, 0);
+    int total = 0;
+    for (int p = 0; p < s.Np_total; ++p)
+      if (klen[p] > 0) {
+        pos[kmax - klen[p] + 1]++;
+        ++total;
+      }
+    for (int b = 0; b <= kmax; ++b) pos[b + 1] += pos[b];
+    order.assign(total, 0);
+    for (int p = 0; p < s.Np_total; ++p)
+      if (klen[p] > 0) order[pos[kmax - klen[p]]++] = p;
+  }
+  const int n_active = (int)order.size();
+  const int gslices = (n_active + 63) / 64;
+  // global slice gs belongs to rank gs % world
+  std::vector<int> local_pts;
+  for (int gs = rank; gs < gslices; gs += world)
+    for (int t = 0; t < 64; ++t) {
+      const int idx = gs * 64 + t;
+      local_pts.push_back(idx < n_active ? order[idx] : -1);
+    }
+  s.nslices = (int)local_pts.size() / 64;
+  s.Np_pad = s.nslices * 64;
+  s.Np = 0;
+  s.pt_orig.assign(s.Np_pad, -1);
+  s.pt_k.assign(s.Np_pad, 0);
+  s.pt_const.assign(s.Np_pad, 0);
+  s.slice_ptr.assign(s.nslices + 1, 0);
+  for (int sl = 0; sl < s.nslices; ++sl) {
+    int K = 0;
+    for (int t = 0; t < 64; ++t) {
+      const int p = local_pts[sl * 64 + t];
+      if (p >= 0) {
+        s.pt_orig[sl * 64 + t] = p;
+        s.pt_k[sl * 64 + t] = klen[p];
+        s.pt_const[sl * 64 + t] = (P->point_constant && P->point_constant[p]) ? 1 : 0;
+        K = std::max(K, klen[p]);
+        s.Np++;
+      }
+    }
+    const int64_t next = (int64_t)s.slice_ptr[sl] + (int64_t)K * 64;
+    if (next > 0x7fffffff) {
+      s.error = "too many observations on one rank for 32-bit slot indices";
+      return TMI_BA_ERR_UNSUPPORTED;
+    }
+    s.slice_ptr[sl + 1] = (int)next;
+  }
+  s.No_pad = s.slice_ptr[s.nslices];
+  s.obs_cam.assign(s.No_pad, -1);
+  s.obs_xy.assign(2 * (size_t)s.No_pad, 0.0);
+  s.obs_cpos.assign(s.No_pad, -1);
+  s.obs_orig.assign(s.No_pad, -1);
+  s.No = 0;
+  // camera-major slot counts
+  std::vector<int> slot_cnt(s.Nrb + 1, 0);
+  for (int lp = 0; lp < s.Np_pad; ++lp) {
+    const int p = s.pt_orig[lp];
+    if (p < 0) continue;
+    const int sl = lp >> 6, t = lp & 63;
+    for (int j = 0; j < klen[p]; ++j) {
+      const int64_t i = tobs[tptr[p] + j];
+      const int64_t e = (int64_t)s.slice_ptr[sl] + (int64_t)j * 64 + t;
+      s.obs_cam[e] = P->obs_camera[i];
+      s.obs_xy[2 * e] = P->obs_xy[2 * i];
+      s.obs_xy[2 * e + 1] = P->obs_xy[2 * i + 1];
+      s.obs_orig[e] = i;
+      const int rb = s.cam_rb[P->obs_camera[i]];
+      if (rb >= 0) slot_cnt[rb + 1]++;
+      s.No++;
+    }
+  }
+  s.cam_ptr.assign(s.Nrb + 1, 0);
+  for (int rb = 0; rb < s.Nrb; ++rb) s.cam_ptr[rb + 1] = s.cam_ptr[rb] + slot_cnt[rb + 1];
+  s.Nslots = s.cam_ptr[s.Nrb];
+  {
+    std::vector<int> fill(s.cam_ptr.begin(), s.cam_ptr.end() - 1);
+    for (int lp = 0; lp < s.Np_pad; ++lp) {
+      const int p = s.pt_orig[lp];
+      if (p < 0) continue;
+      const int sl = lp >> 6, t = lp & 63;
+      for (int j = 0; j < klen[p]; ++j) {
+        const int64_t e = (int64_t)s.slice_ptr[sl] + (int64_t)j * 64 + t;
+        const int rb = s.cam_rb[s.obs_cam[e]];
+        if (rb >= 0) s.obs_cpos[e] = fill[rb]++;
+      }
+    }
+  }
+
+  // ---- block structure of S from ALL tracks (rank independent) -------------------
+  KeyMap blocks;
+  blocks.init(1 << 16);
+  std::vector<int> rbs;
+  for (int p = 0; p < s.Np_total; ++p) {
+    if (klen[p] < 2) continue;
+    if (P->point_constant && P->point_constant[p]) continue;  // no elimination, no coupling
+    rbs.clear();
+    for (int j = 0; j < klen[p]; ++j) {
+      const int rb = s.cam_rb[P->obs_camera[tobs[tptr[p] + j]]];
+      if (rb >= 0) rbs.push_back(rb);
+    }
+    for (size_t a = 0; a < rbs.size(); ++a)
+      for (size_t b = a + 1; b < rbs.size(); ++b)
+        blocks.put(((uint64_t)rbs[a] << 32) | (uint32_t)rbs[b], 0);
+  }
+  std::vector<uint64_t> ukeys;
+  ukeys.reserve(blocks.n);
+  for (size_t i = 0; i < blocks.keys.size(); ++i)
+    if (blocks.keys[i] != ~0ULL) ukeys.push_back(blocks.keys[i]);
+  std::sort(ukeys.begin(), ukeys.end());
+  s.nub = (int64_t)ukeys.size();
+  if (s.nub * 2 + s.Nrb > 0x7fffffff) {
+    s.error = "reduced camera matrix has too many blocks for 32-bit block indices";
+    return TMI_BA_ERR_UNSUPPORTED;
+  }
+  s.ub_i.resize(s.nub);
+  s.ub_j.resize(s.nub);
+  for (int64_t u = 0; u < s.nub; ++u) {
+    s.ub_i[u] = (int)(ukeys[u] >> 32);
+    s.ub_j[u] = (int)(ukeys[u] & 0xffffffffu);
+    *blocks.find(ukeys[u]) = (int)u;
+  }
+  // BSR (both triangles + diagonal), columns ascending inside a row
+  s.nnzb = 2 * s.nub + s.Nrb;
+  s.row_ptr.assign(s.Nrb + 1, 0);
+  for (int i = 0; i < s.Nrb; ++i) s.row_ptr[i + 1] = 1;
+  for (int64_t u = 0; u < s.nub; ++u) {
+    s.row_ptr[s.ub_i[u] + 1]++;
+    s.row_ptr[s.ub_j[u] + 1]++;
+  }
+  for (int i = 0; i < s.Nrb; ++i) s.row_ptr[i + 1] += s.row_ptr[i];
+  s.col_idx.assign(s.nnzb, 0);
+  s.diag_pos.assign(s.Nrb, 0);
+  s.ub_pos.assign(s.nub, 0);
+  s.ub_pos_t.assign(s.nub, 0);
+  {
+    // row i = [lower blocks (j < i) ascending j | diagonal | upper blocks ascending j].
+    // The sorted upper list visits, for a fixed bj, the bi in ascending order,
+    // and for a fixed bi the bj in ascending order, so two fill cursors suffice.
+    std::vector<int> nlow(s.Nrb, 0);
+    for (int64_t u = 0; u < s.nub; ++u) nlow[s.ub_j[u]]++;
+    std::vector<int> low_fill(s.Nrb), up_fill(s.Nrb);
+    for (int i = 0; i < s.Nrb; ++i) {
+      low_fill[i] = s.row_ptr[i];
+      s.diag_pos[i] = s.row_ptr[i] + nlow[i];
+      s.col_idx[s.diag_pos[i]] = i;
+      up_fill[i] = s.diag_pos[i] + 1;
+    }
+    for (int64_t u = 0; u < s.nub; ++u) {
+      const int bi = s.ub_i[u], bj = s.ub_j[u];
+      s.ub_pos[u] = up_fill[bi];
+      s.col_idx[up_fill[bi]++] = bj;
+      s.ub_pos_t[u] = low_fill[bj];
+      s.col_idx[low_fill[bj]++] = bi;
+    }
+  }
+
+  // ---- pair lists from this rank's tracks ----------------------------------------
+  s.pair_ptr.assign(s.nub + 1, 0);
+  std::vector<int> slots;
+  auto for_each_pair = [&](auto&& fn) {
+    for (int lp = 0; lp < s.Np_pad; ++lp) {
+      const int p = s.pt_orig[lp];
+      if (p < 0 || klen[p] < 2 || s.pt_const[lp]) continue;
+      const int sl = lp >> 6, t = lp & 63;
+      rbs.clear();
+      slots.clear();
+      for (int j = 0; j < klen[p]; ++j) {
+        const int64_t e = (int64_t)s.slice_ptr[sl] + (int64_t)j * 64 + t;
+        const int rb = s.cam_rb[s.obs_cam[e]];
+        if (rb >= 0) {
+          rbs.push_back(rb);
+          slots.push_back(s.obs_cpos[e]);
+        }
+      }
+      for (size_t a = 0; a < rbs.size(); ++a)
+        for (size_t b = a + 1; b < rbs.size(); ++b) {
+          const int u = *blocks.find(((uint64_t)rbs[a] << 32) | (uint32_t)rbs[b]);
+          fn(u, slots[a], slots[b]);
+        }
+    }
+  };
+  for_each_pair([&](int u, int, int) { s.pair_ptr[u + 1]++; });
+  for (int64_t u = 0; u < s.nub; ++u) s.pair_ptr[u + 1] += s.pair_ptr[u];
+  s.npairs = s.pair_ptr[s.nub];
+  s.pair_i.assign(s.npairs, 0);
+  s.pair_j.assign(s.npairs, 0);
+  {
+    std::vector<int64_t> fill(s.pair_ptr.begin(), s.pair_ptr.end() - 1);
+    for_each_pair([&](int u, int si, int sj) {
+      s.pair_i[fill[u]] = si;
+      s.pair_j[fill[u]] = sj;
+      fill[u]++;
+    });
+  }
+  s.ub_order.resize(s.nub);
+  std::iota(s.ub_order.begin(), s.ub_order.end(), 0);
+  std::stable_sort(s.ub_order.begin(), s.ub_order.end(), [&](int a, int b) {
+    return (s.pair_ptr[a + 1] - s.pair_ptr[a]) > (s.pair_ptr[b + 1] - s.pair_ptr[b]);
+  });
+  return TMI_BA_OK;
+}
+
+}  // namespace tmi

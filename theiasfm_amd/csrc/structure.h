@@ -1,0 +1,82 @@
+// Host-side static structure of one bundle-adjustment problem: everything that
+// does not change over the Levenberg-Marquardt iterations.  Built once per
+// tmi_ba_solver_create (counted in setup time, like Ceres' preprocessor in
+// bundle_adjuster.cc:210-211) and uploaded to HBM.
+//
+//   * reduced camera blocks ("rblocks"): the free extrinsics columns of a
+//     camera merged with the free intrinsics columns of its (private)
+//     intrinsics group, zero padded to a uniform dimension D;
+//   * track-major order: tracks sorted by length and packed in slices of 64
+//     (one wavefront) so that "thread t handles track 64 s + t, observation j"
+//     reads element  slice_ptr[s] + 64 j + t  -- perfectly coalesced;
+//   * camera-major order: a slot per observation grouped by rblock, the order
+//     the per-camera reductions and the Schur pair gathers read;
+//   * the block structure of the reduced camera matrix S (BSR, both
+//     triangles) and, per structurally non-zero upper block (bi < bj), the
+//     list of observation pairs (slot_i, slot_j) whose tracks are seen by both
+//     cameras -- S_ij = - sum_pairs Y_i Y_j^T is then a gather, with no atomics
+//     and a fixed summation order (bit-reproducible).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/theia_mi355_ba.h"
+
+namespace tmi {
+
+struct Structure {
+  int D = 0;        // uniform (padded) reduced block dimension
+  int Nc = 0, G = 0;
+  int Np_total = 0;  // tracks in the whole problem
+  int Np = 0;        // tracks owned by this rank
+  int nslices = 0;   // ceil(Np / 64)
+  int Np_pad = 0;    // 64 * nslices
+  int64_t No = 0;    // observations owned by this rank
+  int64_t No_pad = 0;
+  int Nrb = 0;
+  int rank = 0, world = 1;
+
+  // rblocks
+  std::vector<int> cam_rb;        // [Nc] rblock of a camera or -1
+  std::vector<int> rb_cam;        // [Nrb]
+  std::vector<int> rb_dim;        // [Nrb] true (unpadded) dimension
+  std::vector<int8_t> rb_cols;    // [Nrb*D] 0..5 extrinsics idx, 6+j intrinsics idx, -1 padding
+  std::vector<uint32_t> cam_mask; // [Nc] bit c set = column c of [ext(6) | intr(10)] is free
+
+  // track-major (SELL-64) layout
+  std::vector<int> pt_orig;       // [Np_pad] caller's track index or -1
+  std::vector<int> pt_k;          // [Np_pad] track length (0 = padding)
+  std::vector<int> slice_ptr;     // [nslices+1]
+  std::vector<int> obs_cam;       // [No_pad] camera or -1 (padding)
+  std::vector<double> obs_xy;     // [2*No_pad]
+  std::vector<int> obs_cpos;      // [No_pad] camera-major slot or -1
+  std::vector<int64_t> obs_orig;  // [No_pad] caller's observation index or -1
+  std::vector<uint8_t> pt_const;  // [Np_pad]
+
+  // camera-major layout
+  int64_t Nslots = 0;
+  std::vector<int> cam_ptr;       // [Nrb+1] slot ranges per rblock
+
+  // reduced camera matrix structure (identical on every rank)
+  int64_t nub = 0;                // upper off-diagonal blocks (bi < bj)
+  std::vector<int> ub_i, ub_j;    // [nub] sorted by (bi, bj)
+  int64_t nnzb = 0;               // BSR blocks, both triangles + diagonal
+  std::vector<int> row_ptr;       // [Nrb+1]
+  std::vector<int> col_idx;       // [nnzb]
+  std::vector<int> diag_pos;      // [Nrb] BSR position of (i, i)
+  std::vector<int> ub_pos;        // [nub] BSR position of (bi, bj)
+  std::vector<int> ub_pos_t;      // [nub] BSR position of (bj, bi)
+  // pair lists (this rank's tracks only)
+  int64_t npairs = 0;
+  std::vector<int64_t> pair_ptr;  // [nub+1]
+  std::vector<int> pair_i, pair_j;  // [npairs] camera-major slots
+  std::vector<int> ub_order;      // [nub] upper blocks by descending pair count
+
+  std::string error;
+};
+
+// Returns TMI_BA_OK or an error status (message in out->error).
+int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* out);
+
+}  // namespace tmi

@@ -1,0 +1,170 @@
+"""Loader + thin ctypes wrapper of the C-ABI library (include/theia_mi355_ba.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` into
+``theiasfm_amd/lib/libtheia_mi355_ba.so``.  There is no CPU fallback: if the
+library is missing, or no HIP device is visible when a solve is requested, the
+calls fail loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtheia_mi355_ba.so")
+_lib = None
+
+# every symbol include/theia_mi355_ba.h declares
+EXPORTS = (
+    "tmi_ba_version", "tmi_ba_device_count", "tmi_ba_status_string", "tmi_ba_options_init",
+    "tmi_ba_intrinsics_size", "tmi_ba_intrinsics_constant_mask", "tmi_ba_solve",
+    "tmi_ba_solver_create", "tmi_ba_solver_set_allreduce", "tmi_ba_solver_solve",
+    "tmi_ba_solver_reset", "tmi_ba_solver_download", "tmi_ba_solver_stream",
+    "tmi_ba_solver_destroy", "tmi_ba_solver_evaluate",
+)
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LibraryMissing(
+            f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(the HIP engine has no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    P, O, S = C.POINTER(abi.CProblem), C.POINTER(abi.COptions), C.POINTER(abi.CSummary)
+    L.tmi_ba_version.restype = C.c_int32
+    L.tmi_ba_device_count.restype = C.c_int32
+    L.tmi_ba_status_string.restype = C.c_char_p
+    L.tmi_ba_status_string.argtypes = [C.c_int32]
+    L.tmi_ba_options_init.argtypes = [O]
+    L.tmi_ba_options_init.restype = None
+    L.tmi_ba_intrinsics_size.argtypes = [C.c_int32]
+    L.tmi_ba_intrinsics_size.restype = C.c_int32
+    L.tmi_ba_intrinsics_constant_mask.argtypes = [C.c_int32, C.c_int32, C.c_void_p]
+    L.tmi_ba_intrinsics_constant_mask.restype = C.c_int32
+    L.tmi_ba_solve.argtypes = [P, O, S]
+    L.tmi_ba_solve.restype = C.c_int32
+    L.tmi_ba_solver_create.argtypes = [P, O, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    L.tmi_ba_solver_create.restype = C.c_int32
+    L.tmi_ba_solver_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
+    L.tmi_ba_solver_set_allreduce.restype = C.c_int32
+    L.tmi_ba_solver_solve.argtypes = [C.c_void_p, O, S]
+    L.tmi_ba_solver_solve.restype = C.c_int32
+    L.tmi_ba_solver_reset.argtypes = [C.c_void_p]
+    L.tmi_ba_solver_reset.restype = C.c_int32
+    L.tmi_ba_solver_download.argtypes = [C.c_void_p, P]
+    L.tmi_ba_solver_download.restype = C.c_int32
+    L.tmi_ba_solver_stream.argtypes = [C.c_void_p]
+    L.tmi_ba_solver_stream.restype = C.c_void_p
+    L.tmi_ba_solver_destroy.argtypes = [C.c_void_p]
+    L.tmi_ba_solver_destroy.restype = None
+    L.tmi_ba_solver_evaluate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.POINTER(C.c_int32)]
+    L.tmi_ba_solver_evaluate.restype = C.c_int32
+    _lib = L
+    return L
+
+
+class EngineError(RuntimeError):
+    def __init__(self, status, where, message=""):
+        self.status = status
+        name = abi.STATUS_NAMES.get(status, str(status))
+        super().__init__(f"{where}: status {status} ({name}) {message}")
+
+
+def solve(problem: abi.Problem, options: abi.COptions):
+    """One-shot tmi_ba_solve: upload, LM on the GPU, download into `problem`."""
+    L = load()
+    cp = problem.as_c()
+    s = abi.CSummary()
+    st = L.tmi_ba_solve(C.byref(cp), C.byref(options), C.byref(s))
+    return st, s
+
+
+class Solver:
+    """Resident form: the problem stays in HBM across solve() calls."""
+
+    def __init__(self, problem: abi.Problem, options: abi.COptions, rank: int = 0, world: int = 1):
+        self._L = load()
+        self.problem = problem
+        self._cp = problem.as_c()
+        self._h = C.c_void_p()
+        self._cb = None
+        st = self._L.tmi_ba_solver_create(C.byref(self._cp), C.byref(options), rank, world,
+                                          C.byref(self._h))
+        if st != 0:
+            self._h = C.c_void_p()
+            raise EngineError(st, "tmi_ba_solver_create")
+
+    def set_allreduce(self, fn):
+        """fn(device_ptr:int, count:int, hip_stream:int) -> 0 on success."""
+        def tramp(buf, count, stream, user):
+            try:
+                return int(fn(buf, count, stream))
+            except Exception as exc:  # never let an exception cross the C boundary
+                print(f"[theiasfm_amd] all-reduce hook raised: {exc!r}", flush=True)
+                return 1
+        self._cb = ALLREDUCE_FN(tramp)
+        st = self._L.tmi_ba_solver_set_allreduce(self._h, self._cb, None)
+        if st != 0:
+            raise EngineError(st, "tmi_ba_solver_set_allreduce")
+
+    def solve(self, options: abi.COptions):
+        s = abi.CSummary()
+        st = self._L.tmi_ba_solver_solve(self._h, C.byref(options), C.byref(s))
+        return st, s
+
+    def reset(self):
+        st = self._L.tmi_ba_solver_reset(self._h)
+        if st != 0:
+            raise EngineError(st, "tmi_ba_solver_reset")
+
+    def download(self):
+        st = self._L.tmi_ba_solver_download(self._h, C.byref(self._cp))
+        if st != 0:
+            raise EngineError(st, "tmi_ba_solver_download")
+        return self.problem
+
+    @property
+    def stream(self) -> int:
+        return int(self._L.tmi_ba_solver_stream(self._h) or 0)
+
+    def evaluate(self, point_dof: int):
+        """Device residuals [N,2], reduced camera Jacobians [N,2,D], point
+        Jacobians [N,2,point_dof], valid [N] in the caller's observation order."""
+        n = self.problem.num_observations
+        bd = C.c_int32(0)
+        # D is not known before the call: allocate for the largest block (16)
+        r = np.zeros((n, 2))
+        A = np.zeros(n * 2 * 16)
+        Jp = np.zeros((n, 2, point_dof))
+        valid = np.zeros(n, dtype=np.uint8)
+        st = self._L.tmi_ba_solver_evaluate(self._h, r.ctypes.data, A.ctypes.data, Jp.ctypes.data,
+                                            valid.ctypes.data, C.byref(bd))
+        if st != 0:
+            raise EngineError(st, "tmi_ba_solver_evaluate")
+        D = bd.value
+        return r, A[: n * 2 * D].reshape(n, 2, D), Jp, valid, D
+
+    def close(self):
+        if self._h:
+            self._L.tmi_ba_solver_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
