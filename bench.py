@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X bundle-adjustment engine (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W [--workload venice1778]
+
+A "step" is one Levenberg-Marquardt iteration (linearize, eliminate tracks,
+build + solve the reduced camera system, back-substitute, trial cost) of the
+synthetic BAL-Venice-1778-sized problem (1778 cameras / 993 923 tracks /
+5 001 946 observations, fp64, 9-dof cameras, 3-dof points, ITERATIVE_SCHUR as
+the reference's own policy picks for >= 1000 views,
+reconstruction_estimator_utils.cc:121-125).  The timed region is ONE
+tmi_ba_solver_solve call running exactly K iterations (tolerances zeroed) on
+inputs already resident in HBM; W warm-up iterations run first and the
+parameters are reset.  value = N_obs * K / wall time = observations/s over all
+ranks (strong scaling: the problem is fixed, tracks are sharded over ranks).
+
+For N > 1 launch with
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(cls: str, n_obs: int, n_cam: int, n_pts: int, dc: int, dp: int, nnzb: int):
+    """Algorithmic HBM bytes of ONE launch of a kernel class, SURVEY 8(d):
+    observations stream 24 B (u, v, 2 x int32), parameters 8 B per scalar,
+    normal-equation blocks once, 8 d_c^2 B per structurally non-zero upper block
+    of the reduced camera matrix.  Intermediates (Jacobians, W, Y) are not
+    algorithmic."""
+    sym = lambda d: d * (d + 1) // 2  # noqa: E731
+    if cls == "linearize":
+        return n_obs * 24 + n_cam * 8 * dc + n_pts * 8 * dp
+    if cls == "point_eliminate":
+        return n_pts * 8 * (sym(dp) + dp)
+    if cls == "camera_diag":
+        return n_cam * 8 * (sym(dc) + dc)
+    if cls == "schur_offdiag":
+        return 2 * nnzb * 8 * dc * dc
+    if cls == "spmv":
+        return nnzb * 8 * dc * dc + 2 * n_cam * 8 * dc
+    if cls == "pcg_vector":
+        return 4 * n_cam * 8 * dc
+    if cls == "back_substitute":
+        return n_obs * 24 + n_cam * 8 * dc + n_pts * 8 * (sym(dp) + 2 * dp)
+    if cls == "update_cost":
+        return n_obs * 24 + n_cam * 8 * dc + n_pts * 8 * dp
+    return 0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="venice1778",
+                    choices=["tiny", "ladybug49", "alamo", "venice1778"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=2)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    from theiasfm_amd import abi, dist, lib, synth
+    import __graft_entry__ as entry
+
+    rank, world, local = dist.init_from_env()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with "
+                  "python -m torch.distributed.run --nproc-per-node N", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    if rank == 0:
+        entry.build_engine()
+    if world > 1:
+        torch.distributed.barrier()
+
+    t0 = time.perf_counter()
+    prob = synth.config(args.workload)
+    t_gen = time.perf_counter() - t0
+    n_obs, n_cam, n_pts = prob.num_observations, prob.num_cameras, prob.num_points
+    # the reference's solver-type policy (reconstruction_estimator_utils.cc:110-133)
+    if n_cam >= 1000:
+        solver_type, solver_name = abi.ITERATIVE_SCHUR, "ITERATIVE_SCHUR/SCHUR_JACOBI"
+    elif n_cam >= 150:
+        solver_type, solver_name = abi.SPARSE_SCHUR, "SPARSE_SCHUR (exact, dense Cholesky of S)"
+    else:
+        solver_type, solver_name = abi.DENSE_SCHUR, "DENSE_SCHUR (exact)"
+    base = dict(point_dof=3, linear_solver_type=solver_type, function_tolerance=0.0,
+                gradient_tolerance=0.0, parameter_tolerance=0.0, device=local)
+    opts = abi.default_options(max_num_iterations=max(args.warmup, 1), **base)
+    t0 = time.perf_counter()
+    solver = lib.Solver(prob, opts, rank, world)
+    if world > 1:
+        solver.set_allreduce(dist.make_device_allreduce())
+    t_create = time.perf_counter() - t0
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        st, s = solver.solve(opts)
+        if st != 0:
+            raise RuntimeError(f"warm-up solve failed: {st} {s.message!r}")
+        solver.reset()
+
+    opts_t = abi.default_options(max_num_iterations=args.steps, profile_kernels=1, **base)
+    sync_all()
+    t0 = time.perf_counter()
+    st, s = solver.solve(opts_t)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        torch.distributed.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if st != 0:
+        raise RuntimeError(f"timed solve failed: {st} {s.message!r}")
+    steps_run = int(s.num_iterations)
+    d = s.as_dict()
+
+    if rank != 0:
+        solver.close()
+        return
+
+    dc, dp = int(s.reduced_block_dim), 3
+    nnzb = int(s.num_schur_blocks)
+    kernels = []
+    for name, launches, sec in zip(abi.KERNEL_CLASS_NAMES, d["kernel_launches"], d["kernel_seconds"]):
+        if launches == 0:
+            continue
+        # per-rank launch: this rank's share of the observations / tracks
+        ab = algorithmic_bytes(name, n_obs // world, n_cam, n_pts // world, dc, dp, nnzb)
+        avg = sec / launches
+        kernels.append(dict(kernel=name, launches=int(launches), total_ms=round(sec * 1e3, 4),
+                            avg_us=round(avg * 1e6, 2), algorithmic_bytes_per_launch=int(ab),
+                            achieved_GBs=round(ab / avg / 1e9, 2) if avg > 0 else None))
+    dom = max((k for k in kernels if k["kernel"] != "allreduce"), key=lambda k: k["total_ms"])
+    roofline = dict(bound="hbm", kernel=dom["kernel"], achieved=dom["achieved_GBs"], peak=HBM_PEAK_GBS,
+                    unit="GB/s", frac=round(dom["achieved_GBs"] / HBM_PEAK_GBS, 5), traffic=None,
+                    launches=dom["launches"], avg_us=dom["avg_us"],
+                    algorithmic_bytes_per_launch=dom["algorithmic_bytes_per_launch"])
+
+    out = dict(
+        metric="ba_observations_per_sec", value=n_obs * steps_run / elapsed, unit="observations/s",
+        n_gpus=world, steps=steps_run, warmup=args.warmup, ms_per_step=1e3 * elapsed / max(steps_run, 1),
+        higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f64", data="synthetic",
+        config=dict(workload=f"{args.workload}-synthetic", cameras=n_cam, tracks=n_pts,
+                    observations=n_obs, camera_dof=dc, point_dof=dp, linear_solver=solver_name,
+                    loss="TRIVIAL", parallelism=f"tracks sharded x{world}, 1 all-reduce of the reduced camera system per LM iteration"),
+        lm_iterations_per_sec=steps_run / elapsed,
+        pcg_iterations=int(s.num_linear_solver_iterations),
+        initial_cost=s.initial_cost, final_cost=s.final_cost, initial_rmse=s.initial_rmse,
+        final_rmse=s.final_rmse, accepted_steps=int(s.num_successful_steps),
+        schur_blocks_upper=nnzb, schur_pairs=int(s.num_schur_pairs),
+        setup_seconds=dict(generate=round(t_gen, 3), create_upload=round(t_create, 3)),
+        roofline=roofline, kernels=kernels)
+    if steps_run != args.steps:
+        out["note"] = f"solver stopped after {steps_run} of {args.steps} iterations: {d['message']}"
+
+    if world == 1 and not args.no_cpu_baseline:
+        # CPU baseline: the in-repo oracle (Ceres-semantics restatement; the real
+        # Theia + Ceres cannot be built offline) on the SAME problem and options
+        # for a bounded number of LM iterations, all host cores via OpenMP.
+        from oracle import oracle
+        iters = max(1, args.cpu_iters)
+        cpu_opts = abi.default_options(max_num_iterations=iters, **{**base, "device": -1})
+        ref = prob.copy()
+        tc = time.perf_counter()
+        st_o, s_o = oracle.solve(ref, cpu_opts)
+        t_cpu = time.perf_counter() - tc
+        # the device on the same bounded sample, for a full-size parity figure
+        solver.reset()
+        dev_opts = abi.default_options(max_num_iterations=iters, **base)
+        st_d, s_d = solver.solve(dev_opts)
+        out["cpu_baseline"] = dict(
+            value=n_obs * int(s_o.num_iterations) / s_o.solve_time_in_seconds, unit="observations/s",
+            cores=oracle.num_threads(), kind="port",
+            sample=f"{int(s_o.num_iterations)} LM iterations of the full {args.workload} problem, same options "
+                   f"(solve {s_o.solve_time_in_seconds:.2f} s + setup {s_o.setup_time_in_seconds:.2f} s, wall {t_cpu:.2f} s)",
+            final_cost=s_o.final_cost, final_rmse=s_o.final_rmse)
+        out["parity_sample"] = dict(
+            iterations=int(s_o.num_iterations), device_cost=s_d.final_cost, oracle_cost=s_o.final_cost,
+            rel_cost_diff=abs(s_d.final_cost - s_o.final_cost) / s_o.final_cost,
+            rmse_abs_diff=abs(s_d.final_rmse - s_o.final_rmse))
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    solver.close()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

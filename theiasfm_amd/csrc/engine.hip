@@ -956,10 +956,11 @@ int32_t tmi_ba_solver_evaluate(tmi_ba_solver* s, double* residuals, double* jac_
   // poison the residual planes so that invalid observations can be told apart
   s->launch.linearize(v, stream, 0, 1.0, s->nblocks_slices);
   const size_t N = (size_t)st.No_pad;
-  std::vector<double> r(2 * N), A((size_t)2 * D * N), Jp((size_t)2 * DP * N);
-  TMI_HIP(hipMemcpyAsync(r.data(), v.pm_r, r.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
-  TMI_HIP(hipMemcpyAsync(A.data(), v.pm_A, A.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
-  TMI_HIP(hipMemcpyAsync(Jp.data(), v.pm_Jp, Jp.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+  std::vector<double> r(residuals ? 2 * N : 0), A(jac_camera ? (size_t)2 * D * N : 0),
+      Jp(jac_point ? (size_t)2 * DP * N : 0);
+  if (residuals) TMI_HIP(hipMemcpyAsync(r.data(), v.pm_r, r.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+  if (jac_camera) TMI_HIP(hipMemcpyAsync(A.data(), v.pm_A, A.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+  if (jac_point) TMI_HIP(hipMemcpyAsync(Jp.data(), v.pm_Jp, Jp.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
   TMI_HIP(hipStreamSynchronize(stream));
   for (size_t e = 0; e < N; ++e) {
     const int64_t i = st.obs_orig[e];

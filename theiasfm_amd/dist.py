@@ -1,0 +1,89 @@
+"""torch.distributed plumbing for the multi-GPU path (one process per GPU).
+
+Tracks are sharded over the ranks inside the C library (slice s of the
+length-sorted track order belongs to rank s % world).  The only data-path
+exchange is the sum of the reduced camera system built from each rank's
+tracks -- once per LM iteration -- plus a few scalars; the engine calls the
+hook below on its own HIP stream with a device pointer, and the hook runs an
+RCCL all-reduce (backend "nccl" is RCCL on ROCm) over xGMI, stream-ordered
+with the engine's kernels.  With backend "gloo" (CPU tests) the buffer is a
+host pointer and the reduction goes through a CPU tensor.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+
+class _DevArray:
+    """Minimal __cuda_array_interface__ carrier so torch can alias a raw device pointer."""
+
+    def __init__(self, ptr: int, count: int):
+        self.__cuda_array_interface__ = {
+            "shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False), "version": 2,
+            "strides": None,
+        }
+
+
+def init_from_env(backend: str | None = None):
+    """Initialise torch.distributed from the torchrun environment.  Returns
+    (rank, world, local_rank).  World size 1 needs no process group."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            if backend is None:
+                backend = "nccl" if torch.cuda.is_available() else "gloo"
+            if backend == "nccl":
+                torch.cuda.set_device(local)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def make_device_allreduce():
+    """Hook for lib.Solver.set_allreduce on GPU: RCCL sum over the default group,
+    enqueued on the engine's stream (no host synchronisation)."""
+    import torch
+    import torch.distributed as dist
+
+    streams = {}
+
+    def hook(ptr: int, count: int, stream: int) -> int:
+        if count <= 0:
+            return 0
+        t = torch.as_tensor(_DevArray(ptr, count), device="cuda")
+        ext = streams.get(stream)
+        if ext is None:
+            ext = torch.cuda.ExternalStream(stream)
+            streams[stream] = ext
+        with torch.cuda.stream(ext):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return 0
+
+    return hook
+
+
+def make_host_allreduce():
+    """Same contract for a host buffer (gloo, used by the CPU tests of the
+    sharding logic): sums `count` doubles at address `ptr` in place."""
+    import torch
+    import torch.distributed as dist
+
+    def hook(ptr: int, count: int, stream: int) -> int:
+        if count <= 0:
+            return 0
+        buf = (C.c_double * count).from_address(ptr)
+        a = np.frombuffer(buf, dtype=np.float64)
+        t = torch.from_numpy(a.copy())
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        a[:] = t.numpy()
+        return 0
+
+    return hook
