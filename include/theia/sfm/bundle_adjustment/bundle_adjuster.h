@@ -1,0 +1,95 @@
+// Source-compatible mirror of
+//   /root/reference/src/theia/sfm/bundle_adjustment/bundle_adjuster.h:60-132.
+// Same public API and the same AddView / AddTrack residual-set semantics
+// (bundle_adjuster.cc:102-180); Optimize() flattens the recorded problem into
+// tmi_ba_problem and calls tmi_ba_solve() where the reference calls ceres::Solve
+// (bundle_adjuster.cc:205), then writes the parameters back in place.
+//
+// NOTE (reference contract, bundle_adjuster.h:58-59): AddView must be called
+// before AddTrack for any view that is to be optimised.
+#ifndef THEIA_MI355_BUNDLE_ADJUSTER_H_
+#define THEIA_MI355_BUNDLE_ADJUSTER_H_
+#include <chrono>
+#include <cstdint>
+#include <memory>
+#include <unordered_map>
+#include <unordered_set>
+#include <utility>
+#include <vector>
+
+#include "theia/sfm/bundle_adjustment/bundle_adjustment.h"
+#include "theia/sfm/feature.h"
+#include "theia/sfm/types.h"
+#include "theia_mi355_ba.h"
+
+namespace theia {
+class Camera;
+class CameraIntrinsicsModel;
+class Reconstruction;
+class Track;
+
+// The flattened problem Optimize() hands to the C ABI (exposed for tests and
+// for callers that want to keep a problem resident with tmi_ba_solver_*).
+struct FlattenedBundleAdjustmentProblem {
+  std::vector<ViewId> view_ids;                   // camera index -> ViewId (ascending)
+  std::vector<TrackId> track_ids;                 // point index -> TrackId (ascending)
+  std::vector<CameraIntrinsicsGroupId> group_ids; // group index -> group id (ascending)
+  std::vector<double> extrinsics, intrinsics, points, obs_xy;
+  std::vector<int32_t> camera_group, group_model, group_offset, obs_camera, obs_point;
+  std::vector<uint8_t> camera_flags, intrinsics_constant, point_constant;
+  tmi_ba_problem AsC();
+};
+
+class BundleAdjuster {
+ public:
+  BundleAdjuster(const BundleAdjustmentOptions& options, Reconstruction* reconstruction);
+  virtual ~BundleAdjuster() {}
+
+  // A residual is created for each estimated track that the view observes.
+  void AddView(const ViewId view_id);
+  // A residual is created for each estimated view (not already optimised) that
+  // observes the track; those views are held constant.
+  void AddTrack(const TrackId track_id);
+  // Optimise the provided views and tracks.
+  BundleAdjustmentSummary Optimize();
+
+  // Extension: the flattened problem (what Optimize() sends to the device).
+  bool Flatten(FlattenedBundleAdjustmentProblem* flat);
+  // Extension: the full device summary of the last Optimize().
+  const tmi_ba_summary& DeviceSummary() const { return device_summary_; }
+
+ protected:
+  void SetCameraExtrinsicsParameterization();
+  void SetCameraIntrinsicsParameterization();
+  std::shared_ptr<CameraIntrinsicsModel> GetIntrinsicsForCameraIntrinsicsGroup(
+      const CameraIntrinsicsGroupId camera_intrinsics_group);
+
+  virtual void SetCameraExtrinsicsConstant(const ViewId view_id);
+  virtual void SetCameraPositionConstant(const ViewId view_id);
+  virtual void SetCameraOrientationConstant(const ViewId view_id);
+  virtual void SetTrackConstant(const TrackId track_id);
+  virtual void SetTrackVariable(const TrackId track_id);
+  virtual void SetCameraSchurGroups(const ViewId view_id);
+  virtual void SetTrackSchurGroup(const TrackId track_id);
+  virtual void AddReprojectionErrorResidual(const Feature& feature, const ViewId view_id,
+                                            const TrackId track_id);
+
+  const BundleAdjustmentOptions options_;
+  Reconstruction* reconstruction_;
+  std::chrono::steady_clock::time_point timer_start_;
+
+  std::unordered_set<ViewId> optimized_views_;
+  std::unordered_set<TrackId> optimized_tracks_;
+  std::unordered_set<CameraIntrinsicsGroupId> optimized_camera_intrinsics_groups_;
+  std::unordered_set<CameraIntrinsicsGroupId> potentially_constant_camera_intrinsics_groups_;
+
+  // what the reference keeps inside ceres::Problem
+  struct Residual { ViewId view; TrackId track; double x, y; };
+  std::vector<Residual> residuals_;
+  std::unordered_map<ViewId, uint8_t> camera_flags_;           // TMI_BA_CAMERA_* bits
+  std::unordered_map<TrackId, bool> track_constant_;
+  std::unordered_map<CameraIntrinsicsGroupId, std::vector<uint8_t> > intrinsics_constant_;
+  tmi_ba_summary device_summary_;
+};
+}  // namespace theia
+#endif

@@ -1,0 +1,86 @@
+// Source-compatible mirror of
+//   /root/reference/src/theia/sfm/bundle_adjustment/bundle_adjustment.h:65-155
+// (OptimizeIntrinsicsType, BundleAdjustmentOptions, BundleAdjustmentSummary, the
+// four free functions).  Same names, same defaults, same meaning; the work is
+// done by the MI355X engine behind include/theia_mi355_ba.h instead of Ceres.
+#ifndef THEIA_MI355_BUNDLE_ADJUSTMENT_H_
+#define THEIA_MI355_BUNDLE_ADJUSTMENT_H_
+#include <unordered_set>
+#include "ceres/types.h"
+#include "theia/sfm/bundle_adjustment/create_loss_function.h"
+#include "theia/sfm/types.h"
+
+namespace theia {
+class Reconstruction;
+
+// bundle_adjustment.h:65-76
+enum class OptimizeIntrinsicsType {
+  NONE = 0x00,
+  FOCAL_LENGTH = 0x01,
+  ASPECT_RATIO = 0x02,
+  SKEW = 0x04,
+  PRINCIPAL_POINTS = 0x08,
+  RADIAL_DISTORTION = 0x10,
+  TANGENTIAL_DISTORTION = 0x20,
+  ALL = FOCAL_LENGTH | ASPECT_RATIO | SKEW | PRINCIPAL_POINTS | RADIAL_DISTORTION |
+        TANGENTIAL_DISTORTION,
+};
+inline OptimizeIntrinsicsType operator|(OptimizeIntrinsicsType a, OptimizeIntrinsicsType b) {
+  return static_cast<OptimizeIntrinsicsType>(static_cast<int>(a) | static_cast<int>(b));
+}
+inline OptimizeIntrinsicsType operator&(OptimizeIntrinsicsType a, OptimizeIntrinsicsType b) {
+  return static_cast<OptimizeIntrinsicsType>(static_cast<int>(a) & static_cast<int>(b));
+}
+inline OptimizeIntrinsicsType& operator|=(OptimizeIntrinsicsType& a, OptimizeIntrinsicsType b) {
+  a = a | b;
+  return a;
+}
+
+// bundle_adjustment.h:78-122 (defaults identical)
+struct BundleAdjustmentOptions {
+  LossFunctionType loss_function_type = LossFunctionType::TRIVIAL;
+  double robust_loss_width = 2.0;
+  ceres::LinearSolverType linear_solver_type = ceres::SPARSE_SCHUR;
+  ceres::PreconditionerType preconditioner_type = ceres::SCHUR_JACOBI;
+  ceres::VisibilityClusteringType visibility_clustering_type = ceres::CANONICAL_VIEWS;
+  bool verbose = false;
+  bool constant_camera_orientation = false;
+  bool constant_camera_position = false;
+  OptimizeIntrinsicsType intrinsics_to_optimize =
+      OptimizeIntrinsicsType::FOCAL_LENGTH | OptimizeIntrinsicsType::RADIAL_DISTORTION;
+  int num_threads = 1;
+  int max_num_iterations = 100;
+  double max_solver_time_in_seconds = 3600.0;
+  bool use_inner_iterations = true;  // accepted; the device path runs plain LM
+  double function_tolerance = 1e-6;
+  double gradient_tolerance = 1e-10;
+  double parameter_tolerance = 1e-8;
+  double max_trust_region_radius = 1e12;
+
+  // Extensions of the MI355X path (not in the reference):
+  //   4 = optimise the homogeneous point as the reference does, 3 = hold w fixed.
+  int point_dof = 4;
+  int device = -1;  // HIP device ordinal, -1 = current
+};
+
+// bundle_adjustment.h:125-133
+struct BundleAdjustmentSummary {
+  bool success = false;
+  double initial_cost = 0.0;
+  double final_cost = 0.0;
+  double setup_time_in_seconds = 0.0;
+  double solve_time_in_seconds = 0.0;
+};
+
+// bundle_adjustment.h:136-155
+BundleAdjustmentSummary BundleAdjustReconstruction(const BundleAdjustmentOptions& options,
+                                                   Reconstruction* reconstruction);
+BundleAdjustmentSummary BundleAdjustPartialReconstruction(
+    const BundleAdjustmentOptions& options, const std::unordered_set<ViewId>& views_to_optimize,
+    const std::unordered_set<TrackId>& tracks_to_optimize, Reconstruction* reconstruction);
+BundleAdjustmentSummary BundleAdjustView(const BundleAdjustmentOptions& options, const ViewId view_id,
+                                         Reconstruction* reconstruction);
+BundleAdjustmentSummary BundleAdjustTrack(const BundleAdjustmentOptions& options,
+                                          const TrackId track_id, Reconstruction* reconstruction);
+}  // namespace theia
+#endif

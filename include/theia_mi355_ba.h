@@ -328,6 +328,17 @@ int32_t tmi_ba_solver_evaluate(tmi_ba_solver* s, double* residuals,
                                double* jac_camera, double* jac_point,
                                uint8_t* valid, int32_t* block_dim);
 
+/* Host-only: statistics of the static structure the engine would build for
+ * rank `rank` of `world` (no GPU needed).  Used by the CPU tests of the track
+ * sharding: out[0] tracks owned, out[1] observations owned, out[2] reduced
+ * blocks, out[3] block dimension D, out[4] upper off-diagonal blocks of S,
+ * out[5] BSR blocks, out[6] observation pairs owned, out[7] checksum of the
+ * (rank independent) block list, out[8] slices, out[9] padded observations,
+ * out[10] checksum of the owned caller observation indices, out[11] sum over
+ * owned pairs of a (slot independent) pair key.  Returns a tmi_ba_status. */
+int32_t tmi_ba_structure_stats(const tmi_ba_problem* problem, int32_t rank, int32_t world,
+                               int64_t out[12]);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

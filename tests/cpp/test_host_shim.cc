@@ -1,0 +1,215 @@
+// Self-test of the C++ host shim (theia::BundleAdjuster on the MI355X C ABI).
+//   ./test_host_shim cpu   problem-semantics checks on the flattened problem
+//   ./test_host_shim gpu   end-to-end BundleAdjustReconstruction / partial BA
+// The expectations restate the AddView / AddTrack rules of
+// /root/reference/src/theia/sfm/bundle_adjustment/bundle_adjuster.cc:102-180,242-287.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "theia/sfm/bundle_adjustment/bundle_adjuster.h"
+#include "theia/sfm/bundle_adjustment/bundle_adjustment.h"
+#include "theia/sfm/reconstruction.h"
+
+using namespace theia;
+
+static int g_fail = 0;
+#define EXPECT(cond)                                                        \
+  do {                                                                      \
+    if (!(cond)) {                                                          \
+      std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond);           \
+      ++g_fail;                                                             \
+    }                                                                       \
+  } while (0)
+
+static double urand(unsigned* s) {
+  *s = *s * 1664525u + 1013904223u;
+  return ((*s >> 8) & 0xffffff) / double(0x1000000);
+}
+
+static void Rodrigues(const double* w, const double* a, double* q) {
+  const double t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  const double wxa[3] = {w[1] * a[2] - w[2] * a[1], w[2] * a[0] - w[0] * a[2], w[0] * a[1] - w[1] * a[0]};
+  if (t2 < 1e-30) {
+    for (int i = 0; i < 3; ++i) q[i] = a[i] + wxa[i];
+    return;
+  }
+  const double t = std::sqrt(t2), c = std::cos(t), s = std::sin(t);
+  const double wa = (w[0] * a[0] + w[1] * a[1] + w[2] * a[2]) * (1 - c) / t2;
+  for (int i = 0; i < 3; ++i) q[i] = a[i] * c + wxa[i] * s / t + w[i] * wa;
+}
+
+// views on a ring looking at the origin region, pinhole f=800, all views see all tracks
+static void BuildScene(Reconstruction* rec, int nviews, int ntracks, bool share_groups, unsigned seed,
+                       double perturb) {
+  unsigned s = seed;
+  std::vector<ViewId> vids;
+  for (int i = 0; i < nviews; ++i) {
+    const std::string name = "view" + std::to_string(i);
+    const ViewId id = share_groups ? rec->AddView(name, i / 2) : rec->AddView(name);
+    vids.push_back(id);
+    Camera* cam = rec->MutableView(id)->MutableCamera();
+    cam->SetPosition(Eigen::Vector3d(10 * (urand(&s) - 0.5), 10 * (urand(&s) - 0.5), -30 + 4 * urand(&s)));
+    cam->SetOrientationFromAngleAxis(Eigen::Vector3d(0.2 * (urand(&s) - 0.5), 0.2 * (urand(&s) - 0.5),
+                                                     0.2 * (urand(&s) - 0.5)));
+    cam->SetFocalLength(800.0);
+    cam->SetPrincipalPoint(500.0, 500.0);
+    rec->MutableView(id)->SetEstimated(true);
+  }
+  for (int t = 0; t < ntracks; ++t) {
+    const TrackId tid = rec->AddTrack();
+    Track* tr = rec->MutableTrack(tid);
+    double X[3] = {6 * (urand(&s) - 0.5), 6 * (urand(&s) - 0.5), 6 * (urand(&s) - 0.5)};
+    for (const ViewId v : vids) {
+      const Camera& cam = rec->View(v)->Camera();
+      const double a[3] = {X[0] - cam.extrinsics()[0], X[1] - cam.extrinsics()[1], X[2] - cam.extrinsics()[2]};
+      double q[3];
+      Rodrigues(cam.extrinsics() + 3, a, q);
+      const double u = 800.0 * q[0] / q[2] + 500.0 + 0.5 * (urand(&s) - 0.5);
+      const double w = 800.0 * q[1] / q[2] + 500.0 + 0.5 * (urand(&s) - 0.5);
+      rec->AddObservation(v, tid, Feature(u, w));
+    }
+    for (int i = 0; i < 3; ++i) (*tr->MutablePoint())[i] = X[i] + perturb * (urand(&s) - 0.5);
+    (*tr->MutablePoint())[3] = 1.0;
+    tr->SetEstimated(true);
+  }
+}
+
+static void TestSemantics() {
+  Reconstruction rec;
+  BuildScene(&rec, 5, 8, /*share_groups=*/true, 7, 0.1);  // groups: {0,1} {2,3} {4}
+  rec.MutableView(3)->SetEstimated(false);
+  rec.MutableTrack(7)->SetEstimated(false);
+  BundleAdjustmentOptions opt;
+  {
+    // full BA: residual set = estimated views x estimated tracks
+    BundleAdjuster ba(opt, &rec);
+    for (ViewId v : rec.ViewIds()) ba.AddView(v);
+    for (TrackId t : rec.TrackIds()) ba.AddTrack(t);
+    ba.AddView(0);   // duplicates ignored (bundle_adjuster.cc:106)
+    ba.AddTrack(0);  // (:144)
+    FlattenedBundleAdjustmentProblem f;
+    EXPECT(ba.Flatten(&f));
+    EXPECT(f.view_ids.size() == 4);
+    EXPECT(f.track_ids.size() == 7);
+    EXPECT(f.obs_camera.size() == 4u * 7u);
+    for (uint8_t c : f.camera_flags) EXPECT(c == 0);
+    for (uint8_t c : f.point_constant) EXPECT(c == 0);
+    EXPECT(f.group_ids.size() == 3);
+    // default intrinsics_to_optimize = FOCAL_LENGTH | RADIAL_DISTORTION: pinhole mask 0 1 1 1 1 0 0
+    const uint8_t want[7] = {0, 1, 1, 1, 1, 0, 0};
+    for (size_t g = 0; g < 3; ++g) EXPECT(std::memcmp(&f.intrinsics_constant[7 * g], want, 7) == 0);
+    // views 0 and 1 share one intrinsics block
+    EXPECT(f.camera_group[0] == f.camera_group[1] && f.camera_group[2] != f.camera_group[0]);
+  }
+  {
+    // partial BA: optimise view 0 and track 0 only
+    BundleAdjuster ba(opt, &rec);
+    ba.AddView(0);
+    ba.AddTrack(0);
+    FlattenedBundleAdjustmentProblem f;
+    EXPECT(ba.Flatten(&f));
+    // view 0 sees its 7 estimated tracks; track 0 adds views 1, 2, 4 (3 is unestimated)
+    EXPECT(f.obs_camera.size() == 7u + 3u);
+    EXPECT(f.view_ids.size() == 4);
+    for (size_t c = 0; c < f.view_ids.size(); ++c)
+      EXPECT(f.camera_flags[c] == (f.view_ids[c] == 0 ? 0 : 3));  // others: extrinsics constant (:164)
+    for (size_t p = 0; p < f.track_ids.size(); ++p)
+      EXPECT(f.point_constant[p] == (f.track_ids[p] == 0 ? 0 : 1));  // anchors stay constant (:137)
+    // group of view 0 (shared with constant view 1) stays variable; groups used only by
+    // constant cameras are fully constant (:271-286)
+    for (size_t g = 0; g < f.group_ids.size(); ++g) {
+      int nconst = 0;
+      for (int k = f.group_offset[g]; k < f.group_offset[g + 1]; ++k) nconst += f.intrinsics_constant[k];
+      EXPECT(nconst == (f.group_ids[g] == 0 ? 4 : 7));
+    }
+  }
+  {
+    BundleAdjustmentOptions o2 = opt;
+    o2.constant_camera_position = true;
+    o2.intrinsics_to_optimize = OptimizeIntrinsicsType::NONE;
+    BundleAdjuster ba(o2, &rec);
+    for (ViewId v : rec.ViewIds()) ba.AddView(v);
+    for (TrackId t : rec.TrackIds()) ba.AddTrack(t);
+    FlattenedBundleAdjustmentProblem f;
+    EXPECT(ba.Flatten(&f));
+    for (uint8_t c : f.camera_flags) EXPECT(c == TMI_BA_CAMERA_POSITION_CONSTANT);
+    for (uint8_t c : f.intrinsics_constant) EXPECT(c == 1);
+  }
+  {
+    // nothing to do: unestimated view / track are skipped silently (:106,144)
+    BundleAdjuster ba(opt, &rec);
+    ba.AddView(3);
+    ba.AddTrack(7);
+    FlattenedBundleAdjustmentProblem f;
+    EXPECT(ba.Flatten(&f));
+    EXPECT(f.obs_camera.empty());
+    const BundleAdjustmentSummary s = ba.Optimize();
+    EXPECT(s.success);
+  }
+  // option defaults (bundle_adjustment.h:78-122)
+  EXPECT(opt.max_num_iterations == 100 && opt.use_inner_iterations && opt.robust_loss_width == 2.0);
+  EXPECT(opt.linear_solver_type == ceres::SPARSE_SCHUR && opt.preconditioner_type == ceres::SCHUR_JACOBI);
+}
+
+static double Rmse(const BundleAdjuster& ba) { return ba.DeviceSummary().final_rmse; }
+
+static void TestGpu() {
+  {
+    Reconstruction rec;
+    BuildScene(&rec, 6, 200, /*share_groups=*/false, 11, 0.3);
+    BundleAdjustmentOptions opt;
+    std::vector<double> before;
+    for (TrackId t : rec.TrackIds()) before.push_back(rec.Track(t)->Point()[0]);
+    BundleAdjuster ba(opt, &rec);
+    for (ViewId v : rec.ViewIds()) ba.AddView(v);
+    for (TrackId t : rec.TrackIds()) ba.AddTrack(t);
+    const BundleAdjustmentSummary s = ba.Optimize();
+    std::printf("full BA: success %d cost %.6e -> %.6e rmse %.4f (%s)\n", s.success, s.initial_cost,
+                s.final_cost, Rmse(ba), ba.DeviceSummary().message);
+    EXPECT(s.success);
+    EXPECT(s.final_cost < 1e-3 * s.initial_cost);
+    EXPECT(Rmse(ba) < 0.3);  // uniform(-0.25, 0.25) pixel noise
+    int changed = 0, i = 0;
+    for (TrackId t : rec.TrackIds()) changed += rec.Track(t)->Point()[0] != before[i++];
+    EXPECT(changed == (int)before.size());  // written back in place
+    // a second BA of the adjusted reconstruction must not increase the cost
+    const BundleAdjustmentSummary s2 = BundleAdjustReconstruction(opt, &rec);
+    EXPECT(s2.success && s2.final_cost <= s2.initial_cost * (1 + 1e-12));
+    EXPECT(std::fabs(s2.initial_cost - s.final_cost) < 1e-9 * s.final_cost);
+  }
+  {
+    // partial BA with anchors + shared constant intrinsics + Huber loss
+    Reconstruction rec;
+    BuildScene(&rec, 6, 120, /*share_groups=*/true, 5, 0.2);
+    BundleAdjustmentOptions opt;
+    opt.intrinsics_to_optimize = OptimizeIntrinsicsType::NONE;
+    opt.loss_function_type = LossFunctionType::HUBER;
+    opt.linear_solver_type = ceres::ITERATIVE_SCHUR;
+    std::unordered_set<ViewId> views = {0, 1, 2};
+    std::unordered_set<TrackId> tracks;
+    for (TrackId t = 0; t < 60; ++t) tracks.insert(t);
+    const Eigen::Vector3d frozen_cam = rec.View(5)->Camera().GetPosition();
+    const double frozen_pt = rec.Track(100)->Point()[1];
+    const BundleAdjustmentSummary s = BundleAdjustPartialReconstruction(opt, views, tracks, &rec);
+    std::printf("partial BA: success %d cost %.6e -> %.6e\n", s.success, s.initial_cost, s.final_cost);
+    EXPECT(s.success && s.final_cost < s.initial_cost);
+    EXPECT(rec.View(5)->Camera().GetPosition()[0] == frozen_cam[0]);
+    EXPECT(rec.Track(100)->Point()[1] == frozen_pt);
+    const BundleAdjustmentSummary sv = BundleAdjustView(opt, 4, &rec);
+    const BundleAdjustmentSummary st = BundleAdjustTrack(opt, 110, &rec);
+    EXPECT(sv.success && st.success);
+    EXPECT(sv.final_cost <= sv.initial_cost && st.final_cost <= st.initial_cost);
+  }
+}
+
+int main(int argc, char** argv) {
+  const std::string mode = argc > 1 ? argv[1] : "cpu";
+  TestSemantics();
+  if (mode == "gpu") TestGpu();
+  std::printf("%s: %d failure(s)\n", mode.c_str(), g_fail);
+  return g_fail ? 1 : 0;
+}

@@ -939,6 +939,34 @@ int32_t tmi_ba_solve(tmi_ba_problem* P, const tmi_ba_options* O, tmi_ba_summary*
   return rc2;
 }
 
+int32_t tmi_ba_structure_stats(const tmi_ba_problem* P, int32_t rank, int32_t world, int64_t out[12]) {
+  if (!P || !out) return TMI_BA_ERR_INVALID_ARGUMENT;
+  Structure st;
+  const int rc = build_structure(P, rank, world, &st);
+  if (rc != TMI_BA_OK) return rc;
+  out[0] = st.Np; out[1] = st.No; out[2] = st.Nrb; out[3] = st.D; out[4] = st.nub;
+  out[5] = st.nnzb; out[6] = st.npairs; out[8] = st.nslices; out[9] = st.No_pad;
+  uint64_t h = 1469598103934665603ULL;
+  for (int64_t u = 0; u < st.nub; ++u) {
+    h = (h ^ (uint64_t)st.ub_i[u]) * 1099511628211ULL;
+    h = (h ^ (uint64_t)st.ub_j[u]) * 1099511628211ULL;
+  }
+  out[7] = (int64_t)(h >> 1);
+  int64_t osum = 0;
+  for (int64_t e = 0; e < st.No_pad; ++e)
+    if (st.obs_orig[e] >= 0) osum += st.obs_orig[e] + 1;
+  out[10] = osum;
+  // pair key independent of slot numbering: caller observation indices of both ends
+  std::vector<int64_t> slot_obs((size_t)st.Nslots, -1);
+  for (int64_t e = 0; e < st.No_pad; ++e)
+    if (st.obs_cpos[e] >= 0) slot_obs[st.obs_cpos[e]] = st.obs_orig[e];
+  int64_t psum = 0;
+  for (int64_t k = 0; k < st.npairs; ++k)
+    psum += (slot_obs[st.pair_i[k]] + 1) * 31 + (slot_obs[st.pair_j[k]] + 1) * 17;
+  out[11] = psum;
+  return TMI_BA_OK;
+}
+
 int32_t tmi_ba_solver_evaluate(tmi_ba_solver* s, double* residuals, double* jac_camera,
                                double* jac_point, uint8_t* valid, int32_t* block_dim) {
   if (!s) return TMI_BA_ERR_INVALID_ARGUMENT;

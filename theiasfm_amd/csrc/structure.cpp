@@ -203,13 +203,37 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S) 
   }
   const int n_active = (int)order.size();
   const int gslices = (n_active + 63) / 64;
-  // global slice gs belongs to rank gs % world
+  // Deal the slices (already in descending track-length order) to the ranks by
+  // longest-processing-time-first on the estimated work of a slice:
+  //   Schur pairs k(k-1)/2  +  5 per observation (the per-observation kernels cost
+  //   about 5x a pair; profiles/r01_a).  Deterministic: ties go to the lowest rank.
+  std::vector<int> slice_rank(gslices, 0);
+  {
+    std::vector<double> load(world, 0.0);
+    for (int gs = 0; gs < gslices; ++gs) {
+      double w = 0.0;
+      for (int t = 0; t < 64; ++t) {
+        const int idx = gs * 64 + t;
+        if (idx < n_active) {
+          const double k = klen[order[idx]];
+          w += 0.5 * k * (k - 1.0) + 5.0 * k;
+        }
+      }
+      int best = 0;
+      for (int r = 1; r < world; ++r)
+        if (load[r] < load[best]) best = r;
+      slice_rank[gs] = best;
+      load[best] += w;
+    }
+  }
   std::vector<int> local_pts;
-  for (int gs = rank; gs < gslices; gs += world)
+  for (int gs = 0; gs < gslices; ++gs) {
+    if (slice_rank[gs] != rank) continue;
     for (int t = 0; t < 64; ++t) {
       const int idx = gs * 64 + t;
       local_pts.push_back(idx < n_active ? order[idx] : -1);
     }
+  }
   s.nslices = (int)local_pts.size() / 64;
   s.Np_pad = s.nslices * 64;
   s.Np = 0;

@@ -1,7 +1,7 @@
 """torch.distributed plumbing for the multi-GPU path (one process per GPU).
 
-Tracks are sharded over the ranks inside the C library (slice s of the
-length-sorted track order belongs to rank s % world).  The only data-path
+Tracks are sharded over the ranks inside the C library (slices of the
+length-sorted track order, dealt longest-work-first).  The only data-path
 exchange is the sum of the reduced camera system built from each rank's
 tracks -- once per LM iteration -- plus a few scalars; the engine calls the
 hook below on its own HIP stream with a device pointer, and the hook runs an

@@ -24,7 +24,7 @@ EXPORTS = (
     "tmi_ba_intrinsics_size", "tmi_ba_intrinsics_constant_mask", "tmi_ba_solve",
     "tmi_ba_solver_create", "tmi_ba_solver_set_allreduce", "tmi_ba_solver_solve",
     "tmi_ba_solver_reset", "tmi_ba_solver_download", "tmi_ba_solver_stream",
-    "tmi_ba_solver_destroy", "tmi_ba_solver_evaluate",
+    "tmi_ba_solver_destroy", "tmi_ba_solver_evaluate", "tmi_ba_structure_stats",
 )
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
@@ -73,8 +73,26 @@ def load():
     L.tmi_ba_solver_evaluate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.POINTER(C.c_int32)]
     L.tmi_ba_solver_evaluate.restype = C.c_int32
+    L.tmi_ba_structure_stats.argtypes = [P, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]
+    L.tmi_ba_structure_stats.restype = C.c_int32
     _lib = L
     return L
+
+
+STRUCTURE_STAT_NAMES = ("tracks", "observations", "reduced_blocks", "block_dim", "upper_blocks",
+                        "bsr_blocks", "pairs", "block_checksum", "slices", "padded_observations",
+                        "observation_checksum", "pair_checksum")
+
+
+def structure_stats(problem: abi.Problem, rank: int = 0, world: int = 1) -> dict:
+    """Host-only statistics of the static structure for one rank (no GPU)."""
+    L = load()
+    cp = problem.as_c()
+    out = (C.c_int64 * 12)()
+    st = L.tmi_ba_structure_stats(C.byref(cp), rank, world, out)
+    if st != 0:
+        raise EngineError(st, "tmi_ba_structure_stats")
+    return dict(zip(STRUCTURE_STAT_NAMES, list(out)))
 
 
 class EngineError(RuntimeError):

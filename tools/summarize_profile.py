@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 runs of bench.py into profiles/<tag>_summary.{md,json}.
+
+  python tools/summarize_profile.py <tag> <stats_dir> [<fetch_dir> <write_dir>]
+
+* <stats_dir>: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py`
+* <fetch_dir>/<write_dir>: separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes.
+HBM traffic follows MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE are
+in KiB; on gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced read
+stream, so fetch bytes are shown both raw and doubled ("x2") -- the truth lies
+between for mixed-width access; WRITE_SIZE is uncalibrated.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    n = name.split("(")[0].replace("void ", "").replace("tmi::", "")
+    return n
+
+
+def read_stats(d):
+    f = glob.glob(os.path.join(d, "**", "*_kernel_stats.csv"), recursive=True)[0]
+    rows = []
+    for r in csv.DictReader(open(f)):
+        rows.append(dict(kernel=short(r["Name"]), calls=int(r["Calls"]), total_ms=float(r["TotalDurationNs"]) / 1e6,
+                         avg_us=float(r["AverageNs"]) / 1e3, pct=float(r["Percentage"])))
+    return rows, f
+
+
+def read_counter(d, counter):
+    f = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)[0]
+    acc, cnt = defaultdict(float), defaultdict(int)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        k = short(r["Kernel_Name"])
+        acc[k] += float(r["Counter_Value"])
+        cnt[k] += 1
+    return {k: acc[k] / cnt[k] * 1024.0 for k in acc}  # bytes per launch
+
+
+def main():
+    tag, stats_dir = sys.argv[1], sys.argv[2]
+    rows, stats_file = read_stats(stats_dir)
+    fetch = read_counter(sys.argv[3], "FETCH_SIZE") if len(sys.argv) > 3 else {}
+    write = read_counter(sys.argv[4], "WRITE_SIZE") if len(sys.argv) > 4 else {}
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    os.makedirs(out_dir, exist_ok=True)
+    for r in rows:
+        r["fetch_bytes_raw"] = fetch.get(r["kernel"])
+        r["write_bytes"] = write.get(r["kernel"])
+        if r["fetch_bytes_raw"] is not None and r["write_bytes"] is not None:
+            r["hbm_bytes_x2fetch"] = 2 * r["fetch_bytes_raw"] + r["write_bytes"]
+            r["hbm_GBs_x2fetch"] = r["hbm_bytes_x2fetch"] / (r["avg_us"] * 1e-6) / 1e9
+    json.dump(rows, open(os.path.join(out_dir, f"{tag}_summary.json"), "w"), indent=1)
+    with open(os.path.join(out_dir, f"{tag}_summary.md"), "w") as fh:
+        fh.write(f"# rocprofv3 summary `{tag}` (bench.py, venice1778-synthetic, 1 x MI355X)\n\n")
+        fh.write("| kernel | calls | avg us | % time | FETCH_SIZE MB/launch (raw) | WRITE_SIZE MB/launch | HBM GB/s (2 x fetch + write) |\n")
+        fh.write("|---|---|---|---|---|---|---|\n")
+        for r in rows:
+            f = "" if r["fetch_bytes_raw"] is None else f"{r['fetch_bytes_raw'] / 1e6:.1f}"
+            w = "" if r["write_bytes"] is None else f"{r['write_bytes'] / 1e6:.1f}"
+            g = "" if "hbm_GBs_x2fetch" not in r else f"{r['hbm_GBs_x2fetch']:.0f}"
+            fh.write(f"| {r['kernel']} | {r['calls']} | {r['avg_us']:.1f} | {r['pct']:.2f} | {f} | {w} | {g} |\n")
+    import shutil
+    shutil.copy(stats_file, os.path.join(out_dir, f"{tag}_kernel_stats.csv"))
+    print(open(os.path.join(out_dir, f"{tag}_summary.md")).read())
+
+
+if __name__ == "__main__":
+    main()
