@@ -273,6 +273,8 @@ typedef struct tmi_ba_solver tmi_ba_solver; /* opaque, device-resident problem *
 int32_t tmi_ba_version(void);           /* major*1000 + minor                 */
 int32_t tmi_ba_device_count(void);      /* gfx950 devices visible, <0 = error */
 const char* tmi_ba_status_string(int32_t status);
+/* Human-readable detail of the last failed call on the calling thread. */
+const char* tmi_ba_last_error(void);
 
 /* Fill `opts` with the reference defaults (bundle_adjustment.h:78-122 plus
  * the Ceres defaults of SURVEY App. B). */

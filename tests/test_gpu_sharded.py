@@ -1,0 +1,122 @@
+"""-m gpu: the multi-GPU code path exercised on ONE device.
+
+A gpurun box has a single GPU, so the sharded path is validated by emulation:
+`world` solver instances (rank r of world, each owning its shard of the tracks)
+run concurrently in threads on the same device; the all-reduce hook sums their
+device buffers exactly where RCCL would.  The sharded solve must reproduce the
+single-rank solve (same LM trajectory; sums differ only in association order).
+A second test drives the real torch.distributed/RCCL hook with a 1-rank group."""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from theiasfm_amd import abi, dist, lib, synth
+
+pytestmark = pytest.mark.gpu
+
+
+class EmulatedAllReduce:
+    def __init__(self, world):
+        import torch
+        self.torch = torch
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+        self.calls = 0
+
+    def hook(self, rank):
+        torch = self.torch
+
+        def fn(ptr, count, stream):
+            torch.cuda.ExternalStream(stream).synchronize()
+            self.slots[rank] = torch.as_tensor(dist._DevArray(ptr, count), device="cuda")
+            self.barrier.wait()
+            if rank == 0:
+                total = self.slots[0].clone()
+                for t in self.slots[1:]:
+                    total += t
+                for t in self.slots:
+                    t.copy_(total)
+                torch.cuda.synchronize()
+                self.calls += 1
+            self.barrier.wait()
+            return 0
+        return fn
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("solver_type", [abi.ITERATIVE_SCHUR, abi.DENSE_SCHUR])
+def test_sharded_solve_matches_single_rank(world, solver_type):
+    import torch
+    torch.cuda.init()
+    prob = synth.config("ladybug49")
+    opts = abi.default_options(linear_solver_type=solver_type, point_dof=3)
+    single = prob.copy()
+    st, s1 = lib.solve(single, opts)
+    assert st == 0
+
+    emu = EmulatedAllReduce(world)
+    shards = [prob.copy() for _ in range(world)]
+    solvers = []
+    for r in range(world):
+        sv = lib.Solver(shards[r], opts, rank=r, world=world)
+        sv.set_allreduce(emu.hook(r))
+        solvers.append(sv)
+    results = [None] * world
+
+    def run(r):
+        results[r] = solvers[r].solve(opts)
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert all(not t.is_alive() for t in threads)
+    assert emu.calls > 0
+    for r in range(world):
+        st_r, s_r = results[r]
+        assert st_r == 0 and s_r.success == 1
+        # every rank reports the same global numbers
+        assert s_r.num_iterations == s1.num_iterations
+        assert s_r.num_successful_steps == s1.num_successful_steps
+        assert abs(s_r.initial_cost - s1.initial_cost) <= 1e-12 * s1.initial_cost
+        assert abs(s_r.final_cost - s1.final_cost) <= 1e-9 * s1.final_cost
+        assert abs(s_r.final_rmse - s1.final_rmse) <= 1e-9
+        assert s_r.final_cost == results[0][1].final_cost
+    # cameras are replicated: identical on every rank and equal to the single-rank result
+    merged = prob.copy()
+    seen = np.zeros(prob.num_points, dtype=int)
+    for r in range(world):
+        out = solvers[r].download()
+        assert np.abs(out.extrinsics - single.extrinsics).max() < 1e-6 * 100.0
+        assert (out.extrinsics == solvers[0].problem.extrinsics).all()
+        moved = np.any(out.points != prob.points, axis=1)
+        seen += moved
+        merged.points[moved] = out.points[moved]
+        solvers[r].close()
+    assert (seen == 1).all()            # every track is owned by exactly one rank
+    assert np.abs(merged.points - single.points).max() < 1e-6 * 100.0
+
+
+def test_rccl_hook_single_rank_group():
+    """The production hook: torch.distributed backend nccl (= RCCL), a raw device
+    pointer aliased as a tensor, enqueued on a foreign HIP stream."""
+    import torch
+    import torch.distributed as td
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if not td.is_initialized():
+        torch.cuda.set_device(0)
+        td.init_process_group(backend="nccl", rank=0, world_size=1)
+    hook = dist.make_device_allreduce()
+    buf = torch.arange(4096, dtype=torch.float64, device="cuda")
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        buf *= 2.0
+    assert hook(buf.data_ptr(), buf.numel(), st.cuda_stream) == 0
+    st.synchronize()
+    assert torch.equal(buf.cpu(), torch.arange(4096, dtype=torch.float64) * 2.0)
+    td.destroy_process_group()

@@ -49,7 +49,7 @@ struct Launch {
                double, int, int, double*);
   void (*point_scale)(const DeviceView&, hipStream_t, int);
   void (*camera_scale)(const DeviceView&, hipStream_t, const int*);
-  void (*point_eliminate)(const DeviceView&, hipStream_t, double, double, double, int, double*);
+  void (*point_eliminate)(const DeviceView&, hipStream_t, double, double, double, int, double*, double*);
   void (*camera_diag)(const DeviceView&, hipStream_t, RedLayout);
   void (*schur_offdiag)(const DeviceView&, hipStream_t, RedLayout);
   void (*expand)(const DeviceView&, hipStream_t, RedLayout, double, double, double);
@@ -80,8 +80,9 @@ Launch make_launch() {
     if (v.Nrb) hipLaunchKernelGGL((camera_scale_kernel<D>), dim3(v.Nrb), dim3(64), 0, st, v, slot_obs);
   };
   L.point_eliminate = [](const DeviceView& v, hipStream_t st, double ir, double lo, double hi, int nb,
-                         double* pm) {
-    hipLaunchKernelGGL((point_eliminate_kernel<D, DP>), dim3(nb), dim3(256), 0, st, v, ir, lo, hi, nb, pm);
+                         double* pm, double* vote) {
+    hipLaunchKernelGGL((point_eliminate_kernel<D, DP>), dim3(nb), dim3(256), 0, st, v, ir, lo, hi, nb, pm,
+                       vote);
   };
   L.camera_diag = [](const DeviceView& v, hipStream_t st, RedLayout R) {
     if (v.Nrb) hipLaunchKernelGGL((camera_diag_kernel<D, DP>), dim3(v.Nrb), dim3(64), 0, st, v, R);
@@ -158,6 +159,7 @@ struct tmi_ba_solver {
   std::vector<void*> allocs;
   // pinned host scalars
   double* h_scal = nullptr;
+  double* h_red = nullptr;  // the 8 all-reduced scalars at the tail of `red`
   int* h_flags = nullptr;
   // initial parameters (for reset) in device order
   std::vector<double> ext0, intr0, pts0;
@@ -183,7 +185,6 @@ struct tmi_ba_solver {
 
 namespace {
 
-std::mutex g_device_mutex;  // serialise solves per process (tmi_ba_solve is re-entrant)
 
 template <class T>
 int dev_alloc(tmi_ba_solver* s, T** p, size_t n) {
@@ -230,6 +231,7 @@ struct Timed {
 int readback(tmi_ba_solver* s) {
   TMI_HIP(hipMemcpyAsync(s->h_scal, s->v.scal, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, s->stream));
   TMI_HIP(hipMemcpyAsync(s->h_flags, s->v.flags, FL_COUNT * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+  TMI_HIP(hipMemcpyAsync(s->h_red, s->v.red + s->RL.scalars, 8 * sizeof(double), hipMemcpyDeviceToHost, s->stream));
   TMI_HIP(hipStreamSynchronize(s->stream));
   return TMI_BA_OK;
 }
@@ -245,6 +247,8 @@ int do_allreduce(tmi_ba_solver* s, double* buf, int64_t count) {
   return TMI_BA_OK;
 }
 
+thread_local std::string g_last_error;  // message of the last failed call on this thread
+
 void set_message(tmi_ba_summary* sum, const char* m) { snprintf(sum->message, sizeof(sum->message), "%s", m); }
 
 }  // namespace
@@ -253,6 +257,8 @@ void set_message(tmi_ba_summary* sum, const char* m) { snprintf(sum->message, si
 extern "C" {
 
 int32_t tmi_ba_version(void) { return TMI_BA_VERSION_MAJOR * 1000 + TMI_BA_VERSION_MINOR; }
+
+const char* tmi_ba_last_error(void) { return g_last_error.c_str(); }
 
 int32_t tmi_ba_device_count(void) {
   int n = 0;
@@ -349,6 +355,7 @@ void tmi_ba_solver_destroy(tmi_ba_solver* s) {
   for (void* p : s->allocs) hipFree(p);
   if (s->h_scal) hipHostFree(s->h_scal);
   if (s->h_flags) hipHostFree(s->h_flags);
+  if (s->h_red) hipHostFree(s->h_red);
   if (s->stream) hipStreamDestroy(s->stream);
   delete s;
 }
@@ -393,6 +400,7 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   TMI_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   TMI_HIP(hipHostMalloc((void**)&s->h_scal, SC_COUNT * sizeof(double), hipHostMallocDefault));
   TMI_HIP(hipHostMalloc((void**)&s->h_flags, FL_COUNT * sizeof(int), hipHostMallocDefault));
+  TMI_HIP(hipHostMalloc((void**)&s->h_red, 8 * sizeof(double), hipHostMallocDefault));
 
   const int D = st.D, DP = s->DP;
   DeviceView& v = s->v;
@@ -466,7 +474,7 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   const int nbmax = std::max(s->nblocks_slices, s->nblocks_points);
 #define AL(ptr, n) if ((rc = dev_alloc(s, &ptr, (size_t)(n)))) return rc;
   AL(v.pm_r, 2 * N) AL(v.pm_A, 2 * D * N) AL(v.pm_Jp, 2 * DP * N) AL(s->d_pm_u, 2 * N)
-  AL(v.cm_Y, (size_t)st.Nslots * YS) AL(v.cm_A, (size_t)st.Nslots * AS)
+  AL(v.cm_Y, (size_t)std::max<int64_t>(st.Nslots, 1) * YS) AL(v.cm_A, (size_t)std::max<int64_t>(st.Nslots, 1) * AS)
   AL(v.scale_c, std::max(n_r, 1)) AL(v.scale_p, NP * DP)
   AL(v.Vinv, NP * NS) AL(v.gp, NP * DP) AL(v.diag_p, NP * DP) AL(v.yp, NP * DP)
   AL(v.red, s->RL.total) AL(v.S, (size_t)st.nnzb * D * D) AL(v.Minv, (size_t)std::max(st.Nrb, 1) * D * D)
@@ -495,9 +503,7 @@ int32_t tmi_ba_solver_create(const tmi_ba_problem* P, const tmi_ba_options* O, i
   const int rc = create_impl(s, P, O, rank, world);
   if (rc != TMI_BA_OK) {
     if (O->verbose) fprintf(stderr, "[tmi_ba] create failed: %s\n", s->error.c_str());
-    // keep the message reachable through a failed handle is not possible; print when verbose
-    static thread_local std::string last_error;
-    last_error = s->error;
+    g_last_error = s->error;
     tmi_ba_solver_destroy(s);
     return rc;
   }
@@ -617,8 +623,8 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
     set_message(sum, "point_dof differs from the value the solver was created with");
     return sum->status;
   }
-  std::lock_guard<std::mutex> lock(g_device_mutex);
   auto fail = [&](int rc) {
+    g_last_error = s->error;
     sum->status = rc;
     sum->success = 0;
     sum->termination = 2;
@@ -750,9 +756,10 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
     ++iter;
     const double inv_radius = 1.0 / radius;
     CKH(hipMemsetAsync(v.flags, 0, FL_COUNT * sizeof(int), stream));
+    CKH(hipMemsetAsync(d_sc, 0, 8 * sizeof(double), stream));
     {
       Timed t(s, TMI_BA_K_POINT_ELIMINATE);
-      s->launch.point_eliminate(v, stream, inv_radius, O->min_lm_diagonal, O->max_lm_diagonal, nbs, s->d_partial_max);
+      s->launch.point_eliminate(v, stream, inv_radius, O->min_lm_diagonal, O->max_lm_diagonal, nbs, s->d_partial_max, d_sc + 6);
     }
     {
       Timed t(s, TMI_BA_K_CAMERA_DIAG);
@@ -762,7 +769,7 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
       Timed t(s, TMI_BA_K_SCHUR_OFFDIAG);
       s->launch.schur_offdiag(v, stream, RL);
     }
-    CK(do_allreduce(s, v.red, RL.scalars));
+    CK(do_allreduce(s, v.red, RL.total));  // d_sc[6] carries the singular-track votes
     {
       Timed t(s, TMI_BA_K_REDUCE);
       s->launch.expand(v, stream, RL, inv_radius, O->min_lm_diagonal, O->max_lm_diagonal);
@@ -781,9 +788,10 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
       CK(solve_reduced_pcg(s, O, &usable, &pcg_iters));
     } else {
       CK(solve_reduced_dense(s, &usable));
-      CK(readback(s));
     }
-    if (s->h_flags[FL_SINGULAR_POINT] || s->h_flags[FL_SINGULAR_BLOCK]) usable = 0;
+    CK(readback(s));
+    // singular track blocks are voted on by every rank (summed in the all-reduce)
+    if (s->h_red[6] > 0.0 || s->h_flags[FL_SINGULAR_BLOCK]) usable = 0;
     if (need_gradient_check) {
       // gradient tolerance: every rank votes, the vote is summed
       double vote[8] = {0};
@@ -930,7 +938,7 @@ int32_t tmi_ba_solve(tmi_ba_problem* P, const tmi_ba_options* O, tmi_ba_summary*
   if (rc != TMI_BA_OK) {
     sum->status = rc;
     sum->termination = 2;
-    set_message(sum, tmi_ba_status_string(rc));
+    set_message(sum, g_last_error.empty() ? tmi_ba_status_string(rc) : g_last_error.c_str());
     return rc;
   }
   const int rc2 = tmi_ba_solver_solve(s, O, sum);
@@ -970,7 +978,6 @@ int32_t tmi_ba_structure_stats(const tmi_ba_problem* P, int32_t rank, int32_t wo
 int32_t tmi_ba_solver_evaluate(tmi_ba_solver* s, double* residuals, double* jac_camera,
                                double* jac_point, uint8_t* valid, int32_t* block_dim) {
   if (!s) return TMI_BA_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lock(g_device_mutex);
   TMI_HIP(hipSetDevice(s->device));
   DeviceView& v = s->v;
   Structure& st = s->st;

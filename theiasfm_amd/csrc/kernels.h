@@ -332,7 +332,7 @@ __global__ void camera_scale_finish_kernel(double* scale_c, int n) {
 template <int D, int DP>
 __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, double inv_radius,
                                                               double lm_lo, double lm_hi, int nblocks,
-                                                              double* partial_max) {
+                                                              double* partial_max, double* singular_vote) {
   constexpr int NS = sym_size(DP);
   constexpr int YS = ys_of(D, DP);
   constexpr int AS = as_of(D);
@@ -398,7 +398,10 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
           Lm[i][j] = t * il;
         }
       }
-      if (!pd) v.flags[FL_SINGULAR_POINT] = 1;
+      if (!pd) {
+        v.flags[FL_SINGULAR_POINT] = 1;
+        *singular_vote = 1.0;  // lives in the all-reduced scalar tail: every rank sees it
+      }
       // Li = L^-1 (lower)
       double Li[DP][DP];
 #pragma unroll

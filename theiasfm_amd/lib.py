@@ -20,7 +20,8 @@ _lib = None
 
 # every symbol include/theia_mi355_ba.h declares
 EXPORTS = (
-    "tmi_ba_version", "tmi_ba_device_count", "tmi_ba_status_string", "tmi_ba_options_init",
+    "tmi_ba_version", "tmi_ba_device_count", "tmi_ba_status_string", "tmi_ba_last_error",
+    "tmi_ba_options_init",
     "tmi_ba_intrinsics_size", "tmi_ba_intrinsics_constant_mask", "tmi_ba_solve",
     "tmi_ba_solver_create", "tmi_ba_solver_set_allreduce", "tmi_ba_solver_solve",
     "tmi_ba_solver_reset", "tmi_ba_solver_download", "tmi_ba_solver_stream",
@@ -42,12 +43,23 @@ def load():
         raise LibraryMissing(
             f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(the HIP engine has no CPU fallback)")
+    # Load order matters: torch bundles its own libamdhip64.so (SONAME
+    # libamdhip64.so.7, the same as /opt/rocm's).  Imported first, the loader
+    # resolves the engine's NEEDED libamdhip64.so.7 to torch's already loaded
+    # runtime, so the engine and torch share ONE HIP runtime and streams / device
+    # pointers are interchangeable (needed by the all-reduce hook).  Loaded the
+    # other way round the process ends up with two runtimes and torch sees no GPU.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     P, O, S = C.POINTER(abi.CProblem), C.POINTER(abi.COptions), C.POINTER(abi.CSummary)
     L.tmi_ba_version.restype = C.c_int32
     L.tmi_ba_device_count.restype = C.c_int32
     L.tmi_ba_status_string.restype = C.c_char_p
     L.tmi_ba_status_string.argtypes = [C.c_int32]
+    L.tmi_ba_last_error.restype = C.c_char_p
     L.tmi_ba_options_init.argtypes = [O]
     L.tmi_ba_options_init.restype = None
     L.tmi_ba_intrinsics_size.argtypes = [C.c_int32]
@@ -99,6 +111,8 @@ class EngineError(RuntimeError):
     def __init__(self, status, where, message=""):
         self.status = status
         name = abi.STATUS_NAMES.get(status, str(status))
+        if not message and _lib is not None:
+            message = (_lib.tmi_ba_last_error() or b"").decode("utf-8", "replace")
         super().__init__(f"{where}: status {status} ({name}) {message}")
 
 
