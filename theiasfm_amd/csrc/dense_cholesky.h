@@ -15,21 +15,30 @@ namespace tmi {
 
 constexpr int kTile = 32;
 
+// scatter the symmetric block storage (upper blocks in `red`, diagonal blocks in
+// Sdiag) into the dense lower + upper triangles
 template <int D>
-__global__ __launch_bounds__(256) void dense_gather_kernel(DeviceView v, double* __restrict__ A, int n) {
+__global__ __launch_bounds__(256) void dense_gather_kernel(DeviceView v, const double* __restrict__ ub,
+                                                           double* __restrict__ A, int n) {
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= (long long)v.nnzb * D * D) return;
-  const int blk = (int)(e / (D * D));
-  const int w = (int)(e - (long long)blk * (D * D));
-  const int a = w / D, b = w - a * D;
-  // block row of `blk`: binary search in row_ptr
-  int lo = 0, hi = v.Nrb;
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (v.row_ptr[mid] <= blk) lo = mid; else hi = mid;
+  const long long n_off = (long long)v.nub * D * D;
+  const long long n_all = n_off + (long long)v.Nrb * D * D;
+  if (e >= n_all) return;
+  if (e < n_off) {
+    const int u = (int)(e / (D * D));
+    const int w = (int)(e - (long long)u * (D * D));
+    const int a = w / D, b = w - a * D;
+    const int row = v.ub_i[u], col = v.ub_j[u];
+    const double val = ub[e];
+    A[(size_t)(row * D + a) * n + (size_t)col * D + b] = val;
+    A[(size_t)(col * D + b) * n + (size_t)row * D + a] = val;
+  } else {
+    const long long f = e - n_off;
+    const int rb = (int)(f / (D * D));
+    const int w = (int)(f - (long long)rb * (D * D));
+    const int a = w / D, b = w - a * D;
+    A[(size_t)(rb * D + a) * n + (size_t)rb * D + b] = v.Sdiag[f];
   }
-  const int row = lo, col = v.col_idx[blk];
-  A[(size_t)(row * D + a) * n + (size_t)col * D + b] = v.S[e];
 }
 
 __global__ __launch_bounds__(256) void chol_potrf_tile_kernel(double* __restrict__ A, int n, int k0,

@@ -13,7 +13,9 @@
 //    red    [nub*D*D | Nrb*D*D | Nrb*D | Nrb*D | Nrb*D | 8]   the all-reduce buffer:
 //           upper blocks, raw diagonal blocks, U diagonal, reduced gradient g~,
 //           camera gradient g_c, scalars
-//    S      [nnzb][D*D]      BSR values, both triangles, LM diagonal added
+//    S is symmetric and lives in `red` itself: upper blocks red[ub + u D^2] (rows contiguous)
+//    Sdiag  [Nrb][D*D]       diagonal blocks with the LM diagonal added
+//    tbuf   [nub][D]         transposed block products of the symmetric SpMV
 #pragma once
 #include <cstdint>
 
@@ -24,6 +26,7 @@ struct DeviceView {
   int No_pad;
   int Nslots;
   int nub, nnzb;
+  int n_order;  // entries of ub_order (multiple of 32)
   long long npairs;
 
   // parameters (current and candidate)
@@ -49,11 +52,11 @@ struct DeviceView {
   const int* rb_cam;
   const signed char* rb_cols;  // [Nrb][D]
   const int* cam_ptr;
-  const int* row_ptr;
-  const int* col_idx;
-  const int* diag_pos;
-  const int* ub_pos;
-  const int* ub_pos_t;
+  const int* urow_ptr;
+  const int* ub_i;
+  const int* ub_j;
+  const int* ucol_ptr;
+  const int* ucol_u;
   const long long* pair_ptr;
   const int* pair_i;
   const int* pair_j;
@@ -72,7 +75,8 @@ struct DeviceView {
   double* diag_p;   // [DP][Np_pad] squared column norms of the point Jacobian
   double* yp;       // [DP][Np_pad]
   double* red;      // all-reduce buffer
-  double* S;        // BSR values
+  double* Sdiag;    // [Nrb][D*D] diagonal blocks + LM diagonal
+  double* tbuf;     // [nub][D]
   double* Minv;     // [Nrb][D*D] inverse diagonal blocks
   double* rhs;      // [Nrb*D]
   double* yc;       // [Nrb*D]
@@ -121,6 +125,7 @@ enum {
   SC_ZETA = 14,
   SC_BNORM = 15,
   SC_GMAX_P = 16,
+  SC_RHO_BAD = 17,  // the next iteration's rho is zero or not finite
   SC_COUNT = 32
 };
 // DeviceView::flags

@@ -54,13 +54,14 @@ struct Launch {
   void (*schur_offdiag)(const DeviceView&, hipStream_t, RedLayout);
   void (*expand)(const DeviceView&, hipStream_t, RedLayout, double, double, double);
   void (*precond)(const DeviceView&, hipStream_t, int);
-  void (*spmv)(const DeviceView&, hipStream_t, const double*, double*);
+  void (*spmv)(const DeviceView&, hipStream_t, const double*, const double*, double*);
   void (*pcg_a)(const DeviceView&, hipStream_t, int, int);
+  void (*pcg_b)(const DeviceView&, hipStream_t, const double*, int, int, int);
   void (*back_substitute)(const DeviceView&, hipStream_t, double*, int, double*);
   void (*update_points)(const DeviceView&, hipStream_t, int, double*);
   void (*update_cameras)(const DeviceView&, hipStream_t, double*);
   void (*camera_gmax)(const DeviceView&, hipStream_t, const double*, double*);
-  void (*dense_gather)(const DeviceView&, hipStream_t, double*, int);
+  void (*dense_gather)(const DeviceView&, hipStream_t, const double*, double*, int);
 };
 
 template <int D, int DP>
@@ -89,26 +90,27 @@ Launch make_launch() {
   };
   L.schur_offdiag = [](const DeviceView& v, hipStream_t st, RedLayout R) {
     if (v.nub)
-      hipLaunchKernelGGL((schur_offdiag_kernel<D, DP>), dim3((v.nub + 3) / 4), dim3(256), 0, st, v, R);
+      hipLaunchKernelGGL((schur_offdiag_kernel<D, DP>), dim3((v.n_order + 3) / 4), dim3(256), 0, st, v, R);
   };
   L.expand = [](const DeviceView& v, hipStream_t st, RedLayout R, double ir, double lo, double hi) {
-    const long long n1 = (long long)v.nub * D * D;
-    if (n1)
-      hipLaunchKernelGGL((expand_offdiag_kernel<D>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0,
-                         st, v, R);
     const int n2 = v.Nrb * D * D;
     if (n2)
-      hipLaunchKernelGGL((expand_diag_kernel<D>), dim3((n2 + 255) / 256), dim3(256), 0, st, v, R, ir,
+      hipLaunchKernelGGL((finish_diag_kernel<D>), dim3((n2 + 255) / 256), dim3(256), 0, st, v, R, ir,
                          lo, hi);
   };
   L.precond = [](const DeviceView& v, hipStream_t st, int identity) {
     if (v.Nrb) hipLaunchKernelGGL((precond_invert_kernel<D>), dim3(v.Nrb), dim3(64), 0, st, v, identity);
   };
-  L.spmv = [](const DeviceView& v, hipStream_t st, const double* x, double* y) {
-    if (v.Nrb) hipLaunchKernelGGL((spmv_kernel<D>), dim3(v.Nrb), dim3(256), 0, st, v, x, y);
+  L.spmv = [](const DeviceView& v, hipStream_t st, const double* ub, const double* x, double* y) {
+    if (!v.Nrb) return;
+    hipLaunchKernelGGL((spmv_rows_kernel<D>), dim3(v.Nrb), dim3(256), 0, st, v, ub, x, y);
+    hipLaunchKernelGGL((spmv_cols_kernel<D>), dim3(v.Nrb), dim3(256), 0, st, v, y);
   };
   L.pcg_a = [](const DeviceView& v, hipStream_t st, int n, int it) {
     hipLaunchKernelGGL((pcg_a_kernel<D>), dim3(1), dim3(1024), 0, st, v, n, it);
+  };
+  L.pcg_b = [](const DeviceView& v, hipStream_t st, const double* b, int n, int it, int stage) {
+    hipLaunchKernelGGL((pcg_b_kernel<D>), dim3(1), dim3(1024), 0, st, v, b, n, it, stage);
   };
   L.back_substitute = [](const DeviceView& v, hipStream_t st, double* pm_u, int nb, double* partial) {
     hipLaunchKernelGGL((back_substitute_kernel<D, DP>), dim3(nb), dim3(256), 0, st, v, pm_u, nb, partial);
@@ -122,11 +124,11 @@ Launch make_launch() {
   L.camera_gmax = [](const DeviceView& v, hipStream_t st, const double* gc, double* out) {
     hipLaunchKernelGGL((camera_gmax_kernel<D>), dim3(1), dim3(1024), 0, st, v, gc, out);
   };
-  L.dense_gather = [](const DeviceView& v, hipStream_t st, double* A, int n) {
-    const long long total = (long long)v.nnzb * D * D;
+  L.dense_gather = [](const DeviceView& v, hipStream_t st, const double* ub, double* A, int n) {
+    const long long total = ((long long)v.nub + v.Nrb) * D * D;
     if (total)
       hipLaunchKernelGGL((dense_gather_kernel<D>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                         st, v, A, n);
+                         st, v, ub, A, n);
   };
   return L;
 }
@@ -408,6 +410,7 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   v.Nc = st.Nc; v.G = st.G; v.Np_pad = st.Np_pad; v.nslices = st.nslices; v.Nrb = st.Nrb;
   v.D = D; v.DP = DP; v.No_pad = (int)st.No_pad; v.Nslots = (int)st.Nslots;
   v.nub = (int)st.nub; v.nnzb = (int)st.nnzb; v.npairs = st.npairs;
+  v.n_order = (int)st.ub_order.size();
   s->RL = red_layout(st.nub, st.Nrb, D);
   s->n_intr = st.G ? P->group_offset[st.G] : 0;
 
@@ -446,9 +449,23 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
     UPI(v.slice_ptr, st.slice_ptr) UPI(v.pt_k, st.pt_k) UPI(v.obs_cam, st.obs_cam)
     UPI(v.obs_cpos, st.obs_cpos) UPI(v.cam_grp, cam_grp) UPI(v.cam_rb, st.cam_rb)
     UPI(v.grp_model, grp_model) UPI(v.grp_off, grp_off) UPI(v.rb_cam, st.rb_cam)
-    UPI(v.cam_ptr, st.cam_ptr) UPI(v.row_ptr, st.row_ptr) UPI(v.col_idx, st.col_idx)
-    UPI(v.diag_pos, st.diag_pos) UPI(v.ub_pos, st.ub_pos) UPI(v.ub_pos_t, st.ub_pos_t)
-    UPI(v.pair_i, st.pair_i) UPI(v.pair_j, st.pair_j) UPI(v.ub_order, st.ub_order)
+    UPI(v.cam_ptr, st.cam_ptr) UPI(v.urow_ptr, st.urow_ptr) UPI(v.ub_i, st.ub_i) UPI(v.ub_j, st.ub_j)
+    UPI(v.ucol_ptr, st.ucol_ptr) UPI(v.ucol_u, st.ucol_u)
+    UPI(v.pair_i, st.pair_i) UPI(v.pair_j, st.pair_j)
+    {
+      // launch headers of schur_offdiag: {block, #pairs, first pair lo, first pair hi}
+      std::vector<int> hdr(st.ub_order.size() * 4, -1);
+      for (size_t k = 0; k < st.ub_order.size(); ++k) {
+        const int u = st.ub_order[k];
+        if (u < 0) continue;
+        const long long p0 = st.pair_ptr[u];
+        hdr[4 * k] = u;
+        hdr[4 * k + 1] = (int)(st.pair_ptr[u + 1] - p0);
+        hdr[4 * k + 2] = (int)(unsigned)(p0 & 0xffffffffLL);
+        hdr[4 * k + 3] = (int)(p0 >> 32);
+      }
+      UPI(v.ub_order, hdr)
+    }
 #undef UPI
     if ((rc = dev_upload(s, &pu, st.cam_mask))) return rc; v.cam_mask = pu;
     if ((rc = dev_upload(s, &pc, st.pt_const))) return rc; v.pt_const = pc;
@@ -477,7 +494,8 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   AL(v.cm_Y, (size_t)std::max<int64_t>(st.Nslots, 1) * YS) AL(v.cm_A, (size_t)std::max<int64_t>(st.Nslots, 1) * AS)
   AL(v.scale_c, std::max(n_r, 1)) AL(v.scale_p, NP * DP)
   AL(v.Vinv, NP * NS) AL(v.gp, NP * DP) AL(v.diag_p, NP * DP) AL(v.yp, NP * DP)
-  AL(v.red, s->RL.total) AL(v.S, (size_t)st.nnzb * D * D) AL(v.Minv, (size_t)std::max(st.Nrb, 1) * D * D)
+  AL(v.red, s->RL.total) AL(v.Sdiag, (size_t)std::max(st.Nrb, 1) * D * D)
+  AL(v.tbuf, (size_t)std::max<int64_t>(st.nub, 1) * D) AL(v.Minv, (size_t)std::max(st.Nrb, 1) * D * D)
   AL(v.rhs, std::max(n_r, 1)) AL(v.yc, std::max(n_r, 1)) AL(v.cg_r, std::max(n_r, 1))
   AL(v.cg_z, std::max(n_r, 1)) AL(v.cg_p, std::max(n_r, 1)) AL(v.cg_q, std::max(n_r, 1))
   AL(v.cg_t, std::max(n_r, 1)) AL(v.partial, (size_t)4 * nbmax) AL(s->d_partial_max, nbmax)
@@ -561,28 +579,29 @@ static int solve_reduced_pcg(tmi_ba_solver* s, const tmi_ba_options* O, int* usa
     Timed t(s, TMI_BA_K_PCG_VECTOR);
     hipLaunchKernelGGL(pcg_begin_kernel, dim3(1), dim3(1024), 0, s->stream, v, b, n);
   }
+  {
+    Timed t(s, TMI_BA_K_PCG_VECTOR);
+    s->launch.pcg_a(v, s->stream, n, 1);  // z, rho, p of the first iteration
+  }
   int it;
   for (it = 1;; ++it) {
     {
-      Timed t(s, TMI_BA_K_PCG_VECTOR);
-      s->launch.pcg_a(v, s->stream, n, it);
-    }
-    {
       Timed t(s, TMI_BA_K_SPMV);
-      s->launch.spmv(v, s->stream, v.cg_p, v.cg_q);
+      s->launch.spmv(v, s->stream, v.red + s->RL.ub, v.cg_p, v.cg_q);
     }
     const bool reset = (it % 10 == 0);  // residual_reset_period
     {
+      // also prepares z, rho, p of iteration it + 1 (unless this is a reset step)
       Timed t(s, TMI_BA_K_PCG_VECTOR);
-      hipLaunchKernelGGL(pcg_b_kernel, dim3(1), dim3(1024), 0, s->stream, v, b, n, it, reset ? 1 : 0);
+      s->launch.pcg_b(v, s->stream, b, n, it, reset ? 1 : 0);
     }
     if (reset) {
       {
         Timed t(s, TMI_BA_K_SPMV);
-        s->launch.spmv(v, s->stream, v.yc, v.cg_t);
+        s->launch.spmv(v, s->stream, v.red + s->RL.ub, v.yc, v.cg_t);
       }
       Timed t(s, TMI_BA_K_PCG_VECTOR);
-      hipLaunchKernelGGL(pcg_b_kernel, dim3(1), dim3(1024), 0, s->stream, v, b, n, it, 2);
+      s->launch.pcg_b(v, s->stream, b, n, it, 2);
     }
     int rc = readback(s);
     if (rc) return rc;
@@ -593,6 +612,10 @@ static int solve_reduced_pcg(tmi_ba_solver* s, const tmi_ba_options* O, int* usa
     if (!(s->h_scal[SC_PQ] > 0.0)) break;  // LINEAR_SOLVER_NO_CONVERGENCE, x kept
     if (s->h_scal[SC_ZETA] < O->eta && it >= O->min_linear_solver_iterations) break;
     if (it >= O->max_linear_solver_iterations) break;
+    if (s->h_scal[SC_RHO_BAD] != 0.0) {  // rho of the next iteration is 0 / inf: FAILURE
+      *usable = 0;
+      break;
+    }
   }
   *iters += it;
   return TMI_BA_OK;
@@ -609,7 +632,7 @@ static int solve_reduced_dense(tmi_ba_solver* s, int* usable) {
   }
   Timed t(s, TMI_BA_K_CHOLESKY);
   TMI_HIP(hipMemsetAsync(s->d_dense, 0, (size_t)n * n * sizeof(double), s->stream));
-  s->launch.dense_gather(v, s->stream, s->d_dense, n);
+  s->launch.dense_gather(v, s->stream, v.red + s->RL.ub, s->d_dense, n);
   dense_cholesky_solve(s->d_dense, n, v.red + s->RL.gt, v.yc, v.flags + FL_SINGULAR_BLOCK, s->stream);
   return TMI_BA_OK;
 }

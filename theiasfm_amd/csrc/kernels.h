@@ -1,7 +1,7 @@
 // HIP kernels of the bundle-adjustment engine (gfx950, wave64, fp64).
 // One Levenberg-Marquardt iteration is
 //   linearize -> point_eliminate -> camera_diag + schur_offdiag -> [all-reduce]
-//   -> expand_S + precond_invert -> PCG (pcg_a / spmv / pcg_b) or dense Cholesky
+//   -> finish_diag + precond_invert -> PCG (pcg_a / symmetric spmv / pcg_b) or dense Cholesky
 //   -> back_substitute -> update -> cost
 // Every kernel is HBM-bound gather/stream work; the only contraction
 // (S_ij = -sum_pairs Y_i Y_j^T, inner dimension 3 x #common tracks) runs on
@@ -18,6 +18,8 @@
 namespace tmi {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+// 16-byte vector that may sit on an 8-byte boundary (global loads only need dword alignment)
+typedef double double2_a8 __attribute__((ext_vector_type(2), aligned(8)));
 
 constexpr int kWave = 64;
 constexpr int kSlicesPerBlock = 4;  // 256 threads
@@ -27,8 +29,10 @@ __host__ __device__ constexpr int sym_idx(int a, int b, int n) {
   return a * n - a * (a - 1) / 2 + (b - a);
 }
 __host__ __device__ constexpr int sym_size(int n) { return n * (n + 1) / 2; }
-__host__ __device__ constexpr int ys_of(int D, int DP) { return (D * DP + 1) & ~1; }
-__host__ __device__ constexpr int as_of(int D) { return 2 * D + 4; }
+// camera-major record strides in doubles, rounded up to whole 64-byte sectors so that a
+// record never straddles an extra sector (gathers) and is written as full sectors
+__host__ __device__ constexpr int ys_of(int D, int DP) { return (D * DP + 7) & ~7; }
+__host__ __device__ constexpr int as_of(int D) { return (2 * D + 4 + 7) & ~7; }
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -336,6 +340,9 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
   constexpr int NS = sym_size(DP);
   constexpr int YS = ys_of(D, DP);
   constexpr int AS = as_of(D);
+  constexpr int STP = (YS > AS ? YS : AS) + 2;  // LDS record pitch, +2 doubles: conflict-free b64/b128
+  __shared__ __attribute__((aligned(16))) double stage[kSlicesPerBlock][32][STP];
+  __shared__ int stage_cpos[kSlicesPerBlock][32];
   const int lane = threadIdx.x & 63;
   const int s = blockIdx.x * kSlicesPerBlock + (threadIdx.x >> 6);
   double gmax = 0.0;
@@ -345,6 +352,8 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
     const size_t base = (size_t)v.slice_ptr[s] + lane;
     const size_t N = (size_t)v.No_pad;
     const size_t NP = (size_t)v.Np_pad;
+    bool have_tp = false;
+    double tp_s[DP], Li_s[DP][DP];
     if (k > 0) {
       double V[NS], g[DP];
 #pragma unroll
@@ -434,10 +443,28 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
         for (int b = 0; b < DP; ++b) t += Vi[a <= b ? sym_idx(a, b, DP) : sym_idx(b, a, DP)] * g[b];
         tp[a] = t;
       }
-      for (int j = 0; j < k; ++j) {
-        const size_t e = base + (size_t)j * 64;
-        const int cpos = v.obs_cpos[e];
-        if (cpos < 0) continue;
+      have_tp = true;
+#pragma unroll
+      for (int a = 0; a < DP; ++a) {
+        tp_s[a] = tp[a];
+#pragma unroll
+        for (int b = 0; b <= a; ++b) Li_s[a][b] = Li[a][b];
+      }
+    }
+    // ---- second pass: Y = A^T (Jp L^-T), r~ = r - Jp t_p into the camera-major records.
+    // Each lane builds its record in registers; the wave then stages 32 records at a
+    // time in LDS and writes them out with consecutive lanes covering consecutive 16 B,
+    // i.e. whole 64-byte sectors per record (scattered 8/16-byte stores cost 2-4x the
+    // bytes in HBM write traffic, profiles/r01_a).  The trip count K is wave uniform.
+    const int K = (v.slice_ptr[s + 1] - v.slice_ptr[s]) >> 6;
+    double* st = &stage[threadIdx.x >> 6][0][0];
+    int* scp = &stage_cpos[threadIdx.x >> 6][0];
+    for (int j = 0; j < K; ++j) {
+      const size_t e = base + (size_t)j * 64;
+      int cpos = -1;
+      if (have_tp && j < k) cpos = v.obs_cpos[e];
+      double Yv[YS], Av[AS];
+      if (cpos >= 0) {
         double J0[DP], J1[DP], Q0[DP], Q1[DP];
 #pragma unroll
         for (int a = 0; a < DP; ++a) {
@@ -448,8 +475,8 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
         double rt0 = r0, rt1 = r1;
 #pragma unroll
         for (int a = 0; a < DP; ++a) {
-          rt0 -= J0[a] * tp[a];
-          rt1 -= J1[a] * tp[a];
+          rt0 -= J0[a] * tp_s[a];
+          rt1 -= J1[a] * tp_s[a];
         }
         // Q_row = Li * Jp_row^T
 #pragma unroll
@@ -457,30 +484,72 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
           double q0 = 0.0, q1 = 0.0;
 #pragma unroll
           for (int a = 0; a <= b; ++a) {
-            q0 += Li[b][a] * J0[a];
-            q1 += Li[b][a] * J1[a];
+            q0 += Li_s[b][a] * J0[a];
+            q1 += Li_s[b][a] * J1[a];
           }
           Q0[b] = q0;
           Q1[b] = q1;
         }
-        double* yrec = v.cm_Y + (size_t)cpos * YS;
-        double* arec = v.cm_A + (size_t)cpos * AS;
-        double Yv[YS];
 #pragma unroll
         for (int a = 0; a < D; ++a) {
           const double a0 = v.pm_A[(size_t)(2 * a) * N + e], a1 = v.pm_A[(size_t)(2 * a + 1) * N + e];
-          arec[a] = a0;
-          arec[D + a] = a1;
+          Av[a] = a0;
+          Av[D + a] = a1;
 #pragma unroll
           for (int b = 0; b < DP; ++b) Yv[a * DP + b] = a0 * Q0[b] + a1 * Q1[b];
         }
-        if (YS > D * DP) Yv[YS - 1] = 0.0;
 #pragma unroll
-        for (int i = 0; i < YS; i += 2) *reinterpret_cast<double2*>(yrec + i) = make_double2(Yv[i], Yv[i + 1]);
-        arec[2 * D] = rt0;
-        arec[2 * D + 1] = rt1;
-        arec[2 * D + 2] = r0;
-        arec[2 * D + 3] = r1;
+        for (int i = D * DP; i < YS; ++i) Yv[i] = 0.0;
+        Av[2 * D] = rt0;
+        Av[2 * D + 1] = rt1;
+        Av[2 * D + 2] = r0;
+        Av[2 * D + 3] = r1;
+#pragma unroll
+        for (int i = 2 * D + 4; i < AS; ++i) Av[i] = 0.0;
+      }
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        // Y records of lanes [32 half, 32 half + 32)
+        if ((lane >> 5) == half) {
+          scp[lane & 31] = cpos;
+          if (cpos >= 0) {
+#pragma unroll
+            for (int i = 0; i < YS; i += 2)
+              *reinterpret_cast<double2*>(st + (lane & 31) * STP + i) = make_double2(Yv[i], Yv[i + 1]);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int c = lane; c < 32 * (YS / 2); c += 64) {
+          const int rec = c / (YS / 2), part = c - rec * (YS / 2);
+          const int cp = scp[rec];
+          if (cp >= 0)
+            *reinterpret_cast<double2*>(v.cm_Y + (size_t)cp * YS + 2 * part) =
+                *reinterpret_cast<const double2*>(st + rec * STP + 2 * part);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // A records of the same lanes
+        if ((lane >> 5) == half && cpos >= 0) {
+#pragma unroll
+          for (int i = 0; i < AS; i += 2)
+            *reinterpret_cast<double2*>(st + (lane & 31) * STP + i) = make_double2(Av[i], Av[i + 1]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int c = lane; c < 32 * (AS / 2); c += 64) {
+          const int rec = c / (AS / 2), part = c - rec * (AS / 2);
+          const int cp = scp[rec];
+          if (cp >= 0)
+            *reinterpret_cast<double2*>(v.cm_A + (size_t)cp * AS + 2 * part) =
+                *reinterpret_cast<const double2*>(st + rec * STP + 2 * part);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
     }
   }
@@ -525,7 +594,7 @@ __global__ __launch_bounds__(64) void camera_diag_kernel(DeviceView v, RedLayout
     }
     const double rt0 = arec[2 * D], rt1 = arec[2 * D + 1], r0 = arec[2 * D + 2], r1 = arec[2 * D + 3];
 #pragma unroll
-    for (int i = 0; i < YS; i += 2) {
+    for (int i = 0; i < ((D * DP + 1) & ~1); i += 2) {
       const double2 t = *reinterpret_cast<const double2*>(yrec + i);
       Y[i] = t.x;
       Y[i + 1] = t.y;
@@ -578,31 +647,46 @@ __global__ __launch_bounds__(256) void schur_offdiag_kernel(DeviceView v, RedLay
   constexpr int YS = ys_of(D, DP);
   const int lane = threadIdx.x & 63;
   const long long ui = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (ui >= v.nub) return;
-  const int u = v.ub_order[ui];
-  const long long p0 = v.pair_ptr[u];
-  const int Ktot = (int)(v.pair_ptr[u + 1] - p0) * DP;
+  if (ui >= v.n_order) return;
+  // one 16-byte header per launch slot: {block, #pairs, first pair (lo, hi)}
+  const int4 hdr = reinterpret_cast<const int4*>(v.ub_order)[ui];
+  const int u = hdr.x;
+  if (u < 0) return;
+  const long long p0 = ((long long)(unsigned)hdr.z) | ((long long)hdr.w << 32);
+  const int npairs = hdr.y;
   const int i = lane & 15, kk = lane >> 4;
   v4f64 acc = {0.0, 0.0, 0.0, 0.0};
   const bool row_ok = i < D;
-  for (int k0 = 0; k0 < Ktot; k0 += 8) {
-    // two MFMA steps per trip: more loads in flight per wave
-    double a[2], b[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int k = k0 + 4 * h + kk;
-      a[h] = 0.0;
-      b[h] = 0.0;
-      if (row_ok && k < Ktot) {
-        const int pr = k / DP;
-        const int c = k - pr * DP;
-        const int si = v.pair_i[p0 + pr], sj = v.pair_j[p0 + pr];
-        a[h] = v.cm_Y[(size_t)si * YS + i * DP + c];
-        b[h] = v.cm_Y[(size_t)sj * YS + i * DP + c];
-      }
+  // Pairs are taken 64 at a time: one coalesced load brings the chunk's slot indices
+  // into the wave (lane l holds pair l), after which every Y gather address comes from
+  // a cross-lane read -- no dependent index load in front of each gather, and eight
+  // gathers per lane are in flight per trip.
+  for (int c0 = 0; c0 < npairs; c0 += 64) {
+    const int nch = min(64, npairs - c0);
+    int my_si = 0, my_sj = 0;
+    if (lane < nch) {
+      my_si = v.pair_i[p0 + c0 + lane];
+      my_sj = v.pair_j[p0 + c0 + lane];
     }
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], acc, 0, 0, 0);
+    const int Kc = nch * DP;
+    for (int k0 = 0; k0 < Kc; k0 += 16) {
+      double a[4], b[4];
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const int k = k0 + 4 * h + kk;
+        const int pr = min(k / DP, 63);
+        const int c = k - (k / DP) * DP;
+        const int si = __shfl(my_si, pr, 64), sj = __shfl(my_sj, pr, 64);
+        a[h] = 0.0;
+        b[h] = 0.0;
+        if (row_ok && k < Kc) {
+          a[h] = v.cm_Y[(size_t)si * YS + i * DP + c];
+          b[h] = v.cm_Y[(size_t)sj * YS + i * DP + c];
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < 4; ++h) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[h], b[h], acc, 0, 0, 0);
+    }
   }
   double* out = v.red + L.ub + (size_t)u * D * D;
   const int col = lane & 15;
@@ -614,23 +698,13 @@ __global__ __launch_bounds__(256) void schur_offdiag_kernel(DeviceView v, RedLay
 }
 
 // ------------------------------------------------------------------------------
-// expand_S (part of class 3's epilogue, timed as TMI_BA_K_REDUCE): scatter the
-// (all-reduced) upper blocks into both triangles of the BSR matrix and add the
-// LM diagonal clamp(U_aa) / radius to the diagonal blocks; padding rows get 1.
+// finish_diag (timed as TMI_BA_K_REDUCE): diagonal blocks of S = (all-reduced)
+// raw diagonal block + LM diagonal clamp(U_aa) / radius; padding rows get 1.
+// The off-diagonal blocks need no post-processing: S is symmetric and the
+// upper blocks are used where schur_offdiag (and the all-reduce) left them.
 // ------------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(256) void expand_offdiag_kernel(DeviceView v, RedLayout L) {
-  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= (long long)v.nub * D * D) return;
-  const long long u = e / (D * D);
-  const int w = (int)(e - u * (D * D));
-  const int a = w / D, b = w - a * D;
-  const double val = v.red[L.ub + e];
-  v.S[(size_t)v.ub_pos[u] * D * D + a * D + b] = val;
-  v.S[(size_t)v.ub_pos_t[u] * D * D + b * D + a] = val;
-}
-template <int D>
-__global__ __launch_bounds__(256) void expand_diag_kernel(DeviceView v, RedLayout L, double inv_radius,
+__global__ __launch_bounds__(256) void finish_diag_kernel(DeviceView v, RedLayout L, double inv_radius,
                                                           double lm_lo, double lm_hi) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= v.Nrb * D * D) return;
@@ -646,7 +720,7 @@ __global__ __launch_bounds__(256) void expand_diag_kernel(DeviceView v, RedLayou
       val += fmin(fmax(d, lm_lo), lm_hi) * inv_radius;
     }
   }
-  v.S[(size_t)v.diag_pos[rb] * D * D + a * D + b] = val;
+  v.Sdiag[e] = val;
 }
 
 // ------------------------------------------------------------------------------
@@ -659,7 +733,7 @@ __global__ __launch_bounds__(64) void precond_invert_kernel(DeviceView v, int id
   __shared__ int bad;
   const int rb = blockIdx.x;
   const int t = threadIdx.x;
-  const double* src = v.S + (size_t)v.diag_pos[rb] * D * D;
+  const double* src = v.Sdiag + (size_t)rb * D * D;
   for (int e = t; e < D * D; e += 64) M[e] = src[e];
   if (t == 0) bad = 0;
   __syncthreads();
@@ -710,41 +784,93 @@ __global__ __launch_bounds__(64) void precond_invert_kernel(DeviceView v, int id
 }
 
 // ------------------------------------------------------------------------------
-// spmv (kernel class 5): q = S p on the BSR matrix, the PCG hot kernel (hot
-// loop 3).  One 256-thread workgroup per block row; lane = g * D + r owns row r
-// of every (4 G)-th block so the wave streams G contiguous D x D blocks per trip
-// (all fetched bytes used); partial rows are combined through LDS in a fixed
-// order.  Purely HBM-bound: 8 D^2 bytes per block per product.
+// spmv (kernel class 5): q = S p with S stored SYMMETRIC (upper blocks + diagonal),
+// the PCG hot kernel (hot loop 3).  Purely HBM-bound: every upper block (8 D^2
+// bytes) is read exactly once per product -- the algorithmic minimum.
+//
+//  rows pass: one 256-thread workgroup per block row i.  lane = g * D + r; the
+//    wave streams G = 64 / D contiguous blocks per trip.  For block u = (i, j)
+//    lane (g, r) forms   row product  sum_c U[r][c] x_j[c]   (accumulated for y_i)
+//    and               col product  sum_c U[c][r] x_i[c]   (= (U^T x_i)[r], the
+//    contribution to y_j) which is parked in tbuf[u][r].  Partial rows are
+//    combined through LDS in a fixed order; the diagonal block is added here.
+//  cols pass: y_j += sum over the blocks of column j of tbuf[u] (fixed order).
+// No atomics anywhere: bit-reproducible.
 // ------------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(256) void spmv_kernel(DeviceView v, const double* __restrict__ x,
-                                                   double* __restrict__ y) {
+__global__ __launch_bounds__(256) void spmv_rows_kernel(DeviceView v, const double* __restrict__ ub,
+                                                        const double* __restrict__ x,
+                                                        double* __restrict__ y) {
   constexpr int G = 64 / D;
   __shared__ double part[4][G][D];
   const int row = blockIdx.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int g = lane / D, r = lane - g * D;
-  double acc = 0.0;
   if (g < G) {
-    const int b0 = v.row_ptr[row], b1 = v.row_ptr[row + 1];
-    for (int b = b0 + w * G + g; b < b1; b += 4 * G) {
-      const double* blk = v.S + (size_t)b * D * D + r * D;
-      const double* xv = x + (size_t)v.col_idx[b] * D;
-      double t = 0.0;
+    double acc = 0.0;
+    double xi[D];
 #pragma unroll
-      for (int c = 0; c < D; ++c) t += blk[c] * xv[c];
+    for (int c = 0; c < D; ++c) xi[c] = x[(size_t)row * D + c];
+    const int u0 = v.urow_ptr[row], u1 = v.urow_ptr[row + 1];
+    for (int u = u0 + w * G + g; u < u1; u += 4 * G) {
+      const double* blk = ub + (size_t)u * D * D;
+      const double* xj = x + (size_t)v.ub_j[u] * D;
+      double t = 0.0, tt = 0.0;
+      // row r of the block: D contiguous doubles (8-byte aligned): 16-byte loads
+      double rowv[D];
+      const double* rp = blk + r * D;
+#pragma unroll
+      for (int c = 0; c + 1 < D; c += 2) {
+        const double2_a8 t2 = *reinterpret_cast<const double2_a8*>(rp + c);
+        rowv[c] = t2.x;
+        rowv[c + 1] = t2.y;
+      }
+      if (D & 1) rowv[D - 1] = rp[D - 1];
+#pragma unroll
+      for (int c = 0; c < D; ++c) {
+        t += rowv[c] * xj[c];
+        tt += blk[c * D + r] * xi[c];  // column r: the group's 9 lanes read 72 contiguous bytes
+      }
       acc += t;
+      v.tbuf[(size_t)u * D + r] = tt;
     }
     part[w][g][r] = acc;
   }
   __syncthreads();
   if (threadIdx.x < D) {
     double s = 0.0;
+    const double* dg = v.Sdiag + (size_t)row * D * D + threadIdx.x * D;
+#pragma unroll
+    for (int c = 0; c < D; ++c) s += dg[c] * x[(size_t)row * D + c];
 #pragma unroll
     for (int ww = 0; ww < 4; ++ww)
 #pragma unroll
       for (int gg = 0; gg < G; ++gg) s += part[ww][gg][threadIdx.x];
     y[(size_t)row * D + threadIdx.x] = s;
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void spmv_cols_kernel(DeviceView v, double* __restrict__ y) {
+  constexpr int G = 64 / D;
+  __shared__ double part[4][G][D];
+  const int col = blockIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int g = lane / D, r = lane - g * D;
+  if (g < G) {
+    double acc = 0.0;
+    const int k0 = v.ucol_ptr[col], k1 = v.ucol_ptr[col + 1];
+    for (int k = k0 + w * G + g; k < k1; k += 4 * G) acc += v.tbuf[(size_t)v.ucol_u[k] * D + r];
+    part[w][g][r] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x < D) {
+    double s = y[(size_t)col * D + threadIdx.x];
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww)
+#pragma unroll
+      for (int gg = 0; gg < G; ++gg) s += part[ww][gg][threadIdx.x];
+    y[(size_t)col * D + threadIdx.x] = s;
   }
 }
 
@@ -809,9 +935,12 @@ __global__ __launch_bounds__(1024) void pcg_a_kernel(DeviceView v, int n, int it
 }
 
 // pq = p.q; alpha = rho / pq; x += alpha p; r -= alpha q (unless reset);
-// Q1 = -x.(b + r); zeta = it (Q1 - Q0) / Q1
+// Q1 = -x.(b + r); zeta = it (Q1 - Q0) / Q1;  and then, already for the NEXT
+// iteration, z = M^-1 r, rho = r.z, beta = rho / last_rho, p = z + beta p -- so one
+// PCG iteration is three launches (spmv rows, spmv cols, this).
 // stage 0: everything; stage 1 (residual reset): update x only, stop before r;
-// stage 2: r = b - t (t = S x), then Q1, zeta.
+// stage 2: r = b - t (t = S x), then Q1, zeta and the next-iteration prologue.
+template <int D>
 __global__ __launch_bounds__(1024) void pcg_b_kernel(DeviceView v, const double* __restrict__ b, int n,
                                                      int it, int stage) {
   __shared__ double sh[16];
@@ -851,6 +980,31 @@ __global__ __launch_bounds__(1024) void pcg_b_kernel(DeviceView v, const double*
     v.scal[SC_ZETA] = it * (Q1 - Q0) / Q1;
     v.scal[SC_Q0] = Q1;
   }
+  // ---- prologue of iteration it + 1 (cg_r written above is re-read by other threads)
+  __syncthreads();
+  double lz = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const int rb = i / D, a = i - rb * D;
+    const double* M = v.Minv + (size_t)rb * D * D + a * D;
+    const double* rr = v.cg_r + (size_t)rb * D;
+    double z = 0.0;
+#pragma unroll
+    for (int c = 0; c < D; ++c) z += M[c] * rr[c];
+    v.cg_z[i] = z;
+    lz += z * v.cg_r[i];
+  }
+  const double rho = block1024_sum(lz, sh);
+  const double last_rho = v.scal[SC_RHO];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    v.scal[SC_LAST_RHO] = last_rho;
+    v.scal[SC_RHO] = rho;
+    // rho == 0 here only matters if another iteration follows; the host stops first
+    // when zeta has converged, so the failure flags are raised by the NEXT call
+    v.scal[SC_RHO_BAD] = (rho == 0.0 || !isfinite(rho) || !isfinite(rho / last_rho)) ? 1.0 : 0.0;
+  }
+  const double beta = rho / last_rho;
+  for (int i = threadIdx.x; i < n; i += 1024) v.cg_p[i] = v.cg_z[i] + beta * v.cg_p[i];
 }
 
 // ------------------------------------------------------------------------------

@@ -334,39 +334,22 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S) 
     s.ub_j[u] = (int)(ukeys[u] & 0xffffffffu);
     *blocks.find(ukeys[u]) = (int)u;
   }
-  // BSR (both triangles + diagonal), columns ascending inside a row
+  // symmetric storage: row ranges of the (bi, bj)-sorted upper list and a column index
   s.nnzb = 2 * s.nub + s.Nrb;
-  s.row_ptr.assign(s.Nrb + 1, 0);
-  for (int i = 0; i < s.Nrb; ++i) s.row_ptr[i + 1] = 1;
+  s.urow_ptr.assign(s.Nrb + 1, 0);
+  s.ucol_ptr.assign(s.Nrb + 1, 0);
   for (int64_t u = 0; u < s.nub; ++u) {
-    s.row_ptr[s.ub_i[u] + 1]++;
-    s.row_ptr[s.ub_j[u] + 1]++;
+    s.urow_ptr[s.ub_i[u] + 1]++;
+    s.ucol_ptr[s.ub_j[u] + 1]++;
   }
-  for (int i = 0; i < s.Nrb; ++i) s.row_ptr[i + 1] += s.row_ptr[i];
-  s.col_idx.assign(s.nnzb, 0);
-  s.diag_pos.assign(s.Nrb, 0);
-  s.ub_pos.assign(s.nub, 0);
-  s.ub_pos_t.assign(s.nub, 0);
+  for (int i = 0; i < s.Nrb; ++i) {
+    s.urow_ptr[i + 1] += s.urow_ptr[i];
+    s.ucol_ptr[i + 1] += s.ucol_ptr[i];
+  }
+  s.ucol_u.assign(s.nub, 0);
   {
-    // row i = [lower blocks (j < i) ascending j | diagonal | upper blocks ascending j].
-    // The sorted upper list visits, for a fixed bj, the bi in ascending order,
-    // and for a fixed bi the bj in ascending order, so two fill cursors suffice.
-    std::vector<int> nlow(s.Nrb, 0);
-    for (int64_t u = 0; u < s.nub; ++u) nlow[s.ub_j[u]]++;
-    std::vector<int> low_fill(s.Nrb), up_fill(s.Nrb);
-    for (int i = 0; i < s.Nrb; ++i) {
-      low_fill[i] = s.row_ptr[i];
-      s.diag_pos[i] = s.row_ptr[i] + nlow[i];
-      s.col_idx[s.diag_pos[i]] = i;
-      up_fill[i] = s.diag_pos[i] + 1;
-    }
-    for (int64_t u = 0; u < s.nub; ++u) {
-      const int bi = s.ub_i[u], bj = s.ub_j[u];
-      s.ub_pos[u] = up_fill[bi];
-      s.col_idx[up_fill[bi]++] = bj;
-      s.ub_pos_t[u] = low_fill[bj];
-      s.col_idx[low_fill[bj]++] = bi;
-    }
+    std::vector<int> fill(s.ucol_ptr.begin(), s.ucol_ptr.end() - 1);
+    for (int64_t u = 0; u < s.nub; ++u) s.ucol_u[fill[s.ub_j[u]]++] = (int)u;  // ascending bi
   }
 
   // ---- pair lists from this rank's tracks ----------------------------------------
@@ -407,11 +390,38 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S) 
       fill[u]++;
     });
   }
-  s.ub_order.resize(s.nub);
-  std::iota(s.ub_order.begin(), s.ub_order.end(), 0);
-  std::stable_sort(s.ub_order.begin(), s.ub_order.end(), [&](int a, int b) {
-    return (s.pair_ptr[a + 1] - s.pair_ptr[a]) > (s.pair_ptr[b + 1] - s.pair_ptr[b]);
-  });
+  // Launch order of the upper blocks for schur_offdiag: one wavefront per block, four
+  // per workgroup, and workgroup w runs on XCD w % 8 (observed dispatch, used for speed
+  // only).  All blocks of a block row gather the SAME camera's Y records on their i
+  // side, so a row is kept on one XCD (row % 8) and rows are walked in order: the i
+  // side then hits that XCD's L2 and the j side (neighbouring rows look at the same
+  // tracks) the memory-side Infinity Cache.  -1 entries pad the shorter queues.
+  {
+    std::vector<std::vector<int>> q(8);
+    for (int64_t u = 0; u < s.nub; ++u) q[s.ub_i[u] & 7].push_back((int)u);
+    // inside a row: longest pair lists first (they are the stragglers)
+    for (auto& v : q) {
+      size_t b = 0;
+      while (b < v.size()) {
+        size_t e = b;
+        while (e < v.size() && s.ub_i[v[e]] == s.ub_i[v[b]]) ++e;
+        std::stable_sort(v.begin() + b, v.begin() + e, [&](int a, int c) {
+          return (s.pair_ptr[a + 1] - s.pair_ptr[a]) > (s.pair_ptr[c + 1] - s.pair_ptr[c]);
+        });
+        b = e;
+      }
+    }
+    size_t longest = 0;
+    for (auto& v : q) longest = std::max(longest, v.size());
+    const size_t groups = (longest + 3) / 4;
+    s.ub_order.assign(groups * 32, -1);
+    for (size_t m = 0; m < groups; ++m)
+      for (int x = 0; x < 8; ++x)
+        for (int t = 0; t < 4; ++t) {
+          const size_t idx = m * 4 + t;
+          if (idx < q[x].size()) s.ub_order[(m * 8 + x) * 4 + t] = q[x][idx];
+        }
+  }
   return TMI_BA_OK;
 }
 

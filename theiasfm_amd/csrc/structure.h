@@ -11,8 +11,8 @@
 //     reads element  slice_ptr[s] + 64 j + t  -- perfectly coalesced;
 //   * camera-major order: a slot per observation grouped by rblock, the order
 //     the per-camera reductions and the Schur pair gathers read;
-//   * the block structure of the reduced camera matrix S (BSR, both
-//     triangles) and, per structurally non-zero upper block (bi < bj), the
+//   * the block structure of the reduced camera matrix S (symmetric storage:
+//     upper blocks by rows + a column index for the transposed products) and, per structurally non-zero upper block (bi < bj), the
 //     list of observation pairs (slot_i, slot_j) whose tracks are seen by both
 //     cameras -- S_ij = - sum_pairs Y_i Y_j^T is then a gather, with no atomics
 //     and a fixed summation order (bit-reproducible).
@@ -61,17 +61,17 @@ struct Structure {
   // reduced camera matrix structure (identical on every rank)
   int64_t nub = 0;                // upper off-diagonal blocks (bi < bj)
   std::vector<int> ub_i, ub_j;    // [nub] sorted by (bi, bj)
-  int64_t nnzb = 0;               // BSR blocks, both triangles + diagonal
-  std::vector<int> row_ptr;       // [Nrb+1]
-  std::vector<int> col_idx;       // [nnzb]
-  std::vector<int> diag_pos;      // [Nrb] BSR position of (i, i)
-  std::vector<int> ub_pos;        // [nub] BSR position of (bi, bj)
-  std::vector<int> ub_pos_t;      // [nub] BSR position of (bj, bi)
+  int64_t nnzb = 0;               // blocks of S counting both triangles + diagonal (statistics)
+  // S is stored symmetric: the upper off-diagonal blocks in (bi, bj) order (rows are
+  // contiguous) plus the diagonal blocks.
+  std::vector<int> urow_ptr;      // [Nrb+1] upper blocks of block row i: [urow_ptr[i], urow_ptr[i+1])
+  std::vector<int> ucol_ptr;      // [Nrb+1] upper blocks in block column j ...
+  std::vector<int> ucol_u;        // [nub]   ... listed here, ascending bi
   // pair lists (this rank's tracks only)
   int64_t npairs = 0;
   std::vector<int64_t> pair_ptr;  // [nub+1]
   std::vector<int> pair_i, pair_j;  // [npairs] camera-major slots
-  std::vector<int> ub_order;      // [nub] upper blocks by descending pair count
+  std::vector<int> ub_order;      // launch order of the upper blocks (XCD-aware, -1 = padding)
 
   std::string error;
 };

@@ -69,6 +69,18 @@ def main():
             fh.write(f"| {r['kernel']} | {r['calls']} | {r['avg_us']:.1f} | {r['pct']:.2f} | {f} | {w} | {g} |\n")
     import shutil
     shutil.copy(stats_file, os.path.join(out_dir, f"{tag}_kernel_stats.csv"))
+    # per kernel CLASS traffic (bench.py's classes) for the roofline `traffic` field
+    cls_of = {"linearize_kernel": "linearize", "point_eliminate_kernel": "point_eliminate",
+              "camera_diag_kernel": "camera_diag", "schur_offdiag_kernel": "schur_offdiag",
+              "precond_invert_kernel": "preconditioner", "spmv_rows_kernel": "spmv",
+              "spmv_cols_kernel": "spmv", "back_substitute_kernel": "back_substitute"}
+    classes = {}
+    for r in rows:
+        base = r["kernel"].split("<")[0]
+        if base in cls_of and "hbm_bytes_x2fetch" in r:
+            classes[cls_of[base]] = classes.get(cls_of[base], 0.0) + r["hbm_bytes_x2fetch"]
+    json.dump(dict(tag=tag, workload="venice1778", correction="2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes",
+                   classes=classes), open(os.path.join(out_dir, "pmc_latest.json"), "w"), indent=1)
     print(open(os.path.join(out_dir, f"{tag}_summary.md")).read())
 
 
