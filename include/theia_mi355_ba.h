@@ -321,14 +321,16 @@ void tmi_ba_solver_destroy(tmi_ba_solver* s);
 
 /* Per-observation evaluation on the device, exposed for parity tests:
  * residuals [2*N], the reduced camera Jacobian blocks [2*D*N] (row major
- * 2 x D, columns = free extrinsics then free intrinsics of the observing
- * camera) and point Jacobian blocks [2*point_dof*N], in the caller's
- * observation order, without loss correction or Jacobi scaling.
- * valid[i] = 0 where the reference functor returns false
+ * 2 x D, columns = free extrinsics then free PRIVATE intrinsics of the observing
+ * camera), the Jacobian w.r.t. the free intrinsics the camera SHARES with other
+ * views [2*D*N] (zero when it shares none) and point Jacobian blocks
+ * [2*point_dof*N], in the caller's observation order, without loss correction
+ * or Jacobi scaling.  valid[i] = 0 where the reference functor returns false
  * (reprojection_error.h:75-77).  Any output pointer may be NULL.            */
 int32_t tmi_ba_solver_evaluate(tmi_ba_solver* s, double* residuals,
-                               double* jac_camera, double* jac_point,
-                               uint8_t* valid, int32_t* block_dim);
+                               double* jac_camera, double* jac_shared,
+                               double* jac_point, uint8_t* valid,
+                               int32_t* block_dim);
 
 /* Host-only: statistics of the static structure the engine would build for
  * rank `rank` of `world` (no GPU needed).  Used by the CPU tests of the track

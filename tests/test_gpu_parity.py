@@ -23,8 +23,9 @@ pytestmark = pytest.mark.gpu
 
 
 def reduced_columns(prob, cam):
-    """Full-Jacobian column indices (into the oracle's 20 wide rows) of the
-    reduced camera block of `cam`: free extrinsics then free intrinsics."""
+    """Full-Jacobian column indices (into the oracle's 20 wide rows) of (a) the reduced
+    camera block of `cam`: free extrinsics then free PRIVATE intrinsics, (b) the free
+    intrinsics `cam` shares with other views (their own block on the device)."""
     f = int(prob.camera_flags[cam])
     cols = []
     if not f & abi.CAMERA_POSITION_CONSTANT:
@@ -32,15 +33,16 @@ def reduced_columns(prob, cam):
     if not f & abi.CAMERA_ORIENTATION_CONSTANT:
         cols += [3, 4, 5]
     g = int(prob.camera_group[cam])
+    a, b = prob.group_offset[g], prob.group_offset[g + 1]
+    free = [6 + i for i in range(b - a) if not prob.intrinsics_constant[a + i]]
     if (prob.camera_group == g).sum() == 1:
-        a, b = prob.group_offset[g], prob.group_offset[g + 1]
-        cols += [6 + i for i in range(b - a) if not prob.intrinsics_constant[a + i]]
-    return cols
+        return cols + free, []
+    return cols, free
 
 
-def mixed_problem(seed, models, bits=abi.INTRINSICS_ALL):
+def mixed_problem(seed, models, bits=abi.INTRINSICS_ALL, share=1):
     p = synth.make_problem(16, 300, 1500, seed=seed, scene="ring", spread=0.5, models=models,
-                           intrinsics_to_optimize=bits)
+                           intrinsics_to_optimize=bits, shared_group_size=share)
     return p
 
 
@@ -55,25 +57,28 @@ def mixed_problem(seed, models, bits=abi.INTRINSICS_ALL):
      abi.INTRINSICS_FOCAL_LENGTH | abi.INTRINSICS_PRINCIPAL_POINTS | abi.INTRINSICS_RADIAL_DISTORTION),
 ])
 @pytest.mark.parametrize("dof", [3, 4])
-def test_residuals_and_jacobians_match_oracle(models, bits, dof):
-    prob = mixed_problem(21, models, bits)
+@pytest.mark.parametrize("share", [1, 3])
+def test_residuals_and_jacobians_match_oracle(models, bits, dof, share):
+    prob = mixed_problem(21, models, bits, share)
     prob.camera_flags[1] = abi.CAMERA_POSITION_CONSTANT
     prob.camera_flags[2] = abi.CAMERA_ORIENTATION_CONSTANT
     prob.points[:, 3] = np.random.default_rng(2).uniform(0.9, 1.1, prob.num_points)
     prob.points[:, :3] *= prob.points[:, 3:4]
     r_o, J_o, ok_o = oracle.evaluate(prob)
     s = lib.Solver(prob, abi.default_options(point_dof=dof))
-    r_d, A_d, Jp_d, ok_d, D = s.evaluate(dof)
+    r_d, A_d, A1_d, Jp_d, ok_d, D = s.evaluate(dof)
     s.close()
     assert (ok_o == 1).all() and (ok_d == 1).all()
     assert np.abs(r_d - r_o).max() < 1e-9
     worst = 0.0
     for i in range(prob.num_observations):
-        cols = reduced_columns(prob, int(prob.obs_camera[i]))
-        ref = J_o[i][:, cols]
-        got = A_d[i][:, :len(cols)]
-        worst = max(worst, (np.abs(got - ref) / np.maximum(1.0, np.abs(ref))).max())
-        assert np.all(A_d[i][:, len(cols):] == 0.0)
+        cols, shared = reduced_columns(prob, int(prob.obs_camera[i]))
+        for got_all, cc in ((A_d[i], cols), (A1_d[i], shared)):
+            if cc:
+                ref = J_o[i][:, cc]
+                got = got_all[:, :len(cc)]
+                worst = max(worst, (np.abs(got - ref) / np.maximum(1.0, np.abs(ref))).max())
+            assert np.all(got_all[:, len(cc):] == 0.0)
     assert worst < 1e-9, worst
     refp = J_o[:, :, 16:16 + dof]
     assert (np.abs(Jp_d - refp) / np.maximum(1.0, np.abs(refp))).max() < 1e-9
@@ -83,7 +88,7 @@ def test_invalid_observation_is_flagged():
     prob = synth.make_problem(3, 10, 30, seed=5, scene="allsee")
     prob.points[0, :3] = prob.extrinsics[0, :3]
     s = lib.Solver(prob, abi.default_options(point_dof=4))
-    _, _, _, ok, _ = s.evaluate(4)
+    _, _, _, _, ok, _ = s.evaluate(4)
     _, _, ok_o = oracle.evaluate(prob)
     assert (ok == ok_o).all() and ok.sum() == prob.num_observations - 1
     st, summ = s.solve(abi.default_options(point_dof=4))
@@ -165,27 +170,52 @@ def test_constant_blocks_are_untouched():
 
 
 def test_fountain11_fixture_known_answer_and_ba(golden_dir):
-    # the reference's own golden data (data/sfm/fountain11.bin)
-    prob = abi.Problem.load(os.path.join(golden_dir, "fountain11_flat.npz"))
+    # the reference's own golden data (data/sfm/fountain11.bin): 11 views
+    # sharing ONE intrinsics group; default options free {f, k1, k2} of that shared block
+    base = abi.Problem.load(os.path.join(golden_dir, "fountain11_flat.npz"))
     known = json.load(open(os.path.join(golden_dir, "fountain11_known.json")))
-    # one intrinsics group shared by the 11 views: the device path needs the
-    # shared block constant (intrinsics NONE, the 1DSfM flag-file setting)
-    prob.set_intrinsics_to_optimize(abi.INTRINSICS_NONE)
-    for solver in (abi.SPARSE_SCHUR, abi.ITERATIVE_SCHUR):
-        dev, ora = run_both(prob, linear_solver_type=solver, point_dof=4)
-        s_d = dev[1]
-        assert abs(s_d.initial_cost - known["survey_cost"]) < 5e-7
-        assert abs(s_d.initial_rmse - known["survey_rmse"]) < 5e-7
-        assert s_d.final_cost <= s_d.initial_cost
-        assert_same_solution(dev, ora, scale=10.0)
-        assert np.abs(dev[2].extrinsics - prob.extrinsics).max() < 1e-2
+    for bits in (abi.INTRINSICS_DEFAULT, abi.INTRINSICS_NONE, abi.INTRINSICS_ALL):
+        prob = base.copy()
+        prob.set_intrinsics_to_optimize(bits)
+        for solver in (abi.SPARSE_SCHUR, abi.ITERATIVE_SCHUR):
+            dev, ora = run_both(prob, linear_solver_type=solver, point_dof=4)
+            s_d = dev[1]
+            assert abs(s_d.initial_cost - known["survey_cost"]) < 5e-7
+            assert abs(s_d.initial_rmse - known["survey_rmse"]) < 5e-7
+            assert s_d.final_cost <= s_d.initial_cost
+            assert_same_solution(dev, ora, scale=10.0, cost_rel=1e-8, rmse_abs=1e-8, param_rel=1e-5)
+            assert np.abs(dev[2].extrinsics - prob.extrinsics).max() < 1e-2
+            assert s_d.num_reduced_blocks == (11 if bits == abi.INTRINSICS_NONE else 12)
 
 
-def test_shared_free_intrinsics_are_rejected_loudly(golden_dir):
-    prob = abi.Problem.load(os.path.join(golden_dir, "fountain11_flat.npz"))
-    prob.set_intrinsics_to_optimize(abi.INTRINSICS_DEFAULT)
-    st, s = lib.solve(prob, abi.default_options())
-    assert st == 5 and s.success == 0
+def test_shared_and_private_intrinsics_groups_mixed():
+    # groups of 1..4 views, three camera models, robust loss: the shared-block path next
+    # to merged private blocks in one problem
+    prob = synth.make_problem(
+        30, 2000, 12000, seed=77, scene="ring", spread=0.4,
+        models=[(abi.PINHOLE, 0.5), (abi.PINHOLE_RADIAL_TANGENTIAL, 0.25), (abi.FISHEYE, 0.25)],
+        intrinsics_to_optimize=abi.INTRINSICS_FOCAL_LENGTH | abi.INTRINSICS_RADIAL_DISTORTION)
+    grp = np.array([0, 0, 0, 1, 2, 2, 3, 4, 4, 4, 4, 5] + list(range(6, 24)), dtype=np.int32)
+    # rebuild the group tables for the new assignment (model of a group = model of its first view)
+    first = np.array([int(np.nonzero(grp == g)[0][0]) for g in range(grp.max() + 1)])
+    old_model = prob.group_model[prob.camera_group[first]]
+    sizes = np.array([abi.INTRINSICS_SIZE[m] for m in old_model])
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    intr = np.concatenate([prob.intrinsics[prob.group_offset[prob.camera_group[c]]:
+                                           prob.group_offset[prob.camera_group[c] + 1]] for c in first])
+    p2 = abi.Problem(prob.extrinsics, grp, prob.camera_flags, old_model, off, intr,
+                     np.zeros(intr.size, np.uint8), prob.points, prob.point_constant,
+                     prob.obs_camera, prob.obs_point, prob.obs_xy)
+    p2.set_intrinsics_to_optimize(abi.INTRINSICS_FOCAL_LENGTH | abi.INTRINSICS_RADIAL_DISTORTION)
+    # pixels were generated with per-view intrinsics: re-synthesise with the shared ones
+    p2.obs_xy = synth.project(p2) + 0.5 * np.random.default_rng(1).normal(size=p2.obs_xy.shape)
+    p2.camera_flags[0] = abi.CAMERA_POSITION_CONSTANT | abi.CAMERA_ORIENTATION_CONSTANT
+    p2.point_constant[::40] = 1
+    for solver, loss in ((abi.DENSE_SCHUR, abi.LOSS_TRIVIAL), (abi.ITERATIVE_SCHUR, abi.LOSS_HUBER)):
+        dev, ora = run_both(p2, linear_solver_type=solver, point_dof=4, loss_function_type=loss,
+                            max_num_iterations=30)
+        assert_same_solution(dev, ora, scale=100.0, cost_rel=1e-8, rmse_abs=1e-8, param_rel=1e-5)
+        assert dev[1].final_cost < dev[1].initial_cost
 
 
 def test_bitwise_reproducible():

@@ -8,7 +8,8 @@
 //    pm_Jp  [2 DP][No_pad]   plane 2*col+row: point Jacobian
 //  camera-major (slot = obs_cpos[e], contiguous per reduced block)
 //    cm_Y   [Nslots][YS]     Y = A^T Jp L^-T  (D x DP row-major, YS = D*DP rounded up to even)
-//    cm_A   [Nslots][AS]     A row 0 (D), A row 1 (D), r~(2), r(2);  AS = 2 D + 4
+//    cm_A   [Nslots][AS]     A row 0 (D), A row 1 (D), r~(2), r(2) [, A1 row 0 (D), A1 row 1 (D)
+//                            when free intrinsics are shared between views]
 //  reduced system
 //    red    [nub*D*D | Nrb*D*D | Nrb*D | Nrb*D | Nrb*D | 8]   the all-reduce buffer:
 //           upper blocks, raw diagonal blocks, U diagonal, reduced gradient g~,
@@ -23,6 +24,8 @@ namespace tmi {
 
 struct DeviceView {
   int Nc, G, Np_pad, nslices, Nrb, D, DP;
+  int Ncam_rb;     // blocks [0, Ncam_rb) are cameras, [Ncam_rb, Nrb) shared intrinsics groups
+  int has_shared;
   int No_pad;
   int Nslots;
   int nub, nnzb;
@@ -49,7 +52,15 @@ struct DeviceView {
   const unsigned* cam_mask;
   const int* grp_model;
   const int* grp_off;
-  const int* rb_cam;
+  const int* rb_cam;           // camera of a camera block, -1 for a shared intrinsics block
+  const int* rb_grp;           // group whose intrinsics the block's intrinsics columns address
+  const int* cam_grb;          // [Nc] block of the camera's shared free intrinsics or -1
+  const unsigned* grp_mask;    // [G] free intrinsics bits of a shared group
+  const int* obs_gslot;        // [No_pad] slot of the (track, shared block) record or -1
+  const unsigned char* obs_gflag;  // bit0 first / bit1 last observation of its run
+  const int* cam_cross_u;      // [Nc] upper block (camera block, shared block) or -1
+  const int* grp_cam_ptr;      // views of each shared block
+  const int* grp_cams;
   const signed char* rb_cols;  // [Nrb][D]
   const int* cam_ptr;
   const int* urow_ptr;
@@ -66,6 +77,8 @@ struct DeviceView {
   double* pm_r;
   double* pm_A;
   double* pm_Jp;
+  double* pm_A1;    // [2 D][No_pad] shared-intrinsics Jacobian columns (has_shared only)
+  double* cam_part; // [Ncam_rb][2 D^2 + 3 D] per-view sums for the shared blocks
   double* cm_Y;
   double* cm_A;
   double* scale_c;  // [Nrb][D]

@@ -48,7 +48,8 @@ struct Launch {
   void (*cost)(const DeviceView&, hipStream_t, const double*, const double*, const double*, int,
                double, int, int, double*);
   void (*point_scale)(const DeviceView&, hipStream_t, int);
-  void (*camera_scale)(const DeviceView&, hipStream_t, const int*);
+  void (*shared_blocks)(const DeviceView&, hipStream_t, RedLayout);
+  void (*cross_add)(const DeviceView&, hipStream_t, RedLayout);
   void (*point_eliminate)(const DeviceView&, hipStream_t, double, double, double, int, double*, double*);
   void (*camera_diag)(const DeviceView&, hipStream_t, RedLayout);
   void (*schur_offdiag)(const DeviceView&, hipStream_t, RedLayout);
@@ -64,11 +65,11 @@ struct Launch {
   void (*dense_gather)(const DeviceView&, hipStream_t, const double*, double*, int);
 };
 
-template <int D, int DP>
+template <int D, int DP, bool SH>
 Launch make_launch() {
   Launch L;
   L.linearize = [](const DeviceView& v, hipStream_t st, int lt, double lw, int nb) {
-    hipLaunchKernelGGL((linearize_kernel<D, DP>), dim3(nb), dim3(256), 0, st, v, lt, lw, nb);
+    hipLaunchKernelGGL((linearize_kernel<D, DP, SH>), dim3(nb), dim3(256), 0, st, v, lt, lw, nb);
   };
   L.cost = [](const DeviceView& v, hipStream_t st, const double* e, const double* i, const double* p,
               int lt, double lw, int fl, int nb, double* partial) {
@@ -77,16 +78,23 @@ Launch make_launch() {
   L.point_scale = [](const DeviceView& v, hipStream_t st, int nb) {
     hipLaunchKernelGGL((point_scale_kernel<DP>), dim3(nb), dim3(256), 0, st, v);
   };
-  L.camera_scale = [](const DeviceView& v, hipStream_t st, const int* slot_obs) {
-    if (v.Nrb) hipLaunchKernelGGL((camera_scale_kernel<D>), dim3(v.Nrb), dim3(64), 0, st, v, slot_obs);
+  L.shared_blocks = [](const DeviceView& v, hipStream_t st, RedLayout R) {
+    if (!SH || v.Nrb == v.Ncam_rb) return;
+    hipLaunchKernelGGL((camera_group_partials_kernel<D, DP>), dim3(v.Ncam_rb), dim3(64), 0, st, v);
+    hipLaunchKernelGGL((group_reduce_kernel<D>), dim3(v.Nrb - v.Ncam_rb), dim3(256), 0, st, v, R);
+  };
+  L.cross_add = [](const DeviceView& v, hipStream_t st, RedLayout R) {
+    if (!SH || v.Nrb == v.Ncam_rb) return;
+    const int n = v.Ncam_rb * D * D;
+    hipLaunchKernelGGL((cross_add_kernel<D>), dim3((n + 255) / 256), dim3(256), 0, st, v, R);
   };
   L.point_eliminate = [](const DeviceView& v, hipStream_t st, double ir, double lo, double hi, int nb,
                          double* pm, double* vote) {
-    hipLaunchKernelGGL((point_eliminate_kernel<D, DP>), dim3(nb), dim3(256), 0, st, v, ir, lo, hi, nb, pm,
+    hipLaunchKernelGGL((point_eliminate_kernel<D, DP, SH>), dim3(nb), dim3(256), 0, st, v, ir, lo, hi, nb, pm,
                        vote);
   };
   L.camera_diag = [](const DeviceView& v, hipStream_t st, RedLayout R) {
-    if (v.Nrb) hipLaunchKernelGGL((camera_diag_kernel<D, DP>), dim3(v.Nrb), dim3(64), 0, st, v, R);
+    if (v.Nrb) hipLaunchKernelGGL((camera_diag_kernel<D, DP, SH>), dim3(v.Nrb), dim3(64), 0, st, v, R);
   };
   L.schur_offdiag = [](const DeviceView& v, hipStream_t st, RedLayout R) {
     if (v.nub)
@@ -113,7 +121,7 @@ Launch make_launch() {
     hipLaunchKernelGGL((pcg_b_kernel<D>), dim3(1), dim3(1024), 0, st, v, b, n, it, stage);
   };
   L.back_substitute = [](const DeviceView& v, hipStream_t st, double* pm_u, int nb, double* partial) {
-    hipLaunchKernelGGL((back_substitute_kernel<D, DP>), dim3(nb), dim3(256), 0, st, v, pm_u, nb, partial);
+    hipLaunchKernelGGL((back_substitute_kernel<D, DP, SH>), dim3(nb), dim3(256), 0, st, v, pm_u, nb, partial);
   };
   L.update_points = [](const DeviceView& v, hipStream_t st, int nb, double* partial) {
     hipLaunchKernelGGL((update_points_kernel<DP>), dim3(nb), dim3(256), 0, st, v, nb, partial);
@@ -133,11 +141,11 @@ Launch make_launch() {
   return L;
 }
 
-static bool get_launch(int D, int DP, Launch* out) {
-#define TMI_CASE(d, p)       \
-  if (D == d && DP == p) {   \
-    *out = make_launch<d, p>(); \
-    return true;             \
+static bool get_launch(int D, int DP, bool shared, Launch* out) {
+#define TMI_CASE(d, p)                                                     \
+  if (D == d && DP == p) {                                                 \
+    *out = shared ? make_launch<d, p, true>() : make_launch<d, p, false>(); \
+    return true;                                                           \
   }
   TMI_CASE(6, 3) TMI_CASE(6, 4) TMI_CASE(9, 3) TMI_CASE(9, 4)
   TMI_CASE(12, 3) TMI_CASE(12, 4) TMI_CASE(16, 3) TMI_CASE(16, 4)
@@ -167,7 +175,6 @@ struct tmi_ba_solver {
   std::vector<double> ext0, intr0, pts0;
   int n_intr = 0;
   // extra device arrays not in the view
-  int* d_slot_obs = nullptr;
   double* d_pm_u = nullptr;
   double* d_partial_max = nullptr;
   double* d_dense = nullptr;  // n_r x n_r when an exact solve is requested
@@ -395,7 +402,7 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
     return rc;
   }
   Structure& st = s->st;
-  if (!get_launch(st.D, s->DP, &s->launch)) {
+  if (!get_launch(st.D, s->DP, st.has_shared, &s->launch)) {
     s->error = "no kernel instantiation for this block size";
     return TMI_BA_ERR_UNSUPPORTED;
   }
@@ -408,6 +415,7 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   DeviceView& v = s->v;
   memset(&v, 0, sizeof(v));
   v.Nc = st.Nc; v.G = st.G; v.Np_pad = st.Np_pad; v.nslices = st.nslices; v.Nrb = st.Nrb;
+  v.Ncam_rb = st.Ncam_rb; v.has_shared = st.has_shared ? 1 : 0;
   v.D = D; v.DP = DP; v.No_pad = (int)st.No_pad; v.Nslots = (int)st.Nslots;
   v.nub = (int)st.nub; v.nnzb = (int)st.nnzb; v.npairs = st.npairs;
   v.n_order = (int)st.ub_order.size();
@@ -448,7 +456,9 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
 #define UPI(dst, vec) if ((rc = dev_upload(s, &p, vec))) return rc; dst = p;
     UPI(v.slice_ptr, st.slice_ptr) UPI(v.pt_k, st.pt_k) UPI(v.obs_cam, st.obs_cam)
     UPI(v.obs_cpos, st.obs_cpos) UPI(v.cam_grp, cam_grp) UPI(v.cam_rb, st.cam_rb)
-    UPI(v.grp_model, grp_model) UPI(v.grp_off, grp_off) UPI(v.rb_cam, st.rb_cam)
+    UPI(v.grp_model, grp_model) UPI(v.grp_off, grp_off) UPI(v.rb_cam, st.rb_cam) UPI(v.rb_grp, st.rb_grp)
+    UPI(v.cam_grb, st.cam_grb) UPI(v.obs_gslot, st.obs_gslot) UPI(v.cam_cross_u, st.cam_cross_u)
+    UPI(v.grp_cam_ptr, st.grp_cam_ptr) UPI(v.grp_cams, st.grp_cams)
     UPI(v.cam_ptr, st.cam_ptr) UPI(v.urow_ptr, st.urow_ptr) UPI(v.ub_i, st.ub_i) UPI(v.ub_j, st.ub_j)
     UPI(v.ucol_ptr, st.ucol_ptr) UPI(v.ucol_u, st.ucol_u)
     UPI(v.pair_i, st.pair_i) UPI(v.pair_j, st.pair_j)
@@ -468,21 +478,16 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
     }
 #undef UPI
     if ((rc = dev_upload(s, &pu, st.cam_mask))) return rc; v.cam_mask = pu;
+    if ((rc = dev_upload(s, &pu, st.grp_mask))) return rc; v.grp_mask = pu;
+    if ((rc = dev_upload(s, &pc, st.obs_gflag))) return rc; v.obs_gflag = pc;
     if ((rc = dev_upload(s, &pc, st.pt_const))) return rc; v.pt_const = pc;
     if ((rc = dev_upload(s, &ps, rb_cols))) return rc; v.rb_cols = ps;
     if ((rc = dev_upload(s, &pl, pair_ptr))) return rc; v.pair_ptr = pl;
     if ((rc = dev_upload(s, &pd, st.obs_xy))) return rc; v.obs_xy = pd;
   }
 #undef UP
-  // slot -> track-major element
-  {
-    std::vector<int> slot_obs((size_t)st.Nslots, 0);
-    for (int64_t e = 0; e < st.No_pad; ++e)
-      if (st.obs_cpos[e] >= 0) slot_obs[st.obs_cpos[e]] = (int)e;
-    if ((rc = dev_upload(s, &s->d_slot_obs, slot_obs))) return rc;
-  }
   const size_t N = (size_t)st.No_pad, NP = (size_t)st.Np_pad;
-  const int YS = ys_of(D, DP), AS = as_of(D), NS = sym_size(DP);
+  const int YS = ys_of(D, DP), AS = as_of(D, st.has_shared), NS = sym_size(DP);
   const int n_r = st.Nrb * D;
   s->nblocks_slices = (st.nslices + kSlicesPerBlock - 1) / kSlicesPerBlock;
   if (s->nblocks_slices < 1) s->nblocks_slices = 1;
@@ -491,6 +496,7 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   const int nbmax = std::max(s->nblocks_slices, s->nblocks_points);
 #define AL(ptr, n) if ((rc = dev_alloc(s, &ptr, (size_t)(n)))) return rc;
   AL(v.pm_r, 2 * N) AL(v.pm_A, 2 * D * N) AL(v.pm_Jp, 2 * DP * N) AL(s->d_pm_u, 2 * N)
+  AL(v.pm_A1, st.has_shared ? 2 * D * N : 1) AL(v.cam_part, (size_t)std::max(st.Ncam_rb, 1) * (2 * D * D + 3 * D))
   AL(v.cm_Y, (size_t)std::max<int64_t>(st.Nslots, 1) * YS) AL(v.cm_A, (size_t)std::max<int64_t>(st.Nslots, 1) * AS)
   AL(v.scale_c, std::max(n_r, 1)) AL(v.scale_p, NP * DP)
   AL(v.Vinv, NP * NS) AL(v.gp, NP * DP) AL(v.diag_p, NP * DP) AL(v.yp, NP * DP)
@@ -730,16 +736,35 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
   sum->initial_rmse = n_obs_global > 0 ? std::sqrt(hsc[1] / n_obs_global) : 0.0;
   double final_ss = hsc[1];
 
+  // builds the camera side of the normal equations from the current linearisation
+  auto build_camera_side = [&](double inv_radius) {
+    {
+      Timed t(s, TMI_BA_K_POINT_ELIMINATE);
+      s->launch.point_eliminate(v, stream, inv_radius, O->min_lm_diagonal, O->max_lm_diagonal, nbs,
+                                s->d_partial_max, d_sc + 6);
+    }
+    {
+      Timed t(s, TMI_BA_K_CAMERA_DIAG);
+      s->launch.camera_diag(v, stream, RL);
+      s->launch.shared_blocks(v, stream, RL);
+    }
+  };
   if (O->jacobi_scaling) {
+    // Jacobi scaling 1 / (1 + ||column||) from the UNSCALED Jacobian at the start point:
+    // track columns directly, camera-side columns as the diagonal of J_c^T J_c which a
+    // first pass of point_eliminate + camera_diag leaves in `red` (udiag).
     {
       Timed t(s, TMI_BA_K_REDUCE);
       s->launch.point_scale(v, stream, nbs);
-      s->launch.camera_scale(v, stream, s->d_slot_obs);
     }
-    CK(do_allreduce(s, v.scale_c, n_r));
+    build_camera_side(1.0);
+    CK(do_allreduce(s, v.red + RL.udiag, n_r));
     {
       Timed t(s, TMI_BA_K_REDUCE);
-      if (n_r) hipLaunchKernelGGL(camera_scale_finish_kernel, dim3((n_r + 255) / 256), dim3(256), 0, stream, v.scale_c, n_r);
+      if (n_r) {
+        CKH(hipMemcpyAsync(v.scale_c, v.red + RL.udiag, (size_t)n_r * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        hipLaunchKernelGGL(camera_scale_finish_kernel, dim3((n_r + 255) / 256), dim3(256), 0, stream, v.scale_c, n_r);
+      }
     }
     linearize();
   }
@@ -780,17 +805,11 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
     const double inv_radius = 1.0 / radius;
     CKH(hipMemsetAsync(v.flags, 0, FL_COUNT * sizeof(int), stream));
     CKH(hipMemsetAsync(d_sc, 0, 8 * sizeof(double), stream));
-    {
-      Timed t(s, TMI_BA_K_POINT_ELIMINATE);
-      s->launch.point_eliminate(v, stream, inv_radius, O->min_lm_diagonal, O->max_lm_diagonal, nbs, s->d_partial_max, d_sc + 6);
-    }
-    {
-      Timed t(s, TMI_BA_K_CAMERA_DIAG);
-      s->launch.camera_diag(v, stream, RL);
-    }
+    build_camera_side(inv_radius);
     {
       Timed t(s, TMI_BA_K_SCHUR_OFFDIAG);
       s->launch.schur_offdiag(v, stream, RL);
+      s->launch.cross_add(v, stream, RL);
     }
     CK(do_allreduce(s, v.red, RL.total));  // d_sc[6] carries the singular-track votes
     {
@@ -999,7 +1018,8 @@ int32_t tmi_ba_structure_stats(const tmi_ba_problem* P, int32_t rank, int32_t wo
 }
 
 int32_t tmi_ba_solver_evaluate(tmi_ba_solver* s, double* residuals, double* jac_camera,
-                               double* jac_point, uint8_t* valid, int32_t* block_dim) {
+                               double* jac_shared, double* jac_point, uint8_t* valid,
+                               int32_t* block_dim) {
   if (!s) return TMI_BA_ERR_INVALID_ARGUMENT;
   TMI_HIP(hipSetDevice(s->device));
   DeviceView& v = s->v;
@@ -1019,6 +1039,8 @@ int32_t tmi_ba_solver_evaluate(tmi_ba_solver* s, double* residuals, double* jac_
   if (residuals) TMI_HIP(hipMemcpyAsync(r.data(), v.pm_r, r.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
   if (jac_camera) TMI_HIP(hipMemcpyAsync(A.data(), v.pm_A, A.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
   if (jac_point) TMI_HIP(hipMemcpyAsync(Jp.data(), v.pm_Jp, Jp.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+  std::vector<double> A1((jac_shared && st.has_shared) ? (size_t)2 * D * N : 0);
+  if (!A1.empty()) TMI_HIP(hipMemcpyAsync(A1.data(), v.pm_A1, A1.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
   TMI_HIP(hipStreamSynchronize(stream));
   for (size_t e = 0; e < N; ++e) {
     const int64_t i = st.obs_orig[e];
@@ -1031,6 +1053,11 @@ int32_t tmi_ba_solver_evaluate(tmi_ba_solver* s, double* residuals, double* jac_
       for (int a = 0; a < D; ++a) {
         jac_camera[(size_t)2 * D * i + a] = A[(size_t)(2 * a) * N + e];
         jac_camera[(size_t)2 * D * i + D + a] = A[(size_t)(2 * a + 1) * N + e];
+      }
+    if (jac_shared)
+      for (int a = 0; a < D; ++a) {
+        jac_shared[(size_t)2 * D * i + a] = A1.empty() ? 0.0 : A1[(size_t)(2 * a) * N + e];
+        jac_shared[(size_t)2 * D * i + D + a] = A1.empty() ? 0.0 : A1[(size_t)(2 * a + 1) * N + e];
       }
     if (jac_point)
       for (int a = 0; a < DP; ++a) {

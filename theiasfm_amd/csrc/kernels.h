@@ -32,7 +32,7 @@ __host__ __device__ constexpr int sym_size(int n) { return n * (n + 1) / 2; }
 // camera-major record strides in doubles, rounded up to whole 64-byte sectors so that a
 // record never straddles an extra sector (gathers) and is written as full sectors
 __host__ __device__ constexpr int ys_of(int D, int DP) { return (D * DP + 7) & ~7; }
-__host__ __device__ constexpr int as_of(int D) { return (2 * D + 4 + 7) & ~7; }
+__host__ __device__ constexpr int as_of(int D, bool SH = false) { return ((SH ? 4 : 2) * D + 4 + 7) & ~7; }
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -112,7 +112,7 @@ struct LinearizeArgs {
   int point_dof_mask;  // unused
 };
 
-template <int D, int DP>
+template <int D, int DP, bool SH>
 __global__ __launch_bounds__(256) void linearize_kernel(DeviceView v, int loss_type, double loss_width,
                                                         int nblocks) {
   const int lane = threadIdx.x & 63;
@@ -152,6 +152,8 @@ __global__ __launch_bounds__(256) void linearize_kernel(DeviceView v, int loss_t
       if (!ok) {
         v.flags[FL_INVALID] = 1;
         for (int d = 0; d < 2 * D; ++d) v.pm_A[(size_t)d * N + e] = 0.0;
+        if (SH)
+          for (int d = 0; d < 2 * D; ++d) v.pm_A1[(size_t)d * N + e] = 0.0;
         for (int d = 0; d < 2 * DP; ++d) v.pm_Jp[(size_t)d * N + e] = 0.0;
         v.pm_r[e] = 0.0;
         v.pm_r[N + e] = 0.0;
@@ -195,6 +197,31 @@ __global__ __launch_bounds__(256) void linearize_kernel(DeviceView v, int loss_t
         }
       }
       for (int d = 2 * dst; d < 2 * D; ++d) v.pm_A[(size_t)d * N + e] = 0.0;
+      if (SH) {
+        // free intrinsics shared between views: their columns go to the group's own block
+        const int grb = v.cam_grb[cam];
+        int dst1 = 0;
+        if (grb >= 0) {
+          const unsigned gmask = v.grp_mask[grp];
+          const double* sc1 = v.scale_c + (size_t)grb * D;
+#pragma unroll
+          for (int c = 0; c < 10; ++c) {
+            if (gmask & (1u << c)) {
+              double j0 = Jint[0][c], j1 = Jint[1][c];
+              if (loss_type != 0) {
+                const double rtj = j0 * r[0] + j1 * r[1];
+                j0 = sqrt_rho1 * (j0 - asn * r[0] * rtj);
+                j1 = sqrt_rho1 * (j1 - asn * r[1] * rtj);
+              }
+              const double scl = sc1[dst1];
+              v.pm_A1[(size_t)(2 * dst1) * N + e] = j0 * scl;
+              v.pm_A1[(size_t)(2 * dst1 + 1) * N + e] = j1 * scl;
+              ++dst1;
+            }
+          }
+        }
+        for (int d = 2 * dst1; d < 2 * D; ++d) v.pm_A1[(size_t)d * N + e] = 0.0;
+      }
 #pragma unroll
       for (int a = 0; a < DP; ++a) {
         double j0 = pconst ? 0.0 : Jpt[0][a], j1 = pconst ? 0.0 : Jpt[1][a];
@@ -295,31 +322,8 @@ __global__ __launch_bounds__(256) void point_scale_kernel(DeviceView v) {
   for (int a = 0; a < DP; ++a) v.scale_p[(size_t)lp * DP + a] = 1.0 / (1.0 + sqrt(n2[a]));
 }
 
-// one wave per reduced block; slot_obs maps a camera-major slot to its
-// track-major element
-template <int D>
-__global__ __launch_bounds__(64) void camera_scale_kernel(DeviceView v, const int* __restrict__ slot_obs) {
-  const int rb = blockIdx.x;
-  const size_t N = (size_t)v.No_pad;
-  double n2[D];
-#pragma unroll
-  for (int a = 0; a < D; ++a) n2[a] = 0.0;
-  for (int s = v.cam_ptr[rb] + threadIdx.x; s < v.cam_ptr[rb + 1]; s += 64) {
-    const size_t e = (size_t)slot_obs[s];
-#pragma unroll
-    for (int a = 0; a < D; ++a) {
-      const double j0 = v.pm_A[(size_t)(2 * a) * N + e], j1 = v.pm_A[(size_t)(2 * a + 1) * N + e];
-      n2[a] += j0 * j0 + j1 * j1;
-    }
-  }
-#pragma unroll
-  for (int a = 0; a < D; ++a) {
-    const double t = wave_sum(n2[a]);
-    if (threadIdx.x == 0) v.scale_c[(size_t)rb * D + a] = t;
-  }
-}
-// With several ranks the per-camera sums are all-reduced between the two
-// kernels; scale_c holds the squared norm in between.
+// scale_c holds the (all-reduced) squared column norms U_aa of the camera side, taken
+// from a first unscaled pass of point_eliminate + camera_diag at the start point.
 __global__ void camera_scale_finish_kernel(double* scale_c, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) scale_c[i] = 1.0 / (1.0 + sqrt(scale_c[i]));
@@ -333,13 +337,13 @@ __global__ void camera_scale_finish_kernel(double* scale_c, int n) {
 // SchurEliminator (hot loop 2) restricted to what the camera side needs.
 // partial: [gmax_p] (max) per block.
 // ------------------------------------------------------------------------------
-template <int D, int DP>
+template <int D, int DP, bool SH>
 __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, double inv_radius,
                                                               double lm_lo, double lm_hi, int nblocks,
                                                               double* partial_max, double* singular_vote) {
   constexpr int NS = sym_size(DP);
   constexpr int YS = ys_of(D, DP);
-  constexpr int AS = as_of(D);
+  constexpr int AS = as_of(D, SH);
   constexpr int STP = (YS > AS ? YS : AS) + 2;  // LDS record pitch, +2 doubles: conflict-free b64/b128
   __shared__ __attribute__((aligned(16))) double stage[kSlicesPerBlock][32][STP];
   __shared__ int stage_cpos[kSlicesPerBlock][32];
@@ -459,10 +463,19 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
     const int K = (v.slice_ptr[s + 1] - v.slice_ptr[s]) >> 6;
     double* st = &stage[threadIdx.x >> 6][0][0];
     int* scp = &stage_cpos[threadIdx.x >> 6][0];
+    double Yg[SH ? YS : 1];  // running sum of the shared block's Y over the current run
+#pragma unroll
+    for (int i = 0; i < (SH ? YS : 1); ++i) Yg[i] = 0.0;
     for (int j = 0; j < K; ++j) {
       const size_t e = base + (size_t)j * 64;
-      int cpos = -1;
-      if (have_tp && j < k) cpos = v.obs_cpos[e];
+      int cpos = -1, gslot = -1, gflag = 0;
+      if (have_tp && j < k) {
+        cpos = v.obs_cpos[e];
+        if (SH) {
+          gslot = v.obs_gslot[e];
+          gflag = v.obs_gflag[e];
+        }
+      }
       double Yv[YS], Av[AS];
       if (cpos >= 0) {
         double J0[DP], J1[DP], Q0[DP], Q1[DP];
@@ -504,8 +517,31 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
         Av[2 * D + 1] = rt1;
         Av[2 * D + 2] = r0;
         Av[2 * D + 3] = r1;
+        if (SH) {
+          // shared intrinsics block: Y1 = A1^T Q summed over the track's observations of
+          // that block (they are adjacent); A1 rides in the A record for the per-view sums
+          if (gflag & 1) {
 #pragma unroll
-        for (int i = 2 * D + 4; i < AS; ++i) Av[i] = 0.0;
+            for (int i = 0; i < YS; ++i) Yg[i] = 0.0;
+          }
+#pragma unroll
+          for (int a = 0; a < D; ++a) {
+            double a0 = 0.0, a1 = 0.0;
+            if (gslot >= 0) {
+              a0 = v.pm_A1[(size_t)(2 * a) * N + e];
+              a1 = v.pm_A1[(size_t)(2 * a + 1) * N + e];
+            }
+            Av[2 * D + 4 + a] = a0;
+            Av[3 * D + 4 + a] = a1;
+#pragma unroll
+            for (int b = 0; b < DP; ++b) Yg[a * DP + b] += a0 * Q0[b] + a1 * Q1[b];
+          }
+#pragma unroll
+          for (int i = 4 * D + 4; i < AS; ++i) Av[i] = 0.0;
+        } else {
+#pragma unroll
+          for (int i = 2 * D + 4; i < AS; ++i) Av[i] = 0.0;
+        }
       }
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
@@ -550,6 +586,31 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (SH) {
+          // completed (track, shared block) sums of the same lanes
+          const bool emit = cpos >= 0 && gslot >= 0 && (gflag & 2);
+          if ((lane >> 5) == half) {
+            scp[lane & 31] = emit ? gslot : -1;
+            if (emit) {
+#pragma unroll
+              for (int i = 0; i < YS; i += 2)
+                *reinterpret_cast<double2*>(st + (lane & 31) * STP + i) = make_double2(Yg[i], Yg[i + 1]);
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          for (int c = lane; c < 32 * (YS / 2); c += 64) {
+            const int rec = c / (YS / 2), part = c - rec * (YS / 2);
+            const int cp = scp[rec];
+            if (cp >= 0)
+              *reinterpret_cast<double2*>(v.cm_Y + (size_t)cp * YS + 2 * part) =
+                  *reinterpret_cast<const double2*>(st + rec * STP + 2 * part);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
       }
     }
   }
@@ -572,11 +633,11 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
 //   S_cc(raw) = sum A^T A - Y Y^T,  U diag = sum diag(A^T A),
 //   g~ = sum A^T r~  (reduced gradient),  g_c = sum A^T r  (camera gradient).
 // ------------------------------------------------------------------------------
-template <int D, int DP>
+template <int D, int DP, bool SH>
 __global__ __launch_bounds__(64) void camera_diag_kernel(DeviceView v, RedLayout L) {
   constexpr int NS = sym_size(D);
   constexpr int YS = ys_of(D, DP);
-  constexpr int AS = as_of(D);
+  constexpr int AS = as_of(D, SH);
   const int rb = blockIdx.x;
   double Ss[NS], Ud[D], gt[D], gc[D];
 #pragma unroll
@@ -1008,10 +1069,133 @@ __global__ __launch_bounds__(1024) void pcg_b_kernel(DeviceView v, const double*
 }
 
 // ------------------------------------------------------------------------------
+// Shared intrinsics blocks (free intrinsics used by several views; kernel class 2).
+// camera_group_partials: one wave per view of a shared block walks the view's records
+//   and forms  C = sum A0^T A1 (cross block),  G = sum A1^T A1,  sum A1^T r~,
+//   sum A1^T r,  diag(G).
+// group_reduce: adds the views' G / gradients to the shared block's diagonal entries of
+//   `red` (fixed order), cross_add puts C into the (view, shared block) upper block.
+// cam_part[view block] = [C (D^2) | G (D^2) | gt (D) | gc (D) | ud (D)]
+// ------------------------------------------------------------------------------
+template <int D, int DP>
+__global__ __launch_bounds__(64) void camera_group_partials_kernel(DeviceView v) {
+  constexpr int AS = as_of(D, true);
+  const int rb = blockIdx.x;
+  const int cam = v.rb_cam[rb];
+  double* out = v.cam_part + (size_t)rb * (2 * D * D + 3 * D);
+  if (cam < 0 || v.cam_grb[cam] < 0) return;
+  {
+    double C[D][D];
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int b = 0; b < D; ++b) C[a][b] = 0.0;
+    for (int s = v.cam_ptr[rb] + threadIdx.x; s < v.cam_ptr[rb + 1]; s += 64) {
+      const double* rec = v.cm_A + (size_t)s * AS;
+      double A0[2][D], A1[2][D];
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        A0[0][a] = rec[a];
+        A0[1][a] = rec[D + a];
+        A1[0][a] = rec[2 * D + 4 + a];
+        A1[1][a] = rec[3 * D + 4 + a];
+      }
+#pragma unroll
+      for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b < D; ++b) C[a][b] += A0[0][a] * A1[0][b] + A0[1][a] * A1[1][b];
+    }
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int b = 0; b < D; ++b) {
+        const double t = wave_sum(C[a][b]);
+        if (threadIdx.x == 0) out[a * D + b] = t;
+      }
+  }
+  {
+    double G[sym_size(D)], gt[D], gc[D], ud[D];
+#pragma unroll
+    for (int i = 0; i < sym_size(D); ++i) G[i] = 0.0;
+#pragma unroll
+    for (int a = 0; a < D; ++a) gt[a] = gc[a] = ud[a] = 0.0;
+    for (int s = v.cam_ptr[rb] + threadIdx.x; s < v.cam_ptr[rb + 1]; s += 64) {
+      const double* rec = v.cm_A + (size_t)s * AS;
+      double A1[2][D];
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        A1[0][a] = rec[2 * D + 4 + a];
+        A1[1][a] = rec[3 * D + 4 + a];
+      }
+      const double rt0 = rec[2 * D], rt1 = rec[2 * D + 1], r0 = rec[2 * D + 2], r1 = rec[2 * D + 3];
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+#pragma unroll
+        for (int b = a; b < D; ++b) G[sym_idx(a, b, D)] += A1[0][a] * A1[0][b] + A1[1][a] * A1[1][b];
+        gt[a] += A1[0][a] * rt0 + A1[1][a] * rt1;
+        gc[a] += A1[0][a] * r0 + A1[1][a] * r1;
+        ud[a] += A1[0][a] * A1[0][a] + A1[1][a] * A1[1][a];
+      }
+    }
+    double* g = out + D * D;
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+#pragma unroll
+      for (int b = a; b < D; ++b) {
+        const double t = wave_sum(G[sym_idx(a, b, D)]);
+        if (threadIdx.x == 0) {
+          g[a * D + b] = t;
+          g[b * D + a] = t;
+        }
+      }
+      const double t1 = wave_sum(gt[a]), t2 = wave_sum(gc[a]), t3 = wave_sum(ud[a]);
+      if (threadIdx.x == 0) {
+        out[2 * D * D + a] = t1;
+        out[2 * D * D + D + a] = t2;
+        out[2 * D * D + 2 * D + a] = t3;
+      }
+    }
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void group_reduce_kernel(DeviceView v, RedLayout L) {
+  const int gi = blockIdx.x;          // shared block index - Ncam_rb
+  const int grb = v.Ncam_rb + gi;
+  constexpr int NE = D * D + 3 * D;
+  for (int e = threadIdx.x; e < NE; e += 256) {
+    double acc = 0.0;
+    for (int k = v.grp_cam_ptr[gi]; k < v.grp_cam_ptr[gi + 1]; ++k) {
+      const int rb = v.cam_rb[v.grp_cams[k]];
+      acc += v.cam_part[(size_t)rb * (2 * D * D + 3 * D) + D * D + e];
+    }
+    if (e < D * D)
+      v.red[L.diag + (size_t)grb * D * D + e] += acc;
+    else if (e < D * D + D)
+      v.red[L.gt + (size_t)grb * D + (e - D * D)] += acc;
+    else if (e < D * D + 2 * D)
+      v.red[L.gc + (size_t)grb * D + (e - D * D - D)] += acc;
+    else
+      v.red[L.udiag + (size_t)grb * D + (e - D * D - 2 * D)] += acc;
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void cross_add_kernel(DeviceView v, RedLayout L) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= v.Ncam_rb * D * D) return;
+  const int rb = e / (D * D);
+  const int cam = v.rb_cam[rb];
+  const int u = v.cam_cross_u[cam];
+  if (u < 0) return;
+  v.red[L.ub + (size_t)u * D * D + (e - rb * D * D)] += v.cam_part[(size_t)rb * (2 * D * D + 3 * D) + (e - rb * D * D)];
+}
+
+// ------------------------------------------------------------------------------
 // back_substitute (kernel class 8): y_p = (V+Dp)^-1 (g_p - W^T y_c) per track and
 // the model cost change -(J d).(r + J d / 2), d = -y (TrustRegionMinimizer).
 // ------------------------------------------------------------------------------
-template <int D, int DP>
+template <int D, int DP, bool SH>
 __global__ __launch_bounds__(256) void back_substitute_kernel(DeviceView v, double* __restrict__ pm_u,
                                                               int nblocks, double* partial) {
   constexpr int NS = sym_size(DP);
@@ -1030,7 +1214,8 @@ __global__ __launch_bounds__(256) void back_substitute_kernel(DeviceView v, doub
       for (int a = 0; a < DP; ++a) w[a] = v.gp[(size_t)a * NP + lp];
       for (int j = 0; j < k; ++j) {
         const size_t e = base + (size_t)j * 64;
-        const int rb = v.cam_rb[v.obs_cam[e]];
+        const int cam = v.obs_cam[e];
+        const int rb = v.cam_rb[cam];
         double u0 = 0.0, u1 = 0.0;
         if (rb >= 0) {
           const double* yc = v.yc + (size_t)rb * D;
@@ -1039,6 +1224,18 @@ __global__ __launch_bounds__(256) void back_substitute_kernel(DeviceView v, doub
             const double ya = yc[a];
             u0 += v.pm_A[(size_t)(2 * a) * N + e] * ya;
             u1 += v.pm_A[(size_t)(2 * a + 1) * N + e] * ya;
+          }
+        }
+        if (SH) {
+          const int grb = v.cam_grb[cam];
+          if (grb >= 0) {
+            const double* yg = v.yc + (size_t)grb * D;
+#pragma unroll
+            for (int a = 0; a < D; ++a) {
+              const double ya = yg[a];
+              u0 += v.pm_A1[(size_t)(2 * a) * N + e] * ya;
+              u1 += v.pm_A1[(size_t)(2 * a + 1) * N + e] * ya;
+            }
           }
         }
         pm_u[e] = u0;
@@ -1125,12 +1322,11 @@ __global__ __launch_bounds__(1024) void update_cameras_kernel(DeviceView v, doub
     const int code = v.rb_cols[i];
     if (code < 0) continue;
     const int rb = i / D;
-    const int cam = v.rb_cam[rb];
     const double d = -v.yc[i] * v.scale_c[i];
     if (code < 6)
-      v.ext_c[(size_t)cam * 6 + code] += d;
+      v.ext_c[(size_t)v.rb_cam[rb] * 6 + code] += d;
     else
-      v.intr_c[v.grp_off[v.cam_grp[cam]] + code - 6] += d;
+      v.intr_c[v.grp_off[v.rb_grp[rb]] + code - 6] += d;
     step += d * d;
   }
   const double s2 = block1024_sum(step, sh);
@@ -1139,11 +1335,15 @@ __global__ __launch_bounds__(1024) void update_cameras_kernel(DeviceView v, doub
   double xn = 0.0;
   for (int rb = threadIdx.x; rb < v.Nrb; rb += 1024) {
     const int cam = v.rb_cam[rb];
-    const unsigned m = v.cam_mask[cam];
-    if (m & 0x3f)
-      for (int a = 0; a < 6; ++a) xn += v.ext_c[(size_t)cam * 6 + a] * v.ext_c[(size_t)cam * 6 + a];
-    if (m >> 6) {
-      const int g = v.cam_grp[cam];
+    bool intr = true;  // a shared intrinsics block
+    if (cam >= 0) {
+      const unsigned m = v.cam_mask[cam];
+      if (m & 0x3f)
+        for (int a = 0; a < 6; ++a) xn += v.ext_c[(size_t)cam * 6 + a] * v.ext_c[(size_t)cam * 6 + a];
+      intr = (m >> 6) != 0;
+    }
+    if (intr) {
+      const int g = v.rb_grp[rb];
       for (int a = v.grp_off[g]; a < v.grp_off[g + 1]; ++a) xn += v.intr_c[a] * v.intr_c[a];
     }
   }

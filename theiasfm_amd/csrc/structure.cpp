@@ -117,43 +117,64 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S) 
     }
 
   // ---- reduced camera blocks --------------------------------------------------
+  // A view whose intrinsics group is private gets ONE block [free extrinsics | free
+  // intrinsics].  Free intrinsics SHARED by several views (one Ceres block per group,
+  // camera.h:247 / reconstruction.cc:113-124) become a block of their own, placed after
+  // the camera blocks; the views of such a group keep an extrinsics-only block.
   std::vector<int> grp_count(s.G, 0);
   for (int c = 0; c < s.Nc; ++c) grp_count[P->camera_group[c]]++;
   std::vector<uint32_t> grp_free(s.G, 0);
+  s.grp_mask.assign(s.G, 0);
+  s.has_shared = false;
   for (int g = 0; g < s.G; ++g) {
     const int o = P->group_offset[g], n = P->group_offset[g + 1] - o;
     for (int a = 0; a < n; ++a)
       if (!P->intrinsics_constant || !P->intrinsics_constant[o + a]) grp_free[g] |= 1u << a;
     if (grp_free[g] && grp_count[g] > 1) {
-      s.error =
-          "free intrinsics shared by several cameras are not supported by the device path yet "
-          "(give each view its own group or hold the shared intrinsics constant)";
-      return TMI_BA_ERR_UNSUPPORTED;
+      s.grp_mask[g] = grp_free[g];
+      s.has_shared = true;
     }
   }
   s.cam_mask.assign(s.Nc, 0);
   s.cam_rb.assign(s.Nc, -1);
+  s.cam_grb.assign(s.Nc, -1);
   int maxdim = 0;
   for (int c = 0; c < s.Nc; ++c) {
     const int f = P->camera_flags ? P->camera_flags[c] : 0;
+    const int g = P->camera_group[c];
     uint32_t m = 0;
     if (!(f & TMI_BA_CAMERA_POSITION_CONSTANT)) m |= 0x07;
     if (!(f & TMI_BA_CAMERA_ORIENTATION_CONSTANT)) m |= 0x38;
-    m |= grp_free[P->camera_group[c]] << 6;
+    if (!s.grp_mask[g]) m |= grp_free[g] << 6;
     s.cam_mask[c] = m;
     const int d = __builtin_popcount(m);
-    if (d > 0) {
+    // a view of a shared free group keeps a (possibly empty, all padding) block: its
+    // camera-major records carry the intrinsics Jacobian for the per-camera sums
+    if (d > 0 || s.grp_mask[g]) {
       s.cam_rb[c] = s.Nrb++;
       s.rb_cam.push_back(c);
+      s.rb_grp.push_back(g);
       s.rb_dim.push_back(d);
       maxdim = std::max(maxdim, d);
     }
   }
+  s.Ncam_rb = s.Nrb;
+  std::vector<int> grp_rb(s.G, -1);
+  for (int g = 0; g < s.G; ++g)
+    if (s.grp_mask[g]) {
+      grp_rb[g] = s.Nrb++;
+      s.rb_cam.push_back(-1);
+      s.rb_grp.push_back(g);
+      const int d = __builtin_popcount(s.grp_mask[g]);
+      s.rb_dim.push_back(d);
+      maxdim = std::max(maxdim, d);
+    }
+  for (int c = 0; c < s.Nc; ++c) s.cam_grb[c] = grp_rb[P->camera_group[c]];
   s.D = pad_dim(std::max(maxdim, 1));
   s.rb_cols.assign((size_t)s.Nrb * s.D, -1);
   for (int rb = 0; rb < s.Nrb; ++rb) {
     int col = 0;
-    const uint32_t m = s.cam_mask[s.rb_cam[rb]];
+    const uint32_t m = s.rb_cam[rb] >= 0 ? s.cam_mask[s.rb_cam[rb]] : (s.grp_mask[s.rb_grp[rb]] << 6);
     for (int b = 0; b < 16; ++b)
       if (m & (1u << b)) s.rb_cols[(size_t)rb * s.D + col++] = (int8_t)b;
   }
@@ -171,12 +192,15 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S) 
     std::vector<int64_t> fill(tptr.begin(), tptr.end() - 1);
     for (int64_t i = 0; i < No_all; ++i) tobs[fill[P->obs_point[i]]++] = i;
   }
-  // inside a track: ascending camera index (deterministic, and what the pair
-  // enumeration below assumes); reject a view observing a track twice
+  // inside a track: a deterministic order; reject a view observing a track twice
   for (int p = 0; p < s.Np_total; ++p) {
     auto b = tobs.begin() + tptr[p], e = tobs.begin() + tptr[p + 1];
+    // observations of one shared intrinsics block are kept adjacent (their Y factors
+    // are summed on the fly), then ascending camera index
     std::sort(b, e, [&](int64_t x, int64_t y) {
-      return P->obs_camera[x] != P->obs_camera[y] ? P->obs_camera[x] < P->obs_camera[y] : x < y;
+      const int cx = P->obs_camera[x], cy = P->obs_camera[y];
+      if (s.cam_grb[cx] != s.cam_grb[cy]) return s.cam_grb[cx] < s.cam_grb[cy];
+      return cx != cy ? cx < cy : x < y;
     });
     for (auto it = b; it != e && it + 1 != e; ++it)
       if (P->obs_camera[*it] == P->obs_camera[*(it + 1)]) {
@@ -265,22 +289,30 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S) 
   s.obs_xy.assign(2 * (size_t)s.No_pad, 0.0);
   s.obs_cpos.assign(s.No_pad, -1);
   s.obs_orig.assign(s.No_pad, -1);
+  s.obs_gslot.assign(s.has_shared ? s.No_pad : 0, -1);
+  s.obs_gflag.assign(s.has_shared ? s.No_pad : 0, 0);
   s.No = 0;
-  // camera-major slot counts
+  // camera-major slot counts: one slot per observation in its camera's block, and one
+  // slot per (track, shared intrinsics block) in that block
   std::vector<int> slot_cnt(s.Nrb + 1, 0);
   for (int lp = 0; lp < s.Np_pad; ++lp) {
     const int p = s.pt_orig[lp];
     if (p < 0) continue;
     const int sl = lp >> 6, t = lp & 63;
+    int prev_g = -1;
     for (int j = 0; j < klen[p]; ++j) {
       const int64_t i = tobs[tptr[p] + j];
       const int64_t e = (int64_t)s.slice_ptr[sl] + (int64_t)j * 64 + t;
-      s.obs_cam[e] = P->obs_camera[i];
+      const int c = P->obs_camera[i];
+      s.obs_cam[e] = c;
       s.obs_xy[2 * e] = P->obs_xy[2 * i];
       s.obs_xy[2 * e + 1] = P->obs_xy[2 * i + 1];
       s.obs_orig[e] = i;
-      const int rb = s.cam_rb[P->obs_camera[i]];
+      const int rb = s.cam_rb[c];
       if (rb >= 0) slot_cnt[rb + 1]++;
+      const int g = s.cam_grb[c];
+      if (g >= 0 && g != prev_g) slot_cnt[g + 1]++;
+      prev_g = g;
       s.No++;
     }
   }
@@ -293,10 +325,31 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S) 
       const int p = s.pt_orig[lp];
       if (p < 0) continue;
       const int sl = lp >> 6, t = lp & 63;
+      int prev_g = -1, cur_slot = -1;
       for (int j = 0; j < klen[p]; ++j) {
         const int64_t e = (int64_t)s.slice_ptr[sl] + (int64_t)j * 64 + t;
-        const int rb = s.cam_rb[s.obs_cam[e]];
+        const int c = s.obs_cam[e];
+        const int rb = s.cam_rb[c];
         if (rb >= 0) s.obs_cpos[e] = fill[rb]++;
+        if (!s.has_shared) continue;
+        const int g = s.cam_grb[c];
+        if (g >= 0) {
+          int flag = 0;
+          if (g != prev_g) {
+            cur_slot = fill[g]++;
+            flag |= 1;  // first observation of the run
+          }
+          s.obs_gslot[e] = cur_slot;
+          // last of the run?  look ahead
+          bool last = (j + 1 == klen[p]);
+          if (!last) {
+            const int64_t en = (int64_t)s.slice_ptr[sl] + (int64_t)(j + 1) * 64 + t;
+            last = s.cam_grb[s.obs_cam[en]] != g;
+          }
+          if (last) flag |= 2;
+          s.obs_gflag[e] = (uint8_t)flag;
+        }
+        prev_g = g;
       }
     }
   }
@@ -305,17 +358,38 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S) 
   KeyMap blocks;
   blocks.init(1 << 16);
   std::vector<int> rbs;
-  for (int p = 0; p < s.Np_total; ++p) {
-    if (klen[p] < 2) continue;
-    if (P->point_constant && P->point_constant[p]) continue;  // no elimination, no coupling
+  auto track_blocks = [&](auto&& cam_of, int k) {
+    // reduced blocks a track touches, ascending: camera blocks, then (once each) the
+    // shared intrinsics blocks
     rbs.clear();
-    for (int j = 0; j < klen[p]; ++j) {
-      const int rb = s.cam_rb[P->obs_camera[tobs[tptr[p] + j]]];
-      if (rb >= 0) rbs.push_back(rb);
+    int prev_g = -1;
+    for (int j = 0; j < k; ++j) {
+      const int c = cam_of(j);
+      if (s.cam_rb[c] >= 0) rbs.push_back(s.cam_rb[c]);
     }
+    for (int j = 0; j < k; ++j) {
+      const int g = s.cam_grb[cam_of(j)];
+      if (g >= 0 && g != prev_g) rbs.push_back(g);
+      prev_g = g;
+    }
+    std::sort(rbs.begin(), rbs.end());
+  };
+  for (int p = 0; p < s.Np_total; ++p) {
+    if (klen[p] < 1) continue;
+    if (P->point_constant && P->point_constant[p]) continue;  // no elimination, no coupling
+    track_blocks([&](int j) { return P->obs_camera[tobs[tptr[p] + j]]; }, klen[p]);
     for (size_t a = 0; a < rbs.size(); ++a)
       for (size_t b = a + 1; b < rbs.size(); ++b)
         blocks.put(((uint64_t)rbs[a] << 32) | (uint32_t)rbs[b], 0);
+  }
+  // J_c^T J_c couples a view's extrinsics with its shared intrinsics block even when
+  // none of its tracks is eliminated
+  if (s.has_shared) {
+    std::vector<char> seen(s.Nc, 0);
+    for (int64_t i = 0; i < No_all; ++i) seen[P->obs_camera[i]] = 1;
+    for (int c = 0; c < s.Nc; ++c)
+      if (seen[c] && s.cam_rb[c] >= 0 && s.cam_grb[c] >= 0)
+        blocks.put(((uint64_t)s.cam_rb[c] << 32) | (uint32_t)s.cam_grb[c], 0);
   }
   std::vector<uint64_t> ukeys;
   ukeys.reserve(blocks.n);
@@ -354,26 +428,27 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S) 
 
   // ---- pair lists from this rank's tracks ----------------------------------------
   s.pair_ptr.assign(s.nub + 1, 0);
-  std::vector<int> slots;
+  std::vector<std::pair<int, int>> rs;  // (block, slot) of a track's virtual observations
   auto for_each_pair = [&](auto&& fn) {
     for (int lp = 0; lp < s.Np_pad; ++lp) {
       const int p = s.pt_orig[lp];
-      if (p < 0 || klen[p] < 2 || s.pt_const[lp]) continue;
+      if (p < 0 || s.pt_const[lp]) continue;
       const int sl = lp >> 6, t = lp & 63;
-      rbs.clear();
-      slots.clear();
+      rs.clear();
+      int prev_g = -1;
       for (int j = 0; j < klen[p]; ++j) {
         const int64_t e = (int64_t)s.slice_ptr[sl] + (int64_t)j * 64 + t;
-        const int rb = s.cam_rb[s.obs_cam[e]];
-        if (rb >= 0) {
-          rbs.push_back(rb);
-          slots.push_back(s.obs_cpos[e]);
-        }
+        const int c = s.obs_cam[e];
+        if (s.cam_rb[c] >= 0) rs.emplace_back(s.cam_rb[c], s.obs_cpos[e]);
+        const int g = s.cam_grb[c];
+        if (g >= 0 && g != prev_g) rs.emplace_back(g, s.obs_gslot[e]);
+        prev_g = g;
       }
-      for (size_t a = 0; a < rbs.size(); ++a)
-        for (size_t b = a + 1; b < rbs.size(); ++b) {
-          const int u = *blocks.find(((uint64_t)rbs[a] << 32) | (uint32_t)rbs[b]);
-          fn(u, slots[a], slots[b]);
+      std::sort(rs.begin(), rs.end());
+      for (size_t a = 0; a < rs.size(); ++a)
+        for (size_t b = a + 1; b < rs.size(); ++b) {
+          const int u = *blocks.find(((uint64_t)rs[a].first << 32) | (uint32_t)rs[b].first);
+          fn(u, rs[a].second, rs[b].second);
         }
     }
   };
@@ -389,6 +464,23 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S) 
       s.pair_j[fill[u]] = sj;
       fill[u]++;
     });
+  }
+  // per view of a shared block: the S block (extrinsics, shared intrinsics) receiving
+  // its J_c^T J_c cross term; per shared block: its views
+  s.cam_cross_u.assign(s.Nc, -1);
+  s.grp_cam_ptr.assign(s.Nrb - s.Ncam_rb + 1, 0);
+  if (s.has_shared) {
+    for (int c = 0; c < s.Nc; ++c)
+      if (s.cam_rb[c] >= 0 && s.cam_grb[c] >= 0) {
+        int* u = blocks.find(((uint64_t)s.cam_rb[c] << 32) | (uint32_t)s.cam_grb[c]);
+        s.cam_cross_u[c] = u ? *u : -1;
+        s.grp_cam_ptr[s.cam_grb[c] - s.Ncam_rb + 1]++;
+      }
+    for (int g = 0; g < s.Nrb - s.Ncam_rb; ++g) s.grp_cam_ptr[g + 1] += s.grp_cam_ptr[g];
+    s.grp_cams.assign(s.grp_cam_ptr.back(), 0);
+    std::vector<int> fill(s.grp_cam_ptr.begin(), s.grp_cam_ptr.end() - 1);
+    for (int c = 0; c < s.Nc; ++c)
+      if (s.cam_rb[c] >= 0 && s.cam_grb[c] >= 0) s.grp_cams[fill[s.cam_grb[c] - s.Ncam_rb]++] = c;
   }
   // Launch order of the upper blocks for schur_offdiag: one wavefront per block, four
   // per workgroup, and workgroup w runs on XCD w % 8 (observed dispatch, used for speed

@@ -37,9 +37,19 @@ struct Structure {
   int Nrb = 0;
   int rank = 0, world = 1;
 
-  // rblocks
+  // rblocks: [0, Ncam_rb) belong to cameras, [Ncam_rb, Nrb) to shared intrinsics groups
+  bool has_shared = false;
+  int Ncam_rb = 0;
   std::vector<int> cam_rb;        // [Nc] rblock of a camera or -1
-  std::vector<int> rb_cam;        // [Nrb]
+  std::vector<int> cam_grb;       // [Nc] rblock of the camera's SHARED free intrinsics or -1
+  std::vector<int> rb_cam;        // [Nrb] camera of a camera block, -1 for a shared intrinsics block
+  std::vector<int> rb_grp;        // [Nrb] intrinsics group the block's intrinsics columns belong to
+  std::vector<uint32_t> grp_mask; // [G] free intrinsics of a SHARED group (0 otherwise)
+  std::vector<int> cam_cross_u;   // [Nc] upper block (cam_rb, cam_grb) or -1
+  std::vector<int> grp_cam_ptr;   // [Nrb-Ncam_rb+1] views of each shared block ...
+  std::vector<int> grp_cams;      //   ... listed here
+  std::vector<int> obs_gslot;     // [No_pad] slot of the (track, shared block) record or -1
+  std::vector<uint8_t> obs_gflag; // [No_pad] bit0 first / bit1 last observation of its run
   std::vector<int> rb_dim;        // [Nrb] true (unpadded) dimension
   std::vector<int8_t> rb_cols;    // [Nrb*D] 0..5 extrinsics idx, 6+j intrinsics idx, -1 padding
   std::vector<uint32_t> cam_mask; // [Nc] bit c set = column c of [ext(6) | intr(10)] is free

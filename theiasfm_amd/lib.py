@@ -83,7 +83,7 @@ def load():
     L.tmi_ba_solver_destroy.argtypes = [C.c_void_p]
     L.tmi_ba_solver_destroy.restype = None
     L.tmi_ba_solver_evaluate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                         C.POINTER(C.c_int32)]
+                                         C.c_void_p, C.POINTER(C.c_int32)]
     L.tmi_ba_solver_evaluate.restype = C.c_int32
     L.tmi_ba_structure_stats.argtypes = [P, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]
     L.tmi_ba_structure_stats.restype = C.c_int32
@@ -174,21 +174,23 @@ class Solver:
         return int(self._L.tmi_ba_solver_stream(self._h) or 0)
 
     def evaluate(self, point_dof: int):
-        """Device residuals [N,2], reduced camera Jacobians [N,2,D], point
-        Jacobians [N,2,point_dof], valid [N] in the caller's observation order."""
+        """Device residuals [N,2], reduced camera Jacobians [N,2,D], shared-intrinsics
+        Jacobians [N,2,D], point Jacobians [N,2,point_dof], valid [N] in the caller's
+        observation order, and D."""
         n = self.problem.num_observations
         bd = C.c_int32(0)
         # D is not known before the call: allocate for the largest block (16)
         r = np.zeros((n, 2))
         A = np.zeros(n * 2 * 16)
+        A1 = np.zeros(n * 2 * 16)
         Jp = np.zeros((n, 2, point_dof))
         valid = np.zeros(n, dtype=np.uint8)
-        st = self._L.tmi_ba_solver_evaluate(self._h, r.ctypes.data, A.ctypes.data, Jp.ctypes.data,
-                                            valid.ctypes.data, C.byref(bd))
+        st = self._L.tmi_ba_solver_evaluate(self._h, r.ctypes.data, A.ctypes.data, A1.ctypes.data,
+                                            Jp.ctypes.data, valid.ctypes.data, C.byref(bd))
         if st != 0:
             raise EngineError(st, "tmi_ba_solver_evaluate")
         D = bd.value
-        return r, A[: n * 2 * D].reshape(n, 2, D), Jp, valid, D
+        return r, A[: n * 2 * D].reshape(n, 2, D), A1[: n * 2 * D].reshape(n, 2, D), Jp, valid, D
 
     def close(self):
         if self._h:
