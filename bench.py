@@ -87,6 +87,10 @@ def main():
                     choices=["tiny", "ladybug49", "alamo", "venice1778"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--schur-mode", default="auto", choices=["auto", "explicit", "implicit"],
+                    help="ITERATIVE_SCHUR: form S explicitly (one all-reduce of S per LM iteration) "
+                         "or apply it implicitly (one small all-reduce per PCG iteration); "
+                         "auto = explicit on one GPU, implicit on several")
     args = ap.parse_args()
 
     import numpy as np
@@ -121,8 +125,9 @@ def main():
         solver_type, solver_name = abi.SPARSE_SCHUR, "SPARSE_SCHUR (exact, dense Cholesky of S)"
     else:
         solver_type, solver_name = abi.DENSE_SCHUR, "DENSE_SCHUR (exact)"
+    schur_mode = {"auto": 0, "explicit": 1, "implicit": 2}[args.schur_mode]
     base = dict(point_dof=3, linear_solver_type=solver_type, function_tolerance=0.0,
-                gradient_tolerance=0.0, parameter_tolerance=0.0, device=local)
+                gradient_tolerance=0.0, parameter_tolerance=0.0, device=local, schur_mode=schur_mode)
     opts = abi.default_options(max_num_iterations=max(args.warmup, 1), **base)
     t0 = time.perf_counter()
     solver = lib.Solver(prob, opts, rank, world)
@@ -187,7 +192,10 @@ def main():
         higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f64", data="synthetic",
         config=dict(workload=f"{args.workload}-synthetic", cameras=n_cam, tracks=n_pts,
                     observations=n_obs, camera_dof=dc, point_dof=dp, linear_solver=solver_name,
-                    loss="TRIVIAL", parallelism=f"tracks sharded x{world}, 1 all-reduce of the reduced camera system per LM iteration"),
+                    loss="TRIVIAL",
+                    schur_operator=("implicit (matrix-free)" if int(s.num_schur_pairs) == 0 and
+                                    solver_type == abi.ITERATIVE_SCHUR else "explicit block-sparse S"),
+                    parallelism=f"tracks sharded x{world}, 1 all-reduce of the reduced camera system per LM iteration"),
         lm_iterations_per_sec=steps_run / elapsed,
         pcg_iterations=int(s.num_linear_solver_iterations),
         initial_cost=s.initial_cost, final_cost=s.final_cost, initial_rmse=s.initial_rmse,

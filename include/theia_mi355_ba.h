@@ -207,6 +207,14 @@ typedef struct tmi_ba_options {
   int32_t profile_kernels; /* 1 = bracket every kernel class with HIP events
                               and report per-class times in the summary      */
   int32_t residual_precision; /* 64 (fp64). 32 reserved for the fp32 path    */
+  int32_t schur_mode;      /* ITERATIVE_SCHUR only.  1 = explicit: form the block
+                              sparse reduced camera matrix S (Schur complement) and
+                              run PCG on it; with several GPUs S is all-reduced once
+                              per LM iteration.  2 = implicit: S is never formed, every
+                              PCG product walks the observations (Ceres'
+                              ImplicitSchurComplement), with several GPUs one small
+                              all-reduce (the reduced vector) per PCG iteration.
+                              0 = auto: explicit on one GPU, implicit on several.    */
 } tmi_ba_options;
 
 /* ---- summary: BundleAdjustmentSummary + device-path extras --------------- */

@@ -128,13 +128,18 @@ def test_lm_matches_oracle_tiny(solver, dof):
     assert_same_solution(dev, ora, scale=30.0, cost_rel=1e-8, rmse_abs=1e-8, param_rel=1e-5)
 
 
-@pytest.mark.parametrize("solver", [abi.ITERATIVE_SCHUR, abi.DENSE_SCHUR])
-def test_lm_matches_oracle_ladybug49(solver):
-    # BASELINE.json configs[1] sized synthetic: 49 / 7776 / 31843, fp64, one GPU
+@pytest.mark.parametrize("solver,mode", [(abi.ITERATIVE_SCHUR, abi.SCHUR_EXPLICIT),
+                                         (abi.ITERATIVE_SCHUR, abi.SCHUR_IMPLICIT),
+                                         (abi.DENSE_SCHUR, abi.SCHUR_AUTO)])
+def test_lm_matches_oracle_ladybug49(solver, mode):
+    # BASELINE.json configs[1] sized synthetic: 49 / 7776 / 31843, fp64, one GPU.
+    # ITERATIVE_SCHUR with the reduced camera matrix formed explicitly and with the
+    # implicit (matrix-free) operator: the same PCG, the same result.
     prob = synth.config("ladybug49")
-    dev, ora = run_both(prob, linear_solver_type=solver, point_dof=3)
+    dev, ora = run_both(prob, linear_solver_type=solver, point_dof=3, schur_mode=mode)
     assert_same_solution(dev, ora, scale=100.0)
     assert dev[1].final_rmse < 0.6
+    assert (dev[1].num_schur_pairs == 0) == (mode == abi.SCHUR_IMPLICIT)
 
 
 def test_lm_matches_oracle_mixed_models_and_huber():
@@ -144,8 +149,8 @@ def test_lm_matches_oracle_mixed_models_and_huber():
         intrinsics_to_optimize=abi.INTRINSICS_FOCAL_LENGTH | abi.INTRINSICS_RADIAL_DISTORTION)
     # a few gross outliers so the robust loss matters
     prob.obs_xy[::97] += 40.0
-    for loss in (abi.LOSS_HUBER, abi.LOSS_CAUCHY):
-        dev, ora = run_both(prob, linear_solver_type=abi.ITERATIVE_SCHUR, point_dof=4,
+    for loss, mode in ((abi.LOSS_HUBER, abi.SCHUR_EXPLICIT), (abi.LOSS_CAUCHY, abi.SCHUR_IMPLICIT)):
+        dev, ora = run_both(prob, linear_solver_type=abi.ITERATIVE_SCHUR, point_dof=4, schur_mode=mode,
                             loss_function_type=loss, robust_loss_width=2.0, max_num_iterations=30)
         assert_same_solution(dev, ora, scale=100.0, cost_rel=1e-8, rmse_abs=1e-8, param_rel=1e-5)
 

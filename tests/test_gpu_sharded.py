@@ -47,12 +47,15 @@ class EmulatedAllReduce:
 
 
 @pytest.mark.parametrize("world", [2, 4])
-@pytest.mark.parametrize("solver_type", [abi.ITERATIVE_SCHUR, abi.DENSE_SCHUR])
-def test_sharded_solve_matches_single_rank(world, solver_type):
+@pytest.mark.parametrize("solver_type,mode", [(abi.ITERATIVE_SCHUR, abi.SCHUR_EXPLICIT),
+                                              (abi.ITERATIVE_SCHUR, abi.SCHUR_IMPLICIT),
+                                              (abi.ITERATIVE_SCHUR, abi.SCHUR_AUTO),
+                                              (abi.DENSE_SCHUR, abi.SCHUR_AUTO)])
+def test_sharded_solve_matches_single_rank(world, solver_type, mode):
     import torch
     torch.cuda.init()
     prob = synth.config("ladybug49")
-    opts = abi.default_options(linear_solver_type=solver_type, point_dof=3)
+    opts = abi.default_options(linear_solver_type=solver_type, point_dof=3, schur_mode=mode)
     single = prob.copy()
     st, s1 = lib.solve(single, opts)
     assert st == 0

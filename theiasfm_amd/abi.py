@@ -25,6 +25,7 @@ LOSS_TRIVIAL, LOSS_HUBER, LOSS_SOFTLONE, LOSS_CAUCHY, LOSS_ARCTAN, LOSS_TUKEY = 
 
 DENSE_QR, DENSE_SCHUR, SPARSE_SCHUR, ITERATIVE_SCHUR, CGNR = 1, 3, 4, 5, 6
 PRECOND_IDENTITY, PRECOND_JACOBI, PRECOND_SCHUR_JACOBI = 0, 1, 2
+SCHUR_AUTO, SCHUR_EXPLICIT, SCHUR_IMPLICIT = 0, 1, 2
 
 INTRINSICS_NONE = 0x00
 INTRINSICS_FOCAL_LENGTH = 0x01
@@ -103,6 +104,7 @@ class COptions(C.Structure):
         ("device", C.c_int32),
         ("profile_kernels", C.c_int32),
         ("residual_precision", C.c_int32),
+        ("schur_mode", C.c_int32),
     ]
 
 
@@ -173,6 +175,7 @@ def default_options(**overrides) -> COptions:
     o.device = -1
     o.profile_kernels = 0
     o.residual_precision = 64
+    o.schur_mode = 0
     for k, v in overrides.items():
         if not hasattr(o, k):
             raise AttributeError(f"tmi_ba_options has no field {k!r}")

@@ -56,8 +56,10 @@ struct Launch {
   void (*expand)(const DeviceView&, hipStream_t, RedLayout, double, double, double);
   void (*precond)(const DeviceView&, hipStream_t, int);
   void (*spmv)(const DeviceView&, hipStream_t, const double*, const double*, double*);
+  void (*implicit_spmv)(const DeviceView&, hipStream_t, RedLayout, const double*, double*, double*,
+                        double*, double, double, double, int, int);
   void (*pcg_a)(const DeviceView&, hipStream_t, int, int);
-  void (*pcg_b)(const DeviceView&, hipStream_t, const double*, int, int, int);
+  void (*pcg_b2)(const DeviceView&, hipStream_t, const double*, int, int, double*);
   void (*back_substitute)(const DeviceView&, hipStream_t, double*, int, double*);
   void (*update_points)(const DeviceView&, hipStream_t, int, double*);
   void (*update_cameras)(const DeviceView&, hipStream_t, double*);
@@ -114,11 +116,18 @@ Launch make_launch() {
     hipLaunchKernelGGL((spmv_rows_kernel<D>), dim3(v.Nrb), dim3(256), 0, st, v, ub, x, y);
     hipLaunchKernelGGL((spmv_cols_kernel<D>), dim3(v.Nrb), dim3(256), 0, st, v, y);
   };
+  L.implicit_spmv = [](const DeviceView& v, hipStream_t st, RedLayout R, const double* x, double* y,
+                       double* pm_u, double* cm_t, double ir, double lo, double hi, int add_diag, int nb) {
+    if (!v.Nrb) return;
+    hipLaunchKernelGGL((implicit_tracks_kernel<D, DP>), dim3(nb), dim3(256), 0, st, v, x, pm_u, cm_t);
+    hipLaunchKernelGGL((implicit_cameras_kernel<D, DP, SH>), dim3(v.Nrb), dim3(64), 0, st, v, R, x, cm_t, y,
+                       ir, lo, hi, add_diag);
+  };
   L.pcg_a = [](const DeviceView& v, hipStream_t st, int n, int it) {
     hipLaunchKernelGGL((pcg_a_kernel<D>), dim3(1), dim3(1024), 0, st, v, n, it);
   };
-  L.pcg_b = [](const DeviceView& v, hipStream_t st, const double* b, int n, int it, int stage) {
-    hipLaunchKernelGGL((pcg_b_kernel<D>), dim3(1), dim3(1024), 0, st, v, b, n, it, stage);
+  L.pcg_b2 = [](const DeviceView& v, hipStream_t st, const double* b, int mode, int nb, double* partial) {
+    hipLaunchKernelGGL((pcg_b2_kernel<D>), dim3(nb), dim3(256), 0, st, v, b, mode, nb, partial);
   };
   L.back_substitute = [](const DeviceView& v, hipStream_t st, double* pm_u, int nb, double* partial) {
     hipLaunchKernelGGL((back_substitute_kernel<D, DP, SH>), dim3(nb), dim3(256), 0, st, v, pm_u, nb, partial);
@@ -176,6 +185,10 @@ struct tmi_ba_solver {
   int n_intr = 0;
   // extra device arrays not in the view
   double* d_pm_u = nullptr;
+  double* d_cm_t = nullptr;   // implicit Schur operator: t_i per camera-major slot
+  bool implicit = false;      // S is never formed (schur_mode)
+  double cur_inv_radius = 0.0;
+  const tmi_ba_options* cur_opts = nullptr;
   double* d_partial_max = nullptr;
   double* d_dense = nullptr;  // n_r x n_r when an exact solve is requested
   int nblocks_slices = 0;     // grid of the per-track kernels
@@ -322,6 +335,7 @@ void tmi_ba_options_init(tmi_ba_options* o) {
   o->device = -1;
   o->profile_kernels = 0;
   o->residual_precision = 64;
+  o->schur_mode = 0;
 }
 
 int32_t tmi_ba_intrinsics_size(int32_t model) {
@@ -396,7 +410,21 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
     return TMI_BA_ERR_UNSUPPORTED;
   }
   s->DP = O->point_dof;
-  int rc = build_structure(P, rank, world, &s->st);
+  const bool iterative_type =
+      (O->linear_solver_type == TMI_BA_ITERATIVE_SCHUR || O->linear_solver_type == TMI_BA_CGNR);
+  if (O->schur_mode < 0 || O->schur_mode > 2) {
+    s->error = "schur_mode must be 0 (auto), 1 (explicit) or 2 (implicit)";
+    return TMI_BA_ERR_INVALID_ARGUMENT;
+  }
+  // implicit needs an iterative solver; auto = explicit on one GPU, implicit on several
+  s->implicit = iterative_type && (O->schur_mode == 2 || (O->schur_mode == 0 && world > 1));
+  int rc = build_structure(P, rank, world, &s->st, !s->implicit);
+  if (rc == TMI_BA_OK && s->implicit && s->st.has_shared) {
+    // shared intrinsics blocks are only wired into the explicit operator so far
+    s->implicit = false;
+    s->st = Structure();
+    rc = build_structure(P, rank, world, &s->st, true);
+  }
   if (rc) {
     s->error = s->st.error;
     return rc;
@@ -496,6 +524,7 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   const int nbmax = std::max(s->nblocks_slices, s->nblocks_points);
 #define AL(ptr, n) if ((rc = dev_alloc(s, &ptr, (size_t)(n)))) return rc;
   AL(v.pm_r, 2 * N) AL(v.pm_A, 2 * D * N) AL(v.pm_Jp, 2 * DP * N) AL(s->d_pm_u, 2 * N)
+  AL(s->d_cm_t, s->implicit ? (size_t)std::max<int64_t>(st.Nslots, 1) * 2 : 1)
   AL(v.pm_A1, st.has_shared ? 2 * D * N : 1) AL(v.cam_part, (size_t)std::max(st.Ncam_rb, 1) * (2 * D * D + 3 * D))
   AL(v.cm_Y, (size_t)std::max<int64_t>(st.Nslots, 1) * YS) AL(v.cm_A, (size_t)std::max<int64_t>(st.Nslots, 1) * AS)
   AL(v.scale_c, std::max(n_r, 1)) AL(v.scale_p, NP * DP)
@@ -504,7 +533,7 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   AL(v.tbuf, (size_t)std::max<int64_t>(st.nub, 1) * D) AL(v.Minv, (size_t)std::max(st.Nrb, 1) * D * D)
   AL(v.rhs, std::max(n_r, 1)) AL(v.yc, std::max(n_r, 1)) AL(v.cg_r, std::max(n_r, 1))
   AL(v.cg_z, std::max(n_r, 1)) AL(v.cg_p, std::max(n_r, 1)) AL(v.cg_q, std::max(n_r, 1))
-  AL(v.cg_t, std::max(n_r, 1)) AL(v.partial, (size_t)4 * nbmax) AL(s->d_partial_max, nbmax)
+  AL(v.cg_t, std::max(n_r, 1)) AL(v.partial, (size_t)4 * std::max(nbmax, (st.Nrb + 3) / 4 + 1)) AL(s->d_partial_max, nbmax)
   AL(v.scal, SC_COUNT) AL(v.flags, FL_COUNT)
 #undef AL
   TMI_HIP(hipMemsetAsync(v.scal, 0, SC_COUNT * sizeof(double), s->stream));
@@ -575,6 +604,26 @@ int32_t tmi_ba_solver_download(tmi_ba_solver* s, tmi_ba_problem* P) {
 
 // ---- the linear solve of one LM iteration ------------------------------------------
 // returns TMI_BA_OK; *usable = 0 for LINEAR_SOLVER_FAILURE
+// q = S x: explicit (symmetric block SpMV on the formed Schur complement) or implicit
+// (two passes over the observations; the reduced vector is all-reduced across ranks)
+static int apply_schur(tmi_ba_solver* s, const double* x, double* y) {
+  DeviceView& v = s->v;
+  const int n = v.Nrb * v.D;
+  if (!s->implicit) {
+    Timed t(s, TMI_BA_K_SPMV);
+    s->launch.spmv(v, s->stream, v.red + s->RL.ub, x, y);
+    return TMI_BA_OK;
+  }
+  {
+    Timed t(s, TMI_BA_K_SPMV);
+    const tmi_ba_options* O = s->cur_opts;
+    const int add_diag = (s->st.world <= 1 || s->st.rank == 0) ? 1 : 0;
+    s->launch.implicit_spmv(v, s->stream, s->RL, x, y, s->d_pm_u, s->d_cm_t, s->cur_inv_radius,
+                            O->min_lm_diagonal, O->max_lm_diagonal, add_diag, s->nblocks_slices);
+  }
+  return do_allreduce(s, y, n);
+}
+
 static int solve_reduced_pcg(tmi_ba_solver* s, const tmi_ba_options* O, int* usable, int64_t* iters) {
   DeviceView& v = s->v;
   const int n = v.Nrb * v.D;
@@ -592,22 +641,26 @@ static int solve_reduced_pcg(tmi_ba_solver* s, const tmi_ba_options* O, int* usa
   int it;
   for (it = 1;; ++it) {
     {
-      Timed t(s, TMI_BA_K_SPMV);
-      s->launch.spmv(v, s->stream, v.red + s->RL.ub, v.cg_p, v.cg_q);
+      const int rcs = apply_schur(s, v.cg_p, v.cg_q);
+      if (rcs) return rcs;
     }
     const bool reset = (it % 10 == 0);  // residual_reset_period
+    const int nbv = (v.Nrb + 3) / 4;
     {
-      // also prepares z, rho, p of iteration it + 1 (unless this is a reset step)
       Timed t(s, TMI_BA_K_PCG_VECTOR);
-      s->launch.pcg_b(v, s->stream, b, n, it, reset ? 1 : 0);
+      hipLaunchKernelGGL(pcg_b1_kernel, dim3(1), dim3(1024), 0, s->stream, v, n);
+      s->launch.pcg_b2(v, s->stream, b, reset ? 1 : 0, nbv, v.partial);
     }
     if (reset) {
-      {
-        Timed t(s, TMI_BA_K_SPMV);
-        s->launch.spmv(v, s->stream, v.red + s->RL.ub, v.yc, v.cg_t);
-      }
+      const int rcs = apply_schur(s, v.yc, v.cg_t);
+      if (rcs) return rcs;
       Timed t(s, TMI_BA_K_PCG_VECTOR);
-      s->launch.pcg_b(v, s->stream, b, n, it, 2);
+      s->launch.pcg_b2(v, s->stream, b, 2, nbv, v.partial);
+    }
+    {
+      // Q1, zeta, and z / rho / p of iteration it + 1
+      Timed t(s, TMI_BA_K_PCG_VECTOR);
+      hipLaunchKernelGGL(pcg_b3_kernel, dim3(1), dim3(1024), 0, s->stream, v, n, it, nbv, v.partial);
     }
     int rc = readback(s);
     if (rc) return rc;
@@ -687,6 +740,12 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
   const int lt = O->loss_function_type;
   const double lw = O->robust_loss_width;
   const bool iterative = (O->linear_solver_type == TMI_BA_ITERATIVE_SCHUR || O->linear_solver_type == TMI_BA_CGNR);
+  s->cur_opts = O;
+  if (s->implicit && !iterative) {
+    s->error = "this solver was created for the implicit Schur operator (ITERATIVE_SCHUR); "
+               "an exact linear solver type needs schur_mode = explicit at creation";
+    return fail(TMI_BA_ERR_INVALID_ARGUMENT);
+  }
   double* d_sc = v.red + RL.scalars;  // 8 device scalars that get all-reduced
 
   // ---- iteration zero ---------------------------------------------------------------
@@ -805,8 +864,9 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
     const double inv_radius = 1.0 / radius;
     CKH(hipMemsetAsync(v.flags, 0, FL_COUNT * sizeof(int), stream));
     CKH(hipMemsetAsync(d_sc, 0, 8 * sizeof(double), stream));
+    s->cur_inv_radius = inv_radius;
     build_camera_side(inv_radius);
-    {
+    if (!s->implicit) {
       Timed t(s, TMI_BA_K_SCHUR_OFFDIAG);
       s->launch.schur_offdiag(v, stream, RL);
       s->launch.cross_add(v, stream, RL);

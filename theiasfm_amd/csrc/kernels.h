@@ -936,6 +936,115 @@ __global__ __launch_bounds__(256) void spmv_cols_kernel(DeviceView v, double* __
 }
 
 // ------------------------------------------------------------------------------
+// Implicit Schur operator (kernel class 5, schur_mode = implicit): q = S p without
+// ever forming S (Ceres' ImplicitSchurComplement, the ITERATIVE_SCHUR path):
+//   S p = D_c p + sum_obs A_i^T t_i,   t_i = u_i - Jp_i z_track,
+//   u_i = A_i p_cam(i),   z = (V + D_p)^-1 sum_{i in track} Jp_i^T u_i.
+//  tracks pass : thread per track (SELL), writes t_i to the observation's camera-major slot
+//  cameras pass: one wave per camera block reduces A_i^T t_i over its records (fixed order)
+// Every product streams the observations once (track-major planes) plus the camera-major
+// A records; with several GPUs only the reduced vector q is all-reduced.
+// ------------------------------------------------------------------------------
+template <int D, int DP>
+__global__ __launch_bounds__(256) void implicit_tracks_kernel(DeviceView v, const double* __restrict__ x,
+                                                              double* __restrict__ pm_u,
+                                                              double* __restrict__ cm_t) {
+  constexpr int NS = sym_size(DP);
+  const int lane = threadIdx.x & 63;
+  const int s = blockIdx.x * kSlicesPerBlock + (threadIdx.x >> 6);
+  if (s >= v.nslices) return;
+  const int lp = s * 64 + lane;
+  const int k = v.pt_k[lp];
+  if (k == 0) return;
+  const size_t base = (size_t)v.slice_ptr[s] + lane;
+  const size_t N = (size_t)v.No_pad;
+  const size_t NP = (size_t)v.Np_pad;
+  double w[DP];
+#pragma unroll
+  for (int a = 0; a < DP; ++a) w[a] = 0.0;
+  for (int j = 0; j < k; ++j) {
+    const size_t e = base + (size_t)j * 64;
+    const int rb = v.cam_rb[v.obs_cam[e]];
+    double u0 = 0.0, u1 = 0.0;
+    if (rb >= 0) {
+      const double* xc = x + (size_t)rb * D;
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        const double xa = xc[a];
+        u0 += v.pm_A[(size_t)(2 * a) * N + e] * xa;
+        u1 += v.pm_A[(size_t)(2 * a + 1) * N + e] * xa;
+      }
+    }
+    pm_u[e] = u0;
+    pm_u[N + e] = u1;
+#pragma unroll
+    for (int a = 0; a < DP; ++a)
+      w[a] += v.pm_Jp[(size_t)(2 * a) * N + e] * u0 + v.pm_Jp[(size_t)(2 * a + 1) * N + e] * u1;
+  }
+  double Vi[NS], z[DP];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) Vi[i] = v.Vinv[(size_t)i * NP + lp];
+#pragma unroll
+  for (int a = 0; a < DP; ++a) {
+    double t = 0.0;
+#pragma unroll
+    for (int b = 0; b < DP; ++b) t += Vi[a <= b ? sym_idx(a, b, DP) : sym_idx(b, a, DP)] * w[b];
+    z[a] = t;
+  }
+  for (int j = 0; j < k; ++j) {
+    const size_t e = base + (size_t)j * 64;
+    const int cpos = v.obs_cpos[e];
+    if (cpos < 0) continue;
+    double t0 = pm_u[e], t1 = pm_u[N + e];
+#pragma unroll
+    for (int a = 0; a < DP; ++a) {
+      t0 -= v.pm_Jp[(size_t)(2 * a) * N + e] * z[a];
+      t1 -= v.pm_Jp[(size_t)(2 * a + 1) * N + e] * z[a];
+    }
+    *reinterpret_cast<double2*>(cm_t + (size_t)cpos * 2) = make_double2(t0, t1);
+  }
+}
+
+template <int D, int DP, bool SH>
+__global__ __launch_bounds__(64) void implicit_cameras_kernel(DeviceView v, RedLayout L,
+                                                              const double* __restrict__ x,
+                                                              const double* __restrict__ cm_t,
+                                                              double* __restrict__ y, double inv_radius,
+                                                              double lm_lo, double lm_hi, int add_diag) {
+  constexpr int AS = as_of(D, SH);
+  const int rb = blockIdx.x;
+  double acc[D];
+#pragma unroll
+  for (int a = 0; a < D; ++a) acc[a] = 0.0;
+  for (int s = v.cam_ptr[rb] + threadIdx.x; s < v.cam_ptr[rb + 1]; s += 64) {
+    const double* arec = v.cm_A + (size_t)s * AS;
+    const double2 t = *reinterpret_cast<const double2*>(cm_t + (size_t)s * 2);
+#pragma unroll
+    for (int a = 0; a < D; ++a) acc[a] += arec[a] * t.x + arec[D + a] * t.y;
+  }
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    double tot = wave_sum(acc[a]);
+    if (threadIdx.x == 0) {
+      // the damping (and the identity on padding rows) enters once: on rank 0 when the
+      // product is all-reduced afterwards
+      if (add_diag) {
+        const double xa = x[(size_t)rb * D + a];
+        if (v.rb_cols[(size_t)rb * D + a] < 0) {
+          tot = xa;
+        } else {
+          const double d = v.red[L.udiag + (size_t)rb * D + a];
+          tot += fmin(fmax(d, lm_lo), lm_hi) * inv_radius * xa;
+        }
+      } else if (v.rb_cols[(size_t)rb * D + a] < 0) {
+        tot = 0.0;
+      }
+      y[(size_t)rb * D + a] = tot;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------
 // PCG vector kernels (class 6), single 1024-thread workgroup each so that dot
 // products, the scalar recurrences and the vector updates of one half-step
 // share a launch and need no host round trip.  Restates
@@ -995,73 +1104,96 @@ __global__ __launch_bounds__(1024) void pcg_a_kernel(DeviceView v, int n, int it
     v.cg_p[i] = (it == 1) ? v.cg_z[i] : v.cg_z[i] + beta * v.cg_p[i];
 }
 
-// pq = p.q; alpha = rho / pq; x += alpha p; r -= alpha q (unless reset);
-// Q1 = -x.(b + r); zeta = it (Q1 - Q0) / Q1;  and then, already for the NEXT
-// iteration, z = M^-1 r, rho = r.z, beta = rho / last_rho, p = z + beta p -- so one
-// PCG iteration is three launches (spmv rows, spmv cols, this).
-// stage 0: everything; stage 1 (residual reset): update x only, stop before r;
-// stage 2: r = b - t (t = S x), then Q1, zeta and the next-iteration prologue.
-template <int D>
-__global__ __launch_bounds__(1024) void pcg_b_kernel(DeviceView v, const double* __restrict__ b, int n,
-                                                     int it, int stage) {
+// One PCG iteration after q = S p (ceres/conjugate_gradients_solver.cc restated) is
+// three light launches instead of one long single-workgroup kernel:
+//   pcg_b1 (1 workgroup)   pq = p.q, alpha = rho / pq
+//   pcg_b2 (many)          x += alpha p; r -= alpha q (or r = b - S x on a residual
+//                          reset); z = M^-1 r with one wave per reduced block (the
+//                          block's r is exchanged by wave shuffles); partial sums of
+//                          Q1 = -x.(b + r) and rho' = r.z
+//   pcg_b3 (1 workgroup)   Q1, zeta = it (Q1 - Q0) / Q1, rho', beta, p = z + beta p
+// mode 0: regular; mode 1: update x only (before the reset product); mode 2: r = b - t.
+__global__ __launch_bounds__(1024) void pcg_b1_kernel(DeviceView v, int n) {
   __shared__ double sh[16];
-  double alpha = 0.0;
-  if (stage != 2) {
-    double local = 0.0;
-    for (int i = threadIdx.x; i < n; i += 1024) local += v.cg_p[i] * v.cg_q[i];
-    const double pq = block1024_sum(local, sh);
-    if (pq <= 0.0 || !isfinite(pq)) {
-      // LINEAR_SOLVER_NO_CONVERGENCE: keep x, report zeta = -1 (stop)
-      if (threadIdx.x == 0) {
-        v.scal[SC_PQ] = pq;
-        v.scal[SC_ZETA] = -1.0;
-      }
-      return;
-    }
-    alpha = v.scal[SC_RHO] / pq;
-    if (threadIdx.x == 0) {
-      v.scal[SC_PQ] = pq;
-      v.scal[SC_ALPHA] = alpha;
-      if (!isfinite(alpha)) v.flags[FL_PCG_FAIL] = 1;
-    }
-    for (int i = threadIdx.x; i < n; i += 1024) {
-      v.yc[i] += alpha * v.cg_p[i];
-      if (stage == 0) v.cg_r[i] -= alpha * v.cg_q[i];
-    }
-    if (stage == 1) return;
-  } else {
-    for (int i = threadIdx.x; i < n; i += 1024) v.cg_r[i] = b[i] - v.cg_t[i];
-  }
   double local = 0.0;
-  for (int i = threadIdx.x; i < n; i += 1024) local -= v.yc[i] * (b[i] + v.cg_r[i]);
-  const double Q1 = block1024_sum(local, sh);
+  for (int i = threadIdx.x; i < n; i += 1024) local += v.cg_p[i] * v.cg_q[i];
+  const double pq = block1024_sum(local, sh);
+  if (threadIdx.x == 0) {
+    v.scal[SC_PQ] = pq;
+    const double alpha = v.scal[SC_RHO] / pq;
+    v.scal[SC_ALPHA] = alpha;
+    if (pq > 0.0 && isfinite(pq) && !isfinite(alpha)) v.flags[FL_PCG_FAIL] = 1;
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void pcg_b2_kernel(DeviceView v, const double* __restrict__ b, int mode,
+                                                     int nblocks, double* __restrict__ partial) {
+  const int lane = threadIdx.x & 63;
+  const int rb = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const double pq = v.scal[SC_PQ];
+  double acc[2] = {0.0, 0.0};
+  // LINEAR_SOLVER_NO_CONVERGENCE (pq <= 0): nothing moves, the host stops
+  if (rb < v.Nrb && pq > 0.0 && isfinite(pq)) {
+    const double alpha = v.scal[SC_ALPHA];
+    const int i = rb * D + lane;
+    double rn = 0.0;
+    if (lane < D) {
+      double x = v.yc[i];
+      if (mode != 2) {
+        x += alpha * v.cg_p[i];
+        v.yc[i] = x;
+      }
+      if (mode == 0) {
+        rn = v.cg_r[i] - alpha * v.cg_q[i];
+        v.cg_r[i] = rn;
+      } else if (mode == 2) {
+        rn = b[i] - v.cg_t[i];
+        v.cg_r[i] = rn;
+      }
+      if (mode != 1) acc[0] = -x * (b[i] + rn);
+    }
+    if (mode != 1) {
+      double z = 0.0;
+      const double* M = v.Minv + (size_t)rb * D * D + (lane < D ? lane : 0) * D;
+#pragma unroll
+      for (int c = 0; c < D; ++c) {
+        const double rc = __shfl(rn, c, 64);
+        if (lane < D) z += M[c] * rc;
+      }
+      if (lane < D) {
+        v.cg_z[i] = z;
+        acc[1] = rn * z;
+      }
+    }
+  }
+  block_sum_store<2>(acc, partial, nblocks);
+}
+
+__global__ __launch_bounds__(1024) void pcg_b3_kernel(DeviceView v, int n, int it, int nblocks,
+                                                      const double* __restrict__ partial) {
+  __shared__ double sh[16];
+  double l0 = 0.0, l1 = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 1024) {
+    l0 += partial[i];
+    l1 += partial[nblocks + i];
+  }
+  const double Q1 = block1024_sum(l0, sh);
+  const double rho = block1024_sum(l1, sh);
+  const double last_rho = v.scal[SC_RHO];
+  const double pq = v.scal[SC_PQ];
+  __syncthreads();
+  if (!(pq > 0.0) || !isfinite(pq)) {
+    if (threadIdx.x == 0) v.scal[SC_ZETA] = -1.0;
+    return;
+  }
   if (threadIdx.x == 0) {
     const double Q0 = v.scal[SC_Q0];
     v.scal[SC_Q1] = Q1;
     v.scal[SC_ZETA] = it * (Q1 - Q0) / Q1;
     v.scal[SC_Q0] = Q1;
-  }
-  // ---- prologue of iteration it + 1 (cg_r written above is re-read by other threads)
-  __syncthreads();
-  double lz = 0.0;
-  for (int i = threadIdx.x; i < n; i += 1024) {
-    const int rb = i / D, a = i - rb * D;
-    const double* M = v.Minv + (size_t)rb * D * D + a * D;
-    const double* rr = v.cg_r + (size_t)rb * D;
-    double z = 0.0;
-#pragma unroll
-    for (int c = 0; c < D; ++c) z += M[c] * rr[c];
-    v.cg_z[i] = z;
-    lz += z * v.cg_r[i];
-  }
-  const double rho = block1024_sum(lz, sh);
-  const double last_rho = v.scal[SC_RHO];
-  __syncthreads();
-  if (threadIdx.x == 0) {
     v.scal[SC_LAST_RHO] = last_rho;
     v.scal[SC_RHO] = rho;
-    // rho == 0 here only matters if another iteration follows; the host stops first
-    // when zeta has converged, so the failure flags are raised by the NEXT call
     v.scal[SC_RHO_BAD] = (rho == 0.0 || !isfinite(rho) || !isfinite(rho / last_rho)) ? 1.0 : 0.0;
   }
   const double beta = rho / last_rho;

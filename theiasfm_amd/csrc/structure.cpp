@@ -77,7 +77,7 @@ int pad_dim(int d) {
 
 }  // namespace
 
-int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S) {
+int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, bool want_pairs) {
   Structure& s = *S;
   if (!P || world < 1 || rank < 0 || rank >= world) {
     s.error = "null problem or bad rank/world";
@@ -374,7 +374,7 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S) 
     }
     std::sort(rbs.begin(), rbs.end());
   };
-  for (int p = 0; p < s.Np_total; ++p) {
+  for (int p = 0; p < s.Np_total && want_pairs; ++p) {
     if (klen[p] < 1) continue;
     if (P->point_constant && P->point_constant[p]) continue;  // no elimination, no coupling
     track_blocks([&](int j) { return P->obs_camera[tobs[tptr[p] + j]]; }, klen[p]);
@@ -384,7 +384,7 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S) 
   }
   // J_c^T J_c couples a view's extrinsics with its shared intrinsics block even when
   // none of its tracks is eliminated
-  if (s.has_shared) {
+  if (s.has_shared && want_pairs) {
     std::vector<char> seen(s.Nc, 0);
     for (int64_t i = 0; i < No_all; ++i) seen[P->obs_camera[i]] = 1;
     for (int c = 0; c < s.Nc; ++c)
@@ -430,7 +430,7 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S) 
   s.pair_ptr.assign(s.nub + 1, 0);
   std::vector<std::pair<int, int>> rs;  // (block, slot) of a track's virtual observations
   auto for_each_pair = [&](auto&& fn) {
-    for (int lp = 0; lp < s.Np_pad; ++lp) {
+    for (int lp = 0; lp < s.Np_pad && want_pairs; ++lp) {
       const int p = s.pt_orig[lp];
       if (p < 0 || s.pt_const[lp]) continue;
       const int sl = lp >> 6, t = lp & 63;

@@ -87,6 +87,9 @@ struct Structure {
 };
 
 // Returns TMI_BA_OK or an error status (message in out->error).
-int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* out);
+// want_pairs = false skips the block structure of S and the pair lists (implicit Schur
+// operator: S is never formed).
+int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* out,
+                    bool want_pairs = true);
 
 }  // namespace tmi
