@@ -100,7 +100,7 @@ Launch make_launch() {
   };
   L.schur_offdiag = [](const DeviceView& v, hipStream_t st, RedLayout R) {
     if (v.nub)
-      hipLaunchKernelGGL((schur_offdiag_kernel<D, DP>), dim3((v.n_order + 3) / 4), dim3(256), 0, st, v, R);
+      hipLaunchKernelGGL((schur_offdiag_kernel<D, DP>), dim3((v.n_order + 4 * kSchurBlocksPerWave - 1) / (4 * kSchurBlocksPerWave)), dim3(256), 0, st, v, R);
   };
   L.expand = [](const DeviceView& v, hipStream_t st, RedLayout R, double ir, double lo, double hi) {
     const int n2 = v.Nrb * D * D;

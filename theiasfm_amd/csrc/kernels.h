@@ -703,58 +703,90 @@ __global__ __launch_bounds__(64) void camera_diag_kernel(DeviceView v, RedLayout
 // has row = (l >> 4) + 4 reg, col = l & 15 (f64 MFMA layout).  No atomics, the
 // summation order is the pair list's (bit-reproducible).
 // ------------------------------------------------------------------------------
+constexpr int kSchurBlocksPerWave = 4;
+
 template <int D, int DP>
 __global__ __launch_bounds__(256) void schur_offdiag_kernel(DeviceView v, RedLayout L) {
   constexpr int YS = ys_of(D, DP);
+  constexpr int R = kSchurBlocksPerWave;
   const int lane = threadIdx.x & 63;
-  const long long ui = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (ui >= v.n_order) return;
-  // one 16-byte header per launch slot: {block, #pairs, first pair (lo, hi)}
-  const int4 hdr = reinterpret_cast<const int4*>(v.ub_order)[ui];
-  const int u = hdr.x;
-  if (u < 0) return;
-  const long long p0 = ((long long)(unsigned)hdr.z) | ((long long)hdr.w << 32);
-  const int npairs = hdr.y;
+  // wave (workgroup w, wave t) owns the R consecutive launch slots starting at
+  // (w * 4 + t) * R; headers {block, #pairs, first pair lo, hi} come in with one load
+  const long long first = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  if (first >= v.n_order) return;
+  int4 hq = make_int4(-1, 0, 0, 0);
+  if (lane < R && first + lane < v.n_order) hq = reinterpret_cast<const int4*>(v.ub_order)[first + lane];
   const int i = lane & 15, kk = lane >> 4;
-  v4f64 acc = {0.0, 0.0, 0.0, 0.0};
   const bool row_ok = i < D;
-  // Pairs are taken 64 at a time: one coalesced load brings the chunk's slot indices
-  // into the wave (lane l holds pair l), after which every Y gather address comes from
-  // a cross-lane read -- no dependent index load in front of each gather, and eight
-  // gathers per lane are in flight per trip.
-  for (int c0 = 0; c0 < npairs; c0 += 64) {
-    const int nch = min(64, npairs - c0);
-    int my_si = 0, my_sj = 0;
-    if (lane < nch) {
-      my_si = v.pair_i[p0 + c0 + lane];
-      my_sj = v.pair_j[p0 + c0 + lane];
-    }
-    const int Kc = nch * DP;
-    for (int k0 = 0; k0 < Kc; k0 += 16) {
-      double a[4], b[4];
-#pragma unroll
-      for (int h = 0; h < 4; ++h) {
-        const int k = k0 + 4 * h + kk;
-        const int pr = min(k / DP, 63);
-        const int c = k - (k / DP) * DP;
-        const int si = __shfl(my_si, pr, 64), sj = __shfl(my_sj, pr, 64);
-        a[h] = 0.0;
-        b[h] = 0.0;
-        if (row_ok && k < Kc) {
-          a[h] = v.cm_Y[(size_t)si * YS + i * DP + c];
-          b[h] = v.cm_Y[(size_t)sj * YS + i * DP + c];
-        }
-      }
-#pragma unroll
-      for (int h = 0; h < 4; ++h) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[h], b[h], acc, 0, 0, 0);
+  const int col = lane & 15;
+  // slot indices of the first chunk (<= 64 pairs) of the NEXT block are fetched while the
+  // current block is being contracted, so only the Y gathers themselves are exposed
+  int nx_si = 0, nx_sj = 0;
+  {
+    const int u0 = __shfl(hq.x, 0, 64), n0 = __shfl(hq.y, 0, 64);
+    const long long q0 = ((long long)(unsigned)__shfl(hq.z, 0, 64)) | ((long long)__shfl(hq.w, 0, 64) << 32);
+    if (u0 >= 0 && lane < min(64, n0)) {
+      nx_si = v.pair_i[q0 + lane];
+      nx_sj = v.pair_j[q0 + lane];
     }
   }
-  double* out = v.red + L.ub + (size_t)u * D * D;
-  const int col = lane & 15;
+#pragma unroll 1
+  for (int r = 0; r < R; ++r) {
+    const int u = __shfl(hq.x, r, 64);
+    const int npairs = __shfl(hq.y, r, 64);
+    const long long p0 = ((long long)(unsigned)__shfl(hq.z, r, 64)) | ((long long)__shfl(hq.w, r, 64) << 32);
+    int my_si = nx_si, my_sj = nx_sj;
+    if (r + 1 < R) {
+      const int u1 = __shfl(hq.x, r + 1, 64), n1 = __shfl(hq.y, r + 1, 64);
+      const long long q1 = ((long long)(unsigned)__shfl(hq.z, r + 1, 64)) | ((long long)__shfl(hq.w, r + 1, 64) << 32);
+      nx_si = 0;
+      nx_sj = 0;
+      if (u1 >= 0 && lane < min(64, n1)) {
+        nx_si = v.pair_i[q1 + lane];
+        nx_sj = v.pair_j[q1 + lane];
+      }
+    }
+    if (u < 0) continue;
+    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+    // Pairs are taken 64 at a time: lane l holds the slots of pair l, every Y gather
+    // address then comes from a cross-lane read, and eight gathers per lane are in
+    // flight per trip.  The flat K = DP * #pairs contraction runs on the f64 MFMA.
+    for (int c0 = 0; c0 < npairs; c0 += 64) {
+      const int nch = min(64, npairs - c0);
+      if (c0 > 0) {
+        my_si = 0;
+        my_sj = 0;
+        if (lane < nch) {
+          my_si = v.pair_i[p0 + c0 + lane];
+          my_sj = v.pair_j[p0 + c0 + lane];
+        }
+      }
+      const int Kc = nch * DP;
+      for (int k0 = 0; k0 < Kc; k0 += 16) {
+        double a[4], b[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = (lane >> 4) + 4 * r;
-    if (row < D && col < D) out[row * D + col] = -acc[r];
+        for (int h = 0; h < 4; ++h) {
+          const int k = k0 + 4 * h + kk;
+          const int pr = min(k / DP, 63);
+          const int c = k - (k / DP) * DP;
+          const int si = __shfl(my_si, pr, 64), sj = __shfl(my_sj, pr, 64);
+          a[h] = 0.0;
+          b[h] = 0.0;
+          if (row_ok && k < Kc) {
+            a[h] = v.cm_Y[(size_t)si * YS + i * DP + c];
+            b[h] = v.cm_Y[(size_t)sj * YS + i * DP + c];
+          }
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[h], b[h], acc, 0, 0, 0);
+      }
+    }
+    double* out = v.red + L.ub + (size_t)u * D * D;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = (lane >> 4) + 4 * q;
+      if (row < D && col < D) out[row * D + col] = -acc[q];
+    }
   }
 }
 

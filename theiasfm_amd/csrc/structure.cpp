@@ -503,15 +503,18 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, 
         b = e;
       }
     }
+    // workgroup w = m * 8 + x takes kSchurWG consecutive entries of queue x; its wave t the
+    // R = kSchurWG / 4 entries [t R, t R + R) of those (engine: kSchurBlocksPerWave)
+    constexpr size_t kSchurWG = 16;
     size_t longest = 0;
     for (auto& v : q) longest = std::max(longest, v.size());
-    const size_t groups = (longest + 3) / 4;
-    s.ub_order.assign(groups * 32, -1);
+    const size_t groups = (longest + kSchurWG - 1) / kSchurWG;
+    s.ub_order.assign(groups * 8 * kSchurWG, -1);
     for (size_t m = 0; m < groups; ++m)
       for (int x = 0; x < 8; ++x)
-        for (int t = 0; t < 4; ++t) {
-          const size_t idx = m * 4 + t;
-          if (idx < q[x].size()) s.ub_order[(m * 8 + x) * 4 + t] = q[x][idx];
+        for (size_t t = 0; t < kSchurWG; ++t) {
+          const size_t idx = m * kSchurWG + t;
+          if (idx < q[x].size()) s.ub_order[(m * 8 + x) * kSchurWG + t] = q[x][idx];
         }
   }
   return TMI_BA_OK;
