@@ -54,11 +54,15 @@ def make_device_allreduce():
     import torch.distributed as dist
 
     streams = {}
+    tensors = {}  # the engine's buffers are persistent: alias each (pointer, count) once
 
     def hook(ptr: int, count: int, stream: int) -> int:
         if count <= 0:
             return 0
-        t = torch.as_tensor(_DevArray(ptr, count), device="cuda")
+        t = tensors.get((ptr, count))
+        if t is None:
+            t = torch.as_tensor(_DevArray(ptr, count), device="cuda")
+            tensors[(ptr, count)] = t
         ext = streams.get(stream)
         if ext is None:
             ext = torch.cuda.ExternalStream(stream)
