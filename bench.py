@@ -87,6 +87,7 @@ def main():
                     choices=["tiny", "ladybug49", "alamo", "venice1778"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"])
     ap.add_argument("--schur-mode", default="auto", choices=["auto", "explicit", "implicit"],
                     help="ITERATIVE_SCHUR: form S explicitly (one all-reduce of S per LM iteration) "
                          "or apply it implicitly (one small all-reduce per PCG iteration); "
@@ -131,8 +132,15 @@ def main():
     opts = abi.default_options(max_num_iterations=max(args.warmup, 1), **base)
     t0 = time.perf_counter()
     solver = lib.Solver(prob, opts, rank, world)
+    transport = "none"
     if world > 1:
-        solver.set_allreduce(dist.make_device_allreduce())
+        # RCCL over xGMI: natively from the engine (ncclAllReduce on its own stream); the
+        # torch.distributed hook is the fallback (and --transport torch forces it)
+        if args.transport == "rccl" and dist.init_native_rccl(solver, rank, world):
+            transport = "rccl (native, ncclAllReduce from the engine)"
+        else:
+            solver.set_allreduce(dist.make_device_allreduce())
+            transport = "rccl via torch.distributed hook"
     t_create = time.perf_counter() - t0
 
     def sync_all():
@@ -195,7 +203,7 @@ def main():
                     loss="TRIVIAL",
                     schur_operator=("implicit (matrix-free)" if int(s.num_schur_pairs) == 0 and
                                     solver_type == abi.ITERATIVE_SCHUR else "explicit block-sparse S"),
-                    parallelism=f"tracks sharded x{world}, 1 all-reduce of the reduced camera system per LM iteration"),
+                    parallelism=f"tracks sharded x{world}", transport=transport),
         lm_iterations_per_sec=steps_run / elapsed,
         pcg_iterations=int(s.num_linear_solver_iterations),
         initial_cost=s.initial_cost, final_cost=s.final_cost, initial_rmse=s.initial_rmse,

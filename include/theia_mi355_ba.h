@@ -318,6 +318,19 @@ int32_t tmi_ba_solver_create(const tmi_ba_problem* problem,
                              int32_t world, tmi_ba_solver** out);
 int32_t tmi_ba_solver_set_allreduce(tmi_ba_solver* s, tmi_ba_allreduce_fn fn,
                                     void* user);
+/* Native RCCL transport (optional, instead of the hook).  The engine resolves
+ * ncclGetUniqueId / ncclCommInitRank / ncclAllReduce at run time from the librccl
+ * already loaded in the process (PyTorch's) or from /opt/rocm, and issues
+ * ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, comm, engine stream) itself:
+ *   rank 0 : tmi_ba_rccl_unique_id(id)  -> ship the 128 bytes to every rank
+ *   all    : tmi_ba_solver_init_rccl(solver, id)   (rank / world from create)
+ * A hook set with tmi_ba_solver_set_allreduce is ignored once RCCL is initialised. */
+int32_t tmi_ba_rccl_unique_id(uint8_t id[128]);
+int32_t tmi_ba_solver_init_rccl(tmi_ba_solver* s, const uint8_t id[128]);
+/* Test aid: sums the solver's 8-double scalar buffer through the configured
+ * transport (even for world = 1) after filling it with `value`; returns the
+ * first element in *out. */
+int32_t tmi_ba_solver_debug_allreduce(tmi_ba_solver* s, double value, double* out);
 int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* options,
                             tmi_ba_summary* summary);
 int32_t tmi_ba_solver_reset(tmi_ba_solver* s);

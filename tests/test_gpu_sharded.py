@@ -6,7 +6,10 @@ run concurrently in threads on the same device; the all-reduce hook sums their
 device buffers exactly where RCCL would.  The sharded solve must reproduce the
 single-rank solve (same LM trajectory; sums differ only in association order).
 A second test drives the real torch.distributed/RCCL hook with a 1-rank group."""
+import json
 import os
+import subprocess
+import sys
 import threading
 
 import numpy as np
@@ -123,3 +126,46 @@ def test_rccl_hook_single_rank_group():
     st.synchronize()
     assert torch.equal(buf.cpu(), torch.arange(4096, dtype=torch.float64) * 2.0)
     td.destroy_process_group()
+
+
+def test_native_rccl_transport_single_rank():
+    """The engine's own RCCL binding (dlopen'ed librccl, ncclCommInitRank, ncclAllReduce
+    on the engine's stream) with a 1-rank communicator."""
+    prob = synth.config("tiny")
+    sv = lib.Solver(prob, abi.default_options(point_dof=3))
+    uid = lib.rccl_unique_id()
+    assert len(uid) == 128 and any(uid)
+    sv.init_rccl(uid)
+    assert sv.debug_allreduce(3.25) == 3.25
+    # a hook is ignored once RCCL is bound
+    sv.set_allreduce(lambda p, n, st: 1)
+    assert sv.debug_allreduce(-1.5) == -1.5
+    st, s = sv.solve(abi.default_options(point_dof=3, max_num_iterations=3))
+    assert st == 0
+    sv.close()
+
+
+@pytest.mark.parametrize("mode", [abi.SCHUR_EXPLICIT, abi.SCHUR_AUTO])
+def test_two_processes_one_gpu(mode):
+    """Real separate processes (RANK / WORLD_SIZE from the environment, as torchrun sets
+    them), each owning its shard of the tracks; they share cuda:0 so the sums travel
+    through gloo instead of RCCL.  AUTO picks the implicit operator for world > 1."""
+    prob = synth.config("ladybug49")
+    single = prob.copy()
+    st, s1 = lib.solve(single, abi.default_options(linear_solver_type=abi.ITERATIVE_SCHUR, point_dof=3))
+    assert st == 0
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29540 + mode), WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "mp_sharded_worker.py"), str(mode)],
+                              env=dict(env, RANK=str(r), LOCAL_RANK="0"), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    res = [json.loads([ln for ln in o.splitlines() if ln.startswith("RESULT ")][0][7:]) for o in outs]
+    for r in res:
+        assert r["status"] == 0 and r["iters"] == s1.num_iterations
+        assert abs(r["cost"] - s1.final_cost) <= 1e-9 * s1.final_cost
+        assert abs(r["rmse"] - s1.final_rmse) <= 1e-9
+        assert np.abs(np.array(r["ext0"]) - single.extrinsics[0]).max() < 1e-6 * 100.0
+        assert (r["pairs"] == 0) == (mode == abi.SCHUR_AUTO)
+    assert res[0]["cost"] == res[1]["cost"] and res[0]["ext0"] == res[1]["ext0"]

@@ -10,6 +10,7 @@
 // handful of scalars read back once per iteration (once per PCG iteration
 // inside the linear solve).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <chrono>
 #include <cmath>
@@ -195,6 +196,7 @@ struct tmi_ba_solver {
   int nblocks_points = 0;
   tmi_ba_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
+  void* nccl_comm = nullptr;  // native RCCL communicator (tmi_ba_solver_init_rccl)
   // profiling
   unsigned prof_mask = 0;
   struct Ev { int cls; hipEvent_t a, b; };
@@ -258,15 +260,68 @@ int readback(tmi_ba_solver* s) {
   return TMI_BA_OK;
 }
 
-int do_allreduce(tmi_ba_solver* s, double* buf, int64_t count) {
-  if (!s->allreduce || s->st.world <= 1) return TMI_BA_OK;
+// ---- RCCL, resolved at run time (no link-time dependency; inside a PyTorch process the
+// already loaded librccl is reused so there is a single RCCL in the process)
+struct Rccl {
+  struct Id { char b[128]; };  // ncclUniqueId (passed by value to ncclCommInitRank)
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, Id, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool ok = false;
+  std::string error;
+};
+Rccl& rccl() {
+  static Rccl r;
+  static bool tried = false;
+  if (tried) return r;
+  tried = true;
+  void* h = nullptr;
+  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  for (const char* n : names)
+    if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+  if (!h)
+    for (const char* n : names)
+      if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+  if (!h) {
+    r.error = "librccl not found";
+    return r;
+  }
+  r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+  r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
+  r.AllReduce = (decltype(r.AllReduce))dlsym(h, "ncclAllReduce");
+  r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+  r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+  r.ok = r.GetUniqueId && r.CommInitRank && r.AllReduce && r.CommDestroy;
+  if (!r.ok) r.error = "librccl lacks the expected symbols";
+  return r;
+}
+
+int transport_allreduce(tmi_ba_solver* s, double* buf, int64_t count) {
   Timed t(s, TMI_BA_K_ALLREDUCE);
+  if (s->nccl_comm) {
+    // ncclDouble = 8, ncclSum = 0 (nccl.h)
+    const int rc = rccl().AllReduce(buf, buf, (size_t)count, 8, 0, s->nccl_comm, s->stream);
+    if (rc != 0) {
+      s->error = std::string("ncclAllReduce failed: ") +
+                 (rccl().GetErrorString ? rccl().GetErrorString(rc) : "error");
+      return TMI_BA_ERR_COLLECTIVE;
+    }
+    return TMI_BA_OK;
+  }
+  if (!s->allreduce) return TMI_BA_OK;
   const int rc = s->allreduce((void*)buf, count, (void*)s->stream, s->allreduce_user);
   if (rc != 0) {
     s->error = "all-reduce callback failed";
     return TMI_BA_ERR_COLLECTIVE;
   }
   return TMI_BA_OK;
+}
+
+int do_allreduce(tmi_ba_solver* s, double* buf, int64_t count) {
+  if (s->st.world <= 1 || (!s->allreduce && !s->nccl_comm)) return TMI_BA_OK;
+  return transport_allreduce(s, buf, count);
 }
 
 thread_local std::string g_last_error;  // message of the last failed call on this thread
@@ -371,6 +426,7 @@ void tmi_ba_solver_destroy(tmi_ba_solver* s) {
   if (!s) return;
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
+  if (s->nccl_comm) rccl().CommDestroy(s->nccl_comm);
   for (auto& e : s->events) {
     hipEventDestroy(e.a);
     hipEventDestroy(e.b);
@@ -572,6 +628,60 @@ int32_t tmi_ba_solver_set_allreduce(tmi_ba_solver* s, tmi_ba_allreduce_fn fn, vo
 }
 
 void* tmi_ba_solver_stream(tmi_ba_solver* s) { return s ? (void*)s->stream : nullptr; }
+
+int32_t tmi_ba_rccl_unique_id(uint8_t id[128]) {
+  if (!id) return TMI_BA_ERR_INVALID_ARGUMENT;
+  Rccl& r = rccl();
+  if (!r.ok) {
+    g_last_error = r.error;
+    return TMI_BA_ERR_COLLECTIVE;
+  }
+  const int rc = r.GetUniqueId((void*)id);
+  if (rc != 0) {
+    g_last_error = "ncclGetUniqueId failed";
+    return TMI_BA_ERR_COLLECTIVE;
+  }
+  return TMI_BA_OK;
+}
+
+int32_t tmi_ba_solver_init_rccl(tmi_ba_solver* s, const uint8_t id[128]) {
+  if (!s || !id) return TMI_BA_ERR_INVALID_ARGUMENT;
+  Rccl& r = rccl();
+  if (!r.ok) {
+    g_last_error = s->error = r.error;
+    return TMI_BA_ERR_COLLECTIVE;
+  }
+  if (hipSetDevice(s->device) != hipSuccess) return TMI_BA_ERR_DEVICE;
+  Rccl::Id uid;
+  memcpy(uid.b, id, 128);
+  void* comm = nullptr;
+  const int rc = r.CommInitRank(&comm, s->st.world, uid, s->st.rank);
+  if (rc != 0 || !comm) {
+    g_last_error = s->error = std::string("ncclCommInitRank failed: ") +
+                              (r.GetErrorString ? r.GetErrorString(rc) : "error");
+    return TMI_BA_ERR_COLLECTIVE;
+  }
+  s->nccl_comm = comm;
+  return TMI_BA_OK;
+}
+
+int32_t tmi_ba_solver_debug_allreduce(tmi_ba_solver* s, double value, double* out) {
+  if (!s || !out) return TMI_BA_ERR_INVALID_ARGUMENT;
+  if (hipSetDevice(s->device) != hipSuccess) return TMI_BA_ERR_DEVICE;
+  double h[8];
+  for (double& x : h) x = value;
+  double* d = s->v.red + s->RL.scalars;
+  if (hipMemcpyAsync(d, h, sizeof(h), hipMemcpyHostToDevice, s->stream) != hipSuccess) return TMI_BA_ERR_DEVICE;
+  const int rc = transport_allreduce(s, d, 8);
+  if (rc) {
+    g_last_error = s->error;
+    return rc;
+  }
+  if (hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s->stream) != hipSuccess) return TMI_BA_ERR_DEVICE;
+  if (hipStreamSynchronize(s->stream) != hipSuccess) return TMI_BA_ERR_DEVICE;
+  *out = h[0];
+  return TMI_BA_OK;
+}
 
 int32_t tmi_ba_solver_reset(tmi_ba_solver* s) {
   if (!s) return TMI_BA_ERR_INVALID_ARGUMENT;

@@ -91,3 +91,46 @@ def make_host_allreduce():
         return 0
 
     return hook
+
+
+def init_native_rccl(solver, rank: int, world: int) -> bool:
+    """Give `solver` its own RCCL communicator (the engine then calls ncclAllReduce
+    itself, no Python in the loop).  The 128-byte ncclUniqueId travels from rank 0
+    through the already initialised torch.distributed group.  Returns False (and leaves
+    the solver untouched) when RCCL cannot be bound, so callers can fall back to the
+    torch.distributed hook."""
+    import torch.distributed as dist
+    from . import lib
+    payload = [None]
+    if rank == 0:
+        try:
+            payload[0] = lib.rccl_unique_id()
+        except lib.EngineError as exc:  # librccl not resolvable
+            payload[0] = repr(exc)
+    dist.broadcast_object_list(payload, src=0)
+    if not isinstance(payload[0], (bytes, bytearray)):
+        return False
+    solver.init_rccl(bytes(payload[0]))
+    return True
+
+
+def make_staged_allreduce():
+    """Device buffer, host transport: copies the buffer to the host, all-reduces it over
+    the default group (e.g. gloo) and copies it back.  For testing the multi-process path
+    on a box where the ranks have to share one GPU (RCCL refuses that)."""
+    import torch
+    import torch.distributed as dist
+
+    def hook(ptr: int, count: int, stream: int) -> int:
+        if count <= 0:
+            return 0
+        ext = torch.cuda.ExternalStream(stream)
+        with torch.cuda.stream(ext):
+            t = torch.as_tensor(_DevArray(ptr, count), device="cuda")
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            t.copy_(h)
+            ext.synchronize()
+        return 0
+
+    return hook

@@ -26,6 +26,7 @@ EXPORTS = (
     "tmi_ba_solver_create", "tmi_ba_solver_set_allreduce", "tmi_ba_solver_solve",
     "tmi_ba_solver_reset", "tmi_ba_solver_download", "tmi_ba_solver_stream",
     "tmi_ba_solver_destroy", "tmi_ba_solver_evaluate", "tmi_ba_structure_stats",
+    "tmi_ba_rccl_unique_id", "tmi_ba_solver_init_rccl", "tmi_ba_solver_debug_allreduce",
 )
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
@@ -85,6 +86,12 @@ def load():
     L.tmi_ba_solver_evaluate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.POINTER(C.c_int32)]
     L.tmi_ba_solver_evaluate.restype = C.c_int32
+    L.tmi_ba_rccl_unique_id.argtypes = [C.c_void_p]
+    L.tmi_ba_rccl_unique_id.restype = C.c_int32
+    L.tmi_ba_solver_init_rccl.argtypes = [C.c_void_p, C.c_void_p]
+    L.tmi_ba_solver_init_rccl.restype = C.c_int32
+    L.tmi_ba_solver_debug_allreduce.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_double)]
+    L.tmi_ba_solver_debug_allreduce.restype = C.c_int32
     L.tmi_ba_structure_stats.argtypes = [P, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]
     L.tmi_ba_structure_stats.restype = C.c_int32
     _lib = L
@@ -105,6 +112,16 @@ def structure_stats(problem: abi.Problem, rank: int = 0, world: int = 1) -> dict
     if st != 0:
         raise EngineError(st, "tmi_ba_structure_stats")
     return dict(zip(STRUCTURE_STAT_NAMES, list(out)))
+
+
+def rccl_unique_id() -> bytes:
+    """ncclGetUniqueId through the engine's run-time RCCL binding (call on rank 0)."""
+    L = load()
+    buf = (C.c_uint8 * 128)()
+    st = L.tmi_ba_rccl_unique_id(buf)
+    if st != 0:
+        raise EngineError(st, "tmi_ba_rccl_unique_id")
+    return bytes(buf)
 
 
 class EngineError(RuntimeError):
@@ -152,6 +169,23 @@ class Solver:
         st = self._L.tmi_ba_solver_set_allreduce(self._h, self._cb, None)
         if st != 0:
             raise EngineError(st, "tmi_ba_solver_set_allreduce")
+
+    def init_rccl(self, unique_id: bytes):
+        """Native RCCL transport: every rank passes the 128-byte id rank 0 obtained from
+        rccl_unique_id() (ship it with torch.distributed / MPI / a file)."""
+        if len(unique_id) != 128:
+            raise ValueError("ncclUniqueId is 128 bytes")
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        st = self._L.tmi_ba_solver_init_rccl(self._h, buf)
+        if st != 0:
+            raise EngineError(st, "tmi_ba_solver_init_rccl")
+
+    def debug_allreduce(self, value: float) -> float:
+        out = C.c_double(0.0)
+        st = self._L.tmi_ba_solver_debug_allreduce(self._h, value, C.byref(out))
+        if st != 0:
+            raise EngineError(st, "tmi_ba_solver_debug_allreduce")
+        return out.value
 
     def solve(self, options: abi.COptions):
         s = abi.CSummary()
