@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=2)
     ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"])
+    ap.add_argument("--residual-precision", type=int, default=64, choices=[64, 32],
+                    help="32 = evaluate residuals/Jacobians in fp32, accumulate in fp64 (config 5)")
     ap.add_argument("--schur-mode", default="auto", choices=["auto", "explicit", "implicit"],
                     help="ITERATIVE_SCHUR: form S explicitly (one all-reduce of S per LM iteration) "
                          "or apply it implicitly (one small all-reduce per PCG iteration); "
@@ -128,7 +130,8 @@ def main():
         solver_type, solver_name = abi.DENSE_SCHUR, "DENSE_SCHUR (exact)"
     schur_mode = {"auto": 0, "explicit": 1, "implicit": 2}[args.schur_mode]
     base = dict(point_dof=3, linear_solver_type=solver_type, function_tolerance=0.0,
-                gradient_tolerance=0.0, parameter_tolerance=0.0, device=local, schur_mode=schur_mode)
+                gradient_tolerance=0.0, parameter_tolerance=0.0, device=local, schur_mode=schur_mode,
+                residual_precision=args.residual_precision)
     opts = abi.default_options(max_num_iterations=max(args.warmup, 1), **base)
     t0 = time.perf_counter()
     solver = lib.Solver(prob, opts, rank, world)
@@ -197,7 +200,9 @@ def main():
     out = dict(
         metric="ba_observations_per_sec", value=n_obs * steps_run / elapsed, unit="observations/s",
         n_gpus=world, steps=steps_run, warmup=args.warmup, ms_per_step=1e3 * elapsed / max(steps_run, 1),
-        higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f64", data="synthetic",
+        higher_is_better=True, scaling="strong", vs_baseline=None,
+        dtype="f64" if args.residual_precision == 64 else "f32 residuals/Jacobians, f64 accumulation",
+        data="synthetic",
         config=dict(workload=f"{args.workload}-synthetic", cameras=n_cam, tracks=n_pts,
                     observations=n_obs, camera_dof=dc, point_dof=dp, linear_solver=solver_name,
                     loss="TRIVIAL",

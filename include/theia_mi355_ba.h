@@ -206,7 +206,12 @@ typedef struct tmi_ba_options {
   int32_t device;          /* HIP device ordinal; -1 = current device        */
   int32_t profile_kernels; /* 1 = bracket every kernel class with HIP events
                               and report per-class times in the summary      */
-  int32_t residual_precision; /* 64 (fp64). 32 reserved for the fp32 path    */
+  int32_t residual_precision; /* 64 = fp64 throughout (reference precision).
+                              32 = residuals and Jacobian blocks evaluated in fp32
+                              (camera translation still removed in fp64), loss
+                              correction and all accumulation (J^T J, gradients,
+                              cost) in fp64 -- BASELINE config 5.  Fixed at
+                              tmi_ba_solver_create.                                */
   int32_t schur_mode;      /* ITERATIVE_SCHUR only.  1 = explicit: form the block
                               sparse reduced camera matrix S (Schur complement) and
                               run PCG on it; with several GPUs S is all-reduced once

@@ -223,6 +223,42 @@ def test_shared_and_private_intrinsics_groups_mixed():
         assert dev[1].final_cost < dev[1].initial_cost
 
 
+def test_fp32_residual_path_against_fp64_oracle():
+    """BASELINE config 5's precision variant: residuals and Jacobian blocks evaluated in
+    fp32 (translation removed in fp64 first), everything accumulated in fp64.  Parity is
+    loosened and stated: residuals 2e-3 px (pixels are O(1e3), fp32 eps 6e-8), Jacobian
+    blocks 2e-4 relative to max(1, |J|), final RMSE within 1e-4 px of the fp64 oracle on
+    mixed camera models with shared intrinsics groups."""
+    prob = synth.make_problem(
+        24, 1500, 9000, seed=33, scene="ring", spread=0.4, shared_group_size=2,
+        models=[(abi.PINHOLE, 0.5), (abi.PINHOLE_RADIAL_TANGENTIAL, 0.25), (abi.FISHEYE, 0.25)],
+        intrinsics_to_optimize=abi.INTRINSICS_FOCAL_LENGTH | abi.INTRINSICS_RADIAL_DISTORTION)
+    r_o, J_o, _ = oracle.evaluate(prob)
+    s = lib.Solver(prob, abi.default_options(point_dof=4, residual_precision=32))
+    r_d, A_d, A1_d, Jp_d, ok_d, D = s.evaluate(4)
+    s.close()
+    assert (ok_d == 1).all()
+    assert np.abs(r_d - r_o).max() < 2e-3
+    assert np.abs(r_d - r_o).max() > 0.0          # it really is a different precision
+    refp = J_o[:, :, 16:20]
+    assert (np.abs(Jp_d - refp) / np.maximum(1.0, np.abs(refp))).max() < 2e-4
+    for i in range(0, prob.num_observations, 7):
+        cols, shared = reduced_columns(prob, int(prob.obs_camera[i]))
+        ref = J_o[i][:, cols]
+        assert (np.abs(A_d[i][:, :len(cols)] - ref) / np.maximum(1.0, np.abs(ref))).max() < 2e-4
+    a, b = prob.copy(), prob.copy()
+    o32 = abi.default_options(linear_solver_type=abi.ITERATIVE_SCHUR, point_dof=4, residual_precision=32)
+    o64 = abi.default_options(linear_solver_type=abi.ITERATIVE_SCHUR, point_dof=4)
+    st_d, s_d = lib.solve(a, o32)
+    st_o, s_o = oracle.solve(b, o64)
+    assert st_d == 0 and st_o == 0
+    assert abs(s_d.final_rmse - s_o.final_rmse) < 1e-4
+    assert abs(s_d.final_cost - s_o.final_cost) < 1e-3 * s_o.final_cost
+    # the fp64-evaluated cost of the fp32 solution agrees with what the device reported
+    c, rmse, _ = oracle.cost(a)
+    assert abs(rmse - s_d.final_rmse) < 1e-4
+
+
 def test_bitwise_reproducible():
     prob = synth.config("ladybug49")
     outs = []

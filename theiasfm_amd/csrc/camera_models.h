@@ -28,22 +28,38 @@ constexpr double kDblEpsilon = 2.220446049250313e-16;
 //  0 PINHOLE [f ar s px py k1 k2]            1 RADTAN [f ar s px py k1 k2 k3 t1 t2]
 //  2 FISHEYE [f ar s px py k1 k2 k3 k4]      3 FOV [f ar px py w]   4 DIVISION [f ar px py k]
 
+// ---- scalar-type plumbing: the functions below are templated on T = double (the
+// reference's precision) or float (BASELINE config 5's fp32 residual path; the camera
+// translation X - w C is always removed in fp64 first, accumulation stays fp64).
+__device__ __forceinline__ double t_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float t_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double t_atan2(double y, double x) { return atan2(y, x); }
+__device__ __forceinline__ float t_atan2(float y, float x) { return atan2f(y, x); }
+__device__ __forceinline__ double t_tan(double x) { return tan(x); }
+__device__ __forceinline__ float t_tan(float x) { return tanf(x); }
+__device__ __forceinline__ double t_atan(double x) { return atan(x); }
+__device__ __forceinline__ float t_atan(float x) { return atanf(x); }
+__device__ __forceinline__ double t_fabs(double x) { return fabs(x); }
+__device__ __forceinline__ float t_fabs(float x) { return fabsf(x); }
+__device__ __forceinline__ void t_sincos(double x, double* s, double* c) { sincos(x, s, c); }
+__device__ __forceinline__ void t_sincos(float x, float* s, float* c) { sincosf(x, s, c); }
+
 // Rodrigues rotation q = R(w) a, as ceres::AngleAxisRotatePoint executes it
 // (call site reprojection_error.h:81-83).  If JAC: R (= dq/da) and dq/dw.
-template <bool JAC>
-__device__ __forceinline__ void rotate_point(const double w[3], const double a[3], double q[3],
-                                             double R[3][3], double dqdw[3][3]) {
-  const double theta2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
-  const double wxa[3] = {w[1] * a[2] - w[2] * a[1], w[2] * a[0] - w[0] * a[2],
+template <bool JAC, typename T>
+__device__ __forceinline__ void rotate_point(const T w[3], const T a[3], T q[3],
+                                             T R[3][3], T dqdw[3][3]) {
+  const T theta2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  const T wxa[3] = {w[1] * a[2] - w[2] * a[1], w[2] * a[0] - w[0] * a[2],
                          w[0] * a[1] - w[1] * a[0]};
   if (theta2 > kDblEpsilon) {
-    const double theta = sqrt(theta2);
-    double s, c;
-    sincos(theta, &s, &c);
-    const double inv_theta = 1.0 / theta;
-    const double A1 = s * inv_theta;                 // sin(t)/t
-    const double B1 = (1.0 - c) * inv_theta * inv_theta;  // (1-cos t)/t^2
-    const double wa = w[0] * a[0] + w[1] * a[1] + w[2] * a[2];
+    const T theta = t_sqrt(theta2);
+    T s, c;
+    t_sincos(theta, &s, &c);
+    const T inv_theta = T(1.0) / theta;
+    const T A1 = s * inv_theta;                 // sin(t)/t
+    const T B1 = (T(1.0) - c) * inv_theta * inv_theta;  // (1-cos t)/t^2
+    const T wa = w[0] * a[0] + w[1] * a[1] + w[2] * a[2];
 #pragma unroll
     for (int i = 0; i < 3; ++i) q[i] = a[i] * c + wxa[i] * A1 + w[i] * (wa * B1);
     if (JAC) {
@@ -57,16 +73,16 @@ __device__ __forceinline__ void rotate_point(const double w[3], const double a[3
       R[2][0] = -A1 * w[1] + B1 * w[2] * w[0];
       R[2][1] = A1 * w[0] + B1 * w[2] * w[1];
       R[2][2] = c + B1 * w[2] * w[2];
-      const double dA1 = (c * theta - s) * inv_theta * inv_theta;  // d(sin t / t)/dt
-      const double dB1 = (s * theta - 2.0 * (1.0 - c)) * inv_theta * inv_theta * inv_theta;
+      const T dA1 = (c * theta - s) * inv_theta * inv_theta;  // d(sin t / t)/dt
+      const T dB1 = (s * theta - T(2.0) * (T(1.0) - c)) * inv_theta * inv_theta * inv_theta;
       // e_k x a
-      const double exa[3][3] = {{0.0, -a[2], a[1]}, {a[2], 0.0, -a[0]}, {-a[1], a[0], 0.0}};
+      const T exa[3][3] = {{T(0.0), -a[2], a[1]}, {a[2], T(0.0), -a[0]}, {-a[1], a[0], T(0.0)}};
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        const double wk = w[k] * inv_theta;  // d theta / d w_k
+        const T wk = w[k] * inv_theta;  // d theta / d w_k
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-          double v = a[i] * (-s * wk) + exa[k][i] * A1 + wxa[i] * (dA1 * wk) +
+          T v = a[i] * (-s * wk) + exa[k][i] * A1 + wxa[i] * (dA1 * wk) +
                      w[i] * (a[k] * B1 + wa * dB1 * wk);
           if (i == k) v += wa * B1;
           dqdw[i][k] = v;
@@ -78,12 +94,12 @@ __device__ __forceinline__ void rotate_point(const double w[3], const double a[3
 #pragma unroll
     for (int i = 0; i < 3; ++i) q[i] = a[i] + wxa[i];
     if (JAC) {
-      R[0][0] = 1.0;   R[0][1] = -w[2]; R[0][2] = w[1];
-      R[1][0] = w[2];  R[1][1] = 1.0;   R[1][2] = -w[0];
-      R[2][0] = -w[1]; R[2][1] = w[0];  R[2][2] = 1.0;
-      dqdw[0][0] = 0.0;   dqdw[0][1] = a[2];  dqdw[0][2] = -a[1];
-      dqdw[1][0] = -a[2]; dqdw[1][1] = 0.0;   dqdw[1][2] = a[0];
-      dqdw[2][0] = a[1];  dqdw[2][1] = -a[0]; dqdw[2][2] = 0.0;
+      R[0][0] = T(1.0);   R[0][1] = -w[2]; R[0][2] = w[1];
+      R[1][0] = w[2];  R[1][1] = T(1.0);   R[1][2] = -w[0];
+      R[2][0] = -w[1]; R[2][1] = w[0];  R[2][2] = T(1.0);
+      dqdw[0][0] = T(0.0);   dqdw[0][1] = a[2];  dqdw[0][2] = -a[1];
+      dqdw[1][0] = -a[2]; dqdw[1][1] = T(0.0);   dqdw[1][2] = a[0];
+      dqdw[2][0] = a[1];  dqdw[2][1] = -a[0]; dqdw[2][2] = T(0.0);
     }
   }
 }
@@ -91,11 +107,11 @@ __device__ __forceinline__ void rotate_point(const double w[3], const double a[3
 // pixel = K-matrix-with-skew applied to the distorted point d, and its chain
 // rule pieces (pinhole_camera_model.h:206-209 and the two siblings).
 // dd_dq: d(distorted)/dq [2][3]; dd_dk: d(distorted)/d(distortion params).
-template <bool JAC, int NDIST>
-__device__ __forceinline__ void apply_k_skew(const double* K, const double d[2], double px[2],
-                                             const double dd_dq[2][3], const double dd_dk[2][NDIST],
-                                             double dpdq[2][3], double dpdK[2][10]) {
-  const double f = K[0], ar = K[1], sk = K[2];
+template <bool JAC, int NDIST, typename T>
+__device__ __forceinline__ void apply_k_skew(const T* K, const T d[2], T px[2],
+                                             const T dd_dq[2][3], const T dd_dk[2][NDIST],
+                                             T dpdq[2][3], T dpdK[2][10]) {
+  const T f = K[0], ar = K[1], sk = K[2];
   px[0] = f * d[0] + sk * d[1] + K[3];
   px[1] = f * ar * d[1] + K[4];
   if (JAC) {
@@ -105,182 +121,183 @@ __device__ __forceinline__ void apply_k_skew(const double* K, const double d[2],
       dpdq[1][j] = f * ar * dd_dq[1][j];
     }
     dpdK[0][0] = d[0];  dpdK[1][0] = ar * d[1];  // f
-    dpdK[0][1] = 0.0;   dpdK[1][1] = f * d[1];   // aspect ratio
-    dpdK[0][2] = d[1];  dpdK[1][2] = 0.0;        // skew
-    dpdK[0][3] = 1.0;   dpdK[1][3] = 0.0;        // px
-    dpdK[0][4] = 0.0;   dpdK[1][4] = 1.0;        // py
+    dpdK[0][1] = T(0.0);   dpdK[1][1] = f * d[1];   // aspect ratio
+    dpdK[0][2] = d[1];  dpdK[1][2] = T(0.0);        // skew
+    dpdK[0][3] = T(1.0);   dpdK[1][3] = T(0.0);        // px
+    dpdK[0][4] = T(0.0);   dpdK[1][4] = T(1.0);        // py
 #pragma unroll
     for (int j = 0; j < NDIST; ++j) {
       dpdK[0][5 + j] = f * dd_dk[0][j] + sk * dd_dk[1][j];
       dpdK[1][5 + j] = f * ar * dd_dk[1][j];
     }
 #pragma unroll
-    for (int j = 5 + NDIST; j < 10; ++j) { dpdK[0][j] = 0.0; dpdK[1][j] = 0.0; }
+    for (int j = 5 + NDIST; j < 10; ++j) { dpdK[0][j] = T(0.0); dpdK[1][j] = T(0.0); }
   }
 }
 
 // n = q.xy / q.z and dn/dq
-template <bool JAC>
-__device__ __forceinline__ void normalize_point(const double q[3], double n[2], double dn[2][3]) {
-  const double iz = 1.0 / q[2];
+template <bool JAC, typename T>
+__device__ __forceinline__ void normalize_point(const T q[3], T n[2], T dn[2][3]) {
+  const T iz = T(1.0) / q[2];
   n[0] = q[0] * iz;
   n[1] = q[1] * iz;
   if (JAC) {
-    dn[0][0] = iz;  dn[0][1] = 0.0; dn[0][2] = -n[0] * iz;
-    dn[1][0] = 0.0; dn[1][1] = iz;  dn[1][2] = -n[1] * iz;
+    dn[0][0] = iz;  dn[0][1] = T(0.0); dn[0][2] = -n[0] * iz;
+    dn[1][0] = T(0.0); dn[1][1] = iz;  dn[1][2] = -n[1] * iz;
   }
 }
 
 // dd_dq = dd_dn (2x2) * dn_dq (2x3)
-__device__ __forceinline__ void chain_2x2_2x3(const double ddn[2][2], const double dn[2][3],
-                                              double out[2][3]) {
+template <typename T>
+__device__ __forceinline__ void chain_2x2_2x3(const T ddn[2][2], const T dn[2][3],
+                                              T out[2][3]) {
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) out[i][j] = ddn[i][0] * dn[0][j] + ddn[i][1] * dn[1][j];
 }
 
-template <bool JAC>
-__device__ __forceinline__ void project_pinhole(const double* K, const double q[3], double px[2],
-                                                double dpdq[2][3], double dpdK[2][10]) {
-  double n[2], dn[2][3];
-  normalize_point<JAC>(q, n, dn);
-  const double r2 = n[0] * n[0] + n[1] * n[1];
-  const double dd = 1.0 + r2 * (K[5] + K[6] * r2);
-  const double d[2] = {n[0] * dd, n[1] * dd};
-  double dd_dq[2][3], dd_dk[2][2];
+template <bool JAC, typename T>
+__device__ __forceinline__ void project_pinhole(const T* K, const T q[3], T px[2],
+                                                T dpdq[2][3], T dpdK[2][10]) {
+  T n[2], dn[2][3];
+  normalize_point<JAC, T>(q, n, dn);
+  const T r2 = n[0] * n[0] + n[1] * n[1];
+  const T dd = T(1.0) + r2 * (K[5] + K[6] * r2);
+  const T d[2] = {n[0] * dd, n[1] * dd};
+  T dd_dq[2][3], dd_dk[2][2];
   if (JAC) {
-    const double g = 2.0 * (K[5] + 2.0 * K[6] * r2);  // d(dd)/d(r2) * 2
-    const double ddn[2][2] = {{dd + n[0] * n[0] * g, n[0] * n[1] * g},
+    const T g = T(2.0) * (K[5] + T(2.0) * K[6] * r2);  // d(dd)/d(r2) * 2
+    const T ddn[2][2] = {{dd + n[0] * n[0] * g, n[0] * n[1] * g},
                               {n[1] * n[0] * g, dd + n[1] * n[1] * g}};
     chain_2x2_2x3(ddn, dn, dd_dq);
     dd_dk[0][0] = n[0] * r2;      dd_dk[1][0] = n[1] * r2;
     dd_dk[0][1] = n[0] * r2 * r2; dd_dk[1][1] = n[1] * r2 * r2;
   }
-  apply_k_skew<JAC, 2>(K, d, px, dd_dq, dd_dk, dpdq, dpdK);
+  apply_k_skew<JAC, 2, T>(K, d, px, dd_dq, dd_dk, dpdq, dpdK);
 }
 
-template <bool JAC>
-__device__ __forceinline__ void project_radtan(const double* K, const double q[3], double px[2],
-                                               double dpdq[2][3], double dpdK[2][10]) {
-  double n[2], dn[2][3];
-  normalize_point<JAC>(q, n, dn);
-  const double x = n[0], y = n[1];
-  const double r2 = x * x + y * y;
-  const double k1 = K[5], k2 = K[6], k3 = K[7], t1 = K[8], t2 = K[9];
-  const double rd = 1.0 + k1 * r2 + k2 * r2 * r2 + k3 * r2 * r2 * r2;
-  const double tx = t2 * (r2 + 2.0 * x * x) + 2.0 * t1 * x * y;
-  const double ty = t1 * (r2 + 2.0 * y * y) + 2.0 * t2 * x * y;
-  const double d[2] = {x * rd + tx, y * rd + ty};
-  double dd_dq[2][3], dd_dk[2][5];
+template <bool JAC, typename T>
+__device__ __forceinline__ void project_radtan(const T* K, const T q[3], T px[2],
+                                               T dpdq[2][3], T dpdK[2][10]) {
+  T n[2], dn[2][3];
+  normalize_point<JAC, T>(q, n, dn);
+  const T x = n[0], y = n[1];
+  const T r2 = x * x + y * y;
+  const T k1 = K[5], k2 = K[6], k3 = K[7], t1 = K[8], t2 = K[9];
+  const T rd = T(1.0) + k1 * r2 + k2 * r2 * r2 + k3 * r2 * r2 * r2;
+  const T tx = t2 * (r2 + T(2.0) * x * x) + T(2.0) * t1 * x * y;
+  const T ty = t1 * (r2 + T(2.0) * y * y) + T(2.0) * t2 * x * y;
+  const T d[2] = {x * rd + tx, y * rd + ty};
+  T dd_dq[2][3], dd_dk[2][5];
   if (JAC) {
-    const double g = k1 + 2.0 * k2 * r2 + 3.0 * k3 * r2 * r2;  // d rd / d r2
-    const double ddn[2][2] = {
-        {rd + 2.0 * x * x * g + 6.0 * t2 * x + 2.0 * t1 * y, 2.0 * x * y * g + 2.0 * t2 * y + 2.0 * t1 * x},
-        {2.0 * x * y * g + 2.0 * t1 * x + 2.0 * t2 * y, rd + 2.0 * y * y * g + 6.0 * t1 * y + 2.0 * t2 * x}};
+    const T g = k1 + T(2.0) * k2 * r2 + T(3.0) * k3 * r2 * r2;  // d rd / d r2
+    const T ddn[2][2] = {
+        {rd + T(2.0) * x * x * g + T(6.0) * t2 * x + T(2.0) * t1 * y, T(2.0) * x * y * g + T(2.0) * t2 * y + T(2.0) * t1 * x},
+        {T(2.0) * x * y * g + T(2.0) * t1 * x + T(2.0) * t2 * y, rd + T(2.0) * y * y * g + T(6.0) * t1 * y + T(2.0) * t2 * x}};
     chain_2x2_2x3(ddn, dn, dd_dq);
     dd_dk[0][0] = x * r2;           dd_dk[1][0] = y * r2;
     dd_dk[0][1] = x * r2 * r2;      dd_dk[1][1] = y * r2 * r2;
     dd_dk[0][2] = x * r2 * r2 * r2; dd_dk[1][2] = y * r2 * r2 * r2;
-    dd_dk[0][3] = 2.0 * x * y;      dd_dk[1][3] = r2 + 2.0 * y * y;  // t1
-    dd_dk[0][4] = r2 + 2.0 * x * x; dd_dk[1][4] = 2.0 * x * y;       // t2
+    dd_dk[0][3] = T(2.0) * x * y;      dd_dk[1][3] = r2 + T(2.0) * y * y;  // t1
+    dd_dk[0][4] = r2 + T(2.0) * x * x; dd_dk[1][4] = T(2.0) * x * y;       // t2
   }
-  apply_k_skew<JAC, 5>(K, d, px, dd_dq, dd_dk, dpdq, dpdK);
+  apply_k_skew<JAC, 5, T>(K, d, px, dd_dq, dd_dk, dpdq, dpdK);
 }
 
-template <bool JAC>
-__device__ __forceinline__ void project_fisheye(const double* K, const double q[3], double px[2],
-                                                double dpdq[2][3], double dpdK[2][10]) {
-  const double x = q[0], y = q[1], z = q[2];
-  const double r2 = x * x + y * y;
-  double d[2], dd_dq[2][3], dd_dk[2][4];
-  if (r2 < 1e-8) {  // fisheye_camera_model.h:243: pass the raw x, y through
+template <bool JAC, typename T>
+__device__ __forceinline__ void project_fisheye(const T* K, const T q[3], T px[2],
+                                                T dpdq[2][3], T dpdK[2][10]) {
+  const T x = q[0], y = q[1], z = q[2];
+  const T r2 = x * x + y * y;
+  T d[2], dd_dq[2][3], dd_dk[2][4];
+  if (r2 < T(1e-8)) {  // fisheye_camera_model.h:243: pass the raw x, y through
     d[0] = x;
     d[1] = y;
     if (JAC) {
-      dd_dq[0][0] = 1.0; dd_dq[0][1] = 0.0; dd_dq[0][2] = 0.0;
-      dd_dq[1][0] = 0.0; dd_dq[1][1] = 1.0; dd_dq[1][2] = 0.0;
+      dd_dq[0][0] = T(1.0); dd_dq[0][1] = T(0.0); dd_dq[0][2] = T(0.0);
+      dd_dq[1][0] = T(0.0); dd_dq[1][1] = T(1.0); dd_dq[1][2] = T(0.0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { dd_dk[0][j] = 0.0; dd_dk[1][j] = 0.0; }
+      for (int j = 0; j < 4; ++j) { dd_dk[0][j] = T(0.0); dd_dk[1][j] = T(0.0); }
     }
   } else {
-    const double r = sqrt(r2);
-    const double az = fabs(z);
-    const double th = atan2(r, az);
-    const double t2 = th * th, t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
-    const double poly = 1.0 + K[5] * t2 + K[6] * t4 + K[7] * t6 + K[8] * t8;
-    const double thd = th * poly;
-    const double sgn = (z < 0.0) ? -1.0 : 1.0;  // :263
-    const double h = sgn * thd / r;
+    const T r = t_sqrt(r2);
+    const T az = t_fabs(z);
+    const T th = t_atan2(r, az);
+    const T t2 = th * th, t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
+    const T poly = T(1.0) + K[5] * t2 + K[6] * t4 + K[7] * t6 + K[8] * t8;
+    const T thd = th * poly;
+    const T sgn = (z < T(0.0)) ? -T(1.0) : T(1.0);  // :263
+    const T h = sgn * thd / r;
     d[0] = h * x;
     d[1] = h * y;
     if (JAC) {
-      const double inv = 1.0 / (r2 + z * z);
-      const double dth_dr = az * inv;
-      const double dth_dz = -r * inv * ((z < 0.0) ? -1.0 : 1.0);  // d|z|/dz, Jet abs: z<0 ? -1 : +1
-      const double dthd = 1.0 + 3.0 * K[5] * t2 + 5.0 * K[6] * t4 + 7.0 * K[7] * t6 + 9.0 * K[8] * t8;
+      const T inv = T(1.0) / (r2 + z * z);
+      const T dth_dr = az * inv;
+      const T dth_dz = -r * inv * ((z < T(0.0)) ? -T(1.0) : T(1.0));  // d|z|/dz, Jet abs: z<0 ? -1 : +1
+      const T dthd = T(1.0) + T(3.0) * K[5] * t2 + T(5.0) * K[6] * t4 + T(7.0) * K[7] * t6 + T(9.0) * K[8] * t8;
       // h = sgn * thd(th(r,z)) / r
-      const double dh_dr = sgn * (dthd * dth_dr / r - thd / r2);
-      const double dh_dz = sgn * dthd * dth_dz / r;
-      const double dr_dx = x / r, dr_dy = y / r;
+      const T dh_dr = sgn * (dthd * dth_dr / r - thd / r2);
+      const T dh_dz = sgn * dthd * dth_dz / r;
+      const T dr_dx = x / r, dr_dy = y / r;
       dd_dq[0][0] = h + x * dh_dr * dr_dx; dd_dq[0][1] = x * dh_dr * dr_dy; dd_dq[0][2] = x * dh_dz;
       dd_dq[1][0] = y * dh_dr * dr_dx; dd_dq[1][1] = h + y * dh_dr * dr_dy; dd_dq[1][2] = y * dh_dz;
-      const double base = sgn * th / r;
+      const T base = sgn * th / r;
       dd_dk[0][0] = base * t2 * x; dd_dk[1][0] = base * t2 * y;
       dd_dk[0][1] = base * t4 * x; dd_dk[1][1] = base * t4 * y;
       dd_dk[0][2] = base * t6 * x; dd_dk[1][2] = base * t6 * y;
       dd_dk[0][3] = base * t8 * x; dd_dk[1][3] = base * t8 * y;
     }
   }
-  apply_k_skew<JAC, 4>(K, d, px, dd_dq, dd_dk, dpdq, dpdK);
+  apply_k_skew<JAC, 4, T>(K, d, px, dd_dq, dd_dk, dpdq, dpdK);
 }
 
-template <bool JAC>
-__device__ __forceinline__ void project_fov(const double* K, const double q[3], double px[2],
-                                            double dpdq[2][3], double dpdK[2][10]) {
-  double n[2], dn[2][3];
-  normalize_point<JAC>(q, n, dn);
-  const double f = K[0], ar = K[1], om = K[4];
-  const double r2 = n[0] * n[0] + n[1] * n[1];
-  double rd, drd_dr2 = 0.0, drd_dom = 0.0;
-  if (om < 1e-3) {  // fov_camera_model.h:227
-    rd = (om * om * r2) / 3.0 - om * om / 12.0 + 1.0;
+template <bool JAC, typename T>
+__device__ __forceinline__ void project_fov(const T* K, const T q[3], T px[2],
+                                            T dpdq[2][3], T dpdK[2][10]) {
+  T n[2], dn[2][3];
+  normalize_point<JAC, T>(q, n, dn);
+  const T f = K[0], ar = K[1], om = K[4];
+  const T r2 = n[0] * n[0] + n[1] * n[1];
+  T rd, drd_dr2 = T(0.0), drd_dom = T(0.0);
+  if (om < T(1e-3)) {  // fov_camera_model.h:227
+    rd = (om * om * r2) / T(3.0) - om * om / T(12.0) + T(1.0);
     if (JAC) {
-      drd_dr2 = om * om / 3.0;
-      drd_dom = 2.0 * om * r2 / 3.0 - om / 6.0;
+      drd_dr2 = om * om / T(3.0);
+      drd_dom = T(2.0) * om * r2 / T(3.0) - om / T(6.0);
     }
-  } else if (r2 < 1e-3) {  // :236
-    const double T = tan(om / 2.0);
-    const double num = -2.0 * T * (4.0 * r2 * T * T - 3.0);
-    rd = num / (3.0 * om);
+  } else if (r2 < T(1e-3)) {  // :236
+    const T th = t_tan(om / T(2.0));  // tan(omega / 2)
+    const T num = -T(2.0) * th * (T(4.0) * r2 * th * th - T(3.0));
+    rd = num / (T(3.0) * om);
     if (JAC) {
-      drd_dr2 = -8.0 * T * T * T / (3.0 * om);
-      const double dT = 0.5 * (1.0 + T * T);
-      const double dnum = (-24.0 * r2 * T * T + 6.0) * dT;
-      drd_dom = dnum / (3.0 * om) - num / (3.0 * om * om);
+      drd_dr2 = -T(8.0) * th * th * th / (T(3.0) * om);
+      const T dth = T(0.5) * (T(1.0) + th * th);
+      const T dnum = (-T(24.0) * r2 * th * th + T(6.0)) * dth;
+      drd_dom = dnum / (T(3.0) * om) - num / (T(3.0) * om * om);
     }
   } else {  // :249-254
-    const double ru = sqrt(r2);
-    const double T = tan(om / 2.0);
-    const double m = 2.0 * ru * T;
-    const double at = atan(m);
+    const T ru = t_sqrt(r2);
+    const T th = t_tan(om / T(2.0));
+    const T m = T(2.0) * ru * th;
+    const T at = t_atan(m);
     rd = at / (ru * om);
     if (JAC) {
-      const double im = 1.0 / (1.0 + m * m);
-      const double drd_dru = (2.0 * T * im) / (ru * om) - at / (r2 * om);
-      drd_dr2 = drd_dru / (2.0 * ru);
-      const double dT = 0.5 * (1.0 + T * T);
-      drd_dom = (2.0 * ru * dT * im) / (ru * om) - at / (ru * om * om);
+      const T im = T(1.0) / (T(1.0) + m * m);
+      const T drd_dru = (T(2.0) * th * im) / (ru * om) - at / (r2 * om);
+      drd_dr2 = drd_dru / (T(2.0) * ru);
+      const T dth = T(0.5) * (T(1.0) + th * th);
+      drd_dom = (T(2.0) * ru * dth * im) / (ru * om) - at / (ru * om * om);
     }
   }
-  const double d[2] = {rd * n[0], rd * n[1]};
+  const T d[2] = {rd * n[0], rd * n[1]};
   px[0] = f * d[0] + K[2];
   px[1] = f * ar * d[1] + K[3];
   if (JAC) {
-    const double g = 2.0 * drd_dr2;
-    const double ddn[2][2] = {{rd + n[0] * n[0] * g, n[0] * n[1] * g},
+    const T g = T(2.0) * drd_dr2;
+    const T ddn[2][2] = {{rd + n[0] * n[0] * g, n[0] * n[1] * g},
                               {n[1] * n[0] * g, rd + n[1] * n[1] * g}};
-    double dd_dq[2][3];
+    T dd_dq[2][3];
     chain_2x2_2x3(ddn, dn, dd_dq);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -288,73 +305,73 @@ __device__ __forceinline__ void project_fov(const double* K, const double q[3], 
       dpdq[1][j] = f * ar * dd_dq[1][j];
     }
     dpdK[0][0] = d[0]; dpdK[1][0] = ar * d[1];
-    dpdK[0][1] = 0.0;  dpdK[1][1] = f * d[1];
-    dpdK[0][2] = 1.0;  dpdK[1][2] = 0.0;
-    dpdK[0][3] = 0.0;  dpdK[1][3] = 1.0;
+    dpdK[0][1] = T(0.0);  dpdK[1][1] = f * d[1];
+    dpdK[0][2] = T(1.0);  dpdK[1][2] = T(0.0);
+    dpdK[0][3] = T(0.0);  dpdK[1][3] = T(1.0);
     dpdK[0][4] = f * n[0] * drd_dom; dpdK[1][4] = f * ar * n[1] * drd_dom;
 #pragma unroll
-    for (int j = 5; j < 10; ++j) { dpdK[0][j] = 0.0; dpdK[1][j] = 0.0; }
+    for (int j = 5; j < 10; ++j) { dpdK[0][j] = T(0.0); dpdK[1][j] = T(0.0); }
   }
 }
 
-template <bool JAC>
-__device__ __forceinline__ void project_division(const double* K, const double q[3], double px[2],
-                                                 double dpdq[2][3], double dpdK[2][10]) {
-  double n[2], dn[2][3];
-  normalize_point<JAC>(q, n, dn);
-  const double f = K[0], ar = K[1], k = K[4];
-  const double fy = f * ar;
-  const double u[2] = {f * n[0], fy * n[1]};
-  const double r2 = u[0] * u[0] + u[1] * u[1];
-  const double denom = 2.0 * k * r2;
-  const double inner = 1.0 - 4.0 * k * r2;
-  double scale = 1.0, dsc_dr2 = 0.0, dsc_dk = 0.0;
-  if (!(fabs(denom) < kDblEpsilon || inner < 0.0)) {  // division_undistortion_camera_model.h:281
-    const double sq = sqrt(inner);
-    scale = (1.0 - sq) / denom;
+template <bool JAC, typename T>
+__device__ __forceinline__ void project_division(const T* K, const T q[3], T px[2],
+                                                 T dpdq[2][3], T dpdK[2][10]) {
+  T n[2], dn[2][3];
+  normalize_point<JAC, T>(q, n, dn);
+  const T f = K[0], ar = K[1], k = K[4];
+  const T fy = f * ar;
+  const T u[2] = {f * n[0], fy * n[1]};
+  const T r2 = u[0] * u[0] + u[1] * u[1];
+  const T denom = T(2.0) * k * r2;
+  const T inner = T(1.0) - T(4.0) * k * r2;
+  T scale = T(1.0), dsc_dr2 = T(0.0), dsc_dk = T(0.0);
+  if (!(t_fabs(denom) < kDblEpsilon || inner < T(0.0))) {  // division_undistortion_camera_model.h:281
+    const T sq = t_sqrt(inner);
+    scale = (T(1.0) - sq) / denom;
     if (JAC) {
-      dsc_dr2 = 1.0 / (sq * r2) - scale / r2;
-      dsc_dk = 1.0 / (k * sq) - scale / k;
+      dsc_dr2 = T(1.0) / (sq * r2) - scale / r2;
+      dsc_dk = T(1.0) / (k * sq) - scale / k;
     }
   }
   px[0] = u[0] * scale + K[2];
   px[1] = u[1] * scale + K[3];
   if (JAC) {
-    const double g = 2.0 * dsc_dr2;
+    const T g = T(2.0) * dsc_dr2;
     // d(distorted)/du
-    const double ddu[2][2] = {{scale + u[0] * u[0] * g, u[0] * u[1] * g},
+    const T ddu[2][2] = {{scale + u[0] * u[0] * g, u[0] * u[1] * g},
                               {u[1] * u[0] * g, scale + u[1] * u[1] * g}};
     // du/dq = diag(f, fy) dn/dq
-    double du_dq[2][3];
+    T du_dq[2][3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) { du_dq[0][j] = f * dn[0][j]; du_dq[1][j] = fy * dn[1][j]; }
     chain_2x2_2x3(ddu, du_dq, dpdq);
     // d/df: du/df = (n0, ar n1); d/dar: du/dar = (0, f n1)
-    const double duf[2] = {n[0], ar * n[1]};
-    const double dua[2] = {0.0, f * n[1]};
+    const T duf[2] = {n[0], ar * n[1]};
+    const T dua[2] = {T(0.0), f * n[1]};
     dpdK[0][0] = ddu[0][0] * duf[0] + ddu[0][1] * duf[1];
     dpdK[1][0] = ddu[1][0] * duf[0] + ddu[1][1] * duf[1];
     dpdK[0][1] = ddu[0][0] * dua[0] + ddu[0][1] * dua[1];
     dpdK[1][1] = ddu[1][0] * dua[0] + ddu[1][1] * dua[1];
-    dpdK[0][2] = 1.0; dpdK[1][2] = 0.0;
-    dpdK[0][3] = 0.0; dpdK[1][3] = 1.0;
+    dpdK[0][2] = T(1.0); dpdK[1][2] = T(0.0);
+    dpdK[0][3] = T(0.0); dpdK[1][3] = T(1.0);
     dpdK[0][4] = u[0] * dsc_dk; dpdK[1][4] = u[1] * dsc_dk;
 #pragma unroll
-    for (int j = 5; j < 10; ++j) { dpdK[0][j] = 0.0; dpdK[1][j] = 0.0; }
+    for (int j = 5; j < 10; ++j) { dpdK[0][j] = T(0.0); dpdK[1][j] = T(0.0); }
   }
 }
 
 // CreateReprojectionErrorCostFunction's dispatch
 // (create_reprojection_error_cost_function.h:51-96).
-template <bool JAC>
-__device__ __forceinline__ void project(int model, const double* K, const double q[3], double px[2],
-                                        double dpdq[2][3], double dpdK[2][10]) {
+template <bool JAC, typename T>
+__device__ __forceinline__ void project(int model, const T* K, const T q[3], T px[2],
+                                        T dpdq[2][3], T dpdK[2][10]) {
   switch (model) {
-    case 0: project_pinhole<JAC>(K, q, px, dpdq, dpdK); break;
-    case 1: project_radtan<JAC>(K, q, px, dpdq, dpdK); break;
-    case 2: project_fisheye<JAC>(K, q, px, dpdq, dpdK); break;
-    case 3: project_fov<JAC>(K, q, px, dpdq, dpdK); break;
-    default: project_division<JAC>(K, q, px, dpdq, dpdK); break;
+    case 0: project_pinhole<JAC, T>(K, q, px, dpdq, dpdK); break;
+    case 1: project_radtan<JAC, T>(K, q, px, dpdq, dpdK); break;
+    case 2: project_fisheye<JAC, T>(K, q, px, dpdq, dpdK); break;
+    case 3: project_fov<JAC, T>(K, q, px, dpdq, dpdK); break;
+    default: project_division<JAC, T>(K, q, px, dpdq, dpdK); break;
   }
 }
 
@@ -363,24 +380,34 @@ __device__ __forceinline__ void project(int model, const double* K, const double
 //   Jext [2][6]  d r / d [C, angle-axis]
 //   Jint [2][10] d r / d intrinsics (model order, zero padded)
 //   Jpt  [2][4]  d r / d X (homogeneous)
-template <bool JAC>
+// Parameters and the feature are always fp64.  The camera translation is removed in
+// fp64 (the one place where fp32 would cancel catastrophically); rotation, projection
+// and the Jacobian chain then run in T.
+template <bool JAC, typename T>
 __device__ __forceinline__ bool reprojection_error(int model, const double* ext, const double* K,
                                                    const double* X, double fx, double fy,
-                                                   double r[2], double Jext[2][6],
-                                                   double Jint[2][10], double Jpt[2][4]) {
-  const double w = X[3];
-  const double a[3] = {X[0] - w * ext[0], X[1] - w * ext[1], X[2] - w * ext[2]};
-  if (a[0] * a[0] + a[1] * a[1] + a[2] * a[2] < 1e-8) return false;
-  double q[3], R[3][3], dqdw[3][3], dpdq[2][3], px[2];
-  rotate_point<JAC>(ext + 3, a, q, R, dqdw);
-  project<JAC>(model, K, q, px, dpdq, Jint);
-  r[0] = px[0] - fx;
-  r[1] = px[1] - fy;
+                                                   T r[2], T Jext[2][6],
+                                                   T Jint[2][10], T Jpt[2][4]) {
+  const double wd = X[3];
+  const double ad[3] = {X[0] - wd * ext[0], X[1] - wd * ext[1], X[2] - wd * ext[2]};
+  if (ad[0] * ad[0] + ad[1] * ad[1] + ad[2] * ad[2] < 1e-8) return false;
+  const T w = (T)wd;
+  const T a[3] = {(T)ad[0], (T)ad[1], (T)ad[2]};
+  const T aa[3] = {(T)ext[3], (T)ext[4], (T)ext[5]};
+  const T C[3] = {(T)ext[0], (T)ext[1], (T)ext[2]};
+  T Kt[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) Kt[i] = (T)K[i];
+  T q[3], R[3][3], dqdw[3][3], dpdq[2][3], px[2];
+  rotate_point<JAC, T>(aa, a, q, R, dqdw);
+  project<JAC, T>(model, Kt, q, px, dpdq, Jint);
+  r[0] = (T)((double)px[0] - fx);
+  r[1] = (T)((double)px[1] - fy);
   if (JAC) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       // M = dp/dq * R   (= d r / d X[0:3])
-      double M[3];
+      T M[3];
 #pragma unroll
       for (int j = 0; j < 3; ++j)
         M[j] = dpdq[i][0] * R[0][j] + dpdq[i][1] * R[1][j] + dpdq[i][2] * R[2][j];
@@ -390,7 +417,7 @@ __device__ __forceinline__ bool reprojection_error(int model, const double* ext,
         Jext[i][j] = -w * M[j];  // da/dC = -w I
         Jext[i][3 + j] = dpdq[i][0] * dqdw[0][j] + dpdq[i][1] * dqdw[1][j] + dpdq[i][2] * dqdw[2][j];
       }
-      Jpt[i][3] = -(M[0] * ext[0] + M[1] * ext[1] + M[2] * ext[2]);  // da/dw = -C
+      Jpt[i][3] = -(M[0] * C[0] + M[1] * C[1] + M[2] * C[2]);  // da/dw = -C
     }
   }
   return true;

@@ -69,15 +69,25 @@ struct Launch {
 };
 
 template <int D, int DP, bool SH>
-Launch make_launch() {
+Launch make_launch(bool fp32) {
   Launch L;
-  L.linearize = [](const DeviceView& v, hipStream_t st, int lt, double lw, int nb) {
-    hipLaunchKernelGGL((linearize_kernel<D, DP, SH>), dim3(nb), dim3(256), 0, st, v, lt, lw, nb);
-  };
-  L.cost = [](const DeviceView& v, hipStream_t st, const double* e, const double* i, const double* p,
-              int lt, double lw, int fl, int nb, double* partial) {
-    hipLaunchKernelGGL((cost_kernel<DP>), dim3(nb), dim3(256), 0, st, v, e, i, p, lt, lw, fl, nb, partial);
-  };
+  if (fp32) {
+    L.linearize = [](const DeviceView& v, hipStream_t st, int lt, double lw, int nb) {
+      hipLaunchKernelGGL((linearize_kernel<D, DP, SH, float>), dim3(nb), dim3(256), 0, st, v, lt, lw, nb);
+    };
+    L.cost = [](const DeviceView& v, hipStream_t st, const double* e, const double* i, const double* p,
+                int lt, double lw, int fl, int nb, double* partial) {
+      hipLaunchKernelGGL((cost_kernel<DP, float>), dim3(nb), dim3(256), 0, st, v, e, i, p, lt, lw, fl, nb, partial);
+    };
+  } else {
+    L.linearize = [](const DeviceView& v, hipStream_t st, int lt, double lw, int nb) {
+      hipLaunchKernelGGL((linearize_kernel<D, DP, SH, double>), dim3(nb), dim3(256), 0, st, v, lt, lw, nb);
+    };
+    L.cost = [](const DeviceView& v, hipStream_t st, const double* e, const double* i, const double* p,
+                int lt, double lw, int fl, int nb, double* partial) {
+      hipLaunchKernelGGL((cost_kernel<DP, double>), dim3(nb), dim3(256), 0, st, v, e, i, p, lt, lw, fl, nb, partial);
+    };
+  }
   L.point_scale = [](const DeviceView& v, hipStream_t st, int nb) {
     hipLaunchKernelGGL((point_scale_kernel<DP>), dim3(nb), dim3(256), 0, st, v);
   };
@@ -151,11 +161,11 @@ Launch make_launch() {
   return L;
 }
 
-static bool get_launch(int D, int DP, bool shared, Launch* out) {
-#define TMI_CASE(d, p)                                                     \
-  if (D == d && DP == p) {                                                 \
-    *out = shared ? make_launch<d, p, true>() : make_launch<d, p, false>(); \
-    return true;                                                           \
+static bool get_launch(int D, int DP, bool shared, bool fp32, Launch* out) {
+#define TMI_CASE(d, p)                                                                 \
+  if (D == d && DP == p) {                                                             \
+    *out = shared ? make_launch<d, p, true>(fp32) : make_launch<d, p, false>(fp32);   \
+    return true;                                                                       \
   }
   TMI_CASE(6, 3) TMI_CASE(6, 4) TMI_CASE(9, 3) TMI_CASE(9, 4)
   TMI_CASE(12, 3) TMI_CASE(12, 4) TMI_CASE(16, 3) TMI_CASE(16, 4)
@@ -461,9 +471,9 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
     s->error = "point_dof must be 3 or 4";
     return TMI_BA_ERR_INVALID_ARGUMENT;
   }
-  if (O->residual_precision != 64 && O->residual_precision != 0) {
-    s->error = "only the fp64 residual path is implemented";
-    return TMI_BA_ERR_UNSUPPORTED;
+  if (O->residual_precision != 64 && O->residual_precision != 32 && O->residual_precision != 0) {
+    s->error = "residual_precision must be 64 or 32";
+    return TMI_BA_ERR_INVALID_ARGUMENT;
   }
   s->DP = O->point_dof;
   const bool iterative_type =
@@ -486,7 +496,7 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
     return rc;
   }
   Structure& st = s->st;
-  if (!get_launch(st.D, s->DP, st.has_shared, &s->launch)) {
+  if (!get_launch(st.D, s->DP, st.has_shared, O->residual_precision == 32, &s->launch)) {
     s->error = "no kernel instantiation for this block size";
     return TMI_BA_ERR_UNSUPPORTED;
   }

@@ -112,7 +112,7 @@ struct LinearizeArgs {
   int point_dof_mask;  // unused
 };
 
-template <int D, int DP, bool SH>
+template <int D, int DP, bool SH, typename RT>
 __global__ __launch_bounds__(256) void linearize_kernel(DeviceView v, int loss_type, double loss_width,
                                                         int nblocks) {
   const int lane = threadIdx.x & 63;
@@ -145,8 +145,11 @@ __global__ __launch_bounds__(256) void linearize_kernel(DeviceView v, int loss_t
 #pragma unroll
       for (int i = 0; i < 6; ++i) E[i] = v.ext[(size_t)cam * 6 + i];
       const double fx = v.obs_xy[2 * e], fy = v.obs_xy[2 * e + 1];
-      double r[2], Jext[2][6], Jint[2][10], Jpt[2][4];
-      const bool ok = reprojection_error<true>(model, E, Kv, X, fx, fy, r, Jext, Jint, Jpt);
+      // RT = double, or float for the fp32 residual path: everything downstream of the
+      // evaluation (loss correction, scaling, normal equations) stays fp64
+      RT rr[2], Jext[2][6], Jint[2][10], Jpt[2][4];
+      const bool ok = reprojection_error<true, RT>(model, E, Kv, X, fx, fy, rr, Jext, Jint, Jpt);
+      double r[2] = {(double)rr[0], (double)rr[1]};
       const unsigned mask = v.cam_mask[cam];
       const int rb = v.cam_rb[cam];
       if (!ok) {
@@ -183,8 +186,8 @@ __global__ __launch_bounds__(256) void linearize_kernel(DeviceView v, int loss_t
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
         if (mask & (1u << c)) {
-          double j0 = (c < 6) ? Jext[0][c < 6 ? c : 0] : Jint[0][c >= 6 ? c - 6 : 0];
-          double j1 = (c < 6) ? Jext[1][c < 6 ? c : 0] : Jint[1][c >= 6 ? c - 6 : 0];
+          double j0 = (double)((c < 6) ? Jext[0][c < 6 ? c : 0] : Jint[0][c >= 6 ? c - 6 : 0]);
+          double j1 = (double)((c < 6) ? Jext[1][c < 6 ? c : 0] : Jint[1][c >= 6 ? c - 6 : 0]);
           if (loss_type != 0) {
             const double rtj = j0 * r[0] + j1 * r[1];
             j0 = sqrt_rho1 * (j0 - asn * r[0] * rtj);
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(256) void linearize_kernel(DeviceView v, int loss_t
 #pragma unroll
           for (int c = 0; c < 10; ++c) {
             if (gmask & (1u << c)) {
-              double j0 = Jint[0][c], j1 = Jint[1][c];
+              double j0 = (double)Jint[0][c], j1 = (double)Jint[1][c];
               if (loss_type != 0) {
                 const double rtj = j0 * r[0] + j1 * r[1];
                 j0 = sqrt_rho1 * (j0 - asn * r[0] * rtj);
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(256) void linearize_kernel(DeviceView v, int loss_t
       }
 #pragma unroll
       for (int a = 0; a < DP; ++a) {
-        double j0 = pconst ? 0.0 : Jpt[0][a], j1 = pconst ? 0.0 : Jpt[1][a];
+        double j0 = pconst ? 0.0 : (double)Jpt[0][a], j1 = pconst ? 0.0 : (double)Jpt[1][a];
         if (loss_type != 0) {
           const double rtj = j0 * r[0] + j1 * r[1];
           j0 = sqrt_rho1 * (j0 - asn * r[0] * rtj);
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(256) void linearize_kernel(DeviceView v, int loss_t
 }
 
 // cost only, at a given parameter set (kernel class 9): hot loop 1, residual-only.
-template <int DP>
+template <int DP, typename RT>
 __global__ __launch_bounds__(256) void cost_kernel(DeviceView v, const double* __restrict__ ext,
                                                    const double* __restrict__ intr,
                                                    const double* __restrict__ pts, int loss_type,
@@ -270,12 +273,13 @@ __global__ __launch_bounds__(256) void cost_kernel(DeviceView v, const double* _
       for (int i = 0; i < 10; ++i) Kv[i] = (i < nk) ? Kp[i] : 0.0;
 #pragma unroll
       for (int i = 0; i < 6; ++i) E[i] = ext[(size_t)cam * 6 + i];
-      double r[2];
-      double (*nul6)[6] = nullptr;
-      double Jint[2][10];
-      double (*nul4)[4] = nullptr;
-      const bool ok = reprojection_error<false>(v.grp_model[grp], E, Kv, X, v.obs_xy[2 * e],
-                                                v.obs_xy[2 * e + 1], r, nul6, Jint, nul4);
+      RT rr[2];
+      RT (*nul6)[6] = nullptr;
+      RT Jint[2][10];
+      RT (*nul4)[4] = nullptr;
+      const bool ok = reprojection_error<false, RT>(v.grp_model[grp], E, Kv, X, v.obs_xy[2 * e],
+                                                    v.obs_xy[2 * e + 1], rr, nul6, Jint, nul4);
+      const double r[2] = {(double)rr[0], (double)rr[1]};
       if (!ok) {
         v.flags[flag_slot] = 1;
         continue;
