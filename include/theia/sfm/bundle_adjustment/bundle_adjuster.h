@@ -40,6 +40,9 @@ struct FlattenedBundleAdjustmentProblem {
   tmi_ba_problem AsC();
 };
 
+// BundleAdjustmentOptions -> the C ABI's option block.
+void ToDeviceOptions(const BundleAdjustmentOptions& options, tmi_ba_options* device_options);
+
 class BundleAdjuster {
  public:
   BundleAdjuster(const BundleAdjustmentOptions& options, Reconstruction* reconstruction);

@@ -5,6 +5,7 @@
 // done by the MI355X engine behind include/theia_mi355_ba.h instead of Ceres.
 #ifndef THEIA_MI355_BUNDLE_ADJUSTMENT_H_
 #define THEIA_MI355_BUNDLE_ADJUSTMENT_H_
+#include <unordered_map>
 #include <unordered_set>
 #include "ceres/types.h"
 #include "theia/sfm/bundle_adjustment/create_loss_function.h"
@@ -82,5 +83,13 @@ BundleAdjustmentSummary BundleAdjustView(const BundleAdjustmentOptions& options,
                                          Reconstruction* reconstruction);
 BundleAdjustmentSummary BundleAdjustTrack(const BundleAdjustmentOptions& options,
                                           const TrackId track_id, Reconstruction* reconstruction);
+
+// Extension of the MI355X path: BundleAdjustTrack for many tracks in ONE device launch
+// (one independent trust-region problem per GPU thread) instead of one call per track per
+// CPU thread (estimate_track.cc:166-204,238-246).  Same per-track semantics and summary as
+// BundleAdjustTrack; tracks that are not estimated are skipped (absent from the result).
+std::unordered_map<TrackId, BundleAdjustmentSummary> BundleAdjustTracks(
+    const BundleAdjustmentOptions& options, const std::unordered_set<TrackId>& track_ids,
+    Reconstruction* reconstruction);
 }  // namespace theia
 #endif

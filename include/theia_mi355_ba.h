@@ -358,6 +358,72 @@ int32_t tmi_ba_solver_evaluate(tmi_ba_solver* s, double* residuals,
                                double* jac_point, uint8_t* valid,
                                int32_t* block_dim);
 
+/* ---- steps either side of the full adjustment ----------------------- */
+
+/* Post-BA outlier filter: theia::SetOutlierTracksToUnestimated
+ * (src/theia/sfm/set_outlier_tracks_to_unestimated.cc:62-133; callers
+ * global_reconstruction_estimator.cc:259-263, incremental_reconstruction_estimator.cc:525,592).
+ * Every camera and track of the flattened problem counts as estimated.  Per track:
+ *   flag 1  a projection lies behind its camera (Camera::ProjectPoint depth < 0, :101-105) or
+ *           the mean squared reprojection error exceeds max_inlier_reprojection_error^2 (:110-115)
+ *   flag 2  no pair of viewing rays subtends min_triangulation_angle_degrees
+ *           (SufficientTriangulationAngle, triangulation.cc:236-250; :120-125)
+ *   flag 0  the track stays estimated.
+ * The caller applies the flags (Track::SetEstimated(false)); the return value of the
+ * reference is num_bad_reprojections + num_insufficient_viewing_angles. */
+typedef struct tmi_ba_filter_summary {
+  int64_t num_estimated_tracks;
+  int64_t num_bad_reprojections;
+  int64_t num_insufficient_viewing_angles;
+  double seconds;        /* wall time of the call */
+  double kernel_seconds; /* the device kernel alone (HIP events) */
+} tmi_ba_filter_summary;
+
+/* On the parameters resident in `solver` (e.g. right after tmi_ba_solver_solve: nothing is
+ * uploaded).  track_flag / track_mean_sq_error are indexed by the caller's track index,
+ * [num_points]; entries of tracks owned by other ranks are left untouched and the counts
+ * cover this rank's tracks.  Either output may be NULL. */
+int32_t tmi_ba_solver_filter_outlier_tracks(tmi_ba_solver* solver,
+                                            double max_inlier_reprojection_error,
+                                            double min_triangulation_angle_degrees,
+                                            uint8_t* track_flag, double* track_mean_sq_error,
+                                            tmi_ba_filter_summary* summary);
+
+/* One-shot form: uploads the problem, filters, frees everything. device < 0 = current. */
+int32_t tmi_ba_filter_outlier_tracks(const tmi_ba_problem* problem, int32_t device,
+                                     double max_inlier_reprojection_error,
+                                     double min_triangulation_angle_degrees, uint8_t* track_flag,
+                                     double* track_mean_sq_error, tmi_ba_filter_summary* summary);
+
+/* Batched theia::BundleAdjustTrack (bundle_adjustment.cc:96-107, called once per track from
+ * estimate_track.cc:238-246): every non-constant track of the problem is adjusted on its own
+ * with all cameras and intrinsics held constant -- one independent trust-region problem per
+ * GPU thread, same Levenberg-Marquardt semantics and options as tmi_ba_solve (the linear
+ * solve is the track's own point_dof x point_dof system; linear_solver_type is irrelevant,
+ * max_solver_time_in_seconds is not enforced).
+ * track_termination[num_points]: 0 CONVERGENCE, 1 NO_CONVERGENCE, 2 FAILURE, 3 residual
+ * evaluation failed at the start point, -1 not adjusted (constant or unobserved track).
+ * BundleAdjustmentSummary::success of the per-track call == (termination is 0 or 1); points
+ * are updated exactly in that case.  All per-track outputs may be NULL. */
+typedef struct tmi_ba_track_batch_summary {
+  int64_t num_tracks;       /* tracks adjusted */
+  int64_t num_success;
+  int64_t total_iterations; /* sum of LM iterations over the tracks */
+  double seconds;
+  double kernel_seconds;
+} tmi_ba_track_batch_summary;
+
+int32_t tmi_ba_solver_adjust_tracks(tmi_ba_solver* solver, const tmi_ba_options* options,
+                                    int8_t* track_termination, int32_t* track_iterations,
+                                    double* track_initial_cost, double* track_final_cost,
+                                    tmi_ba_track_batch_summary* summary);
+
+/* One-shot form; problem->points is updated in place. */
+int32_t tmi_ba_adjust_tracks(tmi_ba_problem* problem, const tmi_ba_options* options,
+                             int8_t* track_termination, int32_t* track_iterations,
+                             double* track_initial_cost, double* track_final_cost,
+                             tmi_ba_track_batch_summary* summary);
+
 /* Host-only: statistics of the static structure the engine would build for
  * rank `rank` of `world` (no GPU needed).  Used by the CPU tests of the track
  * sharding: out[0] tracks owned, out[1] observations owned, out[2] reduced

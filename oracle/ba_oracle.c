@@ -1518,3 +1518,181 @@ int32_t oracle_ba_solve(tmi_ba_problem* P, const tmi_ba_options* O, tmi_ba_summa
   free_state(s);
   return sum->status;
 }
+
+/* ---- post-BA outlier filter -------------------------------- */
+/* SufficientTriangulationAngle, reference triangulation/triangulation.cc:236-250;
+ * DegToRad: math/util.h:48-56 */
+int32_t oracle_sufficient_triangulation_angle(const double* rays3, int64_t n,
+                                              double min_triangulation_angle_degrees) {
+  const double cos_of_min_angle = cos(min_triangulation_angle_degrees * (M_PI / 180.0));
+  for (int64_t i = 0; i < n; ++i)
+    for (int64_t j = i + 1; j < n; ++j) {
+      const double d = rays3[3 * i] * rays3[3 * j] + rays3[3 * i + 1] * rays3[3 * j + 1] +
+                       rays3[3 * i + 2] * rays3[3 * j + 2];
+      if (d < cos_of_min_angle) return 1;
+    }
+  return 0;
+}
+
+/* SetOutlierTracksToUnestimated, reference set_outlier_tracks_to_unestimated.cc:62-133,
+ * over the flattened problem (every camera and every track of `P` is "estimated").
+ * flag: 0 kept, 1 bad reprojection (mean squared error above the threshold, or a
+ * projection behind a camera :101-105), 2 insufficient viewing angle (:120-125).
+ * Observations of a track are visited in the caller's order (the reference follows
+ * unordered_set iteration; the outcome does not depend on it apart from the rounding
+ * of the sum).  counts = {estimated tracks, bad reprojections, insufficient angles}. */
+int32_t oracle_filter_outlier_tracks(const tmi_ba_problem* P, double max_inlier_reprojection_error,
+                                     double min_triangulation_angle_degrees, uint8_t* flag,
+                                     double* mean_sq_error, int64_t counts[3]) {
+  const double max_sq = max_inlier_reprojection_error * max_inlier_reprojection_error;
+  const int64_t Np = P->num_points, No = P->num_observations;
+  int64_t* ptr = (int64_t*)calloc((size_t)Np + 2, sizeof(int64_t));
+  int64_t* idx = (int64_t*)malloc(sizeof(int64_t) * (size_t)(No > 0 ? No : 1));
+  for (int64_t o = 0; o < No; ++o) ptr[P->obs_point[o] + 2]++;
+  for (int64_t p = 0; p < Np; ++p) ptr[p + 2] += ptr[p + 1];
+  for (int64_t o = 0; o < No; ++o) idx[ptr[P->obs_point[o] + 1]++] = o;
+  int64_t nbad = 0, nangle = 0;
+#pragma omp parallel for schedule(dynamic, 256) reduction(+ : nbad, nangle)
+  for (int64_t p = 0; p < Np; ++p) {
+    const double* X = P->points + 4 * p;
+    const int64_t b = ptr[p], e = ptr[p + 1];
+    double* rays = (double*)malloc(sizeof(double) * 3 * (size_t)(e - b + 1));
+    int64_t nr = 0;
+    int estimated = 1;
+    int64_t nproj = 0;
+    double sum = 0.0;
+    for (int64_t q = b; q < e; ++q) {
+      const int64_t o = idx[q];
+      const int cam = P->obs_camera[o];
+      const double* ext = P->extrinsics + 6 * (size_t)cam;
+      const int g = P->camera_group[cam];
+      /* :87-89 ray = hnormalized(point) - position, normalized */
+      double r[3] = {X[0] / X[3] - ext[0], X[1] / X[3] - ext[1], X[2] / X[3] - ext[2]};
+      const double n2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+      if (n2 > 0.0) {
+        const double n = sqrt(n2);
+        r[0] /= n; r[1] /= n; r[2] /= n;
+      }
+      rays[3 * nr] = r[0]; rays[3 * nr + 1] = r[1]; rays[3 * nr + 2] = r[2];
+      ++nr;
+      double px[2];
+      const double depth = oracle_project_point(P->group_model[g], ext,
+                                                P->intrinsics + P->group_offset[g], X, px);
+      if (depth < 0) {
+        estimated = 0;
+        break;
+      }
+      const double dx = px[0] - P->obs_xy[2 * o], dy = px[1] - P->obs_xy[2 * o + 1];
+      sum += dx * dx + dy * dy;
+      ++nproj;
+    }
+    int f = 0;
+    double mean = sum / (double)nproj;
+    if (!estimated) {
+      f = 1;
+    } else if (mean > max_sq) {
+      f = 1;
+    } else if (!oracle_sufficient_triangulation_angle(rays, nr, min_triangulation_angle_degrees)) {
+      f = 2;
+    }
+    if (f == 1) ++nbad;
+    if (f == 2) ++nangle;
+    if (flag) flag[p] = (uint8_t)f;
+    if (mean_sq_error) mean_sq_error[p] = mean;
+    free(rays);
+  }
+  if (counts) {
+    counts[0] = Np;
+    counts[1] = nbad;
+    counts[2] = nangle;
+  }
+  free(ptr);
+  free(idx);
+  return TMI_BA_OK;
+}
+
+/* ---- batched BundleAdjustTrack -------------------------------- */
+/* theia::BundleAdjustTrack, reference bundle_adjustment.cc:96-107 -> BundleAdjuster::AddTrack
+ * (bundle_adjuster.cc:141-180): the residuals of one track, every observing camera's
+ * extrinsics and intrinsics constant, the track variable; solved with the LM above.
+ * Run once per non-constant track of `P` (the way estimate_track.cc:238-246 calls it), each
+ * on its own sub-problem.  termination: 0/1/2 as tmi_ba_summary, 3 = evaluation failed at
+ * the start point, -1 = not adjusted (constant or unobserved track). */
+int32_t oracle_adjust_tracks(tmi_ba_problem* P, const tmi_ba_options* O, int8_t* termination,
+                             int32_t* iterations, double* initial_cost, double* final_cost) {
+  if (!validate(P) || !O) return TMI_BA_ERR_INVALID_ARGUMENT;
+  const int64_t Np = P->num_points, No = P->num_observations;
+  int64_t* ptr = (int64_t*)calloc((size_t)Np + 2, sizeof(int64_t));
+  int64_t* idx = (int64_t*)malloc(sizeof(int64_t) * (size_t)(No > 0 ? No : 1));
+  for (int64_t o = 0; o < No; ++o) ptr[P->obs_point[o] + 2]++;
+  for (int64_t p = 0; p < Np; ++p) ptr[p + 2] += ptr[p + 1];
+  for (int64_t o = 0; o < No; ++o) idx[ptr[P->obs_point[o] + 1]++] = o;
+#pragma omp parallel for schedule(dynamic, 16)
+  for (int64_t p = 0; p < Np; ++p) {
+    const int64_t b = ptr[p], e = ptr[p + 1];
+    const int k = (int)(e - b);
+    if (k == 0 || (P->point_constant && P->point_constant[p])) {
+      if (termination) termination[p] = -1;
+      if (iterations) iterations[p] = 0;
+      if (initial_cost) initial_cost[p] = 0.0;
+      if (final_cost) final_cost[p] = 0.0;
+      continue;
+    }
+    /* sub-problem: the k observing cameras, one private copy of their intrinsics each */
+    double* ext = (double*)malloc(sizeof(double) * 6 * (size_t)k);
+    int32_t* cgrp = (int32_t*)malloc(sizeof(int32_t) * (size_t)k);
+    uint8_t* cflag = (uint8_t*)malloc((size_t)k);
+    int32_t* gmodel = (int32_t*)malloc(sizeof(int32_t) * (size_t)k);
+    int32_t* goff = (int32_t*)malloc(sizeof(int32_t) * ((size_t)k + 1));
+    double* intr = (double*)malloc(sizeof(double) * 10 * (size_t)k);
+    uint8_t* iconst = (uint8_t*)malloc(10 * (size_t)k);
+    int32_t* ocam = (int32_t*)malloc(sizeof(int32_t) * (size_t)k);
+    int32_t* opt = (int32_t*)calloc((size_t)k, sizeof(int32_t));
+    double* oxy = (double*)malloc(sizeof(double) * 2 * (size_t)k);
+    double X[4];
+    uint8_t pconst = 0;
+    memcpy(X, P->points + 4 * p, sizeof(X));
+    goff[0] = 0;
+    for (int j = 0; j < k; ++j) {
+      const int64_t o = idx[b + j];
+      const int cam = P->obs_camera[o];
+      const int g = P->camera_group[cam];
+      const int n = P->group_offset[g + 1] - P->group_offset[g];
+      memcpy(ext + 6 * j, P->extrinsics + 6 * (size_t)cam, sizeof(double) * 6);
+      cgrp[j] = j;
+      cflag[j] = TMI_BA_CAMERA_POSITION_CONSTANT | TMI_BA_CAMERA_ORIENTATION_CONSTANT;
+      gmodel[j] = P->group_model[g];
+      memcpy(intr + goff[j], P->intrinsics + P->group_offset[g], sizeof(double) * (size_t)n);
+      memset(iconst + goff[j], 1, (size_t)n);
+      goff[j + 1] = goff[j] + n;
+      ocam[j] = j;
+      oxy[2 * j] = P->obs_xy[2 * o];
+      oxy[2 * j + 1] = P->obs_xy[2 * o + 1];
+    }
+    tmi_ba_problem Q;
+    memset(&Q, 0, sizeof(Q));
+    Q.num_cameras = k; Q.extrinsics = ext; Q.camera_group = cgrp; Q.camera_flags = cflag;
+    Q.num_groups = k; Q.group_model = gmodel; Q.group_offset = goff; Q.intrinsics = intr;
+    Q.intrinsics_constant = iconst;
+    Q.num_points = 1; Q.points = X; Q.point_constant = &pconst;
+    Q.num_observations = k; Q.obs_camera = ocam; Q.obs_point = opt; Q.obs_xy = oxy;
+    tmi_ba_options o2 = *O;
+    o2.linear_solver_type = TMI_BA_DENSE_QR; /* bundle_adjustment.cc:100-101 */
+    o2.use_inner_iterations = 0;
+    o2.verbose = 0;
+    tmi_ba_summary sm;
+    const int32_t st = oracle_ba_solve(&Q, &o2, &sm);
+    int8_t t = (int8_t)sm.termination;
+    if (st == TMI_BA_ERR_EVALUATION_FAILED) t = 3;
+    if (termination) termination[p] = t;
+    if (iterations) iterations[p] = sm.num_iterations;
+    if (initial_cost) initial_cost[p] = sm.initial_cost;
+    if (final_cost) final_cost[p] = sm.final_cost;
+    if (t == 0 || t == 1) memcpy(P->points + 4 * p, X, sizeof(X));
+    free(ext); free(cgrp); free(cflag); free(gmodel); free(goff); free(intr); free(iconst);
+    free(ocam); free(opt); free(oxy);
+  }
+  free(ptr);
+  free(idx);
+  return TMI_BA_OK;
+}

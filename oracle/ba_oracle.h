@@ -79,6 +79,28 @@ void oracle_loss(int32_t type, double width, double s, double rho[3]);
  * tmi_ba_intrinsics_constant_mask). */
 int32_t oracle_intrinsics_constant_mask(int32_t model, int32_t bitmask, uint8_t* mask);
 
+/* SufficientTriangulationAngle (triangulation.cc:236-250) over n unit rays. */
+int32_t oracle_sufficient_triangulation_angle(const double* rays3, int64_t n,
+                                              double min_triangulation_angle_degrees);
+
+/* SetOutlierTracksToUnestimated (set_outlier_tracks_to_unestimated.cc:62-133) over the
+ * flattened problem.  flag[num_points]: 0 kept, 1 bad reprojection / behind a camera,
+ * 2 insufficient viewing angle; mean_sq_error[num_points] (may be NULL; value at the
+ * point the reference's loop stops); counts = {estimated, bad reprojections,
+ * insufficient angles}. */
+int32_t oracle_filter_outlier_tracks(const tmi_ba_problem* problem,
+                                     double max_inlier_reprojection_error,
+                                     double min_triangulation_angle_degrees, uint8_t* flag,
+                                     double* mean_sq_error, int64_t counts[3]);
+
+/* theia::BundleAdjustTrack (bundle_adjustment.cc:96-107) run once per non-constant track,
+ * each on its own sub-problem with the observing cameras constant.  problem->points is
+ * updated for usable solutions.  termination: 0/1/2 as in tmi_ba_summary, 3 evaluation
+ * failed at the start, -1 not adjusted.  Outputs may be NULL. */
+int32_t oracle_adjust_tracks(tmi_ba_problem* problem, const tmi_ba_options* options,
+                             int8_t* termination, int32_t* iterations, double* initial_cost,
+                             double* final_cost);
+
 int32_t oracle_num_threads(void);
 
 #ifdef __cplusplus

@@ -47,6 +47,14 @@ def lib():
         L.oracle_intrinsics_constant_mask.argtypes = [C.c_int32, C.c_int32, C.c_void_p]
         L.oracle_intrinsics_constant_mask.restype = C.c_int32
         L.oracle_num_threads.restype = C.c_int32
+        L.oracle_adjust_tracks.argtypes = [C.POINTER(abi.CProblem), C.POINTER(abi.COptions),
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_adjust_tracks.restype = C.c_int32
+        L.oracle_sufficient_triangulation_angle.argtypes = [C.c_void_p, C.c_int64, C.c_double]
+        L.oracle_sufficient_triangulation_angle.restype = C.c_int32
+        L.oracle_filter_outlier_tracks.argtypes = [C.POINTER(abi.CProblem), C.c_double, C.c_double,
+                                                   C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_filter_outlier_tracks.restype = C.c_int32
         _lib = L
     return _lib
 
@@ -130,6 +138,41 @@ def intrinsics_constant_mask(model, bits):
     out = np.zeros(abi.INTRINSICS_SIZE[model], dtype=np.uint8)
     lib().oracle_intrinsics_constant_mask(model, bits, out.ctypes.data)
     return out
+
+
+def sufficient_triangulation_angle(rays, min_angle_degrees) -> bool:
+    rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 3)
+    return bool(lib().oracle_sufficient_triangulation_angle(rays.ctypes.data, rays.shape[0],
+                                                            float(min_angle_degrees)))
+
+
+def filter_outlier_tracks(problem: abi.Problem, max_inlier_reprojection_error,
+                          min_triangulation_angle_degrees):
+    """flag [Np] (0 kept / 1 bad reprojection / 2 insufficient angle), mean squared
+    reprojection error [Np], counts (estimated, bad reprojections, insufficient angles)."""
+    n = problem.num_points
+    flag = np.zeros(n, dtype=np.uint8)
+    mean = np.zeros(n)
+    counts = np.zeros(3, dtype=np.int64)
+    cp = problem.as_c()
+    lib().oracle_filter_outlier_tracks(C.byref(cp), float(max_inlier_reprojection_error),
+                                       float(min_triangulation_angle_degrees), flag.ctypes.data,
+                                       mean.ctypes.data, counts.ctypes.data)
+    return flag, mean, counts
+
+
+def adjust_tracks(problem: abi.Problem, options: abi.COptions):
+    """Per-track BundleAdjustTrack on the CPU; problem.points updated in place."""
+    n = problem.num_points
+    term = np.full(n, -1, dtype=np.int8)
+    iters = np.zeros(n, dtype=np.int32)
+    c0 = np.zeros(n)
+    c1 = np.zeros(n)
+    cp = problem.as_c()
+    st = lib().oracle_adjust_tracks(C.byref(cp), C.byref(options), term.ctypes.data,
+                                    iters.ctypes.data, c0.ctypes.data, c1.ctypes.data)
+    assert st == 0, st
+    return term, iters, c0, c1
 
 
 def num_threads() -> int:

@@ -13,6 +13,7 @@
 #include "theia/sfm/bundle_adjustment/bundle_adjuster.h"
 #include "theia/sfm/bundle_adjustment/bundle_adjustment.h"
 #include "theia/sfm/reconstruction.h"
+#include "theia/sfm/set_outlier_tracks_to_unestimated.h"
 
 using namespace theia;
 
@@ -225,10 +226,77 @@ static void TestGpu() {
   }
 }
 
+// SetOutlierTracksToUnestimated (set_outlier_tracks_to_unestimated.cc:62-133) and the batched
+// BundleAdjustTracks, end to end through the shim.
+static void TestTrackOpsGpu() {
+  Reconstruction rec;
+  BuildScene(&rec, 6, 150, /*share_groups=*/false, 21, 0.0);
+  // track 0: a gross feature error in every view; track 1: behind the cameras;
+  // track 2: far away (no viewing angle); track 3: not estimated (must be ignored);
+  // track 4: none of its views estimated is impossible here, so un-estimate one view instead
+  for (ViewId v : rec.ViewIds()) {
+    const Feature* f = rec.View(v)->GetFeature(0);
+    rec.MutableView(v)->AddFeature(0, Feature(f->x() + 25.0, f->y() - 25.0));
+  }
+  (*rec.MutableTrack(1)->MutablePoint())[2] = -200.0;
+  for (int i = 0; i < 3; ++i) (*rec.MutableTrack(2)->MutablePoint())[i] *= 1.0;
+  (*rec.MutableTrack(2)->MutablePoint())[2] = 1e7;
+  rec.MutableTrack(3)->SetEstimated(false);
+  const int removed = SetOutlierTracksToUnestimated(4.0, 1.0, &rec);
+  std::printf("outlier filter: %d removed\n", removed);
+  EXPECT(!rec.Track(0)->IsEstimated());
+  EXPECT(!rec.Track(1)->IsEstimated());
+  EXPECT(!rec.Track(2)->IsEstimated());
+  EXPECT(!rec.Track(3)->IsEstimated());
+  int estimated = 0;
+  for (TrackId t : rec.TrackIds()) estimated += rec.Track(t)->IsEstimated();
+  EXPECT(removed == 3);            // track 3 was not estimated: not counted (:77-79)
+  EXPECT(estimated == 150 - 4);    // noise-free tracks with a wide baseline stay
+  // only the listed tracks are examined
+  (*rec.MutableTrack(10)->MutablePoint())[2] = -200.0;
+  (*rec.MutableTrack(11)->MutablePoint())[2] = -200.0;
+  EXPECT(SetOutlierTracksToUnestimated(std::unordered_set<TrackId>{10}, 4.0, 1.0, &rec) == 1);
+  EXPECT(!rec.Track(10)->IsEstimated() && rec.Track(11)->IsEstimated());
+  (*rec.MutableTrack(11)->MutablePoint())[2] = 0.0;
+
+  // batched track adjustment == BundleAdjustTrack per track
+  Reconstruction a, b;
+  BuildScene(&a, 6, 80, false, 33, 0.8);
+  BuildScene(&b, 6, 80, false, 33, 0.8);
+  BundleAdjustmentOptions opt;
+  std::unordered_set<TrackId> ids;
+  for (TrackId t : a.TrackIds()) ids.insert(t);
+  a.MutableTrack(7)->SetEstimated(false);
+  b.MutableTrack(7)->SetEstimated(false);
+  const Eigen::Vector3d cam0 = a.View(0)->Camera().GetPosition();
+  const auto res = BundleAdjustTracks(opt, ids, &a);
+  EXPECT(res.size() == 79 && !res.count(7));
+  double worst = 0.0;
+  int ok = 0;
+  for (TrackId t : b.TrackIds()) {
+    if (t == 7) continue;
+    const BundleAdjustmentSummary s1 = BundleAdjustTrack(opt, t, &b);
+    const BundleAdjustmentSummary& sN = res.at(t);
+    ok += sN.success;
+    EXPECT(s1.success == sN.success);
+    EXPECT(std::fabs(s1.final_cost - sN.final_cost) <= 1e-9 * (1.0 + s1.final_cost));
+    EXPECT(sN.final_cost <= sN.initial_cost);
+    for (int i = 0; i < 4; ++i)
+      worst = std::fmax(worst, std::fabs(a.Track(t)->Point()[i] - b.Track(t)->Point()[i]));
+  }
+  std::printf("batched track BA: %d/79 usable, max |dX| vs per-track BA %.3e\n", ok, worst);
+  EXPECT(ok == 79);
+  EXPECT(worst < 1e-9);
+  EXPECT(a.View(0)->Camera().GetPosition()[0] == cam0[0]);  // cameras are constant
+}
+
 int main(int argc, char** argv) {
   const std::string mode = argc > 1 ? argv[1] : "cpu";
   TestSemantics();
-  if (mode == "gpu") TestGpu();
+  if (mode == "gpu") {
+    TestGpu();
+    TestTrackOpsGpu();
+  }
   std::printf("%s: %d failure(s)\n", mode.c_str(), g_fail);
   return g_fail ? 1 : 0;
 }

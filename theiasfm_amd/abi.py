@@ -144,6 +144,26 @@ class CSummary(C.Structure):
         return d
 
 
+class CFilterSummary(C.Structure):
+    _fields_ = [
+        ("num_estimated_tracks", C.c_int64),
+        ("num_bad_reprojections", C.c_int64),
+        ("num_insufficient_viewing_angles", C.c_int64),
+        ("seconds", C.c_double),
+        ("kernel_seconds", C.c_double),
+    ]
+
+
+class CTrackBatchSummary(C.Structure):
+    _fields_ = [
+        ("num_tracks", C.c_int64),
+        ("num_success", C.c_int64),
+        ("total_iterations", C.c_int64),
+        ("seconds", C.c_double),
+        ("kernel_seconds", C.c_double),
+    ]
+
+
 def default_options(**overrides) -> COptions:
     """BundleAdjustmentOptions defaults (bundle_adjustment.h:78-122) plus the
     Ceres defaults Theia inherits.  Mirrors tmi_ba_options_init."""

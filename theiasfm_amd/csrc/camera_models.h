@@ -423,6 +423,19 @@ __device__ __forceinline__ bool reprojection_error(int model, const double* ext,
   return true;
 }
 
+// Camera::ProjectPoint (camera.cc:204-213): pixel and depth = rotated_z / w; unlike the
+// residual functor it has no degenerate-point test.
+__device__ __forceinline__ double project_point_depth(int model, const double* ext,
+                                                      const double* K, const double* X,
+                                                      double px[2]) {
+  const double a[3] = {X[0] - X[3] * ext[0], X[1] - X[3] * ext[1], X[2] - X[3] * ext[2]};
+  const double aa[3] = {ext[3], ext[4], ext[5]};
+  double q[3], R[3][3], dqdw[3][3], dpdq[2][3], dpdK[2][10];
+  rotate_point<false, double>(aa, a, q, R, dqdw);
+  project<false, double>(model, K, q, px, dpdq, dpdK);
+  return q[2] / X[3];
+}
+
 // ceres/loss_function.cc (1.x) restated for the device: rho, rho', rho''.
 __device__ __forceinline__ void loss_eval(int type, double a, double s, double rho[3]) {
   switch (type) {

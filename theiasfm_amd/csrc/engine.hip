@@ -23,6 +23,7 @@
 #include "../../include/theia_mi355_ba.h"
 #include "dense_cholesky.h"
 #include "kernels.h"
+#include "track_kernels.h"
 #include "structure.h"
 
 namespace tmi {
@@ -215,6 +216,15 @@ struct tmi_ba_solver {
   int64_t launches[TMI_BA_NUM_KERNEL_CLASSES] = {0};
   std::string error;
   double setup_seconds = 0.0;
+  // per-track side kernels (outlier filter, batched track adjustment): parameters + SELL
+  // layout only when `light`; output arrays allocated on first use
+  bool light = false;
+  unsigned char* d_trk_flag = nullptr;
+  double* d_trk_mean = nullptr;
+  signed char* d_trk_term = nullptr;
+  int* d_trk_iter = nullptr;
+  double* d_trk_c0 = nullptr;
+  double* d_trk_c1 = nullptr;
 };
 
 namespace {
@@ -450,7 +460,8 @@ void tmi_ba_solver_destroy(tmi_ba_solver* s) {
 }
 
 static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_options* O, int rank,
-                       int world) {
+                       int world, bool light = false) {
+  s->light = light;
   const double t0 = now_s();
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -484,7 +495,8 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   }
   // implicit needs an iterative solver; auto = explicit on one GPU, implicit on several
   s->implicit = iterative_type && (O->schur_mode == 2 || (O->schur_mode == 0 && world > 1));
-  int rc = build_structure(P, rank, world, &s->st, !s->implicit);
+  if (light) s->implicit = false;
+  int rc = build_structure(P, rank, world, &s->st, !s->implicit && !light);
   if (rc == TMI_BA_OK && s->implicit && s->st.has_shared) {
     // shared intrinsics blocks are only wired into the explicit operator so far
     s->implicit = false;
@@ -588,6 +600,11 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   s->nblocks_points = (st.Np_pad + 255) / 256;
   if (s->nblocks_points < 1) s->nblocks_points = 1;
   const int nbmax = std::max(s->nblocks_slices, s->nblocks_points);
+  if (light) {
+    TMI_HIP(hipStreamSynchronize(s->stream));
+    s->setup_seconds = now_s() - t0;
+    return TMI_BA_OK;
+  }
 #define AL(ptr, n) if ((rc = dev_alloc(s, &ptr, (size_t)(n)))) return rc;
   AL(v.pm_r, 2 * N) AL(v.pm_A, 2 * D * N) AL(v.pm_Jp, 2 * DP * N) AL(s->d_pm_u, 2 * N)
   AL(s->d_cm_t, s->implicit ? (size_t)std::max<int64_t>(st.Nslots, 1) * 2 : 1)
@@ -820,9 +837,10 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
   if (!s || !O || !sum) return TMI_BA_ERR_INVALID_ARGUMENT;
   memset(sum, 0, sizeof(*sum));
   sum->termination = 2;
-  if (O->point_dof != s->DP) {
+  if (O->point_dof != s->DP || s->light) {
     sum->status = TMI_BA_ERR_INVALID_ARGUMENT;
-    set_message(sum, "point_dof differs from the value the solver was created with");
+    set_message(sum, s->light ? "this handle only holds the per-track side kernels"
+                              : "point_dof differs from the value the solver was created with");
     return sum->status;
   }
   auto fail = [&](int rc) {
@@ -1169,6 +1187,185 @@ int32_t tmi_ba_solve(tmi_ba_problem* P, const tmi_ba_options* O, tmi_ba_summary*
   return rc2;
 }
 
+// ---- per-track side kernels ----------------------------------
+static int ensure_track_outputs(tmi_ba_solver* s) {
+  if (s->d_trk_flag) return TMI_BA_OK;
+  const size_t n = (size_t)std::max(s->st.Np_pad, 1);
+  int rc;
+  if ((rc = dev_alloc(s, &s->d_trk_flag, n))) return rc;
+  if ((rc = dev_alloc(s, &s->d_trk_mean, n))) return rc;
+  if ((rc = dev_alloc(s, &s->d_trk_term, n))) return rc;
+  if ((rc = dev_alloc(s, &s->d_trk_iter, n))) return rc;
+  if ((rc = dev_alloc(s, &s->d_trk_c0, n))) return rc;
+  if ((rc = dev_alloc(s, &s->d_trk_c1, n))) return rc;
+  return TMI_BA_OK;
+}
+
+int32_t tmi_ba_solver_filter_outlier_tracks(tmi_ba_solver* s, double max_inlier_reprojection_error,
+                                            double min_triangulation_angle_degrees,
+                                            uint8_t* track_flag, double* track_mean_sq_error,
+                                            tmi_ba_filter_summary* sum) {
+  if (!s || !sum) return TMI_BA_ERR_INVALID_ARGUMENT;
+  memset(sum, 0, sizeof(*sum));
+  const double t0 = now_s();
+  TMI_HIP(hipSetDevice(s->device));
+  int rc = ensure_track_outputs(s);
+  if (rc) return rc;
+  const Structure& st = s->st;
+  const double max_sq = max_inlier_reprojection_error * max_inlier_reprojection_error;
+  const double cos_min = std::cos(min_triangulation_angle_degrees * (M_PI / 180.0));
+  hipEvent_t ea, eb;
+  TMI_HIP(hipEventCreate(&ea));
+  TMI_HIP(hipEventCreate(&eb));
+  TMI_HIP(hipEventRecord(ea, s->stream));
+  if (st.nslices > 0)
+    hipLaunchKernelGGL(outlier_filter_kernel, dim3(s->nblocks_slices), dim3(256), 0, s->stream, s->v, max_sq,
+                       cos_min, s->d_trk_flag, s->d_trk_mean);
+  TMI_HIP(hipEventRecord(eb, s->stream));
+  std::vector<unsigned char> flag((size_t)st.Np_pad);
+  std::vector<double> mean(track_mean_sq_error ? (size_t)st.Np_pad : 0);
+  if (!flag.empty())
+    TMI_HIP(hipMemcpyAsync(flag.data(), s->d_trk_flag, flag.size(), hipMemcpyDeviceToHost, s->stream));
+  if (!mean.empty())
+    TMI_HIP(hipMemcpyAsync(mean.data(), s->d_trk_mean, mean.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  TMI_HIP(hipStreamSynchronize(s->stream));
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, ea, eb);
+  hipEventDestroy(ea);
+  hipEventDestroy(eb);
+  for (int lp = 0; lp < st.Np_pad; ++lp) {
+    const int p = st.pt_orig[lp];
+    if (p < 0) continue;
+    const unsigned char f = flag[lp];
+    sum->num_estimated_tracks++;
+    if (f == 1) sum->num_bad_reprojections++;
+    if (f == 2) sum->num_insufficient_viewing_angles++;
+    if (track_flag) track_flag[p] = f;
+    if (track_mean_sq_error) track_mean_sq_error[p] = mean[lp];
+  }
+  sum->kernel_seconds = ms * 1e-3;
+  sum->seconds = now_s() - t0;
+  return TMI_BA_OK;
+}
+
+int32_t tmi_ba_filter_outlier_tracks(const tmi_ba_problem* P, int32_t device,
+                                     double max_inlier_reprojection_error,
+                                     double min_triangulation_angle_degrees, uint8_t* track_flag,
+                                     double* track_mean_sq_error, tmi_ba_filter_summary* sum) {
+  if (!P || !sum) return TMI_BA_ERR_INVALID_ARGUMENT;
+  memset(sum, 0, sizeof(*sum));
+  const double t0 = now_s();
+  tmi_ba_options O;
+  tmi_ba_options_init(&O);
+  O.device = device;
+  tmi_ba_solver* s = new tmi_ba_solver();
+  int rc = create_impl(s, P, &O, 0, 1, /*light=*/true);
+  if (rc == TMI_BA_OK)
+    rc = tmi_ba_solver_filter_outlier_tracks(s, max_inlier_reprojection_error,
+                                             min_triangulation_angle_degrees, track_flag,
+                                             track_mean_sq_error, sum);
+  else
+    g_last_error = s->error;
+  tmi_ba_solver_destroy(s);
+  sum->seconds = now_s() - t0;
+  return rc;
+}
+
+int32_t tmi_ba_solver_adjust_tracks(tmi_ba_solver* s, const tmi_ba_options* O, int8_t* track_termination,
+                                    int32_t* track_iterations, double* track_initial_cost,
+                                    double* track_final_cost, tmi_ba_track_batch_summary* sum) {
+  if (!s || !O || !sum) return TMI_BA_ERR_INVALID_ARGUMENT;
+  memset(sum, 0, sizeof(*sum));
+  if (O->point_dof != s->DP) return TMI_BA_ERR_INVALID_ARGUMENT;
+  const double t0 = now_s();
+  TMI_HIP(hipSetDevice(s->device));
+  int rc = ensure_track_outputs(s);
+  if (rc) return rc;
+  const Structure& st = s->st;
+  TrackLmArgs A;
+  A.loss_type = O->loss_function_type;
+  A.loss_width = O->robust_loss_width;
+  A.jacobi_scaling = O->jacobi_scaling;
+  A.max_num_iterations = O->max_num_iterations;
+  A.max_num_consecutive_invalid_steps = O->max_num_consecutive_invalid_steps;
+  A.function_tolerance = O->function_tolerance;
+  A.gradient_tolerance = O->gradient_tolerance;
+  A.parameter_tolerance = O->parameter_tolerance;
+  A.initial_radius = O->initial_trust_region_radius;
+  A.max_radius = O->max_trust_region_radius;
+  A.min_radius = O->min_trust_region_radius;
+  A.min_relative_decrease = O->min_relative_decrease;
+  A.lm_lo = O->min_lm_diagonal;
+  A.lm_hi = O->max_lm_diagonal;
+  hipEvent_t ea, eb;
+  TMI_HIP(hipEventCreate(&ea));
+  TMI_HIP(hipEventCreate(&eb));
+  TMI_HIP(hipEventRecord(ea, s->stream));
+  if (st.nslices > 0) {
+    if (s->DP == 3)
+      hipLaunchKernelGGL(track_lm_kernel<3>, dim3(s->nblocks_slices), dim3(256), 0, s->stream, s->v, A,
+                         s->d_trk_term, s->d_trk_iter, s->d_trk_c0, s->d_trk_c1);
+    else
+      hipLaunchKernelGGL(track_lm_kernel<4>, dim3(s->nblocks_slices), dim3(256), 0, s->stream, s->v, A,
+                         s->d_trk_term, s->d_trk_iter, s->d_trk_c0, s->d_trk_c1);
+  }
+  TMI_HIP(hipEventRecord(eb, s->stream));
+  const size_t n = (size_t)st.Np_pad;
+  std::vector<signed char> term(n);
+  std::vector<int> iters(n);
+  std::vector<double> c0(track_initial_cost ? n : 0), c1(track_final_cost ? n : 0);
+  if (n) {
+    TMI_HIP(hipMemcpyAsync(term.data(), s->d_trk_term, n, hipMemcpyDeviceToHost, s->stream));
+    TMI_HIP(hipMemcpyAsync(iters.data(), s->d_trk_iter, n * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    if (!c0.empty()) TMI_HIP(hipMemcpyAsync(c0.data(), s->d_trk_c0, n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    if (!c1.empty()) TMI_HIP(hipMemcpyAsync(c1.data(), s->d_trk_c1, n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  }
+  TMI_HIP(hipStreamSynchronize(s->stream));
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, ea, eb);
+  hipEventDestroy(ea);
+  hipEventDestroy(eb);
+  for (int lp = 0; lp < st.Np_pad; ++lp) {
+    const int p = st.pt_orig[lp];
+    if (p < 0) continue;
+    const int t = term[lp];
+    if (t >= 0) {
+      sum->num_tracks++;
+      if (t == 0 || t == 1) sum->num_success++;
+      sum->total_iterations += iters[lp];
+    }
+    if (track_termination) track_termination[p] = (int8_t)t;
+    if (track_iterations) track_iterations[p] = iters[lp];
+    if (track_initial_cost) track_initial_cost[p] = c0[lp];
+    if (track_final_cost) track_final_cost[p] = c1[lp];
+  }
+  sum->kernel_seconds = ms * 1e-3;
+  sum->seconds = now_s() - t0;
+  return TMI_BA_OK;
+}
+
+int32_t tmi_ba_adjust_tracks(tmi_ba_problem* P, const tmi_ba_options* O, int8_t* track_termination,
+                             int32_t* track_iterations, double* track_initial_cost,
+                             double* track_final_cost, tmi_ba_track_batch_summary* sum) {
+  if (!P || !O || !sum) return TMI_BA_ERR_INVALID_ARGUMENT;
+  memset(sum, 0, sizeof(*sum));
+  const double t0 = now_s();
+  tmi_ba_solver* s = new tmi_ba_solver();
+  int rc = create_impl(s, P, O, 0, 1, /*light=*/true);
+  if (rc == TMI_BA_OK) {
+    rc = tmi_ba_solver_adjust_tracks(s, O, track_termination, track_iterations, track_initial_cost,
+                                     track_final_cost, sum);
+    if (rc == TMI_BA_OK) {
+      rc = tmi_ba_solver_download(s, P);  // cameras are constant here: only points changed
+    }
+  } else {
+    g_last_error = s->error;
+  }
+  tmi_ba_solver_destroy(s);
+  sum->seconds = now_s() - t0;
+  return rc;
+}
+
 int32_t tmi_ba_structure_stats(const tmi_ba_problem* P, int32_t rank, int32_t world, int64_t out[12]) {
   if (!P || !out) return TMI_BA_ERR_INVALID_ARGUMENT;
   Structure st;
@@ -1200,7 +1397,7 @@ int32_t tmi_ba_structure_stats(const tmi_ba_problem* P, int32_t rank, int32_t wo
 int32_t tmi_ba_solver_evaluate(tmi_ba_solver* s, double* residuals, double* jac_camera,
                                double* jac_shared, double* jac_point, uint8_t* valid,
                                int32_t* block_dim) {
-  if (!s) return TMI_BA_ERR_INVALID_ARGUMENT;
+  if (!s || s->light) return TMI_BA_ERR_INVALID_ARGUMENT;
   TMI_HIP(hipSetDevice(s->device));
   DeviceView& v = s->v;
   Structure& st = s->st;

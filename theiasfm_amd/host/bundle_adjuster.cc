@@ -214,6 +214,27 @@ static int ToAbiSolver(ceres::LinearSolverType t) {
   }
 }
 
+// BundleAdjustmentOptions -> tmi_ba_options, field for field (SetSolverOptions,
+// bundle_adjuster.cc:57-79)
+void ToDeviceOptions(const BundleAdjustmentOptions& options, tmi_ba_options* o) {
+  tmi_ba_options_init(o);
+  o->loss_function_type = static_cast<int32_t>(options.loss_function_type);
+  o->robust_loss_width = options.robust_loss_width;
+  o->linear_solver_type = ToAbiSolver(options.linear_solver_type);
+  o->preconditioner_type = static_cast<int32_t>(options.preconditioner_type);
+  o->verbose = options.verbose ? 1 : 0;
+  o->num_threads = options.num_threads;
+  o->max_num_iterations = options.max_num_iterations;
+  o->max_solver_time_in_seconds = options.max_solver_time_in_seconds;
+  o->use_inner_iterations = options.use_inner_iterations ? 1 : 0;
+  o->function_tolerance = options.function_tolerance;
+  o->gradient_tolerance = options.gradient_tolerance;
+  o->parameter_tolerance = options.parameter_tolerance;
+  o->max_trust_region_radius = options.max_trust_region_radius;
+  o->point_dof = options.point_dof;
+  o->device = options.device;
+}
+
 // bundle_adjuster.cc:182-221
 BundleAdjustmentSummary BundleAdjuster::Optimize() {
   BundleAdjustmentSummary summary;
@@ -228,22 +249,7 @@ BundleAdjustmentSummary BundleAdjuster::Optimize() {
     return summary;
   }
   tmi_ba_options o;
-  tmi_ba_options_init(&o);
-  o.loss_function_type = static_cast<int32_t>(options_.loss_function_type);
-  o.robust_loss_width = options_.robust_loss_width;
-  o.linear_solver_type = ToAbiSolver(options_.linear_solver_type);
-  o.preconditioner_type = static_cast<int32_t>(options_.preconditioner_type);
-  o.verbose = options_.verbose ? 1 : 0;
-  o.num_threads = options_.num_threads;
-  o.max_num_iterations = options_.max_num_iterations;
-  o.max_solver_time_in_seconds = options_.max_solver_time_in_seconds;
-  o.use_inner_iterations = options_.use_inner_iterations ? 1 : 0;
-  o.function_tolerance = options_.function_tolerance;
-  o.gradient_tolerance = options_.gradient_tolerance;
-  o.parameter_tolerance = options_.parameter_tolerance;
-  o.max_trust_region_radius = options_.max_trust_region_radius;
-  o.point_dof = options_.point_dof;
-  o.device = options_.device;
+  ToDeviceOptions(options_, &o);
   tmi_ba_problem p = flat.AsC();
   tmi_ba_solve(&p, &o, &device_summary_);
   summary.success = device_summary_.success != 0;

@@ -27,6 +27,8 @@ EXPORTS = (
     "tmi_ba_solver_reset", "tmi_ba_solver_download", "tmi_ba_solver_stream",
     "tmi_ba_solver_destroy", "tmi_ba_solver_evaluate", "tmi_ba_structure_stats",
     "tmi_ba_rccl_unique_id", "tmi_ba_solver_init_rccl", "tmi_ba_solver_debug_allreduce",
+    "tmi_ba_solver_filter_outlier_tracks", "tmi_ba_filter_outlier_tracks",
+    "tmi_ba_solver_adjust_tracks", "tmi_ba_adjust_tracks",
 )
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
@@ -94,6 +96,18 @@ def load():
     L.tmi_ba_solver_debug_allreduce.restype = C.c_int32
     L.tmi_ba_structure_stats.argtypes = [P, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]
     L.tmi_ba_structure_stats.restype = C.c_int32
+    FS, TS = C.POINTER(abi.CFilterSummary), C.POINTER(abi.CTrackBatchSummary)
+    L.tmi_ba_solver_filter_outlier_tracks.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p,
+                                                      C.c_void_p, FS]
+    L.tmi_ba_solver_filter_outlier_tracks.restype = C.c_int32
+    L.tmi_ba_filter_outlier_tracks.argtypes = [P, C.c_int32, C.c_double, C.c_double, C.c_void_p,
+                                               C.c_void_p, FS]
+    L.tmi_ba_filter_outlier_tracks.restype = C.c_int32
+    L.tmi_ba_solver_adjust_tracks.argtypes = [C.c_void_p, O, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, TS]
+    L.tmi_ba_solver_adjust_tracks.restype = C.c_int32
+    L.tmi_ba_adjust_tracks.argtypes = [P, O, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, TS]
+    L.tmi_ba_adjust_tracks.restype = C.c_int32
     _lib = L
     return L
 
@@ -140,6 +154,43 @@ def solve(problem: abi.Problem, options: abi.COptions):
     s = abi.CSummary()
     st = L.tmi_ba_solve(C.byref(cp), C.byref(options), C.byref(s))
     return st, s
+
+
+def filter_outlier_tracks(problem: abi.Problem, max_inlier_reprojection_error: float,
+                          min_triangulation_angle_degrees: float, device: int = -1):
+    """One-shot SetOutlierTracksToUnestimated: (flag [Np] uint8, mean squared reprojection
+    error [Np], CFilterSummary)."""
+    L = load()
+    cp = problem.as_c()
+    n = problem.num_points
+    flag = np.zeros(n, dtype=np.uint8)
+    mean = np.zeros(n)
+    fs = abi.CFilterSummary()
+    st = L.tmi_ba_filter_outlier_tracks(C.byref(cp), device, float(max_inlier_reprojection_error),
+                                        float(min_triangulation_angle_degrees), flag.ctypes.data,
+                                        mean.ctypes.data, C.byref(fs))
+    if st != 0:
+        raise EngineError(st, "tmi_ba_filter_outlier_tracks")
+    return flag, mean, fs
+
+
+def adjust_tracks(problem: abi.Problem, options: abi.COptions):
+    """One-shot batched BundleAdjustTrack; problem.points is updated in place.  Returns
+    (termination [Np] int8, iterations [Np] int32, initial cost [Np], final cost [Np],
+    CTrackBatchSummary)."""
+    L = load()
+    cp = problem.as_c()
+    n = problem.num_points
+    term = np.full(n, -1, dtype=np.int8)
+    iters = np.zeros(n, dtype=np.int32)
+    c0 = np.zeros(n)
+    c1 = np.zeros(n)
+    ts = abi.CTrackBatchSummary()
+    st = L.tmi_ba_adjust_tracks(C.byref(cp), C.byref(options), term.ctypes.data, iters.ctypes.data,
+                                c0.ctypes.data, c1.ctypes.data, C.byref(ts))
+    if st != 0:
+        raise EngineError(st, "tmi_ba_adjust_tracks")
+    return term, iters, c0, c1, ts
 
 
 class Solver:
@@ -202,6 +253,35 @@ class Solver:
         if st != 0:
             raise EngineError(st, "tmi_ba_solver_download")
         return self.problem
+
+    def filter_outlier_tracks(self, max_inlier_reprojection_error: float,
+                              min_triangulation_angle_degrees: float):
+        """SetOutlierTracksToUnestimated on the resident parameters (this rank's tracks)."""
+        n = self.problem.num_points
+        flag = np.full(n, 255, dtype=np.uint8)
+        mean = np.full(n, np.nan)
+        fs = abi.CFilterSummary()
+        st = self._L.tmi_ba_solver_filter_outlier_tracks(
+            self._h, float(max_inlier_reprojection_error), float(min_triangulation_angle_degrees),
+            flag.ctypes.data, mean.ctypes.data, C.byref(fs))
+        if st != 0:
+            raise EngineError(st, "tmi_ba_solver_filter_outlier_tracks")
+        return flag, mean, fs
+
+    def adjust_tracks(self, options: abi.COptions):
+        """Batched BundleAdjustTrack on the resident parameters (this rank's tracks)."""
+        n = self.problem.num_points
+        term = np.full(n, -1, dtype=np.int8)
+        iters = np.zeros(n, dtype=np.int32)
+        c0 = np.zeros(n)
+        c1 = np.zeros(n)
+        ts = abi.CTrackBatchSummary()
+        st = self._L.tmi_ba_solver_adjust_tracks(self._h, C.byref(options), term.ctypes.data,
+                                                 iters.ctypes.data, c0.ctypes.data, c1.ctypes.data,
+                                                 C.byref(ts))
+        if st != 0:
+            raise EngineError(st, "tmi_ba_solver_adjust_tracks")
+        return term, iters, c0, c1, ts
 
     @property
     def stream(self) -> int:
