@@ -179,6 +179,28 @@ static bool get_launch(int D, int DP, bool shared, bool fp32, Launch* out) {
 using namespace tmi;
 
 // ---- the opaque solver ----------------------------------------------------------
+namespace tmi {
+struct HostMirror {
+  double scal[SC_COUNT];
+  double red[8];
+  int flags[FL_COUNT];
+  unsigned long long seq;
+};
+__global__ void publish_kernel(const double* __restrict__ scal, const double* __restrict__ red8,
+                               const int* __restrict__ flags, HostMirror* m, unsigned long long seq) {
+  const int t = threadIdx.x;  // 64 threads
+  if (t < SC_COUNT) m->scal[t] = scal[t];
+  if (t < 8) m->red[t] = red8[t];
+  if (t < FL_COUNT) m->flags[t] = flags[t];
+  __threadfence_system();
+  __syncthreads();
+  if (t == 0) __hip_atomic_store(&m->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void flag_to_scalar_kernel(const int* __restrict__ flag, double* __restrict__ dst) {
+  if (threadIdx.x == 0) *dst = (*flag) ? 1.0 : 0.0;
+}
+}  // namespace tmi
+
 struct tmi_ba_solver {
   Structure st;
   Launch launch;
@@ -188,10 +210,14 @@ struct tmi_ba_solver {
   int device = 0;
   hipStream_t stream = nullptr;
   std::vector<void*> allocs;
-  // pinned host scalars
-  double* h_scal = nullptr;
-  double* h_red = nullptr;  // the 8 all-reduced scalars at the tail of `red`
-  int* h_flags = nullptr;
+  // host mirror of the device scalars: pinned, mapped, coherent.  A one-workgroup kernel
+  // publishes them and bumps `seq`; the host polls `seq` (no copy commands, no stream sync)
+  HostMirror* h_mirror = nullptr;
+  HostMirror* d_mirror = nullptr;  // device address of the same memory
+  unsigned long long mirror_seq = 0;
+  double* h_scal = nullptr;   // = h_mirror->scal
+  double* h_red = nullptr;    // = h_mirror->red: the 8 all-reduced scalars at the tail of `red`
+  int* h_flags = nullptr;     // = h_mirror->flags
   // initial parameters (for reset) in device order
   std::vector<double> ext0, intr0, pts0;
   int n_intr = 0;
@@ -273,10 +299,24 @@ struct Timed {
 };
 
 int readback(tmi_ba_solver* s) {
-  TMI_HIP(hipMemcpyAsync(s->h_scal, s->v.scal, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-  TMI_HIP(hipMemcpyAsync(s->h_flags, s->v.flags, FL_COUNT * sizeof(int), hipMemcpyDeviceToHost, s->stream));
-  TMI_HIP(hipMemcpyAsync(s->h_red, s->v.red + s->RL.scalars, 8 * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-  TMI_HIP(hipStreamSynchronize(s->stream));
+  const unsigned long long seq = ++s->mirror_seq;
+  hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, s->stream, s->v.scal,
+                     s->v.red + s->RL.scalars, s->v.flags, s->d_mirror, seq);
+  volatile unsigned long long* p = &s->h_mirror->seq;
+  for (unsigned spin = 1;; ++spin) {
+    if (*p == seq) break;
+    if ((spin & 0xfffu) == 0) {
+      // safety net: once the stream has drained the data is in host memory regardless
+      const hipError_t q = hipStreamQuery(s->stream);
+      if (q == hipSuccess) break;
+      if (q != hipErrorNotReady) {
+        s->error = std::string("hipStreamQuery: ") + hipGetErrorString(q);
+        return TMI_BA_ERR_DEVICE;
+      }
+    }
+    __builtin_ia32_pause();
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
   return TMI_BA_OK;
 }
 
@@ -452,9 +492,7 @@ void tmi_ba_solver_destroy(tmi_ba_solver* s) {
     hipEventDestroy(e.b);
   }
   for (void* p : s->allocs) hipFree(p);
-  if (s->h_scal) hipHostFree(s->h_scal);
-  if (s->h_flags) hipHostFree(s->h_flags);
-  if (s->h_red) hipHostFree(s->h_red);
+  if (s->h_mirror) hipHostFree(s->h_mirror);
   if (s->stream) hipStreamDestroy(s->stream);
   delete s;
 }
@@ -513,9 +551,12 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
     return TMI_BA_ERR_UNSUPPORTED;
   }
   TMI_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-  TMI_HIP(hipHostMalloc((void**)&s->h_scal, SC_COUNT * sizeof(double), hipHostMallocDefault));
-  TMI_HIP(hipHostMalloc((void**)&s->h_flags, FL_COUNT * sizeof(int), hipHostMallocDefault));
-  TMI_HIP(hipHostMalloc((void**)&s->h_red, 8 * sizeof(double), hipHostMallocDefault));
+  TMI_HIP(hipHostMalloc((void**)&s->h_mirror, sizeof(HostMirror), hipHostMallocMapped | hipHostMallocCoherent));
+  memset(s->h_mirror, 0, sizeof(HostMirror));
+  TMI_HIP(hipHostGetDevicePointer((void**)&s->d_mirror, s->h_mirror, 0));
+  s->h_scal = s->h_mirror->scal;
+  s->h_red = s->h_mirror->red;
+  s->h_flags = s->h_mirror->flags;
 
   const int D = st.D, DP = s->DP;
   DeviceView& v = s->v;
@@ -901,17 +942,11 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
   };
   linearize();
   // d_sc[0] = cost, d_sc[1] = ss, d_sc[2] = #ranks with an invalid residual
-  {
-    int rc2 = readback(s);
-    if (rc2) return fail(rc2);
-    const double inv = s->h_flags[FL_INVALID] ? 1.0 : 0.0;
-    CKH(hipMemcpyAsync(d_sc + 2, &inv, sizeof(double), hipMemcpyHostToDevice, stream));
-    CKH(hipStreamSynchronize(stream));
-  }
+  hipLaunchKernelGGL(flag_to_scalar_kernel, dim3(1), dim3(64), 0, stream, v.flags + FL_INVALID, d_sc + 2);
   CK(do_allreduce(s, d_sc, 8));
+  CK(readback(s));
   double hsc[8];
-  CKH(hipMemcpyAsync(hsc, d_sc, sizeof(hsc), hipMemcpyDeviceToHost, stream));
-  CKH(hipStreamSynchronize(stream));
+  memcpy(hsc, s->h_red, sizeof(hsc));
   const int64_t No_global_hint = st.No;  // per-rank; RMSE uses the global count below
   (void)No_global_hint;
   if (hsc[2] > 0.0) {
@@ -976,8 +1011,8 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
     hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, stream, v.partial, nbp, d_sc);
   }
   CK(do_allreduce(s, d_sc, 8));
-  CKH(hipMemcpyAsync(hsc, d_sc, sizeof(hsc), hipMemcpyDeviceToHost, stream));
   CK(readback(s));
+  memcpy(hsc, s->h_red, sizeof(hsc));
   xnorm_cam_sq = s->h_scal[SC_STEP_SQ + 1];
   xnorm_pts_sq = hsc[0];
   double x_norm = std::sqrt(xnorm_cam_sq + xnorm_pts_sq);
@@ -1029,7 +1064,8 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
     } else {
       CK(solve_reduced_dense(s, &usable));
     }
-    CK(readback(s));
+    // the PCG loop ends on a readback and launches nothing after it: the mirror is current
+    if (!(iterative && n_r > 0)) CK(readback(s));
     // singular track blocks are voted on by every rank (summed in the all-reduce)
     if (s->h_red[6] > 0.0 || s->h_flags[FL_SINGULAR_BLOCK]) usable = 0;
     if (need_gradient_check) {
@@ -1071,14 +1107,10 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
         hipLaunchKernelGGL(reduce_sum_kernel, dim3(2), dim3(256), 0, stream, v.partial, nbs, d_sc + 3);
       }
       // d_sc: [mcc, step_sq_points, |x+|^2 points, cand_cost, cand_ss, invalid votes]
-      CK(readback(s));
-      {
-        const double inv = s->h_flags[FL_INVALID] ? 1.0 : 0.0;
-        CKH(hipMemcpyAsync(d_sc + 5, &inv, sizeof(double), hipMemcpyHostToDevice, stream));
-      }
+      hipLaunchKernelGGL(flag_to_scalar_kernel, dim3(1), dim3(64), 0, stream, v.flags + FL_INVALID, d_sc + 5);
       CK(do_allreduce(s, d_sc, 8));
-      CKH(hipMemcpyAsync(hsc, d_sc, sizeof(hsc), hipMemcpyDeviceToHost, stream));
-      CKH(hipStreamSynchronize(stream));
+      CK(readback(s));
+      memcpy(hsc, s->h_red, sizeof(hsc));
       model_cost_change = hsc[0];
       step_sq = hsc[1] + s->h_scal[SC_STEP_SQ];
       cand_xp_sq = hsc[2];
@@ -1243,6 +1275,14 @@ int32_t tmi_ba_solver_filter_outlier_tracks(tmi_ba_solver* s, double max_inlier_
     if (track_flag) track_flag[p] = f;
     if (track_mean_sq_error) track_mean_sq_error[p] = mean[lp];
   }
+  // a track nobody observes: mean = 0 / 0, no ray pair -> insufficient viewing angle
+  // (set_outlier_tracks_to_unestimated.cc:108,120-125 with empty lists)
+  for (const int p : st.unobserved) {
+    sum->num_estimated_tracks++;
+    sum->num_insufficient_viewing_angles++;
+    if (track_flag) track_flag[p] = 2;
+    if (track_mean_sq_error) track_mean_sq_error[p] = std::nan("");
+  }
   sum->kernel_seconds = ms * 1e-3;
   sum->seconds = now_s() - t0;
   return TMI_BA_OK;
@@ -1338,6 +1378,12 @@ int32_t tmi_ba_solver_adjust_tracks(tmi_ba_solver* s, const tmi_ba_options* O, i
     if (track_iterations) track_iterations[p] = iters[lp];
     if (track_initial_cost) track_initial_cost[p] = c0[lp];
     if (track_final_cost) track_final_cost[p] = c1[lp];
+  }
+  for (const int p : st.unobserved) {
+    if (track_termination) track_termination[p] = -1;
+    if (track_iterations) track_iterations[p] = 0;
+    if (track_initial_cost) track_initial_cost[p] = 0.0;
+    if (track_final_cost) track_final_cost[p] = 0.0;
   }
   sum->kernel_seconds = ms * 1e-3;
   sum->seconds = now_s() - t0;

@@ -226,6 +226,12 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, 
       if (klen[p] > 0) order[pos[kmax - klen[p]]++] = p;
   }
   const int n_active = (int)order.size();
+  // tracks without observations are in no slice; rank 0 answers for them in the
+  // per-track side kernels (outlier filter / batched track adjustment)
+  s.unobserved.clear();
+  if (rank == 0)
+    for (int p = 0; p < s.Np_total; ++p)
+      if (klen[p] == 0) s.unobserved.push_back(p);
   const int gslices = (n_active + 63) / 64;
   // Deal the slices (already in descending track-length order) to the ranks by
   // longest-processing-time-first on the estimated work of a slice:

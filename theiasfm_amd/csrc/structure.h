@@ -63,6 +63,7 @@ struct Structure {
   std::vector<int> obs_cpos;      // [No_pad] camera-major slot or -1
   std::vector<int64_t> obs_orig;  // [No_pad] caller's observation index or -1
   std::vector<uint8_t> pt_const;  // [Np_pad]
+  std::vector<int> unobserved;    // tracks without observations (listed on rank 0 only)
 
   // camera-major layout
   int64_t Nslots = 0;
