@@ -424,6 +424,48 @@ int32_t tmi_ba_adjust_tracks(tmi_ba_problem* problem, const tmi_ba_options* opti
                              double* track_initial_cost, double* track_final_cost,
                              tmi_ba_track_batch_summary* summary);
 
+/* Pre-BA track sub-sampling: theia::SelectGoodTracksForBundleAdjustment
+ * (src/theia/sfm/select_good_tracks_for_bundle_adjustment.cc:251-327; callers
+ * global_reconstruction_estimator.cc:475-486, incremental_reconstruction_estimator.cc:497-515).
+ * Track statistics (:81-110: observation count truncated at long_track_length_threshold, mean
+ * squared reprojection error over all observations) are computed on the device; the
+ * selection logic runs on the host:
+ *   1. per view, the features are binned into image_grid_cell_size_pixels cells and the
+ *      track with the minimum (truncated length, mean error) of every occupied cell is
+ *      selected (:150-196 with the comparator at :65-69);
+ *   2. per view, if fewer than min_num_optimized_tracks_per_view of its tracks are selected,
+ *      the not yet selected ones with the smallest track index are added (:201-249 ranks
+ *      std::pair<TrackId, statistics> with the default operator<).
+ * The reference iterates unordered containers; the engine fixes what that leaves open: views
+ * in ascending index order, grid-cell ties to the smaller track index.
+ * view_mask[num_cameras] (NULL = every view): the views whose features take part in steps 1
+ * and 2 -- the reference's overload with an explicit view set (:280-327); the statistics of a
+ * track always cover all of its observations (:81-110).
+ * selected[num_points] (required): 1 = optimise this track.  stats_len / stats_err
+ * [num_points] may be NULL.  Needs an unsharded handle (world == 1). */
+typedef struct tmi_ba_select_summary {
+  int64_t num_tracks;
+  int64_t num_selected;
+  int64_t num_selected_grid; /* selected by the grid step alone */
+  double seconds;
+  double kernel_seconds;     /* the statistics kernel (HIP events) */
+} tmi_ba_select_summary;
+
+int32_t tmi_ba_solver_select_good_tracks(tmi_ba_solver* solver, int32_t long_track_length_threshold,
+                                         int32_t image_grid_cell_size_pixels,
+                                         int32_t min_num_optimized_tracks_per_view,
+                                         const uint8_t* view_mask, uint8_t* selected,
+                                         int32_t* stats_len, double* stats_err,
+                                         tmi_ba_select_summary* summary);
+
+int32_t tmi_ba_select_good_tracks(const tmi_ba_problem* problem, int32_t device,
+                                  int32_t long_track_length_threshold,
+                                  int32_t image_grid_cell_size_pixels,
+                                  int32_t min_num_optimized_tracks_per_view,
+                                  const uint8_t* view_mask, uint8_t* selected,
+                                  int32_t* stats_len, double* stats_err,
+                                  tmi_ba_select_summary* summary);
+
 /* Host-only: statistics of the static structure the engine would build for
  * rank `rank` of `world` (no GPU needed).  Used by the CPU tests of the track
  * sharding: out[0] tracks owned, out[1] observations owned, out[2] reduced

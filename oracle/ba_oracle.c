@@ -1696,3 +1696,125 @@ int32_t oracle_adjust_tracks(tmi_ba_problem* P, const tmi_ba_options* O, int8_t*
   free(idx);
   return TMI_BA_OK;
 }
+
+/* ---- pre-BA track sub-sampling -------------------------------- */
+/* SelectGoodTracksForBundleAdjustment, reference
+ * select_good_tracks_for_bundle_adjustment.cc:81-327, over the flattened problem (every
+ * view and track estimated).  The reference iterates unordered containers; this
+ * restatement fixes the orders it leaves open -- views ascending, ties of the grid-cell
+ * minimum to the smaller track index -- and keeps its comparators as written:
+ *   - a grid cell keeps the MINIMUM of (truncated track length, mean squared reprojection
+ *     error) (CompareGridCellElements :65-69 with std::min_element :187-190);
+ *   - the per-view top-up ranks candidates with std::pair's default operator< on
+ *     (TrackId, statistics), i.e. by track id (:236-247).
+ * stats_len / stats_err (optional outputs): the track statistics (:81-110). */
+typedef struct { int len; double err; } trk_stat;
+
+static int stat_less(const trk_stat* a, const trk_stat* b) {
+  if (a->len != b->len) return a->len < b->len;
+  return a->err < b->err;
+}
+
+typedef struct { int64_t key; int track; } cell_ent;
+
+static int cmp_i32(const void* a, const void* b) {
+  const int x = *(const int*)a, y = *(const int*)b;
+  return (x > y) - (x < y);
+}
+
+int32_t oracle_select_good_tracks(const tmi_ba_problem* P, int32_t long_track_length_threshold,
+                                  int32_t image_grid_cell_size_pixels,
+                                  int32_t min_num_optimized_tracks_per_view,
+                                  const uint8_t* view_mask, uint8_t* selected,
+                                  int32_t* stats_len, double* stats_err) {
+  if (!validate(P) || !selected || image_grid_cell_size_pixels <= 0) return TMI_BA_ERR_INVALID_ARGUMENT;
+  const int64_t Np = P->num_points, No = P->num_observations;
+  const int Nc = P->num_cameras;
+  trk_stat* st = (trk_stat*)calloc((size_t)Np + 1, sizeof(trk_stat));
+  /* ComputeStatisticsForTrack :81-110: every observation counts, no cheirality test */
+  {
+    double* sum = (double*)calloc((size_t)Np + 1, sizeof(double));
+    int* cnt = (int*)calloc((size_t)Np + 1, sizeof(int));
+    for (int64_t o = 0; o < No; ++o) {
+      const int cam = P->obs_camera[o], p = P->obs_point[o];
+      const int g = P->camera_group[cam];
+      double px[2];
+      oracle_project_point(P->group_model[g], P->extrinsics + 6 * (size_t)cam,
+                           P->intrinsics + P->group_offset[g], P->points + 4 * (size_t)p, px);
+      const double dx = px[0] - P->obs_xy[2 * o], dy = px[1] - P->obs_xy[2 * o + 1];
+      sum[p] += dx * dx + dy * dy;
+      cnt[p]++;
+    }
+    for (int64_t p = 0; p < Np; ++p) {
+      st[p].len = cnt[p] < long_track_length_threshold ? cnt[p] : long_track_length_threshold;
+      st[p].err = sum[p] / (double)cnt[p];
+      if (stats_len) stats_len[p] = st[p].len;
+      if (stats_err) stats_err[p] = st[p].err;
+    }
+    free(sum);
+    free(cnt);
+  }
+  memset(selected, 0, (size_t)Np);
+  /* observations by view */
+  int64_t* vptr = (int64_t*)calloc((size_t)Nc + 2, sizeof(int64_t));
+  int64_t* vobs = (int64_t*)malloc(sizeof(int64_t) * (size_t)(No > 0 ? No : 1));
+  for (int64_t o = 0; o < No; ++o) vptr[P->obs_camera[o] + 2]++;
+  for (int c = 0; c < Nc; ++c) vptr[c + 2] += vptr[c + 1];
+  for (int64_t o = 0; o < No; ++o) vobs[vptr[P->obs_camera[o] + 1]++] = o;
+  const double inv_grid_cell_size = 1.0 / image_grid_cell_size_pixels; /* :158 */
+  /* SelectBestTracksFromEachImageGridCell :150-196 */
+  for (int c = 0; c < Nc; ++c) {
+    if (view_mask && !view_mask[c]) continue; /* the overload with a view set :280-327 */
+    const int64_t b = vptr[c], e = vptr[c + 1];
+    const int64_t n = e - b;
+    if (n == 0) continue;
+    int64_t cap = 16;
+    while (cap < 2 * n) cap *= 2;
+    cell_ent* tab = (cell_ent*)malloc(sizeof(cell_ent) * (size_t)cap);
+    for (int64_t i = 0; i < cap; ++i) tab[i].track = -1;
+    for (int64_t q = b; q < e; ++q) {
+      const int64_t o = vobs[q];
+      const int t = P->obs_point[o];
+      const int cx = (int)(P->obs_xy[2 * o] * inv_grid_cell_size);     /* .cast<int>() :174 */
+      const int cy = (int)(P->obs_xy[2 * o + 1] * inv_grid_cell_size);
+      const int64_t key = ((int64_t)cx << 32) ^ (int64_t)(uint32_t)cy;
+      uint64_t h = (uint64_t)key * 0x9E3779B97F4A7C15ULL;
+      int64_t i = (int64_t)(h >> 20) & (cap - 1);
+      while (tab[i].track >= 0 && tab[i].key != key) i = (i + 1) & (cap - 1);
+      if (tab[i].track < 0) {
+        tab[i].key = key;
+        tab[i].track = t;
+      } else {
+        const int cur = tab[i].track;
+        if (stat_less(&st[t], &st[cur]) || (!stat_less(&st[cur], &st[t]) && t < cur)) tab[i].track = t;
+      }
+    }
+    for (int64_t i = 0; i < cap; ++i)
+      if (tab[i].track >= 0) selected[tab[i].track] = 1;
+    free(tab);
+  }
+  /* SelectTopRankedTracksInView :201-249, views in ascending order */
+  for (int c = 0; c < Nc; ++c) {
+    if (view_mask && !view_mask[c]) continue;
+    const int64_t b = vptr[c], e = vptr[c + 1];
+    int num_optimized = 0, num_estimated = (int)(e - b);
+    for (int64_t q = b; q < e; ++q) num_optimized += selected[P->obs_point[vobs[q]]];
+    if (num_optimized >= min_num_optimized_tracks_per_view) continue; /* the early return :224-226 */
+    if (num_optimized == num_estimated) continue;
+    int needed = min_num_optimized_tracks_per_view - num_optimized;
+    if (needed > num_estimated - num_optimized) needed = num_estimated - num_optimized;
+    int* cand = (int*)malloc(sizeof(int) * (size_t)(num_estimated + 1));
+    int nc = 0;
+    for (int64_t q = b; q < e; ++q) {
+      const int t = P->obs_point[vobs[q]];
+      if (!selected[t]) cand[nc++] = t;
+    }
+    qsort(cand, (size_t)nc, sizeof(int), cmp_i32); /* pair<TrackId, ...> default order */
+    for (int i = 0; i < needed && i < nc; ++i) selected[cand[i]] = 1;
+    free(cand);
+  }
+  free(vptr);
+  free(vobs);
+  free(st);
+  return TMI_BA_OK;
+}

@@ -101,6 +101,17 @@ int32_t oracle_adjust_tracks(tmi_ba_problem* problem, const tmi_ba_options* opti
                              int8_t* termination, int32_t* iterations, double* initial_cost,
                              double* final_cost);
 
+/* SelectGoodTracksForBundleAdjustment (select_good_tracks_for_bundle_adjustment.cc:81-327)
+ * over the flattened problem; selected[num_points] = 1 for the tracks to optimise;
+ * view_mask[num_cameras] (NULL = all) restricts the views that select (:280-327).
+ * stats_len / stats_err (may be NULL): truncated track length and mean squared
+ * reprojection error per track (:81-110). */
+int32_t oracle_select_good_tracks(const tmi_ba_problem* problem, int32_t long_track_length_threshold,
+                                  int32_t image_grid_cell_size_pixels,
+                                  int32_t min_num_optimized_tracks_per_view,
+                                  const uint8_t* view_mask, uint8_t* selected,
+                                  int32_t* stats_len, double* stats_err);
+
 int32_t oracle_num_threads(void);
 
 #ifdef __cplusplus

@@ -47,6 +47,9 @@ def lib():
         L.oracle_intrinsics_constant_mask.argtypes = [C.c_int32, C.c_int32, C.c_void_p]
         L.oracle_intrinsics_constant_mask.restype = C.c_int32
         L.oracle_num_threads.restype = C.c_int32
+        L.oracle_select_good_tracks.argtypes = [C.POINTER(abi.CProblem), C.c_int32, C.c_int32, C.c_int32,
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_select_good_tracks.restype = C.c_int32
         L.oracle_adjust_tracks.argtypes = [C.POINTER(abi.CProblem), C.POINTER(abi.COptions),
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_adjust_tracks.restype = C.c_int32
@@ -173,6 +176,25 @@ def adjust_tracks(problem: abi.Problem, options: abi.COptions):
                                     iters.ctypes.data, c0.ctypes.data, c1.ctypes.data)
     assert st == 0, st
     return term, iters, c0, c1
+
+
+def select_good_tracks(problem: abi.Problem, long_track_length_threshold: int,
+                       image_grid_cell_size_pixels: int, min_num_optimized_tracks_per_view: int,
+                       view_mask=None):
+    """selected [Np] uint8, truncated length [Np] int32, mean squared error [Np]."""
+    n = problem.num_points
+    sel = np.zeros(n, dtype=np.uint8)
+    ln = np.zeros(n, dtype=np.int32)
+    err = np.zeros(n)
+    cp = problem.as_c()
+    vm = None if view_mask is None else np.ascontiguousarray(view_mask, dtype=np.uint8)
+    st = lib().oracle_select_good_tracks(C.byref(cp), long_track_length_threshold,
+                                         image_grid_cell_size_pixels,
+                                         min_num_optimized_tracks_per_view,
+                                         None if vm is None else vm.ctypes.data, sel.ctypes.data,
+                                         ln.ctypes.data, err.ctypes.data)
+    assert st == 0, st
+    return sel, ln, err
 
 
 def num_threads() -> int:

@@ -13,6 +13,7 @@
 #include "theia/sfm/bundle_adjustment/bundle_adjuster.h"
 #include "theia/sfm/bundle_adjustment/bundle_adjustment.h"
 #include "theia/sfm/reconstruction.h"
+#include "theia/sfm/select_good_tracks_for_bundle_adjustment.h"
 #include "theia/sfm/set_outlier_tracks_to_unestimated.h"
 
 using namespace theia;
@@ -288,6 +289,25 @@ static void TestTrackOpsGpu() {
   EXPECT(ok == 79);
   EXPECT(worst < 1e-9);
   EXPECT(a.View(0)->Camera().GetPosition()[0] == cam0[0]);  // cameras are constant
+
+  // SelectGoodTracksForBundleAdjustment: every view ends up with at least the minimum
+  // number of selected tracks, non-estimated tracks are never chosen, fewer than all
+  Reconstruction c;
+  BuildScene(&c, 6, 400, false, 44, 0.1);
+  c.MutableTrack(5)->SetEstimated(false);
+  std::unordered_set<TrackId> chosen;
+  EXPECT(SelectGoodTracksForBundleAdjustment(c, 10, 100, 60, &chosen));
+  EXPECT(!chosen.count(5));
+  EXPECT(chosen.size() >= 60 && chosen.size() < 399);
+  for (ViewId v : c.ViewIds()) {
+    int n = 0;
+    for (TrackId t : c.View(v)->TrackIds()) n += chosen.count(t) ? 1 : 0;
+    EXPECT(n >= 60);
+  }
+  std::unordered_set<TrackId> chosen2;
+  EXPECT(SelectGoodTracksForBundleAdjustment(c, std::unordered_set<ViewId>{0, 1}, 10, 100, 60, &chosen2));
+  EXPECT(!chosen2.empty() && chosen2.size() <= chosen.size());
+  std::printf("track selection: %zu of 399 (all views), %zu (views 0,1)\n", chosen.size(), chosen2.size());
 }
 
 int main(int argc, char** argv) {

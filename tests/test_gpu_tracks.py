@@ -199,3 +199,39 @@ def test_adjust_tracks_on_resident_solver_then_ba():
     st_o, sm_o = oracle.solve(R, o)
     assert sm.num_iterations == sm_o.num_iterations
     np.testing.assert_allclose(sm.final_cost, sm_o.final_cost, rtol=1e-9)
+
+
+@pytest.mark.parametrize("models,share", [(None, 1), (MODELS, 3)])
+@pytest.mark.parametrize("long_thr,cell,min_per_view", [(10, 100, 100), (3, 40, 20), (10, 100000, 50)])
+def test_select_good_tracks_matches_oracle(models, share, long_thr, cell, min_per_view):
+    """SelectGoodTracksForBundleAdjustment: device statistics + engine-side selection against
+    the oracle's independent restatement; the selected sets must be identical."""
+    P = synth.make_problem(24, 4000, 18000, seed=51, scene="ring", spread=0.3, models=models,
+                           shared_group_size=share, perturb=0.5)
+    sel_o, ln_o, err_o = oracle.select_good_tracks(P, long_thr, cell, min_per_view)
+    sel_d, ln_d, err_d, ss = lib.select_good_tracks(P, long_thr, cell, min_per_view)
+    np.testing.assert_array_equal(ln_d, ln_o)
+    np.testing.assert_allclose(err_d, err_o, rtol=1e-9, atol=1e-12)
+    np.testing.assert_array_equal(sel_d, sel_o)
+    assert ss.num_selected == sel_o.sum() and ss.num_tracks == P.num_points
+    assert 0 < sel_o.sum() < P.num_points
+    # restricted to a subset of the views
+    mask = (np.arange(P.num_cameras) % 3 != 0).astype(np.uint8)
+    sel_om, _, _ = oracle.select_good_tracks(P, long_thr, cell, min_per_view, view_mask=mask)
+    sel_dm, _, _, _ = lib.select_good_tracks(P, long_thr, cell, min_per_view, view_mask=mask)
+    np.testing.assert_array_equal(sel_dm, sel_om)
+
+
+def test_select_then_partial_ba_on_resident_solver():
+    """select -> statistics come from the resident parameters; sharded handles refuse."""
+    P = synth.make_problem(12, 1200, 5000, seed=53)
+    o = abi.default_options(point_dof=3, max_num_iterations=3)
+    s = lib.Solver(P.copy(), o)
+    sel_d, ln_d, err_d, ss = s.select_good_tracks(10, 100, 80)
+    s.close()
+    sel_o, ln_o, err_o = oracle.select_good_tracks(P, 10, 100, 80)
+    np.testing.assert_array_equal(sel_d, sel_o)
+    s2 = lib.Solver(P.copy(), o, rank=0, world=2)
+    with pytest.raises(lib.EngineError):
+        s2.select_good_tracks(10, 100, 80)
+    s2.close()

@@ -127,3 +127,62 @@ def test_adjust_tracks_matches_single_track_solve():
     np.testing.assert_allclose(Q.points[t], S.points[0], rtol=1e-12, atol=1e-12)
     assert sm.num_iterations == iters[t]
     np.testing.assert_allclose(sm.final_cost, c1[t], rtol=1e-12)
+
+
+# ---- SelectGoodTracksForBundleAdjustment (select_good_tracks_for_bundle_adjustment.cc) ----
+def test_select_good_tracks_rules_by_construction():
+    """Two views, tracks laid out so that every rule of the reference code is visible."""
+    # tracks 0..5 seen by both cameras; feature positions chosen per cell (cell size 100 px)
+    pts = [[1.0, 0.0, 50.0], [1.2, 0.0, 50.0], [6.0, 3.0, 50.0], [6.2, 3.0, 50.0], [-4.0, -3.0, 60.0],
+           [-4.1, -3.0, 60.0]]
+    P = two_camera_problem(pts, baseline=10.0)
+    # give every track a distinct, known mean error: shift its features in x by d pixels
+    d = np.array([3.0, 1.0, 2.0, 4.0, 0.5, 0.6])
+    P.obs_xy[:, 0] += np.repeat(d, 2)
+    sel, ln, err = oracle.select_good_tracks(P, 10, 100, 0)
+    assert ln.tolist() == [2] * 6
+    np.testing.assert_allclose(err, d * d, rtol=1e-9)
+    cells = {}
+    for cam in range(2):
+        for o in np.flatnonzero(P.obs_camera == cam):
+            key = (cam, int(P.obs_xy[o, 0] / 100.0), int(P.obs_xy[o, 1] / 100.0))
+            cells.setdefault(key, []).append(int(P.obs_point[o]))
+    expect = set()
+    for members in cells.values():
+        expect.add(min(members, key=lambda t: (ln[t], err[t], t)))
+    assert set(np.flatnonzero(sel)) == expect
+    assert 0 < len(expect) < 6
+    # the (truncated) length is the FIRST key and the minimum wins (:65-69, :187-190): a track
+    # seen by one view only beats every two-view track of its cell whatever its error
+    keep = np.ones(P.num_observations, bool)
+    t_short = max(expect ^ set(range(6)))  # a track that lost its cell
+    keep[np.flatnonzero((P.obs_point == t_short) & (P.obs_camera == 1))] = False
+    Q = P.copy()
+    Q.obs_camera, Q.obs_point, Q.obs_xy = P.obs_camera[keep], P.obs_point[keep], P.obs_xy[keep]
+    sel2, ln2, _ = oracle.select_good_tracks(Q, 10, 100, 0)
+    assert ln2[t_short] == 1 and sel2[t_short] == 1
+    # truncation: with threshold 1 every length ties and the error decides
+    sel3, ln3, _ = oracle.select_good_tracks(Q, 1, 100, 0)
+    assert ln3.max() == 1
+    # top-up: with a huge cell nothing but one track per view is chosen by the grid step, the
+    # rest is filled in ascending track index (:236-247) up to the minimum
+    sel4, _, _ = oracle.select_good_tracks(P, 10, 100000, 4)
+    grid_only, _, _ = oracle.select_good_tracks(P, 10, 100000, 0)
+    assert grid_only.sum() <= 2
+    chosen = set(np.flatnonzero(sel4))
+    assert len(chosen) == 4
+    rest = sorted(set(range(6)) - set(np.flatnonzero(grid_only)))
+    assert chosen == set(np.flatnonzero(grid_only)) | set(rest[:4 - int(grid_only.sum())])
+    # a view mask removes that view's cells and top-up but not its observations from the statistics
+    sel5, ln5, err5 = oracle.select_good_tracks(P, 10, 100, 0, view_mask=[1, 0])
+    assert ln5.tolist() == [2] * 6
+    assert set(np.flatnonzero(sel5)) <= expect
+
+
+def test_select_good_tracks_min_per_view_is_met():
+    P = synth.make_problem(10, 1500, 7000, seed=17)
+    sel, ln, err = oracle.select_good_tracks(P, 10, 100, 120)
+    per_view = np.bincount(P.obs_camera[sel[P.obs_point] == 1], minlength=P.num_cameras)
+    seen = np.bincount(P.obs_camera, minlength=P.num_cameras)
+    assert np.all(per_view >= np.minimum(120, seen))
+    assert sel.sum() < P.num_points

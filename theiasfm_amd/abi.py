@@ -164,6 +164,16 @@ class CTrackBatchSummary(C.Structure):
     ]
 
 
+class CSelectSummary(C.Structure):
+    _fields_ = [
+        ("num_tracks", C.c_int64),
+        ("num_selected", C.c_int64),
+        ("num_selected_grid", C.c_int64),
+        ("seconds", C.c_double),
+        ("kernel_seconds", C.c_double),
+    ]
+
+
 def default_options(**overrides) -> COptions:
     """BundleAdjustmentOptions defaults (bundle_adjustment.h:78-122) plus the
     Ceres defaults Theia inherits.  Mirrors tmi_ba_options_init."""

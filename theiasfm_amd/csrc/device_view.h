@@ -22,6 +22,10 @@
 
 namespace tmi {
 
+// SpMV rows pass: a wave streams kSpmvTrips trips of 64 / D upper blocks (its chunk);
+// shared by the host work list (structure.cpp) and the kernel (kernels.h)
+constexpr int kSpmvTrips = 8;
+
 struct DeviceView {
   int Nc, G, Np_pad, nslices, Nrb, D, DP;
   int Ncam_rb;     // blocks [0, Ncam_rb) are cameras, [Ncam_rb, Nrb) shared intrinsics groups
@@ -68,6 +72,10 @@ struct DeviceView {
   const int* ub_j;
   const int* ucol_ptr;
   const int* ucol_u;
+  const int* spc_row;   // SpMV rows pass work list: chunk -> block row, first upper block
+  const int* spc_u0;
+  const int* spc_rptr;  // [Nrb+1] chunks of a block row
+  int n_spc;
   const long long* pair_ptr;
   const int* pair_i;
   const int* pair_j;
@@ -90,6 +98,7 @@ struct DeviceView {
   double* red;      // all-reduce buffer
   double* Sdiag;    // [Nrb][D*D] diagonal blocks + LM diagonal
   double* tbuf;     // [nub][D]
+  double* rbuf;     // [n_spc][D] per-chunk partial row products of the SpMV
   double* Minv;     // [Nrb][D*D] inverse diagonal blocks
   double* rhs;      // [Nrb*D]
   double* yc;       // [Nrb*D]

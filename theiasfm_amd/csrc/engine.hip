@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -125,8 +126,8 @@ Launch make_launch(bool fp32) {
   };
   L.spmv = [](const DeviceView& v, hipStream_t st, const double* ub, const double* x, double* y) {
     if (!v.Nrb) return;
-    hipLaunchKernelGGL((spmv_rows_kernel<D>), dim3(v.Nrb), dim3(256), 0, st, v, ub, x, y);
-    hipLaunchKernelGGL((spmv_cols_kernel<D>), dim3(v.Nrb), dim3(256), 0, st, v, y);
+    if (v.n_spc) hipLaunchKernelGGL((spmv_rows_kernel<D>), dim3((v.n_spc + 3) / 4), dim3(256), 0, st, v, ub, x);
+    hipLaunchKernelGGL((spmv_cols_kernel<D>), dim3(v.Nrb), dim3(256), 0, st, v, x, y);
   };
   L.implicit_spmv = [](const DeviceView& v, hipStream_t st, RedLayout R, const double* x, double* y,
                        double* pm_u, double* cm_t, double ir, double lo, double hi, int add_diag, int nb) {
@@ -566,6 +567,7 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   v.D = D; v.DP = DP; v.No_pad = (int)st.No_pad; v.Nslots = (int)st.Nslots;
   v.nub = (int)st.nub; v.nnzb = (int)st.nnzb; v.npairs = st.npairs;
   v.n_order = (int)st.ub_order.size();
+  v.n_spc = (int)st.spc_row.size();
   s->RL = red_layout(st.nub, st.Nrb, D);
   s->n_intr = st.G ? P->group_offset[st.G] : 0;
 
@@ -608,6 +610,7 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
     UPI(v.grp_cam_ptr, st.grp_cam_ptr) UPI(v.grp_cams, st.grp_cams)
     UPI(v.cam_ptr, st.cam_ptr) UPI(v.urow_ptr, st.urow_ptr) UPI(v.ub_i, st.ub_i) UPI(v.ub_j, st.ub_j)
     UPI(v.ucol_ptr, st.ucol_ptr) UPI(v.ucol_u, st.ucol_u)
+    UPI(v.spc_row, st.spc_row) UPI(v.spc_u0, st.spc_u0) UPI(v.spc_rptr, st.spc_rptr)
     UPI(v.pair_i, st.pair_i) UPI(v.pair_j, st.pair_j)
     {
       // launch headers of schur_offdiag: {block, #pairs, first pair lo, first pair hi}
@@ -654,7 +657,7 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   AL(v.scale_c, std::max(n_r, 1)) AL(v.scale_p, NP * DP)
   AL(v.Vinv, NP * NS) AL(v.gp, NP * DP) AL(v.diag_p, NP * DP) AL(v.yp, NP * DP)
   AL(v.red, s->RL.total) AL(v.Sdiag, (size_t)std::max(st.Nrb, 1) * D * D)
-  AL(v.tbuf, (size_t)std::max<int64_t>(st.nub, 1) * D) AL(v.Minv, (size_t)std::max(st.Nrb, 1) * D * D)
+  AL(v.tbuf, (size_t)std::max<int64_t>(st.nub, 1) * D) AL(v.rbuf, (size_t)std::max<size_t>(st.spc_row.size(), 1) * D) AL(v.Minv, (size_t)std::max(st.Nrb, 1) * D * D)
   AL(v.rhs, std::max(n_r, 1)) AL(v.yc, std::max(n_r, 1)) AL(v.cg_r, std::max(n_r, 1))
   AL(v.cg_z, std::max(n_r, 1)) AL(v.cg_p, std::max(n_r, 1)) AL(v.cg_q, std::max(n_r, 1))
   AL(v.cg_t, std::max(n_r, 1)) AL(v.partial, (size_t)4 * std::max(nbmax, (st.Nrb + 3) / 4 + 1)) AL(s->d_partial_max, nbmax)
@@ -1407,6 +1410,146 @@ int32_t tmi_ba_adjust_tracks(tmi_ba_problem* P, const tmi_ba_options* O, int8_t*
   } else {
     g_last_error = s->error;
   }
+  tmi_ba_solver_destroy(s);
+  sum->seconds = now_s() - t0;
+  return rc;
+}
+
+// SelectGoodTracksForBundleAdjustment (select_good_tracks_for_bundle_adjustment.cc:251-327):
+// the projections (track statistics) run on the device, the per-view grid / ranking logic --
+// integer compares over the view's feature list -- on the host.
+int32_t tmi_ba_solver_select_good_tracks(tmi_ba_solver* s, int32_t long_track_length_threshold,
+                                         int32_t image_grid_cell_size_pixels,
+                                         int32_t min_num_optimized_tracks_per_view,
+                                         const uint8_t* view_mask, uint8_t* selected,
+                                         int32_t* stats_len, double* stats_err,
+                                         tmi_ba_select_summary* sum) {
+  if (!s || !sum || !selected || image_grid_cell_size_pixels <= 0) return TMI_BA_ERR_INVALID_ARGUMENT;
+  memset(sum, 0, sizeof(*sum));
+  const Structure& st = s->st;
+  if (st.world > 1) {
+    g_last_error = s->error = "track selection ranks every view's tracks: run it on an unsharded handle";
+    return TMI_BA_ERR_UNSUPPORTED;
+  }
+  const double t0 = now_s();
+  TMI_HIP(hipSetDevice(s->device));
+  int rc = ensure_track_outputs(s);
+  if (rc) return rc;
+  hipEvent_t ea, eb;
+  TMI_HIP(hipEventCreate(&ea));
+  TMI_HIP(hipEventCreate(&eb));
+  TMI_HIP(hipEventRecord(ea, s->stream));
+  if (st.nslices > 0)
+    hipLaunchKernelGGL(track_stats_kernel, dim3(s->nblocks_slices), dim3(256), 0, s->stream, s->v,
+                       s->d_trk_iter, s->d_trk_mean);
+  TMI_HIP(hipEventRecord(eb, s->stream));
+  const size_t n = (size_t)st.Np_pad;
+  std::vector<int> cnt(n);
+  std::vector<double> mean(n);
+  if (n) {
+    TMI_HIP(hipMemcpyAsync(cnt.data(), s->d_trk_iter, n * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    TMI_HIP(hipMemcpyAsync(mean.data(), s->d_trk_mean, n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  }
+  TMI_HIP(hipStreamSynchronize(s->stream));
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, ea, eb);
+  hipEventDestroy(ea);
+  hipEventDestroy(eb);
+  sum->kernel_seconds = ms * 1e-3;
+
+  const int Np = st.Np_total;
+  struct Stat { int len; double err; };
+  std::vector<Stat> stat((size_t)Np, Stat{0, std::nan("")});
+  for (int lp = 0; lp < st.Np_pad; ++lp) {
+    const int p = st.pt_orig[lp];
+    if (p < 0) continue;
+    stat[p].len = std::min(cnt[lp], long_track_length_threshold);
+    stat[p].err = mean[lp];
+  }
+  if (stats_len) for (int p = 0; p < Np; ++p) stats_len[p] = stat[p].len;
+  if (stats_err) for (int p = 0; p < Np; ++p) stats_err[p] = stat[p].err;
+  memset(selected, 0, (size_t)Np);
+  // features by view: (cell, track) records from the resident track-major layout
+  struct Feat { int64_t cell; int track; };
+  std::vector<int64_t> vptr((size_t)st.Nc + 2, 0);
+  const double inv_cell = 1.0 / image_grid_cell_size_pixels;
+  for (int64_t e = 0; e < st.No_pad; ++e)
+    if (st.obs_cam[e] >= 0) vptr[st.obs_cam[e] + 2]++;
+  for (int c = 0; c < st.Nc; ++c) vptr[c + 2] += vptr[c + 1];
+  std::vector<Feat> feats((size_t)st.No);
+  for (int sl = 0; sl < st.nslices; ++sl) {
+    const int K = (st.slice_ptr[sl + 1] - st.slice_ptr[sl]) >> 6;
+    for (int j = 0; j < K; ++j)
+      for (int t = 0; t < 64; ++t) {
+        const int64_t e = (int64_t)st.slice_ptr[sl] + 64 * j + t;
+        const int cam = st.obs_cam[e];
+        if (cam < 0) continue;
+        const int cx = (int)(st.obs_xy[2 * e] * inv_cell), cy = (int)(st.obs_xy[2 * e + 1] * inv_cell);
+        feats[vptr[cam + 1]++] = Feat{((int64_t)cx << 32) ^ (int64_t)(uint32_t)cy, st.pt_orig[sl * 64 + t]};
+      }
+  }
+  auto better = [&](int a, int b) {  // (length, error) ascending, then track index
+    if (stat[a].len != stat[b].len) return stat[a].len < stat[b].len;
+    if (stat[a].err != stat[b].err) return stat[a].err < stat[b].err;
+    return a < b;
+  };
+  // best track of every occupied grid cell (:150-196)
+  for (int c = 0; c < st.Nc; ++c) {
+    if (view_mask && !view_mask[c]) continue;
+    auto b = feats.begin() + vptr[c], e = feats.begin() + vptr[c + 1];
+    std::sort(b, e, [&](const Feat& x, const Feat& y) {
+      if (x.cell != y.cell) return x.cell < y.cell;
+      return better(x.track, y.track);
+    });
+    for (auto it = b; it != e; ++it)
+      if (it == b || it->cell != (it - 1)->cell) {
+        if (!selected[it->track]) sum->num_selected_grid++;
+        selected[it->track] = 1;
+      }
+  }
+  // top up views that see fewer than the minimum number of selected tracks (:201-249),
+  // views in ascending order; candidates ranked by track index (pair<TrackId, ...> order)
+  std::vector<int> cand;
+  for (int c = 0; c < st.Nc; ++c) {
+    if (view_mask && !view_mask[c]) continue;
+    const int64_t b = vptr[c], e = vptr[c + 1];
+    const int num_estimated = (int)(e - b);
+    int num_optimized = 0;
+    for (int64_t q = b; q < e; ++q) num_optimized += selected[feats[q].track];
+    if (num_optimized >= min_num_optimized_tracks_per_view || num_optimized == num_estimated) continue;
+    const int needed = std::min(min_num_optimized_tracks_per_view - num_optimized, num_estimated - num_optimized);
+    cand.clear();
+    for (int64_t q = b; q < e; ++q)
+      if (!selected[feats[q].track]) cand.push_back(feats[q].track);
+    std::sort(cand.begin(), cand.end());
+    for (int i = 0; i < needed && i < (int)cand.size(); ++i) selected[cand[i]] = 1;
+  }
+  sum->num_tracks = Np;
+  for (int p = 0; p < Np; ++p) sum->num_selected += selected[p];
+  sum->seconds = now_s() - t0;
+  return TMI_BA_OK;
+}
+
+int32_t tmi_ba_select_good_tracks(const tmi_ba_problem* P, int32_t device,
+                                  int32_t long_track_length_threshold,
+                                  int32_t image_grid_cell_size_pixels,
+                                  int32_t min_num_optimized_tracks_per_view,
+                                  const uint8_t* view_mask, uint8_t* selected,
+                                  int32_t* stats_len, double* stats_err, tmi_ba_select_summary* sum) {
+  if (!P || !sum) return TMI_BA_ERR_INVALID_ARGUMENT;
+  memset(sum, 0, sizeof(*sum));
+  const double t0 = now_s();
+  tmi_ba_options O;
+  tmi_ba_options_init(&O);
+  O.device = device;
+  tmi_ba_solver* s = new tmi_ba_solver();
+  int rc = create_impl(s, P, &O, 0, 1, /*light=*/true);
+  if (rc == TMI_BA_OK)
+    rc = tmi_ba_solver_select_good_tracks(s, long_track_length_threshold, image_grid_cell_size_pixels,
+                                          min_num_optimized_tracks_per_view, view_mask, selected,
+                                          stats_len, stats_err, sum);
+  else
+    g_last_error = s->error;
   tmi_ba_solver_destroy(s);
   sum->seconds = now_s() - t0;
   return rc;

@@ -885,70 +885,103 @@ __global__ __launch_bounds__(64) void precond_invert_kernel(DeviceView v, int id
 // the PCG hot kernel (hot loop 3).  Purely HBM-bound: every upper block (8 D^2
 // bytes) is read exactly once per product -- the algorithmic minimum.
 //
-//  rows pass: one 256-thread workgroup per block row i.  lane = g * D + r; the
-//    wave streams G = 64 / D contiguous blocks per trip.  For block u = (i, j)
-//    lane (g, r) forms   row product  sum_c U[r][c] x_j[c]   (accumulated for y_i)
-//    and               col product  sum_c U[c][r] x_i[c]   (= (U^T x_i)[r], the
-//    contribution to y_j) which is parked in tbuf[u][r].  Partial rows are
-//    combined through LDS in a fixed order; the diagonal block is added here.
-//  cols pass: y_j += sum over the blocks of column j of tbuf[u] (fixed order).
+//  rows pass: the upper blocks of a block row are cut into chunks of kSpmvTrips * G
+//    consecutive blocks (G = 64 / D), ONE WAVEFRONT PER CHUNK (host work list spc_*): every
+//    wave streams the same amount of S regardless of how long its row is (row lengths of
+//    the upper triangle run from ~N to 0).  Per trip the wave fetches G blocks = G D^2
+//    contiguous doubles with fully coalesced 16-byte loads and parks them in its own LDS
+//    area; lane (g, c) then reads COLUMN c of block g = (i, j) once and uses it twice:
+//      t_j[c]  = sum_r U[r][c] x_i[r]     -> tbuf[u][c]   (the transposed product for y_j)
+//      a[r]   += U[r][c] x_j[c]           (r = 0..D-1: this lane's share of y_i)
+//    and the D accumulators are summed over the wave at the end of the chunk -> rbuf.
+//    (Reading rows and columns straight from global memory costs ~10 cache-line accesses
+//    per line of S in the vector L1 and caps the kernel at half the HBM rate.)
+//  cols pass: y_j = Sdiag_j x_j + sum over the chunks of row j of rbuf
+//                 + sum over the blocks of column j of tbuf[u]        (fixed orders).
 // No atomics anywhere: bit-reproducible.
 // ------------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(256) void spmv_rows_kernel(DeviceView v, const double* __restrict__ ub,
-                                                        const double* __restrict__ x,
-                                                        double* __restrict__ y) {
+                                                        const double* __restrict__ x) {
   constexpr int G = 64 / D;
-  __shared__ double part[4][G][D];
-  const int row = blockIdx.x;
+  constexpr int BLK = D * D;
+  constexpr int NW = G * BLK;            // doubles per trip
+  constexpr int NLD = (NW + 127) / 128;  // 16-byte loads per lane per trip
+  constexpr int PITCH = (NW + 1) & ~1;
+  __shared__ __attribute__((aligned(16))) double sblk[4][PITCH];  // private to each wave
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int g = lane / D, r = lane - g * D;
-  if (g < G) {
-    double acc = 0.0;
-    double xi[D];
+  const int cidx = blockIdx.x * 4 + w;
+  if (cidx >= v.n_spc) return;  // no workgroup barrier below
+  const int row = v.spc_row[cidx];
+  const int u0 = v.spc_u0[cidx];
+  const int u1 = min(u0 + kSpmvTrips * G, v.urow_ptr[row + 1]);
+  const int g = lane / D, c = lane - g * D;
+  double xi[D], a[D];
 #pragma unroll
-    for (int c = 0; c < D; ++c) xi[c] = x[(size_t)row * D + c];
-    const int u0 = v.urow_ptr[row], u1 = v.urow_ptr[row + 1];
-    for (int u = u0 + w * G + g; u < u1; u += 4 * G) {
-      const double* blk = ub + (size_t)u * D * D;
-      const double* xj = x + (size_t)v.ub_j[u] * D;
-      double t = 0.0, tt = 0.0;
-      // row r of the block: D contiguous doubles (8-byte aligned): 16-byte loads
-      double rowv[D];
-      const double* rp = blk + r * D;
-#pragma unroll
-      for (int c = 0; c + 1 < D; c += 2) {
-        const double2_a8 t2 = *reinterpret_cast<const double2_a8*>(rp + c);
-        rowv[c] = t2.x;
-        rowv[c + 1] = t2.y;
-      }
-      if (D & 1) rowv[D - 1] = rp[D - 1];
-#pragma unroll
-      for (int c = 0; c < D; ++c) {
-        t += rowv[c] * xj[c];
-        tt += blk[c * D + r] * xi[c];  // column r: the group's 9 lanes read 72 contiguous bytes
-      }
-      acc += t;
-      v.tbuf[(size_t)u * D + r] = tt;
-    }
-    part[w][g][r] = acc;
+  for (int r = 0; r < D; ++r) {
+    xi[r] = x[(size_t)row * D + r];
+    a[r] = 0.0;
   }
-  __syncthreads();
-  if (threadIdx.x < D) {
-    double s = 0.0;
-    const double* dg = v.Sdiag + (size_t)row * D * D + threadIdx.x * D;
+  double* __restrict__ tb = v.tbuf;
+
+  double2_a8 ld[NLD];
+  double xjc = 0.0;
+  auto fetch = [&](int ub0) {
+    const int nv = max(0, min(G, u1 - ub0)) * BLK;  // valid doubles of this trip
+    const double* src = ub + (size_t)ub0 * BLK;
 #pragma unroll
-    for (int c = 0; c < D; ++c) s += dg[c] * x[(size_t)row * D + c];
+    for (int i = 0; i < NLD; ++i) {
+      const int e = 2 * (64 * i + lane);
+      double2_a8 t2 = {0.0, 0.0};
+      if (e + 1 < nv) {
+        t2 = *reinterpret_cast<const double2_a8*>(src + e);
+      } else if (e < nv) {
+        t2.x = src[e];
+      }
+      ld[i] = t2;
+    }
+    const int u = ub0 + g;
+    xjc = (g < G && u < u1) ? x[(size_t)v.ub_j[u] * D + c] : 0.0;
+  };
+  fetch(u0);
+#pragma unroll 1
+  for (int ub0 = u0; ub0 < u1; ub0 += G) {
+    // LDS operations of one wave execute in order and the staging area is the wave's own:
+    // no workgroup barrier, only compiler fences around the exchange
 #pragma unroll
-    for (int ww = 0; ww < 4; ++ww)
+    for (int i = 0; i < NLD; ++i) {
+      const int e = 2 * (64 * i + lane);
+      if (e < PITCH) *reinterpret_cast<double2_a8*>(&sblk[w][e]) = ld[i];
+    }
+    const double xj = xjc;
+    __builtin_amdgcn_wave_barrier();
+    if (ub0 + G < u1) fetch(ub0 + G);  // the next trip's loads fly while this one is consumed
+    const int u = ub0 + g;
+    if (g < G && u < u1) {
+      const double* blk = &sblk[w][g * BLK];
+      double tt = 0.0;
 #pragma unroll
-      for (int gg = 0; gg < G; ++gg) s += part[ww][gg][threadIdx.x];
-    y[(size_t)row * D + threadIdx.x] = s;
+      for (int r = 0; r < D; ++r) {
+        const double e = blk[r * D + c];
+        tt += e * xi[r];
+        a[r] += e * xj;
+      }
+      tb[(size_t)u * D + c] = tt;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // sum the D accumulators over the wave (fixed butterfly => reproducible)
+#pragma unroll
+  for (int r = 0; r < D; ++r) a[r] = wave_sum(a[r]);
+  if (lane == 0) {
+#pragma unroll
+    for (int r = 0; r < D; ++r) v.rbuf[(size_t)cidx * D + r] = a[r];
   }
 }
 
 template <int D>
-__global__ __launch_bounds__(256) void spmv_cols_kernel(DeviceView v, double* __restrict__ y) {
+__global__ __launch_bounds__(256) void spmv_cols_kernel(DeviceView v, const double* __restrict__ x,
+                                                        double* __restrict__ y) {
   constexpr int G = 64 / D;
   __shared__ double part[4][G][D];
   const int col = blockIdx.x;
@@ -962,7 +995,11 @@ __global__ __launch_bounds__(256) void spmv_cols_kernel(DeviceView v, double* __
   }
   __syncthreads();
   if (threadIdx.x < D) {
-    double s = y[(size_t)col * D + threadIdx.x];
+    double s = 0.0;
+    const double* dg = v.Sdiag + (size_t)col * D * D + threadIdx.x * D;
+#pragma unroll
+    for (int cc = 0; cc < D; ++cc) s += dg[cc] * x[(size_t)col * D + cc];
+    for (int c = v.spc_rptr[col]; c < v.spc_rptr[col + 1]; ++c) s += v.rbuf[(size_t)c * D + threadIdx.x];
 #pragma unroll
     for (int ww = 0; ww < 4; ++ww)
 #pragma unroll

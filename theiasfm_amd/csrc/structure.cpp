@@ -5,6 +5,7 @@
 // SetCameraExtrinsicsParameterization / SetCameraIntrinsicsParameterization
 // (bundle_adjuster.cc:223-287): constant coordinates simply have no column.
 #include "structure.h"
+#include "device_view.h"
 
 #include <algorithm>
 #include <cstring>
@@ -425,6 +426,21 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, 
   for (int i = 0; i < s.Nrb; ++i) {
     s.urow_ptr[i + 1] += s.urow_ptr[i];
     s.ucol_ptr[i + 1] += s.ucol_ptr[i];
+  }
+  // balanced work list of the symmetric SpMV's rows pass: a block row is cut into chunks of
+  // kSpmvTrips * (64 / D) consecutive upper blocks, one wavefront per chunk (kernels.h)
+  {
+    const int chunk = kSpmvTrips * (64 / std::max(s.D, 1));
+    s.spc_row.clear();
+    s.spc_u0.clear();
+    s.spc_rptr.assign(s.Nrb + 1, 0);
+    for (int i = 0; i < s.Nrb; ++i) {
+      for (int u = s.urow_ptr[i]; u < s.urow_ptr[i + 1]; u += chunk) {
+        s.spc_row.push_back(i);
+        s.spc_u0.push_back(u);
+      }
+      s.spc_rptr[i + 1] = (int)s.spc_row.size();
+    }
   }
   s.ucol_u.assign(s.nub, 0);
   {

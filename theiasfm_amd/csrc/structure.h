@@ -78,6 +78,8 @@ struct Structure {
   std::vector<int> urow_ptr;      // [Nrb+1] upper blocks of block row i: [urow_ptr[i], urow_ptr[i+1])
   std::vector<int> ucol_ptr;      // [Nrb+1] upper blocks in block column j ...
   std::vector<int> ucol_u;        // [nub]   ... listed here, ascending bi
+  std::vector<int> spc_row, spc_u0;  // SpMV rows pass: chunk -> (block row, first upper block)
+  std::vector<int> spc_rptr;      // [Nrb+1] chunks of block row i
   // pair lists (this rank's tracks only)
   int64_t npairs = 0;
   std::vector<int64_t> pair_ptr;  // [nub+1]

@@ -1,6 +1,7 @@
 // Host shim for the steps either side of the full adjustment:
 //   SetOutlierTracksToUnestimated   set_outlier_tracks_to_unestimated.cc:49-133
 //   BundleAdjustTracks              batched form of bundle_adjustment.cc:96-107
+//   SelectGoodTracksForBundleAdjustment   select_good_tracks_for_bundle_adjustment.cc:251-327
 // Both flatten "the estimated views observing these estimated tracks" -- exactly the
 // residual set BundleAdjuster::AddTrack builds (bundle_adjuster.cc:141-180) -- and hand it
 // to the C ABI.
@@ -10,6 +11,7 @@
 #include "theia/sfm/bundle_adjustment/bundle_adjuster.h"
 #include "theia/sfm/bundle_adjustment/bundle_adjustment.h"
 #include "theia/sfm/reconstruction.h"
+#include "theia/sfm/select_good_tracks_for_bundle_adjustment.h"
 #include "theia/sfm/set_outlier_tracks_to_unestimated.h"
 
 namespace theia {
@@ -110,6 +112,61 @@ std::unordered_map<TrackId, BundleAdjustmentSummary> BundleAdjustTracks(
     std::copy(flat.points.begin() + 4 * t, flat.points.begin() + 4 * t + 4, X);
   }
   return result;
+}
+
+// select_good_tracks_for_bundle_adjustment.cc:264-277
+bool SelectGoodTracksForBundleAdjustment(const Reconstruction& reconstruction,
+                                         const int long_track_length_threshold,
+                                         const int image_grid_cell_size_pixels,
+                                         const int min_num_optimized_tracks_per_view,
+                                         std::unordered_set<TrackId>* tracks_to_optimize) {
+  std::unordered_set<ViewId> view_ids;  // GetEstimatedViewsFromReconstruction
+  for (const ViewId v : reconstruction.ViewIds())
+    if (reconstruction.View(v)->IsEstimated()) view_ids.insert(v);
+  return SelectGoodTracksForBundleAdjustment(reconstruction, view_ids, long_track_length_threshold,
+                                             image_grid_cell_size_pixels,
+                                             min_num_optimized_tracks_per_view, tracks_to_optimize);
+}
+
+// select_good_tracks_for_bundle_adjustment.cc:280-327
+bool SelectGoodTracksForBundleAdjustment(const Reconstruction& reconstruction,
+                                         const std::unordered_set<ViewId>& view_ids,
+                                         const int long_track_length_threshold,
+                                         const int image_grid_cell_size_pixels,
+                                         const int min_num_optimized_tracks_per_view,
+                                         std::unordered_set<TrackId>* tracks_to_optimize) {
+  if (tracks_to_optimize == nullptr) return false;
+  // the estimated tracks seen by these views, with ALL their estimated views (the track
+  // statistics run over every view of a track, :92-104)
+  std::unordered_set<TrackId> tracks;
+  for (const ViewId v : view_ids) {
+    const View* view = reconstruction.View(v);
+    if (view == nullptr) continue;
+    for (const TrackId t : view->TrackIds()) {
+      const Track* track = reconstruction.Track(t);
+      if (track != nullptr && track->IsEstimated()) tracks.insert(t);
+    }
+  }
+  FlattenedBundleAdjustmentProblem flat;
+  // flattening reads the reconstruction only
+  if (!FlattenTracks(BundleAdjustmentOptions(), tracks, const_cast<Reconstruction*>(&reconstruction), &flat))
+    return false;
+  if (flat.track_ids.empty()) return true;
+  std::vector<uint8_t> view_mask(flat.view_ids.size(), 0), selected(flat.track_ids.size(), 0);
+  for (size_t c = 0; c < flat.view_ids.size(); ++c) view_mask[c] = view_ids.count(flat.view_ids[c]) ? 1 : 0;
+  tmi_ba_select_summary ss;
+  tmi_ba_problem p = flat.AsC();
+  const int rc = tmi_ba_select_good_tracks(&p, -1, long_track_length_threshold, image_grid_cell_size_pixels,
+                                           min_num_optimized_tracks_per_view, view_mask.data(),
+                                           selected.data(), nullptr, nullptr, &ss);
+  if (rc != TMI_BA_OK) {
+    std::fprintf(stderr, "[theia::SelectGoodTracksForBundleAdjustment] device path failed: %s\n",
+                 tmi_ba_last_error());
+    return false;
+  }
+  for (size_t t = 0; t < flat.track_ids.size(); ++t)
+    if (selected[t]) tracks_to_optimize->insert(flat.track_ids[t]);
+  return true;
 }
 
 }  // namespace theia

@@ -29,6 +29,7 @@ EXPORTS = (
     "tmi_ba_rccl_unique_id", "tmi_ba_solver_init_rccl", "tmi_ba_solver_debug_allreduce",
     "tmi_ba_solver_filter_outlier_tracks", "tmi_ba_filter_outlier_tracks",
     "tmi_ba_solver_adjust_tracks", "tmi_ba_adjust_tracks",
+    "tmi_ba_solver_select_good_tracks", "tmi_ba_select_good_tracks",
 )
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
@@ -108,6 +109,13 @@ def load():
     L.tmi_ba_solver_adjust_tracks.restype = C.c_int32
     L.tmi_ba_adjust_tracks.argtypes = [P, O, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, TS]
     L.tmi_ba_adjust_tracks.restype = C.c_int32
+    SS = C.POINTER(abi.CSelectSummary)
+    L.tmi_ba_solver_select_good_tracks.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, SS]
+    L.tmi_ba_solver_select_good_tracks.restype = C.c_int32
+    L.tmi_ba_select_good_tracks.argtypes = [P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, SS]
+    L.tmi_ba_select_good_tracks.restype = C.c_int32
     _lib = L
     return L
 
@@ -172,6 +180,27 @@ def filter_outlier_tracks(problem: abi.Problem, max_inlier_reprojection_error: f
     if st != 0:
         raise EngineError(st, "tmi_ba_filter_outlier_tracks")
     return flag, mean, fs
+
+
+def select_good_tracks(problem: abi.Problem, long_track_length_threshold: int,
+                       image_grid_cell_size_pixels: int, min_num_optimized_tracks_per_view: int,
+                       view_mask=None, device: int = -1):
+    """One-shot SelectGoodTracksForBundleAdjustment: (selected [Np] uint8, truncated length
+    [Np] int32, mean squared error [Np], CSelectSummary)."""
+    L = load()
+    cp = problem.as_c()
+    n = problem.num_points
+    sel = np.zeros(n, dtype=np.uint8)
+    ln = np.zeros(n, dtype=np.int32)
+    err = np.zeros(n)
+    ss = abi.CSelectSummary()
+    vm = None if view_mask is None else np.ascontiguousarray(view_mask, dtype=np.uint8)
+    st = L.tmi_ba_select_good_tracks(C.byref(cp), device, long_track_length_threshold,
+                                     image_grid_cell_size_pixels, min_num_optimized_tracks_per_view,
+                                     None if vm is None else vm.ctypes.data, sel.ctypes.data, ln.ctypes.data, err.ctypes.data, C.byref(ss))
+    if st != 0:
+        raise EngineError(st, "tmi_ba_select_good_tracks")
+    return sel, ln, err, ss
 
 
 def adjust_tracks(problem: abi.Problem, options: abi.COptions):
@@ -267,6 +296,23 @@ class Solver:
         if st != 0:
             raise EngineError(st, "tmi_ba_solver_filter_outlier_tracks")
         return flag, mean, fs
+
+    def select_good_tracks(self, long_track_length_threshold: int, image_grid_cell_size_pixels: int,
+                           min_num_optimized_tracks_per_view: int, view_mask=None):
+        """SelectGoodTracksForBundleAdjustment on the resident parameters (unsharded handle)."""
+        n = self.problem.num_points
+        sel = np.zeros(n, dtype=np.uint8)
+        ln = np.zeros(n, dtype=np.int32)
+        err = np.zeros(n)
+        ss = abi.CSelectSummary()
+        vm = None if view_mask is None else np.ascontiguousarray(view_mask, dtype=np.uint8)
+        st = self._L.tmi_ba_solver_select_good_tracks(
+            self._h, long_track_length_threshold, image_grid_cell_size_pixels,
+            min_num_optimized_tracks_per_view, None if vm is None else vm.ctypes.data, sel.ctypes.data, ln.ctypes.data, err.ctypes.data,
+            C.byref(ss))
+        if st != 0:
+            raise EngineError(st, "tmi_ba_solver_select_good_tracks")
+        return sel, ln, err, ss
 
     def adjust_tracks(self, options: abi.COptions):
         """Batched BundleAdjustTrack on the resident parameters (this rank's tracks)."""
