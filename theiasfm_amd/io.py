@@ -6,7 +6,10 @@
   camera.h:206-245, camera_intrinsics_prior.h:58-107, io/eigen_serializable.h:47-59).
   Only the subset of the format the shipped fixtures use is understood
   (PINHOLE intrinsics, Camera v0/v1, CameraIntrinsicsPrior v4).
-* ``read_bal``: Bundle-Adjustment-in-the-Large text problems converted to the
+* ``write_theia_reconstruction`` / ``update_reconstruction``: the way back -- the adjusted
+  values patched into the archive that was read (reference writer:
+  src/theia/io/reconstruction_writer.cc), so the real Theia can consume the result.
+* ``read_bal`` / ``write_bal``: Bundle-Adjustment-in-the-Large text problems converted to the
   reference's conventions exactly as its Bundler importer does
   (reference: src/theia/io/read_bundler_files.cc:94-133,169,190).
 * ``flatten_reconstruction``: the residual set BundleAdjustReconstruction builds
@@ -57,6 +60,7 @@ class TheiaView:
     intrinsics: np.ndarray           # [7] pinhole
     image_size: tuple
     features: dict                   # track id -> (x, y)
+    offsets: dict = field(default_factory=dict)  # byte offsets of the fields BA rewrites
 
 
 @dataclass
@@ -64,6 +68,7 @@ class TheiaTrack:
     is_estimated: bool
     view_ids: list
     point: np.ndarray                # [4]
+    offsets: dict = field(default_factory=dict)
 
 
 @dataclass
@@ -72,6 +77,8 @@ class TheiaReconstruction:
     tracks: dict = field(default_factory=dict)     # track id -> TheiaTrack
     view_to_group: dict = field(default_factory=dict)
     groups: dict = field(default_factory=dict)
+    raw: bytes = b""                 # the archive as read (write_theia_reconstruction patches it)
+    intrinsics_offsets: dict = field(default_factory=dict)  # shared pointer id -> byte offset
 
 
 def read_theia_reconstruction(path: str) -> TheiaReconstruction:
@@ -114,9 +121,11 @@ def read_theia_reconstruction(path: str) -> TheiaReconstruction:
         vid = r.take("I")
         ver("View")
         name = r.string()
+        off = {"is_estimated": r.o}
         is_est = bool(r.take("B"))
         cam_ver = ver("Camera")
         if cam_ver > 0:
+            off["extrinsics"] = r.o
             ext = r.f64(6)
             pid = r.take("I")
             if pid & 0x80000000:
@@ -129,13 +138,17 @@ def read_theia_reconstruction(path: str) -> TheiaReconstruction:
                 if ver("PinholeCameraModel") > 0:
                     ver("CameraIntrinsicsModel")
                     n = r.take("Q")
+                    rec.intrinsics_offsets[ptr & 0x7FFFFFFF] = r.o
                     shared[ptr & 0x7FFFFFFF] = r.f64(n)
                 else:
+                    rec.intrinsics_offsets[ptr & 0x7FFFFFFF] = r.o
                     shared[ptr & 0x7FFFFFFF] = r.f64(7)
             intr_id = ptr & 0x7FFFFFFF
             intr = shared[intr_id]
             size = r.take("ii")
         else:  # Camera v0: 13 doubles [extrinsics(6), pinhole intrinsics(7)] + size
+            off["extrinsics"] = r.o
+            off["intrinsics"] = r.o + 48
             p = r.f64(13)
             ext, intr = p[:6], p[6:]
             intr_id = -1 - vid
@@ -154,17 +167,19 @@ def read_theia_reconstruction(path: str) -> TheiaReconstruction:
             rows, cols = r.take("ii")
             xy = r.f64(rows * cols)
             feats[tid] = (float(xy[0]), float(xy[1]))
-        rec.views[vid] = TheiaView(name, is_est, ext, intr_id, intr, size, feats)
+        rec.views[vid] = TheiaView(name, is_est, ext, intr_id, intr, size, feats, off)
     for _ in range(r.take("Q")):
         tid = r.take("I")
         ver("Track")
+        toff = {"is_estimated": r.o}
         is_est = bool(r.take("B"))
         vids = [r.take("I") for _ in range(r.take("Q"))]
         rows, cols = r.take("ii")
+        toff["point"] = r.o
         pt = r.f64(rows * cols)
         rows, cols = r.take("ii")
         r.o += rows * cols
-        rec.tracks[tid] = TheiaTrack(is_est, vids, pt)
+        rec.tracks[tid] = TheiaTrack(is_est, vids, pt, toff)
     for _ in range(r.take("Q")):
         k, v = r.take("II")
         rec.view_to_group[k] = v
@@ -173,7 +188,60 @@ def read_theia_reconstruction(path: str) -> TheiaReconstruction:
         rec.groups[g] = [r.take("I") for _ in range(r.take("Q"))]
     if r.o != len(r.d):
         raise ValueError(f"trailing bytes in archive: parsed {r.o} of {len(r.d)}")
+    rec.raw = r.d
     return rec
+
+
+def write_theia_reconstruction(path: str, rec: TheiaReconstruction) -> None:
+    """Writes `rec` as a cereal portable-binary archive the reference can read back
+    (src/theia/io/reconstruction_writer.cc; same class layouts as the reader above).
+
+    Bundle adjustment and the steps around it change values, never structure: camera
+    extrinsics and intrinsics, track points and the estimated flags.  The writer therefore
+    re-emits the archive `rec` was read from with exactly those fields replaced, so
+    everything this package does not model (view names, priors, colours, feature tables)
+    stays bit for bit what Theia wrote; an unmodified reconstruction round-trips to an
+    identical file."""
+    if not rec.raw:
+        raise ValueError("write_theia_reconstruction needs a reconstruction obtained from "
+                         "read_theia_reconstruction")
+    out = bytearray(rec.raw)
+    done = set()
+    for view in rec.views.values():
+        struct.pack_into("<B", out, view.offsets["is_estimated"], 1 if view.is_estimated else 0)
+        struct.pack_into("<6d", out, view.offsets["extrinsics"], *np.asarray(view.extrinsics, float))
+        if "intrinsics" in view.offsets:  # Camera v0: private copy inside the camera
+            struct.pack_into("<7d", out, view.offsets["intrinsics"], *np.asarray(view.intrinsics, float))
+        elif view.intrinsics_ptr not in done:  # shared block: stored once, at its first use
+            done.add(view.intrinsics_ptr)
+            vals = np.asarray(view.intrinsics, float)
+            struct.pack_into(f"<{len(vals)}d", out, rec.intrinsics_offsets[view.intrinsics_ptr], *vals)
+    for track in rec.tracks.values():
+        struct.pack_into("<B", out, track.offsets["is_estimated"], 1 if track.is_estimated else 0)
+        struct.pack_into("<4d", out, track.offsets["point"], *np.asarray(track.point, float))
+    with open(path, "wb") as fh:
+        fh.write(bytes(out))
+
+
+def update_reconstruction(rec: TheiaReconstruction, prob: Problem, track_flags=None) -> None:
+    """Writes an adjusted flattened problem (from flatten_reconstruction) back into `rec`:
+    what BundleAdjuster::Optimize leaves in the caller's Reconstruction.  track_flags
+    (optional, per problem track; non-zero = SetEstimated(false)) applies the outcome of
+    the outlier filter."""
+    vids, tids = prob.meta["view_ids"], prob.meta["track_ids"]
+    for ci, v in enumerate(vids):
+        view = rec.views[v]
+        view.extrinsics = prob.extrinsics[ci].copy()
+        g = int(prob.camera_group[ci])
+        a, b = prob.group_offset[g], prob.group_offset[g + 1]
+        new = prob.intrinsics[a:b].copy()
+        for other in rec.views.values():  # every view of the shared block sees the update
+            if other.intrinsics_ptr == view.intrinsics_ptr:
+                other.intrinsics = new
+    for pi, t in enumerate(tids):
+        rec.tracks[t].point = prob.points[pi].copy()
+        if track_flags is not None and track_flags[pi]:
+            rec.tracks[t].is_estimated = False
 
 
 def flatten_reconstruction(rec: TheiaReconstruction,
@@ -258,3 +326,29 @@ def read_bal(path: str, intrinsics_to_optimize: int = abi.INTRINSICS_DEFAULT) ->
         obs_point=obs[:, 1].astype(np.int32), obs_xy=xy)
     prob.set_intrinsics_to_optimize(intrinsics_to_optimize)
     return prob
+
+
+def write_bal(path: str, prob: Problem) -> None:
+    """Inverse of read_bal (PINHOLE cameras with private intrinsics, w = 1 points)."""
+    if np.any(prob.group_model != abi.PINHOLE) or prob.num_groups != prob.num_cameras:
+        raise ValueError("BAL holds one pinhole camera [f, k1, k2] per view")
+    nc = prob.num_cameras
+    flip = np.diag([1.0, -1.0, -1.0])
+    Rt = Rotation.from_rotvec(prob.extrinsics[:, 3:6]).as_matrix()
+    C = prob.extrinsics[:, :3]
+    tp = -np.einsum("nij,nj->ni", Rt, C)          # t' = -R_theia C
+    Rb = np.einsum("ij,njk->nik", flip, Rt)       # R = diag(1,-1,-1) R_theia
+    t = tp @ flip.T
+    aa = Rotation.from_matrix(Rb).as_rotvec()
+    K = prob.intrinsics.reshape(nc, 7)[prob.camera_group]
+    pts = prob.points[:, :3] / prob.points[:, 3:4]
+    with open(path, "w") as fh:
+        fh.write(f"{nc} {prob.num_points} {prob.num_observations}\n")
+        for c, p, (x, y) in zip(prob.obs_camera, prob.obs_point, prob.obs_xy):
+            fh.write(f"{int(c)} {int(p)} {x:.17g} {-y:.17g}\n")
+        for i in range(nc):
+            for val in (*aa[i], *t[i], K[i, 0], K[i, 5], K[i, 6]):
+                fh.write(f"{val:.17g}\n")
+        for X in pts:
+            for val in X:
+                fh.write(f"{val:.17g}\n")
