@@ -73,7 +73,10 @@ def main():
     cls_of = {"linearize_kernel": "linearize", "point_eliminate_kernel": "point_eliminate",
               "camera_diag_kernel": "camera_diag", "schur_offdiag_kernel": "schur_offdiag",
               "precond_invert_kernel": "preconditioner", "spmv_rows_kernel": "spmv",
-              "spmv_cols_kernel": "spmv", "back_substitute_kernel": "back_substitute"}
+              "spmv_cols_kernel": "spmv", "back_substitute_kernel": "back_substitute",
+              "implicit_tracks_kernel": "spmv", "implicit_cameras_kernel": "spmv",
+              "cost_kernel": "update_cost", "update_points_kernel": "update_cost",
+              "update_cameras_kernel": "update_cost"}
     classes = {}
     for r in rows:
         base = r["kernel"].split("<")[0]
