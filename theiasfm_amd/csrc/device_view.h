@@ -25,9 +25,14 @@ namespace tmi {
 // SpMV rows pass: a wave streams kSpmvTrips trips of 64 / D upper blocks (its chunk);
 // shared by the host work list (structure.cpp) and the kernel (kernels.h)
 constexpr int kSpmvTrips = 8;
+// per-track kernels: slices whose longest track has at least this many observations are run
+// with 16 lanes per track (kernels.h, track_map)
+constexpr int kWideK = 12;
 
 struct DeviceView {
   int Nc, G, Np_pad, nslices, Nrb, D, DP;
+  int n_wide;          // leading slices run with 16 lanes per track
+  int n_track_blocks;  // grid of the per-track kernels: 4 n_wide + ceil((nslices - n_wide) / 4)
   int Ncam_rb;     // blocks [0, Ncam_rb) are cameras, [Ncam_rb, Nrb) shared intrinsics groups
   int has_shared;
   int No_pad;

@@ -230,7 +230,8 @@ struct tmi_ba_solver {
   const tmi_ba_options* cur_opts = nullptr;
   double* d_partial_max = nullptr;
   double* d_dense = nullptr;  // n_r x n_r when an exact solve is requested
-  int nblocks_slices = 0;     // grid of the per-track kernels
+  int nblocks_slices = 0;     // ceil(nslices / 4): grid of the thread-per-track side kernels
+  int nblocks_tracks = 0;     // grid of the per-track kernels of the solve (DeviceView::n_track_blocks)
   int nblocks_points = 0;
   tmi_ba_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
@@ -643,7 +644,10 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   if (s->nblocks_slices < 1) s->nblocks_slices = 1;
   s->nblocks_points = (st.Np_pad + 255) / 256;
   if (s->nblocks_points < 1) s->nblocks_points = 1;
-  const int nbmax = std::max(s->nblocks_slices, s->nblocks_points);
+  v.n_wide = st.n_wide;
+  v.n_track_blocks = 4 * st.n_wide + (st.nslices - st.n_wide + kSlicesPerBlock - 1) / kSlicesPerBlock;
+  s->nblocks_tracks = std::max(v.n_track_blocks, 1);
+  const int nbmax = std::max(std::max(s->nblocks_slices, s->nblocks_tracks), s->nblocks_points);
   if (light) {
     TMI_HIP(hipStreamSynchronize(s->stream));
     s->setup_seconds = now_s() - t0;
@@ -800,7 +804,7 @@ static int apply_schur(tmi_ba_solver* s, const double* x, double* y) {
     const tmi_ba_options* O = s->cur_opts;
     const int add_diag = (s->st.world <= 1 || s->st.rank == 0) ? 1 : 0;
     s->launch.implicit_spmv(v, s->stream, s->RL, x, y, s->d_pm_u, s->d_cm_t, s->cur_inv_radius,
-                            O->min_lm_diagonal, O->max_lm_diagonal, add_diag, s->nblocks_slices);
+                            O->min_lm_diagonal, O->max_lm_diagonal, add_diag, s->nblocks_tracks);
   }
   return do_allreduce(s, y, n);
 }
@@ -905,7 +909,7 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
   const RedLayout& RL = s->RL;
   const int D = st.D;
   const int n_r = st.Nrb * D;
-  const int nbs = s->nblocks_slices, nbp = s->nblocks_points;
+  const int nbs = s->nblocks_tracks, nbp = s->nblocks_points;
   hipStream_t stream = s->stream;
   s->prof_mask = (O->profile_kernels == 1) ? 0xffffffffu : (unsigned)O->profile_kernels;
   s->ev_used = 0;
@@ -1598,7 +1602,7 @@ int32_t tmi_ba_solver_evaluate(tmi_ba_solver* s, double* residuals, double* jac_
   hipLaunchKernelGGL(fill_kernel, dim3((n_r + 255) / 256 + 1), dim3(256), 0, stream, v.scale_c, (long long)n_r, 1.0);
   hipLaunchKernelGGL(fill_kernel, dim3((unsigned)(((long long)st.Np_pad * DP + 255) / 256 + 1)), dim3(256), 0, stream, v.scale_p, (long long)st.Np_pad * DP, 1.0);
   // poison the residual planes so that invalid observations can be told apart
-  s->launch.linearize(v, stream, 0, 1.0, s->nblocks_slices);
+  s->launch.linearize(v, stream, 0, 1.0, s->nblocks_tracks);
   const size_t N = (size_t)st.No_pad;
   std::vector<double> r(residuals ? 2 * N : 0), A(jac_camera ? (size_t)2 * D * N : 0),
       Jp(jac_point ? (size_t)2 * DP * N : 0);

@@ -45,6 +45,78 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 
+// ------------------------------------------------------------------------------
+// Track -> lane mapping of the per-track kernels.
+// Slices are sorted by track length.  A thread per track means the longest slice sets a
+// serial floor (63 dependent iterations on the Venice-sized problem) that does not shrink
+// when the tracks are sharded over several GPUs.  The first v.n_wide slices (those whose
+// longest track has >= kWideK observations) are therefore run "wide": a track is shared by
+// 16 consecutive lanes (lane i takes observations i, i + 16, ...), per-track sums are
+// finished with a fixed 16-lane butterfly, and a 256-thread workgroup covers a quarter of a
+// slice.  All other slices keep the thread-per-track mapping (workgroup = 4 slices).
+//   grid = 4 * n_wide + ceil((nslices - n_wide) / 4)        (DeviceView::n_track_blocks)
+// Which slices are wide depends on the slice only (never on the rank count), so the
+// summation order of a track is the same in a sharded and an unsharded run.
+// ------------------------------------------------------------------------------
+constexpr int kWideLanes = 16;
+
+struct TrackMap {
+  int s;        // slice
+  int lp;       // padded track index 64 s + t
+  int k;        // observations of the track (0 = padding)
+  size_t base;  // element of observation 0: slice_ptr[s] + t; observation j at base + 64 j
+  int j0, jstep;  // this lane's observations j0, j0 + jstep, ...
+  int trips;    // wave-uniform trip count covering the slice
+  bool wide, leader, valid;
+};
+
+__device__ __forceinline__ TrackMap track_map(const DeviceView& v) {
+  TrackMap m;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nwb = 4 * v.n_wide;
+  int t;
+  if ((int)blockIdx.x < nwb) {
+    m.wide = true;
+    m.s = blockIdx.x >> 2;
+    t = 16 * (blockIdx.x & 3) + 4 * w + (lane >> 4);
+    m.j0 = lane & (kWideLanes - 1);
+    m.jstep = kWideLanes;
+    m.leader = m.j0 == 0;
+  } else {
+    m.wide = false;
+    m.s = v.n_wide + ((int)blockIdx.x - nwb) * kSlicesPerBlock + w;
+    t = lane;
+    m.j0 = 0;
+    m.jstep = 1;
+    m.leader = true;
+  }
+  m.valid = m.s < v.nslices;
+  m.lp = m.s * 64 + t;
+  m.k = 0;
+  m.base = 0;
+  m.trips = 0;
+  if (m.valid) {
+    m.k = v.pt_k[m.lp];
+    const int sp0 = v.slice_ptr[m.s];
+    m.base = (size_t)sp0 + t;
+    const int K = (v.slice_ptr[m.s + 1] - sp0) >> 6;
+    m.trips = m.wide ? (K + kWideLanes - 1) / kWideLanes : K;
+  }
+  return m;
+}
+
+// sum over the 16 lanes that share a track (identity for thread-per-track slices); every lane
+// of the group receives the total; fixed butterfly => reproducible
+__device__ __forceinline__ double group_sum(double x, bool wide) {
+  if (wide) {
+    x += __shfl_xor(x, 1, 64);
+    x += __shfl_xor(x, 2, 64);
+    x += __shfl_xor(x, 4, 64);
+    x += __shfl_xor(x, 8, 64);
+  }
+  return x;
+}
+
 // Sum NV per-thread values over a 256-thread workgroup and store them at
 // partial[v * nblocks + blockIdx.x] (fixed order => reproducible).
 template <int NV>
@@ -115,14 +187,11 @@ struct LinearizeArgs {
 template <int D, int DP, bool SH, typename RT>
 __global__ __launch_bounds__(256) void linearize_kernel(DeviceView v, int loss_type, double loss_width,
                                                         int nblocks) {
-  const int lane = threadIdx.x & 63;
-  const int s = blockIdx.x * kSlicesPerBlock + (threadIdx.x >> 6);
+  const TrackMap tm = track_map(v);
   double acc[2] = {0.0, 0.0};
-  if (s < v.nslices) {
-    const int lp = s * 64 + lane;
-    const int k = v.pt_k[lp];
-    const int base = v.slice_ptr[s] + lane;
-    const int K = (v.slice_ptr[s + 1] - v.slice_ptr[s]) >> 6;
+  if (tm.valid) {
+    const int lp = tm.lp;
+    const int k = tm.k;
     const size_t N = (size_t)v.No_pad;
     double X[4];
 #pragma unroll
@@ -131,9 +200,8 @@ __global__ __launch_bounds__(256) void linearize_kernel(DeviceView v, int loss_t
     double sp[DP];
 #pragma unroll
     for (int a = 0; a < DP; ++a) sp[a] = v.scale_p[(size_t)lp * DP + a];
-    for (int j = 0; j < K; ++j) {
-      if (j >= k) continue;
-      const size_t e = (size_t)base + (size_t)j * 64;
+    for (int j = tm.j0; j < k; j += tm.jstep) {
+      const size_t e = tm.base + (size_t)j * 64;
       const int cam = v.obs_cam[e];
       const int grp = v.cam_grp[cam];
       const int model = v.grp_model[grp];
@@ -250,20 +318,16 @@ __global__ __launch_bounds__(256) void cost_kernel(DeviceView v, const double* _
                                                    const double* __restrict__ pts, int loss_type,
                                                    double loss_width, int flag_slot, int nblocks,
                                                    double* partial) {
-  const int lane = threadIdx.x & 63;
-  const int s = blockIdx.x * kSlicesPerBlock + (threadIdx.x >> 6);
+  const TrackMap tm = track_map(v);
   double acc[2] = {0.0, 0.0};
-  if (s < v.nslices) {
-    const int lp = s * 64 + lane;
-    const int k = v.pt_k[lp];
-    const int base = v.slice_ptr[s] + lane;
-    const int K = (v.slice_ptr[s + 1] - v.slice_ptr[s]) >> 6;
+  if (tm.valid) {
+    const int lp = tm.lp;
+    const int k = tm.k;
     double X[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) X[i] = pts[(size_t)lp * 4 + i];
-    for (int j = 0; j < K; ++j) {
-      if (j >= k) continue;
-      const size_t e = (size_t)base + (size_t)j * 64;
+    for (int j = tm.j0; j < k; j += tm.jstep) {
+      const size_t e = tm.base + (size_t)j * 64;
       const int cam = v.obs_cam[e];
       const int grp = v.cam_grp[cam];
       const double* Kp = intr + v.grp_off[grp];
@@ -304,17 +368,16 @@ __global__ __launch_bounds__(256) void cost_kernel(DeviceView v, const double* _
 // ------------------------------------------------------------------------------
 template <int DP>
 __global__ __launch_bounds__(256) void point_scale_kernel(DeviceView v) {
-  const int lane = threadIdx.x & 63;
-  const int s = blockIdx.x * kSlicesPerBlock + (threadIdx.x >> 6);
-  if (s >= v.nslices) return;
-  const int lp = s * 64 + lane;
-  const int k = v.pt_k[lp];
-  const size_t base = (size_t)v.slice_ptr[s] + lane;
+  const TrackMap tm = track_map(v);
+  if (!tm.valid) return;
+  const int lp = tm.lp;
+  const int k = tm.k;
+  const size_t base = tm.base;
   const size_t N = (size_t)v.No_pad;
   double n2[DP];
 #pragma unroll
   for (int a = 0; a < DP; ++a) n2[a] = 0.0;
-  for (int j = 0; j < k; ++j) {
+  for (int j = tm.j0; j < k; j += tm.jstep) {
     const size_t e = base + (size_t)j * 64;
 #pragma unroll
     for (int a = 0; a < DP; ++a) {
@@ -323,7 +386,10 @@ __global__ __launch_bounds__(256) void point_scale_kernel(DeviceView v) {
     }
   }
 #pragma unroll
-  for (int a = 0; a < DP; ++a) v.scale_p[(size_t)lp * DP + a] = 1.0 / (1.0 + sqrt(n2[a]));
+  for (int a = 0; a < DP; ++a) {
+    const double t = group_sum(n2[a], tm.wide);
+    if (tm.leader) v.scale_p[(size_t)lp * DP + a] = 1.0 / (1.0 + sqrt(t));
+  }
 }
 
 // scale_c holds the (all-reduced) squared column norms U_aa of the camera side, taken
@@ -352,12 +418,12 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
   __shared__ __attribute__((aligned(16))) double stage[kSlicesPerBlock][32][STP];
   __shared__ int stage_cpos[kSlicesPerBlock][32];
   const int lane = threadIdx.x & 63;
-  const int s = blockIdx.x * kSlicesPerBlock + (threadIdx.x >> 6);
+  const TrackMap tm = track_map(v);
   double gmax = 0.0;
-  if (s < v.nslices) {
-    const int lp = s * 64 + lane;
-    const int k = v.pt_k[lp];
-    const size_t base = (size_t)v.slice_ptr[s] + lane;
+  if (tm.valid) {
+    const int lp = tm.lp;
+    const int k = tm.k;
+    const size_t base = tm.base;
     const size_t N = (size_t)v.No_pad;
     const size_t NP = (size_t)v.Np_pad;
     bool have_tp = false;
@@ -368,7 +434,7 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
       for (int i = 0; i < NS; ++i) V[i] = 0.0;
 #pragma unroll
       for (int a = 0; a < DP; ++a) g[a] = 0.0;
-      for (int j = 0; j < k; ++j) {
+      for (int j = tm.j0; j < k; j += tm.jstep) {
         const size_t e = base + (size_t)j * 64;
         double J0[DP], J1[DP];
 #pragma unroll
@@ -384,15 +450,21 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
           g[a] += J0[a] * r0 + J1[a] * r1;
         }
       }
+      // wide slices: finish the sums over the 16 lanes that share the track; every lane of
+      // the group then factors the same DP x DP block (redundantly), the leader stores it
+#pragma unroll
+      for (int i = 0; i < NS; ++i) V[i] = group_sum(V[i], tm.wide);
+#pragma unroll
+      for (int a = 0; a < DP; ++a) g[a] = group_sum(g[a], tm.wide);
       // LM damping and Cholesky V + Dp = L L^T (L lower, packed by rows into Lm[a][b], b <= a)
       double Lm[DP][DP];
       bool pd = true;
 #pragma unroll
       for (int a = 0; a < DP; ++a) {
         const double d = V[sym_idx(a, a, DP)];
-        v.diag_p[(size_t)a * NP + lp] = d;
+        if (tm.leader) v.diag_p[(size_t)a * NP + lp] = d;
         V[sym_idx(a, a, DP)] = d + fmin(fmax(d, lm_lo), lm_hi) * inv_radius;
-        v.gp[(size_t)a * NP + lp] = g[a];
+        if (tm.leader) v.gp[(size_t)a * NP + lp] = g[a];
         gmax = fmax(gmax, fabs(g[a] / v.scale_p[(size_t)lp * DP + a]));
       }
 #pragma unroll
@@ -442,7 +514,7 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
 #pragma unroll
           for (int m = b; m < DP; ++m) t += Li[m][a] * Li[m][b];
           Vi[sym_idx(a, b, DP)] = t;
-          v.Vinv[(size_t)sym_idx(a, b, DP) * NP + lp] = t;
+          if (tm.leader) v.Vinv[(size_t)sym_idx(a, b, DP) * NP + lp] = t;
         }
 #pragma unroll
       for (int a = 0; a < DP; ++a) {
@@ -464,13 +536,13 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
     // time in LDS and writes them out with consecutive lanes covering consecutive 16 B,
     // i.e. whole 64-byte sectors per record (scattered 8/16-byte stores cost 2-4x the
     // bytes in HBM write traffic, profiles/r01_a).  The trip count K is wave uniform.
-    const int K = (v.slice_ptr[s + 1] - v.slice_ptr[s]) >> 6;
     double* st = &stage[threadIdx.x >> 6][0][0];
     int* scp = &stage_cpos[threadIdx.x >> 6][0];
     double Yg[SH ? YS : 1];  // running sum of the shared block's Y over the current run
 #pragma unroll
     for (int i = 0; i < (SH ? YS : 1); ++i) Yg[i] = 0.0;
-    for (int j = 0; j < K; ++j) {
+    for (int trip = 0; trip < tm.trips; ++trip) {
+      const int j = tm.j0 + trip * tm.jstep;
       const size_t e = base + (size_t)j * 64;
       int cpos = -1, gslot = -1, gflag = 0;
       if (have_tp && j < k) {
@@ -1025,19 +1097,18 @@ __global__ __launch_bounds__(256) void implicit_tracks_kernel(DeviceView v, cons
                                                               double* __restrict__ pm_u,
                                                               double* __restrict__ cm_t) {
   constexpr int NS = sym_size(DP);
-  const int lane = threadIdx.x & 63;
-  const int s = blockIdx.x * kSlicesPerBlock + (threadIdx.x >> 6);
-  if (s >= v.nslices) return;
-  const int lp = s * 64 + lane;
-  const int k = v.pt_k[lp];
-  if (k == 0) return;
-  const size_t base = (size_t)v.slice_ptr[s] + lane;
+  const TrackMap tm = track_map(v);
+  if (!tm.valid) return;
+  const int lp = tm.lp;
+  const int k = tm.k;
+  if (k == 0) return;  // uniform over the lanes that share a track
+  const size_t base = tm.base;
   const size_t N = (size_t)v.No_pad;
   const size_t NP = (size_t)v.Np_pad;
   double w[DP];
 #pragma unroll
   for (int a = 0; a < DP; ++a) w[a] = 0.0;
-  for (int j = 0; j < k; ++j) {
+  for (int j = tm.j0; j < k; j += tm.jstep) {
     const size_t e = base + (size_t)j * 64;
     const int rb = v.cam_rb[v.obs_cam[e]];
     double u0 = 0.0, u1 = 0.0;
@@ -1056,6 +1127,8 @@ __global__ __launch_bounds__(256) void implicit_tracks_kernel(DeviceView v, cons
     for (int a = 0; a < DP; ++a)
       w[a] += v.pm_Jp[(size_t)(2 * a) * N + e] * u0 + v.pm_Jp[(size_t)(2 * a + 1) * N + e] * u1;
   }
+#pragma unroll
+  for (int a = 0; a < DP; ++a) w[a] = group_sum(w[a], tm.wide);
   double Vi[NS], z[DP];
 #pragma unroll
   for (int i = 0; i < NS; ++i) Vi[i] = v.Vinv[(size_t)i * NP + lp];
@@ -1066,7 +1139,7 @@ __global__ __launch_bounds__(256) void implicit_tracks_kernel(DeviceView v, cons
     for (int b = 0; b < DP; ++b) t += Vi[a <= b ? sym_idx(a, b, DP) : sym_idx(b, a, DP)] * w[b];
     z[a] = t;
   }
-  for (int j = 0; j < k; ++j) {
+  for (int j = tm.j0; j < k; j += tm.jstep) {
     const size_t e = base + (size_t)j * 64;
     const int cpos = v.obs_cpos[e];
     if (cpos < 0) continue;
@@ -1406,20 +1479,19 @@ template <int D, int DP, bool SH>
 __global__ __launch_bounds__(256) void back_substitute_kernel(DeviceView v, double* __restrict__ pm_u,
                                                               int nblocks, double* partial) {
   constexpr int NS = sym_size(DP);
-  const int lane = threadIdx.x & 63;
-  const int s = blockIdx.x * kSlicesPerBlock + (threadIdx.x >> 6);
+  const TrackMap tm = track_map(v);
   double acc[1] = {0.0};
-  if (s < v.nslices) {
-    const int lp = s * 64 + lane;
-    const int k = v.pt_k[lp];
-    const size_t base = (size_t)v.slice_ptr[s] + lane;
+  if (tm.valid) {
+    const int lp = tm.lp;
+    const int k = tm.k;
+    const size_t base = tm.base;
     const size_t N = (size_t)v.No_pad;
     const size_t NP = (size_t)v.Np_pad;
     if (k > 0) {
       double w[DP];
 #pragma unroll
-      for (int a = 0; a < DP; ++a) w[a] = v.gp[(size_t)a * NP + lp];
-      for (int j = 0; j < k; ++j) {
+      for (int a = 0; a < DP; ++a) w[a] = tm.leader ? v.gp[(size_t)a * NP + lp] : 0.0;
+      for (int j = tm.j0; j < k; j += tm.jstep) {
         const size_t e = base + (size_t)j * 64;
         const int cam = v.obs_cam[e];
         const int rb = v.cam_rb[cam];
@@ -1451,6 +1523,8 @@ __global__ __launch_bounds__(256) void back_substitute_kernel(DeviceView v, doub
         for (int a = 0; a < DP; ++a)
           w[a] -= v.pm_Jp[(size_t)(2 * a) * N + e] * u0 + v.pm_Jp[(size_t)(2 * a + 1) * N + e] * u1;
       }
+#pragma unroll
+      for (int a = 0; a < DP; ++a) w[a] = group_sum(w[a], tm.wide);
       double Vi[NS], yp[DP];
 #pragma unroll
       for (int i = 0; i < NS; ++i) Vi[i] = v.Vinv[(size_t)i * NP + lp];
@@ -1460,9 +1534,9 @@ __global__ __launch_bounds__(256) void back_substitute_kernel(DeviceView v, doub
 #pragma unroll
         for (int b = 0; b < DP; ++b) t += Vi[a <= b ? sym_idx(a, b, DP) : sym_idx(b, a, DP)] * w[b];
         yp[a] = t;
-        v.yp[(size_t)a * NP + lp] = t;
+        if (tm.leader) v.yp[(size_t)a * NP + lp] = t;
       }
-      for (int j = 0; j < k; ++j) {
+      for (int j = tm.j0; j < k; j += tm.jstep) {
         const size_t e = base + (size_t)j * 64;
         double m0 = pm_u[e], m1 = pm_u[N + e];
 #pragma unroll

@@ -291,6 +291,13 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, 
     }
     s.slice_ptr[sl + 1] = (int)next;
   }
+  // leading slices (the order is by descending length) that the per-track kernels run with 16
+  // lanes per track; the shared-intrinsics kernels accumulate runs of adjacent observations
+  // serially and keep one thread per track
+  s.n_wide = 0;
+  if (!s.has_shared)
+    while (s.n_wide < s.nslices && ((s.slice_ptr[s.n_wide + 1] - s.slice_ptr[s.n_wide]) >> 6) >= kWideK)
+      ++s.n_wide;
   s.No_pad = s.slice_ptr[s.nslices];
   s.obs_cam.assign(s.No_pad, -1);
   s.obs_xy.assign(2 * (size_t)s.No_pad, 0.0);

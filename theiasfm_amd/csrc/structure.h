@@ -58,6 +58,7 @@ struct Structure {
   std::vector<int> pt_orig;       // [Np_pad] caller's track index or -1
   std::vector<int> pt_k;          // [Np_pad] track length (0 = padding)
   std::vector<int> slice_ptr;     // [nslices+1]
+  int n_wide = 0;                 // leading slices with >= kWideK observations per track (device_view.h)
   std::vector<int> obs_cam;       // [No_pad] camera or -1 (padding)
   std::vector<double> obs_xy;     // [2*No_pad]
   std::vector<int> obs_cpos;      // [No_pad] camera-major slot or -1

@@ -1,0 +1,52 @@
+"""Single-GPU probe of the per-rank cost at world sizes 1/2/4/8 (no second GPU needed):
+rank 0 of `world` runs its shard, the all-reduce hook multiplies the buffer by `world` (stands in
+for "the other ranks contribute about the same") on the engine's stream.  Numbers are per-rank
+compute + launch + read-back time, WITHOUT real xGMI latency; results are not a solution."""
+import json
+import sys
+import time
+
+sys.path.insert(0, ".")
+import torch  # noqa: E402
+
+from theiasfm_amd import abi, dist, lib, synth  # noqa: E402
+
+prob = synth.config("venice1778")
+steps = 10
+for world in (1, 2, 4, 8):
+    for mode in ((0,) if world == 1 else (0, 1)):
+        base = dict(point_dof=3, linear_solver_type=abi.ITERATIVE_SCHUR, function_tolerance=0.0,
+                    gradient_tolerance=0.0, parameter_tolerance=0.0, schur_mode=mode)
+        o = abi.default_options(max_num_iterations=2, **base)
+        s = lib.Solver(prob, o, 0, world)
+        streams, tensors = {}, {}
+
+        def hook(ptr, count, stream, world=world):
+            t = tensors.get((ptr, count))
+            if t is None:
+                t = torch.as_tensor(dist._DevArray(ptr, count), device="cuda")
+                tensors[(ptr, count)] = t
+            ext = streams.get(stream)
+            if ext is None:
+                ext = streams[stream] = torch.cuda.ExternalStream(stream)
+            with torch.cuda.stream(ext):
+                t.mul_(float(world))
+            return 0
+
+        if world > 1:
+            s.set_allreduce(hook)
+        s.solve(o)
+        s.reset()
+        ot = abi.default_options(max_num_iterations=steps, profile_kernels=1, **base)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        st, sm = s.solve(ot)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        d = sm.as_dict()
+        ks = {n: (l, round(1e3 * sec, 3)) for n, l, sec in zip(abi.KERNEL_CLASS_NAMES, d["kernel_launches"], d["kernel_seconds"]) if l}
+        print(json.dumps(dict(world=world, schur_mode=["auto", "explicit"][mode], its=int(sm.num_iterations),
+                              ms_per_iter=round(1e3 * el / max(1, sm.num_iterations), 3),
+                              pcg=int(sm.num_linear_solver_iterations), kernel_ms_total=round(sum(v[1] for v in ks.values()), 2),
+                              kernels=ks)))
+        s.close()
