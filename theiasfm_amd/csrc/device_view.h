@@ -26,8 +26,10 @@ namespace tmi {
 // shared by the host work list (structure.cpp) and the kernel (kernels.h)
 constexpr int kSpmvTrips = 8;
 // per-track kernels: slices whose longest track has at least this many observations are run
-// with 16 lanes per track (kernels.h, track_map)
+// with 16 lanes per track (kernels.h, track_map); the larger value applies when a rank holds
+// >= 5000 slices (structure.cpp)
 constexpr int kWideK = 12;
+constexpr int kWideKLarge = 20;
 
 struct DeviceView {
   int Nc, G, Np_pad, nslices, Nrb, D, DP;

@@ -8,6 +8,7 @@
 #include "device_view.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -295,9 +296,17 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, 
   // lanes per track; the shared-intrinsics kernels accumulate runs of adjacent observations
   // serially and keep one thread per track
   s.n_wide = 0;
-  if (!s.has_shared)
-    while (s.n_wide < s.nslices && ((s.slice_ptr[s.n_wide + 1] - s.slice_ptr[s.n_wide]) >> 6) >= kWideK)
-      ++s.n_wide;
+  {
+    // Measured on the Venice-sized problem (tools/exp_wide.sh): with the whole problem on one
+    // GPU (15.5 k slices) the bulk hides most of the tail and a high threshold is best
+    // (5.15 ms per iteration at 20-24 vs 5.26 at 12); with an eighth of the tracks the
+    // longest thread-per-track slice is the critical path and 10-12 wins (1.77 vs 2.05 ms).
+    int wide_k = s.nslices >= 5000 ? kWideKLarge : kWideK;
+    if (const char* e = std::getenv("TMI_BA_WIDE_K")) wide_k = std::max(1, std::atoi(e));  // tuning knob
+    if (!s.has_shared)
+      while (s.n_wide < s.nslices && ((s.slice_ptr[s.n_wide + 1] - s.slice_ptr[s.n_wide]) >> 6) >= wide_k)
+        ++s.n_wide;
+  }
   s.No_pad = s.slice_ptr[s.nslices];
   s.obs_cam.assign(s.No_pad, -1);
   s.obs_xy.assign(2 * (size_t)s.No_pad, 0.0);

@@ -13,7 +13,8 @@ from theiasfm_amd import abi, dist, lib, synth  # noqa: E402
 
 prob = synth.config("venice1778")
 steps = 10
-for world in (1, 2, 4, 8):
+worlds = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
+for world in worlds:
     for mode in ((0,) if world == 1 else (0, 1)):
         base = dict(point_dof=3, linear_solver_type=abi.ITERATIVE_SCHUR, function_tolerance=0.0,
                     gradient_tolerance=0.0, parameter_tolerance=0.0, schur_mode=mode)
