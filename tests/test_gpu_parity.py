@@ -312,3 +312,29 @@ def test_full_size_properties(name):
     q = prob.copy()
     st2, s2 = lib.solve(q, o)
     assert s2.final_cost == s.final_cost and (q.points == p.points).all()
+
+
+@pytest.mark.parametrize("wide_k", [1, 6, 12, 100000])
+@pytest.mark.parametrize("dof,solver,mode", [(3, abi.ITERATIVE_SCHUR, abi.SCHUR_EXPLICIT),
+                                             (4, abi.ITERATIVE_SCHUR, abi.SCHUR_IMPLICIT),
+                                             (3, abi.SPARSE_SCHUR, abi.SCHUR_AUTO)])
+def test_track_lane_mapping_does_not_change_the_result(wide_k, dof, solver, mode, monkeypatch):
+    """Long slices run with 16 lanes per track, short ones with a thread per track
+    (kernels.h track_map).  Whatever the threshold -- every slice wide, none, or in between --
+    the solve must match the oracle; only the summation order inside a track differs."""
+    monkeypatch.setenv("TMI_BA_WIDE_K", str(wide_k))
+    prob = synth.config("ladybug49")
+    o = dict(linear_solver_type=solver, point_dof=dof, schur_mode=mode, loss_function_type=abi.LOSS_HUBER,
+             robust_loss_width=3.0, max_num_iterations=12)
+    dev, ora = run_both(prob, **o)
+    assert_same_solution(dev, ora, scale=100.0, cost_rel=1e-8 if dof == 4 else 1e-9,
+                         rmse_abs=1e-8 if dof == 4 else 1e-9, param_rel=1e-5)
+    assert dev[1].num_iterations == ora[1].num_iterations
+    # residuals and Jacobian blocks through the same mapping
+    s = lib.Solver(prob.copy(), abi.default_options(point_dof=dof))
+    r, A, A1, Jp, valid, D = s.evaluate(dof)
+    s.close()
+    r_o, J_o, v_o = oracle.evaluate(prob)
+    assert valid.all() and v_o.all()
+    np.testing.assert_allclose(r, r_o, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(Jp, J_o[:, :, 16:16 + dof], rtol=1e-9, atol=1e-9)
