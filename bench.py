@@ -153,20 +153,25 @@ def main():
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
-    # Warm-up with every kernel class timed (HIP events on the engine's stream): it also
-    # tells which class dominates.  The timed region then carries events for THAT class only
-    # (two event records per launch of every class cost a few % of an iteration); the full
-    # per-class table comes from a third, untimed pass of the same K iterations.
-    dom_idx = abi.KERNEL_CLASS_NAMES.index("schur_offdiag")
+    # Warm-up (W iterations), then an untimed pass of the same K iterations with every kernel
+    # class timed (HIP events on the engine's stream): it gives the per-class table and tells
+    # which class dominates.  The timed region carries events for THAT class only (two event
+    # records per launch of every class cost a few % of an iteration).
     if args.warmup > 0:
-        opts_w = abi.default_options(max_num_iterations=args.warmup, profile_kernels=1, **base)
+        opts_w = abi.default_options(max_num_iterations=args.warmup, **base)
         st, s = solver.solve(opts_w)
         if st != 0:
             raise RuntimeError(f"warm-up solve failed: {st} {s.message!r}")
-        secs = list(s.kernel_seconds)
-        secs[abi.KERNEL_CLASS_NAMES.index("allreduce")] = 0.0
-        dom_idx = max(range(len(secs)), key=lambda i: secs[i])
         solver.reset()
+    opts_p = abi.default_options(max_num_iterations=args.steps, profile_kernels=1, **base)
+    st_p, s_p = solver.solve(opts_p)
+    if st_p != 0:
+        raise RuntimeError(f"profiling pass failed: {st_p} {s_p.message!r}")
+    d_p = s_p.as_dict()
+    secs = list(s_p.kernel_seconds)
+    secs[abi.KERNEL_CLASS_NAMES.index("allreduce")] = 0.0
+    dom_idx = max(range(len(secs)), key=lambda i: secs[i])
+    solver.reset()
 
     opts_t = abi.default_options(max_num_iterations=args.steps,
                                  profile_kernels=(1 << dom_idx) if dom_idx > 0 else 1, **base)
@@ -184,13 +189,6 @@ def main():
         raise RuntimeError(f"timed solve failed: {st} {s.message!r}")
     steps_run = int(s.num_iterations)
     d = s.as_dict()
-    # untimed pass: same K iterations, every class timed -> the per-class table
-    solver.reset()
-    opts_p = abi.default_options(max_num_iterations=args.steps, profile_kernels=1, **base)
-    st_p, s_p = solver.solve(opts_p)
-    if st_p != 0:
-        raise RuntimeError(f"profiling pass failed: {st_p} {s_p.message!r}")
-    d_p = s_p.as_dict()
 
     if rank != 0:
         solver.close()
@@ -290,18 +288,33 @@ def main():
                                                                "parameter_tolerance": 1e-8,
                                                                "gradient_tolerance": 1e-10})
         term_d, it_d, _, c1_d, ts = solver.adjust_tracks(trk_opts)
+        # CPU port on a bounded sample: the first 100 000 tracks (the rest are marked constant,
+        # which the per-track oracle skips)
+        n_cpu = min(100_000, n_pts)
         ref2 = prob0.copy()
+        ref2.point_constant = ref2.point_constant.copy()
+        ref2.point_constant[n_cpu:] = 1
         tc = time.perf_counter()
         term_o, it_o, _, c1_o = oracle.adjust_tracks(ref2, trk_opts)
         t_t = time.perf_counter() - tc
+        sm = slice(0, n_cpu)
         side["batched_track_ba"] = dict(
             kernel_ms=round(ts.kernel_seconds * 1e3, 3), tracks=int(ts.num_tracks),
             lm_iterations=int(ts.total_iterations), tracks_per_s=ts.num_tracks / ts.kernel_seconds,
-            cpu_port_tracks_per_s=ts.num_tracks / t_t,
-            termination_mismatches=int((term_d != term_o).sum()),
-            iteration_mismatches=int((it_d != it_o).sum()),
-            final_cost_rel_diff_above_1e9=int((np.abs(c1_d - c1_o) > 1e-9 * np.maximum(c1_o, 1e-12)).sum()),
-            total_final_cost=dict(device=float(c1_d.sum()), oracle=float(c1_o.sum())))
+            cpu_port_tracks_per_s=n_cpu / t_t, cpu_port_sample=f"first {n_cpu} tracks, {oracle.num_threads()} threads",
+            termination_mismatches=int((term_d[sm] != term_o[sm]).sum()),
+            iteration_mismatches=int((it_d[sm] != it_o[sm]).sum()),
+            final_cost_rel_diff_above_1e9=int((np.abs(c1_d[sm] - c1_o[sm]) > 1e-9 * np.maximum(c1_o[sm], 1e-12)).sum()),
+            sample_final_cost=dict(device=float(c1_d[sm].sum()), oracle=float(c1_o[sm].sum())))
+        solver.reset()
+        sel_d, ln_d, err_d, ss = solver.select_good_tracks(10, 100, 100)
+        tc = time.perf_counter()
+        sel_o, _, _ = oracle.select_good_tracks(prob0, 10, 100, 100)
+        t_s = time.perf_counter() - tc
+        side["track_selection"] = dict(
+            statistics_kernel_us=round(ss.kernel_seconds * 1e6, 1), call_ms=round(ss.seconds * 1e3, 2),
+            cpu_port_ms=round(t_s * 1e3, 1), selected=int(ss.num_selected), of=int(ss.num_tracks),
+            selection_equal=bool((sel_d == sel_o).all()))
         out["side_kernels"] = side
     solver.close()
     print(json.dumps(out))
