@@ -319,6 +319,12 @@ int readback(tmi_ba_solver* s) {
     __builtin_ia32_pause();
   }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  // a kernel that could not be launched (bad configuration, out of resources) shows up here
+  const hipError_t le = hipGetLastError();
+  if (le != hipSuccess) {
+    s->error = std::string("kernel launch failed: ") + hipGetErrorString(le);
+    return TMI_BA_ERR_DEVICE;
+  }
   return TMI_BA_OK;
 }
 
