@@ -129,9 +129,12 @@ def main():
     else:
         solver_type, solver_name = abi.DENSE_SCHUR, "DENSE_SCHUR (exact)"
     schur_mode = {"auto": 0, "explicit": 1, "implicit": 2}[args.schur_mode]
+    # use_inner_iterations = 0: a step is the trust-region iteration proper (the coordinate-descent
+    # sweep Ceres can add after each step is measured by the parity tests, not here), on the
+    # device and in the CPU baseline alike
     base = dict(point_dof=3, linear_solver_type=solver_type, function_tolerance=0.0,
                 gradient_tolerance=0.0, parameter_tolerance=0.0, device=local, schur_mode=schur_mode,
-                residual_precision=args.residual_precision)
+                residual_precision=args.residual_precision, use_inner_iterations=0)
     opts = abi.default_options(max_num_iterations=max(args.warmup, 1), **base)
     prob0 = prob.copy() if (world == 1 and not args.no_cpu_baseline) else None  # Solver.download() writes into `prob`
     t0 = time.perf_counter()

@@ -52,7 +52,7 @@ struct BundleAdjustmentOptions {
   int num_threads = 1;
   int max_num_iterations = 100;
   double max_solver_time_in_seconds = 3600.0;
-  bool use_inner_iterations = true;  // accepted; the device path runs plain LM
+  bool use_inner_iterations = true;  // one coordinate-descent sweep after every LM step
   double function_tolerance = 1e-6;
   double gradient_tolerance = 1e-10;
   double parameter_tolerance = 1e-8;

@@ -179,8 +179,11 @@ typedef struct tmi_ba_options {
   int32_t num_threads;               /* accepted, unused by the device path   */
   int32_t max_num_iterations;        /* 100                                   */
   double max_solver_time_in_seconds; /* 3600                                  */
-  int32_t use_inner_iterations;      /* accepted; the device path runs plain
-                                        LM (no inner iterations), see DESIGN  */
+  int32_t use_inner_iterations;      /* 1 (reference default, bundle_adjustment.h:112): after
+                                        every trust-region step one coordinate-descent sweep
+                                        over intrinsics blocks, extrinsics blocks, points
+                                        (Ceres inner iterations), until their relative gain
+                                        drops below 1e-3                         */
   double function_tolerance;         /* 1e-6                                  */
   double gradient_tolerance;         /* 1e-10                                 */
   double parameter_tolerance;        /* 1e-8                                  */
@@ -246,6 +249,8 @@ typedef struct tmi_ba_summary {
   int64_t num_schur_blocks;      /* structurally non-zero D x D blocks of S,
                                     upper triangle incl. diagonal            */
   int64_t num_schur_pairs;       /* observation pairs feeding off-diagonal S */
+  int32_t num_inner_iteration_steps; /* LM iterations that ran an inner-iteration sweep */
+  int32_t reserved0;
   /* per kernel class (index = tmi_ba_kernel_class): launches and total
    * device time from HIP events; filled when options.profile_kernels != 0   */
   int64_t kernel_launches[TMI_BA_NUM_KERNEL_CLASSES];

@@ -1179,6 +1179,156 @@ static double state_norm(const ost* s) {
   return sqrt(v);
 }
 
+int32_t oracle_adjust_tracks(tmi_ba_problem* P, const tmi_ba_options* O, int8_t* termination,
+                             int32_t* iterations, double* initial_cost, double* final_cost);
+
+/* ---- inner iterations -------------------------------------------------------------
+ * Ceres' CoordinateDescentMinimizer (coordinate_descent_minimizer.cc, 1.14) as the
+ * TrustRegionMinimizer calls it from DoInnerIterationsIfNeeded when
+ * Solver::Options::use_inner_iterations is set (Theia: BundleAdjustmentOptions::
+ * use_inner_iterations = true, bundle_adjustment.h:112; bundle_adjuster.cc:74).  Ceres is
+ * external to the reference: restated from the 1.14 sources' documented behaviour.
+ *
+ * Theia leaves inner_iteration_ordering empty, so Ceres computes one
+ * (CoordinateDescentMinimizer::CreateOrdering = recursive independent sets of the Hessian
+ * graph, reversed: "cameras before points").  Round 0 of the recursion takes every point
+ * block; the extrinsics and intrinsics block of a view are adjacent, so rounds 1 and 2 split
+ * them -- Ceres picks by degree and then by hash order, i.e. the reference leaves WHICH of
+ * the two goes first undefined.  This restatement fixes it: intrinsics blocks, then
+ * extrinsics blocks, then points.
+ *
+ * Every block of a set is minimised on its own with all other blocks constant:
+ * TrustRegionMinimizer with default Minimizer::Options (50 iterations, function / gradient /
+ * parameter tolerance 1e-6 / 1e-10 / 1e-8, LM radius 1e4 <= 1e16, DENSE_QR, Jacobi scaling),
+ * the residual blocks keep their loss function. */
+static void inner_options(const tmi_ba_options* O, tmi_ba_options* o2) {
+  tmi_ba_options d;
+  memset(&d, 0, sizeof(d));
+  d.loss_function_type = O->loss_function_type;
+  d.robust_loss_width = O->robust_loss_width;
+  d.linear_solver_type = TMI_BA_DENSE_QR;
+  d.preconditioner_type = O->preconditioner_type;
+  d.num_threads = 1;
+  d.max_num_iterations = 50;
+  d.max_solver_time_in_seconds = 1e9;
+  d.use_inner_iterations = 0;
+  d.function_tolerance = 1e-6;
+  d.gradient_tolerance = 1e-10;
+  d.parameter_tolerance = 1e-8;
+  d.max_trust_region_radius = 1e16;
+  d.initial_trust_region_radius = 1e4;
+  d.min_trust_region_radius = 1e-32;
+  d.min_relative_decrease = 1e-3;
+  d.min_lm_diagonal = 1e-6;
+  d.max_lm_diagonal = 1e32;
+  d.eta = 0.1;
+  d.max_linear_solver_iterations = 500;
+  d.max_num_consecutive_invalid_steps = 5;
+  d.jacobi_scaling = 1;
+  d.point_dof = O->point_dof;
+  d.device = -1;
+  d.residual_precision = 64;
+  *o2 = d;
+}
+
+/* Minimise over ONE camera-side block: the intrinsics of group `g` (kind 1; the views
+ * listed in cams[] share it) or the extrinsics of camera cams[0] (kind 0).  V: the
+ * problem whose parameter arrays hold the current inner iterate (updated on success). */
+static void inner_solve_camera_block(const tmi_ba_problem* V, const tmi_ba_options* o2, int kind,
+                                     int g, const int* cams, int ncams, const int64_t* cam_ptr,
+                                     const int64_t* cam_obs) {
+  int64_t nobs = 0;
+  for (int a = 0; a < ncams; ++a) nobs += cam_ptr[cams[a] + 1] - cam_ptr[cams[a]];
+  if (nobs == 0) return;
+  const int n_intr = V->group_offset[g + 1] - V->group_offset[g];
+  double* ext = (double*)malloc(sizeof(double) * 6 * (size_t)ncams);
+  int32_t* cgrp = (int32_t*)calloc((size_t)ncams, sizeof(int32_t));
+  uint8_t* cflag = (uint8_t*)malloc((size_t)ncams);
+  int32_t gmodel = V->group_model[g];
+  int32_t goff[2] = {0, n_intr};
+  double intr[10];
+  uint8_t iconst[10];
+  memcpy(intr, V->intrinsics + V->group_offset[g], sizeof(double) * (size_t)n_intr);
+  for (int a = 0; a < n_intr; ++a)
+    iconst[a] = (kind == 1) ? (V->intrinsics_constant ? V->intrinsics_constant[V->group_offset[g] + a] : 0) : 1;
+  double* pts = (double*)malloc(sizeof(double) * 4 * (size_t)nobs);
+  uint8_t* pconst = (uint8_t*)malloc((size_t)nobs);
+  int32_t* ocam = (int32_t*)malloc(sizeof(int32_t) * (size_t)nobs);
+  int32_t* opt = (int32_t*)malloc(sizeof(int32_t) * (size_t)nobs);
+  double* oxy = (double*)malloc(sizeof(double) * 2 * (size_t)nobs);
+  int64_t k = 0;
+  for (int a = 0; a < ncams; ++a) {
+    const int c = cams[a];
+    memcpy(ext + 6 * a, V->extrinsics + 6 * (size_t)c, sizeof(double) * 6);
+    cflag[a] = (kind == 0) ? (V->camera_flags ? V->camera_flags[c] : 0)
+                           : (uint8_t)(TMI_BA_CAMERA_POSITION_CONSTANT | TMI_BA_CAMERA_ORIENTATION_CONSTANT);
+    for (int64_t q = cam_ptr[c]; q < cam_ptr[c + 1]; ++q, ++k) {
+      const int64_t o = cam_obs[q];
+      /* every observation brings its own (constant) copy of the point: no index map needed */
+      memcpy(pts + 4 * k, V->points + 4 * (size_t)V->obs_point[o], sizeof(double) * 4);
+      pconst[k] = 1;
+      ocam[k] = a;
+      opt[k] = (int32_t)k;
+      oxy[2 * k] = V->obs_xy[2 * o];
+      oxy[2 * k + 1] = V->obs_xy[2 * o + 1];
+    }
+  }
+  tmi_ba_problem Q;
+  memset(&Q, 0, sizeof(Q));
+  Q.num_cameras = ncams; Q.extrinsics = ext; Q.camera_group = cgrp; Q.camera_flags = cflag;
+  Q.num_groups = 1; Q.group_model = &gmodel; Q.group_offset = goff; Q.intrinsics = intr;
+  Q.intrinsics_constant = iconst;
+  Q.num_points = (int32_t)nobs; Q.points = pts; Q.point_constant = pconst;
+  Q.num_observations = nobs; Q.obs_camera = ocam; Q.obs_point = opt; Q.obs_xy = oxy;
+  tmi_ba_summary sm;
+  oracle_ba_solve(&Q, o2, &sm);
+  if (sm.success) {
+    if (kind == 0)
+      memcpy(V->extrinsics + 6 * (size_t)cams[0], ext, sizeof(double) * 6);
+    else
+      memcpy(V->intrinsics + V->group_offset[g], intr, sizeof(double) * (size_t)n_intr);
+  }
+  free(ext); free(cgrp); free(cflag); free(pts); free(pconst); free(ocam); free(opt); free(oxy);
+}
+
+/* One sweep of the coordinate descent over the parameter arrays of V (in place). */
+static void inner_iterations(tmi_ba_problem* V, const tmi_ba_options* O) {
+  tmi_ba_options o2;
+  inner_options(O, &o2);
+  const int Nc = V->num_cameras, G = V->num_groups;
+  const int64_t No = V->num_observations;
+  int64_t* cam_ptr = (int64_t*)calloc((size_t)Nc + 2, sizeof(int64_t));
+  int64_t* cam_obs = (int64_t*)malloc(sizeof(int64_t) * (size_t)(No > 0 ? No : 1));
+  for (int64_t o = 0; o < No; ++o) cam_ptr[V->obs_camera[o] + 2]++;
+  for (int c = 0; c < Nc; ++c) cam_ptr[c + 2] += cam_ptr[c + 1];
+  for (int64_t o = 0; o < No; ++o) cam_obs[cam_ptr[V->obs_camera[o] + 1]++] = o;
+  /* views of each group */
+  int* gptr = (int*)calloc((size_t)G + 2, sizeof(int));
+  int* gcam = (int*)malloc(sizeof(int) * (size_t)(Nc > 0 ? Nc : 1));
+  for (int c = 0; c < Nc; ++c) gptr[V->camera_group[c] + 2]++;
+  for (int g = 0; g < G; ++g) gptr[g + 2] += gptr[g + 1];
+  for (int c = 0; c < Nc; ++c) gcam[gptr[V->camera_group[c] + 1]++] = c;
+  /* set 1: intrinsics blocks with a free coordinate */
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int g = 0; g < G; ++g) {
+    int nfree = 0;
+    for (int a = V->group_offset[g]; a < V->group_offset[g + 1]; ++a)
+      nfree += !(V->intrinsics_constant && V->intrinsics_constant[a]);
+    if (nfree == 0 || gptr[g + 1] == gptr[g]) continue;
+    inner_solve_camera_block(V, &o2, 1, g, gcam + gptr[g], gptr[g + 1] - gptr[g], cam_ptr, cam_obs);
+  }
+  /* set 2: extrinsics blocks with a free coordinate */
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int c = 0; c < Nc; ++c) {
+    const int f = V->camera_flags ? V->camera_flags[c] : 0;
+    if ((f & TMI_BA_CAMERA_POSITION_CONSTANT) && (f & TMI_BA_CAMERA_ORIENTATION_CONSTANT)) continue;
+    inner_solve_camera_block(V, &o2, 0, V->camera_group[c], &c, 1, cam_ptr, cam_obs);
+  }
+  /* set 3: the points, each against its (now constant) cameras */
+  oracle_adjust_tracks(V, &o2, NULL, NULL, NULL, NULL);
+  free(cam_ptr); free(cam_obs); free(gptr); free(gcam);
+}
+
 int32_t oracle_ba_solve(tmi_ba_problem* P, const tmi_ba_options* O, tmi_ba_summary* sum) {
   if (!O || !sum) return TMI_BA_ERR_INVALID_ARGUMENT;
   memset(sum, 0, sizeof(*sum));
@@ -1341,6 +1491,7 @@ int32_t oracle_ba_solve(tmi_ba_problem* P, const tmi_ba_options* O, tmi_ba_summa
   double decrease_factor = 2.0;
   int reuse_diagonal = 0;
   int invalid_run = 0;
+  int inner_enabled = O->use_inner_iterations ? 1 : 0;
   int iter = 0;
   int termination = 1; /* NO_CONVERGENCE unless stated */
   const char* why = "maximum number of iterations reached";
@@ -1436,6 +1587,48 @@ int32_t oracle_ba_solve(tmi_ba_problem* P, const tmi_ba_options* O, tmi_ba_summa
       s->intr = sv_i;
       s->pts = sv_p;
       if (cbad) cand_cost = DBL_MAX;
+      /* DoInnerIterationsIfNeeded (trust_region_minimizer.cc) */
+      int inner_useful = 0;
+      if (inner_enabled && cand_cost < DBL_MAX) {
+        double* b_ext = (double*)malloc(sizeof(double) * 6 * (size_t)(s->Nc + 1));
+        double* b_intr = (double*)malloc(sizeof(double) * (size_t)(n_intr_total + 1));
+        double* b_pts = (double*)malloc(sizeof(double) * 4 * (size_t)(s->Np + 1));
+        memcpy(b_ext, cand_ext, sizeof(double) * 6 * (size_t)s->Nc);
+        memcpy(b_intr, cand_intr, sizeof(double) * (size_t)n_intr_total);
+        memcpy(b_pts, cand_pts, sizeof(double) * 4 * (size_t)s->Np);
+        tmi_ba_problem V = *P;
+        V.extrinsics = cand_ext;
+        V.intrinsics = cand_intr;
+        V.points = cand_pts;
+        inner_iterations(&V, O);
+        s->ext = cand_ext;
+        s->intr = cand_intr;
+        s->pts = cand_pts;
+        double inner_cost, inner_ss;
+        const int64_t ibad = evaluate(s, 0, 0, &inner_cost, &inner_ss);
+        s->ext = sv_e;
+        s->intr = sv_i;
+        s->pts = sv_p;
+        if (ibad) {
+          /* "Inner iteration failed": the trust-region candidate stands */
+          memcpy(cand_ext, b_ext, sizeof(double) * 6 * (size_t)s->Nc);
+          memcpy(cand_intr, b_intr, sizeof(double) * (size_t)n_intr_total);
+          memcpy(cand_pts, b_pts, sizeof(double) * 4 * (size_t)s->Np);
+        } else {
+          model_cost_change += cand_cost - inner_cost;
+          inner_useful = inner_cost < cost;
+          const double progress = 1.0 - inner_cost / cand_cost;
+          inner_enabled = progress > 1e-3; /* inner_iteration_tolerance */
+          cand_cost = inner_cost;
+          /* step norm of the combined step, in the ambient space */
+          step_sq = 0.0;
+          for (int64_t i = 0; i < 6 * (int64_t)s->Nc; ++i) step_sq += (cand_ext[i] - s->ext[i]) * (cand_ext[i] - s->ext[i]);
+          for (int64_t i = 0; i < n_intr_total; ++i) step_sq += (cand_intr[i] - s->intr[i]) * (cand_intr[i] - s->intr[i]);
+          for (int64_t i = 0; i < 4 * (int64_t)s->Np; ++i) step_sq += (cand_pts[i] - s->pts[i]) * (cand_pts[i] - s->pts[i]);
+          sum->num_inner_iteration_steps++;
+        }
+        free(b_ext); free(b_intr); free(b_pts);
+      }
       /* ParameterToleranceReached */
       const double step_norm = sqrt(step_sq);
       if (step_norm <= O->parameter_tolerance * (x_norm + O->parameter_tolerance)) {
@@ -1451,7 +1644,8 @@ int32_t oracle_ba_solve(tmi_ba_problem* P, const tmi_ba_options* O, tmi_ba_summa
         break;
       }
       const double relative_decrease = cost_change / model_cost_change;
-      if (relative_decrease > O->min_relative_decrease) {
+      /* IsStepSuccessful: a net decrease through the inner iterations also accepts */
+      if (inner_useful || relative_decrease > O->min_relative_decrease) {
         /* HandleSuccessfulStep */
         memcpy(s->ext, cand_ext, sizeof(double) * 6 * (size_t)s->Nc);
         memcpy(s->intr, cand_intr, sizeof(double) * (size_t)n_intr_total);

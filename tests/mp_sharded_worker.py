@@ -15,6 +15,7 @@ def main():
     rank, world, _ = dist.init_from_env(backend="gloo")
     prob = synth.config("ladybug49")
     opts = abi.default_options(linear_solver_type=abi.ITERATIVE_SCHUR, point_dof=3, schur_mode=mode,
+                               use_inner_iterations=0,
                                device=0)
     sv = lib.Solver(prob, opts, rank, world)
     sv.set_allreduce(dist.make_staged_allreduce())

@@ -151,7 +151,8 @@ def test_lm_matches_oracle_mixed_models_and_huber():
     prob.obs_xy[::97] += 40.0
     for loss, mode in ((abi.LOSS_HUBER, abi.SCHUR_EXPLICIT), (abi.LOSS_CAUCHY, abi.SCHUR_IMPLICIT)):
         dev, ora = run_both(prob, linear_solver_type=abi.ITERATIVE_SCHUR, point_dof=4, schur_mode=mode,
-                            loss_function_type=loss, robust_loss_width=2.0, max_num_iterations=30)
+                            loss_function_type=loss, robust_loss_width=2.0, max_num_iterations=30,
+                            use_inner_iterations=0)
         # point_dof = 4 + PCG + a robust loss: the free scale of every homogeneous point turns
         # summation-order rounding into ~1e-8 differences; BASELINE.json's
         # bar is 1e-6
@@ -338,3 +339,46 @@ def test_track_lane_mapping_does_not_change_the_result(wide_k, dof, solver, mode
     assert valid.all() and v_o.all()
     np.testing.assert_allclose(r, r_o, rtol=0, atol=1e-9)
     np.testing.assert_allclose(Jp, J_o[:, :, 16:16 + dof], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("dof", [3, 4])
+@pytest.mark.parametrize("case", ["private", "shared", "robust_mixed", "anchored"])
+def test_inner_iterations_match_oracle(dof, case):
+    """use_inner_iterations = 1 (the reference default): after every trust-region step one
+    coordinate-descent sweep over intrinsics blocks, extrinsics blocks and points.  Device:
+    batched per-block LM kernels (inner_kernels.h) + the batched track solver; oracle: its LM on
+    one-block sub-problems.  point_dof = 3 agrees to round-off; with 4 the free scale of the
+    homogeneous points limits agreement to ~1e-5."""
+    kw = dict(seed=61, scene="ring", spread=0.4)
+    opt = dict(linear_solver_type=abi.SPARSE_SCHUR, point_dof=dof, max_num_iterations=8, use_inner_iterations=1)
+    if case == "private":
+        prob = synth.make_problem(12, 500, 2600, **kw)
+    elif case == "shared":
+        prob = synth.make_problem(12, 500, 2600, shared_group_size=4, intrinsics_to_optimize=abi.INTRINSICS_ALL, **kw)
+    elif case == "robust_mixed":
+        prob = synth.make_problem(12, 500, 2600, models=[(abi.PINHOLE, 0.4), (abi.PINHOLE_RADIAL_TANGENTIAL, 0.2),
+                                                          (abi.FISHEYE, 0.2), (abi.FOV, 0.1),
+                                                          (abi.DIVISION_UNDISTORTION, 0.1)],
+                                  intrinsics_to_optimize=abi.INTRINSICS_FOCAL_LENGTH | abi.INTRINSICS_RADIAL_DISTORTION,
+                                  **kw)
+        prob.obs_xy[::53] += 25.0
+        opt.update(loss_function_type=abi.LOSS_HUBER, robust_loss_width=2.0, linear_solver_type=abi.ITERATIVE_SCHUR)
+    else:
+        prob = synth.make_problem(12, 500, 2600, **kw)
+        prob.camera_flags[0] = abi.CAMERA_POSITION_CONSTANT | abi.CAMERA_ORIENTATION_CONSTANT
+        prob.camera_flags[1] = abi.CAMERA_POSITION_CONSTANT
+        prob.camera_flags[2] = abi.CAMERA_ORIENTATION_CONSTANT
+        prob.point_constant[::5] = 1
+        prob.set_intrinsics_to_optimize(abi.INTRINSICS_NONE)
+    dev, ora = run_both(prob, **opt)
+    assert ora[1].num_inner_iteration_steps > 0
+    assert dev[1].num_inner_iteration_steps == ora[1].num_inner_iteration_steps
+    tol = 1e-9 if dof == 3 else 1e-4
+    if dof == 4:  # homogeneous points agree up to scale
+        for _, _, q in (dev, ora):
+            q.points = q.points / q.points[:, 3:4]
+    assert_same_solution(dev, ora, scale=100.0, cost_rel=tol, rmse_abs=tol, param_rel=1e-5 if dof == 3 else 1e-3)
+    # and the sweep pays: the same number of LM iterations without it ends higher
+    plain = prob.copy()
+    st, s_plain = lib.solve(plain, abi.default_options(**{**opt, "use_inner_iterations": 0}))
+    assert st == 0 and dev[1].final_cost <= s_plain.final_cost * (1 + 1e-9)

@@ -58,7 +58,9 @@ def test_sharded_solve_matches_single_rank(world, solver_type, mode):
     import torch
     torch.cuda.init()
     prob = synth.config("ladybug49")
-    opts = abi.default_options(linear_solver_type=solver_type, point_dof=3, schur_mode=mode)
+    # inner iterations need every observation of a view on one rank: plain LM on both sides
+    opts = abi.default_options(linear_solver_type=solver_type, point_dof=3, schur_mode=mode,
+                               use_inner_iterations=0)
     single = prob.copy()
     st, s1 = lib.solve(single, opts)
     assert st == 0
@@ -152,7 +154,8 @@ def test_two_processes_one_gpu(mode):
     through gloo instead of RCCL.  AUTO picks the implicit operator for world > 1."""
     prob = synth.config("ladybug49")
     single = prob.copy()
-    st, s1 = lib.solve(single, abi.default_options(linear_solver_type=abi.ITERATIVE_SCHUR, point_dof=3))
+    st, s1 = lib.solve(single, abi.default_options(linear_solver_type=abi.ITERATIVE_SCHUR, point_dof=3,
+                                                   use_inner_iterations=0))
     assert st == 0
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29540 + mode), WORLD_SIZE="2")

@@ -121,7 +121,9 @@ def test_adjust_tracks_matches_single_track_solve():
     S.point_constant = np.zeros(1, np.uint8)
     S.obs_camera, S.obs_xy = P.obs_camera[sel], P.obs_xy[sel]
     S.obs_point = np.zeros(int(sel.sum()), np.int32)
-    o2 = abi.default_options(point_dof=4, max_num_iterations=25, linear_solver_type=abi.DENSE_QR)
+    # BundleAdjustTrack: DENSE_QR, no inner iterations (bundle_adjustment.cc:100-101)
+    o2 = abi.default_options(point_dof=4, max_num_iterations=25, linear_solver_type=abi.DENSE_QR,
+                             use_inner_iterations=0)
     st, sm = oracle.solve(S, o2)
     assert st == 0
     np.testing.assert_allclose(Q.points[t], S.points[0], rtol=1e-12, atol=1e-12)

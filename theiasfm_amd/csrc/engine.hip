@@ -25,6 +25,7 @@
 #include "dense_cholesky.h"
 #include "kernels.h"
 #include "track_kernels.h"
+#include "inner_kernels.h"
 #include "structure.h"
 
 namespace tmi {
@@ -244,6 +245,18 @@ struct tmi_ba_solver {
   int64_t launches[TMI_BA_NUM_KERNEL_CLASSES] = {0};
   std::string error;
   double setup_seconds = 0.0;
+  // inner iterations (inner_kernels.h): built on first use
+  struct InnerCtx {
+    bool ready = false;
+    InnerSet set[2];  // 0 extrinsics blocks, 1 intrinsics blocks
+    double* x0[2] = {nullptr, nullptr};
+    double* xc[2] = {nullptr, nullptr};
+    double* bak_ext = nullptr;
+    double* bak_intr = nullptr;
+    double* bak_pts = nullptr;
+    int* d_active = nullptr;
+    int* h_active = nullptr;  // pinned
+  } inner;
   // per-track side kernels (outlier filter, batched track adjustment): parameters + SELL
   // layout only when `light`; output arrays allocated on first use
   bool light = false;
@@ -501,6 +514,7 @@ void tmi_ba_solver_destroy(tmi_ba_solver* s) {
   }
   for (void* p : s->allocs) hipFree(p);
   if (s->h_mirror) hipHostFree(s->h_mirror);
+  if (s->inner.h_active) hipHostFree(s->inner.h_active);
   if (s->stream) hipStreamDestroy(s->stream);
   delete s;
 }
@@ -887,6 +901,192 @@ static int solve_reduced_dense(tmi_ba_solver* s, int* usable) {
   return TMI_BA_OK;
 }
 
+// ---- inner iterations: one coordinate-descent sweep over the candidate arrays -----------
+static int ensure_track_outputs(tmi_ba_solver* s);
+
+static int ensure_inner(tmi_ba_solver* s) {
+  tmi_ba_solver::InnerCtx& I = s->inner;
+  if (I.ready) return TMI_BA_OK;
+  const Structure& st = s->st;
+  int rc;
+  // view-major observation index from the track-major layout
+  std::vector<int> vo_ptr((size_t)st.Nc + 2, 0), vo_e((size_t)st.No), vo_lp((size_t)st.No);
+  for (int64_t e = 0; e < st.No_pad; ++e)
+    if (st.obs_cam[e] >= 0) vo_ptr[st.obs_cam[e] + 2]++;
+  for (int c = 0; c < st.Nc; ++c) vo_ptr[c + 2] += vo_ptr[c + 1];
+  for (int sl = 0; sl < st.nslices; ++sl) {
+    const int K = (st.slice_ptr[sl + 1] - st.slice_ptr[sl]) >> 6;
+    for (int j = 0; j < K; ++j)
+      for (int t = 0; t < 64; ++t) {
+        const int64_t e = (int64_t)st.slice_ptr[sl] + 64 * j + t;
+        const int cam = st.obs_cam[e];
+        if (cam < 0) continue;
+        const int q = vo_ptr[cam + 1]++;
+        vo_e[q] = (int)e;
+        vo_lp[q] = sl * 64 + t;
+      }
+  }
+  vo_ptr.pop_back();
+  int *d_vo_ptr, *d_vo_e, *d_vo_lp;
+  if ((rc = dev_upload(s, &d_vo_ptr, vo_ptr))) return rc;
+  if ((rc = dev_upload(s, &d_vo_e, vo_e))) return rc;
+  if ((rc = dev_upload(s, &d_vo_lp, vo_lp))) return rc;
+  double* d_part;
+  int* d_part_bad;
+  if ((rc = dev_alloc(s, &d_part, (size_t)std::max(st.Nc, 1) * kInnerPart))) return rc;
+  if ((rc = dev_alloc(s, &d_part_bad, (size_t)std::max(st.Nc, 1)))) return rc;
+  if ((rc = dev_alloc(s, &I.d_active, 1))) return rc;
+  TMI_HIP(hipHostMalloc((void**)&I.h_active, sizeof(int), hipHostMallocDefault));
+  for (int kind = 0; kind < 2; ++kind) {
+    std::vector<int> view_block((size_t)st.Nc, -1), bptr(1, 0), bviews, bn, bparam, bsize;
+    std::vector<signed char> bcols;
+    if (kind == 0) {
+      for (int c = 0; c < st.Nc; ++c) {
+        const unsigned m = st.cam_mask[c] & 0x3fu;
+        if (!m) continue;
+        view_block[c] = (int)bn.size();
+        bviews.push_back(c);
+        bptr.push_back((int)bviews.size());
+        int n = 0;
+        signed char cols[kInnerMaxN] = {0};
+        for (int a = 0; a < 6; ++a)
+          if (m & (1u << a)) cols[n++] = (signed char)a;
+        bn.push_back(n);
+        bcols.insert(bcols.end(), cols, cols + kInnerMaxN);
+        bparam.push_back(6 * c);
+        bsize.push_back(6);
+      }
+    } else {
+      for (int g = 0; g < st.G; ++g) {
+        const unsigned m = st.grp_free[g];
+        if (!m) continue;
+        const int b = (int)bn.size();
+        for (int c = 0; c < st.Nc; ++c)
+          if (st.cam_group[c] == g) {
+            view_block[c] = b;
+            bviews.push_back(c);
+          }
+        bptr.push_back((int)bviews.size());
+        int n = 0;
+        signed char cols[kInnerMaxN] = {0};
+        for (int a = 0; a < kInnerMaxN; ++a)
+          if (m & (1u << a)) cols[n++] = (signed char)a;
+        bn.push_back(n);
+        bcols.insert(bcols.end(), cols, cols + kInnerMaxN);
+        bparam.push_back(st.group_offset[g]);
+        bsize.push_back(st.group_offset[g + 1] - st.group_offset[g]);
+      }
+    }
+    InnerSet& S = I.set[kind];
+    memset(&S, 0, sizeof(S));
+    S.kind = kind;
+    S.nblocks = (int)bn.size();
+    int* pi;
+    signed char* pc;
+    if ((rc = dev_upload(s, &pi, view_block))) return rc; S.view_block = pi;
+    if ((rc = dev_upload(s, &pi, bptr))) return rc; S.blk_views_ptr = pi;
+    if ((rc = dev_upload(s, &pi, bviews))) return rc; S.blk_views = pi;
+    if ((rc = dev_upload(s, &pi, bn))) return rc; S.blk_n = pi;
+    if ((rc = dev_upload(s, &pc, bcols))) return rc; S.blk_cols = pc;
+    if ((rc = dev_upload(s, &pi, bparam))) return rc; S.blk_param = pi;
+    if ((rc = dev_upload(s, &pi, bsize))) return rc; S.blk_size = pi;
+    S.vo_ptr = d_vo_ptr; S.vo_e = d_vo_e; S.vo_lp = d_vo_lp;
+    const size_t nx = kind == 0 ? (size_t)6 * std::max(st.Nc, 1) : (size_t)std::max(s->n_intr, 1);
+    if ((rc = dev_alloc(s, &I.x0[kind], nx))) return rc;
+    if ((rc = dev_alloc(s, &I.xc[kind], nx))) return rc;
+    S.part = d_part; S.part_bad = d_part_bad;
+    const size_t nb = (size_t)std::max(S.nblocks, 1);
+    if ((rc = dev_alloc(s, &S.H, nb * kInnerNS))) return rc;
+    if ((rc = dev_alloc(s, &S.g, nb * kInnerMaxN))) return rc;
+    if ((rc = dev_alloc(s, &S.scale, nb * kInnerMaxN))) return rc;
+    if ((rc = dev_alloc(s, &S.st_d, nb * 8))) return rc;
+    if ((rc = dev_alloc(s, &S.st_i, nb * 8))) return rc;
+    S.active = I.d_active;
+  }
+  if ((rc = dev_alloc(s, &I.bak_ext, (size_t)6 * std::max(st.Nc, 1)))) return rc;
+  if ((rc = dev_alloc(s, &I.bak_intr, (size_t)std::max(s->n_intr, 1)))) return rc;
+  if ((rc = dev_alloc(s, &I.bak_pts, (size_t)4 * std::max(st.Np_pad, 1)))) return rc;
+  I.ready = true;
+  return TMI_BA_OK;
+}
+
+// Moves the candidate (ext_c, intr_c, pts_c) by one sweep; the values before the sweep stay
+// in the bak_* buffers.
+static int run_inner_sweep(tmi_ba_solver* s, const tmi_ba_options* O) {
+  int rc = ensure_inner(s);
+  if (rc) return rc;
+  tmi_ba_solver::InnerCtx& I = s->inner;
+  const Structure& st = s->st;
+  DeviceView& v = s->v;
+  hipStream_t stream = s->stream;
+  TMI_HIP(hipMemcpyAsync(I.bak_ext, v.ext_c, (size_t)6 * st.Nc * sizeof(double), hipMemcpyDeviceToDevice, stream));
+  if (s->n_intr) TMI_HIP(hipMemcpyAsync(I.bak_intr, v.intr_c, (size_t)s->n_intr * sizeof(double), hipMemcpyDeviceToDevice, stream));
+  TMI_HIP(hipMemcpyAsync(I.bak_pts, v.pts_c, (size_t)4 * st.Np_pad * sizeof(double), hipMemcpyDeviceToDevice, stream));
+  for (int kind = 1; kind >= 0; --kind) {  // intrinsics blocks, then extrinsics blocks
+    InnerSet S = I.set[kind];
+    if (S.nblocks == 0 || st.Nc == 0) continue;
+    S.x = kind == 0 ? v.ext_c : v.intr_c;
+    S.xc = I.xc[kind];
+    S.x0 = I.x0[kind];
+    S.loss_type = O->loss_function_type;
+    S.loss_width = O->robust_loss_width;
+    const size_t nx = kind == 0 ? (size_t)6 * st.Nc : (size_t)s->n_intr;
+    TMI_HIP(hipMemcpyAsync(I.x0[kind], S.x, nx * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    TMI_HIP(hipMemcpyAsync(I.xc[kind], S.x, nx * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    hipLaunchKernelGGL(inner_init_kernel, dim3((S.nblocks + 255) / 256), dim3(256), 0, stream, S);
+    // at most 50 steps per block + the re-linearisation round of the last accepted one
+    for (int round = 0; round < 52; ++round) {
+      Timed t(s, TMI_BA_K_LINEARIZE);
+      if (kind == 0) {
+        hipLaunchKernelGGL((inner_eval_kernel<0, true>), dim3(st.Nc), dim3(256), 0, stream, v, S);
+        hipLaunchKernelGGL(inner_step_kernel, dim3(S.nblocks), dim3(64), 0, stream, S);
+        hipLaunchKernelGGL((inner_eval_kernel<0, false>), dim3(st.Nc), dim3(256), 0, stream, v, S);
+      } else {
+        hipLaunchKernelGGL((inner_eval_kernel<1, true>), dim3(st.Nc), dim3(256), 0, stream, v, S);
+        hipLaunchKernelGGL(inner_step_kernel, dim3(S.nblocks), dim3(64), 0, stream, S);
+        hipLaunchKernelGGL((inner_eval_kernel<1, false>), dim3(st.Nc), dim3(256), 0, stream, v, S);
+      }
+      TMI_HIP(hipMemsetAsync(I.d_active, 0, sizeof(int), stream));
+      hipLaunchKernelGGL(inner_decide_kernel, dim3(S.nblocks), dim3(64), 0, stream, S);
+      TMI_HIP(hipMemcpyAsync(I.h_active, I.d_active, sizeof(int), hipMemcpyDeviceToHost, stream));
+      TMI_HIP(hipStreamSynchronize(stream));
+      if (*I.h_active == 0) break;
+    }
+  }
+  // the points, each against its (now constant) cameras: the batched single-track solver on
+  // the candidate arrays, Ceres' default minimizer options
+  if (st.nslices > 0) {
+    TrackLmArgs A;
+    A.loss_type = O->loss_function_type;
+    A.loss_width = O->robust_loss_width;
+    A.jacobi_scaling = 1;
+    A.max_num_iterations = 50;
+    A.max_num_consecutive_invalid_steps = 5;
+    A.function_tolerance = 1e-6;
+    A.gradient_tolerance = 1e-10;
+    A.parameter_tolerance = 1e-8;
+    A.initial_radius = 1e4;
+    A.max_radius = 1e16;
+    A.min_radius = 1e-32;
+    A.min_relative_decrease = 1e-3;
+    A.lm_lo = 1e-6;
+    A.lm_hi = 1e32;
+    if ((rc = ensure_track_outputs(s))) return rc;
+    DeviceView vc = v;
+    vc.ext = v.ext_c;
+    vc.intr = v.intr_c;
+    vc.pts = v.pts_c;
+    Timed t(s, TMI_BA_K_LINEARIZE);
+    if (s->DP == 3)
+      hipLaunchKernelGGL(track_lm_kernel<3>, dim3(s->nblocks_slices), dim3(256), 0, stream, vc, A, s->d_trk_term,
+                         s->d_trk_iter, s->d_trk_c0, s->d_trk_c1);
+    else
+      hipLaunchKernelGGL(track_lm_kernel<4>, dim3(s->nblocks_slices), dim3(256), 0, stream, vc, A, s->d_trk_term,
+                         s->d_trk_iter, s->d_trk_c0, s->d_trk_c1);
+  }
+  return TMI_BA_OK;
+}
+
 int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_summary* sum) {
   if (!s || !O || !sum) return TMI_BA_ERR_INVALID_ARGUMENT;
   memset(sum, 0, sizeof(*sum));
@@ -1039,6 +1239,8 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
   const char* why = "maximum number of iterations reached";
   int64_t pcg_iters = 0;
   bool need_gradient_check = true;  // after the first build and after every accepted step
+  // inner iterations need every observation of a view on this rank: single-rank solves only
+  bool inner_enabled = O->use_inner_iterations != 0 && st.world <= 1;
 
   for (;;) {
     if (iter >= O->max_num_iterations) break;
@@ -1133,6 +1335,42 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
       cand_invalid = hsc[5] > 0.0;
       if (!(model_cost_change > 0.0)) usable = 0;
     }
+    // DoInnerIterationsIfNeeded (Ceres trust_region_minimizer.cc): one coordinate-descent
+    // sweep from the trust-region candidate; its gain is credited to the model
+    bool inner_useful = false;
+    if (usable && inner_enabled && !cand_invalid) {
+      CK(run_inner_sweep(s, O));
+      {
+        Timed t(s, TMI_BA_K_UPDATE_COST);
+        CKH(hipMemsetAsync(v.flags + FL_INVALID, 0, sizeof(int), stream));
+        s->launch.cost(v, stream, v.ext_c, v.intr_c, v.pts_c, lt, lw, FL_INVALID, nbs, v.partial);
+        hipLaunchKernelGGL(reduce_sum_kernel, dim3(2), dim3(256), 0, stream, v.partial, nbs, d_sc + 3);
+        hipLaunchKernelGGL(flag_to_scalar_kernel, dim3(1), dim3(64), 0, stream, v.flags + FL_INVALID, d_sc + 5);
+        hipLaunchKernelGGL(diff_sq_kernel, dim3(1), dim3(1024), 0, stream, v.ext, v.ext_c, (long long)6 * st.Nc, v.scal + SC_II_DEXT);
+        hipLaunchKernelGGL(diff_sq_kernel, dim3(1), dim3(1024), 0, stream, v.intr, v.intr_c, (long long)s->n_intr, v.scal + SC_II_DINTR);
+        hipLaunchKernelGGL(points_diff_kernel, dim3(nbp), dim3(256), 0, stream, v, nbp, v.partial);
+        hipLaunchKernelGGL(reduce_sum_kernel, dim3(2), dim3(256), 0, stream, v.partial, nbp, v.scal + SC_II_DPTS);
+        hipLaunchKernelGGL(cameras_norm_kernel, dim3(1), dim3(1024), 0, stream, v, v.scal + SC_II_XC);
+      }
+      CK(readback(s));
+      const double inner_cost = s->h_red[3], inner_ss = s->h_red[4];
+      if (s->h_red[5] > 0.0) {
+        // "Inner iteration failed": the trust-region candidate stands
+        CKH(hipMemcpyAsync(v.ext_c, s->inner.bak_ext, (size_t)6 * st.Nc * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        if (s->n_intr) CKH(hipMemcpyAsync(v.intr_c, s->inner.bak_intr, (size_t)s->n_intr * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        CKH(hipMemcpyAsync(v.pts_c, s->inner.bak_pts, (size_t)4 * st.Np_pad * sizeof(double), hipMemcpyDeviceToDevice, stream));
+      } else {
+        model_cost_change += cand_cost - inner_cost;
+        inner_useful = inner_cost < cost;
+        inner_enabled = (1.0 - inner_cost / cand_cost) > 1e-3;  // inner_iteration_tolerance
+        cand_cost = inner_cost;
+        cand_ss = inner_ss;
+        step_sq = s->h_scal[SC_II_DEXT] + s->h_scal[SC_II_DINTR] + s->h_scal[SC_II_DPTS];
+        cand_xc_sq = s->h_scal[SC_II_XC];
+        cand_xp_sq = s->h_scal[SC_II_XP];
+        sum->num_inner_iteration_steps++;
+      }
+    }
     if (!usable) {
       // HandleInvalidStep
       sum->num_unsuccessful_steps++;
@@ -1165,7 +1403,7 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
       break;
     }
     const double relative_decrease = cost_change / model_cost_change;
-    if (relative_decrease > O->min_relative_decrease) {
+    if (inner_useful || relative_decrease > O->min_relative_decrease) {  // IsStepSuccessful
       std::swap(v.ext, v.ext_c);
       std::swap(v.intr, v.intr_c);
       std::swap(v.pts, v.pts_c);

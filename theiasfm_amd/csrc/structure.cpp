@@ -137,6 +137,10 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, 
       s.has_shared = true;
     }
   }
+  s.grp_free = grp_free;
+  if (s.Nc) s.cam_group.assign(P->camera_group, P->camera_group + s.Nc);
+  if (P->group_offset) s.group_offset.assign(P->group_offset, P->group_offset + s.G + 1);
+  else s.group_offset.assign(1, 0);
   s.cam_mask.assign(s.Nc, 0);
   s.cam_rb.assign(s.Nc, -1);
   s.cam_grb.assign(s.Nc, -1);

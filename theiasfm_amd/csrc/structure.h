@@ -53,6 +53,9 @@ struct Structure {
   std::vector<int> rb_dim;        // [Nrb] true (unpadded) dimension
   std::vector<int8_t> rb_cols;    // [Nrb*D] 0..5 extrinsics idx, 6+j intrinsics idx, -1 padding
   std::vector<uint32_t> cam_mask; // [Nc] bit c set = column c of [ext(6) | intr(10)] is free
+  std::vector<uint32_t> grp_free; // [G] free intrinsics bits of a group (shared or private)
+  std::vector<int> cam_group;     // [Nc] intrinsics group of a camera
+  std::vector<int> group_offset;  // [G+1] offsets into the intrinsics array
 
   // track-major (SELL-64) layout
   std::vector<int> pt_orig;       // [Np_pad] caller's track index or -1
