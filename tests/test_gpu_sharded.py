@@ -54,13 +54,15 @@ class EmulatedAllReduce:
                                               (abi.ITERATIVE_SCHUR, abi.SCHUR_IMPLICIT),
                                               (abi.ITERATIVE_SCHUR, abi.SCHUR_AUTO),
                                               (abi.DENSE_SCHUR, abi.SCHUR_AUTO)])
-def test_sharded_solve_matches_single_rank(world, solver_type, mode):
+@pytest.mark.parametrize("inner", [0, 1])
+def test_sharded_solve_matches_single_rank(world, solver_type, mode, inner):
     import torch
     torch.cuda.init()
     prob = synth.config("ladybug49")
-    # inner iterations need every observation of a view on one rank: plain LM on both sides
+    # inner = 1: the coordinate-descent sweep after each LM step; the per-view sums of its
+    # camera-side blocks are all-reduced, its point set is local to the owning rank
     opts = abi.default_options(linear_solver_type=solver_type, point_dof=3, schur_mode=mode,
-                               use_inner_iterations=0)
+                               use_inner_iterations=inner)
     single = prob.copy()
     st, s1 = lib.solve(single, opts)
     assert st == 0

@@ -155,11 +155,9 @@ enum {
   SC_BNORM = 15,
   SC_GMAX_P = 16,
   SC_RHO_BAD = 17,  // the next iteration's rho is zero or not finite
-  SC_II_DEXT = 18,  // inner iterations: |x - candidate|^2 over extrinsics / intrinsics / points,
+  SC_II_DEXT = 18,  // inner iterations: |x - candidate|^2 over extrinsics / intrinsics,
   SC_II_DINTR = 19,
-  SC_II_DPTS = 20,  //   (DPTS and XP are written as one pair)
-  SC_II_XP = 21,    //   |candidate|^2 over the live points / the non-constant camera blocks
-  SC_II_XC = 22,
+  SC_II_XC = 22,    //   |candidate|^2 over the non-constant camera blocks
   SC_COUNT = 32
 };
 // DeviceView::flags

@@ -932,9 +932,7 @@ static int ensure_inner(tmi_ba_solver* s) {
   if ((rc = dev_upload(s, &d_vo_e, vo_e))) return rc;
   if ((rc = dev_upload(s, &d_vo_lp, vo_lp))) return rc;
   double* d_part;
-  int* d_part_bad;
   if ((rc = dev_alloc(s, &d_part, (size_t)std::max(st.Nc, 1) * kInnerPart))) return rc;
-  if ((rc = dev_alloc(s, &d_part_bad, (size_t)std::max(st.Nc, 1)))) return rc;
   if ((rc = dev_alloc(s, &I.d_active, 1))) return rc;
   TMI_HIP(hipHostMalloc((void**)&I.h_active, sizeof(int), hipHostMallocDefault));
   for (int kind = 0; kind < 2; ++kind) {
@@ -994,7 +992,7 @@ static int ensure_inner(tmi_ba_solver* s) {
     const size_t nx = kind == 0 ? (size_t)6 * std::max(st.Nc, 1) : (size_t)std::max(s->n_intr, 1);
     if ((rc = dev_alloc(s, &I.x0[kind], nx))) return rc;
     if ((rc = dev_alloc(s, &I.xc[kind], nx))) return rc;
-    S.part = d_part; S.part_bad = d_part_bad;
+    S.part = d_part;
     const size_t nb = (size_t)std::max(S.nblocks, 1);
     if ((rc = dev_alloc(s, &S.H, nb * kInnerNS))) return rc;
     if ((rc = dev_alloc(s, &S.g, nb * kInnerMaxN))) return rc;
@@ -1036,16 +1034,28 @@ static int run_inner_sweep(tmi_ba_solver* s, const tmi_ba_options* O) {
     hipLaunchKernelGGL(inner_init_kernel, dim3((S.nblocks + 255) / 256), dim3(256), 0, stream, S);
     // at most 50 steps per block + the re-linearisation round of the last accepted one
     for (int round = 0; round < 52; ++round) {
-      Timed t(s, TMI_BA_K_LINEARIZE);
-      if (kind == 0) {
-        hipLaunchKernelGGL((inner_eval_kernel<0, true>), dim3(st.Nc), dim3(256), 0, stream, v, S);
-        hipLaunchKernelGGL(inner_step_kernel, dim3(S.nblocks), dim3(64), 0, stream, S);
-        hipLaunchKernelGGL((inner_eval_kernel<0, false>), dim3(st.Nc), dim3(256), 0, stream, v, S);
-      } else {
-        hipLaunchKernelGGL((inner_eval_kernel<1, true>), dim3(st.Nc), dim3(256), 0, stream, v, S);
-        hipLaunchKernelGGL(inner_step_kernel, dim3(S.nblocks), dim3(64), 0, stream, S);
-        hipLaunchKernelGGL((inner_eval_kernel<1, false>), dim3(st.Nc), dim3(256), 0, stream, v, S);
+      // a view's observations may be spread over the ranks: the per-view partials are summed
+      // across them after each evaluation pass; the per-block kernels then run replicated
+      const size_t part_bytes = (size_t)st.Nc * kInnerPart * sizeof(double);
+      {
+        Timed t(s, TMI_BA_K_LINEARIZE);
+        TMI_HIP(hipMemsetAsync(S.part, 0, part_bytes, stream));
+        if (kind == 0)
+          hipLaunchKernelGGL((inner_eval_kernel<0, true>), dim3(st.Nc), dim3(256), 0, stream, v, S);
+        else
+          hipLaunchKernelGGL((inner_eval_kernel<1, true>), dim3(st.Nc), dim3(256), 0, stream, v, S);
       }
+      if ((rc = do_allreduce(s, S.part, (int64_t)st.Nc * kInnerPart))) return rc;
+      {
+        Timed t(s, TMI_BA_K_LINEARIZE);
+        hipLaunchKernelGGL(inner_step_kernel, dim3(S.nblocks), dim3(64), 0, stream, S);
+        TMI_HIP(hipMemsetAsync(S.part, 0, part_bytes, stream));
+        if (kind == 0)
+          hipLaunchKernelGGL((inner_eval_kernel<0, false>), dim3(st.Nc), dim3(256), 0, stream, v, S);
+        else
+          hipLaunchKernelGGL((inner_eval_kernel<1, false>), dim3(st.Nc), dim3(256), 0, stream, v, S);
+      }
+      if ((rc = do_allreduce(s, S.part, (int64_t)st.Nc * kInnerPart))) return rc;
       TMI_HIP(hipMemsetAsync(I.d_active, 0, sizeof(int), stream));
       hipLaunchKernelGGL(inner_decide_kernel, dim3(S.nblocks), dim3(64), 0, stream, S);
       TMI_HIP(hipMemcpyAsync(I.h_active, I.d_active, sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -1239,8 +1249,7 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
   const char* why = "maximum number of iterations reached";
   int64_t pcg_iters = 0;
   bool need_gradient_check = true;  // after the first build and after every accepted step
-  // inner iterations need every observation of a view on this rank: single-rank solves only
-  bool inner_enabled = O->use_inner_iterations != 0 && st.world <= 1;
+  bool inner_enabled = O->use_inner_iterations != 0;
 
   for (;;) {
     if (iter >= O->max_num_iterations) break;
@@ -1348,10 +1357,13 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
         hipLaunchKernelGGL(flag_to_scalar_kernel, dim3(1), dim3(64), 0, stream, v.flags + FL_INVALID, d_sc + 5);
         hipLaunchKernelGGL(diff_sq_kernel, dim3(1), dim3(1024), 0, stream, v.ext, v.ext_c, (long long)6 * st.Nc, v.scal + SC_II_DEXT);
         hipLaunchKernelGGL(diff_sq_kernel, dim3(1), dim3(1024), 0, stream, v.intr, v.intr_c, (long long)s->n_intr, v.scal + SC_II_DINTR);
+        // per-track sums go where the trial step left its own: d_sc[1] = |step|^2 over the
+        // points, d_sc[2] = |x+|^2 over the points (summed over the ranks below)
         hipLaunchKernelGGL(points_diff_kernel, dim3(nbp), dim3(256), 0, stream, v, nbp, v.partial);
-        hipLaunchKernelGGL(reduce_sum_kernel, dim3(2), dim3(256), 0, stream, v.partial, nbp, v.scal + SC_II_DPTS);
+        hipLaunchKernelGGL(reduce_sum_kernel, dim3(2), dim3(256), 0, stream, v.partial, nbp, d_sc + 1);
         hipLaunchKernelGGL(cameras_norm_kernel, dim3(1), dim3(1024), 0, stream, v, v.scal + SC_II_XC);
       }
+      CK(do_allreduce(s, d_sc, 8));
       CK(readback(s));
       const double inner_cost = s->h_red[3], inner_ss = s->h_red[4];
       if (s->h_red[5] > 0.0) {
@@ -1365,9 +1377,9 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
         inner_enabled = (1.0 - inner_cost / cand_cost) > 1e-3;  // inner_iteration_tolerance
         cand_cost = inner_cost;
         cand_ss = inner_ss;
-        step_sq = s->h_scal[SC_II_DEXT] + s->h_scal[SC_II_DINTR] + s->h_scal[SC_II_DPTS];
+        step_sq = s->h_scal[SC_II_DEXT] + s->h_scal[SC_II_DINTR] + s->h_red[1];
         cand_xc_sq = s->h_scal[SC_II_XC];
-        cand_xp_sq = s->h_scal[SC_II_XP];
+        cand_xp_sq = s->h_red[2];
         sum->num_inner_iteration_steps++;
       }
     }

@@ -31,7 +31,7 @@ namespace tmi {
 
 constexpr int kInnerMaxN = 10;                                  // widest block (intrinsics)
 constexpr int kInnerNS = kInnerMaxN * (kInnerMaxN + 1) / 2;     // packed upper triangle
-constexpr int kInnerPart = 1 + kInnerMaxN + kInnerNS;           // per-view partial: cost, g, H
+constexpr int kInnerPart = 1 + kInnerMaxN + kInnerNS + 1;       // per-view partial: cost, g, H, invalid vote
 
 // everything one set (KIND 0 extrinsics, 1 intrinsics) needs, passed by value
 struct InnerSet {
@@ -54,8 +54,8 @@ struct InnerSet {
   double* xc;              // candidate of the sub-problems, same indexing
   const double* x0;        // value at the start of the set (restored when a block FAILS)
   // per-view partials and per-block state
-  double* part;            // [Nc][kInnerPart]
-  int* part_bad;           // [Nc] a residual of the view could not be evaluated
+  double* part;            // [Nc][kInnerPart]; the last slot counts residuals that could not be
+                           //   evaluated (a double so that the all-reduce can sum it)
   double* H;               // [nblocks][kInnerNS] unscaled J^T J
   double* g;               // [nblocks][kInnerMaxN] unscaled J^T r
   double* scale;           // [nblocks][kInnerMaxN]
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void inner_eval_kernel(DeviceView v, InnerSet 
     }
     out[dst] = t;
   }
-  if (threadIdx.x == 0) S.part_bad[cam] = shbad[0] | shbad[1] | shbad[2] | shbad[3];
+  if (threadIdx.x == 0) out[kInnerPart - 1] = (shbad[0] | shbad[1] | shbad[2] | shbad[3]) ? 1.0 : 0.0;
 }
 
 // ---- per-block helpers (lane 0 of the block's wave) --------------------------------------
@@ -241,9 +241,8 @@ __global__ __launch_bounds__(64) void inner_step_kernel(InnerSet S) {
       for (int q = S.blk_views_ptr[b]; q < S.blk_views_ptr[b + 1]; ++q) t += S.part[(size_t)S.blk_views[q] * kInnerPart + i];
       tot[i] = t;
     }
-    if (lane == 0)
-      for (int q = S.blk_views_ptr[b]; q < S.blk_views_ptr[b + 1]; ++q)
-        if (S.part_bad[S.blk_views[q]]) anybad = 1;
+    __syncthreads();
+    if (lane == 0 && tot[kInnerPart - 1] > 0.0) anybad = 1;
     __syncthreads();
   }
   if (lane != 0) return;
@@ -371,7 +370,7 @@ __global__ __launch_bounds__(64) void inner_decide_kernel(InnerSet S) {
   bool bad = false;
   for (int q = S.blk_views_ptr[b]; q < S.blk_views_ptr[b + 1]; ++q) {
     cand_cost += S.part[(size_t)S.blk_views[q] * kInnerPart];
-    bad = bad || S.part_bad[S.blk_views[q]];
+    bad = bad || S.part[(size_t)S.blk_views[q] * kInnerPart + kInnerPart - 1] > 0.0;
   }
   if (bad) cand_cost = 1.7976931348623157e308;
   const double cost = sd[ISD_COST];
@@ -415,10 +414,9 @@ __global__ void inner_init_kernel(InnerSet S) {
   sd[ISD_DF] = 2.0;
   si[ISI_NEED_LIN] = 1;
   si[ISI_FRESH] = 1;
-  // a block without observations takes no part
-  int nobs = 0;
-  for (int q = S.blk_views_ptr[b]; q < S.blk_views_ptr[b + 1]; ++q) nobs += S.vo_ptr[S.blk_views[q] + 1] - S.vo_ptr[S.blk_views[q]];
-  if (nobs == 0 || S.blk_n[b] == 0) si[ISI_DONE] = 1;
+  // (a block nobody observes has a zero gradient and stops at its first gradient test; the
+  // observation counts are per rank and cannot decide that here)
+  if (S.blk_n[b] == 0) si[ISI_DONE] = 1;
 }
 
 // |a - b|^2 over n doubles (one workgroup, fixed order): the step norm of an LM iteration that
