@@ -55,10 +55,18 @@ class EmulatedAllReduce:
                                               (abi.ITERATIVE_SCHUR, abi.SCHUR_AUTO),
                                               (abi.DENSE_SCHUR, abi.SCHUR_AUTO)])
 @pytest.mark.parametrize("inner", [0, 1])
-def test_sharded_solve_matches_single_rank(world, solver_type, mode, inner):
+@pytest.mark.parametrize("shared", [False, True])
+def test_sharded_solve_matches_single_rank(world, solver_type, mode, inner, shared):
     import torch
     torch.cuda.init()
-    prob = synth.config("ladybug49")
+    if shared:
+        # free intrinsics shared by groups of three views, mixed camera models (BASELINE config 5)
+        prob = synth.make_problem(18, 1200, 6000, seed=71, scene="ring", spread=0.4, shared_group_size=3,
+                                  models=[(abi.PINHOLE, 0.5), (abi.PINHOLE_RADIAL_TANGENTIAL, 0.25),
+                                          (abi.FISHEYE, 0.25)],
+                                  intrinsics_to_optimize=abi.INTRINSICS_FOCAL_LENGTH | abi.INTRINSICS_RADIAL_DISTORTION)
+    else:
+        prob = synth.config("ladybug49")
     # inner = 1: the coordinate-descent sweep after each LM step; the per-view sums of its
     # camera-side blocks are all-reduced, its point set is local to the owning rank
     opts = abi.default_options(linear_solver_type=solver_type, point_dof=3, schur_mode=mode,

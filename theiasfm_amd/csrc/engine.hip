@@ -133,9 +133,14 @@ Launch make_launch(bool fp32) {
   L.implicit_spmv = [](const DeviceView& v, hipStream_t st, RedLayout R, const double* x, double* y,
                        double* pm_u, double* cm_t, double ir, double lo, double hi, int add_diag, int nb) {
     if (!v.Nrb) return;
-    hipLaunchKernelGGL((implicit_tracks_kernel<D, DP>), dim3(nb), dim3(256), 0, st, v, x, pm_u, cm_t);
+    hipLaunchKernelGGL((implicit_tracks_kernel<D, DP, SH>), dim3(nb), dim3(256), 0, st, v, x, pm_u, cm_t);
+    // cam_part is free between two builds of the normal equations: the per-view partial
+    // products of the shared intrinsics blocks live in its head
     hipLaunchKernelGGL((implicit_cameras_kernel<D, DP, SH>), dim3(v.Nrb), dim3(64), 0, st, v, R, x, cm_t, y,
-                       ir, lo, hi, add_diag);
+                       ir, lo, hi, add_diag, v.cam_part);
+    if (SH && v.Nrb > v.Ncam_rb)
+      hipLaunchKernelGGL((implicit_groups_kernel<D>), dim3(v.Nrb - v.Ncam_rb), dim3(64), 0, st, v, R, x, v.cam_part,
+                         y, ir, lo, hi, add_diag);
   };
   L.pcg_a = [](const DeviceView& v, hipStream_t st, int n, int it) {
     hipLaunchKernelGGL((pcg_a_kernel<D>), dim3(1), dim3(1024), 0, st, v, n, it);
@@ -557,12 +562,6 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   s->implicit = iterative_type && (O->schur_mode == 2 || (O->schur_mode == 0 && world > 1));
   if (light) s->implicit = false;
   int rc = build_structure(P, rank, world, &s->st, !s->implicit && !light);
-  if (rc == TMI_BA_OK && s->implicit && s->st.has_shared) {
-    // shared intrinsics blocks are only wired into the explicit operator so far
-    s->implicit = false;
-    s->st = Structure();
-    rc = build_structure(P, rank, world, &s->st, true);
-  }
   if (rc) {
     s->error = s->st.error;
     return rc;

@@ -1092,7 +1092,7 @@ __global__ __launch_bounds__(256) void spmv_cols_kernel(DeviceView v, const doub
 // Every product streams the observations once (track-major planes) plus the camera-major
 // A records; with several GPUs only the reduced vector q is all-reduced.
 // ------------------------------------------------------------------------------
-template <int D, int DP>
+template <int D, int DP, bool SH>
 __global__ __launch_bounds__(256) void implicit_tracks_kernel(DeviceView v, const double* __restrict__ x,
                                                               double* __restrict__ pm_u,
                                                               double* __restrict__ cm_t) {
@@ -1110,7 +1110,8 @@ __global__ __launch_bounds__(256) void implicit_tracks_kernel(DeviceView v, cons
   for (int a = 0; a < DP; ++a) w[a] = 0.0;
   for (int j = tm.j0; j < k; j += tm.jstep) {
     const size_t e = base + (size_t)j * 64;
-    const int rb = v.cam_rb[v.obs_cam[e]];
+    const int cam = v.obs_cam[e];
+    const int rb = v.cam_rb[cam];
     double u0 = 0.0, u1 = 0.0;
     if (rb >= 0) {
       const double* xc = x + (size_t)rb * D;
@@ -1119,6 +1120,19 @@ __global__ __launch_bounds__(256) void implicit_tracks_kernel(DeviceView v, cons
         const double xa = xc[a];
         u0 += v.pm_A[(size_t)(2 * a) * N + e] * xa;
         u1 += v.pm_A[(size_t)(2 * a + 1) * N + e] * xa;
+      }
+    }
+    if (SH) {
+      // columns of the view's shared intrinsics block
+      const int grb = v.cam_grb[cam];
+      if (grb >= 0) {
+        const double* xg = x + (size_t)grb * D;
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+          const double xa = xg[a];
+          u0 += v.pm_A1[(size_t)(2 * a) * N + e] * xa;
+          u1 += v.pm_A1[(size_t)(2 * a + 1) * N + e] * xa;
+        }
       }
     }
     pm_u[e] = u0;
@@ -1158,17 +1172,33 @@ __global__ __launch_bounds__(64) void implicit_cameras_kernel(DeviceView v, RedL
                                                               const double* __restrict__ x,
                                                               const double* __restrict__ cm_t,
                                                               double* __restrict__ y, double inv_radius,
-                                                              double lm_lo, double lm_hi, int add_diag) {
+                                                              double lm_lo, double lm_hi, int add_diag,
+                                                              double* __restrict__ grp_part) {
   constexpr int AS = as_of(D, SH);
   const int rb = blockIdx.x;
-  double acc[D];
+  if (SH && rb >= v.Ncam_rb) return;  // shared blocks: implicit_groups_kernel
+  double acc[D], acc1[SH ? D : 1];
 #pragma unroll
   for (int a = 0; a < D; ++a) acc[a] = 0.0;
+#pragma unroll
+  for (int a = 0; a < (SH ? D : 1); ++a) acc1[a] = 0.0;
   for (int s = v.cam_ptr[rb] + threadIdx.x; s < v.cam_ptr[rb + 1]; s += 64) {
     const double* arec = v.cm_A + (size_t)s * AS;
     const double2 t = *reinterpret_cast<const double2*>(cm_t + (size_t)s * 2);
 #pragma unroll
     for (int a = 0; a < D; ++a) acc[a] += arec[a] * t.x + arec[D + a] * t.y;
+    if (SH) {
+      // the view's rows of the shared intrinsics block ride in the same record
+#pragma unroll
+      for (int a = 0; a < D; ++a) acc1[a] += arec[2 * D + 4 + a] * t.x + arec[3 * D + 4 + a] * t.y;
+    }
+  }
+  if (SH) {
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      const double tot1 = wave_sum(acc1[a]);
+      if (threadIdx.x == 0) grp_part[(size_t)rb * D + a] = tot1;
+    }
   }
 #pragma unroll
   for (int a = 0; a < D; ++a) {
@@ -1190,6 +1220,34 @@ __global__ __launch_bounds__(64) void implicit_cameras_kernel(DeviceView v, RedL
       y[(size_t)rb * D + a] = tot;
     }
   }
+}
+
+// shared intrinsics blocks of the implicit product: sum of the per-view partials in the
+// block's view order (fixed), plus the damping on rank 0
+template <int D>
+__global__ __launch_bounds__(64) void implicit_groups_kernel(DeviceView v, RedLayout L,
+                                                             const double* __restrict__ x,
+                                                             const double* __restrict__ grp_part,
+                                                             double* __restrict__ y, double inv_radius,
+                                                             double lm_lo, double lm_hi, int add_diag) {
+  const int gi = blockIdx.x;
+  const int grb = v.Ncam_rb + gi;
+  const int a = threadIdx.x;
+  if (a >= D) return;
+  double tot = 0.0;
+  for (int k = v.grp_cam_ptr[gi]; k < v.grp_cam_ptr[gi + 1]; ++k) tot += grp_part[(size_t)v.cam_rb[v.grp_cams[k]] * D + a];
+  if (add_diag) {
+    const double xa = x[(size_t)grb * D + a];
+    if (v.rb_cols[(size_t)grb * D + a] < 0) {
+      tot = xa;
+    } else {
+      const double d = v.red[L.udiag + (size_t)grb * D + a];
+      tot += fmin(fmax(d, lm_lo), lm_hi) * inv_radius * xa;
+    }
+  } else if (v.rb_cols[(size_t)grb * D + a] < 0) {
+    tot = 0.0;
+  }
+  y[(size_t)grb * D + a] = tot;
 }
 
 // ------------------------------------------------------------------------------
