@@ -406,3 +406,78 @@ def test_matrix_free_operator_with_shared_intrinsics(dof, share):
     assert st == 0 and s_e.num_schur_pairs > 0
     assert abs(s_e.final_cost - dev_i[1].final_cost) <= tol * s_e.final_cost
     assert s_e.num_linear_solver_iterations == dev_i[1].num_linear_solver_iterations
+
+
+def _subset(prob, keep_obs):
+    q = prob.copy()
+    q.obs_camera, q.obs_point, q.obs_xy = prob.obs_camera[keep_obs], prob.obs_point[keep_obs], prob.obs_xy[keep_obs]
+    return q
+
+
+@pytest.mark.parametrize("case", ["no_observations", "everything_constant", "one_view_free", "one_track_free",
+                                  "unobserved_view_and_single_view_tracks", "n_tracks_63", "n_tracks_64",
+                                  "n_tracks_65", "one_camera"])
+def test_edge_cases_match_oracle(case):
+    """Degenerate and boundary shapes (the reference's BundleAdjustView / BundleAdjustTrack problem
+    shapes, empty and ragged inputs, slice-boundary track counts): same status, same summary, same
+    parameters as the oracle."""
+    base = synth.make_problem(7, 130, 620, seed=91, scene="ring", spread=0.6)
+    opt = dict(linear_solver_type=abi.DENSE_SCHUR, point_dof=3, max_num_iterations=15)
+    prob = base
+    if case == "no_observations":
+        prob = _subset(base, np.zeros(base.num_observations, bool))
+    elif case == "everything_constant":
+        prob = base.copy()
+        prob.camera_flags[:] = abi.CAMERA_POSITION_CONSTANT | abi.CAMERA_ORIENTATION_CONSTANT
+        prob.intrinsics_constant[:] = 1
+        prob.point_constant[:] = 1
+    elif case == "one_view_free":  # BundleAdjustView (bundle_adjustment.cc:82-93)
+        prob = base.copy()
+        prob.camera_flags[:] = abi.CAMERA_POSITION_CONSTANT | abi.CAMERA_ORIENTATION_CONSTANT
+        prob.camera_flags[3] = 0
+        prob.point_constant[:] = 1
+        free_group = prob.camera_group[3]
+        for g in range(prob.num_groups):
+            if g != free_group:
+                prob.intrinsics_constant[prob.group_offset[g]:prob.group_offset[g + 1]] = 1
+        opt["linear_solver_type"] = abi.DENSE_QR
+    elif case == "one_track_free":  # BundleAdjustTrack (bundle_adjustment.cc:96-107)
+        prob = base.copy()
+        prob.camera_flags[:] = abi.CAMERA_POSITION_CONSTANT | abi.CAMERA_ORIENTATION_CONSTANT
+        prob.intrinsics_constant[:] = 1
+        prob.point_constant[:] = 1
+        prob.point_constant[17] = 0
+        opt["linear_solver_type"] = abi.DENSE_QR
+    elif case == "unobserved_view_and_single_view_tracks":
+        keep = base.obs_camera != 2                       # view 2 observes nothing
+        for t in range(0, 20):                            # tracks 0..19 keep one observation each
+            idx = np.flatnonzero((base.obs_point == t) & keep)
+            keep[idx[1:]] = False
+        prob = _subset(base, keep)
+    elif case.startswith("n_tracks_"):
+        n = int(case.split("_")[-1])
+        prob = _subset(base, base.obs_point < n)
+        prob.points = prob.points[:n].copy()
+        prob.point_constant = prob.point_constant[:n].copy()
+    elif case == "one_camera":
+        keep = base.obs_camera == 0
+        prob = _subset(base, keep)
+        prob.extrinsics = base.extrinsics[:1].copy()
+        prob.camera_group = np.zeros(1, np.int32)
+        prob.camera_flags = base.camera_flags[:1].copy()
+        g = int(base.camera_group[0])
+        prob.group_model = base.group_model[g:g + 1].copy()
+        prob.intrinsics = base.intrinsics[base.group_offset[g]:base.group_offset[g + 1]].copy()
+        prob.intrinsics_constant = base.intrinsics_constant[base.group_offset[g]:base.group_offset[g + 1]].copy()
+        prob.group_offset = np.array([0, len(prob.intrinsics)], np.int32)
+    dev, ora = run_both(prob, **opt)
+    (st_d, s_d, a), (st_o, s_o, b) = dev, ora
+    assert st_d == st_o, (st_d, s_d.message, st_o, s_o.message)
+    assert s_d.success == s_o.success and s_d.termination == s_o.termination
+    assert s_d.num_iterations == s_o.num_iterations
+    assert abs(s_d.initial_cost - s_o.initial_cost) <= 1e-12 * max(s_o.initial_cost, 1e-300)
+    # (a cost driven to the round-off floor -- one camera, free points -- has no meaningful digits)
+    assert abs(s_d.final_cost - s_o.final_cost) <= 1e-9 * max(s_o.final_cost, 1e-9 * s_o.initial_cost, 1e-12)
+    assert np.abs(a.extrinsics - b.extrinsics).max(initial=0.0) <= 1e-6
+    assert np.abs(a.points - b.points).max(initial=0.0) <= 1e-6
+    assert np.abs(a.intrinsics - b.intrinsics).max(initial=0.0) <= 1e-6 * max(1.0, np.abs(b.intrinsics).max(initial=0.0))
