@@ -246,6 +246,22 @@ def main():
         kernels_note="per-class table: separate untimed pass of the same iterations with every class timed")
     if steps_run != args.steps:
         out["note"] = f"solver stopped after {steps_run} of {args.steps} iterations: {d['message']}"
+    # Whole-iteration figure of SURVEY 8(d): B_iter = B_lin + B_schur + B_pcg + B_back + B_cost with the
+    # measured block count and PCG iterations (intermediates -- Jacobians, Y -- are not algorithmic)
+    sym = lambda n: n * (n + 1) // 2  # noqa: E731
+    n_pcg = int(s.num_linear_solver_iterations) / max(steps_run, 1)
+    b_lin = n_obs * 24 + n_cam * 8 * dc + n_pts * 8 * dp + n_cam * 8 * (sym(dc) + dc) + n_pts * 8 * (sym(dp) + dp)
+    b_schur = 2 * nnzb * 8 * dc * dc
+    b_pcg = n_pcg * (nnzb * 8 * dc * dc + 6 * n_cam * 8 * dc)
+    b_back = n_obs * 24 + n_cam * 8 * dc + n_pts * 8 * (sym(dp) + 2 * dp)
+    b_cost = n_obs * 24 + n_cam * 8 * dc + n_pts * 8 * dp
+    b_iter = b_lin + b_schur + b_pcg + b_back + b_cost
+    out["iteration_roofline"] = dict(
+        algorithmic_bytes_per_lm_iteration=int(b_iter), pcg_iterations_per_lm_iteration=round(n_pcg, 2),
+        achieved_GBs=round(b_iter * steps_run / elapsed / 1e9, 1), peak_GBs=HBM_PEAK_GBS * world,
+        frac=round(b_iter * steps_run / elapsed / 1e9 / (HBM_PEAK_GBS * world), 5),
+        note="SURVEY 8(d) formula; the kernels move ~19 GB per iteration (profiles/), ~4x these bytes, because "
+             "Jacobian blocks and the per-observation Schur factors are stored and gathered rather than recomputed")
 
     if world == 1 and not args.no_cpu_baseline:
         # CPU baseline: the in-repo oracle (Ceres-semantics restatement; the real

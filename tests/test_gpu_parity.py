@@ -481,3 +481,42 @@ def test_edge_cases_match_oracle(case):
     assert np.abs(a.extrinsics - b.extrinsics).max(initial=0.0) <= 1e-6
     assert np.abs(a.points - b.points).max(initial=0.0) <= 1e-6
     assert np.abs(a.intrinsics - b.intrinsics).max(initial=0.0) <= 1e-6 * max(1.0, np.abs(b.intrinsics).max(initial=0.0))
+
+
+def test_alamo_sized_1dsfm_flag_variant():
+    """Config 3 with the options of the reference's 1DSfM flag file
+    (applications/build_1dsfm_reconstruction_flags.txt:66-76: HUBER, width 10, intrinsics constant),
+    exact linear solver (SPARSE_SCHUR for < 1000 views, reconstruction_estimator_utils.cc:121-130).
+    Full-size properties: the robust cost decreases, the CPU re-evaluation of the result agrees with
+    the device's summary, intrinsics stay put, a second run is bit-identical."""
+    prob = synth.config("alamo")
+    prob.set_intrinsics_to_optimize(abi.INTRINSICS_NONE)
+    rng = np.random.default_rng(3)
+    prob.obs_xy[rng.random(prob.num_observations) < 0.01] += 60.0  # gross outliers for the loss to bite
+    o = abi.default_options(linear_solver_type=abi.SPARSE_SCHUR, point_dof=3, max_num_iterations=10,
+                            loss_function_type=abi.LOSS_HUBER, robust_loss_width=10.0)
+    p = prob.copy()
+    st, s = lib.solve(p, o)
+    assert st == 0 and s.success == 1 and s.reduced_block_dim == 6
+    assert s.final_cost < 0.5 * s.initial_cost  # 1 % gross outliers keep their Huber cost
+    c0, _, _ = oracle.cost(prob, o)
+    c1, rmse1, bad = oracle.cost(p, o)
+    assert bad == 0
+    assert abs(c0 - s.initial_cost) < 1e-10 * c0 and abs(c1 - s.final_cost) < 1e-10 * c1
+    assert abs(rmse1 - s.final_rmse) < 1e-10
+    assert (p.intrinsics == prob.intrinsics).all()
+    q = prob.copy()
+    st2, s2 = lib.solve(q, o)
+    assert s2.final_cost == s.final_cost and (q.extrinsics == p.extrinsics).all()
+
+
+@pytest.mark.parametrize("solver,mode", [(abi.DENSE_SCHUR, abi.SCHUR_AUTO), (abi.ITERATIVE_SCHUR, abi.SCHUR_IMPLICIT)])
+def test_very_long_tracks(solver, mode):
+    """Every view sees every track (the reference's own synthetic recipe, config 1 scaled up): 150
+    observations per track -- ten trips of the 16-lanes-per-track mapping, 11 175 Schur pairs per
+    track, a dense reduced camera matrix."""
+    prob = synth.make_problem(150, 96, 150 * 96, seed=7, scene="allsee")
+    dev, ora = run_both(prob, linear_solver_type=solver, schur_mode=mode, point_dof=3, max_num_iterations=8,
+                        use_inner_iterations=0)
+    assert_same_solution(dev, ora, scale=30.0)
+    assert dev[1].num_schur_blocks == 150 * 151 // 2 or mode == abi.SCHUR_IMPLICIT
