@@ -183,7 +183,8 @@ typedef struct tmi_ba_options {
                                         every trust-region step one coordinate-descent sweep
                                         over intrinsics blocks, extrinsics blocks, points
                                         (Ceres inner iterations), until their relative gain
-                                        drops below 1e-3                         */
+                                        drops below 1e-3; evaluated in fp64 whatever
+                                        residual_precision says                  */
   double function_tolerance;         /* 1e-6                                  */
   double gradient_tolerance;         /* 1e-10                                 */
   double parameter_tolerance;        /* 1e-8                                  */

@@ -83,3 +83,34 @@ def test_invalid_start_point_fails_without_touching_inputs():
     st, s = oracle.solve(prob, abi.default_options())
     assert st == 6 and s.success == 0
     assert (prob.points == before.points).all()
+
+
+def test_inner_iterations_config1_on_and_off():
+    """SURVEY 8(d) config 1 with use_inner_iterations on and off.  The coordinate-descent sweep after
+    each trust-region step can only lower the candidate's cost: after the same number of LM
+    iterations the run with inner iterations is at least as low, the sweeps are counted, and they
+    stop once their relative gain drops below 1e-3 (Ceres inner_iteration_tolerance)."""
+    prob = synth.config("tiny")
+    res = {}
+    for inner in (0, 1):
+        p = prob.copy()
+        o = abi.default_options(point_dof=4, linear_solver_type=abi.DENSE_SCHUR, use_inner_iterations=inner,
+                                max_num_iterations=3, function_tolerance=0.0, parameter_tolerance=0.0,
+                                gradient_tolerance=0.0)
+        st, s = oracle.solve(p, o)
+        assert st == 0 and s.success == 1
+        res[inner] = s
+    assert res[0].num_inner_iteration_steps == 0
+    assert 1 <= res[1].num_inner_iteration_steps <= 3
+    assert res[1].final_cost <= res[0].final_cost * (1 + 1e-12)
+    # run on: both settle in the same valley (all three cameras are free, so the problem keeps its
+    # 7 gauge directions and the cost creeps for a long time: agreement to 1e-3, not to round-off)
+    fin = {}
+    for inner in (0, 1):
+        p = prob.copy()
+        st, s = oracle.solve(p, abi.default_options(point_dof=3, linear_solver_type=abi.DENSE_SCHUR,
+                                                    use_inner_iterations=inner, max_num_iterations=50,
+                                                    function_tolerance=1e-12))
+        fin[inner] = s
+    assert abs(fin[1].final_cost - fin[0].final_cost) <= 1e-3 * fin[0].final_cost
+    assert fin[1].num_inner_iteration_steps < fin[1].num_iterations  # switched off before the end
