@@ -11,15 +11,16 @@
 namespace theia {
 class Reconstruction;
 
-// Removes features that have a reprojection error larger than the reprojection error
-// threshold. Additionally, any features that are poorly constrained because of a small
-// viewing angle are removed. Returns the number of features removed (-1 if the device path
-// failed; the reference cannot fail). Only the input tracks are checked.
+// Post-BA clean-up.  A track of `tracks` loses its estimated flag when (a) one of its views sees
+// the point behind the camera, (b) its mean squared reprojection error over the estimated views
+// exceeds max_inlier_reprojection_error^2, or (c) no two viewing rays are at least
+// min_triangulation_angle_degrees apart.  The return value counts the tracks dropped by (a)-(c)
+// (-1 if the device path failed; the reference cannot fail).
 int SetOutlierTracksToUnestimated(const std::unordered_set<TrackId>& tracks,
                                   const double max_inlier_reprojection_error,
                                   const double min_triangulation_angle_degrees,
                                   Reconstruction* reconstruction);
-// Same as above, but checks all tracks.
+// The same over every track of the reconstruction.
 int SetOutlierTracksToUnestimated(const double max_inlier_reprojection_error,
                                   const double min_triangulation_angle_degrees,
                                   Reconstruction* reconstruction);
