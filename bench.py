@@ -87,7 +87,10 @@ def main():
                     choices=["tiny", "ladybug49", "alamo", "venice1778"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=2)
-    ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"])
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "torch", "staged"],
+                    help="rccl: ncclAllReduce issued by the engine; torch: torch.distributed (nccl) hook; staged: "
+                         "gloo through host memory with every rank on GPU 0 -- a functional check of the "
+                         "multi-process path on a single-GPU box, not a measurement")
     ap.add_argument("--residual-precision", type=int, default=64, choices=[64, 32],
                     help="32 = evaluate residuals/Jacobians in fp32, accumulate in fp64 (config 5)")
     ap.add_argument("--schur-mode", default="auto", choices=["auto", "explicit", "implicit"],
@@ -102,7 +105,9 @@ def main():
     from theiasfm_amd import abi, dist, lib, synth
     import __graft_entry__ as entry
 
-    rank, world, local = dist.init_from_env()
+    rank, world, local = dist.init_from_env(backend="gloo" if args.transport == "staged" else None)
+    if args.transport == "staged":
+        local = 0
     if world != args.gpus:
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with "
@@ -143,7 +148,10 @@ def main():
     if world > 1:
         # RCCL over xGMI: natively from the engine (ncclAllReduce on its own stream); the
         # torch.distributed hook is the fallback (and --transport torch forces it)
-        if args.transport == "rccl" and dist.init_native_rccl(solver, rank, world):
+        if args.transport == "staged":
+            solver.set_allreduce(dist.make_staged_allreduce())
+            transport = "gloo, staged through host memory (functional check only)"
+        elif args.transport == "rccl" and dist.init_native_rccl(solver, rank, world):
             transport = "rccl (native, ncclAllReduce from the engine)"
         else:
             solver.set_allreduce(dist.make_device_allreduce())
@@ -185,7 +193,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         torch.distributed.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.transport == "staged" else "cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     if st != 0:
