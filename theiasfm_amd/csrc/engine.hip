@@ -1870,24 +1870,26 @@ int32_t tmi_ba_solver_evaluate(tmi_ba_solver* s, double* residuals, double* jac_
   for (size_t e = 0; e < N; ++e) {
     const int64_t i = st.obs_orig[e];
     if (i < 0) continue;
+    // the planes are tiled by 64 observations (kernels.h pidx)
+    auto at = [e](int npl, int plane) { return (e >> 6) * (size_t)(npl * 64) + (size_t)plane * 64 + (e & 63); };
     if (residuals) {
-      residuals[2 * i] = r[e];
-      residuals[2 * i + 1] = r[N + e];
+      residuals[2 * i] = r[at(2, 0)];
+      residuals[2 * i + 1] = r[at(2, 1)];
     }
     if (jac_camera)
       for (int a = 0; a < D; ++a) {
-        jac_camera[(size_t)2 * D * i + a] = A[(size_t)(2 * a) * N + e];
-        jac_camera[(size_t)2 * D * i + D + a] = A[(size_t)(2 * a + 1) * N + e];
+        jac_camera[(size_t)2 * D * i + a] = A[at(2 * D, 2 * a)];
+        jac_camera[(size_t)2 * D * i + D + a] = A[at(2 * D, 2 * a + 1)];
       }
     if (jac_shared)
       for (int a = 0; a < D; ++a) {
-        jac_shared[(size_t)2 * D * i + a] = A1.empty() ? 0.0 : A1[(size_t)(2 * a) * N + e];
-        jac_shared[(size_t)2 * D * i + D + a] = A1.empty() ? 0.0 : A1[(size_t)(2 * a + 1) * N + e];
+        jac_shared[(size_t)2 * D * i + a] = A1.empty() ? 0.0 : A1[at(2 * D, 2 * a)];
+        jac_shared[(size_t)2 * D * i + D + a] = A1.empty() ? 0.0 : A1[at(2 * D, 2 * a + 1)];
       }
     if (jac_point)
       for (int a = 0; a < DP; ++a) {
-        jac_point[(size_t)2 * DP * i + a] = Jp[(size_t)(2 * a) * N + e];
-        jac_point[(size_t)2 * DP * i + DP + a] = Jp[(size_t)(2 * a + 1) * N + e];
+        jac_point[(size_t)2 * DP * i + a] = Jp[at(2 * DP, 2 * a)];
+        jac_point[(size_t)2 * DP * i + DP + a] = Jp[at(2 * DP, 2 * a + 1)];
       }
     if (valid) valid[i] = 1;
   }

@@ -29,6 +29,15 @@ __host__ __device__ constexpr int sym_idx(int a, int b, int n) {
   return a * n - a * (a - 1) / 2 + (b - a);
 }
 __host__ __device__ constexpr int sym_size(int n) { return n * (n + 1) / 2; }
+// Per-observation planes are stored in TILES of 64 observations: element (plane, e) of an
+// NPL-plane buffer lives at (e / 64) * NPL * 64 + plane * 64 + e % 64.  A wave working on 64
+// consecutive observations then reads / writes ONE contiguous NPL * 512-byte region per buffer
+// instead of NPL regions No_pad * 8 bytes apart: `linearize` used to keep 26 write streams open
+// per wave and spent 63 % of its wave cycles in s_waitcnt at 2.3 TB/s of stores.
+template <int NPL>
+__host__ __device__ __forceinline__ size_t pidx(int plane, size_t e) {
+  return (e >> 6) * (size_t)(NPL * 64) + (size_t)plane * 64 + (e & 63);
+}
 // camera-major record strides in doubles, rounded up to whole 64-byte sectors so that a
 // record never straddles an extra sector (gathers) and is written as full sectors
 __host__ __device__ constexpr int ys_of(int D, int DP) { return (D * DP + 7) & ~7; }
@@ -222,12 +231,12 @@ __global__ __launch_bounds__(256) void linearize_kernel(DeviceView v, int loss_t
       const int rb = v.cam_rb[cam];
       if (!ok) {
         v.flags[FL_INVALID] = 1;
-        for (int d = 0; d < 2 * D; ++d) v.pm_A[(size_t)d * N + e] = 0.0;
+        for (int d = 0; d < 2 * D; ++d) v.pm_A[pidx<2 * D>(d, e)] = 0.0;
         if (SH)
-          for (int d = 0; d < 2 * D; ++d) v.pm_A1[(size_t)d * N + e] = 0.0;
-        for (int d = 0; d < 2 * DP; ++d) v.pm_Jp[(size_t)d * N + e] = 0.0;
-        v.pm_r[e] = 0.0;
-        v.pm_r[N + e] = 0.0;
+          for (int d = 0; d < 2 * D; ++d) v.pm_A1[pidx<2 * D>(d, e)] = 0.0;
+        for (int d = 0; d < 2 * DP; ++d) v.pm_Jp[pidx<2 * DP>(d, e)] = 0.0;
+        v.pm_r[pidx<2>(0, e)] = 0.0;
+        v.pm_r[pidx<2>(1, e)] = 0.0;
         continue;
       }
       const double sq = r[0] * r[0] + r[1] * r[1];
@@ -262,12 +271,12 @@ __global__ __launch_bounds__(256) void linearize_kernel(DeviceView v, int loss_t
             j1 = sqrt_rho1 * (j1 - asn * r[1] * rtj);
           }
           const double scl = sc[dst];
-          v.pm_A[(size_t)(2 * dst) * N + e] = j0 * scl;
-          v.pm_A[(size_t)(2 * dst + 1) * N + e] = j1 * scl;
+          v.pm_A[pidx<2 * D>((2 * dst), e)] = j0 * scl;
+          v.pm_A[pidx<2 * D>((2 * dst + 1), e)] = j1 * scl;
           ++dst;
         }
       }
-      for (int d = 2 * dst; d < 2 * D; ++d) v.pm_A[(size_t)d * N + e] = 0.0;
+      for (int d = 2 * dst; d < 2 * D; ++d) v.pm_A[pidx<2 * D>(d, e)] = 0.0;
       if (SH) {
         // free intrinsics shared between views: their columns go to the group's own block
         const int grb = v.cam_grb[cam];
@@ -285,13 +294,13 @@ __global__ __launch_bounds__(256) void linearize_kernel(DeviceView v, int loss_t
                 j1 = sqrt_rho1 * (j1 - asn * r[1] * rtj);
               }
               const double scl = sc1[dst1];
-              v.pm_A1[(size_t)(2 * dst1) * N + e] = j0 * scl;
-              v.pm_A1[(size_t)(2 * dst1 + 1) * N + e] = j1 * scl;
+              v.pm_A1[pidx<2 * D>((2 * dst1), e)] = j0 * scl;
+              v.pm_A1[pidx<2 * D>((2 * dst1 + 1), e)] = j1 * scl;
               ++dst1;
             }
           }
         }
-        for (int d = 2 * dst1; d < 2 * D; ++d) v.pm_A1[(size_t)d * N + e] = 0.0;
+        for (int d = 2 * dst1; d < 2 * D; ++d) v.pm_A1[pidx<2 * D>(d, e)] = 0.0;
       }
 #pragma unroll
       for (int a = 0; a < DP; ++a) {
@@ -301,11 +310,11 @@ __global__ __launch_bounds__(256) void linearize_kernel(DeviceView v, int loss_t
           j0 = sqrt_rho1 * (j0 - asn * r[0] * rtj);
           j1 = sqrt_rho1 * (j1 - asn * r[1] * rtj);
         }
-        v.pm_Jp[(size_t)(2 * a) * N + e] = j0 * sp[a];
-        v.pm_Jp[(size_t)(2 * a + 1) * N + e] = j1 * sp[a];
+        v.pm_Jp[pidx<2 * DP>((2 * a), e)] = j0 * sp[a];
+        v.pm_Jp[pidx<2 * DP>((2 * a + 1), e)] = j1 * sp[a];
       }
-      v.pm_r[e] = r[0] * rscale;
-      v.pm_r[N + e] = r[1] * rscale;
+      v.pm_r[pidx<2>(0, e)] = r[0] * rscale;
+      v.pm_r[pidx<2>(1, e)] = r[1] * rscale;
     }
   }
   block_sum_store<2>(acc, v.partial, nblocks);
@@ -381,7 +390,7 @@ __global__ __launch_bounds__(256) void point_scale_kernel(DeviceView v) {
     const size_t e = base + (size_t)j * 64;
 #pragma unroll
     for (int a = 0; a < DP; ++a) {
-      const double j0 = v.pm_Jp[(size_t)(2 * a) * N + e], j1 = v.pm_Jp[(size_t)(2 * a + 1) * N + e];
+      const double j0 = v.pm_Jp[pidx<2 * DP>((2 * a), e)], j1 = v.pm_Jp[pidx<2 * DP>((2 * a + 1), e)];
       n2[a] += j0 * j0 + j1 * j1;
     }
   }
@@ -439,10 +448,10 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
         double J0[DP], J1[DP];
 #pragma unroll
         for (int a = 0; a < DP; ++a) {
-          J0[a] = v.pm_Jp[(size_t)(2 * a) * N + e];
-          J1[a] = v.pm_Jp[(size_t)(2 * a + 1) * N + e];
+          J0[a] = v.pm_Jp[pidx<2 * DP>((2 * a), e)];
+          J1[a] = v.pm_Jp[pidx<2 * DP>((2 * a + 1), e)];
         }
-        const double r0 = v.pm_r[e], r1 = v.pm_r[N + e];
+        const double r0 = v.pm_r[pidx<2>(0, e)], r1 = v.pm_r[pidx<2>(1, e)];
 #pragma unroll
         for (int a = 0; a < DP; ++a) {
 #pragma unroll
@@ -557,10 +566,10 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
         double J0[DP], J1[DP], Q0[DP], Q1[DP];
 #pragma unroll
         for (int a = 0; a < DP; ++a) {
-          J0[a] = v.pm_Jp[(size_t)(2 * a) * N + e];
-          J1[a] = v.pm_Jp[(size_t)(2 * a + 1) * N + e];
+          J0[a] = v.pm_Jp[pidx<2 * DP>((2 * a), e)];
+          J1[a] = v.pm_Jp[pidx<2 * DP>((2 * a + 1), e)];
         }
-        const double r0 = v.pm_r[e], r1 = v.pm_r[N + e];
+        const double r0 = v.pm_r[pidx<2>(0, e)], r1 = v.pm_r[pidx<2>(1, e)];
         double rt0 = r0, rt1 = r1;
 #pragma unroll
         for (int a = 0; a < DP; ++a) {
@@ -581,7 +590,7 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
         }
 #pragma unroll
         for (int a = 0; a < D; ++a) {
-          const double a0 = v.pm_A[(size_t)(2 * a) * N + e], a1 = v.pm_A[(size_t)(2 * a + 1) * N + e];
+          const double a0 = v.pm_A[pidx<2 * D>((2 * a), e)], a1 = v.pm_A[pidx<2 * D>((2 * a + 1), e)];
           Av[a] = a0;
           Av[D + a] = a1;
 #pragma unroll
@@ -604,8 +613,8 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
           for (int a = 0; a < D; ++a) {
             double a0 = 0.0, a1 = 0.0;
             if (gslot >= 0) {
-              a0 = v.pm_A1[(size_t)(2 * a) * N + e];
-              a1 = v.pm_A1[(size_t)(2 * a + 1) * N + e];
+              a0 = v.pm_A1[pidx<2 * D>((2 * a), e)];
+              a1 = v.pm_A1[pidx<2 * D>((2 * a + 1), e)];
             }
             Av[2 * D + 4 + a] = a0;
             Av[3 * D + 4 + a] = a1;
@@ -1118,8 +1127,8 @@ __global__ __launch_bounds__(256) void implicit_tracks_kernel(DeviceView v, cons
 #pragma unroll
       for (int a = 0; a < D; ++a) {
         const double xa = xc[a];
-        u0 += v.pm_A[(size_t)(2 * a) * N + e] * xa;
-        u1 += v.pm_A[(size_t)(2 * a + 1) * N + e] * xa;
+        u0 += v.pm_A[pidx<2 * D>((2 * a), e)] * xa;
+        u1 += v.pm_A[pidx<2 * D>((2 * a + 1), e)] * xa;
       }
     }
     if (SH) {
@@ -1130,16 +1139,16 @@ __global__ __launch_bounds__(256) void implicit_tracks_kernel(DeviceView v, cons
 #pragma unroll
         for (int a = 0; a < D; ++a) {
           const double xa = xg[a];
-          u0 += v.pm_A1[(size_t)(2 * a) * N + e] * xa;
-          u1 += v.pm_A1[(size_t)(2 * a + 1) * N + e] * xa;
+          u0 += v.pm_A1[pidx<2 * D>((2 * a), e)] * xa;
+          u1 += v.pm_A1[pidx<2 * D>((2 * a + 1), e)] * xa;
         }
       }
     }
-    pm_u[e] = u0;
-    pm_u[N + e] = u1;
+    pm_u[pidx<2>(0, e)] = u0;
+    pm_u[pidx<2>(1, e)] = u1;
 #pragma unroll
     for (int a = 0; a < DP; ++a)
-      w[a] += v.pm_Jp[(size_t)(2 * a) * N + e] * u0 + v.pm_Jp[(size_t)(2 * a + 1) * N + e] * u1;
+      w[a] += v.pm_Jp[pidx<2 * DP>((2 * a), e)] * u0 + v.pm_Jp[pidx<2 * DP>((2 * a + 1), e)] * u1;
   }
 #pragma unroll
   for (int a = 0; a < DP; ++a) w[a] = group_sum(w[a], tm.wide);
@@ -1157,11 +1166,11 @@ __global__ __launch_bounds__(256) void implicit_tracks_kernel(DeviceView v, cons
     const size_t e = base + (size_t)j * 64;
     const int cpos = v.obs_cpos[e];
     if (cpos < 0) continue;
-    double t0 = pm_u[e], t1 = pm_u[N + e];
+    double t0 = pm_u[pidx<2>(0, e)], t1 = pm_u[pidx<2>(1, e)];
 #pragma unroll
     for (int a = 0; a < DP; ++a) {
-      t0 -= v.pm_Jp[(size_t)(2 * a) * N + e] * z[a];
-      t1 -= v.pm_Jp[(size_t)(2 * a + 1) * N + e] * z[a];
+      t0 -= v.pm_Jp[pidx<2 * DP>((2 * a), e)] * z[a];
+      t1 -= v.pm_Jp[pidx<2 * DP>((2 * a + 1), e)] * z[a];
     }
     *reinterpret_cast<double2*>(cm_t + (size_t)cpos * 2) = make_double2(t0, t1);
   }
@@ -1559,8 +1568,8 @@ __global__ __launch_bounds__(256) void back_substitute_kernel(DeviceView v, doub
 #pragma unroll
           for (int a = 0; a < D; ++a) {
             const double ya = yc[a];
-            u0 += v.pm_A[(size_t)(2 * a) * N + e] * ya;
-            u1 += v.pm_A[(size_t)(2 * a + 1) * N + e] * ya;
+            u0 += v.pm_A[pidx<2 * D>((2 * a), e)] * ya;
+            u1 += v.pm_A[pidx<2 * D>((2 * a + 1), e)] * ya;
           }
         }
         if (SH) {
@@ -1570,16 +1579,16 @@ __global__ __launch_bounds__(256) void back_substitute_kernel(DeviceView v, doub
 #pragma unroll
             for (int a = 0; a < D; ++a) {
               const double ya = yg[a];
-              u0 += v.pm_A1[(size_t)(2 * a) * N + e] * ya;
-              u1 += v.pm_A1[(size_t)(2 * a + 1) * N + e] * ya;
+              u0 += v.pm_A1[pidx<2 * D>((2 * a), e)] * ya;
+              u1 += v.pm_A1[pidx<2 * D>((2 * a + 1), e)] * ya;
             }
           }
         }
-        pm_u[e] = u0;
-        pm_u[N + e] = u1;
+        pm_u[pidx<2>(0, e)] = u0;
+        pm_u[pidx<2>(1, e)] = u1;
 #pragma unroll
         for (int a = 0; a < DP; ++a)
-          w[a] -= v.pm_Jp[(size_t)(2 * a) * N + e] * u0 + v.pm_Jp[(size_t)(2 * a + 1) * N + e] * u1;
+          w[a] -= v.pm_Jp[pidx<2 * DP>((2 * a), e)] * u0 + v.pm_Jp[pidx<2 * DP>((2 * a + 1), e)] * u1;
       }
 #pragma unroll
       for (int a = 0; a < DP; ++a) w[a] = group_sum(w[a], tm.wide);
@@ -1596,15 +1605,15 @@ __global__ __launch_bounds__(256) void back_substitute_kernel(DeviceView v, doub
       }
       for (int j = tm.j0; j < k; j += tm.jstep) {
         const size_t e = base + (size_t)j * 64;
-        double m0 = pm_u[e], m1 = pm_u[N + e];
+        double m0 = pm_u[pidx<2>(0, e)], m1 = pm_u[pidx<2>(1, e)];
 #pragma unroll
         for (int a = 0; a < DP; ++a) {
-          m0 += v.pm_Jp[(size_t)(2 * a) * N + e] * yp[a];
-          m1 += v.pm_Jp[(size_t)(2 * a + 1) * N + e] * yp[a];
+          m0 += v.pm_Jp[pidx<2 * DP>((2 * a), e)] * yp[a];
+          m1 += v.pm_Jp[pidx<2 * DP>((2 * a + 1), e)] * yp[a];
         }
         m0 = -m0;
         m1 = -m1;
-        acc[0] -= m0 * (v.pm_r[e] + 0.5 * m0) + m1 * (v.pm_r[N + e] + 0.5 * m1);
+        acc[0] -= m0 * (v.pm_r[pidx<2>(0, e)] + 0.5 * m0) + m1 * (v.pm_r[pidx<2>(1, e)] + 0.5 * m1);
       }
     }
   }
