@@ -19,6 +19,7 @@
 //    tbuf   [nub][D]         transposed block products of the symmetric SpMV
 #pragma once
 #include <cstdint>
+#include <hip/hip_runtime.h>
 
 namespace tmi {
 
@@ -59,6 +60,7 @@ struct DeviceView {
   const double* obs_xy;  // [No_pad][2]
   const int* obs_cpos;
   const int* cam_grp;
+  const int4* cam_rec;         // [Nc] {camera model, intrinsics offset, #intrinsics, free-column mask}
   const int* cam_rb;
   const unsigned* cam_mask;
   const int* grp_model;

@@ -648,6 +648,16 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
     }
 #undef UPI
     if ((rc = dev_upload(s, &pu, st.cam_mask))) return rc; v.cam_mask = pu;
+    {
+      std::vector<int4> rec((size_t)st.Nc);
+      for (int c = 0; c < st.Nc; ++c) {
+        const int g = cam_grp[c];
+        rec[c] = make_int4(grp_model[g], grp_off[g], grp_off[g + 1] - grp_off[g], (int)st.cam_mask[c]);
+      }
+      int4* pr;
+      if ((rc = dev_upload(s, &pr, rec))) return rc;
+      v.cam_rec = pr;
+    }
     if ((rc = dev_upload(s, &pu, st.grp_mask))) return rc; v.grp_mask = pu;
     if ((rc = dev_upload(s, &pc, st.obs_gflag))) return rc; v.obs_gflag = pc;
     if ((rc = dev_upload(s, &pc, st.pt_const))) return rc; v.pt_const = pc;

@@ -209,13 +209,20 @@ __global__ __launch_bounds__(256) void linearize_kernel(DeviceView v, int loss_t
     double sp[DP];
 #pragma unroll
     for (int a = 0; a < DP; ++a) sp[a] = v.scale_p[(size_t)lp * DP + a];
+    // the camera of the NEXT observation is fetched one iteration ahead and a view's model,
+    // intrinsics offset / size and free-column mask come in one 16-byte record (cam_rec), so
+    // the dependent chain of an iteration is  camera record -> parameters  instead of
+    // index -> group -> offset -> parameters  (the kernel spent 63 % of its cycles in s_waitcnt)
+    int cam_next = (tm.j0 < k) ? v.obs_cam[tm.base + (size_t)tm.j0 * 64] : 0;
     for (int j = tm.j0; j < k; j += tm.jstep) {
       const size_t e = tm.base + (size_t)j * 64;
-      const int cam = v.obs_cam[e];
+      const int cam = cam_next;
+      if (j + tm.jstep < k) cam_next = v.obs_cam[e + (size_t)tm.jstep * 64];
+      const int4 rec = v.cam_rec[cam];
       const int grp = v.cam_grp[cam];
-      const int model = v.grp_model[grp];
-      const double* Kp = v.intr + v.grp_off[grp];
-      const int nk = v.grp_off[grp + 1] - v.grp_off[grp];
+      const int model = rec.x;
+      const double* Kp = v.intr + rec.y;
+      const int nk = rec.z;
       double Kv[10], E[6];
 #pragma unroll
       for (int i = 0; i < 10; ++i) Kv[i] = (i < nk) ? Kp[i] : 0.0;
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(256) void linearize_kernel(DeviceView v, int loss_t
       RT rr[2], Jext[2][6], Jint[2][10], Jpt[2][4];
       const bool ok = reprojection_error<true, RT>(model, E, Kv, X, fx, fy, rr, Jext, Jint, Jpt);
       double r[2] = {(double)rr[0], (double)rr[1]};
-      const unsigned mask = v.cam_mask[cam];
+      const unsigned mask = (unsigned)rec.w;
       const int rb = v.cam_rb[cam];
       if (!ok) {
         v.flags[FL_INVALID] = 1;
@@ -335,12 +342,14 @@ __global__ __launch_bounds__(256) void cost_kernel(DeviceView v, const double* _
     double X[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) X[i] = pts[(size_t)lp * 4 + i];
+    int cam_next = (tm.j0 < k) ? v.obs_cam[tm.base + (size_t)tm.j0 * 64] : 0;
     for (int j = tm.j0; j < k; j += tm.jstep) {
       const size_t e = tm.base + (size_t)j * 64;
-      const int cam = v.obs_cam[e];
-      const int grp = v.cam_grp[cam];
-      const double* Kp = intr + v.grp_off[grp];
-      const int nk = v.grp_off[grp + 1] - v.grp_off[grp];
+      const int cam = cam_next;
+      if (j + tm.jstep < k) cam_next = v.obs_cam[e + (size_t)tm.jstep * 64];
+      const int4 rec = v.cam_rec[cam];
+      const double* Kp = intr + rec.y;
+      const int nk = rec.z;
       double Kv[10], E[6];
 #pragma unroll
       for (int i = 0; i < 10; ++i) Kv[i] = (i < nk) ? Kp[i] : 0.0;
@@ -350,7 +359,7 @@ __global__ __launch_bounds__(256) void cost_kernel(DeviceView v, const double* _
       RT (*nul6)[6] = nullptr;
       RT Jint[2][10];
       RT (*nul4)[4] = nullptr;
-      const bool ok = reprojection_error<false, RT>(v.grp_model[grp], E, Kv, X, v.obs_xy[2 * e],
+      const bool ok = reprojection_error<false, RT>(rec.x, E, Kv, X, v.obs_xy[2 * e],
                                                     v.obs_xy[2 * e + 1], rr, nul6, Jint, nul4);
       const double r[2] = {(double)rr[0], (double)rr[1]};
       if (!ok) {
