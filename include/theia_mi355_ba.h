@@ -335,7 +335,8 @@ int32_t tmi_ba_solver_set_allreduce(tmi_ba_solver* s, tmi_ba_allreduce_fn fn,
  * ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, comm, engine stream) itself:
  *   rank 0 : tmi_ba_rccl_unique_id(id)  -> ship the 128 bytes to every rank
  *   all    : tmi_ba_solver_init_rccl(solver, id)   (rank / world from create)
- * A hook set with tmi_ba_solver_set_allreduce is ignored once RCCL is initialised. */
+ * A hook set with tmi_ba_solver_set_allreduce is ignored once RCCL is initialised;
+ * tmi_ba_solver_init_rccl(solver, NULL) destroys the communicator again (fall back to the hook). */
 int32_t tmi_ba_rccl_unique_id(uint8_t id[128]);
 int32_t tmi_ba_solver_init_rccl(tmi_ba_solver* s, const uint8_t id[128]);
 /* Test aid: sums the solver's 8-double scalar buffer through the configured

@@ -749,7 +749,16 @@ int32_t tmi_ba_rccl_unique_id(uint8_t id[128]) {
 }
 
 int32_t tmi_ba_solver_init_rccl(tmi_ba_solver* s, const uint8_t id[128]) {
-  if (!s || !id) return TMI_BA_ERR_INVALID_ARGUMENT;
+  if (!s) return TMI_BA_ERR_INVALID_ARGUMENT;
+  if (!id) {  // drop the communicator (the caller falls back to its own all-reduce hook)
+    if (s->nccl_comm) {
+      hipSetDevice(s->device);
+      hipStreamSynchronize(s->stream);
+      rccl().CommDestroy(s->nccl_comm);
+      s->nccl_comm = nullptr;
+    }
+    return TMI_BA_OK;
+  }
   Rccl& r = rccl();
   if (!r.ok) {
     g_last_error = s->error = r.error;

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -110,7 +111,21 @@ def init_native_rccl(solver, rank: int, world: int) -> bool:
     dist.broadcast_object_list(payload, src=0)
     if not isinstance(payload[0], (bytes, bytearray)):
         return False
-    solver.init_rccl(bytes(payload[0]))
+    ok = 1
+    try:
+        solver.init_rccl(bytes(payload[0]))
+    except lib.EngineError as exc:
+        print(f"[theiasfm_amd] rank {rank}: native RCCL transport unavailable ({exc}); "
+              "falling back to the torch.distributed hook", file=sys.stderr, flush=True)
+        ok = 0
+    # every rank must take the same decision
+    import torch
+    flag = torch.tensor([ok], dtype=torch.int32,
+                        device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        solver.init_rccl(None)
+        return False
     return True
 
 

@@ -253,6 +253,11 @@ class Solver:
     def init_rccl(self, unique_id: bytes):
         """Native RCCL transport: every rank passes the 128-byte id rank 0 obtained from
         rccl_unique_id() (ship it with torch.distributed / MPI / a file)."""
+        if unique_id is None:  # drop the communicator: the all-reduce hook applies again
+            st = self._L.tmi_ba_solver_init_rccl(self._h, None)
+            if st != 0:
+                raise EngineError(st, "tmi_ba_solver_init_rccl")
+            return
         if len(unique_id) != 128:
             raise ValueError("ncclUniqueId is 128 bytes")
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
