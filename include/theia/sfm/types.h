@@ -1,15 +1,14 @@
-// reference: src/theia/sfm/types.h:47-53
+// Id types of the data model, as in the reference (src/theia/sfm/types.h:47-53): 32-bit
+// unsigned ids, the all-ones value marks "no such id".
 #ifndef THEIA_MI355_SFM_TYPES_H_
 #define THEIA_MI355_SFM_TYPES_H_
 #include <cstdint>
-#include <limits>
 namespace theia {
-typedef uint32_t ViewId;
-typedef uint32_t TrackId;
-typedef uint32_t CameraIntrinsicsGroupId;
-static const ViewId kInvalidViewId = std::numeric_limits<ViewId>::max();
-static const TrackId kInvalidTrackId = std::numeric_limits<TrackId>::max();
-static const CameraIntrinsicsGroupId kInvalidCameraIntrinsicsGroupId =
-    std::numeric_limits<CameraIntrinsicsGroupId>::max();
+using ViewId = std::uint32_t;
+using TrackId = std::uint32_t;
+using CameraIntrinsicsGroupId = std::uint32_t;
+constexpr ViewId kInvalidViewId = UINT32_MAX;
+constexpr TrackId kInvalidTrackId = UINT32_MAX;
+constexpr CameraIntrinsicsGroupId kInvalidCameraIntrinsicsGroupId = UINT32_MAX;
 }  // namespace theia
 #endif
