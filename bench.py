@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="venice1778",
-                    choices=["tiny", "ladybug49", "alamo", "venice1778"])
+                    choices=["tiny", "ladybug49", "alamo", "venice1778", "venice1778_heavy"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=2)
     ap.add_argument("--transport", default="rccl", choices=["rccl", "torch", "staged"],

@@ -38,6 +38,9 @@ CONFIG_SIZES = {
     "ladybug49": (49, 7776, 31843),
     "alamo": (570, 140000, 900000),
     "venice1778": (1778, 993923, 5001946),
+    # the same sizes with 0.2 % of the tracks seen by 24..400 views (not a BASELINE config: a stress
+    # case for the long-track paths, cf. SURVEY 8d "max k a few hundred")
+    "venice1778_heavy": (1778, 993923, 5001946),
 }
 
 
@@ -109,13 +112,18 @@ def project(problem: Problem, obs_index=None) -> np.ndarray:
 
 
 # ---- visibility -------------------------------------------------------------
-def _track_lengths(rng, n_cameras, n_points, n_obs):
+def _track_lengths(rng, n_cameras, n_points, n_obs, heavy_tail=0.0):
     mean_k = n_obs / n_points
     if mean_k >= n_cameras:
         return np.full(n_points, n_cameras, dtype=np.int64)
     p = 1.0 / max(mean_k - 1.0, 1.0 + 1e-9)
     k = 1 + rng.geometric(min(p, 1.0), n_points).astype(np.int64)
     k = np.clip(k, 2, n_cameras)
+    if heavy_tail > 0.0:
+        # a fraction `heavy_tail` of the tracks is seen by tens to hundreds of views (landmark
+        # points of internet photo collections; SURVEY 8d config 4: "max k a few hundred")
+        long = np.flatnonzero(rng.random(n_points) < heavy_tail)
+        k[long] = np.clip(np.rint(24.0 * (1.0 + rng.pareto(1.3, long.size))), 24, min(n_cameras, 400)).astype(np.int64)
     # steer the total to exactly n_obs
     for _ in range(64):
         diff = int(n_obs - k.sum())
@@ -134,8 +142,8 @@ def _track_lengths(rng, n_cameras, n_points, n_obs):
     return k
 
 
-def _visibility(rng, n_cameras, n_points, n_obs, spread):
-    k = _track_lengths(rng, n_cameras, n_points, n_obs)
+def _visibility(rng, n_cameras, n_points, n_obs, spread, heavy_tail=0.0):
+    k = _track_lengths(rng, n_cameras, n_points, n_obs, heavy_tail)
     # window width w = m*k cameras, m heavy tailed, w <= n_cameras
     m_max = np.maximum(n_cameras // k, 1)
     m = np.rint(spread * n_cameras / k * rng.lognormal(0.0, 0.9, n_points)).astype(np.int64)
@@ -164,7 +172,7 @@ def _look_at(C, target, up=np.array([0.0, 1.0, 0.0])):
 def make_problem(n_cameras: int, n_points: int, n_obs: int, seed: int, *,
                  scene: str = "ring", spread: float = 0.12, pixel_noise: float = 0.5,
                  perturb: float = 1.0, models=None, shared_group_size: int = 1,
-                 intrinsics_to_optimize: int = abi.INTRINSICS_DEFAULT) -> Problem:
+                 intrinsics_to_optimize: int = abi.INTRINSICS_DEFAULT, heavy_tail: float = 0.0) -> Problem:
     """Build a seeded synthetic problem.
 
     scene "allsee": the reference test recipe (config 1), every view sees every track.
@@ -200,7 +208,7 @@ def make_problem(n_cameras: int, n_points: int, n_obs: int, seed: int, *,
         target = radius * 0.1 * rng.normal(size=(n_cameras, 3))
         aa = _look_at(C, target)
         X = radius * 0.3 * rng.uniform(-1, 1, (n_points, 3))
-        cam, pt, _ = _visibility(rng, n_cameras, n_points, n_obs, spread)
+        cam, pt, _ = _visibility(rng, n_cameras, n_points, n_obs, spread, heavy_tail)
         depth = radius
         f = rng.uniform(600, 900, n_cameras)
         pp = np.zeros((n_cameras, 2))
@@ -271,7 +279,9 @@ def config(name: str, **kw) -> Problem:
     nc, npt, nobs = CONFIG_SIZES[name]
     if name == "tiny":
         return make_problem(nc, npt, nobs, seed=1, scene="allsee", **kw)
-    seeds = {"ladybug49": 49, "alamo": 570, "venice1778": 1778}
-    spreads = {"ladybug49": 0.35, "alamo": 0.15, "venice1778": 0.12}
+    seeds = {"ladybug49": 49, "alamo": 570, "venice1778": 1778, "venice1778_heavy": 1778}
+    spreads = {"ladybug49": 0.35, "alamo": 0.15, "venice1778": 0.12, "venice1778_heavy": 0.12}
     kw.setdefault("spread", spreads[name])
+    if name == "venice1778_heavy":
+        kw.setdefault("heavy_tail", 0.002)
     return make_problem(nc, npt, nobs, seed=seeds[name], scene="ring", **kw)
