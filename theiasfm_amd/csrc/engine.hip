@@ -1532,7 +1532,7 @@ int32_t tmi_ba_solver_filter_outlier_tracks(tmi_ba_solver* s, double max_inlier_
   TMI_HIP(hipEventCreate(&eb));
   TMI_HIP(hipEventRecord(ea, s->stream));
   if (st.nslices > 0)
-    hipLaunchKernelGGL(outlier_filter_kernel, dim3(s->nblocks_slices), dim3(256), 0, s->stream, s->v, max_sq,
+    hipLaunchKernelGGL(outlier_filter_kernel, dim3(s->nblocks_tracks), dim3(256), 0, s->stream, s->v, max_sq,
                        cos_min, s->d_trk_flag, s->d_trk_mean);
   TMI_HIP(hipEventRecord(eb, s->stream));
   std::vector<unsigned char> flag((size_t)st.Np_pad);

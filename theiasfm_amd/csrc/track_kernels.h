@@ -42,61 +42,65 @@ __device__ __forceinline__ void unit_ray(const double* __restrict__ ext, int cam
 __global__ __launch_bounds__(256) void outlier_filter_kernel(DeviceView v, double max_sq, double cos_min,
                                                              unsigned char* __restrict__ flag,
                                                              double* __restrict__ mean_sq) {
-  const int lane = threadIdx.x & 63;
-  const int s = blockIdx.x * kSlicesPerBlock + (threadIdx.x >> 6);
-  if (s >= v.nslices) return;
-  const int lp = s * 64 + lane;
-  const int k = v.pt_k[lp];
-  const size_t base = (size_t)v.slice_ptr[s] + lane;
+  // long slices: 16 lanes per track (kernels.h track_map) -- the pair scan of a 400-view track
+  // is 80 000 ray pairs, shared here by 16 lanes
+  const TrackMap tm = track_map(v);
+  if (!tm.valid) return;
+  const int lp = tm.lp;
+  const int k = tm.k;
+  const size_t base = tm.base;
   double X[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) X[i] = v.pts[(size_t)lp * 4 + i];
-  bool behind = false;
-  double sum = 0.0;
-  int nproj = 0;
-  for (int j = 0; j < k; ++j) {
+  double behind = 0.0, sum = 0.0, nproj = 0.0;
+  for (int j = tm.j0; j < k; j += tm.jstep) {
     const size_t e = base + (size_t)j * 64;
     const int cam = v.obs_cam[e];
-    const int grp = v.cam_grp[cam];
-    const double* Kp = v.intr + v.grp_off[grp];
-    const int nk = v.grp_off[grp + 1] - v.grp_off[grp];
+    const int4 rec = v.cam_rec[cam];
+    const double* Kp = v.intr + rec.y;
+    const int nk = rec.z;
     double Kv[10], E[6], px[2];
 #pragma unroll
     for (int i = 0; i < 10; ++i) Kv[i] = (i < nk) ? Kp[i] : 0.0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) E[i] = v.ext[(size_t)cam * 6 + i];
-    const double depth = project_point_depth(v.grp_model[grp], E, Kv, X, px);
+    const double depth = project_point_depth(rec.x, E, Kv, X, px);
     if (depth < 0) {  // :101-105
-      behind = true;
+      behind = 1.0;
       break;
     }
     const double dx = px[0] - v.obs_xy[2 * e], dy = px[1] - v.obs_xy[2 * e + 1];
     sum += dx * dx + dy * dy;
-    ++nproj;
+    nproj += 1.0;
   }
-  const double mean = sum / (double)nproj;
+  behind = group_sum(behind, tm.wide);
+  sum = group_sum(sum, tm.wide);
+  nproj = group_sum(nproj, tm.wide);
+  const double mean = sum / nproj;
   int f = 0;
-  if (behind || mean > max_sq) {
+  if (behind > 0.0 || mean > max_sq) {
     f = 1;
   } else {
     const double Xh[3] = {X[0] / X[3], X[1] / X[3], X[2] / X[3]};
-    bool sufficient = false;
-    for (int i = 0; i < k && !sufficient; ++i) {
+    double sufficient = 0.0;
+    for (int i = tm.j0; i < k && sufficient == 0.0; i += tm.jstep) {
       double ri[3];
       unit_ray(v.ext, v.obs_cam[base + (size_t)i * 64], Xh, ri);
       for (int j = i + 1; j < k; ++j) {
         double rj[3];
         unit_ray(v.ext, v.obs_cam[base + (size_t)j * 64], Xh, rj);
         if (ri[0] * rj[0] + ri[1] * rj[1] + ri[2] * rj[2] < cos_min) {
-          sufficient = true;
+          sufficient = 1.0;
           break;
         }
       }
     }
-    if (!sufficient) f = 2;
+    if (group_sum(sufficient, tm.wide) == 0.0) f = 2;
   }
-  flag[lp] = (unsigned char)f;
-  if (mean_sq) mean_sq[lp] = mean;
+  if (tm.leader) {
+    flag[lp] = (unsigned char)f;
+    if (mean_sq) mean_sq[lp] = mean;
+  }
 }
 
 // ------------------------------------------------------------------------------------
