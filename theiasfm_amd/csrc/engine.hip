@@ -567,6 +567,8 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
     return rc;
   }
   Structure& st = s->st;
+  const bool setup_timing = getenv("TMI_BA_SETUP_TIMING") != nullptr;
+  if (setup_timing) fprintf(stderr, "[tmi_ba setup] %-28s %.3f s\n", "build_structure total", now_s() - t0);
   if (!get_launch(st.D, s->DP, st.has_shared, O->residual_precision == 32, &s->launch)) {
     s->error = "no kernel instantiation for this block size";
     return TMI_BA_ERR_UNSUPPORTED;
@@ -704,6 +706,7 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   TMI_HIP(hipMemsetAsync(v.cm_A, 0, (size_t)std::max<int64_t>(st.Nslots, 1) * AS * sizeof(double), s->stream));
   TMI_HIP(hipStreamSynchronize(s->stream));
   s->setup_seconds = now_s() - t0;
+  if (setup_timing) fprintf(stderr, "[tmi_ba setup] %-28s %.3f s\n", "create total (incl. upload)", s->setup_seconds);
   return TMI_BA_OK;
 }
 

@@ -9,8 +9,11 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <numeric>
+#include <thread>
 
 namespace tmi {
 namespace {
@@ -79,7 +82,21 @@ int pad_dim(int d) {
 
 }  // namespace
 
+namespace {
+double wall_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+}  // namespace
+
 int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, bool want_pairs) {
+  const bool timing = std::getenv("TMI_BA_SETUP_TIMING") != nullptr;
+  double t_phase = wall_s();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    const double now = wall_s();
+    fprintf(stderr, "[tmi_ba setup] %-28s %.3f s\n", what, now - t_phase);
+    t_phase = now;
+  };
   Structure& s = *S;
   if (!P || world < 1 || rank < 0 || rank >= world) {
     s.error = "null problem or bad rank/world";
@@ -185,6 +202,7 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, 
       if (m & (1u << b)) s.rb_cols[(size_t)rb * s.D + col++] = (int8_t)b;
   }
 
+  lap("reduced blocks");
   // ---- tracks: lengths, order by descending length, shard ------------------------
   std::vector<int> klen(s.Np_total, 0);
   for (int64_t i = 0; i < No_all; ++i) klen[P->obs_point[i]]++;
@@ -381,13 +399,28 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, 
     }
   }
 
+  lap("track order, layout, slots");
   // ---- block structure of S from ALL tracks (rank independent) -------------------
   KeyMap blocks;
   blocks.init(1 << 16);
-  std::vector<int> rbs;
-  auto track_blocks = [&](auto&& cam_of, int k) {
-    // reduced blocks a track touches, ascending: camera blocks, then (once each) the
-    // shared intrinsics blocks
+  // Host threads for the two passes over the tracks (block set, pair lists): the pair lists
+  // of a Venice-sized problem are 16 M entries behind 16 M hash look-ups -- single-threaded
+  // they were 80 % of the set-up time.  Every result below is independent of the thread count.
+  const int n_threads = (!want_pairs || No_all < 200000)
+                            ? 1
+                            : (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+  auto run_threads = [&](auto&& body) {  // body(thread index)
+    if (n_threads == 1) {
+      body(0);
+      return;
+    }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < n_threads; ++t) pool.emplace_back([&, t] { body(t); });
+    for (auto& th : pool) th.join();
+  };
+  // reduced blocks a track touches, ascending: camera blocks, then (once each) the shared
+  // intrinsics blocks
+  auto track_blocks = [&](std::vector<int>& rbs, auto&& cam_of, int k) {
     rbs.clear();
     int prev_g = -1;
     for (int j = 0; j < k; ++j) {
@@ -401,13 +434,36 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, 
     }
     std::sort(rbs.begin(), rbs.end());
   };
-  for (int p = 0; p < s.Np_total && want_pairs; ++p) {
-    if (klen[p] < 1) continue;
-    if (P->point_constant && P->point_constant[p]) continue;  // no elimination, no coupling
-    track_blocks([&](int j) { return P->obs_camera[tobs[tptr[p] + j]]; }, klen[p]);
-    for (size_t a = 0; a < rbs.size(); ++a)
-      for (size_t b = a + 1; b < rbs.size(); ++b)
-        blocks.put(((uint64_t)rbs[a] << 32) | (uint32_t)rbs[b], 0);
+  const bool dense_flags = want_pairs && (int64_t)s.Nrb * s.Nrb <= (int64_t)64 << 20;
+  if (dense_flags) {
+    // one byte per (row, column): set concurrently (every writer stores the same 1), then
+    // swept in row-major order into the key map
+    std::vector<uint8_t> present((size_t)s.Nrb * s.Nrb, 0);
+    run_threads([&](int t) {
+      std::vector<int> rbs;
+      const int p0 = (int)((int64_t)s.Np_total * t / n_threads), p1 = (int)((int64_t)s.Np_total * (t + 1) / n_threads);
+      for (int p = p0; p < p1; ++p) {
+        if (klen[p] < 1) continue;
+        if (P->point_constant && P->point_constant[p]) continue;  // no elimination, no coupling
+        track_blocks(rbs, [&](int j) { return P->obs_camera[tobs[tptr[p] + j]]; }, klen[p]);
+        for (size_t a = 0; a < rbs.size(); ++a)
+          for (size_t b = a + 1; b < rbs.size(); ++b)
+            __atomic_store_n(&present[(size_t)rbs[a] * s.Nrb + rbs[b]], (uint8_t)1, __ATOMIC_RELAXED);
+      }
+    });
+    for (int a = 0; a < s.Nrb; ++a)
+      for (int b = a + 1; b < s.Nrb; ++b)
+        if (present[(size_t)a * s.Nrb + b]) blocks.put(((uint64_t)a << 32) | (uint32_t)b, 0);
+  } else {
+    std::vector<int> rbs;
+    for (int p = 0; p < s.Np_total && want_pairs; ++p) {
+      if (klen[p] < 1) continue;
+      if (P->point_constant && P->point_constant[p]) continue;  // no elimination, no coupling
+      track_blocks(rbs, [&](int j) { return P->obs_camera[tobs[tptr[p] + j]]; }, klen[p]);
+      for (size_t a = 0; a < rbs.size(); ++a)
+        for (size_t b = a + 1; b < rbs.size(); ++b)
+          blocks.put(((uint64_t)rbs[a] << 32) | (uint32_t)rbs[b], 0);
+    }
   }
   // J_c^T J_c couples a view's extrinsics with its shared intrinsics block even when
   // none of its tracks is eliminated
@@ -434,6 +490,12 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, 
     s.ub_i[u] = (int)(ukeys[u] >> 32);
     s.ub_j[u] = (int)(ukeys[u] & 0xffffffffu);
     *blocks.find(ukeys[u]) = (int)u;
+  }
+  // dense (row, column) -> block index table for the pair pass (a hash look-up per pair otherwise)
+  std::vector<int> blk_id;
+  if (dense_flags) {
+    blk_id.assign((size_t)s.Nrb * s.Nrb, -1);
+    for (int64_t u = 0; u < s.nub; ++u) blk_id[(size_t)s.ub_i[u] * s.Nrb + s.ub_j[u]] = (int)u;
   }
   // symmetric storage: row ranges of the (bi, bj)-sorted upper list and a column index
   s.nnzb = 2 * s.nub + s.Nrb;
@@ -468,11 +530,13 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, 
     for (int64_t u = 0; u < s.nub; ++u) s.ucol_u[fill[s.ub_j[u]]++] = (int)u;  // ascending bi
   }
 
+  lap("block structure of S");
   // ---- pair lists from this rank's tracks ----------------------------------------
   s.pair_ptr.assign(s.nub + 1, 0);
-  std::vector<std::pair<int, int>> rs;  // (block, slot) of a track's virtual observations
-  auto for_each_pair = [&](auto&& fn) {
-    for (int lp = 0; lp < s.Np_pad && want_pairs; ++lp) {
+  // the (block, slot_i, slot_j) triples of the tracks [lp0, lp1), in track order
+  auto for_each_pair = [&](int lp0, int lp1, auto&& fn) {
+    std::vector<std::pair<int, int>> rs;  // (block, slot) of a track's virtual observations
+    for (int lp = lp0; lp < lp1 && want_pairs; ++lp) {
       const int p = s.pt_orig[lp];
       if (p < 0 || s.pt_const[lp]) continue;
       const int sl = lp >> 6, t = lp & 63;
@@ -489,24 +553,58 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, 
       std::sort(rs.begin(), rs.end());
       for (size_t a = 0; a < rs.size(); ++a)
         for (size_t b = a + 1; b < rs.size(); ++b) {
-          const int u = *blocks.find(((uint64_t)rs[a].first << 32) | (uint32_t)rs[b].first);
+          const int u = blk_id.empty() ? *blocks.find(((uint64_t)rs[a].first << 32) | (uint32_t)rs[b].first)
+                                       : blk_id[(size_t)rs[a].first * s.Nrb + rs[b].first];
           fn(u, rs[a].second, rs[b].second);
         }
     }
   };
-  for_each_pair([&](int u, int, int) { s.pair_ptr[u + 1]++; });
-  for (int64_t u = 0; u < s.nub; ++u) s.pair_ptr[u + 1] += s.pair_ptr[u];
+  // contiguous track ranges of about equal pair work: thread t owns [cut[t], cut[t+1]).  A
+  // block's pair list is ordered by track, whatever the number of threads.
+  std::vector<int> cut(n_threads + 1, s.Np_pad);
+  {
+    std::vector<int64_t> work((size_t)s.Np_pad + 1, 0);
+    for (int lp = 0; lp < s.Np_pad; ++lp) {
+      const int64_t k = s.pt_k[lp];
+      work[lp + 1] = work[lp] + k * (k - 1) / 2 + 1;
+    }
+    cut[0] = 0;
+    for (int t = 1; t < n_threads; ++t)
+      cut[t] = (int)(std::lower_bound(work.begin(), work.end(), work.back() * t / n_threads) - work.begin());
+    for (int t = 1; t <= n_threads; ++t) cut[t] = std::max(cut[t], cut[t - 1]);
+    cut[n_threads] = s.Np_pad;
+  }
+  // count per (thread, block), then: pair_ptr = prefix over blocks, and the counts become the
+  // thread's first position inside each block
+  std::vector<std::vector<int>> cnt(n_threads);
+  run_threads([&](int t) {
+    cnt[t].assign((size_t)s.nub + 1, 0);
+    for_each_pair(cut[t], cut[t + 1], [&](int u, int, int) { cnt[t][u]++; });
+  });
+  for (int64_t u = 0; u < s.nub; ++u) {
+    int64_t tot = 0;
+    for (int t = 0; t < n_threads; ++t) {
+      const int c = cnt[t][u];
+      cnt[t][u] = (int)tot;
+      tot += c;
+    }
+    if (tot > 0x7fffffff) {
+      s.error = "a block of the reduced camera matrix has too many observation pairs";
+      return TMI_BA_ERR_UNSUPPORTED;
+    }
+    s.pair_ptr[u + 1] = s.pair_ptr[u] + tot;
+  }
   s.npairs = s.pair_ptr[s.nub];
   s.pair_i.assign(s.npairs, 0);
   s.pair_j.assign(s.npairs, 0);
-  {
-    std::vector<int64_t> fill(s.pair_ptr.begin(), s.pair_ptr.end() - 1);
-    for_each_pair([&](int u, int si, int sj) {
-      s.pair_i[fill[u]] = si;
-      s.pair_j[fill[u]] = sj;
-      fill[u]++;
+  run_threads([&](int t) {
+    for_each_pair(cut[t], cut[t + 1], [&](int u, int si, int sj) {
+      const int64_t pos = s.pair_ptr[u] + cnt[t][u]++;
+      s.pair_i[pos] = si;
+      s.pair_j[pos] = sj;
     });
-  }
+  });
+  lap("pair lists");
   // per view of a shared block: the S block (extrinsics, shared intrinsics) receiving
   // its J_c^T J_c cross term; per shared block: its views
   s.cam_cross_u.assign(s.Nc, -1);
@@ -559,6 +657,7 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, 
           if (idx < q[x].size()) s.ub_order[(m * 8 + x) * kSchurWG + t] = q[x][idx];
         }
   }
+  lap("launch order");
   return TMI_BA_OK;
 }
 
