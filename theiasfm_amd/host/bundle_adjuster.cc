@@ -141,24 +141,56 @@ void BundleAdjuster::AddReprojectionErrorResidual(const Feature& feature, const 
   track_constant_.emplace(track_id, true);
 }
 
+namespace {
+// id -> dense index over a sorted list of distinct ids: direct table when the ids are
+// compact (Reconstruction hands them out consecutively), binary search otherwise
+template <class Id>
+struct IdIndex {
+  std::vector<Id> ids;       // ascending, distinct
+  std::vector<int> table;    // [max id + 1] or empty
+  void Build(std::vector<Id>* raw) {
+    std::sort(raw->begin(), raw->end());
+    raw->erase(std::unique(raw->begin(), raw->end()), raw->end());
+    ids.swap(*raw);
+    table.clear();
+    if (!ids.empty() && static_cast<uint64_t>(ids.back()) < 8ull * ids.size() + (1u << 20)) {
+      table.assign(static_cast<size_t>(ids.back()) + 1, -1);
+      for (size_t i = 0; i < ids.size(); ++i) table[ids[i]] = static_cast<int>(i);
+    }
+  }
+  int operator()(Id id) const {
+    if (!table.empty()) return table[id];
+    return static_cast<int>(std::lower_bound(ids.begin(), ids.end(), id) - ids.begin());
+  }
+};
+}  // namespace
+
 bool BundleAdjuster::Flatten(FlattenedBundleAdjustmentProblem* f) {
   if (f == nullptr || reconstruction_ == nullptr) return false;
   *f = FlattenedBundleAdjustmentProblem();
   SetCameraExtrinsicsParameterization();
   SetCameraIntrinsicsParameterization();
-  std::map<ViewId, int> cam_index;
-  std::map<TrackId, int> pt_index;
-  std::map<CameraIntrinsicsGroupId, int> grp_index;
-  for (const Residual& r : residuals_) {
-    cam_index[r.view] = 0;
-    pt_index[r.track] = 0;
-    grp_index[reconstruction_->CameraIntrinsicsGroupIdFromViewId(r.view)] = 0;
+  // sorted ids => deterministic block order (Ceres follows unordered_map iteration)
+  IdIndex<ViewId> cam_index;
+  IdIndex<TrackId> pt_index;
+  IdIndex<CameraIntrinsicsGroupId> grp_index;
+  {
+    std::vector<ViewId> v;
+    std::vector<TrackId> t;
+    v.reserve(residuals_.size());
+    t.reserve(residuals_.size());
+    for (const Residual& r : residuals_) {
+      v.push_back(r.view);
+      t.push_back(r.track);
+    }
+    cam_index.Build(&v);
+    pt_index.Build(&t);
+    std::vector<CameraIntrinsicsGroupId> g;
+    g.reserve(cam_index.ids.size());
+    for (const ViewId id : cam_index.ids) g.push_back(reconstruction_->CameraIntrinsicsGroupIdFromViewId(id));
+    grp_index.Build(&g);
   }
-  int n = 0;
-  for (auto& g : grp_index) {
-    g.second = n++;
-    f->group_ids.push_back(g.first);
-  }
+  f->group_ids = grp_index.ids;
   f->group_offset.push_back(0);
   for (const CameraIntrinsicsGroupId g : f->group_ids) {
     std::shared_ptr<CameraIntrinsicsModel> intr = GetIntrinsicsForCameraIntrinsicsGroup(g);
@@ -172,33 +204,48 @@ bool BundleAdjuster::Flatten(FlattenedBundleAdjustmentProblem* f) {
       f->intrinsics_constant.insert(f->intrinsics_constant.end(), np, 1);
     f->group_offset.push_back(f->group_offset.back() + np);
   }
-  n = 0;
-  for (auto& c : cam_index) {
-    c.second = n++;
-    f->view_ids.push_back(c.first);
-    const Camera& cam = reconstruction_->View(c.first)->Camera();
+  f->view_ids = cam_index.ids;
+  f->extrinsics.reserve(6 * f->view_ids.size());
+  for (const ViewId id : f->view_ids) {
+    const Camera& cam = reconstruction_->View(id)->Camera();
     f->extrinsics.insert(f->extrinsics.end(), cam.extrinsics(), cam.extrinsics() + 6);
-    f->camera_group.push_back(grp_index[reconstruction_->CameraIntrinsicsGroupIdFromViewId(c.first)]);
-    f->camera_flags.push_back(camera_flags_[c.first]);
+    f->camera_group.push_back(grp_index(reconstruction_->CameraIntrinsicsGroupIdFromViewId(id)));
+    f->camera_flags.push_back(camera_flags_[id]);
   }
-  n = 0;
-  for (auto& p : pt_index) {
-    p.second = n++;
-    f->track_ids.push_back(p.first);
-    const Eigen::Vector4d& X = reconstruction_->Track(p.first)->Point();
+  f->track_ids = pt_index.ids;
+  f->points.reserve(4 * f->track_ids.size());
+  for (const TrackId id : f->track_ids) {
+    const Eigen::Vector4d& X = reconstruction_->Track(id)->Point();
     f->points.insert(f->points.end(), X.data(), X.data() + 4);
-    f->point_constant.push_back(track_constant_[p.first] ? 1 : 0);
+    f->point_constant.push_back(track_constant_[id] ? 1 : 0);
   }
-  // deterministic observation order: by (track, view)
-  std::vector<Residual> sorted = residuals_;
-  std::sort(sorted.begin(), sorted.end(), [](const Residual& a, const Residual& b) {
-    return a.track != b.track ? a.track < b.track : a.view < b.view;
-  });
-  for (const Residual& r : sorted) {
-    f->obs_camera.push_back(cam_index[r.view]);
-    f->obs_point.push_back(pt_index[r.track]);
-    f->obs_xy.push_back(r.x);
-    f->obs_xy.push_back(r.y);
+  // deterministic observation order: by (track, view) -- a counting sort by track, then each
+  // track's few observations by view
+  const size_t n = residuals_.size(), np = f->track_ids.size();
+  std::vector<int> pt_of(n);
+  std::vector<size_t> first(np + 1, 0);
+  for (size_t i = 0; i < n; ++i) {
+    pt_of[i] = pt_index(residuals_[i].track);
+    first[pt_of[i] + 1]++;
+  }
+  for (size_t p = 0; p < np; ++p) first[p + 1] += first[p];
+  std::vector<uint32_t> order(n);
+  {
+    std::vector<size_t> fill(first.begin(), first.end() - 1);
+    for (size_t i = 0; i < n; ++i) order[fill[pt_of[i]]++] = static_cast<uint32_t>(i);
+  }
+  for (size_t p = 0; p < np; ++p)
+    std::sort(order.begin() + first[p], order.begin() + first[p + 1],
+              [&](uint32_t a, uint32_t b) { return residuals_[a].view < residuals_[b].view; });
+  f->obs_camera.resize(n);
+  f->obs_point.resize(n);
+  f->obs_xy.resize(2 * n);
+  for (size_t q = 0; q < n; ++q) {
+    const Residual& r = residuals_[order[q]];
+    f->obs_camera[q] = cam_index(r.view);
+    f->obs_point[q] = pt_of[order[q]];
+    f->obs_xy[2 * q] = r.x;
+    f->obs_xy[2 * q + 1] = r.y;
   }
   return true;
 }
