@@ -99,6 +99,8 @@ struct DeviceView {
   double* cm_Y;
   double* cm_A;
   double* scale_c;  // [Nrb][D]
+  double* scale_cam; // [Nc][16] scale_c expanded to the columns [ext(6) | intr(10)] of every view
+                     //   (0 on constant columns): linearize indexes it statically
   double* scale_p;  // [Np_pad][DP]
   double* Vinv;     // [DP(DP+1)/2][Np_pad]  planes, symmetric inverse of V + Dp
   double* gp;       // [DP][Np_pad]

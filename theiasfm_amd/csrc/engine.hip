@@ -57,6 +57,7 @@ struct Launch {
   void (*point_eliminate)(const DeviceView&, hipStream_t, double, double, double, int, double*, double*);
   void (*camera_diag)(const DeviceView&, hipStream_t, RedLayout);
   void (*schur_offdiag)(const DeviceView&, hipStream_t, RedLayout);
+  void (*expand_scale)(const DeviceView&, hipStream_t);
   void (*expand)(const DeviceView&, hipStream_t, RedLayout, double, double, double);
   void (*precond)(const DeviceView&, hipStream_t, int);
   void (*spmv)(const DeviceView&, hipStream_t, const double*, const double*, double*);
@@ -111,6 +112,9 @@ Launch make_launch(bool fp32) {
   };
   L.camera_diag = [](const DeviceView& v, hipStream_t st, RedLayout R) {
     if (v.Nrb) hipLaunchKernelGGL((camera_diag_kernel<D, DP, SH>), dim3(v.Nrb), dim3(64), 0, st, v, R);
+  };
+  L.expand_scale = [](const DeviceView& v, hipStream_t st) {
+    if (v.Nc) hipLaunchKernelGGL((expand_camera_scale_kernel<D>), dim3((v.Nc + 255) / 256), dim3(256), 0, st, v);
   };
   L.schur_offdiag = [](const DeviceView& v, hipStream_t st, RedLayout R) {
     if (v.nub)
@@ -689,7 +693,7 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   AL(s->d_cm_t, s->implicit ? (size_t)std::max<int64_t>(st.Nslots, 1) * 2 : 1)
   AL(v.pm_A1, st.has_shared ? 2 * D * N : 1) AL(v.cam_part, (size_t)std::max(st.Ncam_rb, 1) * (2 * D * D + 3 * D))
   AL(v.cm_Y, (size_t)std::max<int64_t>(st.Nslots, 1) * YS) AL(v.cm_A, (size_t)std::max<int64_t>(st.Nslots, 1) * AS)
-  AL(v.scale_c, std::max(n_r, 1)) AL(v.scale_p, NP * DP)
+  AL(v.scale_c, std::max(n_r, 1)) AL(v.scale_cam, (size_t)std::max(st.Nc, 1) * 16) AL(v.scale_p, NP * DP)
   AL(v.Vinv, NP * NS) AL(v.gp, NP * DP) AL(v.diag_p, NP * DP) AL(v.yp, NP * DP)
   AL(v.red, s->RL.total) AL(v.Sdiag, (size_t)std::max(st.Nrb, 1) * D * D)
   AL(v.tbuf, (size_t)std::max<int64_t>(st.nub, 1) * D) AL(v.rbuf, (size_t)std::max<size_t>(st.spc_row.size(), 1) * D) AL(v.Minv, (size_t)std::max(st.Nrb, 1) * D * D)
@@ -1175,6 +1179,7 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
   CKH(hipMemsetAsync(v.flags, 0, FL_COUNT * sizeof(int), stream));
   CKH(hipMemsetAsync(v.yc, 0, std::max(n_r, 1) * sizeof(double), stream));
   hipLaunchKernelGGL(fill_kernel, dim3((n_r + 255) / 256 + 1), dim3(256), 0, stream, v.scale_c, (long long)n_r, 1.0);
+  s->launch.expand_scale(v, stream);
   hipLaunchKernelGGL(fill_kernel, dim3((unsigned)(((long long)st.Np_pad * s->DP + 255) / 256 + 1)), dim3(256), 0, stream, v.scale_p, (long long)st.Np_pad * s->DP, 1.0);
   auto linearize = [&]() {
     {
@@ -1240,6 +1245,7 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
       if (n_r) {
         CKH(hipMemcpyAsync(v.scale_c, v.red + RL.udiag, (size_t)n_r * sizeof(double), hipMemcpyDeviceToDevice, stream));
         hipLaunchKernelGGL(camera_scale_finish_kernel, dim3((n_r + 255) / 256), dim3(256), 0, stream, v.scale_c, n_r);
+        s->launch.expand_scale(v, stream);
       }
     }
     linearize();
@@ -1877,6 +1883,7 @@ int32_t tmi_ba_solver_evaluate(tmi_ba_solver* s, double* residuals, double* jac_
   if (block_dim) *block_dim = D;
   TMI_HIP(hipMemsetAsync(v.flags, 0, FL_COUNT * sizeof(int), stream));
   hipLaunchKernelGGL(fill_kernel, dim3((n_r + 255) / 256 + 1), dim3(256), 0, stream, v.scale_c, (long long)n_r, 1.0);
+  s->launch.expand_scale(v, stream);
   hipLaunchKernelGGL(fill_kernel, dim3((unsigned)(((long long)st.Np_pad * DP + 255) / 256 + 1)), dim3(256), 0, stream, v.scale_p, (long long)st.Np_pad * DP, 1.0);
   // poison the residual planes so that invalid observations can be told apart
   s->launch.linearize(v, stream, 0, 1.0, s->nblocks_tracks);

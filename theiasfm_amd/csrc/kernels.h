@@ -179,6 +179,30 @@ __global__ void fill_kernel(double* p, long long n, double v) {
   if (i < n) p[i] = v;
 }
 
+// scale_c (per reduced column) expanded per view to the 16 source columns [ext(6) | intr(10)];
+// launched whenever scale_c changes (start of a solve, after the Jacobi-scaling pre-pass)
+template <int D>
+__global__ void expand_camera_scale_kernel(DeviceView v) {
+  const int cam = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cam >= v.Nc) return;
+  const unsigned mask = v.cam_mask[cam];
+  const int rb = v.cam_rb[cam];
+  const int grb = v.has_shared ? v.cam_grb[cam] : -1;
+  const unsigned gmask = grb >= 0 ? v.grp_mask[v.cam_grp[cam]] : 0u;
+  int dst = 0, dst1 = 0;
+  for (int c = 0; c < 16; ++c) {
+    double sc = 0.0;
+    if (mask & (1u << c)) {
+      sc = rb >= 0 ? v.scale_c[(size_t)rb * D + dst] : 0.0;
+      ++dst;
+    } else if (c >= 6 && (gmask & (1u << (c - 6)))) {
+      sc = v.scale_c[(size_t)grb * D + dst1];
+      ++dst1;
+    }
+    v.scale_cam[(size_t)cam * 16 + c] = sc;
+  }
+}
+
 // ------------------------------------------------------------------------------
 // linearize: residual + Jacobian blocks per observation (kernel class 0).
 // Thread (slice s, lane t) walks the observations of track 64 s + t.
@@ -229,6 +253,11 @@ __global__ __launch_bounds__(256) void linearize_kernel(DeviceView v, int loss_t
 #pragma unroll
       for (int i = 0; i < 6; ++i) E[i] = v.ext[(size_t)cam * 6 + i];
       const double fx = v.obs_xy[2 * e], fy = v.obs_xy[2 * e + 1];
+      // column scales of this view, fetched with the parameters and indexed statically below
+      // (keeps loads out of the store sequence; measured neutral on the kernel time)
+      double scf[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) scf[c] = v.scale_cam[(size_t)cam * 16 + c];
       // RT = double, or float for the fp32 residual path: everything downstream of the
       // evaluation (loss correction, scaling, normal equations) stays fp64
       RT rr[2], Jext[2][6], Jint[2][10], Jpt[2][4];
@@ -266,7 +295,6 @@ __global__ __launch_bounds__(256) void linearize_kernel(DeviceView v, int loss_t
       acc[1] += sq;
       // reduced camera block: free columns of [ext(6) | intr(10)], compacted
       int dst = 0;
-      const double* sc = v.scale_c + (size_t)(rb < 0 ? 0 : rb) * D;
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
         if (mask & (1u << c)) {
@@ -277,7 +305,7 @@ __global__ __launch_bounds__(256) void linearize_kernel(DeviceView v, int loss_t
             j0 = sqrt_rho1 * (j0 - asn * r[0] * rtj);
             j1 = sqrt_rho1 * (j1 - asn * r[1] * rtj);
           }
-          const double scl = sc[dst];
+          const double scl = scf[c];
           v.pm_A[pidx<2 * D>((2 * dst), e)] = j0 * scl;
           v.pm_A[pidx<2 * D>((2 * dst + 1), e)] = j1 * scl;
           ++dst;
@@ -290,7 +318,6 @@ __global__ __launch_bounds__(256) void linearize_kernel(DeviceView v, int loss_t
         int dst1 = 0;
         if (grb >= 0) {
           const unsigned gmask = v.grp_mask[grp];
-          const double* sc1 = v.scale_c + (size_t)grb * D;
 #pragma unroll
           for (int c = 0; c < 10; ++c) {
             if (gmask & (1u << c)) {
@@ -300,7 +327,7 @@ __global__ __launch_bounds__(256) void linearize_kernel(DeviceView v, int loss_t
                 j0 = sqrt_rho1 * (j0 - asn * r[0] * rtj);
                 j1 = sqrt_rho1 * (j1 - asn * r[1] * rtj);
               }
-              const double scl = sc1[dst1];
+              const double scl = scf[6 + c];
               v.pm_A1[pidx<2 * D>((2 * dst1), e)] = j0 * scl;
               v.pm_A1[pidx<2 * D>((2 * dst1 + 1), e)] = j1 * scl;
               ++dst1;
