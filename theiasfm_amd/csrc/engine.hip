@@ -1900,7 +1900,9 @@ int32_t tmi_ba_solver_evaluate(tmi_ba_solver* s, double* residuals, double* jac_
     const int64_t i = st.obs_orig[e];
     if (i < 0) continue;
     // the planes are tiled by 64 observations (kernels.h pidx)
-    auto at = [e](int npl, int plane) { return (e >> 6) * (size_t)(npl * 64) + (size_t)plane * 64 + (e & 63); };
+    auto at = [e](int npl, int plane) {
+      return (e >> 6) * (size_t)(npl * 64) + (size_t)(plane >> 1) * 128 + ((e & 63) << 1) + (size_t)(plane & 1);
+    };
     if (residuals) {
       residuals[2 * i] = r[at(2, 0)];
       residuals[2 * i + 1] = r[at(2, 1)];

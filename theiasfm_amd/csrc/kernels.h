@@ -30,7 +30,7 @@ __host__ __device__ constexpr int sym_idx(int a, int b, int n) {
 }
 __host__ __device__ constexpr int sym_size(int n) { return n * (n + 1) / 2; }
 // Per-observation planes are stored in TILES of 64 observations: element (plane, e) of an
-// NPL-plane buffer lives at (e / 64) * NPL * 64 + plane * 64 + e % 64.  A wave working on 64
+// NPL-plane buffer lives at (e / 64) * NPL * 64 + (plane / 2) * 128 + 2 (e % 64) + plane % 2.  A wave working on 64
 // consecutive observations then reads / writes ONE contiguous NPL * 512-byte region per buffer
 // instead of NPL regions No_pad * 8 bytes apart: `linearize` used to keep 26 write streams open
 // per wave and spent 63 % of its wave cycles in s_waitcnt at 2.3 TB/s of stores.
@@ -40,9 +40,11 @@ typedef double nt_double2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void store_nt(double* dst, const double* src) {
   __builtin_nontemporal_store(*reinterpret_cast<const nt_double2*>(src), reinterpret_cast<nt_double2*>(dst));
 }
+// Inside a tile the two rows of a column (planes 2a and 2a + 1: the u- and v-residual rows of the
+// same Jacobian column) are interleaved per lane, so both come and go in one 16-byte access per lane.
 template <int NPL>
 __host__ __device__ __forceinline__ size_t pidx(int plane, size_t e) {
-  return (e >> 6) * (size_t)(NPL * 64) + (size_t)plane * 64 + (e & 63);
+  return (e >> 6) * (size_t)(NPL * 64) + (size_t)(plane >> 1) * 128 + ((e & 63) << 1) + (size_t)(plane & 1);
 }
 // camera-major record strides in doubles, rounded up to whole 64-byte sectors so that a
 // record never straddles an extra sector (gathers) and is written as full sectors
