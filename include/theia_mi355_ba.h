@@ -181,8 +181,9 @@ typedef struct tmi_ba_options {
   double max_solver_time_in_seconds; /* 3600                                  */
   int32_t use_inner_iterations;      /* 1 (reference default, bundle_adjustment.h:112): after
                                         every trust-region step one coordinate-descent sweep
-                                        over intrinsics blocks, extrinsics blocks, points
-                                        (Ceres inner iterations), until their relative gain
+                                        over extrinsics blocks, intrinsics blocks, points
+                                        (Ceres inner iterations in the reversed solver
+                                        ordering, bundle_adjuster.cc:193-200), until their relative gain
                                         drops below 1e-3; evaluated in fp64 whatever
                                         residual_precision says                  */
   double function_tolerance;         /* 1e-6                                  */

@@ -1189,13 +1189,12 @@ int32_t oracle_adjust_tracks(tmi_ba_problem* P, const tmi_ba_options* O, int8_t*
  * use_inner_iterations = true, bundle_adjustment.h:112; bundle_adjuster.cc:74).  Ceres is
  * external to the reference: restated from the 1.14 sources' documented behaviour.
  *
- * Theia leaves inner_iteration_ordering empty, so Ceres computes one
- * (CoordinateDescentMinimizer::CreateOrdering = recursive independent sets of the Hessian
- * graph, reversed: "cameras before points").  Round 0 of the recursion takes every point
- * block; the extrinsics and intrinsics block of a view are adjacent, so rounds 1 and 2 split
- * them -- Ceres picks by degree and then by hash order, i.e. the reference leaves WHICH of
- * the two goes first undefined.  This restatement fixes it: intrinsics blocks, then
- * extrinsics blocks, then points.
+ * Theia sets the ordering explicitly (bundle_adjuster.cc:193-200): a copy of the linear
+ * solver ordering -- group 0 tracks, 1 intrinsics, 2 extrinsics (bundle_adjuster.cc:346-371)
+ * -- with ParameterBlockOrdering::Reverse() applied, so the coordinate descent visits the
+ * groups as  extrinsics blocks -> intrinsics blocks -> points.  Each group is an independent
+ * set (a residual touches one extrinsics, one intrinsics and one point block), which is what
+ * Ceres requires of a user-supplied inner_iteration_ordering.
  *
  * Every block of a set is minimised on its own with all other blocks constant:
  * TrustRegionMinimizer with default Minimizer::Options (50 iterations, function / gradient /
@@ -1291,6 +1290,12 @@ static void inner_solve_camera_block(const tmi_ba_problem* V, const tmi_ba_optio
   free(ext); free(cgrp); free(cflag); free(pts); free(pconst); free(ocam); free(opt); free(oxy);
 }
 
+/* Test hook: 0 = the reference's order (extrinsics, intrinsics, points); 1 = intrinsics before
+ * extrinsics (the order a round-1 misreading used; kept only so tests can show that the two
+ * orders are distinguishable and that the device follows the reference's). */
+static int g_inner_order = 0;
+void oracle_set_inner_order(int32_t order) { g_inner_order = order ? 1 : 0; }
+
 /* One sweep of the coordinate descent over the parameter arrays of V (in place). */
 static void inner_iterations(tmi_ba_problem* V, const tmi_ba_options* O) {
   tmi_ba_options o2;
@@ -1308,25 +1313,38 @@ static void inner_iterations(tmi_ba_problem* V, const tmi_ba_options* O) {
   for (int c = 0; c < Nc; ++c) gptr[V->camera_group[c] + 2]++;
   for (int g = 0; g < G; ++g) gptr[g + 2] += gptr[g + 1];
   for (int c = 0; c < Nc; ++c) gcam[gptr[V->camera_group[c] + 1]++] = c;
-  /* set 1: intrinsics blocks with a free coordinate */
+  for (int pass = 0; pass < 2; ++pass) {
+    const int kind = g_inner_order ? 1 - pass : pass;  /* 0 extrinsics, 1 intrinsics */
+    if (kind == 0) {
+      /* set 1: extrinsics blocks with a free coordinate */
 #pragma omp parallel for schedule(dynamic, 1)
-  for (int g = 0; g < G; ++g) {
-    int nfree = 0;
-    for (int a = V->group_offset[g]; a < V->group_offset[g + 1]; ++a)
-      nfree += !(V->intrinsics_constant && V->intrinsics_constant[a]);
-    if (nfree == 0 || gptr[g + 1] == gptr[g]) continue;
-    inner_solve_camera_block(V, &o2, 1, g, gcam + gptr[g], gptr[g + 1] - gptr[g], cam_ptr, cam_obs);
-  }
-  /* set 2: extrinsics blocks with a free coordinate */
+      for (int c = 0; c < Nc; ++c) {
+        const int f = V->camera_flags ? V->camera_flags[c] : 0;
+        if ((f & TMI_BA_CAMERA_POSITION_CONSTANT) && (f & TMI_BA_CAMERA_ORIENTATION_CONSTANT)) continue;
+        inner_solve_camera_block(V, &o2, 0, V->camera_group[c], &c, 1, cam_ptr, cam_obs);
+      }
+    } else {
+      /* set 2: intrinsics blocks with a free coordinate */
 #pragma omp parallel for schedule(dynamic, 1)
-  for (int c = 0; c < Nc; ++c) {
-    const int f = V->camera_flags ? V->camera_flags[c] : 0;
-    if ((f & TMI_BA_CAMERA_POSITION_CONSTANT) && (f & TMI_BA_CAMERA_ORIENTATION_CONSTANT)) continue;
-    inner_solve_camera_block(V, &o2, 0, V->camera_group[c], &c, 1, cam_ptr, cam_obs);
+      for (int g = 0; g < G; ++g) {
+        int nfree = 0;
+        for (int a = V->group_offset[g]; a < V->group_offset[g + 1]; ++a)
+          nfree += !(V->intrinsics_constant && V->intrinsics_constant[a]);
+        if (nfree == 0 || gptr[g + 1] == gptr[g]) continue;
+        inner_solve_camera_block(V, &o2, 1, g, gcam + gptr[g], gptr[g + 1] - gptr[g], cam_ptr, cam_obs);
+      }
+    }
   }
   /* set 3: the points, each against its (now constant) cameras */
   oracle_adjust_tracks(V, &o2, NULL, NULL, NULL, NULL);
   free(cam_ptr); free(cam_obs); free(gptr); free(gcam);
+}
+
+/* One coordinate-descent sweep at the problem's current parameters (in place); test entry. */
+int32_t oracle_inner_sweep(tmi_ba_problem* P, const tmi_ba_options* O) {
+  if (!O || !validate(P)) return TMI_BA_ERR_INVALID_ARGUMENT;
+  inner_iterations(P, O);
+  return TMI_BA_OK;
 }
 
 int32_t oracle_ba_solve(tmi_ba_problem* P, const tmi_ba_options* O, tmi_ba_summary* sum) {

@@ -42,6 +42,14 @@ extern "C" {
 int32_t oracle_ba_solve(tmi_ba_problem* problem, const tmi_ba_options* options,
                         tmi_ba_summary* summary);
 
+/* One inner-iteration (coordinate descent) sweep at the problem's current parameters, in
+ * place: extrinsics blocks, intrinsics blocks, points -- the reversed linear-solver ordering
+ * the reference hands to Ceres (bundle_adjuster.cc:193-200, groups :346-371). */
+int32_t oracle_inner_sweep(tmi_ba_problem* problem, const tmi_ba_options* options);
+/* Test hook: 1 swaps the first two sets (intrinsics before extrinsics), 0 restores the
+ * reference order.  Exists so tests can show the orders are distinguishable. */
+void oracle_set_inner_order(int32_t order);
+
 /* Per-observation evaluation with dual numbers at the problem's current
  * parameters, in the caller's observation order:
  *   residuals [2N]; jac_full [2*20*N] row-major 2x20 with columns

@@ -32,6 +32,10 @@ def lib():
         L.oracle_ba_solve.argtypes = [C.POINTER(abi.CProblem), C.POINTER(abi.COptions),
                                       C.POINTER(abi.CSummary)]
         L.oracle_ba_solve.restype = C.c_int32
+        L.oracle_inner_sweep.argtypes = [C.POINTER(abi.CProblem), C.POINTER(abi.COptions)]
+        L.oracle_inner_sweep.restype = C.c_int32
+        L.oracle_set_inner_order.argtypes = [C.c_int32]
+        L.oracle_set_inner_order.restype = None
         L.oracle_ba_evaluate.argtypes = [C.POINTER(abi.CProblem), C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_ba_evaluate.restype = C.c_int32
         L.oracle_ba_cost.argtypes = [C.POINTER(abi.CProblem), C.POINTER(abi.COptions),
@@ -68,6 +72,18 @@ def solve(problem: abi.Problem, options: abi.COptions):
     s = abi.CSummary()
     st = lib().oracle_ba_solve(C.byref(cp), C.byref(options), C.byref(s))
     return st, s
+
+
+def inner_sweep(problem: abi.Problem, options: abi.COptions):
+    """One coordinate-descent sweep (Ceres inner iterations) in place."""
+    cp = problem.as_c()
+    st = lib().oracle_inner_sweep(C.byref(cp), C.byref(options))
+    assert st == 0, st
+
+
+def set_inner_order(order: int):
+    """0 = reference order (extrinsics, intrinsics, points); 1 = intrinsics first (test hook)."""
+    lib().oracle_set_inner_order(int(order))
 
 
 def evaluate(problem: abi.Problem):

@@ -108,6 +108,21 @@ static void TestSemantics() {
     EXPECT(f.camera_group[0] == f.camera_group[1] && f.camera_group[2] != f.camera_group[0]);
   }
   {
+    // out-of-contract order (AddTrack pulls in view 1, AddView(1) comes later): the reference
+    // would duplicate the (view 1, track 0) residual block; the shim keeps it once and the
+    // view's extrinsics stay constant as AddTrack left them (bundle_adjuster.cc:164)
+    BundleAdjuster ba(opt, &rec);
+    ba.AddTrack(0);
+    ba.AddView(1);
+    FlattenedBundleAdjustmentProblem f;
+    EXPECT(ba.Flatten(&f));
+    // track 0 in views 0, 1, 2, 4 + view 1's other 6 estimated tracks
+    EXPECT(f.obs_camera.size() == 4u + 6u);
+    for (size_t q = 1; q < f.obs_camera.size(); ++q)
+      EXPECT(!(f.obs_camera[q] == f.obs_camera[q - 1] && f.obs_point[q] == f.obs_point[q - 1]));
+    for (size_t c = 0; c < f.view_ids.size(); ++c) EXPECT(f.camera_flags[c] == 3);
+  }
+  {
     // partial BA: optimise view 0 and track 0 only
     BundleAdjuster ba(opt, &rec);
     ba.AddView(0);

@@ -197,6 +197,63 @@ def test_fountain11_fixture_known_answer_and_ba(golden_dir):
             assert s_d.num_reduced_blocks == (11 if bits == abi.INTRINSICS_NONE else 12)
 
 
+def test_fountain11_point_gradient_vanishes_on_device(golden_dir):
+    """Pin to real Ceres output: the fixture's tracks were each optimised by Ceres
+    (estimate_track.cc:238-246), so the DEVICE's analytic point Jacobian and residual must give
+    J_p^T r ~ 0 there.  Same statistic and thresholds as tests/test_oracle_pins.py."""
+    prob = abi.Problem.load(os.path.join(golden_dir, "fountain11_flat.npz"))
+    s = lib.Solver(prob.copy(), abi.default_options(point_dof=4))
+    r, A, A1, Jp, valid, D = s.evaluate(4)
+    s.close()
+    assert valid.all()
+    pt = prob.obs_point
+    g = np.zeros((prob.num_points, 4))
+    n = np.zeros_like(g)
+    np.add.at(g, pt, np.einsum("nij,ni->nj", Jp, r))
+    np.add.at(n, pt, np.sqrt((Jp ** 2).sum(1)) * np.linalg.norm(r, axis=1)[:, None])
+    rel = np.abs(g) / np.maximum(n, 1e-300)
+    assert np.median(rel) < 1e-7
+    assert np.quantile(rel, 0.90) < 1e-5
+
+
+@pytest.mark.parametrize("loss", [abi.LOSS_SOFTLONE, abi.LOSS_ARCTAN, abi.LOSS_TUKEY, abi.LOSS_HUBER, abi.LOSS_CAUCHY])
+@pytest.mark.parametrize("solver", [abi.SPARSE_SCHUR, abi.ITERATIVE_SCHUR])
+def test_every_loss_function_matches_oracle(loss, solver):
+    """CreateLossFunction's six types (create_loss_function.cc:42-71): rho, rho', rho'' and the
+    Triggs correction on the device against the oracle, in a full solve with outliers."""
+    prob = synth.make_problem(16, 900, 5200, seed=77, scene="ring", spread=0.45)
+    prob.obs_xy[::41] += 30.0
+    # Tukey's rho' vanishes beyond the width: start close enough that inliers stay inside it
+    width = 6.0 if loss == abi.LOSS_TUKEY else 2.0
+    dev, ora = run_both(prob, linear_solver_type=solver, point_dof=3, loss_function_type=loss,
+                        robust_loss_width=width, max_num_iterations=12, use_inner_iterations=0)
+    assert_same_solution(dev, ora, scale=100.0, cost_rel=1e-9, rmse_abs=1e-9, param_rel=1e-6)
+    assert dev[1].final_cost < dev[1].initial_cost
+
+
+def test_inner_iteration_order_is_the_references():
+    """bundle_adjuster.cc:193-200: extrinsics blocks, then intrinsics blocks, then points.
+    The oracle's order is pinned on the CPU (tests/test_oracle_pins.py); here the device must
+    follow the reference order and be far from the swapped one."""
+    prob = synth.make_problem(6, 120, 560, seed=5, scene="ring", spread=0.6, shared_group_size=2,
+                              intrinsics_to_optimize=abi.INTRINSICS_FOCAL_LENGTH | abi.INTRINSICS_RADIAL_DISTORTION,
+                              perturb=3.0)
+    prob.intrinsics[prob.group_offset[:-1]] *= 1.02
+    opt = dict(linear_solver_type=abi.DENSE_SCHUR, point_dof=3, max_num_iterations=1, use_inner_iterations=1)
+    dev, ora = run_both(prob, **opt)
+    assert dev[1].num_inner_iteration_steps == 1
+    assert_same_solution(dev, ora, scale=100.0, cost_rel=1e-9, rmse_abs=1e-9, param_rel=1e-6)
+    try:
+        oracle.set_inner_order(1)
+        swapped = prob.copy()
+        st, s_sw = oracle.solve(swapped, abi.default_options(**opt))
+    finally:
+        oracle.set_inner_order(0)
+    assert st == 0
+    assert abs(s_sw.final_cost - dev[1].final_cost) > 1e-6 * dev[1].final_cost
+    assert np.abs(swapped.extrinsics - dev[2].extrinsics).max() > 1e-6
+
+
 def test_shared_and_private_intrinsics_groups_mixed():
     # groups of 1..4 views, three camera models, robust loss: the shared-block path next
     # to merged private blocks in one problem
@@ -345,7 +402,8 @@ def test_track_lane_mapping_does_not_change_the_result(wide_k, dof, solver, mode
 @pytest.mark.parametrize("case", ["private", "shared", "robust_mixed", "anchored"])
 def test_inner_iterations_match_oracle(dof, case):
     """use_inner_iterations = 1 (the reference default): after every trust-region step one
-    coordinate-descent sweep over intrinsics blocks, extrinsics blocks and points.  Device:
+    coordinate-descent sweep over extrinsics blocks, intrinsics blocks and points (the reversed
+    solver ordering, bundle_adjuster.cc:193-200).  Device:
     batched per-block LM kernels (inner_kernels.h) + the batched track solver; oracle: its LM on
     one-block sub-problems.  point_dof = 3 agrees to round-off; with 4 the free scale of the
     homogeneous points limits agreement to ~1e-5."""

@@ -126,7 +126,8 @@ def test_filter_on_resident_solver_after_ba_and_sharded():
 
 
 @pytest.mark.parametrize("dof", [3, 4])
-@pytest.mark.parametrize("loss", [abi.LOSS_TRIVIAL, abi.LOSS_HUBER, abi.LOSS_CAUCHY])
+@pytest.mark.parametrize("loss", [abi.LOSS_TRIVIAL, abi.LOSS_HUBER, abi.LOSS_CAUCHY, abi.LOSS_SOFTLONE,
+                                  abi.LOSS_ARCTAN, abi.LOSS_TUKEY])
 def test_adjust_tracks_matches_oracle(dof, loss):
     P = synth.make_problem(20, 1500, 7000, seed=31 + dof, scene="ring", spread=0.3, models=MODELS)
     rng = np.random.default_rng(7)

@@ -1045,7 +1045,9 @@ static int run_inner_sweep(tmi_ba_solver* s, const tmi_ba_options* O) {
   TMI_HIP(hipMemcpyAsync(I.bak_ext, v.ext_c, (size_t)6 * st.Nc * sizeof(double), hipMemcpyDeviceToDevice, stream));
   if (s->n_intr) TMI_HIP(hipMemcpyAsync(I.bak_intr, v.intr_c, (size_t)s->n_intr * sizeof(double), hipMemcpyDeviceToDevice, stream));
   TMI_HIP(hipMemcpyAsync(I.bak_pts, v.pts_c, (size_t)4 * st.Np_pad * sizeof(double), hipMemcpyDeviceToDevice, stream));
-  for (int kind = 1; kind >= 0; --kind) {  // intrinsics blocks, then extrinsics blocks
+  // reversed linear-solver ordering (bundle_adjuster.cc:193-200 with the groups of :346-371):
+  // extrinsics blocks, then intrinsics blocks, then the points
+  for (int kind = 0; kind <= 1; ++kind) {
     InnerSet S = I.set[kind];
     if (S.nblocks == 0 || st.Nc == 0) continue;
     S.x = kind == 0 ? v.ext_c : v.intr_c;

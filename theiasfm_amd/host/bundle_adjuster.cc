@@ -237,15 +237,24 @@ bool BundleAdjuster::Flatten(FlattenedBundleAdjustmentProblem* f) {
   for (size_t p = 0; p < np; ++p)
     std::sort(order.begin() + first[p], order.begin() + first[p + 1],
               [&](uint32_t a, uint32_t b) { return residuals_[a].view < residuals_[b].view; });
-  f->obs_camera.resize(n);
-  f->obs_point.resize(n);
-  f->obs_xy.resize(2 * n);
+  // A (view, track) pair can have been pushed twice when AddTrack(t) pulled in a view that a
+  // later AddView(v) adds again -- a call order outside the class contract ("AddView before
+  // AddTrack", bundle_adjuster.h:58-59; the free functions follow it).  The reference would
+  // then hold the residual block twice; the device layout holds an observation once, so the
+  // duplicate is dropped here (the view's extrinsics stay constant, as in the reference).
+  f->obs_camera.reserve(n);
+  f->obs_point.reserve(n);
+  f->obs_xy.reserve(2 * n);
   for (size_t q = 0; q < n; ++q) {
     const Residual& r = residuals_[order[q]];
-    f->obs_camera[q] = cam_index(r.view);
-    f->obs_point[q] = pt_of[order[q]];
-    f->obs_xy[2 * q] = r.x;
-    f->obs_xy[2 * q + 1] = r.y;
+    if (q > 0) {
+      const Residual& prev = residuals_[order[q - 1]];
+      if (prev.view == r.view && prev.track == r.track) continue;
+    }
+    f->obs_camera.push_back(cam_index(r.view));
+    f->obs_point.push_back(pt_of[order[q]]);
+    f->obs_xy.push_back(r.x);
+    f->obs_xy.push_back(r.y);
   }
   return true;
 }
