@@ -1,18 +1,25 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X bundle-adjustment engine (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W [--workload venice1778]
+  python bench.py --gpus N --steps K --warmup W [--workload venice1778_heavy]
 
 A "step" is one Levenberg-Marquardt iteration (linearize, eliminate tracks,
 build + solve the reduced camera system, back-substitute, trial cost) of the
 synthetic BAL-Venice-1778-sized problem (1778 cameras / 993 923 tracks /
 5 001 946 observations, fp64, 9-dof cameras, 3-dof points, ITERATIVE_SCHUR as
 the reference's own policy picks for >= 1000 views,
-reconstruction_estimator_utils.cc:121-125).  The timed region is ONE
-tmi_ba_solver_solve call running exactly K iterations (tolerances zeroed) on
-inputs already resident in HBM; W warm-up iterations run first and the
-parameters are reset.  value = N_obs * K / wall time = observations/s over all
-ranks (strong scaling: the problem is fixed, tracks are sharded over ranks).
+reconstruction_estimator_utils.cc:121-125; the default workload is the
+heavy-tailed variant of SURVEY 8(d) config 4, tracks of up to 400 views).  The
+timed region runs exactly K iterations on inputs already resident in HBM, as
+ceil(K / 10) solves of <= 10 iterations from the same perturbed start
+(tolerances disabled; the problem converges in ~12 iterations, so a single long
+solve would coast at the fixed point) with a device-side parameter reset in
+between; W warm-up iterations run first.  value = N_obs * K / wall time =
+observations/s over all ranks (strong scaling: the problem is fixed, tracks
+are sharded over ranks).  Beside the headline (1 GPU): the reference's default
+operating point (inner iterations on), the CPU port on all cores and on one
+core, the end-to-end wall clock of the C++ entry point, the side kernels and
+the plain venice1778 variant.
 
 For N > 1 launch with
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -78,14 +85,35 @@ def pmc_traffic(kernel_class: str, workload: str, world: int):
     return None if v is None else int(v)
 
 
+def write_problem_file(prob, path):
+    """flat problem for tools/e2e_bench.cc (PINHOLE, one intrinsics group per view)"""
+    import numpy as np
+    assert prob.num_groups == prob.num_cameras and (prob.group_model == 0).all()
+    with open(path, "wb") as f:
+        np.array([prob.num_cameras, prob.num_points, prob.num_observations], dtype=np.int64).tofile(f)
+        prob.extrinsics.astype(np.float64).tofile(f)
+        prob.intrinsics.astype(np.float64).tofile(f)
+        prob.points.astype(np.float64).tofile(f)
+        prob.obs_camera.astype(np.int32).tofile(f)
+        prob.obs_point.astype(np.int32).tofile(f)
+        prob.obs_xy.astype(np.float64).tofile(f)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="venice1778",
+    ap.add_argument("--workload", default="venice1778_heavy",
                     choices=["tiny", "ladybug49", "alamo", "venice1778", "venice1778_heavy"])
+    ap.add_argument("--solve-length", type=int, default=10,
+                    help="LM iterations per solve: the K timed iterations are ceil(K / this) solves from the "
+                         "same perturbed start (the problem converges in ~12 iterations; a single K-iteration "
+                         "solve would coast at the fixed point)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the lines beside the headline: plain venice1778, inner iterations, end-to-end "
+                         "C++ entry point, side kernels")
     ap.add_argument("--cpu-iters", type=int, default=2)
     ap.add_argument("--transport", default="rccl", choices=["rccl", "torch", "staged"],
                     help="rccl: ncclAllReduce issued by the engine; torch: torch.distributed (nccl) hook; staged: "
@@ -122,41 +150,24 @@ def main():
     if world > 1:
         torch.distributed.barrier()
 
-    t0 = time.perf_counter()
-    prob = synth.config(args.workload)
-    t_gen = time.perf_counter() - t0
-    n_obs, n_cam, n_pts = prob.num_observations, prob.num_cameras, prob.num_points
-    # the reference's solver-type policy (reconstruction_estimator_utils.cc:110-133)
-    if n_cam >= 1000:
-        solver_type, solver_name = abi.ITERATIVE_SCHUR, "ITERATIVE_SCHUR/SCHUR_JACOBI"
-    elif n_cam >= 150:
-        solver_type, solver_name = abi.SPARSE_SCHUR, "SPARSE_SCHUR (exact, dense Cholesky of S)"
-    else:
-        solver_type, solver_name = abi.DENSE_SCHUR, "DENSE_SCHUR (exact)"
+    def solver_policy(n_cam):
+        # the reference's solver-type policy (reconstruction_estimator_utils.cc:110-133)
+        if n_cam >= 1000:
+            return abi.ITERATIVE_SCHUR, "ITERATIVE_SCHUR/SCHUR_JACOBI"
+        if n_cam >= 150:
+            return abi.SPARSE_SCHUR, "SPARSE_SCHUR (exact, dense Cholesky of S)"
+        return abi.DENSE_SCHUR, "DENSE_SCHUR (exact)"
+
     schur_mode = {"auto": 0, "explicit": 1, "implicit": 2}[args.schur_mode]
-    # use_inner_iterations = 0: a step is the trust-region iteration proper (the coordinate-descent
-    # sweep Ceres can add after each step is measured by the parity tests, not here), on the
-    # device and in the CPU baseline alike
-    base = dict(point_dof=3, linear_solver_type=solver_type, function_tolerance=0.0,
-                gradient_tolerance=0.0, parameter_tolerance=0.0, device=local, schur_mode=schur_mode,
-                residual_precision=args.residual_precision, use_inner_iterations=0)
-    opts = abi.default_options(max_num_iterations=max(args.warmup, 1), **base)
-    prob0 = prob.copy() if (world == 1 and not args.no_cpu_baseline) else None  # Solver.download() writes into `prob`
-    t0 = time.perf_counter()
-    solver = lib.Solver(prob, opts, rank, world)
-    transport = "none"
-    if world > 1:
-        # RCCL over xGMI: natively from the engine (ncclAllReduce on its own stream); the
-        # torch.distributed hook is the fallback (and --transport torch forces it)
-        if args.transport == "staged":
-            solver.set_allreduce(dist.make_staged_allreduce())
-            transport = "gloo, staged through host memory (functional check only)"
-        elif args.transport == "rccl" and dist.init_native_rccl(solver, rank, world):
-            transport = "rccl (native, ncclAllReduce from the engine)"
-        else:
-            solver.set_allreduce(dist.make_device_allreduce())
-            transport = "rccl via torch.distributed hook"
-    t_create = time.perf_counter() - t0
+
+    def base_options(n_cam):
+        # Tolerances are DISABLED (negative: |dcost| <= tol * cost etc. can never hold), so a solve
+        # runs exactly max_num_iterations trust-region iterations.  use_inner_iterations = 0 for the
+        # headline: a step is the trust-region iteration proper, on the device and in the CPU baseline
+        # alike; the reference's default (inner iterations on) is timed beside it below.
+        return dict(point_dof=3, linear_solver_type=solver_policy(n_cam)[0], function_tolerance=-1.0,
+                    gradient_tolerance=-1.0, parameter_tolerance=-1.0, device=local, schur_mode=schur_mode,
+                    residual_precision=args.residual_precision, use_inner_iterations=0)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -164,52 +175,97 @@ def main():
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
-    # Warm-up (W iterations), then an untimed pass of the same K iterations with every kernel
-    # class timed (HIP events on the engine's stream): it gives the per-class table and tells
-    # which class dominates.  The timed region carries events for THAT class only (two event
-    # records per launch of every class cost a few % of an iteration).
-    if args.warmup > 0:
-        opts_w = abi.default_options(max_num_iterations=args.warmup, **base)
-        st, s = solver.solve(opts_w)
-        if st != 0:
-            raise RuntimeError(f"warm-up solve failed: {st} {s.message!r}")
+    def run_chunks(solver, base, steps, profile):
+        """`steps` LM iterations as solves of --solve-length iterations from the start point; the
+        device-resident reset between two solves is part of the region.  Returns (iterations run,
+        summed kernel seconds, summed launches, last summary, PCG iterations, accepted steps)."""
+        left, done = steps, 0
+        secs = [0.0] * abi.NUM_KERNEL_CLASSES
+        launches = [0] * abi.NUM_KERNEL_CLASSES
+        pcg = acc = 0
+        s = None
+        while left > 0:
+            n = min(left, max(1, args.solve_length))
+            st, s = solver.solve(abi.default_options(max_num_iterations=n, profile_kernels=profile, **base))
+            if st != 0:
+                raise RuntimeError(f"solve failed: {st} {s.message!r}")
+            done += int(s.num_iterations)
+            pcg += int(s.num_linear_solver_iterations)
+            acc += int(s.num_successful_steps)
+            for i in range(abi.NUM_KERNEL_CLASSES):
+                secs[i] += s.kernel_seconds[i]
+                launches[i] += s.kernel_launches[i]
+            left -= n
+            if int(s.num_iterations) != n:
+                break  # a failure mode (invalid steps, minimum radius): reported through steps != K
+            if left > 0:
+                solver.reset()
+        return done, secs, launches, s, pcg, acc
+
+    def measure(workload, steps, warmup, with_transport):
+        """creates the resident solver, warms up, profiles, times; returns a dict of raw results"""
+        t0 = time.perf_counter()
+        prob = synth.config(workload)
+        t_gen = time.perf_counter() - t0
+        base = base_options(prob.num_cameras)
+        prob0 = prob.copy() if rank == 0 else None  # Solver.download() writes into `prob`
+        t0 = time.perf_counter()
+        solver = lib.Solver(prob, abi.default_options(max_num_iterations=1, **base), rank, world)
+        transport = "none"
+        if world > 1 and with_transport:
+            # RCCL over xGMI: natively from the engine (ncclAllReduce on its own stream); the
+            # torch.distributed hook is the fallback (and --transport torch forces it)
+            if args.transport == "staged":
+                solver.set_allreduce(dist.make_staged_allreduce())
+                transport = "gloo, staged through host memory (functional check only)"
+            elif args.transport == "rccl" and dist.init_native_rccl(solver, rank, world):
+                transport = "rccl (native, ncclAllReduce from the engine)"
+            else:
+                solver.set_allreduce(dist.make_device_allreduce())
+                transport = "rccl via torch.distributed hook"
+        t_create = time.perf_counter() - t0
+        if warmup > 0:
+            st, s = solver.solve(abi.default_options(max_num_iterations=warmup, **base))
+            if st != 0:
+                raise RuntimeError(f"warm-up solve failed: {st} {s.message!r}")
+            solver.reset()
+        # untimed pass of the same iterations with every kernel class timed (HIP events on the engine's
+        # stream): the per-class table, and which class dominates.  The timed region carries events for
+        # THAT class only (two event records per launch of every class cost a few % of an iteration).
+        _, secs_p, launches_p, _, _, _ = run_chunks(solver, base, steps, 1)
+        secs_nc = list(secs_p)
+        secs_nc[abi.KERNEL_CLASS_NAMES.index("allreduce")] = 0.0
+        dom_idx = max(range(len(secs_nc)), key=lambda i: secs_nc[i])
         solver.reset()
-    opts_p = abi.default_options(max_num_iterations=args.steps, profile_kernels=1, **base)
-    st_p, s_p = solver.solve(opts_p)
-    if st_p != 0:
-        raise RuntimeError(f"profiling pass failed: {st_p} {s_p.message!r}")
-    d_p = s_p.as_dict()
-    secs = list(s_p.kernel_seconds)
-    secs[abi.KERNEL_CLASS_NAMES.index("allreduce")] = 0.0
-    dom_idx = max(range(len(secs)), key=lambda i: secs[i])
-    solver.reset()
+        sync_all()
+        t0 = time.perf_counter()
+        done, secs_t, launches_t, s, pcg, acc = run_chunks(solver, base, steps, (1 << dom_idx) if dom_idx > 0 else 1)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            torch.distributed.barrier()
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.transport == "staged" else "cuda")
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return dict(prob=prob, prob0=prob0, base=base, solver=solver, transport=transport, t_gen=t_gen,
+                    t_create=t_create, steps_run=done, elapsed=elapsed, summary=s, pcg=pcg, accepted=acc,
+                    secs_p=secs_p, launches_p=launches_p, secs_t=secs_t, launches_t=launches_t, dom_idx=dom_idx)
 
-    opts_t = abi.default_options(max_num_iterations=args.steps,
-                                 profile_kernels=(1 << dom_idx) if dom_idx > 0 else 1, **base)
-    sync_all()
-    t0 = time.perf_counter()
-    st, s = solver.solve(opts_t)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        torch.distributed.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.transport == "staged" else "cuda")
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
-    if st != 0:
-        raise RuntimeError(f"timed solve failed: {st} {s.message!r}")
-    steps_run = int(s.num_iterations)
-    d = s.as_dict()
-
+    m = measure(args.workload, args.steps, args.warmup, True)
+    solver, s, prob, prob0, base = m["solver"], m["summary"], m["prob"], m["prob0"], m["base"]
+    steps_run, elapsed = m["steps_run"], m["elapsed"]
+    n_obs, n_cam, n_pts = prob.num_observations, prob.num_cameras, prob.num_points
+    solver_type, solver_name = solver_policy(n_cam)
     if rank != 0:
         solver.close()
         return
 
     dc, dp = int(s.reduced_block_dim), 3
     nnzb = int(s.num_schur_blocks)
-    def table(dd):
+
+    def table(launch_list, sec_list):
         rows = []
-        for name, launches, sec in zip(abi.KERNEL_CLASS_NAMES, dd["kernel_launches"], dd["kernel_seconds"]):
+        for name, launches, sec in zip(abi.KERNEL_CLASS_NAMES, launch_list, sec_list):
             if launches == 0 or sec <= 0.0:
                 continue
             # per-rank launch: this rank's share of the observations / tracks
@@ -220,17 +276,35 @@ def main():
                              achieved_GBs=round(ab / avg / 1e9, 2) if avg > 0 else None))
         return rows
 
-    kernels = table(d_p)
-    dom_name = abi.KERNEL_CLASS_NAMES[dom_idx]
-    timed_rows = [k for k in table(d) if k["kernel"] == dom_name]
+    kernels = table(m["launches_p"], m["secs_p"])
+    dom_name = abi.KERNEL_CLASS_NAMES[m["dom_idx"]]
+    timed_rows = [k for k in table(m["launches_t"], m["secs_t"]) if k["kernel"] == dom_name]
     dom = timed_rows[0] if timed_rows else max((k for k in kernels if k["kernel"] != "allreduce"),
                                                key=lambda k: k["total_ms"])
     roofline = dict(bound="hbm", kernel=dom["kernel"], achieved=dom["achieved_GBs"], peak=HBM_PEAK_GBS,
                     unit="GB/s", frac=round(dom["achieved_GBs"] / HBM_PEAK_GBS, 5),
                     traffic=pmc_traffic(dom["kernel"], args.workload, world),
+                    traffic_source="profiles/pmc_latest.json: rocprofv3 --pmc passes of this command, committed "
+                                   "(counters cannot be read from inside the process)",
                     launches=dom["launches"], avg_us=dom["avg_us"],
                     algorithmic_bytes_per_launch=dom["algorithmic_bytes_per_launch"],
                     measured="HIP events on the engine's stream inside the timed region")
+
+    explicit = not (int(s.num_schur_pairs) == 0 and solver_type == abi.ITERATIVE_SCHUR)
+    n_r = n_cam * dc
+    if world > 1:
+        # doubles all-reduced per LM iteration
+        per_lm = (nnzb * dc * dc + n_cam * 3 * dc + 8) if explicit else (n_cam * (dc * dc + 3 * dc) + 8)
+        per_pcg = 0 if explicit else n_r
+        n_pcg_it = m["pcg"] / max(steps_run, 1)
+        allreduce = dict(bytes_per_lm_iteration=int(8 * (per_lm + 8 + per_pcg * n_pcg_it)),
+                         collectives_per_lm_iteration=round(2 + (0 if explicit else n_pcg_it), 2),
+                         note=("one all-reduce of the reduced camera normal equations per LM iteration" if explicit else
+                               "matrix-free operator: the diagonal blocks + gradients once per LM iteration and the "
+                               "reduced vector (8 d_c N_c bytes) once per PCG iteration -- deviates from the "
+                               "north-star wording, S itself would be ~0.8 GB per iteration"))
+    else:
+        allreduce = None
 
     out = dict(
         metric="ba_observations_per_sec", value=n_obs * steps_run / elapsed, unit="observations/s",
@@ -240,24 +314,28 @@ def main():
         data="synthetic",
         config=dict(workload=f"{args.workload}-synthetic", cameras=n_cam, tracks=n_pts,
                     observations=n_obs, camera_dof=dc, point_dof=dp, linear_solver=solver_name,
-                    loss="TRIVIAL",
-                    schur_operator=("implicit (matrix-free)" if int(s.num_schur_pairs) == 0 and
-                                    solver_type == abi.ITERATIVE_SCHUR else "explicit block-sparse S"),
-                    parallelism=f"tracks sharded x{world}", transport=transport),
+                    loss="TRIVIAL", use_inner_iterations=0,
+                    solves=f"{-(-args.steps // max(1, args.solve_length))} x <= {args.solve_length} iterations from the "
+                           "perturbed start, device-side reset in between (inside the timed region)",
+                    schur_mode=args.schur_mode,
+                    schur_operator=("explicit block-sparse S" if explicit else "implicit (matrix-free)"),
+                    parallelism=f"tracks sharded x{world}", transport=m["transport"]),
         lm_iterations_per_sec=steps_run / elapsed,
-        pcg_iterations=int(s.num_linear_solver_iterations),
+        pcg_iterations=int(m["pcg"]),
         initial_cost=s.initial_cost, final_cost=s.final_cost, initial_rmse=s.initial_rmse,
-        final_rmse=s.final_rmse, accepted_steps=int(s.num_successful_steps),
+        final_rmse=s.final_rmse, accepted_steps=int(m["accepted"]),
         schur_blocks_upper=nnzb, schur_pairs=int(s.num_schur_pairs),
-        setup_seconds=dict(generate=round(t_gen, 3), create_upload=round(t_create, 3)),
+        setup_seconds=dict(generate=round(m["t_gen"], 3), create_upload=round(m["t_create"], 3)),
         roofline=roofline, kernels=kernels,
         kernels_note="per-class table: separate untimed pass of the same iterations with every class timed")
+    if allreduce:
+        out["allreduce"] = allreduce
     if steps_run != args.steps:
-        out["note"] = f"solver stopped after {steps_run} of {args.steps} iterations: {d['message']}"
+        out["note"] = f"solver stopped after {steps_run} of {args.steps} iterations: {s.message!r}"
     # Whole-iteration figure of SURVEY 8(d): B_iter = B_lin + B_schur + B_pcg + B_back + B_cost with the
     # measured block count and PCG iterations (intermediates -- Jacobians, Y -- are not algorithmic)
     sym = lambda n: n * (n + 1) // 2  # noqa: E731
-    n_pcg = int(s.num_linear_solver_iterations) / max(steps_run, 1)
+    n_pcg = m["pcg"] / max(steps_run, 1)
     b_lin = n_obs * 24 + n_cam * 8 * dc + n_pts * 8 * dp + n_cam * 8 * (sym(dc) + dc) + n_pts * 8 * (sym(dp) + dp)
     b_schur = 2 * nnzb * 8 * dc * dc
     b_pcg = n_pcg * (nnzb * 8 * dc * dc + 6 * n_cam * 8 * dc)
@@ -268,8 +346,27 @@ def main():
         algorithmic_bytes_per_lm_iteration=int(b_iter), pcg_iterations_per_lm_iteration=round(n_pcg, 2),
         achieved_GBs=round(b_iter * steps_run / elapsed / 1e9, 1), peak_GBs=HBM_PEAK_GBS * world,
         frac=round(b_iter * steps_run / elapsed / 1e9 / (HBM_PEAK_GBS * world), 5),
-        note="SURVEY 8(d) formula; the kernels move ~19 GB per iteration (profiles/), ~4x these bytes, because "
-             "Jacobian blocks and the per-observation Schur factors are stored and gathered rather than recomputed")
+        note="SURVEY 8(d) formula; the kernels move several times these bytes (profiles/) because Jacobian blocks "
+             "and the per-observation Schur factors are stored and gathered rather than recomputed")
+
+    extras = world == 1 and not args.no_extras
+    if extras:
+        # ---- the reference's default operating point: inner iterations ON
+        # (reconstruction_estimator_utils.cc:117, bundle_adjustment.h:112), same problem, same start
+        solver.reset()
+        n_in = min(5, args.steps)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        st_i, s_i = solver.solve(abi.default_options(max_num_iterations=n_in, **{**base, "use_inner_iterations": 1}))
+        torch.cuda.synchronize()
+        t_in = time.perf_counter() - t0
+        out["with_inner_iterations"] = dict(
+            steps=int(s_i.num_iterations), ms_per_step=round(1e3 * t_in / max(int(s_i.num_iterations), 1), 3),
+            observations_per_s=n_obs * int(s_i.num_iterations) / t_in,
+            coordinate_descent_sweeps=int(s_i.num_inner_iteration_steps), final_cost=s_i.final_cost,
+            status=int(st_i),
+            note="one solve of the first iterations with use_inner_iterations = 1 (Ceres switches the sweeps off "
+                 "once their relative gain drops below 1e-3)")
 
     if world == 1 and not args.no_cpu_baseline:
         # CPU baseline: the in-repo oracle (Ceres-semantics restatement; the real
@@ -297,9 +394,63 @@ def main():
             rel_cost_diff=abs(s_d.final_cost - s_o.final_cost) / s_o.final_cost,
             rmse_abs_diff=abs(s_d.final_rmse - s_o.final_rmse))
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        # Theia's default is num_threads = 1 (bundle_adjustment.h:107): the same port on ONE core, on a
+        # bounded sample -- every 48th track with all its observations, all cameras
+        keep_pts = np.arange(0, n_pts, 48)
+        remap = np.full(n_pts, -1, dtype=np.int64)
+        remap[keep_pts] = np.arange(keep_pts.size)
+        sel = np.flatnonzero(remap[prob0.obs_point] >= 0)
+        sub = abi.Problem(prob0.extrinsics.copy(), prob0.camera_group.copy(), prob0.camera_flags.copy(),
+                          prob0.group_model.copy(), prob0.group_offset.copy(), prob0.intrinsics.copy(),
+                          prob0.intrinsics_constant.copy(), prob0.points[keep_pts].copy(),
+                          prob0.point_constant[keep_pts].copy(), prob0.obs_camera[sel].copy(),
+                          remap[prob0.obs_point[sel]].astype(np.int32), prob0.obs_xy[sel].copy())
+        nthr = oracle.num_threads()
+        oracle.set_num_threads(1)
+        try:
+            st_1, s_1 = oracle.solve(sub, abi.default_options(max_num_iterations=2, **{**base, "device": -1}))
+        finally:
+            oracle.set_num_threads(nthr)
+        out["cpu_baseline_single_thread"] = dict(
+            value=sub.num_observations * int(s_1.num_iterations) / s_1.solve_time_in_seconds, unit="observations/s",
+            cores=1, kind="port",
+            sample=f"{int(s_1.num_iterations)} LM iterations on every 48th track ({sub.num_observations} observations, "
+                   f"all {n_cam} cameras), solve {s_1.solve_time_in_seconds:.2f} s")
+        out["speedup_vs_cpu_single_thread"] = out["value"] / out["cpu_baseline_single_thread"]["value"]
+
+    if extras:
+        # ---- end-to-end wall clock of the drop-in C++ entry point on the same problem:
+        # theia::BundleAdjustReconstruction = AddView/AddTrack + flatten + structure build + upload +
+        # LM + download + write-back (tools/e2e_bench.cc).  NOT the headline value (inputs start on the host).
+        import subprocess
+        import tempfile
+        entry.build_host_shim()
+        exe = os.path.join(ROOT, "tools", "e2e_bench")
+        if os.path.exists(exe):
+            with tempfile.TemporaryDirectory() as td:
+                path = os.path.join(td, "problem.bin")
+                write_problem_file(prob0, path)
+                solver.close()  # free the HBM of the resident solver first
+                solver = None
+                e2e = {}
+                for key, inner in (("inner_iterations_off", 0), ("inner_iterations_on", 1)):
+                    p = subprocess.run([exe, path, str(args.solve_length), str(inner), "2" if inner == 0 else "1"],
+                                       capture_output=True, text=True, timeout=900)
+                    try:
+                        e2e[key] = json.loads(p.stdout.strip().splitlines()[-1])
+                    except (ValueError, IndexError):
+                        e2e[key] = dict(error=(p.stderr or p.stdout)[-400:], returncode=p.returncode)
+                out["end_to_end"] = e2e
+        if solver is None:
+            solver = lib.Solver(prob0.copy(), abi.default_options(max_num_iterations=1, **base), 0, 1)
+
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle
         # The steps either side of the BA on the same resident
         # problem, outside the timed region: kernel time from HIP events, the oracle beside it.
         side = {}
+        solver.reset()
+        solver.solve(abi.default_options(max_num_iterations=max(1, args.cpu_iters), **base))
         adjusted = solver.download().copy()
         flag_d, _, fs = solver.filter_outlier_tracks(4.0, 2.0)
         flag_d, _, fs = solver.filter_outlier_tracks(4.0, 2.0)  # second launch: warm
@@ -344,6 +495,15 @@ def main():
             selection_equal=bool((sel_d == sel_o).all()))
         out["side_kernels"] = side
     solver.close()
+
+    if extras and args.workload == "venice1778_heavy":
+        # the same sizes with geometric track lengths only (max 63): round 1's headline workload
+        mp = measure("venice1778", args.steps, args.warmup, False)
+        mp["solver"].close()
+        out["variants"] = {"venice1778-synthetic": dict(
+            ms_per_step=round(1e3 * mp["elapsed"] / max(mp["steps_run"], 1), 4), steps=mp["steps_run"],
+            value=n_obs * mp["steps_run"] / mp["elapsed"], schur_pairs=int(mp["summary"].num_schur_pairs),
+            pcg_iterations=int(mp["pcg"]), final_rmse=mp["summary"].final_rmse)}
     print(json.dumps(out))
 
 

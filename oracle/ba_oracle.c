@@ -99,6 +99,14 @@ int32_t oracle_num_threads(void) {
 #endif
 }
 
+void oracle_set_num_threads(int32_t n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 static int model_size(int model) {
   /* kIntrinsicsSize: pinhole_camera_model.h:84, pinhole_radial_tangential_
    * camera_model.h:89, fisheye_camera_model.h:65, fov_camera_model.h:67,

@@ -121,6 +121,8 @@ int32_t oracle_select_good_tracks(const tmi_ba_problem* problem, int32_t long_tr
                                   int32_t* stats_len, double* stats_err);
 
 int32_t oracle_num_threads(void);
+/* OpenMP threads used by the calls that follow (bench.py: single-thread baseline). */
+void oracle_set_num_threads(int32_t n);
 
 #ifdef __cplusplus
 }

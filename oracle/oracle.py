@@ -18,8 +18,17 @@ _LIB_PATH = os.path.join(_HERE, "liboracle_ba.so")
 _lib = None
 
 
+def _stale() -> bool:
+    if not os.path.exists(_LIB_PATH):
+        return True
+    t = os.path.getmtime(_LIB_PATH)
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h")) or f == "Makefile"]
+    srcs.append(os.path.join(_HERE, "..", "include", "theia_mi355_ba.h"))
+    return any(os.path.exists(f) and os.path.getmtime(f) > t for f in srcs)
+
+
 def build(force: bool = False) -> str:
-    if force or not os.path.exists(_LIB_PATH):
+    if force or _stale():
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _LIB_PATH
 
@@ -51,6 +60,8 @@ def lib():
         L.oracle_intrinsics_constant_mask.argtypes = [C.c_int32, C.c_int32, C.c_void_p]
         L.oracle_intrinsics_constant_mask.restype = C.c_int32
         L.oracle_num_threads.restype = C.c_int32
+        L.oracle_set_num_threads.argtypes = [C.c_int32]
+        L.oracle_set_num_threads.restype = None
         L.oracle_select_good_tracks.argtypes = [C.POINTER(abi.CProblem), C.c_int32, C.c_int32, C.c_int32,
                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_select_good_tracks.restype = C.c_int32
@@ -215,3 +226,7 @@ def select_good_tracks(problem: abi.Problem, long_track_length_threshold: int,
 
 def num_threads() -> int:
     return lib().oracle_num_threads()
+
+
+def set_num_threads(n: int) -> None:
+    lib().oracle_set_num_threads(int(n))

@@ -423,6 +423,140 @@ __device__ __forceinline__ bool reprojection_error(int model, const double* ext,
   return true;
 }
 
+// ------------------------------------------------------------------------------
+// Prepared per-camera record (camera_prepare_kernel, kernels.h).  The rotation
+// q = R(w) a is evaluated N_obs times per pass but depends on the CAMERA only:
+// sqrt, sincos and the divisions of Rodrigues' formula run once per camera per
+// parameter set; the per-observation work is two 3x3 products.  The derivative
+// wrt the angle-axis uses the left Jacobian of SO(3): R(w + d) = exp([Jl d]x) R(w), so
+//   dq/dw_k = Jl[:,k] x q   and   dpdq_r . dq/dw_k = Jl[:,k] . (q x dpdq_r).
+// In the first-order branch of ceres::AngleAxisRotatePoint (theta^2 <= DBL_EPSILON:
+// q = a + w x a, reprojection_error.h:81 / ceres rotation.h) the executed expression has
+// dq/dw_k = e_k x a: there Jl = I and the cross product takes a instead of q (`small`).
+//   [0..8]   R row-major            [9..11]  C              [12..21] intrinsics (zero padded)
+//   [22]     small-angle flag       [23]     -
+//   [24..32] Jl diag(scale_w)       [33..35] scale of the position columns
+//   [36..45] scale of the intrinsics columns                [46..47] -
+// The first 24 doubles are all a residual-only pass needs.
+// ------------------------------------------------------------------------------
+constexpr int kPrepStride = 48;
+constexpr int kPrepCostWords = 24;
+
+__device__ __forceinline__ void prepare_camera_record(const double* __restrict__ ext,
+                                                      const double* __restrict__ K, int nk,
+                                                      const double* __restrict__ scale16,
+                                                      double* __restrict__ out) {
+  const double w[3] = {ext[3], ext[4], ext[5]};
+  const double theta2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  double R[9], Jl[9], small = 0.0;
+  if (theta2 > kDblEpsilon) {
+    const double theta = sqrt(theta2);
+    double s, c;
+    sincos(theta, &s, &c);
+    const double inv_theta = 1.0 / theta;
+    const double A1 = s * inv_theta;
+    const double B1 = (1.0 - c) * inv_theta * inv_theta;
+    const double C1 = (theta - s) * inv_theta * inv_theta * inv_theta;
+    // R = c I + A1 [w]x + B1 w w^T  (the same expression rotate_point builds)
+    R[0] = c + B1 * w[0] * w[0];
+    R[1] = -A1 * w[2] + B1 * w[0] * w[1];
+    R[2] = A1 * w[1] + B1 * w[0] * w[2];
+    R[3] = A1 * w[2] + B1 * w[1] * w[0];
+    R[4] = c + B1 * w[1] * w[1];
+    R[5] = -A1 * w[0] + B1 * w[1] * w[2];
+    R[6] = -A1 * w[1] + B1 * w[2] * w[0];
+    R[7] = A1 * w[0] + B1 * w[2] * w[1];
+    R[8] = c + B1 * w[2] * w[2];
+    // Jl = I + B1 [w]x + C1 [w]x^2,  [w]x^2 = w w^T - theta^2 I
+    const double d = 1.0 - C1 * theta2;
+    Jl[0] = d + C1 * w[0] * w[0];
+    Jl[1] = -B1 * w[2] + C1 * w[0] * w[1];
+    Jl[2] = B1 * w[1] + C1 * w[0] * w[2];
+    Jl[3] = B1 * w[2] + C1 * w[1] * w[0];
+    Jl[4] = d + C1 * w[1] * w[1];
+    Jl[5] = -B1 * w[0] + C1 * w[1] * w[2];
+    Jl[6] = -B1 * w[1] + C1 * w[2] * w[0];
+    Jl[7] = B1 * w[0] + C1 * w[2] * w[1];
+    Jl[8] = d + C1 * w[2] * w[2];
+  } else {
+    R[0] = 1.0;   R[1] = -w[2]; R[2] = w[1];
+    R[3] = w[2];  R[4] = 1.0;   R[5] = -w[0];
+    R[6] = -w[1]; R[7] = w[0];  R[8] = 1.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Jl[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    small = 1.0;
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) out[i] = R[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) out[9 + i] = ext[i];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) out[12 + i] = (i < nk) ? K[i] : 0.0;
+  out[22] = small;
+  out[23] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[24 + 3 * i + k] = Jl[3 * i + k] * scale16[3 + k];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) out[33 + i] = scale16[i];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) out[36 + i] = scale16[6 + i];
+  out[46] = 0.0;
+  out[47] = 0.0;
+}
+
+// reprojection_error on a prepared record P (global memory or LDS).  Same value predicates
+// and outputs as reprojection_error; with JAC the angle-axis columns of Jext and nothing
+// else come out already multiplied by their Jacobi scale (folded into Jl).
+template <bool JAC, typename T>
+__device__ __forceinline__ bool reprojection_error_prepared(int model, const double* P,
+                                                            const double* X, double fx, double fy,
+                                                            T r[2], T Jext[2][6], T Jint[2][10],
+                                                            T Jpt[2][4]) {
+  const double wd = X[3];
+  const double ad[3] = {X[0] - wd * P[9], X[1] - wd * P[10], X[2] - wd * P[11]};
+  if (ad[0] * ad[0] + ad[1] * ad[1] + ad[2] * ad[2] < 1e-8) return false;
+  const T a[3] = {(T)ad[0], (T)ad[1], (T)ad[2]};
+  T Rm[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Rm[i] = (T)P[i];
+  T q[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) q[i] = Rm[3 * i] * a[0] + Rm[3 * i + 1] * a[1] + Rm[3 * i + 2] * a[2];
+  T Kt[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) Kt[i] = (T)P[12 + i];
+  T dpdq[2][3], px[2];
+  project<JAC, T>(model, Kt, q, px, dpdq, Jint);
+  r[0] = (T)((double)px[0] - fx);
+  r[1] = (T)((double)px[1] - fy);
+  if (JAC) {
+    const T w = (T)wd;
+    const bool small = P[22] != 0.0;
+    const T p[3] = {small ? a[0] : q[0], small ? a[1] : q[1], small ? a[2] : q[2]};
+    const T C[3] = {(T)P[9], (T)P[10], (T)P[11]};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      T M[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        M[j] = dpdq[i][0] * Rm[j] + dpdq[i][1] * Rm[3 + j] + dpdq[i][2] * Rm[6 + j];
+      // c = p x dpdq_i
+      const T c[3] = {p[1] * dpdq[i][2] - p[2] * dpdq[i][1], p[2] * dpdq[i][0] - p[0] * dpdq[i][2],
+                      p[0] * dpdq[i][1] - p[1] * dpdq[i][0]};
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        Jpt[i][j] = M[j];
+        Jext[i][j] = -w * M[j];
+        Jext[i][3 + j] = c[0] * (T)P[24 + j] + c[1] * (T)P[27 + j] + c[2] * (T)P[30 + j];
+      }
+      Jpt[i][3] = -(M[0] * C[0] + M[1] * C[1] + M[2] * C[2]);
+    }
+  }
+  return true;
+}
+
 // Camera::ProjectPoint (camera.cc:204-213): pixel and depth = rotated_z / w; unlike the
 // residual functor it has no degenerate-point test.
 __device__ __forceinline__ double project_point_depth(int model, const double* ext,

@@ -8,8 +8,8 @@
 //    pm_Jp  [2 DP][No_pad]   plane 2*col+row: point Jacobian
 //  camera-major (slot = obs_cpos[e], contiguous per reduced block)
 //    cm_Y   [Nslots][YS]     Y = A^T Jp L^-T  (D x DP row-major, YS = D*DP rounded up to even)
-//    cm_A   [Nslots][AS]     A row 0 (D), A row 1 (D), r~(2), r(2) [, A1 row 0 (D), A1 row 1 (D)
-//                            when free intrinsics are shared between views]
+//    cm_A   [Nslots][AS]     A row 0 (D), A row 1 (D), N = I - Q Q^T (3), r~(2), r(2) [, A1 row 0 (D),
+//                            A1 row 1 (D) when free intrinsics are shared between views]
 //  reduced system
 //    red    [nub*D*D | Nrb*D*D | Nrb*D | Nrb*D | Nrb*D | 8]   the all-reduce buffer:
 //           upper blocks, raw diagonal blocks, U diagonal, reduced gradient g~,
@@ -102,6 +102,8 @@ struct DeviceView {
   double* scale_cam; // [Nc][16] scale_c expanded to the columns [ext(6) | intr(10)] of every view
                      //   (0 on constant columns): linearize indexes it statically
   double* scale_p;  // [Np_pad][DP]
+  double* prep;     // [Nc][kPrepStride] prepared camera records of (ext, intr)     (camera_models.h)
+  double* prep_c;   // ... of the candidate (ext_c, intr_c); swapped with prep on acceptance
   double* Vinv;     // [DP(DP+1)/2][Np_pad]  planes, symmetric inverse of V + Dp
   double* gp;       // [DP][Np_pad]
   double* diag_p;   // [DP][Np_pad] squared column norms of the point Jacobian

@@ -48,9 +48,11 @@ static double now_s() {
 
 // ---- per (D, DP) launch table --------------------------------------------------
 struct Launch {
-  void (*linearize)(const DeviceView&, hipStream_t, int, double, int);
-  void (*cost)(const DeviceView&, hipStream_t, const double*, const double*, const double*, int,
-               double, int, int, double*);
+  // evaluation at a parameter set: prepared camera records (default) or, with
+  // TMI_BA_LEGACY_EVAL=1, the per-observation Rodrigues path of round 1 (kept for A/B timing)
+  void (*linearize)(const DeviceView&, hipStream_t, const double* prep, int, double, int);
+  void (*cost)(const DeviceView&, hipStream_t, const double* prep, const double*, const double*,
+               const double*, int, double, int, int, double*);
   void (*point_scale)(const DeviceView&, hipStream_t, int);
   void (*shared_blocks)(const DeviceView&, hipStream_t, RedLayout);
   void (*cross_add)(const DeviceView&, hipStream_t, RedLayout);
@@ -75,23 +77,37 @@ struct Launch {
 template <int D, int DP, bool SH>
 Launch make_launch(bool fp32) {
   Launch L;
-  if (fp32) {
-    L.linearize = [](const DeviceView& v, hipStream_t st, int lt, double lw, int nb) {
-      hipLaunchKernelGGL((linearize_kernel<D, DP, SH, float>), dim3(nb), dim3(256), 0, st, v, lt, lw, nb);
-    };
-    L.cost = [](const DeviceView& v, hipStream_t st, const double* e, const double* i, const double* p,
-                int lt, double lw, int fl, int nb, double* partial) {
-      hipLaunchKernelGGL((cost_kernel<DP, float>), dim3(nb), dim3(256), 0, st, v, e, i, p, lt, lw, fl, nb, partial);
-    };
-  } else {
-    L.linearize = [](const DeviceView& v, hipStream_t st, int lt, double lw, int nb) {
-      hipLaunchKernelGGL((linearize_kernel<D, DP, SH, double>), dim3(nb), dim3(256), 0, st, v, lt, lw, nb);
-    };
-    L.cost = [](const DeviceView& v, hipStream_t st, const double* e, const double* i, const double* p,
-                int lt, double lw, int fl, int nb, double* partial) {
-      hipLaunchKernelGGL((cost_kernel<DP, double>), dim3(nb), dim3(256), 0, st, v, e, i, p, lt, lw, fl, nb, partial);
-    };
+  static const bool legacy = getenv("TMI_BA_LEGACY_EVAL") != nullptr;
+  static const bool occ1 = getenv("TMI_BA_LINEARIZE_OCC1") != nullptr;  // A/B: one workgroup per CU's worth of registers
+#define TMI_EVAL(RT)                                                                                    \
+  if (legacy) {                                                                                         \
+    L.linearize = [](const DeviceView& v, hipStream_t st, const double*, int lt, double lw, int nb) {   \
+      hipLaunchKernelGGL((linearize_legacy_kernel<D, DP, SH, RT>), dim3(nb), dim3(256), 0, st, v, lt, lw, nb); \
+    };                                                                                                  \
+    L.cost = [](const DeviceView& v, hipStream_t st, const double*, const double* e, const double* i,   \
+                const double* p, int lt, double lw, int fl, int nb, double* partial) {                  \
+      hipLaunchKernelGGL((cost_legacy_kernel<DP, RT>), dim3(nb), dim3(256), 0, st, v, e, i, p, lt, lw, fl, nb, partial); \
+    };                                                                                                  \
+  } else {                                                                                              \
+    if (occ1)                                                                                           \
+      L.linearize = [](const DeviceView& v, hipStream_t st, const double* prep, int lt, double lw, int nb) { \
+        hipLaunchKernelGGL((linearize_kernel<D, DP, SH, RT, 1>), dim3(nb), dim3(256), 0, st, v, prep, lt, lw, nb); \
+      };                                                                                                \
+    else                                                                                                \
+      L.linearize = [](const DeviceView& v, hipStream_t st, const double* prep, int lt, double lw, int nb) { \
+        hipLaunchKernelGGL((linearize_kernel<D, DP, SH, RT, 2>), dim3(nb), dim3(256), 0, st, v, prep, lt, lw, nb); \
+      };                                                                                                \
+    L.cost = [](const DeviceView& v, hipStream_t st, const double* prep, const double*, const double*,  \
+                const double* p, int lt, double lw, int fl, int nb, double* partial) {                  \
+      hipLaunchKernelGGL((cost_kernel<DP, RT>), dim3(nb), dim3(256), 0, st, v, prep, p, lt, lw, fl, nb, partial); \
+    };                                                                                                  \
   }
+  if (fp32) {
+    TMI_EVAL(float)
+  } else {
+    TMI_EVAL(double)
+  }
+#undef TMI_EVAL
   L.point_scale = [](const DeviceView& v, hipStream_t st, int nb) {
     hipLaunchKernelGGL((point_scale_kernel<DP>), dim3(nb), dim3(256), 0, st, v);
   };
@@ -229,14 +245,16 @@ struct tmi_ba_solver {
   double* h_scal = nullptr;   // = h_mirror->scal
   double* h_red = nullptr;    // = h_mirror->red: the 8 all-reduced scalars at the tail of `red`
   int* h_flags = nullptr;     // = h_mirror->flags
-  // initial parameters (for reset) in device order
+  // initial parameters (for reset) in device order, on the host and resident in HBM
   std::vector<double> ext0, intr0, pts0;
+  double *d_ext0 = nullptr, *d_intr0 = nullptr, *d_pts0 = nullptr;
   int n_intr = 0;
   // extra device arrays not in the view
   double* d_pm_u = nullptr;
   double* d_cm_t = nullptr;   // implicit Schur operator: t_i per camera-major slot
   bool implicit = false;      // S is never formed (schur_mode)
   double cur_inv_radius = 0.0;
+  double time_vote = 0.0;     // this rank's "solver time exceeded" vote (source of a small async copy)
   const tmi_ba_options* cur_opts = nullptr;
   double* d_partial_max = nullptr;
   double* d_dense = nullptr;  // n_r x n_r when an exact solve is requested
@@ -620,6 +638,11 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
     if ((rc = dev_upload(s, &d_intr, s->intr0))) return rc;
     if ((rc = dev_upload(s, &d_pts, s->pts0))) return rc;
     v.ext_c = d_ext; v.intr_c = d_intr; v.pts_c = d_pts;
+    if (!light) {
+      if ((rc = dev_upload(s, &s->d_ext0, s->ext0))) return rc;
+      if ((rc = dev_upload(s, &s->d_intr0, s->intr0))) return rc;
+      if ((rc = dev_upload(s, &s->d_pts0, s->pts0))) return rc;
+    }
   }
   std::vector<int> cam_grp(P->camera_group, P->camera_group + st.Nc);
   std::vector<int> grp_model(P->group_model, P->group_model + st.G);
@@ -694,6 +717,7 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   AL(v.pm_A1, st.has_shared ? 2 * D * N : 1) AL(v.cam_part, (size_t)std::max(st.Ncam_rb, 1) * (2 * D * D + 3 * D))
   AL(v.cm_Y, (size_t)std::max<int64_t>(st.Nslots, 1) * YS) AL(v.cm_A, (size_t)std::max<int64_t>(st.Nslots, 1) * AS)
   AL(v.scale_c, std::max(n_r, 1)) AL(v.scale_cam, (size_t)std::max(st.Nc, 1) * 16) AL(v.scale_p, NP * DP)
+  AL(v.prep, (size_t)std::max(st.Nc, 1) * kPrepStride) AL(v.prep_c, (size_t)std::max(st.Nc, 1) * kPrepStride)
   AL(v.Vinv, NP * NS) AL(v.gp, NP * DP) AL(v.diag_p, NP * DP) AL(v.yp, NP * DP)
   AL(v.red, s->RL.total) AL(v.Sdiag, (size_t)std::max(st.Nrb, 1) * D * D)
   AL(v.tbuf, (size_t)std::max<int64_t>(st.nub, 1) * D) AL(v.rbuf, (size_t)std::max<size_t>(st.spc_row.size(), 1) * D) AL(v.Minv, (size_t)std::max(st.Nrb, 1) * D * D)
@@ -806,9 +830,14 @@ int32_t tmi_ba_solver_debug_allreduce(tmi_ba_solver* s, double value, double* ou
 int32_t tmi_ba_solver_reset(tmi_ba_solver* s) {
   if (!s) return TMI_BA_ERR_INVALID_ARGUMENT;
   TMI_HIP(hipSetDevice(s->device));
-  TMI_HIP(hipMemcpyAsync(s->v.ext, s->ext0.data(), s->ext0.size() * sizeof(double), hipMemcpyHostToDevice, s->stream));
-  TMI_HIP(hipMemcpyAsync(s->v.intr, s->intr0.data(), s->intr0.size() * sizeof(double), hipMemcpyHostToDevice, s->stream));
-  TMI_HIP(hipMemcpyAsync(s->v.pts, s->pts0.data(), s->pts0.size() * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  // from the resident copy when there is one (a device-to-device copy: microseconds)
+  const hipMemcpyKind kind = s->d_ext0 ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  if (!s->ext0.empty())
+    TMI_HIP(hipMemcpyAsync(s->v.ext, s->d_ext0 ? s->d_ext0 : s->ext0.data(), s->ext0.size() * sizeof(double), kind, s->stream));
+  if (!s->intr0.empty())
+    TMI_HIP(hipMemcpyAsync(s->v.intr, s->d_intr0 ? s->d_intr0 : s->intr0.data(), s->intr0.size() * sizeof(double), kind, s->stream));
+  if (!s->pts0.empty())
+    TMI_HIP(hipMemcpyAsync(s->v.pts, s->d_pts0 ? s->d_pts0 : s->pts0.data(), s->pts0.size() * sizeof(double), kind, s->stream));
   TMI_HIP(hipStreamSynchronize(s->stream));
   return TMI_BA_OK;
 }
@@ -830,6 +859,14 @@ int32_t tmi_ba_solver_download(tmi_ba_solver* s, tmi_ba_problem* P) {
     for (int a = 0; a < 4; ++a) P->points[(size_t)4 * p + a] = pts[(size_t)4 * lp + a];
   }
   return TMI_BA_OK;
+}
+
+// prepared camera records of a parameter set (camera_models.h); must follow every change of
+// the extrinsics / intrinsics it is taken from and every change of the column scales
+static void prepare_cameras(tmi_ba_solver* s, const double* ext, const double* intr, double* prep) {
+  if (s->v.Nc)
+    hipLaunchKernelGGL(camera_prepare_kernel, dim3((s->v.Nc + 255) / 256), dim3(256), 0, s->stream, s->v, ext,
+                       intr, prep);
 }
 
 // ---- the linear solve of one LM iteration ------------------------------------------
@@ -1182,11 +1219,12 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
   CKH(hipMemsetAsync(v.yc, 0, std::max(n_r, 1) * sizeof(double), stream));
   hipLaunchKernelGGL(fill_kernel, dim3((n_r + 255) / 256 + 1), dim3(256), 0, stream, v.scale_c, (long long)n_r, 1.0);
   s->launch.expand_scale(v, stream);
+  prepare_cameras(s, v.ext, v.intr, v.prep);
   hipLaunchKernelGGL(fill_kernel, dim3((unsigned)(((long long)st.Np_pad * s->DP + 255) / 256 + 1)), dim3(256), 0, stream, v.scale_p, (long long)st.Np_pad * s->DP, 1.0);
   auto linearize = [&]() {
     {
       Timed t(s, TMI_BA_K_LINEARIZE);
-      s->launch.linearize(v, stream, lt, lw, nbs);
+      s->launch.linearize(v, stream, v.prep, lt, lw, nbs);
     }
     Timed t(s, TMI_BA_K_REDUCE);
     hipLaunchKernelGGL(reduce_sum_kernel, dim3(2), dim3(256), 0, stream, v.partial, nbs, d_sc);
@@ -1248,6 +1286,7 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
         CKH(hipMemcpyAsync(v.scale_c, v.red + RL.udiag, (size_t)n_r * sizeof(double), hipMemcpyDeviceToDevice, stream));
         hipLaunchKernelGGL(camera_scale_finish_kernel, dim3((n_r + 255) / 256), dim3(256), 0, stream, v.scale_c, n_r);
         s->launch.expand_scale(v, stream);
+        prepare_cameras(s, v.ext, v.intr, v.prep);
       }
     }
     linearize();
@@ -1279,10 +1318,14 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
   int64_t pcg_iters = 0;
   bool need_gradient_check = true;  // after the first build and after every accepted step
   bool inner_enabled = O->use_inner_iterations != 0;
+  bool time_up = false;
 
   for (;;) {
     if (iter >= O->max_num_iterations) break;
-    if (now_s() - t_start >= O->max_solver_time_in_seconds) {
+    // On a sharded solve every termination decision must come from all-reduced data or the
+    // ranks would leave the loop at different iterations and the next collective would hang:
+    // the local clocks only VOTE (summed with the trial-step scalars below), the sum decides.
+    if (st.world > 1 ? time_up : (now_s() - t_start >= O->max_solver_time_in_seconds)) {
       why = "maximum solver time reached";
       break;
     }
@@ -1356,14 +1399,21 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
         s->launch.update_cameras(v, stream, v.scal + SC_STEP_SQ);
         s->launch.update_points(v, stream, nbp, v.partial);
         hipLaunchKernelGGL(reduce_sum_kernel, dim3(2), dim3(256), 0, stream, v.partial, nbp, d_sc + 1);
-        s->launch.cost(v, stream, v.ext_c, v.intr_c, v.pts_c, lt, lw, FL_INVALID, nbs, v.partial);
+        prepare_cameras(s, v.ext_c, v.intr_c, v.prep_c);
+        s->launch.cost(v, stream, v.prep_c, v.ext_c, v.intr_c, v.pts_c, lt, lw, FL_INVALID, nbs, v.partial);
         hipLaunchKernelGGL(reduce_sum_kernel, dim3(2), dim3(256), 0, stream, v.partial, nbs, d_sc + 3);
       }
-      // d_sc: [mcc, step_sq_points, |x+|^2 points, cand_cost, cand_ss, invalid votes]
+      // d_sc: [mcc, step_sq_points, |x+|^2 points, cand_cost, cand_ss, invalid votes, singular
+      //        track votes, time-limit votes]
       hipLaunchKernelGGL(flag_to_scalar_kernel, dim3(1), dim3(64), 0, stream, v.flags + FL_INVALID, d_sc + 5);
+      if (st.world > 1) {
+        s->time_vote = (now_s() - t_start >= O->max_solver_time_in_seconds) ? 1.0 : 0.0;
+        CKH(hipMemcpyAsync(d_sc + 7, &s->time_vote, sizeof(double), hipMemcpyHostToDevice, stream));
+      }
       CK(do_allreduce(s, d_sc, 8));
       CK(readback(s));
       memcpy(hsc, s->h_red, sizeof(hsc));
+      time_up = st.world > 1 && hsc[7] > 0.0;
       model_cost_change = hsc[0];
       step_sq = hsc[1] + s->h_scal[SC_STEP_SQ];
       cand_xp_sq = hsc[2];
@@ -1381,7 +1431,8 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
       {
         Timed t(s, TMI_BA_K_UPDATE_COST);
         CKH(hipMemsetAsync(v.flags + FL_INVALID, 0, sizeof(int), stream));
-        s->launch.cost(v, stream, v.ext_c, v.intr_c, v.pts_c, lt, lw, FL_INVALID, nbs, v.partial);
+        prepare_cameras(s, v.ext_c, v.intr_c, v.prep_c);  // the sweep moved the candidate cameras
+        s->launch.cost(v, stream, v.prep_c, v.ext_c, v.intr_c, v.pts_c, lt, lw, FL_INVALID, nbs, v.partial);
         hipLaunchKernelGGL(reduce_sum_kernel, dim3(2), dim3(256), 0, stream, v.partial, nbs, d_sc + 3);
         hipLaunchKernelGGL(flag_to_scalar_kernel, dim3(1), dim3(64), 0, stream, v.flags + FL_INVALID, d_sc + 5);
         hipLaunchKernelGGL(diff_sq_kernel, dim3(1), dim3(1024), 0, stream, v.ext, v.ext_c, (long long)6 * st.Nc, v.scal + SC_II_DEXT);
@@ -1400,6 +1451,7 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
         CKH(hipMemcpyAsync(v.ext_c, s->inner.bak_ext, (size_t)6 * st.Nc * sizeof(double), hipMemcpyDeviceToDevice, stream));
         if (s->n_intr) CKH(hipMemcpyAsync(v.intr_c, s->inner.bak_intr, (size_t)s->n_intr * sizeof(double), hipMemcpyDeviceToDevice, stream));
         CKH(hipMemcpyAsync(v.pts_c, s->inner.bak_pts, (size_t)4 * st.Np_pad * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        prepare_cameras(s, v.ext_c, v.intr_c, v.prep_c);
       } else {
         model_cost_change += cand_cost - inner_cost;
         inner_useful = inner_cost < cost;
@@ -1448,6 +1500,7 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
       std::swap(v.ext, v.ext_c);
       std::swap(v.intr, v.intr_c);
       std::swap(v.pts, v.pts_c);
+      std::swap(v.prep, v.prep_c);
       cost = cand_cost;
       final_ss = cand_ss;
       x_norm = std::sqrt(cand_xc_sq + cand_xp_sq);
@@ -1886,9 +1939,10 @@ int32_t tmi_ba_solver_evaluate(tmi_ba_solver* s, double* residuals, double* jac_
   TMI_HIP(hipMemsetAsync(v.flags, 0, FL_COUNT * sizeof(int), stream));
   hipLaunchKernelGGL(fill_kernel, dim3((n_r + 255) / 256 + 1), dim3(256), 0, stream, v.scale_c, (long long)n_r, 1.0);
   s->launch.expand_scale(v, stream);
+  prepare_cameras(s, v.ext, v.intr, v.prep);
   hipLaunchKernelGGL(fill_kernel, dim3((unsigned)(((long long)st.Np_pad * DP + 255) / 256 + 1)), dim3(256), 0, stream, v.scale_p, (long long)st.Np_pad * DP, 1.0);
   // poison the residual planes so that invalid observations can be told apart
-  s->launch.linearize(v, stream, 0, 1.0, s->nblocks_tracks);
+  s->launch.linearize(v, stream, v.prep, 0, 1.0, s->nblocks_tracks);
   const size_t N = (size_t)st.No_pad;
   std::vector<double> r(residuals ? 2 * N : 0), A(jac_camera ? (size_t)2 * D * N : 0),
       Jp(jac_point ? (size_t)2 * DP * N : 0);

@@ -49,7 +49,14 @@ __host__ __device__ __forceinline__ size_t pidx(int plane, size_t e) {
 // camera-major record strides in doubles, rounded up to whole 64-byte sectors so that a
 // record never straddles an extra sector (gathers) and is written as full sectors
 __host__ __device__ constexpr int ys_of(int D, int DP) { return (D * DP + 7) & ~7; }
-__host__ __device__ constexpr int as_of(int D, bool SH = false) { return ((SH ? 4 : 2) * D + 4 + 7) & ~7; }
+__host__ __device__ constexpr int as_of(int D, bool SH = false) { return ((SH ? 4 : 2) * D + 7 + 7) & ~7; }
+// camera-major A record: [A row 0 (D) | A row 1 (D) | N00 N01 N11 | r~ (2) | r (2) | A1 rows (2 D, SH)]
+// N = I - Q Q^T (Q = Jp L^-T, 2 x DP): sum A^T N A = sum (A^T A - Y Y^T), so the per-camera
+// reductions read this record only and never the Y record.
+__host__ __device__ constexpr int a_off_n(int D) { return 2 * D; }
+__host__ __device__ constexpr int a_off_rt(int D) { return 2 * D + 3; }
+__host__ __device__ constexpr int a_off_r(int D) { return 2 * D + 5; }
+__host__ __device__ constexpr int a_off_sh(int D) { return 2 * D + 7; }
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -226,8 +233,8 @@ struct LinearizeArgs {
 };
 
 template <int D, int DP, bool SH, typename RT>
-__global__ __launch_bounds__(256) void linearize_kernel(DeviceView v, int loss_type, double loss_width,
-                                                        int nblocks) {
+__global__ __launch_bounds__(256) void linearize_legacy_kernel(DeviceView v, int loss_type, double loss_width,
+                                                               int nblocks) {
   const TrackMap tm = track_map(v);
   double acc[2] = {0.0, 0.0};
   if (tm.valid) {
@@ -364,7 +371,7 @@ __global__ __launch_bounds__(256) void linearize_kernel(DeviceView v, int loss_t
 
 // cost only, at a given parameter set (kernel class 9): hot loop 1, residual-only.
 template <int DP, typename RT>
-__global__ __launch_bounds__(256) void cost_kernel(DeviceView v, const double* __restrict__ ext,
+__global__ __launch_bounds__(256) void cost_legacy_kernel(DeviceView v, const double* __restrict__ ext,
                                                    const double* __restrict__ intr,
                                                    const double* __restrict__ pts, int loss_type,
                                                    double loss_width, int flag_slot, int nblocks,
@@ -411,6 +418,303 @@ __global__ __launch_bounds__(256) void cost_kernel(DeviceView v, const double* _
       }
       acc[1] += sq;
     }
+  }
+  block_sum_store<2>(acc, partial, nblocks);
+}
+
+// ------------------------------------------------------------------------------
+// Prepared-camera evaluation path (default): camera_prepare + linearize + cost.
+//
+// camera_prepare_kernel: one thread per view turns [C, angle-axis], the view's intrinsics and
+// its 16 column scales into the 48-double record of camera_models.h (R, C, K, Jl diag(scale),
+// scales).  N_c threads; everything transcendental about the rotation happens here.
+//
+// The per-observation kernels are track-major, so the 64 lanes of a wave need 64 DIFFERENT
+// camera records per trip.  A lane reading its record straight from global memory costs one
+// L1 tag lookup per lane per 16-byte load (64 lookups per instruction, 12 instructions for
+// half a record); instead the wave copies the 64 half records (192 B each) into LDS
+// COOPERATIVELY -- consecutive lanes fetch consecutive 16-byte chunks, ~5 records per load
+// instruction -- and every lane then reads its own record from LDS on demand, which also keeps
+// the camera data out of the register file until the expression that uses it.
+// ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void camera_prepare_kernel(DeviceView v, const double* __restrict__ ext,
+                                                             const double* __restrict__ intr,
+                                                             double* __restrict__ prep) {
+  const int cam = blockIdx.x * 256 + threadIdx.x;
+  if (cam >= v.Nc) return;
+  const int4 rec = v.cam_rec[cam];
+  prepare_camera_record(ext + (size_t)cam * 6, intr + rec.y, rec.z, v.scale_cam + (size_t)cam * 16,
+                        prep + (size_t)cam * kPrepStride);
+}
+
+constexpr int kStageWords = kPrepCostWords;  // doubles of one staged half record
+constexpr int kStagePitch = kStageWords + 2; // +2 doubles: conflict-free 16-byte LDS accesses
+
+// lane l wants words [off, off + kStageWords) of record idx (idx < 0: nothing); on return
+// st[l * kStagePitch + i] holds word off + i of lane l's record.  Wave-collective.
+__device__ __forceinline__ void stage_camera_records(const double* __restrict__ prep, int off, int idx,
+                                                     double* st, int lane) {
+  constexpr int CH = kStageWords / 2;
+  // the previous contents may still be being read by other lanes of this wave
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int it = 0; it < CH; ++it) {
+    const int f = it * 64 + lane;
+    const int rec = f / CH, part = f - rec * CH;
+    const int id = __shfl(idx, rec, 64);
+    if (id >= 0) {
+      const double2 t = *reinterpret_cast<const double2*>(prep + (size_t)id * kPrepStride + off + 2 * part);
+      *reinterpret_cast<double2*>(st + rec * kStagePitch + 2 * part) = t;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// linearize (kernel class 0), prepared-camera version.  Same outputs as the legacy kernel.
+// Per trip: stage [R C K flag] -> value, projection Jacobian, M = dp/dq R, c = p x dp/dq;
+// stage [Jl scale] -> angle-axis columns, scaling and the plane stores.
+// OCC = minimum workgroups per CU the register allocation must allow (2: 256 registers per
+// lane, a handful of doubles spilled in the rarely taken camera-model branches).
+template <int D, int DP, bool SH, typename RT, int OCC>
+__global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const double* __restrict__ prep,
+                                                             int loss_type, double loss_width, int nblocks) {
+  __shared__ __attribute__((aligned(16))) double stage[kSlicesPerBlock][64 * kStagePitch];
+  const TrackMap tm = track_map(v);
+  const int lane = threadIdx.x & 63;
+  double* st = stage[threadIdx.x >> 6];
+  const double* P = st + lane * kStagePitch;
+  double acc[2] = {0.0, 0.0};
+  const int lp = tm.lp;
+  const int k = tm.k;  // 0 for padding tracks and beyond the last slice
+  double X[4] = {0.0, 0.0, 0.0, 1.0};
+  double sp[DP];
+#pragma unroll
+  for (int a = 0; a < DP; ++a) sp[a] = 0.0;
+  bool pconst = false;
+  if (tm.valid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) X[i] = v.pts[(size_t)lp * 4 + i];
+    pconst = v.pt_const[lp] != 0;
+#pragma unroll
+    for (int a = 0; a < DP; ++a) sp[a] = v.scale_p[(size_t)lp * DP + a];
+  }
+  int cam_next = (tm.j0 < k) ? v.obs_cam[tm.base + (size_t)tm.j0 * 64] : -1;
+  for (int trip = 0; trip < tm.trips; ++trip) {
+    const int j = tm.j0 + trip * tm.jstep;
+    const bool act = j < k;
+    const size_t e = tm.base + (size_t)j * 64;
+    const int cam = act ? cam_next : -1;
+    if (j + tm.jstep < k) cam_next = v.obs_cam[e + (size_t)tm.jstep * 64];
+    int4 rec = make_int4(0, 0, 0, 0);
+    double fx = 0.0, fy = 0.0;
+    if (act) {
+      rec = v.cam_rec[cam];
+      const double2 f2 = *reinterpret_cast<const double2*>(v.obs_xy + 2 * e);
+      fx = f2.x;
+      fy = f2.y;
+    }
+    stage_camera_records(prep, 0, cam, st, lane);
+    // ---- phase A: value, dp/dq, dp/dK; M = dp/dq R; c = p x dp/dq ----
+    bool ok = false;
+    RT Jint[2][10], M[2][3], cx[2][3], Jp3[2];
+    double r[2] = {0.0, 0.0};
+    if (act) {
+      const double wd = X[3];
+      const double ad[3] = {X[0] - wd * P[9], X[1] - wd * P[10], X[2] - wd * P[11]};
+      ok = !(ad[0] * ad[0] + ad[1] * ad[1] + ad[2] * ad[2] < 1e-8);
+      if (ok) {
+        const RT a[3] = {(RT)ad[0], (RT)ad[1], (RT)ad[2]};
+        RT q[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          q[i] = (RT)P[3 * i] * a[0] + (RT)P[3 * i + 1] * a[1] + (RT)P[3 * i + 2] * a[2];
+        RT Kt[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) Kt[i] = (RT)P[12 + i];
+        RT dpdq[2][3], px[2];
+        project<true, RT>(rec.x, Kt, q, px, dpdq, Jint);
+        r[0] = (double)(RT)((double)px[0] - fx);
+        r[1] = (double)(RT)((double)px[1] - fy);
+        const bool small = P[22] != 0.0;
+        const RT p[3] = {small ? a[0] : q[0], small ? a[1] : q[1], small ? a[2] : q[2]};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+          for (int jj = 0; jj < 3; ++jj)
+            M[i][jj] = dpdq[i][0] * (RT)P[jj] + dpdq[i][1] * (RT)P[3 + jj] + dpdq[i][2] * (RT)P[6 + jj];
+          cx[i][0] = p[1] * dpdq[i][2] - p[2] * dpdq[i][1];
+          cx[i][1] = p[2] * dpdq[i][0] - p[0] * dpdq[i][2];
+          cx[i][2] = p[0] * dpdq[i][1] - p[1] * dpdq[i][0];
+          Jp3[i] = -(M[i][0] * (RT)P[9] + M[i][1] * (RT)P[10] + M[i][2] * (RT)P[11]);
+        }
+      }
+    }
+    stage_camera_records(prep, kStageWords, cam, st, lane);
+    // ---- phase B: P[0..8] = Jl diag(scale_w), P[9..11] = position scales, P[12..21] = intrinsics scales
+    if (!act) continue;
+    if (!ok) {
+      v.flags[FL_INVALID] = 1;
+      for (int d = 0; d < 2 * D; ++d) __builtin_nontemporal_store(0.0, &v.pm_A[pidx<2 * D>(d, e)]);
+      if (SH)
+        for (int d = 0; d < 2 * D; ++d) __builtin_nontemporal_store(0.0, &v.pm_A1[pidx<2 * D>(d, e)]);
+      for (int d = 0; d < 2 * DP; ++d) __builtin_nontemporal_store(0.0, &v.pm_Jp[pidx<2 * DP>(d, e)]);
+      __builtin_nontemporal_store(0.0, &v.pm_r[pidx<2>(0, e)]);
+      __builtin_nontemporal_store(0.0, &v.pm_r[pidx<2>(1, e)]);
+      continue;
+    }
+    const double sq = r[0] * r[0] + r[1] * r[1];
+    double sqrt_rho1 = 1.0, asn = 0.0, rscale = 1.0;
+    if (loss_type != 0) {
+      double rho[3];
+      loss_eval(loss_type, loss_width, sq, rho);
+      acc[0] += 0.5 * rho[0];
+      sqrt_rho1 = sqrt(rho[1]);
+      rscale = sqrt_rho1;
+      if (!(sq == 0.0 || rho[2] <= 0.0)) {
+        const double Dd = 1.0 + 2.0 * sq * rho[2] / rho[1];
+        const double alpha = 1.0 - sqrt(Dd);
+        rscale = sqrt_rho1 / (1.0 - alpha);
+        asn = alpha / sq;
+      }
+    } else {
+      acc[0] += 0.5 * sq;
+    }
+    acc[1] += sq;
+    const double wneg = -X[3];
+    const unsigned mask = (unsigned)rec.w;
+    // reduced camera block: free columns of [ext(6) | intr(10)], compacted
+    int dst = 0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      if (mask & (1u << c)) {
+        double j0, j1, scl;
+        if (c < 3) {
+          j0 = wneg * (double)M[0][c < 3 ? c : 0];
+          j1 = wneg * (double)M[1][c < 3 ? c : 0];
+          scl = P[9 + (c < 3 ? c : 0)];
+        } else if (c < 6) {
+          const int kk = (c >= 3 && c < 6) ? c - 3 : 0;
+          j0 = (double)(cx[0][0] * (RT)P[kk] + cx[0][1] * (RT)P[3 + kk] + cx[0][2] * (RT)P[6 + kk]);
+          j1 = (double)(cx[1][0] * (RT)P[kk] + cx[1][1] * (RT)P[3 + kk] + cx[1][2] * (RT)P[6 + kk]);
+          scl = 1.0;  // folded into Jl
+        } else {
+          j0 = (double)Jint[0][c >= 6 ? c - 6 : 0];
+          j1 = (double)Jint[1][c >= 6 ? c - 6 : 0];
+          scl = P[12 + (c >= 6 ? c - 6 : 0)];
+        }
+        if (loss_type != 0) {
+          const double rtj = j0 * r[0] + j1 * r[1];
+          j0 = sqrt_rho1 * (j0 - asn * r[0] * rtj);
+          j1 = sqrt_rho1 * (j1 - asn * r[1] * rtj);
+        }
+        __builtin_nontemporal_store(j0 * scl, &v.pm_A[pidx<2 * D>((2 * dst), e)]);
+        __builtin_nontemporal_store(j1 * scl, &v.pm_A[pidx<2 * D>((2 * dst + 1), e)]);
+        ++dst;
+      }
+    }
+    for (int d = 2 * dst; d < 2 * D; ++d) __builtin_nontemporal_store(0.0, &v.pm_A[pidx<2 * D>(d, e)]);
+    if (SH) {
+      // free intrinsics shared between views: their columns go to the group's own block
+      const int grb = v.cam_grb[cam];
+      int dst1 = 0;
+      if (grb >= 0) {
+        const unsigned gmask = v.grp_mask[v.cam_grp[cam]];
+#pragma unroll
+        for (int c = 0; c < 10; ++c) {
+          if (gmask & (1u << c)) {
+            double j0 = (double)Jint[0][c], j1 = (double)Jint[1][c];
+            if (loss_type != 0) {
+              const double rtj = j0 * r[0] + j1 * r[1];
+              j0 = sqrt_rho1 * (j0 - asn * r[0] * rtj);
+              j1 = sqrt_rho1 * (j1 - asn * r[1] * rtj);
+            }
+            const double scl = P[12 + c];
+            __builtin_nontemporal_store(j0 * scl, &v.pm_A1[pidx<2 * D>((2 * dst1), e)]);
+            __builtin_nontemporal_store(j1 * scl, &v.pm_A1[pidx<2 * D>((2 * dst1 + 1), e)]);
+            ++dst1;
+          }
+        }
+      }
+      for (int d = 2 * dst1; d < 2 * D; ++d) __builtin_nontemporal_store(0.0, &v.pm_A1[pidx<2 * D>(d, e)]);
+    }
+#pragma unroll
+    for (int a = 0; a < DP; ++a) {
+      double j0 = 0.0, j1 = 0.0;
+      if (!pconst) {
+        j0 = (a < 3) ? (double)M[0][a < 3 ? a : 0] : (double)Jp3[0];
+        j1 = (a < 3) ? (double)M[1][a < 3 ? a : 0] : (double)Jp3[1];
+      }
+      if (loss_type != 0) {
+        const double rtj = j0 * r[0] + j1 * r[1];
+        j0 = sqrt_rho1 * (j0 - asn * r[0] * rtj);
+        j1 = sqrt_rho1 * (j1 - asn * r[1] * rtj);
+      }
+      __builtin_nontemporal_store(j0 * sp[a], &v.pm_Jp[pidx<2 * DP>((2 * a), e)]);
+      __builtin_nontemporal_store(j1 * sp[a], &v.pm_Jp[pidx<2 * DP>((2 * a + 1), e)]);
+    }
+    __builtin_nontemporal_store(r[0] * rscale, &v.pm_r[pidx<2>(0, e)]);
+    __builtin_nontemporal_store(r[1] * rscale, &v.pm_r[pidx<2>(1, e)]);
+  }
+  block_sum_store<2>(acc, v.partial, nblocks);
+}
+
+// cost only, at a prepared parameter set (kernel class 9): hot loop 1, residual-only.
+template <int DP, typename RT>
+__global__ __launch_bounds__(256) void cost_kernel(DeviceView v, const double* __restrict__ prep,
+                                                   const double* __restrict__ pts, int loss_type,
+                                                   double loss_width, int flag_slot, int nblocks,
+                                                   double* partial) {
+  __shared__ __attribute__((aligned(16))) double stage[kSlicesPerBlock][64 * kStagePitch];
+  const TrackMap tm = track_map(v);
+  const int lane = threadIdx.x & 63;
+  double* st = stage[threadIdx.x >> 6];
+  const double* P = st + lane * kStagePitch;
+  double acc[2] = {0.0, 0.0};
+  const int k = tm.k;
+  double X[4] = {0.0, 0.0, 0.0, 1.0};
+  if (tm.valid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) X[i] = pts[(size_t)tm.lp * 4 + i];
+  }
+  int cam_next = (tm.j0 < k) ? v.obs_cam[tm.base + (size_t)tm.j0 * 64] : -1;
+  for (int trip = 0; trip < tm.trips; ++trip) {
+    const int j = tm.j0 + trip * tm.jstep;
+    const bool act = j < k;
+    const size_t e = tm.base + (size_t)j * 64;
+    const int cam = act ? cam_next : -1;
+    if (j + tm.jstep < k) cam_next = v.obs_cam[e + (size_t)tm.jstep * 64];
+    int model = 0;
+    double fx = 0.0, fy = 0.0;
+    if (act) {
+      model = v.cam_rec[cam].x;
+      const double2 f2 = *reinterpret_cast<const double2*>(v.obs_xy + 2 * e);
+      fx = f2.x;
+      fy = f2.y;
+    }
+    stage_camera_records(prep, 0, cam, st, lane);
+    if (!act) continue;
+    RT rr[2];
+    RT (*nul6)[6] = nullptr;
+    RT Jint[2][10];
+    RT (*nul4)[4] = nullptr;
+    const bool ok = reprojection_error_prepared<false, RT>(model, P, X, fx, fy, rr, nul6, Jint, nul4);
+    if (!ok) {
+      v.flags[flag_slot] = 1;
+      continue;
+    }
+    const double r[2] = {(double)rr[0], (double)rr[1]};
+    const double sq = r[0] * r[0] + r[1] * r[1];
+    if (loss_type != 0) {
+      double rho[3];
+      loss_eval(loss_type, loss_width, sq, rho);
+      acc[0] += 0.5 * rho[0];
+    } else {
+      acc[0] += 0.5 * sq;
+    }
+    acc[1] += sq;
   }
   block_sum_store<2>(acc, partial, nblocks);
 }
@@ -642,10 +946,22 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
         }
 #pragma unroll
         for (int i = D * DP; i < YS; ++i) Yv[i] = 0.0;
-        Av[2 * D] = rt0;
-        Av[2 * D + 1] = rt1;
-        Av[2 * D + 2] = r0;
-        Av[2 * D + 3] = r1;
+        {
+          double n00 = 1.0, n01 = 0.0, n11 = 1.0;
+#pragma unroll
+          for (int b = 0; b < DP; ++b) {
+            n00 -= Q0[b] * Q0[b];
+            n01 -= Q0[b] * Q1[b];
+            n11 -= Q1[b] * Q1[b];
+          }
+          Av[a_off_n(D)] = n00;
+          Av[a_off_n(D) + 1] = n01;
+          Av[a_off_n(D) + 2] = n11;
+        }
+        Av[a_off_rt(D)] = rt0;
+        Av[a_off_rt(D) + 1] = rt1;
+        Av[a_off_r(D)] = r0;
+        Av[a_off_r(D) + 1] = r1;
         if (SH) {
           // shared intrinsics block: Y1 = A1^T Q summed over the track's observations of
           // that block (they are adjacent); A1 rides in the A record for the per-view sums
@@ -660,16 +976,16 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
               a0 = v.pm_A1[pidx<2 * D>((2 * a), e)];
               a1 = v.pm_A1[pidx<2 * D>((2 * a + 1), e)];
             }
-            Av[2 * D + 4 + a] = a0;
-            Av[3 * D + 4 + a] = a1;
+            Av[a_off_sh(D) + a] = a0;
+            Av[a_off_sh(D) + D + a] = a1;
 #pragma unroll
             for (int b = 0; b < DP; ++b) Yg[a * DP + b] += a0 * Q0[b] + a1 * Q1[b];
           }
 #pragma unroll
-          for (int i = 4 * D + 4; i < AS; ++i) Av[i] = 0.0;
+          for (int i = 4 * D + 7; i < AS; ++i) Av[i] = 0.0;
         } else {
 #pragma unroll
-          for (int i = 2 * D + 4; i < AS; ++i) Av[i] = 0.0;
+          for (int i = 2 * D + 7; i < AS; ++i) Av[i] = 0.0;
         }
       }
 #pragma unroll
@@ -756,13 +1072,12 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
 // ------------------------------------------------------------------------------
 // camera_diag (kernel class 2): one wavefront per reduced block walks that
 // camera's camera-major records and reduces, in registers + wave shuffles,
-//   S_cc(raw) = sum A^T A - Y Y^T,  U diag = sum diag(A^T A),
+//   S_cc(raw) = sum A^T N A (= sum A^T A - Y Y^T),  U diag = sum diag(A^T A),
 //   g~ = sum A^T r~  (reduced gradient),  g_c = sum A^T r  (camera gradient).
 // ------------------------------------------------------------------------------
 template <int D, int DP, bool SH>
 __global__ __launch_bounds__(64) void camera_diag_kernel(DeviceView v, RedLayout L) {
   constexpr int NS = sym_size(D);
-  constexpr int YS = ys_of(D, DP);
   constexpr int AS = as_of(D, SH);
   const int rb = blockIdx.x;
   double Ss[NS], Ud[D], gt[D], gc[D];
@@ -770,34 +1085,57 @@ __global__ __launch_bounds__(64) void camera_diag_kernel(DeviceView v, RedLayout
   for (int i = 0; i < NS; ++i) Ss[i] = 0.0;
 #pragma unroll
   for (int a = 0; a < D; ++a) Ud[a] = gt[a] = gc[a] = 0.0;
+  if (SH && rb >= v.Ncam_rb) {
+    // shared intrinsics block: its slots are (track, block) records whose Y is a SUM over the
+    // track's observations of the block (point_eliminate), so Y Y^T has no per-observation
+    // N form; the J^T J part arrives through group_reduce.  Raw diagonal = - sum Y Y^T.
+    constexpr int YS = ys_of(D, DP);
+    for (int s = v.cam_ptr[rb] + threadIdx.x; s < v.cam_ptr[rb + 1]; s += 64) {
+      const double* yrec = v.cm_Y + (size_t)s * YS;
+      double Y[YS];
+#pragma unroll
+      for (int i = 0; i < YS; i += 2) {
+        const double2 t = *reinterpret_cast<const double2*>(yrec + i);
+        Y[i] = t.x;
+        Y[i + 1] = t.y;
+      }
+#pragma unroll
+      for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = a; b < D; ++b) {
+          double t = 0.0;
+#pragma unroll
+          for (int c = 0; c < DP; ++c) t -= Y[a * DP + c] * Y[b * DP + c];
+          Ss[sym_idx(a, b, D)] += t;
+        }
+    }
+  } else
   for (int s = v.cam_ptr[rb] + threadIdx.x; s < v.cam_ptr[rb + 1]; s += 64) {
     const double* arec = v.cm_A + (size_t)s * AS;
-    const double* yrec = v.cm_Y + (size_t)s * YS;
-    double A0[D], A1[D], Y[YS];
+    double rec[2 * D + 8];
 #pragma unroll
-    for (int i = 0; i < D; i += 1) {
-      A0[i] = arec[i];
-      A1[i] = arec[D + i];
+    for (int i = 0; i < 2 * D + 8; i += 2) {
+      const double2 t = *reinterpret_cast<const double2*>(arec + i);
+      rec[i] = t.x;
+      rec[i + 1] = t.y;
     }
-    const double rt0 = arec[2 * D], rt1 = arec[2 * D + 1], r0 = arec[2 * D + 2], r1 = arec[2 * D + 3];
+    const double n00 = rec[a_off_n(D)], n01 = rec[a_off_n(D) + 1], n11 = rec[a_off_n(D) + 2];
+    const double rt0 = rec[a_off_rt(D)], rt1 = rec[a_off_rt(D) + 1];
+    const double r0 = rec[a_off_r(D)], r1 = rec[a_off_r(D) + 1];
+    double B0[D], B1[D];
 #pragma unroll
-    for (int i = 0; i < ((D * DP + 1) & ~1); i += 2) {
-      const double2 t = *reinterpret_cast<const double2*>(yrec + i);
-      Y[i] = t.x;
-      Y[i + 1] = t.y;
+    for (int a = 0; a < D; ++a) {
+      B0[a] = n00 * rec[a] + n01 * rec[D + a];
+      B1[a] = n01 * rec[a] + n11 * rec[D + a];
     }
 #pragma unroll
     for (int a = 0; a < D; ++a) {
+      const double a0 = rec[a], a1 = rec[D + a];
 #pragma unroll
-      for (int b = a; b < D; ++b) {
-        double t = A0[a] * A0[b] + A1[a] * A1[b];
-#pragma unroll
-        for (int c = 0; c < DP; ++c) t -= Y[a * DP + c] * Y[b * DP + c];
-        Ss[sym_idx(a, b, D)] += t;
-      }
-      Ud[a] += A0[a] * A0[a] + A1[a] * A1[a];
-      gt[a] += A0[a] * rt0 + A1[a] * rt1;
-      gc[a] += A0[a] * r0 + A1[a] * r1;
+      for (int b = a; b < D; ++b) Ss[sym_idx(a, b, D)] += a0 * B0[b] + a1 * B1[b];
+      Ud[a] += a0 * a0 + a1 * a1;
+      gt[a] += a0 * rt0 + a1 * rt1;
+      gc[a] += a0 * r0 + a1 * r1;
     }
   }
   double* diag = v.red + L.diag + (size_t)rb * D * D;
@@ -1240,7 +1578,7 @@ __global__ __launch_bounds__(64) void implicit_cameras_kernel(DeviceView v, RedL
     if (SH) {
       // the view's rows of the shared intrinsics block ride in the same record
 #pragma unroll
-      for (int a = 0; a < D; ++a) acc1[a] += arec[2 * D + 4 + a] * t.x + arec[3 * D + 4 + a] * t.y;
+      for (int a = 0; a < D; ++a) acc1[a] += arec[a_off_sh(D) + a] * t.x + arec[a_off_sh(D) + D + a] * t.y;
     }
   }
   if (SH) {
@@ -1485,8 +1823,8 @@ __global__ __launch_bounds__(64) void camera_group_partials_kernel(DeviceView v)
       for (int a = 0; a < D; ++a) {
         A0[0][a] = rec[a];
         A0[1][a] = rec[D + a];
-        A1[0][a] = rec[2 * D + 4 + a];
-        A1[1][a] = rec[3 * D + 4 + a];
+        A1[0][a] = rec[a_off_sh(D) + a];
+        A1[1][a] = rec[a_off_sh(D) + D + a];
       }
 #pragma unroll
       for (int a = 0; a < D; ++a)
@@ -1512,10 +1850,10 @@ __global__ __launch_bounds__(64) void camera_group_partials_kernel(DeviceView v)
       double A1[2][D];
 #pragma unroll
       for (int a = 0; a < D; ++a) {
-        A1[0][a] = rec[2 * D + 4 + a];
-        A1[1][a] = rec[3 * D + 4 + a];
+        A1[0][a] = rec[a_off_sh(D) + a];
+        A1[1][a] = rec[a_off_sh(D) + D + a];
       }
-      const double rt0 = rec[2 * D], rt1 = rec[2 * D + 1], r0 = rec[2 * D + 2], r1 = rec[2 * D + 3];
+      const double rt0 = rec[a_off_rt(D)], rt1 = rec[a_off_rt(D) + 1], r0 = rec[a_off_r(D)], r1 = rec[a_off_r(D) + 1];
 #pragma unroll
       for (int a = 0; a < D; ++a) {
 #pragma unroll

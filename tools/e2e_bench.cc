@@ -1,0 +1,112 @@
+// End-to-end wall clock of the drop-in entry point: theia::BundleAdjustReconstruction() on a
+// theia::Reconstruction of benchmark size (reference: bundle_adjustment.cc:66-80), i.e.
+//   AddView x N_c + AddTrack x N_p (residual set, hash containers)  -> Flatten
+//   -> tmi_ba_solve (structure build, upload, LM on the GPU, download) -> write back.
+// bench.py writes the flat synthetic problem to a file, this tool loads it into the
+// Reconstruction containers and times the call the way a Theia pipeline would see it.
+//
+//   e2e_bench <problem.bin> <max_iterations> <use_inner_iterations 0|1> [repeat]
+// problem.bin: int64 Nc, Np, No | ext[6 Nc] | pinhole intrinsics[7 Nc] | points[4 Np] |
+//              obs_camera[No] i32 | obs_point[No] i32 | obs_xy[2 No]      (little endian, fp64)
+// Prints ONE JSON line.
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "theia/sfm/bundle_adjustment/bundle_adjustment.h"
+#include "theia/sfm/reconstruction.h"
+
+using namespace theia;
+
+static double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+template <class T>
+static bool read_vec(FILE* f, std::vector<T>* v, size_t n) {
+  v->resize(n);
+  return n == 0 || fread(v->data(), sizeof(T), n, f) == n;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 4) {
+    fprintf(stderr, "usage: %s problem.bin max_iterations use_inner_iterations [repeat]\n", argv[0]);
+    return 2;
+  }
+  const int max_it = atoi(argv[2]);
+  const bool inner = atoi(argv[3]) != 0;
+  const int repeat = argc > 4 ? atoi(argv[4]) : 1;
+  FILE* f = fopen(argv[1], "rb");
+  if (!f) {
+    perror("open");
+    return 2;
+  }
+  int64_t hdr[3];
+  if (fread(hdr, sizeof(int64_t), 3, f) != 3) return 2;
+  const int64_t Nc = hdr[0], Np = hdr[1], No = hdr[2];
+  std::vector<double> ext, intr, pts, xy;
+  std::vector<int32_t> ocam, opt;
+  if (!read_vec(f, &ext, 6 * Nc) || !read_vec(f, &intr, 7 * Nc) || !read_vec(f, &pts, 4 * Np) ||
+      !read_vec(f, &ocam, No) || !read_vec(f, &opt, No) || !read_vec(f, &xy, 2 * No)) {
+    fprintf(stderr, "short file\n");
+    return 2;
+  }
+  fclose(f);
+
+  double best_total = 1e300, best_setup = 0, best_solve = 0, build_s = 0;
+  BundleAdjustmentSummary sum;
+  for (int rep = 0; rep < repeat; ++rep) {
+    const double tb = now_s();
+    Reconstruction rec;
+    std::vector<ViewId> vid(Nc);
+    for (int64_t c = 0; c < Nc; ++c) {
+      vid[c] = rec.AddView("v" + std::to_string(c));
+      View* view = rec.MutableView(vid[c]);
+      Camera* cam = view->MutableCamera();
+      for (int a = 0; a < 6; ++a) cam->mutable_extrinsics()[a] = ext[6 * c + a];
+      for (int a = 0; a < 7; ++a) cam->mutable_intrinsics()[a] = intr[7 * c + a];
+      view->SetEstimated(true);
+    }
+    std::vector<TrackId> tid(Np);
+    for (int64_t p = 0; p < Np; ++p) {
+      tid[p] = rec.AddTrack();
+      Track* tr = rec.MutableTrack(tid[p]);
+      for (int a = 0; a < 4; ++a) (*tr->MutablePoint())[a] = pts[4 * p + a];
+      tr->SetEstimated(true);
+    }
+    for (int64_t i = 0; i < No; ++i) rec.AddObservation(vid[ocam[i]], tid[opt[i]], Feature(xy[2 * i], xy[2 * i + 1]));
+    build_s = now_s() - tb;
+
+    BundleAdjustmentOptions opt_ba;
+    // the reference's solver policy (reconstruction_estimator_utils.cc:110-133)
+    opt_ba.linear_solver_type = Nc >= 1000 ? ceres::ITERATIVE_SCHUR : (Nc >= 150 ? ceres::SPARSE_SCHUR : ceres::DENSE_SCHUR);
+    opt_ba.preconditioner_type = ceres::SCHUR_JACOBI;
+    opt_ba.max_num_iterations = max_it;
+    opt_ba.use_inner_iterations = inner;
+    // a fixed number of iterations so that runs are comparable
+    opt_ba.function_tolerance = -1.0;
+    opt_ba.gradient_tolerance = -1.0;
+    opt_ba.parameter_tolerance = -1.0;
+    opt_ba.point_dof = 3;
+    const double t0 = now_s();
+    sum = BundleAdjustReconstruction(opt_ba, &rec);
+    const double total = now_s() - t0;
+    if (total < best_total) {
+      best_total = total;
+      best_setup = sum.setup_time_in_seconds;
+      best_solve = sum.solve_time_in_seconds;
+    }
+  }
+  printf("{\"entry\": \"theia::BundleAdjustReconstruction\", \"cameras\": %lld, \"tracks\": %lld, "
+         "\"observations\": %lld, \"max_num_iterations\": %d, \"use_inner_iterations\": %d, \"success\": %d, "
+         "\"wall_seconds\": %.6f, \"setup_seconds\": %.6f, \"solve_seconds\": %.6f, "
+         "\"host_other_seconds\": %.6f, \"initial_cost\": %.9e, \"final_cost\": %.9e, "
+         "\"build_reconstruction_seconds\": %.3f, \"repeat\": %d}\n",
+         (long long)Nc, (long long)Np, (long long)No, max_it, inner ? 1 : 0, sum.success ? 1 : 0, best_total,
+         best_setup, best_solve, best_total - best_setup - best_solve, sum.initial_cost, sum.final_cost, build_s,
+         repeat);
+  return sum.success ? 0 : 1;
+}

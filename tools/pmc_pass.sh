@@ -4,7 +4,7 @@ tag=$1; re=$2; shift 2
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_$tag
 rm -rf $O; cd $R
-timeout 500 rocprofv3 --kernel-trace --pmc "$@" --kernel-include-regex "$re" --output-format csv -d $O -- python bench.py --steps 6 --warmup 1 --no-cpu-baseline > $O.log 2>&1
+timeout 500 rocprofv3 --kernel-trace --pmc "$@" --kernel-include-regex "$re" --output-format csv -d $O -- python bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-extras > $O.log 2>&1
 python - "$O" <<'PY'
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/**/*_counter_collection.csv", recursive=True)
