@@ -132,10 +132,17 @@ Launch make_launch(bool fp32) {
   L.expand_scale = [](const DeviceView& v, hipStream_t st) {
     if (v.Nc) hipLaunchKernelGGL((expand_camera_scale_kernel<D>), dim3((v.Nc + 255) / 256), dim3(256), 0, st, v);
   };
-  L.schur_offdiag = [](const DeviceView& v, hipStream_t st, RedLayout R) {
-    if (v.nub)
-      hipLaunchKernelGGL((schur_offdiag_kernel<D, DP>), dim3((v.n_order + 4 * kSchurBlocksPerWave - 1) / (4 * kSchurBlocksPerWave)), dim3(256), 0, st, v, R);
-  };
+  static const bool schur_gather = getenv("TMI_BA_SCHUR_GATHER") != nullptr;  // A/B: round 1's per-lane gathers
+  if (schur_gather)
+    L.schur_offdiag = [](const DeviceView& v, hipStream_t st, RedLayout R) {
+      if (v.nub)
+        hipLaunchKernelGGL((schur_offdiag_gather_kernel<D, DP>), dim3((v.n_order + 4 * kSchurBlocksPerWave - 1) / (4 * kSchurBlocksPerWave)), dim3(256), 0, st, v, R);
+    };
+  else
+    L.schur_offdiag = [](const DeviceView& v, hipStream_t st, RedLayout R) {
+      if (v.nub)
+        hipLaunchKernelGGL((schur_offdiag_kernel<D, DP>), dim3((v.n_order + 4 * kSchurBlocksPerWave - 1) / (4 * kSchurBlocksPerWave)), dim3(256), 0, st, v, R);
+    };
   L.expand = [](const DeviceView& v, hipStream_t st, RedLayout R, double ir, double lo, double hi) {
     const int n2 = v.Nrb * D * D;
     if (n2)

@@ -1170,7 +1170,7 @@ __global__ __launch_bounds__(64) void camera_diag_kernel(DeviceView v, RedLayout
 constexpr int kSchurBlocksPerWave = 4;
 
 template <int D, int DP>
-__global__ __launch_bounds__(256) void schur_offdiag_kernel(DeviceView v, RedLayout L) {
+__global__ __launch_bounds__(256) void schur_offdiag_gather_kernel(DeviceView v, RedLayout L) {
   constexpr int YS = ys_of(D, DP);
   constexpr int R = kSchurBlocksPerWave;
   const int lane = threadIdx.x & 63;
@@ -1253,6 +1253,164 @@ __global__ __launch_bounds__(256) void schur_offdiag_kernel(DeviceView v, RedLay
       const int row = (lane >> 4) + 4 * q;
       if (row < D && col < D) out[row * D + col] = -acc[q];
     }
+  }
+}
+
+// schur_offdiag, LDS-staged version (default).  Same launch slots, headers, pair lists, MFMA
+// contraction and summation order as the gather kernel above; what changes is how the Y
+// records reach the matrix cores.  There every lane fetched single doubles of "its" matrix
+// element straight from global memory (36 useful 8-byte lanes per load instruction, 24 load
+// instructions per 16 pairs, every instruction a fresh set of L1 tag look-ups).  Here the wave
+// copies the 2 x 16 records of a chunk of 16 pairs into LDS with 16-byte loads in which
+// consecutive lanes cover consecutive parts of a record (7 load instructions per 16 pairs for
+// 9 x 3 records), and the MFMA operands are read from LDS.  The loads of chunk t + 1 are in flight
+// in registers and the pair indices of chunk t + 2 are being fetched while chunk t is contracted.
+constexpr int kSchurPairsPerChunk = 16;
+
+template <int D, int DP>
+__global__ __launch_bounds__(256) void schur_offdiag_kernel(DeviceView v, RedLayout L) {
+  constexpr int YS = ys_of(D, DP);
+  constexpr int R = kSchurBlocksPerWave;
+  constexpr int PC = kSchurPairsPerChunk;
+  constexpr int PARTS = (D * DP + 1) / 2;          // 16-byte parts of a record that carry data
+  constexpr int PITCH = YS + 2;                    // doubles; keeps the 16-byte parts aligned
+  constexpr int NL = (2 * PC * PARTS + 63) / 64;   // 16-byte loads per lane per chunk
+  constexpr int STEPS = PC * DP / 4;               // MFMA steps (K = 4 each) of a full chunk
+  static_assert((PC * DP) % 4 == 0, "chunk K must be a multiple of the MFMA K");
+  __shared__ __attribute__((aligned(16))) double lds_all[4][2 * PC * PITCH];
+  const int lane = threadIdx.x & 63;
+  double* lds = lds_all[threadIdx.x >> 6];
+  const long long first = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  if (first >= v.n_order) return;  // wave-uniform; no workgroup barrier below
+  int4 hq = make_int4(-1, 0, 0, 0);
+  if (lane < R && first + lane < v.n_order) hq = reinterpret_cast<const int4*>(v.ub_order)[first + lane];
+  // headers of the R launch slots as wave-uniform scalars
+  int hu[R], hn[R];
+  long long hp[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    hu[r] = __builtin_amdgcn_readlane(hq.x, r);
+    hn[r] = hu[r] >= 0 ? __builtin_amdgcn_readlane(hq.y, r) : 0;
+    hp[r] = ((long long)(unsigned)__builtin_amdgcn_readlane(hq.z, r)) |
+            ((long long)__builtin_amdgcn_readlane(hq.w, r) << 32);
+  }
+  // per-lane LDS offsets of the MFMA operands of step h: K index k = 4 h + (lane >> 4) is
+  // (pair k / DP, component k % DP); row / column = lane & 15
+  const int i = lane & 15, kk = lane >> 4;
+  const bool row_ok = i < D;
+  int koff[STEPS];
+#pragma unroll
+  for (int h = 0; h < STEPS; ++h) {
+    const int k = 4 * h + kk;
+    const int pr = k / DP;
+    koff[h] = pr * PITCH + (row_ok ? i : 0) * DP + (k - pr * DP);
+  }
+  // chunk iterator over (slot r, first pair c0): wave-uniform.  A block without pairs on this
+  // rank (sharded solves) still has ONE chunk, of zero pairs, so that its zeros get written.
+  struct Chunk {
+    int r, c0, n;  // launch slot (R = past the end), first pair, pairs in this chunk
+  };
+  auto hn_of = [&](int r) {
+    int n = 0;
+#pragma unroll
+    for (int q = 0; q < R; ++q) n = (q == r) ? hn[q] : n;
+    return n;
+  };
+  auto hu_of = [&](int r) {
+    int u = -1;
+#pragma unroll
+    for (int q = 0; q < R; ++q) u = (q == r) ? hu[q] : u;
+    return u;
+  };
+  auto hp_of = [&](int r) {
+    long long p0 = 0;
+#pragma unroll
+    for (int q = 0; q < R; ++q) p0 = (q == r) ? hp[q] : p0;
+    return p0;
+  };
+  auto span_of = [&](int r) { return hu_of(r) >= 0 ? max(hn_of(r), 1) : 0; };
+  auto make_chunk = [&](int r, int c0) {
+    Chunk c;
+    while (r < R && c0 >= span_of(r)) {
+      ++r;
+      c0 = 0;
+    }
+    c.r = r;
+    c.c0 = c0;
+    c.n = r < R ? max(0, min(PC, hn_of(r) - c0)) : 0;
+    return c;
+  };
+  // lanes [0, PC) hold the i-side slots of the chunk's pairs, lanes [PC, 2 PC) the j-side slots
+  auto load_slots = [&](const Chunk& c) {
+    int sl = 0;
+    if (c.n > 0) {
+      const long long q = hp_of(c.r) + c.c0;
+      if (lane < c.n) sl = v.pair_i[q + lane];
+      else if (lane >= PC && lane < PC + c.n) sl = v.pair_j[q + lane - PC];
+    }
+    return sl;
+  };
+  double2 pf[NL];
+  auto issue_loads = [&](const Chunk& c, int slots) {
+#pragma unroll
+    for (int it = 0; it < NL; ++it) {
+      const int f = it * 64 + lane;
+      const int rec = f / PARTS, part = f - rec * PARTS;
+      const int pr = rec >= PC ? rec - PC : rec;
+      const int sl = __shfl(slots, rec < 2 * PC ? rec : 0, 64);
+      double2 t = make_double2(0.0, 0.0);
+      if (rec < 2 * PC && pr < c.n)
+        t = *reinterpret_cast<const double2*>(v.cm_Y + (size_t)sl * YS + 2 * part);
+      pf[it] = t;
+    }
+  };
+  Chunk A = make_chunk(0, 0);
+  int slots_a = load_slots(A);
+  issue_loads(A, slots_a);
+  Chunk B = make_chunk(A.r, A.c0 + PC);
+  int slots_b = load_slots(B);
+  v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+  while (A.r < R) {
+    // registers -> LDS (the previous chunk's operands have been consumed)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < NL; ++it) {
+      const int f = it * 64 + lane;
+      const int rec = f / PARTS, part = f - rec * PARTS;
+      if (rec < 2 * PC) *reinterpret_cast<double2*>(lds + rec * PITCH + 2 * part) = pf[it];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // next chunk's records and the chunk after's indices go out before the contraction
+    if (B.n > 0) issue_loads(B, slots_b);
+    const Chunk C = make_chunk(B.r, B.c0 + PC);
+    const int slots_c = load_slots(C);
+    if (A.c0 == 0) acc = (v4f64){0.0, 0.0, 0.0, 0.0};
+    const int ksteps = (A.n * DP + 3) / 4;
+#pragma unroll
+    for (int h = 0; h < STEPS; ++h) {
+      if (h < ksteps) {
+        double a = lds[koff[h]];
+        double b = lds[PC * PITCH + koff[h]];
+        a = row_ok ? a : 0.0;
+        b = row_ok ? b : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+      }
+    }
+    if (A.c0 + PC >= span_of(A.r)) {
+      // last chunk of the block: write it out
+      double* out = v.red + L.ub + (size_t)hu_of(A.r) * D * D;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = (lane >> 4) + 4 * q;
+        if (row < D && i < D) out[row * D + i] = -acc[q];
+      }
+    }
+    A = B;
+    B = C;
+    slots_b = slots_c;
   }
 }
 
