@@ -11,12 +11,118 @@ FOUNTAIN = "/root/reference/data/sfm/fountain11.bin"  # only in the development 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+GT_FOUNTAIN = "/root/reference/data/sfm/gt_fountain11.bin"  # Camera v0 / CameraIntrinsicsPrior v0 archive
+
+
 @pytest.mark.skipif(not os.path.exists(FOUNTAIN), reason="reference fixture not on this machine")
-def test_cereal_archive_round_trip_is_byte_identical(tmp_path):
-    rec = io.read_theia_reconstruction(FOUNTAIN)
+@pytest.mark.parametrize("path", [FOUNTAIN, GT_FOUNTAIN])
+def test_cereal_archive_regenerated_from_parsed_fields_is_byte_identical(tmp_path, path):
+    """The writer builds the archive from scratch (no bytes of the input are reused): what it emits
+    for the parsed fields of the reference's own files must be those files, in both the current
+    class versions (fountain11.bin) and the legacy ones (gt_fountain11.bin)."""
+    rec = io.read_theia_reconstruction(path)
+    rec.raw = b""
     out = tmp_path / "same.bin"
     io.write_theia_reconstruction(str(out), rec)
-    assert out.read_bytes() == open(FOUNTAIN, "rb").read()
+    assert out.read_bytes() == open(path, "rb").read()
+
+
+def test_reconstruction_built_in_memory_round_trips(tmp_path):
+    """A Problem (mixed camera models, shared intrinsics groups) -> Reconstruction -> archive ->
+    Reconstruction -> flattened Problem gives back the same arrays: the hand-off file for a
+    real Theia + Ceres (tools/make_ceres_golden.md)."""
+    P = synth.make_problem(9, 80, 400, seed=4, scene="ring", spread=0.7, shared_group_size=2,
+                           models=[(abi.PINHOLE, 0.3), (abi.PINHOLE_RADIAL_TANGENTIAL, 0.2), (abi.FISHEYE, 0.2),
+                                   (abi.FOV, 0.15), (abi.DIVISION_UNDISTORTION, 0.15)])
+    rec = io.reconstruction_from_problem(P, image_size=(1000, 800))
+    path = tmp_path / "built.bin"
+    io.write_theia_reconstruction(str(path), rec)
+    rec2 = io.read_theia_reconstruction(str(path))
+    assert rec2.versions["Camera"] == 1 and rec2.versions["CameraIntrinsicsPrior"] == 4
+    assert [v.name for v in rec2.views.values()] == [f"view_{c:06d}" for c in range(9)]
+    # shared groups: the views of a group point at ONE intrinsics object in the archive
+    ptrs = {}
+    for vid, v in rec2.views.items():
+        ptrs.setdefault(rec2.view_to_group[vid], set()).add(v.intrinsics_ptr)
+    assert all(len(p) == 1 for p in ptrs.values()) and len(ptrs) == P.num_groups
+    Q = io.flatten_reconstruction(rec2, intrinsics_to_optimize=abi.INTRINSICS_DEFAULT)
+    np.testing.assert_array_equal(Q.extrinsics, P.extrinsics)
+    np.testing.assert_array_equal(Q.camera_group, P.camera_group)
+    np.testing.assert_array_equal(Q.group_model, P.group_model)
+    np.testing.assert_array_equal(Q.intrinsics, P.intrinsics)
+    np.testing.assert_array_equal(Q.points, P.points)
+    # flatten orders observations by (track, view): compare as sets of rows
+    key = lambda X: np.lexsort((X.obs_camera, X.obs_point))  # noqa: E731
+    kq, kp = key(Q), key(P)
+    np.testing.assert_array_equal(Q.obs_camera[kq], P.obs_camera[kp])
+    np.testing.assert_array_equal(Q.obs_point[kq], P.obs_point[kp])
+    np.testing.assert_array_equal(Q.obs_xy[kq], P.obs_xy[kp])
+    # written twice -> identical bytes (deterministic writer)
+    path2 = tmp_path / "again.bin"
+    io.write_theia_reconstruction(str(path2), io.reconstruction_from_problem(P, image_size=(1000, 800)))
+    assert path.read_bytes() == path2.read_bytes()
+
+
+def _write_bundle(path, cams, pts):
+    """cams: (f, k1, k2, R[3x3], t[3]); pts: (X[3], rgb, [(cam, key, x, y), ...])"""
+    with open(path, "w") as fh:
+        fh.write("# Bundle file v0.3\n%d %d\n" % (len(cams), len(pts)))
+        for f, k1, k2, R, t in cams:
+            fh.write("%.9g %.9g %.9g\n" % (f, k1, k2))
+            for row in R:
+                fh.write("%.17g %.17g %.17g\n" % tuple(row))
+            fh.write("%.17g %.17g %.17g\n" % tuple(t))
+        for X, rgb, views in pts:
+            fh.write("%.17g %.17g %.17g\n%d %d %d\n" % (*X, *rgb))
+            fh.write("%d " % len(views) + " ".join("%d %d %.4f %.4f" % v for v in views) + "\n")
+
+
+def test_bundler_reader_follows_the_reference_importer(tmp_path):
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(5)
+    cams = []
+    for i in range(4):
+        R = Rotation.from_rotvec(0.3 * rng.standard_normal(3)).as_matrix()
+        cams.append((700.0 + 10.3 * i, -0.05, 0.01, R, rng.standard_normal(3)))
+    cams[2] = (0.0, 0.0, 0.0, cams[2][3], cams[2][4])  # invalid focal length: the view is dropped
+    pts = [
+        ((1.0, 2.0, 9.0), (10, 20, 30), [(0, 5, 12.75, -3.25), (1, 6, -7.5, 8.9), (3, 2, 1.0, 1.0)]),
+        ((0.0, 0.0, 0.0), (1, 1, 1), [(0, 1, 1.0, 1.0), (1, 1, 2.0, 2.0)]),        # position exactly 0: skipped
+        ((2.0, 1.0, 7.0), (255, 0, 7), [(0, 1, 4.0, 4.0), (0, 2, 5.0, 5.0)]),      # a view twice: skipped
+        ((3.0, 1.0, 8.0), (9, 9, 9), [(2, 1, 4.0, 4.0), (1, 2, 5.2, -6.8)]),       # one left after the drop: skipped
+        ((4.0, -1.0, 6.0), (0, 128, 255), [(2, 0, 1.0, 1.0), (1, 3, 100.0, 50.0), (3, 4, -20.9, 30.1)]),
+    ]
+    bundle = tmp_path / "bundle.out"
+    _write_bundle(bundle, cams, pts)
+    lst = tmp_path / "list.txt"
+    lst.write_text("imgs/a.jpg 0 650.5\nimgs/b.jpg\nimgs/c.jpg 0 600\nd.jpg 0 0\n")
+    rec = io.read_bundler(str(bundle), str(lst))
+    assert sorted(rec.views) == [0, 1, 3] and [rec.views[v].name for v in (0, 1, 3)] == ["a.jpg", "b.jpg", "d.jpg"]
+    assert rec.views[0].prior.priors["focal_length"] == (True, [650.5])
+    assert rec.views[1].prior.priors["focal_length"][0] is False
+    assert sorted(rec.tracks) == [0, 1] and rec.next_track_id == 2
+    assert rec.tracks[0].color == (10, 20, 30) and rec.tracks[1].view_ids == [1, 3]
+    # conventions (read_bundler_files.cc:94-133): C = -R_t^T t', R_t = diag(1,-1,-1) R
+    flip = np.diag([1.0, -1.0, -1.0])
+    for i in (0, 1, 3):
+        f, k1, k2, R, t = cams[i]
+        Rt = flip @ R
+        v = rec.views[i]
+        np.testing.assert_allclose(Rotation.from_rotvec(v.extrinsics[3:]).as_matrix(), Rt, atol=1e-12)
+        np.testing.assert_allclose(v.extrinsics[:3], -Rt.T @ (flip @ t), atol=1e-12)
+        assert v.intrinsics[0] == float(np.float32(f)) and v.intrinsics[5] == float(np.float32(k1))
+        assert v.intrinsics[3] == 0.0 and v.intrinsics[4] == 0.0
+    # keypoints are truncated to integers and y is flipped, exactly as the importer does
+    assert rec.views[0].features[0] == (12.0, 3.0) and rec.views[1].features[0] == (-7.0, -8.0)
+    assert rec.views[3].features[1] == (-20.0, -30.0)
+    np.testing.assert_array_equal(rec.tracks[1].point, [4.0, -1.0, 6.0, 1.0])
+    # and the result flattens / serialises like any other reconstruction
+    P = io.flatten_reconstruction(rec)
+    assert (P.num_cameras, P.num_points, P.num_observations) == (3, 2, 5)
+    out = tmp_path / "bundler.bin"
+    io.write_theia_reconstruction(str(out), rec)
+    assert io.flatten_reconstruction(io.read_theia_reconstruction(str(out))).num_observations == 5
+
 
 
 @pytest.mark.skipif(not os.path.exists(FOUNTAIN), reason="reference fixture not on this machine")
