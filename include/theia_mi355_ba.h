@@ -474,6 +474,41 @@ int32_t tmi_ba_select_good_tracks(const tmi_ba_problem* problem, int32_t device,
                                   int32_t* stats_len, double* stats_err,
                                   tmi_ba_select_summary* summary);
 
+/* Batched theia::BundleAdjustTwoViews (src/theia/sfm/bundle_adjustment/bundle_adjust_two_views.cc:
+ * 113-191; called once per verified view pair from two_view_match_geometric_verification.cc:285):
+ * every pair is an independent small bundle adjustment -- camera 1 extrinsics constant, camera 2
+ * extrinsics free, each camera's intrinsics constant or free in the focal length only (:66-98),
+ * one homogeneous point per correspondence seen by both cameras, no loss, DENSE_SCHUR, at most
+ * max_num_iterations (the reference: 200) iterations, otherwise Ceres' default solver options
+ * (SetSolverOptions :58-68).  One wavefront per pair runs the pair's whole trust-region solve.
+ * Arrays are caller-owned; extrinsics2, intrinsics1/2 (focal length) and points are updated in place
+ * for the pairs whose termination is 0 or 1 (Ceres' IsSolutionUsable).
+ *   point_dof: 4 = the reference (no point parameterization); 3 holds the homogeneous w fixed.
+ *   pair_termination / pair_iterations / pair_initial_cost / pair_final_cost [num_pairs] may be NULL;
+ *   termination: 0 CONVERGENCE, 1 NO_CONVERGENCE, 2 FAILURE, 3 residual evaluation failed at the
+ *   start point, -1 pair without correspondences. */
+typedef struct tmi_ba_two_view_batch {
+  int32_t num_pairs;
+  const double* extrinsics1;            /* [6 * num_pairs] held constant                       */
+  double* extrinsics2;                  /* [6 * num_pairs] in/out                              */
+  const int32_t* model1;                /* [num_pairs] tmi_ba_camera_model                     */
+  const int32_t* model2;
+  double* intrinsics1;                  /* [10 * num_pairs] model order, zero padded; in/out   */
+  double* intrinsics2;
+  const uint8_t* constant_intrinsics1;  /* [num_pairs] TwoViewBundleAdjustmentOptions flags;   */
+  const uint8_t* constant_intrinsics2;  /*   NULL = constant (the reference default)           */
+  const int64_t* correspondence_ptr;    /* [num_pairs + 1] ranges into the arrays below        */
+  const double* features1;              /* [2 * N] pixel in image 1                            */
+  const double* features2;              /* [2 * N] pixel in image 2                            */
+  double* points;                       /* [4 * N] homogeneous points, in/out                  */
+} tmi_ba_two_view_batch;
+
+int32_t tmi_ba_adjust_two_views(tmi_ba_two_view_batch* batch, int32_t point_dof,
+                                int32_t max_num_iterations, int32_t device,
+                                int8_t* pair_termination, int32_t* pair_iterations,
+                                double* pair_initial_cost, double* pair_final_cost,
+                                tmi_ba_track_batch_summary* summary);
+
 /* Host-only: statistics of the static structure the engine would build for
  * rank `rank` of `world` (no GPU needed).  Used by the CPU tests of the track
  * sharding: out[0] tracks owned, out[1] observations owned, out[2] reduced

@@ -2038,3 +2038,99 @@ int32_t oracle_select_good_tracks(const tmi_ba_problem* P, int32_t long_track_le
   free(st);
   return TMI_BA_OK;
 }
+
+/* ---- BundleAdjustTwoViews (reference bundle_adjust_two_views.cc:113-191), one pair at a time -----
+ * The pair is an ordinary problem for the LM above: two cameras (the first with constant
+ * extrinsics), two private intrinsics groups whose only free coordinate is the focal length when
+ * TwoViewBundleAdjustmentOptions says so (:66-98: SubsetParameterization over indices 1..n-1), one
+ * point per correspondence observed by both, DENSE_SCHUR, 200 iterations, Ceres' default
+ * tolerances and radius bounds (SetSolverOptions :58-68 sets nothing else), no loss, no inner
+ * iterations. */
+int32_t oracle_adjust_two_views(tmi_ba_two_view_batch* B, int32_t point_dof, int32_t max_num_iterations,
+                                int8_t* termination, int32_t* iterations, double* initial_cost,
+                                double* final_cost) {
+  if (!B) return TMI_BA_ERR_INVALID_ARGUMENT;
+  tmi_ba_options o;
+  memset(&o, 0, sizeof(o));
+  o.loss_function_type = TMI_BA_LOSS_TRIVIAL;
+  o.robust_loss_width = 2.0;
+  o.linear_solver_type = TMI_BA_DENSE_SCHUR;
+  o.preconditioner_type = TMI_BA_PRECOND_SCHUR_JACOBI;
+  o.num_threads = 1;
+  o.max_num_iterations = max_num_iterations;
+  o.max_solver_time_in_seconds = 1e9;
+  o.use_inner_iterations = 0;
+  o.function_tolerance = 1e-6;
+  o.gradient_tolerance = 1e-10;
+  o.parameter_tolerance = 1e-8;
+  o.max_trust_region_radius = 1e16;
+  o.initial_trust_region_radius = 1e4;
+  o.min_trust_region_radius = 1e-32;
+  o.min_relative_decrease = 1e-3;
+  o.min_lm_diagonal = 1e-6;
+  o.max_lm_diagonal = 1e32;
+  o.eta = 0.1;
+  o.max_linear_solver_iterations = 500;
+  o.max_num_consecutive_invalid_steps = 5;
+  o.jacobi_scaling = 1;
+  o.point_dof = point_dof;
+  o.device = -1;
+  o.residual_precision = 64;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int p = 0; p < B->num_pairs; ++p) {
+    const int64_t c0 = B->correspondence_ptr[p], n = B->correspondence_ptr[p + 1] - c0;
+    if (n <= 0) {
+      if (termination) termination[p] = -1;
+      if (iterations) iterations[p] = 0;
+      if (initial_cost) initial_cost[p] = 0.0;
+      if (final_cost) final_cost[p] = 0.0;
+      continue;
+    }
+    const int n1 = model_size(B->model1[p]), n2 = model_size(B->model2[p]);
+    double ext[12], intr[20];
+    memcpy(ext, B->extrinsics1 + 6 * (size_t)p, sizeof(double) * 6);
+    memcpy(ext + 6, B->extrinsics2 + 6 * (size_t)p, sizeof(double) * 6);
+    memcpy(intr, B->intrinsics1 + 10 * (size_t)p, sizeof(double) * (size_t)n1);
+    memcpy(intr + n1, B->intrinsics2 + 10 * (size_t)p, sizeof(double) * (size_t)n2);
+    int32_t cgrp[2] = {0, 1}, gmodel[2] = {B->model1[p], B->model2[p]}, goff[3] = {0, n1, n1 + n2};
+    uint8_t cflag[2] = {(uint8_t)(TMI_BA_CAMERA_POSITION_CONSTANT | TMI_BA_CAMERA_ORIENTATION_CONSTANT), 0};
+    uint8_t iconst[20];
+    memset(iconst, 1, sizeof(iconst));
+    if (B->constant_intrinsics1 && !B->constant_intrinsics1[p]) iconst[0] = 0;
+    if (B->constant_intrinsics2 && !B->constant_intrinsics2[p]) iconst[n1] = 0;
+    int32_t* ocam = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)n);
+    int32_t* opt = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)n);
+    double* oxy = (double*)malloc(sizeof(double) * 4 * (size_t)n);
+    for (int64_t q = 0; q < n; ++q) {
+      ocam[2 * q] = 0;
+      ocam[2 * q + 1] = 1;
+      opt[2 * q] = opt[2 * q + 1] = (int32_t)q;
+      oxy[4 * q] = B->features1[2 * (c0 + q)];
+      oxy[4 * q + 1] = B->features1[2 * (c0 + q) + 1];
+      oxy[4 * q + 2] = B->features2[2 * (c0 + q)];
+      oxy[4 * q + 3] = B->features2[2 * (c0 + q) + 1];
+    }
+    tmi_ba_problem Q;
+    memset(&Q, 0, sizeof(Q));
+    Q.num_cameras = 2; Q.extrinsics = ext; Q.camera_group = cgrp; Q.camera_flags = cflag;
+    Q.num_groups = 2; Q.group_model = gmodel; Q.group_offset = goff; Q.intrinsics = intr;
+    Q.intrinsics_constant = iconst;
+    Q.num_points = (int32_t)n; Q.points = B->points + 4 * (size_t)c0; Q.point_constant = NULL;
+    Q.num_observations = 2 * n; Q.obs_camera = ocam; Q.obs_point = opt; Q.obs_xy = oxy;
+    tmi_ba_summary sm;
+    const int32_t st = oracle_ba_solve(&Q, &o, &sm);
+    int8_t t = (int8_t)sm.termination;
+    if (st == TMI_BA_ERR_EVALUATION_FAILED) t = 3;
+    if (termination) termination[p] = t;
+    if (iterations) iterations[p] = sm.num_iterations;
+    if (initial_cost) initial_cost[p] = sm.initial_cost;
+    if (final_cost) final_cost[p] = sm.final_cost;
+    if (sm.success) {  /* the points were updated in place by the solve */
+      memcpy(B->extrinsics2 + 6 * (size_t)p, ext + 6, sizeof(double) * 6);
+      B->intrinsics1[10 * (size_t)p] = intr[0];
+      B->intrinsics2[10 * (size_t)p] = intr[n1];
+    }
+    free(ocam); free(opt); free(oxy);
+  }
+  return TMI_BA_OK;
+}

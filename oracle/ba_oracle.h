@@ -120,6 +120,12 @@ int32_t oracle_select_good_tracks(const tmi_ba_problem* problem, int32_t long_tr
                                   const uint8_t* view_mask, uint8_t* selected,
                                   int32_t* stats_len, double* stats_err);
 
+/* theia::BundleAdjustTwoViews for every pair of the batch (bundle_adjust_two_views.cc:113-191),
+ * through the LM above.  Same arrays and codes as tmi_ba_adjust_two_views. */
+int32_t oracle_adjust_two_views(tmi_ba_two_view_batch* batch, int32_t point_dof, int32_t max_num_iterations,
+                                int8_t* termination, int32_t* iterations, double* initial_cost,
+                                double* final_cost);
+
 int32_t oracle_num_threads(void);
 /* OpenMP threads used by the calls that follow (bench.py: single-thread baseline). */
 void oracle_set_num_threads(int32_t n);

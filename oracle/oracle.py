@@ -68,6 +68,9 @@ def lib():
         L.oracle_adjust_tracks.argtypes = [C.POINTER(abi.CProblem), C.POINTER(abi.COptions),
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_adjust_tracks.restype = C.c_int32
+        L.oracle_adjust_two_views.argtypes = [C.POINTER(abi.CTwoViewBatch), C.c_int32, C.c_int32,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_adjust_two_views.restype = C.c_int32
         L.oracle_sufficient_triangulation_angle.argtypes = [C.c_void_p, C.c_int64, C.c_double]
         L.oracle_sufficient_triangulation_angle.restype = C.c_int32
         L.oracle_filter_outlier_tracks.argtypes = [C.POINTER(abi.CProblem), C.c_double, C.c_double,
@@ -201,6 +204,20 @@ def adjust_tracks(problem: abi.Problem, options: abi.COptions):
     cp = problem.as_c()
     st = lib().oracle_adjust_tracks(C.byref(cp), C.byref(options), term.ctypes.data,
                                     iters.ctypes.data, c0.ctypes.data, c1.ctypes.data)
+    assert st == 0, st
+    return term, iters, c0, c1
+
+
+def adjust_two_views(batch: abi.TwoViewBatch, point_dof: int = 4, max_num_iterations: int = 200):
+    """BundleAdjustTwoViews pair by pair on the CPU; the batch is updated in place."""
+    n = batch.num_pairs
+    term = np.full(n, -1, dtype=np.int8)
+    iters = np.zeros(n, dtype=np.int32)
+    c0 = np.zeros(n)
+    c1 = np.zeros(n)
+    cb = batch.as_c()
+    st = lib().oracle_adjust_two_views(C.byref(cb), int(point_dof), int(max_num_iterations), term.ctypes.data,
+                                       iters.ctypes.data, c0.ctypes.data, c1.ctypes.data)
     assert st == 0, st
     return term, iters, c0, c1
 

@@ -166,6 +166,24 @@ class CTrackBatchSummary(C.Structure):
     ]
 
 
+class CTwoViewBatch(C.Structure):
+    _fields_ = [
+        ("num_pairs", C.c_int32),
+        ("extrinsics1", C.POINTER(C.c_double)),
+        ("extrinsics2", C.POINTER(C.c_double)),
+        ("model1", C.POINTER(C.c_int32)),
+        ("model2", C.POINTER(C.c_int32)),
+        ("intrinsics1", C.POINTER(C.c_double)),
+        ("intrinsics2", C.POINTER(C.c_double)),
+        ("constant_intrinsics1", C.POINTER(C.c_uint8)),
+        ("constant_intrinsics2", C.POINTER(C.c_uint8)),
+        ("correspondence_ptr", C.POINTER(C.c_int64)),
+        ("features1", C.POINTER(C.c_double)),
+        ("features2", C.POINTER(C.c_double)),
+        ("points", C.POINTER(C.c_double)),
+    ]
+
+
 class CSelectSummary(C.Structure):
     _fields_ = [
         ("num_tracks", C.c_int64),
@@ -358,3 +376,63 @@ class Problem:
             "extrinsics", "camera_group", "camera_flags", "group_model", "group_offset",
             "intrinsics", "intrinsics_constant", "points", "point_constant", "obs_camera",
             "obs_point", "obs_xy")))
+
+
+@dataclass
+class TwoViewBatch:
+    """View pairs for the batched BundleAdjustTwoViews (``tmi_ba_two_view_batch``)."""
+
+    extrinsics1: np.ndarray            # [P, 6] constant
+    extrinsics2: np.ndarray            # [P, 6] in/out
+    model1: np.ndarray                 # [P] int32
+    model2: np.ndarray
+    intrinsics1: np.ndarray            # [P, 10] zero padded
+    intrinsics2: np.ndarray
+    constant_intrinsics1: np.ndarray   # [P] uint8
+    constant_intrinsics2: np.ndarray
+    correspondence_ptr: np.ndarray     # [P + 1] int64
+    features1: np.ndarray              # [N, 2]
+    features2: np.ndarray
+    points: np.ndarray                 # [N, 4]
+
+    def __post_init__(self):
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+        self.extrinsics1 = f64(self.extrinsics1).reshape(-1, 6)
+        self.extrinsics2 = f64(self.extrinsics2).reshape(-1, 6)
+        self.model1 = np.ascontiguousarray(self.model1, dtype=np.int32)
+        self.model2 = np.ascontiguousarray(self.model2, dtype=np.int32)
+        self.intrinsics1 = f64(self.intrinsics1).reshape(-1, 10)
+        self.intrinsics2 = f64(self.intrinsics2).reshape(-1, 10)
+        self.constant_intrinsics1 = np.ascontiguousarray(self.constant_intrinsics1, dtype=np.uint8)
+        self.constant_intrinsics2 = np.ascontiguousarray(self.constant_intrinsics2, dtype=np.uint8)
+        self.correspondence_ptr = np.ascontiguousarray(self.correspondence_ptr, dtype=np.int64)
+        self.features1 = f64(self.features1).reshape(-1, 2)
+        self.features2 = f64(self.features2).reshape(-1, 2)
+        self.points = f64(self.points).reshape(-1, 4)
+
+    @property
+    def num_pairs(self) -> int:
+        return self.extrinsics1.shape[0]
+
+    def copy(self) -> "TwoViewBatch":
+        return TwoViewBatch(*[getattr(self, f).copy() for f in (
+            "extrinsics1", "extrinsics2", "model1", "model2", "intrinsics1", "intrinsics2",
+            "constant_intrinsics1", "constant_intrinsics2", "correspondence_ptr", "features1", "features2",
+            "points")])
+
+    def as_c(self) -> CTwoViewBatch:
+        b = CTwoViewBatch()
+        b.num_pairs = self.num_pairs
+        b.extrinsics1 = _ptr(self.extrinsics1, C.c_double)
+        b.extrinsics2 = _ptr(self.extrinsics2, C.c_double)
+        b.model1 = _ptr(self.model1, C.c_int32)
+        b.model2 = _ptr(self.model2, C.c_int32)
+        b.intrinsics1 = _ptr(self.intrinsics1, C.c_double)
+        b.intrinsics2 = _ptr(self.intrinsics2, C.c_double)
+        b.constant_intrinsics1 = _ptr(self.constant_intrinsics1, C.c_uint8)
+        b.constant_intrinsics2 = _ptr(self.constant_intrinsics2, C.c_uint8)
+        b.correspondence_ptr = _ptr(self.correspondence_ptr, C.c_int64)
+        b.features1 = _ptr(self.features1, C.c_double)
+        b.features2 = _ptr(self.features2, C.c_double)
+        b.points = _ptr(self.points, C.c_double)
+        return b

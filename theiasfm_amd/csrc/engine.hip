@@ -26,6 +26,7 @@
 #include "kernels.h"
 #include "track_kernels.h"
 #include "inner_kernels.h"
+#include "two_view_kernels.h"
 #include "structure.h"
 
 namespace tmi {
@@ -1902,6 +1903,162 @@ int32_t tmi_ba_select_good_tracks(const tmi_ba_problem* P, int32_t device,
   tmi_ba_solver_destroy(s);
   sum->seconds = now_s() - t0;
   return rc;
+}
+
+// ---- batched two-view bundle adjustment ------------------------------
+int32_t tmi_ba_adjust_two_views(tmi_ba_two_view_batch* Bh, int32_t point_dof, int32_t max_num_iterations,
+                                int32_t device, int8_t* pair_termination, int32_t* pair_iterations,
+                                double* pair_initial_cost, double* pair_final_cost,
+                                tmi_ba_track_batch_summary* sum) {
+  if (!Bh || !sum) return TMI_BA_ERR_INVALID_ARGUMENT;
+  memset(sum, 0, sizeof(*sum));
+  if ((point_dof != 3 && point_dof != 4) || Bh->num_pairs < 0 || max_num_iterations < 0)
+    return TMI_BA_ERR_INVALID_ARGUMENT;
+  const int P = Bh->num_pairs;
+  if (P > 0 && (!Bh->extrinsics1 || !Bh->extrinsics2 || !Bh->model1 || !Bh->model2 || !Bh->intrinsics1 ||
+                !Bh->intrinsics2 || !Bh->correspondence_ptr))
+    return TMI_BA_ERR_INVALID_ARGUMENT;
+  const double t0 = now_s();
+  const int64_t N = P ? Bh->correspondence_ptr[P] : 0;
+  for (int p = 0; p < P; ++p) {
+    if (Bh->correspondence_ptr[p + 1] < Bh->correspondence_ptr[p] || Bh->model1[p] < 0 || Bh->model1[p] > 4 ||
+        Bh->model2[p] < 0 || Bh->model2[p] > 4)
+      return TMI_BA_ERR_INVALID_ARGUMENT;
+  }
+  if (N > 0 && (!Bh->features1 || !Bh->features2 || !Bh->points)) return TMI_BA_ERR_INVALID_ARGUMENT;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    g_last_error = "no HIP device visible (the device path has no CPU fallback)";
+    return TMI_BA_ERR_NO_DEVICE;
+  }
+  if (device >= ndev) return TMI_BA_ERR_INVALID_ARGUMENT;
+  if (P == 0) return TMI_BA_OK;
+  // a throw-away holder for the allocations (freed by tmi_ba_solver_destroy)
+  tmi_ba_solver* s = new tmi_ba_solver();
+  s->light = true;
+  auto done = [&](int rc) {
+    if (rc != TMI_BA_OK) g_last_error = s->error;
+    tmi_ba_solver_destroy(s);
+    sum->seconds = now_s() - t0;
+    return rc;
+  };
+  if (device >= 0) s->device = device;
+  else if (hipGetDevice(&s->device) != hipSuccess) return done(TMI_BA_ERR_DEVICE);
+  if (hipSetDevice(s->device) != hipSuccess) return done(TMI_BA_ERR_DEVICE);
+  if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return done(TMI_BA_ERR_DEVICE);
+  int rc;
+  TwoViewBatch B;
+  memset(&B, 0, sizeof(B));
+  B.num_pairs = P;
+  auto up = [&](auto** dst, const auto* src, size_t n) -> int {
+    typedef typename std::remove_const<typename std::remove_pointer<decltype(src)>::type>::type T;
+    T* d = nullptr;
+    int r = dev_alloc(s, &d, n);
+    if (r) return r;
+    if (n && hipMemcpyAsync(d, src, n * sizeof(T), hipMemcpyHostToDevice, s->stream) != hipSuccess) {
+      s->error = "hipMemcpyAsync failed";
+      return TMI_BA_ERR_DEVICE;
+    }
+    *dst = d;
+    return TMI_BA_OK;
+  };
+  std::vector<unsigned char> c1((size_t)P, 1), c2((size_t)P, 1);
+  if (Bh->constant_intrinsics1) c1.assign(Bh->constant_intrinsics1, Bh->constant_intrinsics1 + P);
+  if (Bh->constant_intrinsics2) c2.assign(Bh->constant_intrinsics2, Bh->constant_intrinsics2 + P);
+  std::vector<long long> cptr(Bh->correspondence_ptr, Bh->correspondence_ptr + P + 1);
+  double *d_e1, *d_e2, *d_k1, *d_k2, *d_f1, *d_f2, *d_pts;
+  int *d_m1, *d_m2;
+  unsigned char *d_c1, *d_c2;
+  long long* d_cptr;
+  const size_t Nn = (size_t)std::max<int64_t>(N, 1);
+  if ((rc = up(&d_e1, Bh->extrinsics1, (size_t)6 * P))) return done(rc);
+  if ((rc = up(&d_e2, (const double*)Bh->extrinsics2, (size_t)6 * P))) return done(rc);
+  if ((rc = up(&d_m1, Bh->model1, (size_t)P))) return done(rc);
+  if ((rc = up(&d_m2, Bh->model2, (size_t)P))) return done(rc);
+  if ((rc = up(&d_k1, (const double*)Bh->intrinsics1, (size_t)10 * P))) return done(rc);
+  if ((rc = up(&d_k2, (const double*)Bh->intrinsics2, (size_t)10 * P))) return done(rc);
+  if ((rc = up(&d_c1, (const unsigned char*)c1.data(), (size_t)P))) return done(rc);
+  if ((rc = up(&d_c2, (const unsigned char*)c2.data(), (size_t)P))) return done(rc);
+  if ((rc = up(&d_cptr, (const long long*)cptr.data(), (size_t)P + 1))) return done(rc);
+  if ((rc = up(&d_f1, Bh->features1, (size_t)2 * N))) return done(rc);
+  if ((rc = up(&d_f2, Bh->features2, (size_t)2 * N))) return done(rc);
+  if ((rc = up(&d_pts, (const double*)Bh->points, (size_t)4 * N))) return done(rc);
+  B.ext1 = d_e1; B.ext2 = d_e2; B.model1 = d_m1; B.model2 = d_m2; B.intr1 = d_k1; B.intr2 = d_k2;
+  B.const1 = d_c1; B.const2 = d_c2; B.corr_ptr = d_cptr; B.feat1 = d_f1; B.feat2 = d_f2; B.points = d_pts;
+  if ((rc = dev_alloc(s, &B.points_c, 4 * Nn))) return done(rc);
+  if ((rc = dev_alloc(s, &B.scale_p, 4 * Nn))) return done(rc);
+  signed char* d_term;
+  int* d_iter;
+  double *d_c0, *d_cf;
+  if ((rc = dev_alloc(s, &d_term, (size_t)P))) return done(rc);
+  if ((rc = dev_alloc(s, &d_iter, (size_t)P))) return done(rc);
+  if ((rc = dev_alloc(s, &d_c0, (size_t)P))) return done(rc);
+  if ((rc = dev_alloc(s, &d_cf, (size_t)P))) return done(rc);
+  TwoViewArgs A;
+  A.point_dof = point_dof;
+  A.max_num_iterations = max_num_iterations;
+  A.jacobi_scaling = 1;
+  // Ceres Solver::Options defaults: bundle_adjust_two_views.cc:58-68 overrides none of these
+  A.function_tolerance = 1e-6;
+  A.gradient_tolerance = 1e-10;
+  A.parameter_tolerance = 1e-8;
+  A.initial_radius = 1e4;
+  A.max_radius = 1e16;
+  A.min_radius = 1e-32;
+  A.min_relative_decrease = 1e-3;
+  A.lm_lo = 1e-6;
+  A.lm_hi = 1e32;
+  A.max_num_consecutive_invalid_steps = 5;
+  hipEvent_t ea, eb;
+  if (hipEventCreate(&ea) != hipSuccess || hipEventCreate(&eb) != hipSuccess) return done(TMI_BA_ERR_DEVICE);
+  hipEventRecord(ea, s->stream);
+  if (point_dof == 3)
+    hipLaunchKernelGGL(two_view_lm_kernel<3>, dim3((P + 3) / 4), dim3(256), 0, s->stream, B, A, d_term, d_iter, d_c0, d_cf);
+  else
+    hipLaunchKernelGGL(two_view_lm_kernel<4>, dim3((P + 3) / 4), dim3(256), 0, s->stream, B, A, d_term, d_iter, d_c0, d_cf);
+  hipEventRecord(eb, s->stream);
+  std::vector<signed char> term((size_t)P);
+  std::vector<int> iters((size_t)P);
+  std::vector<double> c0((size_t)P), cf((size_t)P), e2((size_t)6 * P), k1((size_t)10 * P), k2((size_t)10 * P),
+      pts((size_t)4 * N);
+  bool okc = hipMemcpyAsync(term.data(), d_term, (size_t)P, hipMemcpyDeviceToHost, s->stream) == hipSuccess;
+  okc = okc && hipMemcpyAsync(iters.data(), d_iter, (size_t)P * sizeof(int), hipMemcpyDeviceToHost, s->stream) == hipSuccess;
+  okc = okc && hipMemcpyAsync(c0.data(), d_c0, (size_t)P * 8, hipMemcpyDeviceToHost, s->stream) == hipSuccess;
+  okc = okc && hipMemcpyAsync(cf.data(), d_cf, (size_t)P * 8, hipMemcpyDeviceToHost, s->stream) == hipSuccess;
+  okc = okc && hipMemcpyAsync(e2.data(), d_e2, e2.size() * 8, hipMemcpyDeviceToHost, s->stream) == hipSuccess;
+  okc = okc && hipMemcpyAsync(k1.data(), d_k1, k1.size() * 8, hipMemcpyDeviceToHost, s->stream) == hipSuccess;
+  okc = okc && hipMemcpyAsync(k2.data(), d_k2, k2.size() * 8, hipMemcpyDeviceToHost, s->stream) == hipSuccess;
+  if (N) okc = okc && hipMemcpyAsync(pts.data(), d_pts, pts.size() * 8, hipMemcpyDeviceToHost, s->stream) == hipSuccess;
+  const hipError_t se = hipStreamSynchronize(s->stream);
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, ea, eb);
+  hipEventDestroy(ea);
+  hipEventDestroy(eb);
+  if (!okc || se != hipSuccess) {
+    s->error = std::string("two-view batch failed on the device: ") + hipGetErrorString(se);
+    return done(TMI_BA_ERR_DEVICE);
+  }
+  for (int p = 0; p < P; ++p) {
+    const int t = term[p];
+    if (t >= 0) {
+      sum->num_tracks++;
+      if (t == 0 || t == 1) sum->num_success++;
+      sum->total_iterations += iters[p];
+    }
+    if (t == 0 || t == 1) {  // IsSolutionUsable: write back
+      for (int a = 0; a < 6; ++a) Bh->extrinsics2[(size_t)6 * p + a] = e2[(size_t)6 * p + a];
+      Bh->intrinsics1[(size_t)10 * p] = k1[(size_t)10 * p];
+      Bh->intrinsics2[(size_t)10 * p] = k2[(size_t)10 * p];
+      for (int64_t q = Bh->correspondence_ptr[p]; q < Bh->correspondence_ptr[p + 1]; ++q)
+        for (int a = 0; a < 4; ++a) Bh->points[4 * q + a] = pts[4 * q + a];
+    }
+    if (pair_termination) pair_termination[p] = (int8_t)t;
+    if (pair_iterations) pair_iterations[p] = iters[p];
+    if (pair_initial_cost) pair_initial_cost[p] = c0[p];
+    if (pair_final_cost) pair_final_cost[p] = cf[p];
+  }
+  sum->kernel_seconds = ms * 1e-3;
+  return done(TMI_BA_OK);
 }
 
 int32_t tmi_ba_structure_stats(const tmi_ba_problem* P, int32_t rank, int32_t world, int64_t out[12]) {

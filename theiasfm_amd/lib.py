@@ -30,6 +30,7 @@ EXPORTS = (
     "tmi_ba_solver_filter_outlier_tracks", "tmi_ba_filter_outlier_tracks",
     "tmi_ba_solver_adjust_tracks", "tmi_ba_adjust_tracks",
     "tmi_ba_solver_select_good_tracks", "tmi_ba_select_good_tracks",
+    "tmi_ba_adjust_two_views",
 )
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
@@ -109,6 +110,9 @@ def load():
     L.tmi_ba_solver_adjust_tracks.restype = C.c_int32
     L.tmi_ba_adjust_tracks.argtypes = [P, O, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, TS]
     L.tmi_ba_adjust_tracks.restype = C.c_int32
+    L.tmi_ba_adjust_two_views.argtypes = [C.POINTER(abi.CTwoViewBatch), C.c_int32, C.c_int32, C.c_int32,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, TS]
+    L.tmi_ba_adjust_two_views.restype = C.c_int32
     SS = C.POINTER(abi.CSelectSummary)
     L.tmi_ba_solver_select_good_tracks.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, SS]
@@ -219,6 +223,26 @@ def adjust_tracks(problem: abi.Problem, options: abi.COptions):
                                 c0.ctypes.data, c1.ctypes.data, C.byref(ts))
     if st != 0:
         raise EngineError(st, "tmi_ba_adjust_tracks")
+    return term, iters, c0, c1, ts
+
+
+def adjust_two_views(batch: abi.TwoViewBatch, point_dof: int = 4, max_num_iterations: int = 200, device: int = -1):
+    """Batched BundleAdjustTwoViews; batch.extrinsics2 / intrinsics / points are updated in place
+    for the usable pairs.  Returns (termination [P] int8, iterations [P] int32, initial cost [P],
+    final cost [P], CTrackBatchSummary)."""
+    L = load()
+    cb = batch.as_c()
+    n = batch.num_pairs
+    term = np.full(n, -1, dtype=np.int8)
+    iters = np.zeros(n, dtype=np.int32)
+    c0 = np.zeros(n)
+    c1 = np.zeros(n)
+    ts = abi.CTrackBatchSummary()
+    st = L.tmi_ba_adjust_two_views(C.byref(cb), int(point_dof), int(max_num_iterations), int(device),
+                                   term.ctypes.data, iters.ctypes.data, c0.ctypes.data, c1.ctypes.data,
+                                   C.byref(ts))
+    if st != 0:
+        raise EngineError(st, "tmi_ba_adjust_two_views")
     return term, iters, c0, c1, ts
 
 

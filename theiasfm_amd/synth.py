@@ -285,3 +285,76 @@ def config(name: str, **kw) -> Problem:
     if name == "venice1778_heavy":
         kw.setdefault("heavy_tail", 0.002)
     return make_problem(nc, npt, nobs, seed=seeds[name], scene="ring", **kw)
+
+
+def make_two_view_batch(n_pairs: int, seed: int, *, min_corr: int = 30, max_corr: int = 400,
+                        models=None, free_intrinsics: float = 0.0, pixel_noise: float = 0.5,
+                        point_noise: float = 0.02) -> abi.TwoViewBatch:
+    """Seeded view pairs as two_view_match_geometric_verification.cc hands them to
+    BundleAdjustTwoViews (:285): camera 1 at the origin looking along +z, camera 2 a baseline away
+    with a small rotation, correspondences of points 4-10 units in front, pixels with noise, the
+    3D points as a (noisy) triangulation.  free_intrinsics: fraction of the pairs whose focal
+    lengths are optimised (TwoViewBundleAdjustmentOptions::constant_camera*_intrinsics = false)."""
+    rng = np.random.default_rng(seed)
+    counts = rng.integers(min_corr, max_corr + 1, n_pairs)
+    ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    N = int(ptr[-1])
+    e1 = np.zeros((n_pairs, 6))
+    e2 = np.zeros((n_pairs, 6))
+    e2[:, :3] = rng.normal(size=(n_pairs, 3)) * [1.0, 0.2, 0.2] + [1.0, 0, 0]
+    e2[:, 3:] = 0.15 * rng.normal(size=(n_pairs, 3))
+    m1 = np.zeros(n_pairs, np.int32)
+    m2 = np.zeros(n_pairs, np.int32)
+    if models:
+        edges = np.cumsum([fr for _, fr in models])
+        for arr in (m1, m2):
+            u = rng.random(n_pairs) * edges[-1]
+            arr[:] = [models[int(np.searchsorted(edges, x))][0] for x in u]
+
+    def intrinsics(model):
+        K = np.zeros((n_pairs, 10))
+        f = rng.uniform(600, 900, n_pairs)
+        for p in range(n_pairs):
+            m = model[p]
+            if m in (abi.PINHOLE, abi.PINHOLE_RADIAL_TANGENTIAL, abi.FISHEYE):
+                K[p, :5] = [f[p], 1.0, 0.0, 500.0, 400.0]
+                if m == abi.PINHOLE:
+                    K[p, 5:7] = [-0.05, 0.01]
+                elif m == abi.PINHOLE_RADIAL_TANGENTIAL:
+                    K[p, 5:10] = [-0.05, 0.01, 0.001, 1e-3, -1e-3]
+                else:
+                    K[p, 5:9] = [-0.02, 0.003, 0.0, 0.0]
+            elif m == abi.FOV:
+                K[p, :5] = [f[p], 1.0, 500.0, 400.0, 0.2]
+            else:
+                K[p, :5] = [f[p], 1.0, 500.0, 400.0, -1e-7]
+        return K
+
+    k1, k2 = intrinsics(m1), intrinsics(m2)
+    X = np.concatenate([rng.uniform(-2, 2, (N, 2)), rng.uniform(4, 10, (N, 1)), np.ones((N, 1))], 1)
+    pair_of = np.repeat(np.arange(n_pairs), counts)
+
+    def proj(ext, model, K):
+        Rm = Rotation.from_rotvec(ext[pair_of, 3:6]).as_matrix()
+        a = X[:, :3] - ext[pair_of, :3]
+        q = np.einsum("nij,nj->ni", Rm, a)
+        out = np.empty((N, 2))
+        for m in np.unique(model):
+            sel = np.nonzero(model[pair_of] == m)[0]
+            out[sel] = _distort(int(m), K[pair_of[sel], :abi.INTRINSICS_SIZE[m]], q[sel])
+        return out
+
+    f1 = proj(e1, m1, k1) + pixel_noise * rng.normal(size=(N, 2))
+    f2 = proj(e2, m2, k2) + pixel_noise * rng.normal(size=(N, 2))
+    pts = X.copy()
+    pts[:, :3] += point_noise * rng.normal(size=(N, 3))
+    e2_0 = e2.copy()
+    e2_0[:, :3] += 0.02 * rng.normal(size=(n_pairs, 3))
+    e2_0[:, 3:] += 0.004 * rng.normal(size=(n_pairs, 3))
+    free = rng.random(n_pairs) < free_intrinsics
+    c1 = np.where(free, 0, 1).astype(np.uint8)
+    c2 = np.where(free, 0, 1).astype(np.uint8)
+    k1_0, k2_0 = k1.copy(), k2.copy()
+    k1_0[free, 0] *= 1.01
+    k2_0[free, 0] *= 0.99
+    return abi.TwoViewBatch(e1, e2_0, m1, m2, k1_0, k2_0, c1, c2, ptr, f1, f2, pts)
