@@ -89,8 +89,39 @@ class BundleAdjuster {
   // what the reference keeps inside ceres::Problem
   struct Residual { ViewId view; TrackId track; double x, y; };
   std::vector<Residual> residuals_;
-  std::unordered_map<ViewId, uint8_t> camera_flags_;           // TMI_BA_CAMERA_* bits
-  std::unordered_map<TrackId, bool> track_constant_;
+  // id -> small state, a flat table when the ids are compact (Reconstruction hands them out
+  // consecutively) and a hash map otherwise: the reference pays hash look-ups into ceres::Problem
+  // per residual (5 M at Venice size); the per-residual path here is one array access.
+  class IdState {
+   public:
+    // -1 = absent
+    int Get(uint32_t id) const {
+      if (id < flat_.size()) return flat_[id];
+      auto it = sparse_.find(id);
+      return it == sparse_.end() ? -1 : it->second;
+    }
+    void Set(uint32_t id, int value) {
+      if (id < kFlatLimit) {
+        if (id >= flat_.size()) flat_.resize(static_cast<size_t>(id) + 1 + flat_.size() / 2, -1);
+        flat_[id] = static_cast<int16_t>(value);
+      } else {
+        sparse_[id] = static_cast<int16_t>(value);
+      }
+    }
+    void SetIfAbsent(uint32_t id, int value) {
+      if (Get(id) < 0) Set(id, value);
+    }
+    // ids present, ascending
+    std::vector<uint32_t> Ids() const;
+
+   private:
+    static constexpr uint32_t kFlatLimit = 1u << 27;
+    std::vector<int16_t> flat_;
+    std::unordered_map<uint32_t, int16_t> sparse_;
+  };
+  IdState camera_flags_;     // TMI_BA_CAMERA_* bits of the views that take part
+  IdState track_constant_;   // 1 constant / 0 variable for the tracks that take part
+  IdState track_estimated_;  // memo of Track::IsEstimated for the tracks AddView met
   std::unordered_map<CameraIntrinsicsGroupId, std::vector<uint8_t> > intrinsics_constant_;
   tmi_ba_summary device_summary_;
 };

@@ -28,6 +28,9 @@ class View {
     auto it = features_.find(track_id);
     return it == features_.end() ? nullptr : &it->second;
   }
+  // Extension: the (track id -> feature) table itself, for callers that walk every feature
+  // (the reference's TrackIds() + GetFeature() pair costs a copy and a look-up per feature).
+  const std::unordered_map<TrackId, Feature>& Features() const { return features_; }
   void AddFeature(const TrackId track_id, const Feature& feature) { features_[track_id] = feature; }
   bool RemoveFeature(const TrackId track_id) { return features_.erase(track_id) > 0; }
 

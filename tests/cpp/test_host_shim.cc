@@ -12,6 +12,7 @@
 
 #include "theia/sfm/bundle_adjustment/bundle_adjuster.h"
 #include "theia/sfm/bundle_adjustment/bundle_adjustment.h"
+#include "theia/sfm/bundle_adjustment/bundle_adjust_two_views.h"
 #include "theia/sfm/reconstruction.h"
 #include "theia/sfm/select_good_tracks_for_bundle_adjustment.h"
 #include "theia/sfm/set_outlier_tracks_to_unestimated.h"
@@ -325,12 +326,91 @@ static void TestTrackOpsGpu() {
   std::printf("track selection: %zu of 399 (all views), %zu (views 0,1)\n", chosen.size(), chosen2.size());
 }
 
+// BundleAdjustTwoViews (bundle_adjust_two_views.cc:113-191) and its batched form through the shim.
+static void TestTwoViewsGpu() {
+  unsigned s = 77;
+  auto make_pair = [&](Camera* c1, Camera* c2, std::vector<FeatureCorrespondence>* corr,
+                       std::vector<Eigen::Vector4d>* pts, int n) {
+    c1->SetFocalLength(800.0);
+    c1->SetPrincipalPoint(500.0, 400.0);
+    c2->SetFocalLength(760.0);
+    c2->SetPrincipalPoint(500.0, 400.0);
+    c2->SetPosition(Eigen::Vector3d(1.0 + 0.2 * urand(&s), 0.1 * urand(&s), 0.1 * urand(&s)));
+    c2->SetOrientationFromAngleAxis(Eigen::Vector3d(0.05 * urand(&s), -0.1 * urand(&s), 0.03));
+    for (int i = 0; i < n; ++i) {
+      const double X[3] = {4 * (urand(&s) - 0.5), 4 * (urand(&s) - 0.5), 5 + 5 * urand(&s)};
+      double px[2][2];
+      for (int c = 0; c < 2; ++c) {
+        const Camera& cam = c ? *c2 : *c1;
+        const double a[3] = {X[0] - cam.extrinsics()[0], X[1] - cam.extrinsics()[1], X[2] - cam.extrinsics()[2]};
+        double q[3];
+        Rodrigues(cam.extrinsics() + 3, a, q);
+        px[c][0] = cam.FocalLength() * q[0] / q[2] + 500.0 + 0.5 * (urand(&s) - 0.5);
+        px[c][1] = cam.FocalLength() * q[1] / q[2] + 400.0 + 0.5 * (urand(&s) - 0.5);
+      }
+      corr->emplace_back(Feature(px[0][0], px[0][1]), Feature(px[1][0], px[1][1]));
+      pts->emplace_back(X[0] + 0.05 * (urand(&s) - 0.5), X[1] + 0.05 * (urand(&s) - 0.5), X[2] + 0.05 * (urand(&s) - 0.5), 1.0);
+    }
+    // start camera 2 off its generating pose
+    c2->mutable_extrinsics()[0] += 0.03;
+    c2->mutable_extrinsics()[4] += 0.004;
+  };
+  const int P = 5;
+  std::vector<Camera> cam1(P), cam2(P), cam1b(P), cam2b(P);
+  std::vector<std::vector<FeatureCorrespondence>> corr(P);
+  std::vector<std::vector<Eigen::Vector4d>> pts(P), ptsb(P);
+  for (int p = 0; p < P; ++p) {
+    make_pair(&cam1[p], &cam2[p], &corr[p], &pts[p], 60 + 40 * p);
+    cam1b[p].DeepCopy(cam1[p]);
+    cam2b[p].DeepCopy(cam2[p]);
+    ptsb[p] = pts[p];
+  }
+  // one by one
+  std::vector<BundleAdjustmentSummary> single(P);
+  for (int p = 0; p < P; ++p) {
+    TwoViewBundleAdjustmentOptions o;
+    o.constant_camera2_intrinsics = (p % 2 == 0);
+    const double e1_before = cam1[p].extrinsics()[0], f1_before = cam1[p].FocalLength();
+    single[p] = BundleAdjustTwoViews(o, corr[p], &cam1[p], &cam2[p], &pts[p]);
+    EXPECT(single[p].success && single[p].final_cost < 0.05 * single[p].initial_cost);
+    EXPECT(cam1[p].extrinsics()[0] == e1_before && cam1[p].FocalLength() == f1_before);  // camera 1 constant
+    if (p % 2 == 0) EXPECT(cam2[p].FocalLength() == 760.0);
+    else EXPECT(cam2[p].FocalLength() != 760.0);
+  }
+  // all at once: the same results
+  std::vector<TwoViewBundleAdjustmentProblem> batch(P);
+  for (int p = 0; p < P; ++p) {
+    batch[p].options.constant_camera2_intrinsics = (p % 2 == 0);
+    batch[p].correspondences = &corr[p];
+    batch[p].camera1 = &cam1b[p];
+    batch[p].camera2 = &cam2b[p];
+    batch[p].points3d = &ptsb[p];
+  }
+  const std::vector<BundleAdjustmentSummary> all = BundleAdjustTwoViewsBatch(&batch);
+  EXPECT(all.size() == static_cast<size_t>(P));
+  double worst = 0.0;
+  for (int p = 0; p < P && all.size() == static_cast<size_t>(P); ++p) {
+    EXPECT(all[p].success == single[p].success);
+    EXPECT(all[p].final_cost == single[p].final_cost);
+    for (int a = 0; a < 6; ++a) worst = std::fmax(worst, std::fabs(cam2[p].extrinsics()[a] - cam2b[p].extrinsics()[a]));
+  }
+  std::printf("two-view BA: %d pairs, cost %.4e -> %.4e (pair 0), batched vs single max |d ext| %.2e\n", P,
+              single[0].initial_cost, single[0].final_cost, worst);
+  EXPECT(worst == 0.0);
+  // mismatched sizes: the reference CHECK-fails; the shim reports failure and touches nothing
+  std::vector<Eigen::Vector4d> short_pts(3);
+  Camera a, b;
+  const BundleAdjustmentSummary bad = BundleAdjustTwoViews(TwoViewBundleAdjustmentOptions(), corr[0], &a, &b, &short_pts);
+  EXPECT(!bad.success);
+}
+
 int main(int argc, char** argv) {
   const std::string mode = argc > 1 ? argv[1] : "cpu";
   TestSemantics();
   if (mode == "gpu") {
     TestGpu();
     TestTrackOpsGpu();
+    TestTwoViewsGpu();
   }
   std::printf("%s: %d failure(s)\n", mode.c_str(), g_fail);
   return g_fail ? 1 : 0;

@@ -123,6 +123,18 @@ struct DeviceView {
   double* partial;  // per-workgroup partial sums (several lanes of scalars)
   double* scal;     // device scalars
   int* flags;       // device flags (invalid residual, singular block, ...)
+  double* dotbuf;   // [Nrb] per-block partial dot products of the product kernels
+  int* ticket;      // [4][kTicketStride] arrival counters of the "last workgroup finishes the reduction" kernels
+  int* pcg_done;    // set by pcg_step once PCG has stopped: speculatively enqueued kernels return at once
+};
+
+// host-visible copy of the device scalars (pinned, mapped, coherent memory): published by a
+// kernel with system-scope stores + a release store of `seq`, polled by the host
+struct HostMirror {
+  double scal[32];
+  double red[8];
+  int flags[8];
+  unsigned long long seq;
 };
 
 // offsets into `red`

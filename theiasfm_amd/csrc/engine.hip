@@ -27,6 +27,8 @@
 #include "track_kernels.h"
 #include "inner_kernels.h"
 #include "two_view_kernels.h"
+#include "select_kernels.h"
+#include <hipcub/hipcub.hpp>
 #include "structure.h"
 
 namespace tmi {
@@ -49,11 +51,11 @@ static double now_s() {
 
 // ---- per (D, DP) launch table --------------------------------------------------
 struct Launch {
-  // evaluation at a parameter set: prepared camera records (default) or, with
-  // TMI_BA_LEGACY_EVAL=1, the per-observation Rodrigues path of round 1 (kept for A/B timing)
-  void (*linearize)(const DeviceView&, hipStream_t, const double* prep, int, double, int);
-  void (*cost)(const DeviceView&, hipStream_t, const double* prep, const double*, const double*,
-               const double*, int, double, int, int, double*);
+  // evaluation at a parameter set through its prepared camera records; `sums` / `flag_dst`:
+  // where the kernel's last workgroup leaves the grid-wide sums / the invalid-residual vote
+  void (*linearize)(const DeviceView&, hipStream_t, const double* prep, int, double, int, double* sums);
+  void (*cost)(const DeviceView&, hipStream_t, const double* prep, const double* pts, int, double, int, int,
+               double* partial, double* sums, double* flag_dst);
   void (*point_scale)(const DeviceView&, hipStream_t, int);
   void (*shared_blocks)(const DeviceView&, hipStream_t, RedLayout);
   void (*cross_add)(const DeviceView&, hipStream_t, RedLayout);
@@ -61,54 +63,43 @@ struct Launch {
   void (*camera_diag)(const DeviceView&, hipStream_t, RedLayout);
   void (*schur_offdiag)(const DeviceView&, hipStream_t, RedLayout);
   void (*expand_scale)(const DeviceView&, hipStream_t);
-  void (*expand)(const DeviceView&, hipStream_t, RedLayout, double, double, double);
+  void (*expand)(const DeviceView&, hipStream_t, RedLayout, double, double, double, int want_gmax);
   void (*precond)(const DeviceView&, hipStream_t, int);
-  void (*spmv)(const DeviceView&, hipStream_t, const double*, const double*, double*);
+  // dot: the product kernel also leaves x . y at y[Nrb D]; spec: return at once if PCG stopped
+  void (*spmv)(const DeviceView&, hipStream_t, const double*, const double*, double*, int dot, int spec);
   void (*implicit_spmv)(const DeviceView&, hipStream_t, RedLayout, const double*, double*, double*,
-                        double*, double, double, double, int, int);
+                        double*, double, double, double, int, int, int dot, int spec);
+  void (*pcg_step)(const DeviceView&, hipStream_t, const double* b, int it, int nb, double eta, int min_it,
+                   int max_it, const double* red8, HostMirror* mirror, unsigned long long seq);
   void (*pcg_a)(const DeviceView&, hipStream_t, int, int);
   void (*pcg_b2)(const DeviceView&, hipStream_t, const double*, int, int, double*);
-  void (*back_substitute)(const DeviceView&, hipStream_t, double*, int, double*);
-  void (*update_points)(const DeviceView&, hipStream_t, int, double*);
-  void (*update_cameras)(const DeviceView&, hipStream_t, double*);
-  void (*camera_gmax)(const DeviceView&, hipStream_t, const double*, double*);
+  void (*back_substitute)(const DeviceView&, hipStream_t, double*, int, double*, double* sums);
+  void (*update_points)(const DeviceView&, hipStream_t, int, double*, double* sums);
+  void (*update_cameras)(const DeviceView&, hipStream_t, double* out, double* prep_c);
+  void (*pcg_init)(const DeviceView&, hipStream_t, const double* b, int nb);
   void (*dense_gather)(const DeviceView&, hipStream_t, const double*, double*, int);
 };
 
 template <int D, int DP, bool SH>
 Launch make_launch(bool fp32) {
   Launch L;
-  static const bool legacy = getenv("TMI_BA_LEGACY_EVAL") != nullptr;
-  static const bool occ1 = getenv("TMI_BA_LINEARIZE_OCC1") != nullptr;  // A/B: one workgroup per CU's worth of registers
-#define TMI_EVAL(RT)                                                                                    \
-  if (legacy) {                                                                                         \
-    L.linearize = [](const DeviceView& v, hipStream_t st, const double*, int lt, double lw, int nb) {   \
-      hipLaunchKernelGGL((linearize_legacy_kernel<D, DP, SH, RT>), dim3(nb), dim3(256), 0, st, v, lt, lw, nb); \
-    };                                                                                                  \
-    L.cost = [](const DeviceView& v, hipStream_t st, const double*, const double* e, const double* i,   \
-                const double* p, int lt, double lw, int fl, int nb, double* partial) {                  \
-      hipLaunchKernelGGL((cost_legacy_kernel<DP, RT>), dim3(nb), dim3(256), 0, st, v, e, i, p, lt, lw, fl, nb, partial); \
-    };                                                                                                  \
-  } else {                                                                                              \
-    if (occ1)                                                                                           \
-      L.linearize = [](const DeviceView& v, hipStream_t st, const double* prep, int lt, double lw, int nb) { \
-        hipLaunchKernelGGL((linearize_kernel<D, DP, SH, RT, 1>), dim3(nb), dim3(256), 0, st, v, prep, lt, lw, nb); \
-      };                                                                                                \
-    else                                                                                                \
-      L.linearize = [](const DeviceView& v, hipStream_t st, const double* prep, int lt, double lw, int nb) { \
-        hipLaunchKernelGGL((linearize_kernel<D, DP, SH, RT, 2>), dim3(nb), dim3(256), 0, st, v, prep, lt, lw, nb); \
-      };                                                                                                \
-    L.cost = [](const DeviceView& v, hipStream_t st, const double* prep, const double*, const double*,  \
-                const double* p, int lt, double lw, int fl, int nb, double* partial) {                  \
-      hipLaunchKernelGGL((cost_kernel<DP, RT>), dim3(nb), dim3(256), 0, st, v, prep, p, lt, lw, fl, nb, partial); \
-    };                                                                                                  \
-  }
   if (fp32) {
-    TMI_EVAL(float)
+    L.linearize = [](const DeviceView& v, hipStream_t st, const double* prep, int lt, double lw, int nb, double* sums) {
+      hipLaunchKernelGGL((linearize_kernel<D, DP, SH, float, 2>), dim3(nb), dim3(256), 0, st, v, prep, lt, lw, nb, sums);
+    };
+    L.cost = [](const DeviceView& v, hipStream_t st, const double* prep, const double* p, int lt, double lw, int fl,
+                int nb, double* partial, double* sums, double* flag_dst) {
+      hipLaunchKernelGGL((cost_kernel<DP, float>), dim3(nb), dim3(256), 0, st, v, prep, p, lt, lw, fl, nb, partial, sums, flag_dst);
+    };
   } else {
-    TMI_EVAL(double)
+    L.linearize = [](const DeviceView& v, hipStream_t st, const double* prep, int lt, double lw, int nb, double* sums) {
+      hipLaunchKernelGGL((linearize_kernel<D, DP, SH, double, 2>), dim3(nb), dim3(256), 0, st, v, prep, lt, lw, nb, sums);
+    };
+    L.cost = [](const DeviceView& v, hipStream_t st, const double* prep, const double* p, int lt, double lw, int fl,
+                int nb, double* partial, double* sums, double* flag_dst) {
+      hipLaunchKernelGGL((cost_kernel<DP, double>), dim3(nb), dim3(256), 0, st, v, prep, p, lt, lw, fl, nb, partial, sums, flag_dst);
+    };
   }
-#undef TMI_EVAL
   L.point_scale = [](const DeviceView& v, hipStream_t st, int nb) {
     hipLaunchKernelGGL((point_scale_kernel<DP>), dim3(nb), dim3(256), 0, st, v);
   };
@@ -144,28 +135,34 @@ Launch make_launch(bool fp32) {
       if (v.nub)
         hipLaunchKernelGGL((schur_offdiag_kernel<D, DP>), dim3((v.n_order + 4 * kSchurBlocksPerWave - 1) / (4 * kSchurBlocksPerWave)), dim3(256), 0, st, v, R);
     };
-  L.expand = [](const DeviceView& v, hipStream_t st, RedLayout R, double ir, double lo, double hi) {
+  L.expand = [](const DeviceView& v, hipStream_t st, RedLayout R, double ir, double lo, double hi, int want_gmax) {
     const int n2 = v.Nrb * D * D;
     if (n2)
       hipLaunchKernelGGL((finish_diag_kernel<D>), dim3((n2 + 255) / 256), dim3(256), 0, st, v, R, ir,
-                         lo, hi);
+                         lo, hi, want_gmax);
   };
   L.precond = [](const DeviceView& v, hipStream_t st, int identity) {
     if (v.Nrb) hipLaunchKernelGGL((precond_invert_kernel<D>), dim3(v.Nrb), dim3(64), 0, st, v, identity);
   };
-  L.spmv = [](const DeviceView& v, hipStream_t st, const double* ub, const double* x, double* y) {
+  L.spmv = [](const DeviceView& v, hipStream_t st, const double* ub, const double* x, double* y, int dot, int spec) {
     if (!v.Nrb) return;
-    if (v.n_spc) hipLaunchKernelGGL((spmv_rows_kernel<D>), dim3((v.n_spc + 3) / 4), dim3(256), 0, st, v, ub, x);
-    hipLaunchKernelGGL((spmv_cols_kernel<D>), dim3(v.Nrb), dim3(256), 0, st, v, x, y);
+    if (v.n_spc) hipLaunchKernelGGL((spmv_rows_kernel<D>), dim3((v.n_spc + 3) / 4), dim3(256), 0, st, v, ub, x, spec);
+    hipLaunchKernelGGL((spmv_cols_kernel<D>), dim3(v.Nrb), dim3(256), 0, st, v, x, y, dot, spec);
+  };
+  L.pcg_step = [](const DeviceView& v, hipStream_t st, const double* b, int it, int nb, double eta, int min_it,
+                  int max_it, const double* red8, HostMirror* mirror, unsigned long long seq) {
+    hipLaunchKernelGGL((pcg_step_kernel<D>), dim3(nb), dim3(kPcgStepThreads), 0, st, v, b, it, nb, eta, min_it,
+                       max_it, red8, mirror, seq);
   };
   L.implicit_spmv = [](const DeviceView& v, hipStream_t st, RedLayout R, const double* x, double* y,
-                       double* pm_u, double* cm_t, double ir, double lo, double hi, int add_diag, int nb) {
+                       double* pm_u, double* cm_t, double ir, double lo, double hi, int add_diag, int nb, int dot,
+                       int spec) {
     if (!v.Nrb) return;
-    hipLaunchKernelGGL((implicit_tracks_kernel<D, DP, SH>), dim3(nb), dim3(256), 0, st, v, x, pm_u, cm_t);
+    hipLaunchKernelGGL((implicit_tracks_kernel<D, DP, SH>), dim3(nb), dim3(256), 0, st, v, x, pm_u, cm_t, spec);
     // cam_part is free between two builds of the normal equations: the per-view partial
     // products of the shared intrinsics blocks live in its head
     hipLaunchKernelGGL((implicit_cameras_kernel<D, DP, SH>), dim3(v.Nrb), dim3(64), 0, st, v, R, x, cm_t, y,
-                       ir, lo, hi, add_diag, v.cam_part);
+                       ir, lo, hi, add_diag, v.cam_part, SH ? 0 : dot, spec);
     if (SH && v.Nrb > v.Ncam_rb)
       hipLaunchKernelGGL((implicit_groups_kernel<D>), dim3(v.Nrb - v.Ncam_rb), dim3(64), 0, st, v, R, x, v.cam_part,
                          y, ir, lo, hi, add_diag);
@@ -176,17 +173,21 @@ Launch make_launch(bool fp32) {
   L.pcg_b2 = [](const DeviceView& v, hipStream_t st, const double* b, int mode, int nb, double* partial) {
     hipLaunchKernelGGL((pcg_b2_kernel<D>), dim3(nb), dim3(256), 0, st, v, b, mode, nb, partial);
   };
-  L.back_substitute = [](const DeviceView& v, hipStream_t st, double* pm_u, int nb, double* partial) {
-    hipLaunchKernelGGL((back_substitute_kernel<D, DP, SH>), dim3(nb), dim3(256), 0, st, v, pm_u, nb, partial);
+  L.back_substitute = [](const DeviceView& v, hipStream_t st, double* pm_u, int nb, double* partial, double* sums) {
+    hipLaunchKernelGGL((back_substitute_kernel<D, DP, SH>), dim3(nb), dim3(256), 0, st, v, pm_u, nb, partial, sums);
   };
-  L.update_points = [](const DeviceView& v, hipStream_t st, int nb, double* partial) {
-    hipLaunchKernelGGL((update_points_kernel<DP>), dim3(nb), dim3(256), 0, st, v, nb, partial);
+  L.update_points = [](const DeviceView& v, hipStream_t st, int nb, double* partial, double* sums) {
+    hipLaunchKernelGGL((update_points_kernel<DP>), dim3(nb), dim3(256), 0, st, v, nb, partial, sums);
   };
-  L.update_cameras = [](const DeviceView& v, hipStream_t st, double* out) {
-    hipLaunchKernelGGL((update_cameras_kernel<D>), dim3(1), dim3(1024), 0, st, v, out);
+  L.update_cameras = [](const DeviceView& v, hipStream_t st, double* out, double* prep_c) {
+    const int n = v.Nc + (SH ? v.Nrb - v.Ncam_rb : 0);
+    hipLaunchKernelGGL((update_cameras_kernel<D, SH>), dim3((std::max(n, 1) + 255) / 256), dim3(256), 0, st, v, out, prep_c);
+    // shared intrinsics: a view's record needs its group's candidate, written by another thread
+    if (SH && v.Nc)
+      hipLaunchKernelGGL(camera_prepare_kernel, dim3((v.Nc + 255) / 256), dim3(256), 0, st, v, v.ext_c, v.intr_c, prep_c);
   };
-  L.camera_gmax = [](const DeviceView& v, hipStream_t st, const double* gc, double* out) {
-    hipLaunchKernelGGL((camera_gmax_kernel<D>), dim3(1), dim3(1024), 0, st, v, gc, out);
+  L.pcg_init = [](const DeviceView& v, hipStream_t st, const double* b, int nb) {
+    hipLaunchKernelGGL((pcg_init_kernel<D>), dim3(nb), dim3(kPcgStepThreads), 0, st, v, b, nb);
   };
   L.dense_gather = [](const DeviceView& v, hipStream_t st, const double* ub, double* A, int n) {
     const long long total = ((long long)v.nub + v.Nrb) * D * D;
@@ -215,12 +216,7 @@ using namespace tmi;
 
 // ---- the opaque solver ----------------------------------------------------------
 namespace tmi {
-struct HostMirror {
-  double scal[SC_COUNT];
-  double red[8];
-  int flags[FL_COUNT];
-  unsigned long long seq;
-};
+static_assert(SC_COUNT == 32 && FL_COUNT == 8, "HostMirror layout (device_view.h)");
 __global__ void publish_kernel(const double* __restrict__ scal, const double* __restrict__ red8,
                                const int* __restrict__ flags, HostMirror* m, unsigned long long seq) {
   const int t = threadIdx.x;  // 64 threads
@@ -301,6 +297,28 @@ struct tmi_ba_solver {
   int* d_trk_iter = nullptr;
   double* d_trk_c0 = nullptr;
   double* d_trk_c1 = nullptr;
+  // device side of the filter / selection bookkeeping (select_kernels.h), built on first use
+  int* d_pt_orig = nullptr;               // [Np_pad] caller's track index or -1
+  unsigned char* d_out_u8 = nullptr;      // [Np_total] flags / selection in the caller's order
+  double* d_out_f64 = nullptr;            // [Np_total]
+  int* d_out_i32 = nullptr;               // [Np_total]
+  int* d_counters = nullptr;              // [4]
+  int* h_counters = nullptr;              // pinned
+  unsigned char* h_stage = nullptr;       // pinned staging for the per-track outputs: [u8 | i32 | f64] x Np_total
+                                          //   (a copy straight into pageable caller memory makes the runtime
+                                          //   pin those pages first: 24 ms for 9 MB, measured)
+  int* d_vbox = nullptr;                  // [Nc][4]
+  long long* d_cell_off = nullptr;        // [Nc + 1]
+  long long* h_cell_total = nullptr;      // pinned
+  long long cell_capacity = 0;
+  std::vector<void*> cell_allocs;         // the three cell arrays (re-allocated when the grid grows)
+  unsigned* d_cell_len = nullptr;
+  unsigned long long* d_cell_err = nullptr;
+  unsigned* d_cell_trk = nullptr;
+  unsigned* d_sel = nullptr;              // [Np_total]
+  unsigned long long* d_vt_keys = nullptr;  // [No_pad] (view << 32 | track) sorted; static per handle
+  long long* d_vt_ptr = nullptr;          // [Nc + 1]
+  unsigned char* d_view_mask = nullptr;   // [Nc]
 };
 
 namespace {
@@ -348,7 +366,14 @@ struct Timed {
   }
 };
 
+void select_mirror(tmi_ba_solver* s, int slot) {
+  s->h_scal = s->h_mirror[slot].scal;
+  s->h_red = s->h_mirror[slot].red;
+  s->h_flags = s->h_mirror[slot].flags;
+}
+
 int readback(tmi_ba_solver* s) {
+  select_mirror(s, 0);
   const unsigned long long seq = ++s->mirror_seq;
   hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, s->stream, s->v.scal,
                      s->v.red + s->RL.scalars, s->v.flags, s->d_mirror, seq);
@@ -550,6 +575,10 @@ void tmi_ba_solver_destroy(tmi_ba_solver* s) {
   for (void* p : s->allocs) hipFree(p);
   if (s->h_mirror) hipHostFree(s->h_mirror);
   if (s->inner.h_active) hipHostFree(s->inner.h_active);
+  if (s->h_counters) hipHostFree(s->h_counters);
+  if (s->h_stage) hipHostFree(s->h_stage);
+  if (s->h_cell_total) hipHostFree(s->h_cell_total);
+  for (void* p : s->cell_allocs) hipFree(p);
   if (s->stream) hipStreamDestroy(s->stream);
   delete s;
 }
@@ -604,8 +633,11 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
     return TMI_BA_ERR_UNSUPPORTED;
   }
   TMI_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-  TMI_HIP(hipHostMalloc((void**)&s->h_mirror, sizeof(HostMirror), hipHostMallocMapped | hipHostMallocCoherent));
-  memset(s->h_mirror, 0, sizeof(HostMirror));
+  // two slots: pcg_step of iteration `it` publishes into slot it & 1, so that the speculatively
+  // launched next iteration can never overwrite scalars the host is still reading; every other
+  // read-back uses slot 0
+  TMI_HIP(hipHostMalloc((void**)&s->h_mirror, 2 * sizeof(HostMirror), hipHostMallocMapped | hipHostMallocCoherent));
+  memset(s->h_mirror, 0, 2 * sizeof(HostMirror));
   TMI_HIP(hipHostGetDevicePointer((void**)&s->d_mirror, s->h_mirror, 0));
   s->h_scal = s->h_mirror->scal;
   s->h_red = s->h_mirror->red;
@@ -701,6 +733,7 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
     if ((rc = dev_upload(s, &ps, rb_cols))) return rc; v.rb_cols = ps;
     if ((rc = dev_upload(s, &pl, pair_ptr))) return rc; v.pair_ptr = pl;
     if ((rc = dev_upload(s, &pd, st.obs_xy))) return rc; v.obs_xy = pd;
+    if ((rc = dev_upload(s, &p, st.pt_orig))) return rc; s->d_pt_orig = p;
   }
 #undef UP
   const size_t N = (size_t)st.No_pad, NP = (size_t)st.Np_pad;
@@ -730,12 +763,16 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   AL(v.red, s->RL.total) AL(v.Sdiag, (size_t)std::max(st.Nrb, 1) * D * D)
   AL(v.tbuf, (size_t)std::max<int64_t>(st.nub, 1) * D) AL(v.rbuf, (size_t)std::max<size_t>(st.spc_row.size(), 1) * D) AL(v.Minv, (size_t)std::max(st.Nrb, 1) * D * D)
   AL(v.rhs, std::max(n_r, 1)) AL(v.yc, std::max(n_r, 1)) AL(v.cg_r, std::max(n_r, 1))
-  AL(v.cg_z, std::max(n_r, 1)) AL(v.cg_p, std::max(n_r, 1)) AL(v.cg_q, std::max(n_r, 1))
+  AL(v.cg_z, std::max(n_r, 1)) AL(v.cg_p, std::max(n_r, 1)) AL(v.cg_q, n_r + 8)
+  AL(v.dotbuf, st.Nrb + 8) AL(v.ticket, 4 * kTicketStride) AL(v.pcg_done, 1)
   AL(v.cg_t, std::max(n_r, 1)) AL(v.partial, (size_t)4 * std::max(nbmax, (st.Nrb + 3) / 4 + 1)) AL(s->d_partial_max, nbmax)
   AL(v.scal, SC_COUNT) AL(v.flags, FL_COUNT)
 #undef AL
   TMI_HIP(hipMemsetAsync(v.scal, 0, SC_COUNT * sizeof(double), s->stream));
   TMI_HIP(hipMemsetAsync(v.flags, 0, FL_COUNT * sizeof(int), s->stream));
+  TMI_HIP(hipMemsetAsync(v.ticket, 0, 4 * kTicketStride * sizeof(int), s->stream));
+  TMI_HIP(hipMemsetAsync(v.pcg_done, 0, sizeof(int), s->stream));
+  TMI_HIP(hipMemsetAsync(v.cg_q, 0, (size_t)(n_r + 8) * sizeof(double), s->stream));
   TMI_HIP(hipMemsetAsync(v.yc, 0, std::max(n_r, 1) * sizeof(double), s->stream));
   TMI_HIP(hipMemsetAsync(v.red, 0, s->RL.total * sizeof(double), s->stream));
   TMI_HIP(hipMemsetAsync(v.cm_Y, 0, (size_t)std::max<int64_t>(st.Nslots, 1) * YS * sizeof(double), s->stream));
@@ -881,12 +918,12 @@ static void prepare_cameras(tmi_ba_solver* s, const double* ext, const double* i
 // returns TMI_BA_OK; *usable = 0 for LINEAR_SOLVER_FAILURE
 // q = S x: explicit (symmetric block SpMV on the formed Schur complement) or implicit
 // (two passes over the observations; the reduced vector is all-reduced across ranks)
-static int apply_schur(tmi_ba_solver* s, const double* x, double* y) {
+static int apply_schur(tmi_ba_solver* s, const double* x, double* y, int dot = 0, int spec = 0) {
   DeviceView& v = s->v;
   const int n = v.Nrb * v.D;
   if (!s->implicit) {
     Timed t(s, TMI_BA_K_SPMV);
-    s->launch.spmv(v, s->stream, v.red + s->RL.ub, x, y);
+    s->launch.spmv(v, s->stream, v.red + s->RL.ub, x, y, dot, spec);
     return TMI_BA_OK;
   }
   {
@@ -894,9 +931,47 @@ static int apply_schur(tmi_ba_solver* s, const double* x, double* y) {
     const tmi_ba_options* O = s->cur_opts;
     const int add_diag = (s->st.world <= 1 || s->st.rank == 0) ? 1 : 0;
     s->launch.implicit_spmv(v, s->stream, s->RL, x, y, s->d_pm_u, s->d_cm_t, s->cur_inv_radius,
-                            O->min_lm_diagonal, O->max_lm_diagonal, add_diag, s->nblocks_tracks);
+                            O->min_lm_diagonal, O->max_lm_diagonal, add_diag, s->nblocks_tracks, dot, spec);
   }
-  return do_allreduce(s, y, n);
+  // with the dot product fused, x . y (this rank's share) rides behind the vector
+  return do_allreduce(s, y, n + (dot ? 1 : 0));
+}
+
+// Wait until slot `slot` of the host mirror shows sequence number `seq` (published by pcg_step).
+static int wait_mirror(tmi_ba_solver* s, int slot, unsigned long long seq) {
+  volatile unsigned long long* p = &s->h_mirror[slot].seq;
+  for (unsigned spin = 1;; ++spin) {
+    if (*p == seq) break;
+    if ((spin & 0xfffu) == 0) {
+      const hipError_t q = hipStreamQuery(s->stream);
+      if (q == hipSuccess) {
+        if (*p == seq) break;
+        // an idle-looking stream can still have launches in the runtime's submission batch: drain
+        // for real before calling the missing sequence number an error
+        if (hipStreamSynchronize(s->stream) != hipSuccess || *p != seq) {
+          char buf[160];
+          snprintf(buf, sizeof(buf), "PCG step did not publish its scalars (expected sequence %llu, mirror holds %llu)",
+                   seq, (unsigned long long)*p);
+          s->error = buf;
+          return TMI_BA_ERR_DEVICE;
+        }
+        break;
+      }
+      if (q != hipErrorNotReady) {
+        s->error = std::string("hipStreamQuery: ") + hipGetErrorString(q);
+        return TMI_BA_ERR_DEVICE;
+      }
+    }
+    __builtin_ia32_pause();
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  select_mirror(s, slot);
+  const hipError_t le = hipGetLastError();
+  if (le != hipSuccess) {
+    s->error = std::string("kernel launch failed: ") + hipGetErrorString(le);
+    return TMI_BA_ERR_DEVICE;
+  }
+  return TMI_BA_OK;
 }
 
 static int solve_reduced_pcg(tmi_ba_solver* s, const tmi_ba_options* O, int* usable, int64_t* iters) {
@@ -906,39 +981,81 @@ static int solve_reduced_pcg(tmi_ba_solver* s, const tmi_ba_options* O, int* usa
   *usable = 1;
   if (n == 0) return TMI_BA_OK;
   {
+    // x = 0, r = b, z = M^-1 b, p = z, rho: one multi-workgroup launch
     Timed t(s, TMI_BA_K_PCG_VECTOR);
-    hipLaunchKernelGGL(pcg_begin_kernel, dim3(1), dim3(1024), 0, s->stream, v, b, n);
+    s->launch.pcg_init(v, s->stream, b, (v.Nrb + kPcgStepThreads / 64 - 1) / (kPcgStepThreads / 64));
   }
-  {
-    Timed t(s, TMI_BA_K_PCG_VECTOR);
-    s->launch.pcg_a(v, s->stream, n, 1);  // z, rho, p of the first iteration
-  }
+  // Fused path (no shared intrinsics blocks): an iteration is  product (+ p.q) -> [all-reduce] ->
+  // pcg_step, and the NEXT iteration's launches are enqueued before this one's scalars are read
+  // (they return at once if pcg_step finds that PCG has stopped), so neither the launch latency
+  // nor the host's poll sits between two iterations.  Every tenth iteration recomputes the
+  // residual (residual_reset_period) through the three-kernel path below.
+  static const bool legacy_pcg = getenv("TMI_BA_PCG_LEGACY") != nullptr;
+  // Speculative enqueue of the next iteration (its kernels return at once if pcg_step finds PCG has
+  // stopped) measured no gain on MI355X -- 5.02 vs 5.04 ms per LM iteration at one GPU, 1.57 vs 1.53 ms
+  // for an eighth of the tracks (profiles/r02_g) -- so it is opt-in.
+  static const bool no_spec = getenv("TMI_BA_PCG_SPEC") == nullptr;
+  const bool fused = !s->st.has_shared && !legacy_pcg;
+  const int nbv = (v.Nrb + 3) / 4;
+  const int nbs16 = (v.Nrb + kPcgStepThreads / 64 - 1) / (kPcgStepThreads / 64);  // workgroups of pcg_step
   int it;
+  bool enqueued = false;           // iteration `it` is already on the stream
+  unsigned long long enq_seq = 0;  // ... and will publish with this sequence number
+  auto enqueue_fused = [&](int iter, int spec) -> int {
+    const int rcs = apply_schur(s, v.cg_p, v.cg_q, /*dot=*/1, spec);
+    if (rcs) return rcs;
+    Timed t(s, TMI_BA_K_PCG_VECTOR);
+    enq_seq = ++s->mirror_seq;
+    s->launch.pcg_step(v, s->stream, b, iter, nbs16, O->eta, O->min_linear_solver_iterations,
+                       O->max_linear_solver_iterations, v.red + s->RL.scalars, s->d_mirror + (iter & 1), enq_seq);
+    hipLaunchKernelGGL(pcg_p_kernel, dim3((n + 255) / 256), dim3(256), 0, s->stream, v, n);
+    return TMI_BA_OK;
+  };
   for (it = 1;; ++it) {
-    {
-      const int rcs = apply_schur(s, v.cg_p, v.cg_q);
-      if (rcs) return rcs;
-    }
     const bool reset = (it % 10 == 0);  // residual_reset_period
-    const int nbv = (v.Nrb + 3) / 4;
-    {
-      Timed t(s, TMI_BA_K_PCG_VECTOR);
-      hipLaunchKernelGGL(pcg_b1_kernel, dim3(1), dim3(1024), 0, s->stream, v, n);
-      s->launch.pcg_b2(v, s->stream, b, reset ? 1 : 0, nbv, v.partial);
+    int rc;
+    if (fused && !reset) {
+      unsigned long long my_seq;
+      if (enqueued) {
+        my_seq = enq_seq;
+      } else {
+        if ((rc = enqueue_fused(it, 0))) return rc;
+        my_seq = enq_seq;
+      }
+      enqueued = false;
+      // speculate on the next iteration unless it is a reset iteration or past the limit
+      unsigned long long next_seq = 0;
+      if (!no_spec && (it + 1) % 10 != 0 && it < O->max_linear_solver_iterations) {
+        if ((rc = enqueue_fused(it + 1, 1))) return rc;
+        next_seq = enq_seq;
+        enqueued = true;
+      }
+      if ((rc = wait_mirror(s, it & 1, my_seq))) return rc;
+      enq_seq = next_seq;
+    } else {
+      {
+        const int rcs = apply_schur(s, v.cg_p, v.cg_q);
+        if (rcs) return rcs;
+      }
+      {
+        Timed t(s, TMI_BA_K_PCG_VECTOR);
+        hipLaunchKernelGGL(pcg_b1_kernel, dim3(1), dim3(1024), 0, s->stream, v, n);
+        s->launch.pcg_b2(v, s->stream, b, reset ? 1 : 0, nbv, v.partial);
+      }
+      if (reset) {
+        const int rcs = apply_schur(s, v.yc, v.cg_t);
+        if (rcs) return rcs;
+        Timed t(s, TMI_BA_K_PCG_VECTOR);
+        s->launch.pcg_b2(v, s->stream, b, 2, nbv, v.partial);
+      }
+      {
+        // Q1, zeta, and z / rho / p of iteration it + 1
+        Timed t(s, TMI_BA_K_PCG_VECTOR);
+        hipLaunchKernelGGL(pcg_b3_kernel, dim3(1), dim3(1024), 0, s->stream, v, n, it, nbv, v.partial);
+      }
+      rc = readback(s);
+      if (rc) return rc;
     }
-    if (reset) {
-      const int rcs = apply_schur(s, v.yc, v.cg_t);
-      if (rcs) return rcs;
-      Timed t(s, TMI_BA_K_PCG_VECTOR);
-      s->launch.pcg_b2(v, s->stream, b, 2, nbv, v.partial);
-    }
-    {
-      // Q1, zeta, and z / rho / p of iteration it + 1
-      Timed t(s, TMI_BA_K_PCG_VECTOR);
-      hipLaunchKernelGGL(pcg_b3_kernel, dim3(1), dim3(1024), 0, s->stream, v, n, it, nbv, v.partial);
-    }
-    int rc = readback(s);
-    if (rc) return rc;
     if (s->h_flags[FL_PCG_FAIL]) {
       *usable = 0;
       break;
@@ -1230,12 +1347,9 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
   prepare_cameras(s, v.ext, v.intr, v.prep);
   hipLaunchKernelGGL(fill_kernel, dim3((unsigned)(((long long)st.Np_pad * s->DP + 255) / 256 + 1)), dim3(256), 0, stream, v.scale_p, (long long)st.Np_pad * s->DP, 1.0);
   auto linearize = [&]() {
-    {
-      Timed t(s, TMI_BA_K_LINEARIZE);
-      s->launch.linearize(v, stream, v.prep, lt, lw, nbs);
-    }
-    Timed t(s, TMI_BA_K_REDUCE);
-    hipLaunchKernelGGL(reduce_sum_kernel, dim3(2), dim3(256), 0, stream, v.partial, nbs, d_sc);
+    // cost and sum of squares land in d_sc[0..1] (finished by the kernel's last workgroup)
+    Timed t(s, TMI_BA_K_LINEARIZE);
+    s->launch.linearize(v, stream, v.prep, lt, lw, nbs, d_sc);
   };
   linearize();
   // d_sc[0] = cost, d_sc[1] = ss, d_sc[2] = #ranks with an invalid residual
@@ -1303,11 +1417,8 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
   double xnorm_cam_sq = 0.0, xnorm_pts_sq = 0.0;
   {
     Timed t(s, TMI_BA_K_UPDATE_COST);
-    CKH(hipMemcpyAsync(v.ext_c, v.ext, (size_t)6 * st.Nc * sizeof(double), hipMemcpyDeviceToDevice, stream));
-    if (s->n_intr) CKH(hipMemcpyAsync(v.intr_c, v.intr, (size_t)s->n_intr * sizeof(double), hipMemcpyDeviceToDevice, stream));
-    s->launch.update_cameras(v, stream, v.scal + SC_STEP_SQ);
-    hipLaunchKernelGGL(points_norm_kernel, dim3(nbp), dim3(256), 0, stream, v, v.pts, nbp, v.partial);
-    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, stream, v.partial, nbp, d_sc);
+    s->launch.update_cameras(v, stream, v.scal + SC_STEP_SQ, v.prep_c);  // y = 0: copies + |x|
+    hipLaunchKernelGGL(points_norm_kernel, dim3(nbp), dim3(256), 0, stream, v, v.pts, nbp, v.partial, d_sc);
   }
   CK(do_allreduce(s, d_sc, 8));
   CK(readback(s));
@@ -1350,13 +1461,10 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
     }
     CK(do_allreduce(s, v.red, RL.total));  // d_sc[6] carries the singular-track votes
     {
+      // diagonal blocks + LM diagonal; with the gradient test pending also max |g_c / scale|
+      // (max |g_p / scale| was finished by point_eliminate's last workgroup)
       Timed t(s, TMI_BA_K_REDUCE);
-      s->launch.expand(v, stream, RL, inv_radius, O->min_lm_diagonal, O->max_lm_diagonal);
-    }
-    if (need_gradient_check) {
-      Timed t(s, TMI_BA_K_REDUCE);
-      hipLaunchKernelGGL(reduce_max_kernel, dim3(1), dim3(256), 0, stream, s->d_partial_max, nbs, v.scal + SC_GMAX_P);
-      s->launch.camera_gmax(v, stream, v.red + RL.gc, v.scal + SC_GMAX);
+      s->launch.expand(v, stream, RL, inv_radius, O->min_lm_diagonal, O->max_lm_diagonal, need_gradient_check ? 1 : 0);
     }
     int usable = 1;
     if (iterative) {
@@ -1397,23 +1505,16 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
     if (usable) {
       {
         Timed t(s, TMI_BA_K_BACK_SUBSTITUTE);
-        s->launch.back_substitute(v, stream, s->d_pm_u, nbs, v.partial);
-        hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, stream, v.partial, nbs, d_sc + 0);
+        s->launch.back_substitute(v, stream, s->d_pm_u, nbs, v.partial, d_sc + 0);
       }
       {
         Timed t(s, TMI_BA_K_UPDATE_COST);
-        CKH(hipMemcpyAsync(v.ext_c, v.ext, (size_t)6 * st.Nc * sizeof(double), hipMemcpyDeviceToDevice, stream));
-        if (s->n_intr) CKH(hipMemcpyAsync(v.intr_c, v.intr, (size_t)s->n_intr * sizeof(double), hipMemcpyDeviceToDevice, stream));
-        s->launch.update_cameras(v, stream, v.scal + SC_STEP_SQ);
-        s->launch.update_points(v, stream, nbp, v.partial);
-        hipLaunchKernelGGL(reduce_sum_kernel, dim3(2), dim3(256), 0, stream, v.partial, nbp, d_sc + 1);
-        prepare_cameras(s, v.ext_c, v.intr_c, v.prep_c);
-        s->launch.cost(v, stream, v.prep_c, v.ext_c, v.intr_c, v.pts_c, lt, lw, FL_INVALID, nbs, v.partial);
-        hipLaunchKernelGGL(reduce_sum_kernel, dim3(2), dim3(256), 0, stream, v.partial, nbs, d_sc + 3);
+        s->launch.update_cameras(v, stream, v.scal + SC_STEP_SQ, v.prep_c);  // candidate cameras + their prepared records
+        s->launch.update_points(v, stream, nbp, v.partial, d_sc + 1);
+        // d_sc: [mcc, step_sq_points, |x+|^2 points, cand_cost, cand_ss, invalid votes, singular
+        //        track votes, time-limit votes]
+        s->launch.cost(v, stream, v.prep_c, v.pts_c, lt, lw, FL_INVALID, nbs, v.partial, d_sc + 3, d_sc + 5);
       }
-      // d_sc: [mcc, step_sq_points, |x+|^2 points, cand_cost, cand_ss, invalid votes, singular
-      //        track votes, time-limit votes]
-      hipLaunchKernelGGL(flag_to_scalar_kernel, dim3(1), dim3(64), 0, stream, v.flags + FL_INVALID, d_sc + 5);
       if (st.world > 1) {
         s->time_vote = (now_s() - t_start >= O->max_solver_time_in_seconds) ? 1.0 : 0.0;
         CKH(hipMemcpyAsync(d_sc + 7, &s->time_vote, sizeof(double), hipMemcpyHostToDevice, stream));
@@ -1440,9 +1541,7 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
         Timed t(s, TMI_BA_K_UPDATE_COST);
         CKH(hipMemsetAsync(v.flags + FL_INVALID, 0, sizeof(int), stream));
         prepare_cameras(s, v.ext_c, v.intr_c, v.prep_c);  // the sweep moved the candidate cameras
-        s->launch.cost(v, stream, v.prep_c, v.ext_c, v.intr_c, v.pts_c, lt, lw, FL_INVALID, nbs, v.partial);
-        hipLaunchKernelGGL(reduce_sum_kernel, dim3(2), dim3(256), 0, stream, v.partial, nbs, d_sc + 3);
-        hipLaunchKernelGGL(flag_to_scalar_kernel, dim3(1), dim3(64), 0, stream, v.flags + FL_INVALID, d_sc + 5);
+        s->launch.cost(v, stream, v.prep_c, v.pts_c, lt, lw, FL_INVALID, nbs, v.partial, d_sc + 3, d_sc + 5);
         hipLaunchKernelGGL(diff_sq_kernel, dim3(1), dim3(1024), 0, stream, v.ext, v.ext_c, (long long)6 * st.Nc, v.scal + SC_II_DEXT);
         hipLaunchKernelGGL(diff_sq_kernel, dim3(1), dim3(1024), 0, stream, v.intr, v.intr_c, (long long)s->n_intr, v.scal + SC_II_DINTR);
         // per-track sums go where the trial step left its own: d_sc[1] = |step|^2 over the
@@ -1583,6 +1682,14 @@ static int ensure_track_outputs(tmi_ba_solver* s) {
   if ((rc = dev_alloc(s, &s->d_trk_iter, n))) return rc;
   if ((rc = dev_alloc(s, &s->d_trk_c0, n))) return rc;
   if ((rc = dev_alloc(s, &s->d_trk_c1, n))) return rc;
+  const size_t nt = (size_t)std::max(s->st.Np_total, 1);
+  if ((rc = dev_alloc(s, &s->d_out_u8, nt))) return rc;
+  if ((rc = dev_alloc(s, &s->d_out_f64, nt))) return rc;
+  if ((rc = dev_alloc(s, &s->d_out_i32, nt))) return rc;
+  if ((rc = dev_alloc(s, &s->d_counters, 4))) return rc;
+  TMI_HIP(hipHostMalloc((void**)&s->h_counters, 4 * sizeof(int), hipHostMallocDefault));
+  TMI_HIP(hipHostMalloc((void**)&s->h_cell_total, sizeof(long long), hipHostMallocDefault));
+  TMI_HIP(hipHostMalloc((void**)&s->h_stage, nt * 16, hipHostMallocDefault));
   return TMI_BA_OK;
 }
 
@@ -1607,26 +1714,53 @@ int32_t tmi_ba_solver_filter_outlier_tracks(tmi_ba_solver* s, double max_inlier_
     hipLaunchKernelGGL(outlier_filter_kernel, dim3(s->nblocks_tracks), dim3(256), 0, s->stream, s->v, max_sq,
                        cos_min, s->d_trk_flag, s->d_trk_mean);
   TMI_HIP(hipEventRecord(eb, s->stream));
-  std::vector<unsigned char> flag((size_t)st.Np_pad);
-  std::vector<double> mean(track_mean_sq_error ? (size_t)st.Np_pad : 0);
-  if (!flag.empty())
-    TMI_HIP(hipMemcpyAsync(flag.data(), s->d_trk_flag, flag.size(), hipMemcpyDeviceToHost, s->stream));
-  if (!mean.empty())
-    TMI_HIP(hipMemcpyAsync(mean.data(), s->d_trk_mean, mean.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-  TMI_HIP(hipStreamSynchronize(s->stream));
   float ms = 0.f;
-  hipEventElapsedTime(&ms, ea, eb);
-  hipEventDestroy(ea);
-  hipEventDestroy(eb);
-  for (int lp = 0; lp < st.Np_pad; ++lp) {
-    const int p = st.pt_orig[lp];
-    if (p < 0) continue;
-    const unsigned char f = flag[lp];
-    sum->num_estimated_tracks++;
-    if (f == 1) sum->num_bad_reprojections++;
-    if (f == 2) sum->num_insufficient_viewing_angles++;
-    if (track_flag) track_flag[p] = f;
-    if (track_mean_sq_error) track_mean_sq_error[p] = mean[lp];
+  if (st.world == 1) {
+    // counts and the permutation to the caller's track order happen on the device; one copy per
+    // requested output (round 1: flags + means of every slot copied out and walked on the host)
+    TMI_HIP(hipMemsetAsync(s->d_counters, 0, 4 * sizeof(int), s->stream));
+    if (st.Np_pad > 0)
+      hipLaunchKernelGGL(filter_finish_kernel, dim3((st.Np_pad + 255) / 256), dim3(256), 0, s->stream, s->d_pt_orig,
+                         st.Np_pad, s->d_trk_flag, s->d_trk_mean, track_flag ? s->d_out_u8 : nullptr,
+                         track_mean_sq_error ? s->d_out_f64 : nullptr, s->d_counters);
+    TMI_HIP(hipMemcpyAsync(s->h_counters, s->d_counters, 4 * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    const size_t ntot = (size_t)st.Np_total;
+    unsigned char* stage_u8 = s->h_stage;
+    double* stage_f64 = reinterpret_cast<double*>(s->h_stage + 8 * ntot);
+    if (track_flag && ntot > 0)
+      TMI_HIP(hipMemcpyAsync(stage_u8, s->d_out_u8, ntot, hipMemcpyDeviceToHost, s->stream));
+    if (track_mean_sq_error && ntot > 0)
+      TMI_HIP(hipMemcpyAsync(stage_f64, s->d_out_f64, ntot * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    TMI_HIP(hipStreamSynchronize(s->stream));
+    if (track_flag && ntot > 0) memcpy(track_flag, stage_u8, ntot);
+    if (track_mean_sq_error && ntot > 0) memcpy(track_mean_sq_error, stage_f64, ntot * sizeof(double));
+    hipEventElapsedTime(&ms, ea, eb);
+    hipEventDestroy(ea);
+    hipEventDestroy(eb);
+    sum->num_estimated_tracks = s->h_counters[0];
+    sum->num_bad_reprojections = s->h_counters[1];
+    sum->num_insufficient_viewing_angles = s->h_counters[2];
+  } else {
+    std::vector<unsigned char> flag((size_t)st.Np_pad);
+    std::vector<double> mean(track_mean_sq_error ? (size_t)st.Np_pad : 0);
+    if (!flag.empty())
+      TMI_HIP(hipMemcpyAsync(flag.data(), s->d_trk_flag, flag.size(), hipMemcpyDeviceToHost, s->stream));
+    if (!mean.empty())
+      TMI_HIP(hipMemcpyAsync(mean.data(), s->d_trk_mean, mean.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    TMI_HIP(hipStreamSynchronize(s->stream));
+    hipEventElapsedTime(&ms, ea, eb);
+    hipEventDestroy(ea);
+    hipEventDestroy(eb);
+    for (int lp = 0; lp < st.Np_pad; ++lp) {
+      const int p = st.pt_orig[lp];
+      if (p < 0) continue;
+      const unsigned char f = flag[lp];
+      sum->num_estimated_tracks++;
+      if (f == 1) sum->num_bad_reprojections++;
+      if (f == 2) sum->num_insufficient_viewing_angles++;
+      if (track_flag) track_flag[p] = f;
+      if (track_mean_sq_error) track_mean_sq_error[p] = mean[lp];
+    }
   }
   // a track nobody observes: mean = 0 / 0, no ray pair -> insufficient viewing angle
   // (set_outlier_tracks_to_unestimated.cc:108,120-125 with empty lists)
@@ -1793,89 +1927,121 @@ int32_t tmi_ba_solver_select_good_tracks(tmi_ba_solver* s, int32_t long_track_le
     hipLaunchKernelGGL(track_stats_kernel, dim3(s->nblocks_slices), dim3(256), 0, s->stream, s->v,
                        s->d_trk_iter, s->d_trk_mean);
   TMI_HIP(hipEventRecord(eb, s->stream));
-  const size_t n = (size_t)st.Np_pad;
-  std::vector<int> cnt(n);
-  std::vector<double> mean(n);
-  if (n) {
-    TMI_HIP(hipMemcpyAsync(cnt.data(), s->d_trk_iter, n * sizeof(int), hipMemcpyDeviceToHost, s->stream));
-    TMI_HIP(hipMemcpyAsync(mean.data(), s->d_trk_mean, n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  const int Np = st.Np_total, Nc = st.Nc;
+  hipStream_t stream = s->stream;
+  // static per handle: every view's tracks sorted by track index (device radix sort)
+  if (!s->d_vt_ptr) {
+    if ((rc = dev_alloc(s, &s->d_vt_ptr, (size_t)Nc + 2))) return rc;
+    if ((rc = dev_alloc(s, &s->d_vt_keys, (size_t)std::max<int64_t>(st.No_pad, 1)))) return rc;
+    if ((rc = dev_alloc(s, &s->d_vbox, (size_t)std::max(Nc, 1) * 4))) return rc;
+    if ((rc = dev_alloc(s, &s->d_cell_off, (size_t)Nc + 2))) return rc;
+    if ((rc = dev_alloc(s, &s->d_sel, (size_t)std::max(Np, 1)))) return rc;
+    if ((rc = dev_alloc(s, &s->d_view_mask, (size_t)std::max(Nc, 1)))) return rc;
+    if (st.No_pad > 0) {
+      unsigned long long* keys_in = nullptr;
+      TMI_HIP(hipMalloc((void**)&keys_in, (size_t)st.No_pad * sizeof(unsigned long long)));
+      hipLaunchKernelGGL(select_keys_kernel, dim3(s->nblocks_slices), dim3(256), 0, stream, s->v, s->d_pt_orig, keys_in);
+      size_t tmp_bytes = 0;
+      hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, keys_in, s->d_vt_keys, (int)st.No_pad, 0, 64, stream);
+      void* tmp = nullptr;
+      TMI_HIP(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
+      hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, keys_in, s->d_vt_keys, (int)st.No_pad, 0, 64, stream);
+      TMI_HIP(hipStreamSynchronize(stream));
+      hipFree(tmp);
+      hipFree(keys_in);
+    }
+    hipLaunchKernelGGL(select_view_ptr_kernel, dim3((Nc + 1 + 255) / 256), dim3(256), 0, stream, s->d_vt_keys,
+                       (long long)st.No_pad, Nc, s->d_vt_ptr);
   }
-  TMI_HIP(hipStreamSynchronize(s->stream));
+  SelectView S;
+  memset(&S, 0, sizeof(S));
+  S.Nc = Nc;
+  S.Np_total = Np;
+  S.view_mask = nullptr;
+  if (view_mask && Nc > 0) {
+    TMI_HIP(hipMemcpyAsync(s->d_view_mask, view_mask, (size_t)Nc, hipMemcpyHostToDevice, stream));
+    S.view_mask = s->d_view_mask;
+  }
+  S.pt_orig = s->d_pt_orig;
+  S.cnt = s->d_trk_iter;
+  S.mean = s->d_trk_mean;
+  S.long_thr = long_track_length_threshold;
+  S.inv_cell = 1.0 / image_grid_cell_size_pixels;
+  S.vbox = s->d_vbox;
+  S.cell_off = s->d_cell_off;
+  S.sel = s->d_sel;
+  S.counters = s->d_counters;
+  const int nb_init = (std::max(std::max(Nc, Np), 4) + 255) / 256;
+  hipLaunchKernelGGL(select_init_kernel, dim3(nb_init), dim3(256), 0, stream, S);
+  if (st.nslices > 0) hipLaunchKernelGGL(select_bounds_kernel, dim3(s->nblocks_slices), dim3(256), 0, stream, s->v, S);
+  hipLaunchKernelGGL(select_offsets_kernel, dim3(1), dim3(1024), 0, stream, S);
+  TMI_HIP(hipMemcpyAsync(s->h_cell_total, s->d_cell_off + Nc, sizeof(long long), hipMemcpyDeviceToHost, stream));
+  TMI_HIP(hipStreamSynchronize(stream));
+  const long long ncells = *s->h_cell_total;
+  if (ncells > ((long long)1 << 31)) {
+    g_last_error = s->error = "track selection: the image grids need more than 2^31 cells (cell size too small "
+                              "for the pixel range of the features)";
+    hipEventDestroy(ea);
+    hipEventDestroy(eb);
+    return TMI_BA_ERR_UNSUPPORTED;
+  }
+  if (ncells > s->cell_capacity) {
+    for (void* p : s->cell_allocs) hipFree(p);
+    s->cell_allocs.clear();
+    s->cell_capacity = 0;
+    const size_t cap = (size_t)(ncells + ncells / 4 + 1024);
+    TMI_HIP(hipMalloc((void**)&s->d_cell_len, cap * sizeof(unsigned)));
+    s->cell_allocs.push_back(s->d_cell_len);
+    TMI_HIP(hipMalloc((void**)&s->d_cell_err, cap * sizeof(unsigned long long)));
+    s->cell_allocs.push_back(s->d_cell_err);
+    TMI_HIP(hipMalloc((void**)&s->d_cell_trk, cap * sizeof(unsigned)));
+    s->cell_allocs.push_back(s->d_cell_trk);
+    s->cell_capacity = (long long)cap;
+  }
+  S.cell_len = s->d_cell_len;
+  S.cell_err = s->d_cell_err;
+  S.cell_trk = s->d_cell_trk;
+  if (ncells > 0) {
+    const unsigned nbc = (unsigned)((ncells + 255) / 256);
+    hipLaunchKernelGGL(select_fill_cells_kernel, dim3(nbc), dim3(256), 0, stream, S, ncells);
+    hipLaunchKernelGGL(select_cells_kernel<1>, dim3(s->nblocks_slices), dim3(256), 0, stream, s->v, S);
+    hipLaunchKernelGGL(select_cells_kernel<2>, dim3(s->nblocks_slices), dim3(256), 0, stream, s->v, S);
+    hipLaunchKernelGGL(select_cells_kernel<3>, dim3(s->nblocks_slices), dim3(256), 0, stream, s->v, S);
+    hipLaunchKernelGGL(select_mark_kernel, dim3(nbc), dim3(256), 0, stream, S, ncells);
+  }
+  if (Nc > 0 && st.No_pad > 0)
+    hipLaunchKernelGGL(select_topup_kernel, dim3(1), dim3(kTopupThreads), 0, stream, S, s->d_vt_keys, s->d_vt_ptr,
+                       min_num_optimized_tracks_per_view);
+  if (Np > 0) hipLaunchKernelGGL(select_finish_kernel, dim3((Np + 255) / 256), dim3(256), 0, stream, S, s->d_out_u8);
+  if ((stats_len || stats_err) && st.Np_pad > 0) {
+    // tracks without observations keep length 0 / NaN error
+    if (stats_len) TMI_HIP(hipMemsetAsync(s->d_out_i32, 0, (size_t)Np * sizeof(int), stream));
+    if (stats_err) TMI_HIP(hipMemsetAsync(s->d_out_f64, 0xff, (size_t)Np * sizeof(double), stream));
+    hipLaunchKernelGGL(scatter_track_stats_kernel, dim3((st.Np_pad + 255) / 256), dim3(256), 0, stream, s->d_pt_orig,
+                       st.Np_pad, s->d_trk_iter, s->d_trk_mean, long_track_length_threshold,
+                       stats_len ? s->d_out_i32 : nullptr, stats_err ? s->d_out_f64 : nullptr);
+  }
+  TMI_HIP(hipMemcpyAsync(s->h_counters, s->d_counters, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
+  unsigned char* stage_u8 = s->h_stage;
+  int* stage_i32 = reinterpret_cast<int*>(s->h_stage + 4 * (size_t)std::max(Np, 1));
+  double* stage_f64 = reinterpret_cast<double*>(s->h_stage + 8 * (size_t)std::max(Np, 1));
+  if (Np > 0) TMI_HIP(hipMemcpyAsync(stage_u8, s->d_out_u8, (size_t)Np, hipMemcpyDeviceToHost, stream));
+  if (stats_len && Np > 0) TMI_HIP(hipMemcpyAsync(stage_i32, s->d_out_i32, (size_t)Np * sizeof(int), hipMemcpyDeviceToHost, stream));
+  if (stats_err && Np > 0) TMI_HIP(hipMemcpyAsync(stage_f64, s->d_out_f64, (size_t)Np * sizeof(double), hipMemcpyDeviceToHost, stream));
+  TMI_HIP(hipStreamSynchronize(stream));
+  if (Np > 0) memcpy(selected, stage_u8, (size_t)Np);
+  if (stats_len && Np > 0) memcpy(stats_len, stage_i32, (size_t)Np * sizeof(int));
+  if (stats_err && Np > 0) memcpy(stats_err, stage_f64, (size_t)Np * sizeof(double));
   float ms = 0.f;
   hipEventElapsedTime(&ms, ea, eb);
   hipEventDestroy(ea);
   hipEventDestroy(eb);
   sum->kernel_seconds = ms * 1e-3;
-
-  const int Np = st.Np_total;
-  struct Stat { int len; double err; };
-  std::vector<Stat> stat((size_t)Np, Stat{0, std::nan("")});
-  for (int lp = 0; lp < st.Np_pad; ++lp) {
-    const int p = st.pt_orig[lp];
-    if (p < 0) continue;
-    stat[p].len = std::min(cnt[lp], long_track_length_threshold);
-    stat[p].err = mean[lp];
-  }
-  if (stats_len) for (int p = 0; p < Np; ++p) stats_len[p] = stat[p].len;
-  if (stats_err) for (int p = 0; p < Np; ++p) stats_err[p] = stat[p].err;
-  memset(selected, 0, (size_t)Np);
-  // features by view: (cell, track) records from the resident track-major layout
-  struct Feat { int64_t cell; int track; };
-  std::vector<int64_t> vptr((size_t)st.Nc + 2, 0);
-  const double inv_cell = 1.0 / image_grid_cell_size_pixels;
-  for (int64_t e = 0; e < st.No_pad; ++e)
-    if (st.obs_cam[e] >= 0) vptr[st.obs_cam[e] + 2]++;
-  for (int c = 0; c < st.Nc; ++c) vptr[c + 2] += vptr[c + 1];
-  std::vector<Feat> feats((size_t)st.No);
-  for (int sl = 0; sl < st.nslices; ++sl) {
-    const int K = (st.slice_ptr[sl + 1] - st.slice_ptr[sl]) >> 6;
-    for (int j = 0; j < K; ++j)
-      for (int t = 0; t < 64; ++t) {
-        const int64_t e = (int64_t)st.slice_ptr[sl] + 64 * j + t;
-        const int cam = st.obs_cam[e];
-        if (cam < 0) continue;
-        const int cx = (int)(st.obs_xy[2 * e] * inv_cell), cy = (int)(st.obs_xy[2 * e + 1] * inv_cell);
-        feats[vptr[cam + 1]++] = Feat{((int64_t)cx << 32) ^ (int64_t)(uint32_t)cy, st.pt_orig[sl * 64 + t]};
-      }
-  }
-  auto better = [&](int a, int b) {  // (length, error) ascending, then track index
-    if (stat[a].len != stat[b].len) return stat[a].len < stat[b].len;
-    if (stat[a].err != stat[b].err) return stat[a].err < stat[b].err;
-    return a < b;
-  };
-  // best track of every occupied grid cell (:150-196)
-  for (int c = 0; c < st.Nc; ++c) {
-    if (view_mask && !view_mask[c]) continue;
-    auto b = feats.begin() + vptr[c], e = feats.begin() + vptr[c + 1];
-    std::sort(b, e, [&](const Feat& x, const Feat& y) {
-      if (x.cell != y.cell) return x.cell < y.cell;
-      return better(x.track, y.track);
-    });
-    for (auto it = b; it != e; ++it)
-      if (it == b || it->cell != (it - 1)->cell) {
-        if (!selected[it->track]) sum->num_selected_grid++;
-        selected[it->track] = 1;
-      }
-  }
-  // top up views that see fewer than the minimum number of selected tracks (:201-249),
-  // views in ascending order; candidates ranked by track index (pair<TrackId, ...> order)
-  std::vector<int> cand;
-  for (int c = 0; c < st.Nc; ++c) {
-    if (view_mask && !view_mask[c]) continue;
-    const int64_t b = vptr[c], e = vptr[c + 1];
-    const int num_estimated = (int)(e - b);
-    int num_optimized = 0;
-    for (int64_t q = b; q < e; ++q) num_optimized += selected[feats[q].track];
-    if (num_optimized >= min_num_optimized_tracks_per_view || num_optimized == num_estimated) continue;
-    const int needed = std::min(min_num_optimized_tracks_per_view - num_optimized, num_estimated - num_optimized);
-    cand.clear();
-    for (int64_t q = b; q < e; ++q)
-      if (!selected[feats[q].track]) cand.push_back(feats[q].track);
-    std::sort(cand.begin(), cand.end());
-    for (int i = 0; i < needed && i < (int)cand.size(); ++i) selected[cand[i]] = 1;
-  }
+  if (stats_err)  // 0xff.. is a NaN pattern; make it the quiet NaN the host path produced
+    for (const int p : st.unobserved) stats_err[p] = std::nan("");
   sum->num_tracks = Np;
-  for (int p = 0; p < Np; ++p) sum->num_selected += selected[p];
+  sum->num_selected_grid = s->h_counters[0];
+  sum->num_selected = s->h_counters[1];
   sum->seconds = now_s() - t0;
   return TMI_BA_OK;
 }
@@ -2106,7 +2272,7 @@ int32_t tmi_ba_solver_evaluate(tmi_ba_solver* s, double* residuals, double* jac_
   prepare_cameras(s, v.ext, v.intr, v.prep);
   hipLaunchKernelGGL(fill_kernel, dim3((unsigned)(((long long)st.Np_pad * DP + 255) / 256 + 1)), dim3(256), 0, stream, v.scale_p, (long long)st.Np_pad * DP, 1.0);
   // poison the residual planes so that invalid observations can be told apart
-  s->launch.linearize(v, stream, v.prep, 0, 1.0, s->nblocks_tracks);
+  s->launch.linearize(v, stream, v.prep, 0, 1.0, s->nblocks_tracks, nullptr);
   const size_t N = (size_t)st.No_pad;
   std::vector<double> r(residuals ? 2 * N : 0), A(jac_camera ? (size_t)2 * D * N : 0),
       Jp(jac_point ? (size_t)2 * DP * N : 0);

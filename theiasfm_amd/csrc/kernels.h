@@ -70,6 +70,49 @@ __device__ __forceinline__ double wave_max(double v) {
 }
 
 // ------------------------------------------------------------------------------
+// Grid-wide hand-over inside ONE launch ("the last workgroup finishes the reduction").
+// MI355X is eight XCDs with separate L2s: an agent-scope FENCE writes back / invalidates the whole
+// L2 of the XCD (measured: a cost kernel whose 4000 workgroups each execute __threadfence() went
+// from 0.16 ms to over 1 ms).  The hand-over below therefore uses no fence at all: the few values
+// that cross workgroups are written and read with agent-scope RELAXED ATOMICS (write-through /
+// cache-bypassing single accesses), the ticket is an agent-scope atomic add, and the only ordering
+// needed -- "my stores have completed before I take the ticket" -- is a workgroup-scope release
+// (s_waitcnt, no cache maintenance).  Anything bigger than a handful of scalars per workgroup
+// must cross a kernel boundary instead.
+// ------------------------------------------------------------------------------
+__device__ __forceinline__ void st_agent(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_agent(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(int* p, int v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int ld_agent(const int* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Call from ONE thread after the workgroup's hand-over stores are done (and a __syncthreads if other
+// threads made them); true in the workgroup that arrives last.  A single counter serialises one
+// atomic per workgroup at one address (measured: +25 us for a 1778-workgroup kernel), so arrivals
+// are counted in kTicketGroups sub-counters and only the last arrival of each sub-counter touches
+// the top one.  `ticket` points at a region of kTicketStride ints: [0] top, [1 ..] sub-counters;
+// all of them are back at zero when the function returns true.
+constexpr int kTicketGroups = 32;
+constexpr int kTicketStride = 64;
+__device__ __forceinline__ bool take_ticket(int* ticket, int nblocks) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  const int g = (int)blockIdx.x & (kTicketGroups - 1);
+  const int in_group = (nblocks - g + kTicketGroups - 1) / kTicketGroups;  // workgroups with this residue
+  if (__hip_atomic_fetch_add(ticket + 1 + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != in_group - 1) return false;
+  __hip_atomic_store(ticket + 1 + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int groups = nblocks < kTicketGroups ? nblocks : kTicketGroups;
+  if (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != groups - 1) return false;
+  __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
+}
+
+// ------------------------------------------------------------------------------
 // Track -> lane mapping of the per-track kernels.
 // Slices are sorted by track length.  A thread per track means the longest slice sets a
 // serial floor (63 dependent iterations on the Venice-sized problem) that does not shrink
@@ -157,7 +200,44 @@ __device__ __forceinline__ void block_sum_store(const double (&v)[NV], double* p
     double s = 0.0;
 #pragma unroll
     for (int k = 0; k < kSlicesPerBlock; ++k) s += sh[threadIdx.x][k];
-    partial[(size_t)threadIdx.x * nblocks + blockIdx.x] = s;
+    st_agent(&partial[(size_t)threadIdx.x * nblocks + blockIdx.x], s);
+  }
+}
+
+// block_sum_store + the grid-wide finish in the same launch: the last workgroup to arrive adds the
+// per-workgroup partials exactly as reduce_sum_kernel would (thread t takes i = t, t + 256, ...,
+// then the same tree), so results are bit-identical to the two-launch form.  dst == nullptr keeps
+// the partials only.  flag_src / flag_dst: optionally the last workgroup also turns a device
+// flag into the double 0 / 1 that rides in the all-reduced scalar tail.
+template <int NV>
+__device__ __forceinline__ void block_sum_finish(const double (&v)[NV], double* partial, int nblocks,
+                                                 int* ticket, double* dst, const int* flag_src = nullptr,
+                                                 double* flag_dst = nullptr) {
+  block_sum_store<NV>(v, partial, nblocks);
+  if (dst == nullptr) return;
+  __shared__ double fin_sh[256];
+  __shared__ int fin_last;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (threadIdx.x == 0) fin_last = take_ticket(ticket, nblocks) ? 1 : 0;
+  __syncthreads();
+  if (!fin_last) return;
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    const double* src = partial + (size_t)q * nblocks;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) acc += ld_agent(&src[i]);
+    fin_sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) fin_sh[threadIdx.x] += fin_sh[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) dst[q] = fin_sh[0];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (flag_dst) *flag_dst = ld_agent(flag_src) ? 1.0 : 0.0;
   }
 }
 
@@ -219,211 +299,10 @@ __global__ void expand_camera_scale_kernel(DeviceView v) {
 }
 
 // ------------------------------------------------------------------------------
-// linearize: residual + Jacobian blocks per observation (kernel class 0).
-// Thread (slice s, lane t) walks the observations of track 64 s + t.
-// Replaces the N_obs AutoDiffCostFunction evaluations of hot loop 1
-// (reprojection_error.h:51-95 under Jets) with analytic Jacobians, applies the
-// loss correction (ceres corrector.cc) and the Jacobi column scaling, and
-// writes the reduced blocks as SoA planes.  cost/ss partials -> partial[0..2).
-// ------------------------------------------------------------------------------
-struct LinearizeArgs {
-  int loss_type;
-  double loss_width;
-  int point_dof_mask;  // unused
-};
-
-template <int D, int DP, bool SH, typename RT>
-__global__ __launch_bounds__(256) void linearize_legacy_kernel(DeviceView v, int loss_type, double loss_width,
-                                                               int nblocks) {
-  const TrackMap tm = track_map(v);
-  double acc[2] = {0.0, 0.0};
-  if (tm.valid) {
-    const int lp = tm.lp;
-    const int k = tm.k;
-    const size_t N = (size_t)v.No_pad;
-    double X[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) X[i] = v.pts[(size_t)lp * 4 + i];
-    const bool pconst = v.pt_const[lp] != 0;
-    double sp[DP];
-#pragma unroll
-    for (int a = 0; a < DP; ++a) sp[a] = v.scale_p[(size_t)lp * DP + a];
-    // the camera of the NEXT observation is fetched one iteration ahead and a view's model,
-    // intrinsics offset / size and free-column mask come in one 16-byte record (cam_rec), so
-    // the dependent chain of an iteration is  camera record -> parameters  instead of
-    // index -> group -> offset -> parameters  (the kernel spent 63 % of its cycles in s_waitcnt)
-    int cam_next = (tm.j0 < k) ? v.obs_cam[tm.base + (size_t)tm.j0 * 64] : 0;
-    for (int j = tm.j0; j < k; j += tm.jstep) {
-      const size_t e = tm.base + (size_t)j * 64;
-      const int cam = cam_next;
-      if (j + tm.jstep < k) cam_next = v.obs_cam[e + (size_t)tm.jstep * 64];
-      const int4 rec = v.cam_rec[cam];
-      const int grp = v.cam_grp[cam];
-      const int model = rec.x;
-      const double* Kp = v.intr + rec.y;
-      const int nk = rec.z;
-      double Kv[10], E[6];
-#pragma unroll
-      for (int i = 0; i < 10; ++i) Kv[i] = (i < nk) ? Kp[i] : 0.0;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) E[i] = v.ext[(size_t)cam * 6 + i];
-      const double fx = v.obs_xy[2 * e], fy = v.obs_xy[2 * e + 1];
-      // column scales of this view, fetched with the parameters and indexed statically below
-      // (keeps loads out of the store sequence; measured neutral on the kernel time)
-      double scf[16];
-#pragma unroll
-      for (int c = 0; c < 16; ++c) scf[c] = v.scale_cam[(size_t)cam * 16 + c];
-      // RT = double, or float for the fp32 residual path: everything downstream of the
-      // evaluation (loss correction, scaling, normal equations) stays fp64
-      RT rr[2], Jext[2][6], Jint[2][10], Jpt[2][4];
-      const bool ok = reprojection_error<true, RT>(model, E, Kv, X, fx, fy, rr, Jext, Jint, Jpt);
-      double r[2] = {(double)rr[0], (double)rr[1]};
-      const unsigned mask = (unsigned)rec.w;
-      const int rb = v.cam_rb[cam];
-      if (!ok) {
-        v.flags[FL_INVALID] = 1;
-        for (int d = 0; d < 2 * D; ++d) __builtin_nontemporal_store(0.0, &v.pm_A[pidx<2 * D>(d, e)]);
-        if (SH)
-          for (int d = 0; d < 2 * D; ++d) __builtin_nontemporal_store(0.0, &v.pm_A1[pidx<2 * D>(d, e)]);
-        for (int d = 0; d < 2 * DP; ++d) __builtin_nontemporal_store(0.0, &v.pm_Jp[pidx<2 * DP>(d, e)]);
-        __builtin_nontemporal_store(0.0, &v.pm_r[pidx<2>(0, e)]);
-        __builtin_nontemporal_store(0.0, &v.pm_r[pidx<2>(1, e)]);
-        continue;
-      }
-      const double sq = r[0] * r[0] + r[1] * r[1];
-      double sqrt_rho1 = 1.0, asn = 0.0, rscale = 1.0;
-      if (loss_type != 0) {
-        double rho[3];
-        loss_eval(loss_type, loss_width, sq, rho);
-        acc[0] += 0.5 * rho[0];
-        sqrt_rho1 = sqrt(rho[1]);
-        rscale = sqrt_rho1;
-        if (!(sq == 0.0 || rho[2] <= 0.0)) {
-          const double Dd = 1.0 + 2.0 * sq * rho[2] / rho[1];
-          const double alpha = 1.0 - sqrt(Dd);
-          rscale = sqrt_rho1 / (1.0 - alpha);
-          asn = alpha / sq;
-        }
-      } else {
-        acc[0] += 0.5 * sq;
-      }
-      acc[1] += sq;
-      // reduced camera block: free columns of [ext(6) | intr(10)], compacted
-      int dst = 0;
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        if (mask & (1u << c)) {
-          double j0 = (double)((c < 6) ? Jext[0][c < 6 ? c : 0] : Jint[0][c >= 6 ? c - 6 : 0]);
-          double j1 = (double)((c < 6) ? Jext[1][c < 6 ? c : 0] : Jint[1][c >= 6 ? c - 6 : 0]);
-          if (loss_type != 0) {
-            const double rtj = j0 * r[0] + j1 * r[1];
-            j0 = sqrt_rho1 * (j0 - asn * r[0] * rtj);
-            j1 = sqrt_rho1 * (j1 - asn * r[1] * rtj);
-          }
-          const double scl = scf[c];
-          __builtin_nontemporal_store(j0 * scl, &v.pm_A[pidx<2 * D>((2 * dst), e)]);
-          __builtin_nontemporal_store(j1 * scl, &v.pm_A[pidx<2 * D>((2 * dst + 1), e)]);
-          ++dst;
-        }
-      }
-      for (int d = 2 * dst; d < 2 * D; ++d) __builtin_nontemporal_store(0.0, &v.pm_A[pidx<2 * D>(d, e)]);
-      if (SH) {
-        // free intrinsics shared between views: their columns go to the group's own block
-        const int grb = v.cam_grb[cam];
-        int dst1 = 0;
-        if (grb >= 0) {
-          const unsigned gmask = v.grp_mask[grp];
-#pragma unroll
-          for (int c = 0; c < 10; ++c) {
-            if (gmask & (1u << c)) {
-              double j0 = (double)Jint[0][c], j1 = (double)Jint[1][c];
-              if (loss_type != 0) {
-                const double rtj = j0 * r[0] + j1 * r[1];
-                j0 = sqrt_rho1 * (j0 - asn * r[0] * rtj);
-                j1 = sqrt_rho1 * (j1 - asn * r[1] * rtj);
-              }
-              const double scl = scf[6 + c];
-              __builtin_nontemporal_store(j0 * scl, &v.pm_A1[pidx<2 * D>((2 * dst1), e)]);
-              __builtin_nontemporal_store(j1 * scl, &v.pm_A1[pidx<2 * D>((2 * dst1 + 1), e)]);
-              ++dst1;
-            }
-          }
-        }
-        for (int d = 2 * dst1; d < 2 * D; ++d) __builtin_nontemporal_store(0.0, &v.pm_A1[pidx<2 * D>(d, e)]);
-      }
-#pragma unroll
-      for (int a = 0; a < DP; ++a) {
-        double j0 = pconst ? 0.0 : (double)Jpt[0][a], j1 = pconst ? 0.0 : (double)Jpt[1][a];
-        if (loss_type != 0) {
-          const double rtj = j0 * r[0] + j1 * r[1];
-          j0 = sqrt_rho1 * (j0 - asn * r[0] * rtj);
-          j1 = sqrt_rho1 * (j1 - asn * r[1] * rtj);
-        }
-        __builtin_nontemporal_store(j0 * sp[a], &v.pm_Jp[pidx<2 * DP>((2 * a), e)]);
-        __builtin_nontemporal_store(j1 * sp[a], &v.pm_Jp[pidx<2 * DP>((2 * a + 1), e)]);
-      }
-      __builtin_nontemporal_store(r[0] * rscale, &v.pm_r[pidx<2>(0, e)]);
-      __builtin_nontemporal_store(r[1] * rscale, &v.pm_r[pidx<2>(1, e)]);
-    }
-  }
-  block_sum_store<2>(acc, v.partial, nblocks);
-}
-
-// cost only, at a given parameter set (kernel class 9): hot loop 1, residual-only.
-template <int DP, typename RT>
-__global__ __launch_bounds__(256) void cost_legacy_kernel(DeviceView v, const double* __restrict__ ext,
-                                                   const double* __restrict__ intr,
-                                                   const double* __restrict__ pts, int loss_type,
-                                                   double loss_width, int flag_slot, int nblocks,
-                                                   double* partial) {
-  const TrackMap tm = track_map(v);
-  double acc[2] = {0.0, 0.0};
-  if (tm.valid) {
-    const int lp = tm.lp;
-    const int k = tm.k;
-    double X[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) X[i] = pts[(size_t)lp * 4 + i];
-    int cam_next = (tm.j0 < k) ? v.obs_cam[tm.base + (size_t)tm.j0 * 64] : 0;
-    for (int j = tm.j0; j < k; j += tm.jstep) {
-      const size_t e = tm.base + (size_t)j * 64;
-      const int cam = cam_next;
-      if (j + tm.jstep < k) cam_next = v.obs_cam[e + (size_t)tm.jstep * 64];
-      const int4 rec = v.cam_rec[cam];
-      const double* Kp = intr + rec.y;
-      const int nk = rec.z;
-      double Kv[10], E[6];
-#pragma unroll
-      for (int i = 0; i < 10; ++i) Kv[i] = (i < nk) ? Kp[i] : 0.0;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) E[i] = ext[(size_t)cam * 6 + i];
-      RT rr[2];
-      RT (*nul6)[6] = nullptr;
-      RT Jint[2][10];
-      RT (*nul4)[4] = nullptr;
-      const bool ok = reprojection_error<false, RT>(rec.x, E, Kv, X, v.obs_xy[2 * e],
-                                                    v.obs_xy[2 * e + 1], rr, nul6, Jint, nul4);
-      const double r[2] = {(double)rr[0], (double)rr[1]};
-      if (!ok) {
-        v.flags[flag_slot] = 1;
-        continue;
-      }
-      const double sq = r[0] * r[0] + r[1] * r[1];
-      if (loss_type != 0) {
-        double rho[3];
-        loss_eval(loss_type, loss_width, sq, rho);
-        acc[0] += 0.5 * rho[0];
-      } else {
-        acc[0] += 0.5 * sq;
-      }
-      acc[1] += sq;
-    }
-  }
-  block_sum_store<2>(acc, partial, nblocks);
-}
-
-// ------------------------------------------------------------------------------
-// Prepared-camera evaluation path (default): camera_prepare + linearize + cost.
+// Evaluation path: camera_prepare + linearize + cost.
+// linearize (kernel class 0) replaces the N_obs AutoDiffCostFunction evaluations of hot loop 1
+// (reprojection_error.h:51-95 under Jets) with analytic Jacobians, applies the loss correction
+// (ceres corrector.cc) and the Jacobi column scaling, and writes the reduced blocks as SoA planes.
 //
 // camera_prepare_kernel: one thread per view turns [C, angle-axis], the view's intrinsics and
 // its 16 column scales into the 48-double record of camera_models.h (R, C, K, Jl diag(scale),
@@ -473,14 +352,15 @@ __device__ __forceinline__ void stage_camera_records(const double* __restrict__ 
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// linearize (kernel class 0), prepared-camera version.  Same outputs as the legacy kernel.
+// linearize (kernel class 0).
 // Per trip: stage [R C K flag] -> value, projection Jacobian, M = dp/dq R, c = p x dp/dq;
 // stage [Jl scale] -> angle-axis columns, scaling and the plane stores.
 // OCC = minimum workgroups per CU the register allocation must allow (2: 256 registers per
 // lane, a handful of doubles spilled in the rarely taken camera-model branches).
 template <int D, int DP, bool SH, typename RT, int OCC>
 __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const double* __restrict__ prep,
-                                                             int loss_type, double loss_width, int nblocks) {
+                                                             int loss_type, double loss_width, int nblocks,
+                                                             double* __restrict__ sums) {
   __shared__ __attribute__((aligned(16))) double stage[kSlicesPerBlock][64 * kStagePitch];
   const TrackMap tm = track_map(v);
   const int lane = threadIdx.x & 63;
@@ -658,7 +538,7 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
     __builtin_nontemporal_store(r[0] * rscale, &v.pm_r[pidx<2>(0, e)]);
     __builtin_nontemporal_store(r[1] * rscale, &v.pm_r[pidx<2>(1, e)]);
   }
-  block_sum_store<2>(acc, v.partial, nblocks);
+  block_sum_finish<2>(acc, v.partial, nblocks, v.ticket + 2 * kTicketStride, sums);
 }
 
 // cost only, at a prepared parameter set (kernel class 9): hot loop 1, residual-only.
@@ -666,7 +546,8 @@ template <int DP, typename RT>
 __global__ __launch_bounds__(256) void cost_kernel(DeviceView v, const double* __restrict__ prep,
                                                    const double* __restrict__ pts, int loss_type,
                                                    double loss_width, int flag_slot, int nblocks,
-                                                   double* partial) {
+                                                   double* partial, double* __restrict__ sums,
+                                                   double* __restrict__ flag_dst) {
   __shared__ __attribute__((aligned(16))) double stage[kSlicesPerBlock][64 * kStagePitch];
   const TrackMap tm = track_map(v);
   const int lane = threadIdx.x & 63;
@@ -702,7 +583,7 @@ __global__ __launch_bounds__(256) void cost_kernel(DeviceView v, const double* _
     RT (*nul4)[4] = nullptr;
     const bool ok = reprojection_error_prepared<false, RT>(model, P, X, fx, fy, rr, nul6, Jint, nul4);
     if (!ok) {
-      v.flags[flag_slot] = 1;
+      st_agent(&v.flags[flag_slot], 1);
       continue;
     }
     const double r[2] = {(double)rr[0], (double)rr[1]};
@@ -716,7 +597,7 @@ __global__ __launch_bounds__(256) void cost_kernel(DeviceView v, const double* _
     }
     acc[1] += sq;
   }
-  block_sum_store<2>(acc, partial, nblocks);
+  block_sum_finish<2>(acc, partial, nblocks, v.ticket + 2 * kTicketStride, sums, v.flags + flag_slot, flag_dst);
 }
 
 // ------------------------------------------------------------------------------
@@ -1061,12 +942,28 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
   const double wm = wave_max(gmax);
   if (lane == 0) shm[threadIdx.x >> 6] = wm;
   __syncthreads();
+  __shared__ int pe_last;
   if (threadIdx.x == 0) {
     double m = shm[0];
     for (int i = 1; i < kSlicesPerBlock; ++i) m = fmax(m, shm[i]);
-    partial_max[blockIdx.x] = m;
+    st_agent(&partial_max[blockIdx.x], m);
+    pe_last = take_ticket(v.ticket + 2 * kTicketStride, nblocks) ? 1 : 0;
   }
-  (void)nblocks;
+  __syncthreads();
+  if (pe_last) {
+    // the last workgroup finishes max |g_p / scale| (what reduce_max_kernel did in a launch of its own)
+    double m = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) m = fmax(m, ld_agent(&partial_max[i]));
+    const double wm2 = wave_max(m);
+    __syncthreads();
+    if (lane == 0) shm[threadIdx.x >> 6] = wm2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = shm[0];
+      for (int i = 1; i < kSlicesPerBlock; ++i) t = fmax(t, shm[i]);
+      v.scal[SC_GMAX_P] = t;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------
@@ -1420,24 +1317,50 @@ __global__ __launch_bounds__(256) void schur_offdiag_kernel(DeviceView v, RedLay
 // The off-diagonal blocks need no post-processing: S is symmetric and the
 // upper blocks are used where schur_offdiag (and the all-reduce) left them.
 // ------------------------------------------------------------------------------
+// want_gmax: also scal[SC_GMAX] = max |g_c / scale| over the free camera columns (the gradient
+// tolerance test), finished by the last workgroup.
 template <int D>
 __global__ __launch_bounds__(256) void finish_diag_kernel(DeviceView v, RedLayout L, double inv_radius,
-                                                          double lm_lo, double lm_hi) {
+                                                          double lm_lo, double lm_hi, int want_gmax) {
+  __shared__ double fd_sh[4];
+  __shared__ int fd_last;
   const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= v.Nrb * D * D) return;
-  const int rb = e / (D * D);
-  const int w = e - rb * (D * D);
-  const int a = w / D, b = w - a * D;
-  double val = v.red[L.diag + e];
-  if (a == b) {
-    if (v.rb_cols[(size_t)rb * D + a] < 0) {
-      val = 1.0;
-    } else {
-      const double d = v.red[L.udiag + (size_t)rb * D + a];
-      val += fmin(fmax(d, lm_lo), lm_hi) * inv_radius;
+  double gm = 0.0;
+  if (e < v.Nrb * D * D) {
+    const int rb = e / (D * D);
+    const int w = e - rb * (D * D);
+    const int a = w / D, b = w - a * D;
+    double val = v.red[L.diag + e];
+    if (a == b) {
+      if (v.rb_cols[(size_t)rb * D + a] < 0) {
+        val = 1.0;
+      } else {
+        const double d = v.red[L.udiag + (size_t)rb * D + a];
+        val += fmin(fmax(d, lm_lo), lm_hi) * inv_radius;
+        if (want_gmax) gm = fabs(v.red[L.gc + (size_t)rb * D + a] / v.scale_c[(size_t)rb * D + a]);
+      }
     }
+    v.Sdiag[e] = val;
   }
-  v.Sdiag[e] = val;
+  if (!want_gmax) return;
+  const double wm = wave_max(gm);
+  if ((threadIdx.x & 63) == 0) fd_sh[threadIdx.x >> 6] = wm;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    st_agent(&v.dotbuf[blockIdx.x], fmax(fmax(fd_sh[0], fd_sh[1]), fmax(fd_sh[2], fd_sh[3])));
+    fd_last = take_ticket(v.ticket + 2 * kTicketStride, (int)gridDim.x) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!fd_last) return;
+  double m = 0.0;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) m = fmax(m, ld_agent(&v.dotbuf[i]));
+  const double wm2 = wave_max(m);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) fd_sh[threadIdx.x >> 6] = wm2;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    v.scal[SC_GMAX] = fmax(fmax(fd_sh[0], fd_sh[1]), fmax(fd_sh[2], fd_sh[3]));
+  }
 }
 
 // ------------------------------------------------------------------------------
@@ -1522,7 +1445,7 @@ __global__ __launch_bounds__(64) void precond_invert_kernel(DeviceView v, int id
 // ------------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(256) void spmv_rows_kernel(DeviceView v, const double* __restrict__ ub,
-                                                        const double* __restrict__ x) {
+                                                        const double* __restrict__ x, int spec) {
   constexpr int G = 64 / D;
   constexpr int BLK = D * D;
   constexpr int NW = G * BLK;            // doubles per trip
@@ -1532,6 +1455,7 @@ __global__ __launch_bounds__(256) void spmv_rows_kernel(DeviceView v, const doub
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int cidx = blockIdx.x * 4 + w;
   if (cidx >= v.n_spc) return;  // no workgroup barrier below
+  if (spec && *v.pcg_done) return;
   const int row = v.spc_row[cidx];
   const int u0 = v.spc_u0[cidx];
   const int u1 = min(u0 + kSpmvTrips * G, v.urow_ptr[row + 1]);
@@ -1599,11 +1523,40 @@ __global__ __launch_bounds__(256) void spmv_rows_kernel(DeviceView v, const doub
   }
 }
 
+// Deterministic grid-wide sum of one value per workgroup without a second launch: every
+// workgroup stores its value, takes a ticket, and the LAST one to arrive adds them up in a fixed
+// order (thread t takes elements t, t + T, ...; then a fixed tree).  Returns true in the last
+// workgroup only (all of its threads), with the total in *total.
+template <int T>
+__device__ __forceinline__ bool last_block_sum(double mine, double* __restrict__ slots, int* ticket, double* total) {
+  __shared__ double lb_sh[T];
+  __shared__ int lb_last;
+  if (threadIdx.x == 0) {
+    st_agent(&slots[blockIdx.x], mine);
+    lb_last = take_ticket(ticket, (int)gridDim.x) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!lb_last) return false;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += T) acc += ld_agent(&slots[i]);
+  lb_sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = T / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) lb_sh[threadIdx.x] += lb_sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  *total = lb_sh[0];
+  return true;
+}
+
+// dot != 0: also y[Nrb D] = x . y (the p.q of a PCG iteration), summed by the last workgroup;
+// spec != 0: return at once when PCG has already stopped (speculative launch).
 template <int D>
 __global__ __launch_bounds__(256) void spmv_cols_kernel(DeviceView v, const double* __restrict__ x,
-                                                        double* __restrict__ y) {
+                                                        double* __restrict__ y, int dot, int spec) {
   constexpr int G = 64 / D;
   __shared__ double part[4][G][D];
+  if (spec && *v.pcg_done) return;
   const int col = blockIdx.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int g = lane / D, r = lane - g * D;
@@ -1625,6 +1578,15 @@ __global__ __launch_bounds__(256) void spmv_cols_kernel(DeviceView v, const doub
 #pragma unroll
       for (int gg = 0; gg < G; ++gg) s += part[ww][gg][threadIdx.x];
     y[(size_t)col * D + threadIdx.x] = s;
+    if (dot) part[0][0][threadIdx.x] = s * x[(size_t)col * D + threadIdx.x];
+  }
+  if (dot) {
+    __syncthreads();
+    double mine = 0.0;
+    if (threadIdx.x == 0)
+      for (int a = 0; a < D; ++a) mine += part[0][0][a];
+    double tot;
+    if (last_block_sum<256>(mine, v.dotbuf, v.ticket, &tot) && threadIdx.x == 0) y[(size_t)v.Nrb * D] = tot;
   }
 }
 
@@ -1641,8 +1603,9 @@ __global__ __launch_bounds__(256) void spmv_cols_kernel(DeviceView v, const doub
 template <int D, int DP, bool SH>
 __global__ __launch_bounds__(256) void implicit_tracks_kernel(DeviceView v, const double* __restrict__ x,
                                                               double* __restrict__ pm_u,
-                                                              double* __restrict__ cm_t) {
+                                                              double* __restrict__ cm_t, int spec) {
   constexpr int NS = sym_size(DP);
+  if (spec && *v.pcg_done) return;
   const TrackMap tm = track_map(v);
   if (!tm.valid) return;
   const int lp = tm.lp;
@@ -1719,10 +1682,11 @@ __global__ __launch_bounds__(64) void implicit_cameras_kernel(DeviceView v, RedL
                                                               const double* __restrict__ cm_t,
                                                               double* __restrict__ y, double inv_radius,
                                                               double lm_lo, double lm_hi, int add_diag,
-                                                              double* __restrict__ grp_part) {
+                                                              double* __restrict__ grp_part, int dot, int spec) {
   constexpr int AS = as_of(D, SH);
+  if (spec && *v.pcg_done) return;
   const int rb = blockIdx.x;
-  if (SH && rb >= v.Ncam_rb) return;  // shared blocks: implicit_groups_kernel
+  if (SH && rb >= v.Ncam_rb) return;  // shared blocks: implicit_groups_kernel (dot is not used with SH)
   double acc[D], acc1[SH ? D : 1];
 #pragma unroll
   for (int a = 0; a < D; ++a) acc[a] = 0.0;
@@ -1746,6 +1710,7 @@ __global__ __launch_bounds__(64) void implicit_cameras_kernel(DeviceView v, RedL
       if (threadIdx.x == 0) grp_part[(size_t)rb * D + a] = tot1;
     }
   }
+  double my_dot = 0.0;
 #pragma unroll
   for (int a = 0; a < D; ++a) {
     double tot = wave_sum(acc[a]);
@@ -1764,7 +1729,13 @@ __global__ __launch_bounds__(64) void implicit_cameras_kernel(DeviceView v, RedL
         tot = 0.0;
       }
       y[(size_t)rb * D + a] = tot;
+      my_dot += tot * x[(size_t)rb * D + a];
     }
+  }
+  if (dot) {
+    // this rank's share of x . y rides behind the product vector and is all-reduced with it
+    double total;
+    if (last_block_sum<64>(my_dot, v.dotbuf, v.ticket, &total) && threadIdx.x == 0) y[(size_t)v.Nrb * D] = total;
   }
 }
 
@@ -1824,6 +1795,9 @@ __global__ __launch_bounds__(1024) void pcg_begin_kernel(DeviceView v, const dou
     v.scal[SC_RHO] = 1.0;
     v.scal[SC_Q0] = 0.0;
     v.flags[FL_PCG_FAIL] = 0;
+    *v.pcg_done = 0;
+    v.ticket[0] = 0;
+    v.ticket[1] = 0;
   }
 }
 
@@ -1950,6 +1924,205 @@ __global__ __launch_bounds__(1024) void pcg_b3_kernel(DeviceView v, int n, int i
   }
   const double beta = rho / last_rho;
   for (int i = threadIdx.x; i < n; i += 1024) v.cg_p[i] = v.cg_z[i] + beta * v.cg_p[i];
+}
+
+// One PCG iteration after q = S p (replaces pcg_b1 + pcg_b2 + pcg_b3 + publish when the product
+// kernel delivered p.q behind the product vector): pcg_step -- every workgroup forms alpha itself,
+// updates x, r and z = M^-1 r of its blocks and hands over its partial sums of Q1 and rho'; the last
+// workgroup to arrive finishes the sums in a fixed order, does the scalar recurrences, decides
+// whether PCG stops (so that kernels enqueued speculatively for the next iteration return at once)
+// and publishes the scalars to the host mirror -- then pcg_p: p = z + beta p (a vector that
+// crosses workgroups must cross a kernel boundary, see the hand-over note at the top).
+constexpr int kPcgStepThreads = 1024;
+template <int D>
+__global__ __launch_bounds__(kPcgStepThreads) void pcg_step_kernel(DeviceView v, const double* __restrict__ b, int it,
+                                                       int nblocks, double eta, int min_it, int max_it,
+                                                       const double* __restrict__ red8, HostMirror* mirror,
+                                                       unsigned long long seq) {
+  if (*v.pcg_done) return;
+  constexpr int T = kPcgStepThreads, W = T / 64;
+  __shared__ double sh[2][T];
+  __shared__ double shw[2][W];
+  __shared__ double pub[SC_COUNT];
+  __shared__ int pubf[FL_COUNT];
+  __shared__ int last;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int rb = blockIdx.x * W + wv;
+  const int n = v.Nrb * D;
+  const double pq = v.cg_q[n];
+  const bool ok = pq > 0.0 && isfinite(pq);
+  const double rho = v.scal[SC_RHO];
+  const double alpha = rho / pq;
+  double acc[2] = {0.0, 0.0};
+  if (rb < v.Nrb && ok) {
+    const int i = rb * D + lane;
+    double rn = 0.0;
+    if (lane < D) {
+      const double x = v.yc[i] + alpha * v.cg_p[i];
+      v.yc[i] = x;
+      rn = v.cg_r[i] - alpha * v.cg_q[i];
+      v.cg_r[i] = rn;
+      acc[0] = -x * (b[i] + rn);
+    }
+    double z = 0.0;
+    const double* M = v.Minv + (size_t)rb * D * D + (lane < D ? lane : 0) * D;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      const double rc = __shfl(rn, c, 64);
+      if (lane < D) z += M[c] * rc;
+    }
+    if (lane < D) {
+      v.cg_z[i] = z;
+      acc[1] = rn * z;
+    }
+  }
+  {
+    const double s0 = wave_sum(acc[0]), s1 = wave_sum(acc[1]);
+    if (lane == 0) {
+      shw[0][wv] = s0;
+      shw[1][wv] = s1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        t0 += shw[0][k];
+        t1 += shw[1][k];
+      }
+      st_agent(&v.partial[blockIdx.x], t0);
+      st_agent(&v.partial[(size_t)nblocks + blockIdx.x], t1);
+      last = take_ticket(v.ticket + 1 * kTicketStride, nblocks) ? 1 : 0;
+    }
+    __syncthreads();
+  }
+  if (!last) return;
+  double l0 = 0.0, l1 = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += T) {
+    l0 += ld_agent(&v.partial[i]);
+    l1 += ld_agent(&v.partial[(size_t)nblocks + i]);
+  }
+  sh[0][threadIdx.x] = l0;
+  sh[1][threadIdx.x] = l1;
+  if (threadIdx.x < SC_COUNT) pub[threadIdx.x] = v.scal[threadIdx.x];
+  if (threadIdx.x < FL_COUNT) pubf[threadIdx.x] = v.flags[threadIdx.x];
+  __syncthreads();
+  for (int o = T / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+      sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double Q1 = sh[0][0], rho_new = sh[1][0];
+    auto set = [&](int slot, double val) {
+      v.scal[slot] = val;
+      pub[slot] = val;
+    };
+    set(SC_PQ, pq);
+    set(SC_ALPHA, alpha);
+    if (ok && !isfinite(alpha)) {
+      v.flags[FL_PCG_FAIL] = 1;
+      pubf[FL_PCG_FAIL] = 1;
+    }
+    double zeta = -1.0, rho_bad = 0.0;
+    if (ok) {
+      const double Q0 = v.scal[SC_Q0];
+      zeta = it * (Q1 - Q0) / Q1;
+      set(SC_Q1, Q1);
+      set(SC_Q0, Q1);
+      set(SC_LAST_RHO, rho);
+      set(SC_RHO, rho_new);
+      rho_bad = (rho_new == 0.0 || !isfinite(rho_new) || !isfinite(rho_new / rho)) ? 1.0 : 0.0;
+      set(SC_RHO_BAD, rho_bad);
+    }
+    set(SC_ZETA, zeta);
+    // the host's stopping rules (solve_reduced_pcg), evaluated here for the speculative launches
+    const bool stop = pubf[FL_PCG_FAIL] != 0 || !ok || (zeta < eta && it >= min_it) || it >= max_it || rho_bad != 0.0;
+    *v.pcg_done = stop ? 1 : 0;
+  }
+  __syncthreads();
+  // publish (what publish_kernel does)
+  const int t = threadIdx.x;
+  if (t < SC_COUNT) mirror->scal[t] = pub[t];
+  if (t < 8) mirror->red[t] = red8[t];
+  if (t < FL_COUNT) mirror->flags[t] = pubf[t];
+  __threadfence_system();
+  __syncthreads();
+  if (t == 0) __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// p = z + beta p, beta = rho / last_rho (both left by pcg_step); nothing if PCG has stopped
+__global__ __launch_bounds__(256) void pcg_p_kernel(DeviceView v, int n) {
+  if (*v.pcg_done) return;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double beta = v.scal[SC_RHO] / v.scal[SC_LAST_RHO];
+  v.cg_p[i] = v.cg_z[i] + beta * v.cg_p[i];
+}
+
+// Start of a PCG solve in one launch (pcg_begin + the first pcg_a): x = 0, r = b, z = M^-1 b,
+// p = z, rho = r.z finished by the last workgroup, which also resets the PCG state.
+template <int D>
+__global__ __launch_bounds__(kPcgStepThreads) void pcg_init_kernel(DeviceView v, const double* __restrict__ b,
+                                                                   int nblocks) {
+  constexpr int T = kPcgStepThreads, W = T / 64;
+  __shared__ double sh[T];
+  __shared__ double shw[W];
+  __shared__ int last;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int rb = blockIdx.x * W + wv;
+  double acc = 0.0;
+  if (rb < v.Nrb) {
+    const int i = rb * D + lane;
+    double rn = 0.0;
+    if (lane < D) {
+      rn = b[i];
+      v.yc[i] = 0.0;
+      v.cg_r[i] = rn;
+    }
+    double z = 0.0;
+    const double* M = v.Minv + (size_t)rb * D * D + (lane < D ? lane : 0) * D;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      const double rc = __shfl(rn, c, 64);
+      if (lane < D) z += M[c] * rc;
+    }
+    if (lane < D) {
+      v.cg_z[i] = z;
+      v.cg_p[i] = z;
+      acc = rn * z;
+    }
+  }
+  const double s0 = wave_sum(acc);
+  if (lane == 0) shw[wv] = s0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < W; ++k) t += shw[k];
+    st_agent(&v.partial[blockIdx.x], t);
+    last = take_ticket(v.ticket + 1 * kTicketStride, nblocks) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!last) return;
+  double l0 = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += T) l0 += ld_agent(&v.partial[i]);
+  sh[threadIdx.x] = l0;
+  __syncthreads();
+  for (int o = T / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double rho = sh[0];
+    v.scal[SC_LAST_RHO] = 1.0;
+    v.scal[SC_RHO] = rho;
+    v.scal[SC_Q0] = 0.0;
+    v.flags[FL_PCG_FAIL] = (rho == 0.0 || !isfinite(rho)) ? 1 : 0;
+    *v.pcg_done = 0;
+  }
 }
 
 // ------------------------------------------------------------------------------
@@ -2081,7 +2254,8 @@ __global__ __launch_bounds__(256) void cross_add_kernel(DeviceView v, RedLayout 
 // ------------------------------------------------------------------------------
 template <int D, int DP, bool SH>
 __global__ __launch_bounds__(256) void back_substitute_kernel(DeviceView v, double* __restrict__ pm_u,
-                                                              int nblocks, double* partial) {
+                                                              int nblocks, double* partial,
+                                                              double* __restrict__ sums) {
   constexpr int NS = sym_size(DP);
   const TrackMap tm = track_map(v);
   double acc[1] = {0.0};
@@ -2154,7 +2328,7 @@ __global__ __launch_bounds__(256) void back_substitute_kernel(DeviceView v, doub
       }
     }
   }
-  block_sum_store<1>(acc, partial, nblocks);
+  block_sum_finish<1>(acc, partial, nblocks, v.ticket + 2 * kTicketStride, sums);
 }
 
 // ------------------------------------------------------------------------------
@@ -2163,7 +2337,8 @@ __global__ __launch_bounds__(256) void back_substitute_kernel(DeviceView v, doub
 // Cameras: single workgroup (the camera part is replicated on every rank).
 // ------------------------------------------------------------------------------
 template <int DP>
-__global__ __launch_bounds__(256) void update_points_kernel(DeviceView v, int nblocks, double* partial) {
+__global__ __launch_bounds__(256) void update_points_kernel(DeviceView v, int nblocks, double* partial,
+                                                            double* __restrict__ sums) {
   const int lp = blockIdx.x * 256 + threadIdx.x;
   double acc[2] = {0.0, 0.0};
   if (lp < v.Np_pad) {
@@ -2181,80 +2356,122 @@ __global__ __launch_bounds__(256) void update_points_kernel(DeviceView v, int nb
       if (live) acc[1] += x * x;
     }
   }
-  block_sum_store<2>(acc, partial, nblocks);
+  block_sum_finish<2>(acc, partial, nblocks, v.ticket + 2 * kTicketStride, sums);
 }
 
 // |x|^2 over the live tracks of a parameter set
 __global__ __launch_bounds__(256) void points_norm_kernel(DeviceView v, const double* __restrict__ pts,
-                                                          int nblocks, double* partial) {
+                                                          int nblocks, double* partial,
+                                                          double* __restrict__ sums) {
   const int lp = blockIdx.x * 256 + threadIdx.x;
   double acc[1] = {0.0};
   if (lp < v.Np_pad && v.pt_k[lp] > 0 && !v.pt_const[lp]) {
 #pragma unroll
     for (int a = 0; a < 4; ++a) acc[0] += pts[(size_t)lp * 4 + a] * pts[(size_t)lp * 4 + a];
   }
-  block_sum_store<1>(acc, partial, nblocks);
+  block_sum_finish<1>(acc, partial, nblocks, v.ticket + 2 * kTicketStride, sums);
 }
 
-// ext_c / intr_c already hold copies of ext / intr.  out[0] = step^2 (cameras),
-// out[1] = |x+|^2 over every coordinate of every non-constant camera block.
-template <int D>
-__global__ __launch_bounds__(1024) void update_cameras_kernel(DeviceView v, double* out) {
-  __shared__ double sh[16];
-  double step = 0.0;
-  const int n = v.Nrb * D;
-  for (int i = threadIdx.x; i < n; i += 1024) {
-    const int code = v.rb_cols[i];
-    if (code < 0) continue;
-    const int rb = i / D;
-    const double d = -v.yc[i] * v.scale_c[i];
-    if (code < 6)
-      v.ext_c[(size_t)v.rb_cam[rb] * 6 + code] += d;
-    else
-      v.intr_c[v.grp_off[v.rb_grp[rb]] + code - 6] += d;
-    step += d * d;
-  }
-  const double s2 = block1024_sum(step, sh);
-  __threadfence_block();
-  __syncthreads();
-  double xn = 0.0;
-  for (int rb = threadIdx.x; rb < v.Nrb; rb += 1024) {
-    const int cam = v.rb_cam[rb];
-    bool intr = true;  // a shared intrinsics block
-    if (cam >= 0) {
-      const unsigned m = v.cam_mask[cam];
-      if (m & 0x3f)
-        for (int a = 0; a < 6; ++a) xn += v.ext_c[(size_t)cam * 6 + a] * v.ext_c[(size_t)cam * 6 + a];
-      intr = (m >> 6) != 0;
+// Candidate cameras in ONE multi-workgroup launch (round 1: two copy commands + a single
+// 1024-thread workgroup, 47 us): thread c < Nc owns view c -- ext_c = ext + d on its free
+// extrinsics, intr_c = intr + d on its PRIVATE free intrinsics (d = -y * scale), a constant
+// group is copied by each of its views (identical values) -- threads beyond own the shared
+// intrinsics blocks.  out[0] = |step|^2 (cameras), out[1] = |x+|^2 over every coordinate of every
+// non-constant camera-side block, finished by the last workgroup.  Without shared intrinsics the
+// thread also writes the candidate's prepared record (camera_models.h), saving the separate
+// camera_prepare launch.  Column of parameter bit a inside its block = popcount of the lower free bits
+// (rb_cols is filled in increasing bit order, structure.cpp).
+template <int D, bool SH>
+__global__ __launch_bounds__(256) void update_cameras_kernel(DeviceView v, double* __restrict__ out,
+                                                             double* __restrict__ prep_c) {
+  __shared__ double uc_sh[2][4];
+  __shared__ int uc_last;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int n_groups_sh = v.Nrb - v.Ncam_rb;
+  double step = 0.0, xn = 0.0;
+  if (c < v.Nc) {
+    const unsigned mask = v.cam_mask[c];
+    const int rb = v.cam_rb[c];
+    const int4 rec = v.cam_rec[c];
+    double e[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      double x = v.ext[(size_t)c * 6 + a];
+      if (mask & (1u << a)) {
+        const int col = __popc(mask & ((1u << a) - 1u));
+        const double d = -v.yc[(size_t)rb * D + col] * v.scale_c[(size_t)rb * D + col];
+        x += d;
+        step += d * d;
+      }
+      e[a] = x;
+      v.ext_c[(size_t)c * 6 + a] = x;
     }
-    if (intr) {
-      const int g = v.rb_grp[rb];
-      for (int a = v.grp_off[g]; a < v.grp_off[g + 1]; ++a) xn += v.intr_c[a] * v.intr_c[a];
+    const bool shared_free = SH && v.cam_grb[c] >= 0;
+    double K[10];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      double x = 0.0;
+      if (j < rec.z) {
+        x = v.intr[rec.y + j];
+        if (mask & (1u << (6 + j))) {
+          const int col = __popc(mask & ((1u << (6 + j)) - 1u));
+          const double d = -v.yc[(size_t)rb * D + col] * v.scale_c[(size_t)rb * D + col];
+          x += d;
+          step += d * d;
+        }
+        if (!shared_free) v.intr_c[rec.y + j] = x;
+      }
+      K[j] = x;
+    }
+    if (rb >= 0) {
+      if (mask & 0x3fu)
+#pragma unroll
+        for (int a = 0; a < 6; ++a) xn += e[a] * e[a];
+      if (mask >> 6)
+#pragma unroll
+        for (int j = 0; j < 10; ++j) xn += K[j] * K[j];
+    }
+    if (!SH) prepare_camera_record(e, K, rec.z, v.scale_cam + (size_t)c * 16, prep_c + (size_t)c * kPrepStride);
+  } else if (SH && c < v.Nc + n_groups_sh) {
+    const int grb = v.Ncam_rb + (c - v.Nc);
+    const int g = v.rb_grp[grb];
+    const unsigned gmask = v.grp_mask[g];
+    const int o = v.grp_off[g], nk = v.grp_off[g + 1] - o;
+    for (int j = 0; j < nk; ++j) {
+      double x = v.intr[o + j];
+      if (gmask & (1u << j)) {
+        const int col = __popc(gmask & ((1u << j) - 1u));
+        const double d = -v.yc[(size_t)grb * D + col] * v.scale_c[(size_t)grb * D + col];
+        x += d;
+        step += d * d;
+      }
+      v.intr_c[o + j] = x;
+      xn += x * x;
     }
   }
-  const double x2 = block1024_sum(xn, sh);
-  if (threadIdx.x == 0) {
-    out[0] = s2;
-    out[1] = x2;
+  const double s0 = wave_sum(step), s1 = wave_sum(xn);
+  if ((threadIdx.x & 63) == 0) {
+    uc_sh[0][threadIdx.x >> 6] = s0;
+    uc_sh[1][threadIdx.x >> 6] = s1;
   }
-}
-
-// max_i |g_c[i] / scale_c[i]| over the free camera columns (single workgroup)
-template <int D>
-__global__ __launch_bounds__(1024) void camera_gmax_kernel(DeviceView v, const double* __restrict__ gc,
-                                                           double* out) {
-  __shared__ double sh[16];
-  double m = 0.0;
-  const int n = v.Nrb * D;
-  for (int i = threadIdx.x; i < n; i += 1024)
-    if (v.rb_cols[i] >= 0) m = fmax(m, fabs(gc[i] / v.scale_c[i]));
-  const double wm = wave_max(m);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = wm;
   __syncthreads();
   if (threadIdx.x == 0) {
-    double t = sh[0];
-    for (int i = 1; i < 16; ++i) t = fmax(t, sh[i]);
-    out[0] = t;
+    const int nb = (int)gridDim.x;
+    st_agent(&v.dotbuf[blockIdx.x], uc_sh[0][0] + uc_sh[0][1] + uc_sh[0][2] + uc_sh[0][3]);
+    st_agent(&v.dotbuf[nb + blockIdx.x], uc_sh[1][0] + uc_sh[1][1] + uc_sh[1][2] + uc_sh[1][3]);
+    uc_last = take_ticket(v.ticket + 2 * kTicketStride, nb) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!uc_last) return;
+  if (threadIdx.x == 0) {
+    const int nb = (int)gridDim.x;
+    double t0 = 0.0, t1 = 0.0;
+    for (int i = 0; i < nb; ++i) {
+      t0 += ld_agent(&v.dotbuf[i]);
+      t1 += ld_agent(&v.dotbuf[nb + i]);
+    }
+    out[0] = t0;
+    out[1] = t1;
   }
 }
 

@@ -16,8 +16,8 @@ steps = 10
 worlds = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
 for world in worlds:
     for mode in ((0,) if world == 1 else (0, 1)):
-        base = dict(point_dof=3, linear_solver_type=abi.ITERATIVE_SCHUR, function_tolerance=0.0,
-                    gradient_tolerance=0.0, parameter_tolerance=0.0, schur_mode=mode,
+        base = dict(point_dof=3, linear_solver_type=abi.ITERATIVE_SCHUR, function_tolerance=-1.0,
+                    gradient_tolerance=-1.0, parameter_tolerance=-1.0, schur_mode=mode,
                     use_inner_iterations=0)
         o = abi.default_options(max_num_iterations=2, **base)
         s = lib.Solver(prob, o, 0, world)
