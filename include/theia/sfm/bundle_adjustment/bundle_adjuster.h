@@ -56,6 +56,14 @@ class BundleAdjuster {
   // Optimise the provided views and tracks.
   BundleAdjustmentSummary Optimize();
 
+  // Extensions: AddView / AddTrack for many ids at once.  Same residual set and constancy rules as
+  // calling AddView / AddTrack one id at a time in the given order; the walk over the views'
+  // feature tables (5 M hash nodes at Venice size, the dominant host cost of a one-shot
+  // BundleAdjustReconstruction) runs on several host threads.  A subclass that overrides the
+  // protected hooks is detected and served by the one-at-a-time path.
+  void AddViews(const std::vector<ViewId>& view_ids);
+  void AddTracks(const std::vector<TrackId>& track_ids);
+
   // Extension: the flattened problem (what Optimize() sends to the device).
   bool Flatten(FlattenedBundleAdjustmentProblem* flat);
   // Extension: the full device summary of the last Optimize().
@@ -111,6 +119,13 @@ class BundleAdjuster {
     void SetIfAbsent(uint32_t id, int value) {
       if (Get(id) < 0) Set(id, value);
     }
+    // make ids 0..max_id flat-addressable up front (so that concurrent readers never see a resize);
+    // false if max_id is beyond the flat range
+    bool Reserve(uint32_t max_id) {
+      if (max_id >= kFlatLimit) return false;
+      if (max_id >= flat_.size()) flat_.resize(static_cast<size_t>(max_id) + 1, -1);
+      return true;
+    }
     // ids present, ascending
     std::vector<uint32_t> Ids() const;
 
@@ -122,6 +137,7 @@ class BundleAdjuster {
   IdState camera_flags_;     // TMI_BA_CAMERA_* bits of the views that take part
   IdState track_constant_;   // 1 constant / 0 variable for the tracks that take part
   IdState track_estimated_;  // memo of Track::IsEstimated for the tracks AddView met
+  IdState view_optimized_;   // flat mirror of optimized_views_ (AddTrack tests it per observation)
   std::unordered_map<CameraIntrinsicsGroupId, std::vector<uint8_t> > intrinsics_constant_;
   tmi_ba_summary device_summary_;
 };

@@ -109,6 +109,30 @@ static void TestSemantics() {
     EXPECT(f.camera_group[0] == f.camera_group[1] && f.camera_group[2] != f.camera_group[0]);
   }
   {
+    // bulk AddViews / AddTracks on several host threads == one id at a time
+    Reconstruction big;
+    BuildScene(&big, 7, 300, /*share_groups=*/true, 9, 0.1);
+    big.MutableView(2)->SetEstimated(false);
+    big.MutableTrack(11)->SetEstimated(false);
+    BundleAdjuster one(opt, &big), bulk(opt, &big);
+    for (ViewId v : big.ViewIds()) one.AddView(v);
+    for (TrackId t : big.TrackIds()) one.AddTrack(t);
+    setenv("TMI_BA_HOST_THREADS", "4", 1);
+    bulk.AddViews(big.ViewIds());
+    bulk.AddTracks(big.TrackIds());
+    FlattenedBundleAdjustmentProblem f1, f2;
+    EXPECT(one.Flatten(&f1) && bulk.Flatten(&f2));
+    unsetenv("TMI_BA_HOST_THREADS");
+    EXPECT(f1.view_ids == f2.view_ids && f1.track_ids == f2.track_ids && f1.group_ids == f2.group_ids);
+    EXPECT(f1.obs_camera == f2.obs_camera && f1.obs_point == f2.obs_point && f1.obs_xy == f2.obs_xy);
+    EXPECT(f1.camera_flags == f2.camera_flags && f1.point_constant == f2.point_constant);
+    EXPECT(f1.intrinsics_constant == f2.intrinsics_constant && f1.extrinsics == f2.extrinsics);
+    EXPECT(f1.obs_camera.size() == 6u * 299u);
+    for (size_t q = 1; q < f2.obs_camera.size(); ++q)  // (track, view) ascending
+      EXPECT(f2.obs_point[q] > f2.obs_point[q - 1] ||
+             (f2.obs_point[q] == f2.obs_point[q - 1] && f2.obs_camera[q] > f2.obs_camera[q - 1]));
+  }
+  {
     // out-of-contract order (AddTrack pulls in view 1, AddView(1) comes later): the reference
     // would duplicate the (view 1, track 0) residual block; the shim keeps it once and the
     // view's extrinsics stay constant as AddTrack left them (bundle_adjuster.cc:164)

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <thread>
+#include <typeinfo>
 #include <atomic>
 #include <cstdlib>
 #include <cstdio>
@@ -19,6 +20,24 @@
 #include "theia/sfm/reconstruction.h"
 
 namespace theia {
+
+namespace {
+int HostThreads(size_t work) {
+  if (const char* e = std::getenv("TMI_BA_HOST_THREADS")) return std::max(1, std::atoi(e));  // tests
+  if (work < 200000) return 1;
+  return static_cast<int>(std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u));
+}
+template <class Body>
+void RunThreads(int n_threads, Body&& body) {
+  if (n_threads <= 1) {
+    body(0);
+    return;
+  }
+  std::vector<std::thread> pool;
+  for (int t = 0; t < n_threads; ++t) pool.emplace_back([&, t] { body(t); });
+  for (auto& th : pool) th.join();
+}
+}  // namespace
 
 tmi_ba_problem FlattenedBundleAdjustmentProblem::AsC() {
   tmi_ba_problem p;
@@ -53,6 +72,7 @@ void BundleAdjuster::AddView(const ViewId view_id) {
   if (view == nullptr) return;  // the reference CHECK-fails; the shim never aborts
   if (!view->IsEstimated() || optimized_views_.count(view_id)) return;
   optimized_views_.emplace(view_id);
+  view_optimized_.Set(view_id, 1);
   SetCameraSchurGroups(view_id);
   optimized_camera_intrinsics_groups_.emplace(reconstruction_->CameraIntrinsicsGroupIdFromViewId(view_id));
   camera_flags_.SetIfAbsent(view_id, 0);
@@ -81,7 +101,7 @@ void BundleAdjuster::AddTrack(const TrackId track_id) {
   for (const ViewId view_id : track->ViewIds()) {
     View* view = reconstruction_->MutableView(view_id);
     if (view == nullptr) continue;
-    if (optimized_views_.count(view_id) || !view->IsEstimated()) continue;
+    if (view_optimized_.Get(view_id) == 1 || !view->IsEstimated()) continue;
     const Feature* feature = view->GetFeature(track_id);
     if (feature == nullptr) continue;
     AddReprojectionErrorResidual(*feature, view_id, track_id);
@@ -91,6 +111,77 @@ void BundleAdjuster::AddTrack(const TrackId track_id) {
   }
   SetTrackVariable(track_id);
   SetTrackSchurGroup(track_id);
+}
+
+void BundleAdjuster::AddViews(const std::vector<ViewId>& view_ids) {
+  if (reconstruction_ == nullptr) return;
+  // the one-at-a-time path for subclasses (their hooks must see every residual) and for ids
+  // outside the flat tables
+  uint32_t max_track = 0;
+  bool flat_ok = typeid(*this) == typeid(BundleAdjuster);
+  std::vector<TrackId> all_tracks;
+  if (flat_ok) {
+    all_tracks = reconstruction_->TrackIds();
+    for (const TrackId t : all_tracks) max_track = std::max<uint32_t>(max_track, t);
+    flat_ok = track_estimated_.Reserve(max_track) && track_constant_.Reserve(max_track);
+  }
+  if (!flat_ok) {
+    for (const ViewId v : view_ids) AddView(v);
+    return;
+  }
+  // sequential bookkeeping per view (cheap), exactly what AddView does before its feature loop
+  std::vector<const View*> todo;
+  std::vector<ViewId> todo_id;
+  size_t work = 0;
+  for (const ViewId view_id : view_ids) {
+    View* view = reconstruction_->MutableView(view_id);
+    if (view == nullptr || !view->IsEstimated() || optimized_views_.count(view_id)) continue;
+    optimized_views_.emplace(view_id);
+    view_optimized_.Set(view_id, 1);
+    SetCameraSchurGroups(view_id);
+    optimized_camera_intrinsics_groups_.emplace(reconstruction_->CameraIntrinsicsGroupIdFromViewId(view_id));
+    camera_flags_.SetIfAbsent(view_id, 0);
+    todo.push_back(view);
+    todo_id.push_back(view_id);
+    work += view->Features().size();
+  }
+  const int n_threads = HostThreads(work);
+  // Track::IsEstimated for every track, threads own disjoint id ranges (read-only look-ups)
+  RunThreads(n_threads, [&](int t) {
+    const size_t i0 = all_tracks.size() * t / n_threads, i1 = all_tracks.size() * (t + 1) / n_threads;
+    for (size_t i = i0; i < i1; ++i) {
+      const TrackId id = all_tracks[i];
+      if (track_estimated_.Get(id) >= 0) continue;
+      const Track* track = reconstruction_->Track(id);
+      track_estimated_.Set(id, (track != nullptr && track->IsEstimated()) ? 1 : 0);  // flat, pre-sized: no resize
+    }
+  });
+  // the feature tables, one view at a time per thread, into thread-local residual lists
+  std::vector<std::vector<Residual> > local(n_threads);
+  std::atomic<size_t> next(0);
+  RunThreads(n_threads, [&](int t) {
+    std::vector<Residual>& out = local[t];
+    for (;;) {
+      const size_t i = next.fetch_add(1);
+      if (i >= todo.size()) break;
+      const ViewId view_id = todo_id[i];
+      for (const auto& kv : todo[i]->Features())
+        if (track_estimated_.Get(kv.first) == 1) out.push_back(Residual{view_id, kv.first, kv.second.x(), kv.second.y()});
+    }
+  });
+  size_t total = residuals_.size();
+  for (const auto& l : local) total += l.size();
+  residuals_.reserve(total);
+  for (const auto& l : local) {
+    // AddReprojectionErrorResidual + SetTrackConstant of every residual (:127-137)
+    for (const Residual& r : l) track_constant_.Set(r.track, 1);
+    residuals_.insert(residuals_.end(), l.begin(), l.end());
+  }
+}
+
+void BundleAdjuster::AddTracks(const std::vector<TrackId>& track_ids) {
+  optimized_tracks_.reserve(optimized_tracks_.size() + track_ids.size());
+  for (const TrackId t : track_ids) AddTrack(t);
 }
 
 // bundle_adjuster.cc:223-240
@@ -264,7 +355,7 @@ bool BundleAdjuster::Flatten(FlattenedBundleAdjustmentProblem* f) {
   //      the few observations of a track by view; output written sequentially.
   const int kShift = 10;
   const size_t nbuckets = (np >> kShift) + 1;
-  const int n_threads = n < 200000 ? 1 : static_cast<int>(std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u));
+  const int n_threads = HostThreads(n);
   auto run_threads = [&](auto&& body) {
     if (n_threads == 1) {
       body(0);
@@ -446,8 +537,8 @@ BundleAdjustmentSummary BundleAdjustPartialReconstruction(const BundleAdjustment
                                                           const std::unordered_set<TrackId>& track_ids,
                                                           Reconstruction* reconstruction) {
   BundleAdjuster bundle_adjuster(options, reconstruction);
-  for (const ViewId v : view_ids) bundle_adjuster.AddView(v);
-  for (const TrackId t : track_ids) bundle_adjuster.AddTrack(t);
+  bundle_adjuster.AddViews(std::vector<ViewId>(view_ids.begin(), view_ids.end()));
+  bundle_adjuster.AddTracks(std::vector<TrackId>(track_ids.begin(), track_ids.end()));
   return bundle_adjuster.Optimize();
 }
 
@@ -455,8 +546,8 @@ BundleAdjustmentSummary BundleAdjustReconstruction(const BundleAdjustmentOptions
                                                    Reconstruction* reconstruction) {
   BundleAdjuster bundle_adjuster(options, reconstruction);
   if (reconstruction == nullptr) return BundleAdjustmentSummary();
-  for (const ViewId v : reconstruction->ViewIds()) bundle_adjuster.AddView(v);
-  for (const TrackId t : reconstruction->TrackIds()) bundle_adjuster.AddTrack(t);
+  bundle_adjuster.AddViews(reconstruction->ViewIds());
+  bundle_adjuster.AddTracks(reconstruction->TrackIds());
   return bundle_adjuster.Optimize();
 }
 
