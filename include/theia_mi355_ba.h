@@ -509,6 +509,12 @@ int32_t tmi_ba_adjust_two_views(tmi_ba_two_view_batch* batch, int32_t point_dof,
                                 double* pair_initial_cost, double* pair_final_cost,
                                 tmi_ba_track_batch_summary* summary);
 
+/* Test hook: FNV-1a checksums of the static structure arrays resident in HBM -- built in HBM by
+ * sort / scan kernels (one rank, no shared intrinsics blocks; TMI_BA_HOST_SETUP=1 disables) or on
+ * host threads otherwise.  out[0] = 1 when the device built it; the other slots are documented at
+ * the definition (engine.hip).  The two builders must agree array for array. */
+int32_t tmi_ba_solver_structure_checksums(tmi_ba_solver* solver, uint64_t out[24]);
+
 /* Host-only: statistics of the static structure the engine would build for
  * rank `rank` of `world` (no GPU needed).  Used by the CPU tests of the track
  * sharding: out[0] tracks owned, out[1] observations owned, out[2] reduced

@@ -28,6 +28,7 @@
 #include "inner_kernels.h"
 #include "two_view_kernels.h"
 #include "select_kernels.h"
+#include "structure_gpu.h"
 #include <hipcub/hipcub.hpp>
 #include "structure.h"
 
@@ -319,6 +320,11 @@ struct tmi_ba_solver {
   unsigned long long* d_vt_keys = nullptr;  // [No_pad] (view << 32 | track) sorted; static per handle
   long long* d_vt_ptr = nullptr;          // [Nc + 1]
   unsigned char* d_view_mask = nullptr;   // [Nc]
+  // device-built structure (structure_gpu.h): the big layout arrays exist in HBM only; host copies
+  // are fetched on demand (inner iterations, tmi_ba_solver_evaluate)
+  bool device_structure = false;
+  long long* d_obs_orig = nullptr;        // [No_pad] caller's observation index or -1
+  int n_order_dev = 0, n_spc_dev = 0;
 };
 
 namespace {
@@ -471,6 +477,436 @@ void set_message(tmi_ba_summary* sum, const char* m) { snprintf(sum->message, si
 
 }  // namespace
 
+// ---- device-side structure build (structure_gpu.h) -------------------------------------------
+namespace {
+int bits_for(unsigned long long n) {  // bits needed to hold values 0 .. n - 1 (at least 1)
+  int b = 1;
+  while (b < 63 && (1ull << b) < n) ++b;
+  return b;
+}
+struct TempPool {
+  std::vector<void*> v;
+  ~TempPool() {
+    for (void* p : v) hipFree(p);
+  }
+  template <class T>
+  hipError_t get(T** p, size_t n) {
+    *p = nullptr;
+    const hipError_t e = hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T));
+    if (e == hipSuccess) v.push_back((void*)*p);
+    return e;
+  }
+};
+}  // namespace
+
+static bool device_setup_possible(const Structure& st, int world, int64_t No, bool want_pairs) {
+  if (getenv("TMI_BA_HOST_SETUP")) return false;
+  if (world != 1 || st.has_shared || st.Nc < 1 || st.Np_total < 1 || No < 1) return false;
+  if (No >= (int64_t)1 << 31) return false;
+  if (want_pairs && (int64_t)st.Nrb * st.Nrb > ((int64_t)1 << 26)) return false;
+  if (bits_for((unsigned)st.Nc) + bits_for((unsigned)st.Np_total) > 62) return false;
+  return true;
+}
+
+// s->st holds what build_blocks left (camera side); fills the rest of s->st that the host needs and
+// the static-structure pointers of s->v.  Orders match structure.cpp element for element.
+static int build_structure_device(tmi_ba_solver* s, const tmi_ba_problem* P, bool want_pairs) {
+  using namespace tmi::sg;
+  Structure& st = s->st;
+  DeviceView& v = s->v;
+  hipStream_t stream = s->stream;
+  const bool timing = getenv("TMI_BA_SETUP_TIMING") != nullptr;
+  double t_phase = now_s();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    hipStreamSynchronize(stream);
+    const double now = now_s();
+    fprintf(stderr, "[tmi_ba setup/device] %-24s %.3f s\n", what, now - t_phase);
+    t_phase = now;
+  };
+  const int64_t No = P->num_observations;
+  const int Np = st.Np_total, Nc = st.Nc, Nrb = st.Nrb;
+  TempPool tmp;
+  void* cub_tmp = nullptr;
+  size_t cub_cap = 0;
+  auto cub_reserve = [&](size_t bytes) -> int {
+    if (bytes <= cub_cap) return TMI_BA_OK;
+    if (cub_tmp) hipFree(cub_tmp);
+    cub_tmp = nullptr;
+    cub_cap = 0;
+    TMI_HIP(hipMalloc(&cub_tmp, bytes + 256));
+    cub_cap = bytes + 256;
+    return TMI_BA_OK;
+  };
+  struct CubFree {
+    void** p;
+    ~CubFree() {
+      if (*p) hipFree(*p);
+    }
+  } cub_free{&cub_tmp};
+  int rc;
+#define SG_SORT_PAIRS(kin, kout, vin, vout, n, bits)                                                        \
+  do {                                                                                                      \
+    size_t bytes_ = 0;                                                                                      \
+    TMI_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes_, kin, kout, vin, vout, (int)(n), 0, bits, stream)); \
+    if ((rc = cub_reserve(bytes_))) return rc;                                                              \
+    TMI_HIP(hipcub::DeviceRadixSort::SortPairs(cub_tmp, bytes_, kin, kout, vin, vout, (int)(n), 0, bits, stream)); \
+  } while (0)
+#define SG_EXCLUSIVE_SUM(in, out, n)                                                                        \
+  do {                                                                                                      \
+    size_t bytes_ = 0;                                                                                      \
+    TMI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes_, in, out, (int)(n), stream));                  \
+    if ((rc = cub_reserve(bytes_))) return rc;                                                              \
+    TMI_HIP(hipcub::DeviceScan::ExclusiveSum(cub_tmp, bytes_, in, out, (int)(n), stream));                  \
+  } while (0)
+  auto nb = [](long long n) { return dim3((unsigned)std::max<long long>((n + 255) / 256, 1)); };  // kernels bound-check
+
+  // ---- observations to the device, track lengths, argument check
+  int *d_ocam, *d_opt, *d_klen, *d_bad;
+  double* d_oxy;
+  TMI_HIP(tmp.get(&d_ocam, (size_t)No));
+  TMI_HIP(tmp.get(&d_opt, (size_t)No));
+  TMI_HIP(tmp.get(&d_oxy, (size_t)2 * No));
+  TMI_HIP(tmp.get(&d_klen, (size_t)Np + 1));
+  TMI_HIP(tmp.get(&d_bad, 1));
+  TMI_HIP(hipMemcpyAsync(d_ocam, P->obs_camera, (size_t)No * sizeof(int), hipMemcpyHostToDevice, stream));
+  TMI_HIP(hipMemcpyAsync(d_opt, P->obs_point, (size_t)No * sizeof(int), hipMemcpyHostToDevice, stream));
+  TMI_HIP(hipMemcpyAsync(d_oxy, P->obs_xy, (size_t)2 * No * sizeof(double), hipMemcpyHostToDevice, stream));
+  TMI_HIP(hipMemsetAsync(d_klen, 0, ((size_t)Np + 1) * sizeof(int), stream));
+  TMI_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), stream));
+  hipLaunchKernelGGL(hist_kernel, nb(No), dim3(256), 0, stream, d_ocam, d_opt, (long long)No, Nc, Np, d_klen, d_bad);
+  lap("upload + histogram");
+
+  // ---- observations sorted by (track, camera); duplicates
+  const int cam_bits = bits_for((unsigned)Nc), pt_bits = bits_for((unsigned)Np);
+  unsigned long long *d_ok_in, *d_ok_out;
+  unsigned *d_ov_in, *d_tobs;
+  TMI_HIP(tmp.get(&d_ok_in, (size_t)No));
+  TMI_HIP(tmp.get(&d_ok_out, (size_t)No));
+  TMI_HIP(tmp.get(&d_ov_in, (size_t)No));
+  TMI_HIP(tmp.get(&d_tobs, (size_t)No));
+  hipLaunchKernelGGL(obs_keys_kernel, nb(No), dim3(256), 0, stream, d_ocam, d_opt, (long long)No, cam_bits, d_ok_in, d_ov_in);
+  SG_SORT_PAIRS(d_ok_in, d_ok_out, d_ov_in, d_tobs, No, cam_bits + pt_bits);
+  hipLaunchKernelGGL(dup_check_kernel, nb(No), dim3(256), 0, stream, d_ok_out, (long long)No, d_bad);
+  // tptr = exclusive scan of the lengths (64-bit)
+  long long *d_klen64, *d_tptr;
+  TMI_HIP(tmp.get(&d_klen64, (size_t)Np + 1));
+  TMI_HIP(tmp.get(&d_tptr, (size_t)Np + 1));
+  hipLaunchKernelGGL(widen_kernel, nb(Np + 1), dim3(256), 0, stream, d_klen, Np + 1, d_klen64);
+  SG_EXCLUSIVE_SUM(d_klen64, d_tptr, Np + 1);
+  // ---- tracks by descending length (stable)
+  unsigned *d_tk_in, *d_tk_out;
+  int *d_tv_in, *d_order;
+  TMI_HIP(tmp.get(&d_tk_in, (size_t)Np));
+  TMI_HIP(tmp.get(&d_tk_out, (size_t)Np));
+  TMI_HIP(tmp.get(&d_tv_in, (size_t)Np));
+  TMI_HIP(tmp.get(&d_order, (size_t)Np));
+  hipLaunchKernelGGL(track_keys_kernel, nb(Np), dim3(256), 0, stream, d_klen, Np, d_tk_in, d_tv_in);
+  SG_SORT_PAIRS(d_tk_in, d_tk_out, d_tv_in, d_order, Np, 32);
+  std::vector<int> order((size_t)Np), klen((size_t)Np);
+  int bad = 0;
+  TMI_HIP(hipMemcpyAsync(order.data(), d_order, (size_t)Np * sizeof(int), hipMemcpyDeviceToHost, stream));
+  TMI_HIP(hipMemcpyAsync(klen.data(), d_klen, (size_t)Np * sizeof(int), hipMemcpyDeviceToHost, stream));
+  TMI_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, stream));
+  TMI_HIP(hipStreamSynchronize(stream));
+  lap("sorts (observations, tracks)");
+  if (bad == 1) {
+    s->error = "observation index out of range";
+    return TMI_BA_ERR_INVALID_ARGUMENT;
+  }
+  if (bad == 2) {
+    s->error = "a track is observed twice by the same view";
+    return TMI_BA_ERR_INVALID_ARGUMENT;
+  }
+  // ---- host: slices (O(#tracks))
+  int n_active = 0;
+  while (n_active < Np && klen[order[n_active]] > 0) ++n_active;
+  st.unobserved.assign(order.begin() + n_active, order.end());  // ascending (stable sort)
+  st.nslices = (n_active + 63) / 64;
+  st.Np_pad = st.nslices * 64;
+  st.Np = n_active;
+  st.pt_orig.assign(st.Np_pad, -1);
+  st.pt_k.assign(st.Np_pad, 0);
+  st.pt_const.assign(st.Np_pad, 0);
+  st.slice_ptr.assign(st.nslices + 1, 0);
+  for (int lp = 0; lp < n_active; ++lp) {
+    const int p = order[lp];
+    st.pt_orig[lp] = p;
+    st.pt_k[lp] = klen[p];
+    st.pt_const[lp] = (P->point_constant && P->point_constant[p]) ? 1 : 0;
+  }
+  for (int sl = 0; sl < st.nslices; ++sl) {
+    const int K = st.pt_k[sl * 64];  // sorted by descending length: the slice's first track is its longest
+    const int64_t next = (int64_t)st.slice_ptr[sl] + (int64_t)K * 64;
+    if (next > 0x7fffffff) {
+      s->error = "too many observations on one rank for 32-bit slot indices";
+      return TMI_BA_ERR_UNSUPPORTED;
+    }
+    st.slice_ptr[sl + 1] = (int)next;
+  }
+  st.n_wide = 0;
+  {
+    int wide_k = st.nslices >= 5000 ? kWideKLarge : kWideK;
+    if (const char* e = getenv("TMI_BA_WIDE_K")) wide_k = std::max(1, atoi(e));
+    while (st.n_wide < st.nslices && ((st.slice_ptr[st.n_wide + 1] - st.slice_ptr[st.n_wide]) >> 6) >= wide_k) ++st.n_wide;
+  }
+  st.No_pad = st.slice_ptr[st.nslices];
+  st.No = No;
+  const int64_t Npad = st.No_pad;
+  {
+    int* pi;
+    unsigned char* pc;
+    if ((rc = dev_upload(s, &pi, st.slice_ptr))) return rc;
+    v.slice_ptr = pi;
+    if ((rc = dev_upload(s, &pi, st.pt_orig))) return rc;
+    s->d_pt_orig = pi;
+    if ((rc = dev_upload(s, &pi, st.pt_k))) return rc;
+    v.pt_k = pi;
+    if ((rc = dev_upload(s, &pc, st.pt_const))) return rc;
+    v.pt_const = pc;
+  }
+  // ---- layout + slots
+  int *d_obs_cam, *d_obs_cpos, *d_cam_rb, *d_cam_ptr;
+  double* d_obs_xy;
+  if ((rc = dev_alloc(s, &d_obs_cam, (size_t)Npad))) return rc;
+  if ((rc = dev_alloc(s, &d_obs_xy, (size_t)2 * Npad))) return rc;
+  if ((rc = dev_alloc(s, &d_obs_cpos, (size_t)Npad))) return rc;
+  if ((rc = dev_alloc(s, &s->d_obs_orig, (size_t)Npad))) return rc;
+  if ((rc = dev_alloc(s, &d_cam_ptr, (size_t)Nrb + 2))) return rc;
+  TMI_HIP(tmp.get(&d_cam_rb, (size_t)Nc));
+  TMI_HIP(hipMemcpyAsync(d_cam_rb, st.cam_rb.data(), (size_t)Nc * sizeof(int), hipMemcpyHostToDevice, stream));
+  TMI_HIP(hipMemsetAsync(d_obs_cam, 0xff, (size_t)std::max<int64_t>(Npad, 1) * sizeof(int), stream));
+  TMI_HIP(hipMemsetAsync(d_obs_xy, 0, (size_t)std::max<int64_t>(2 * Npad, 1) * sizeof(double), stream));
+  TMI_HIP(hipMemsetAsync(d_obs_cpos, 0xff, (size_t)std::max<int64_t>(Npad, 1) * sizeof(int), stream));
+  TMI_HIP(hipMemsetAsync(s->d_obs_orig, 0xff, (size_t)std::max<int64_t>(Npad, 1) * sizeof(long long), stream));
+  long long *d_ptk64, *d_tstart;
+  TMI_HIP(tmp.get(&d_ptk64, (size_t)st.Np_pad + 1));
+  TMI_HIP(tmp.get(&d_tstart, (size_t)st.Np_pad + 1));
+  TMI_HIP(hipMemsetAsync(d_ptk64, 0, ((size_t)st.Np_pad + 1) * sizeof(long long), stream));
+  hipLaunchKernelGGL(widen_kernel, nb(st.Np_pad), dim3(256), 0, stream, v.pt_k, st.Np_pad, d_ptk64);
+  SG_EXCLUSIVE_SUM(d_ptk64, d_tstart, st.Np_pad + 1);
+  unsigned *d_sk_in, *d_sk_out, *d_se_in, *d_se_out;
+  TMI_HIP(tmp.get(&d_sk_in, (size_t)No));
+  TMI_HIP(tmp.get(&d_sk_out, (size_t)No));
+  TMI_HIP(tmp.get(&d_se_in, (size_t)No));
+  TMI_HIP(tmp.get(&d_se_out, (size_t)No));
+  hipLaunchKernelGGL(layout_kernel, nb(st.Np_pad), dim3(256), 0, stream, st.Np_pad, s->d_pt_orig, v.pt_k, v.slice_ptr,
+                     d_tptr, d_tobs, d_ocam, d_oxy, d_cam_rb, Nrb, d_tstart, d_obs_cam, d_obs_xy, s->d_obs_orig,
+                     d_sk_in, d_se_in);
+  SG_SORT_PAIRS(d_sk_in, d_sk_out, d_se_in, d_se_out, No, bits_for((unsigned)Nrb + 1));
+  hipLaunchKernelGGL(slot_assign_kernel, nb(No), dim3(256), 0, stream, d_sk_out, d_se_out, (long long)No, Nrb, d_obs_cpos);
+  hipLaunchKernelGGL((lower_bound_kernel<unsigned, int>), nb(Nrb + 1), dim3(256), 0, stream, d_sk_out, (long long)No,
+                     (long long)Nrb, d_cam_ptr);
+  int nslots = 0;
+  TMI_HIP(hipMemcpyAsync(&nslots, d_cam_ptr + Nrb, sizeof(int), hipMemcpyDeviceToHost, stream));
+  TMI_HIP(hipStreamSynchronize(stream));
+  st.Nslots = nslots;
+  v.obs_cam = d_obs_cam;
+  v.obs_xy = d_obs_xy;
+  v.obs_cpos = d_obs_cpos;
+  v.cam_ptr = d_cam_ptr;
+  lap("layout + slots");
+
+  st.nub = 0;
+  st.npairs = 0;
+  st.nnzb = st.Nrb;
+  s->n_order_dev = 0;
+  s->n_spc_dev = 0;
+  int *d_urow_ptr, *d_ucol_ptr, *d_spc_rptr;
+  if ((rc = dev_alloc(s, &d_urow_ptr, (size_t)Nrb + 2))) return rc;
+  if ((rc = dev_alloc(s, &d_ucol_ptr, (size_t)Nrb + 2))) return rc;
+  if ((rc = dev_alloc(s, &d_spc_rptr, (size_t)Nrb + 2))) return rc;
+  TMI_HIP(hipMemsetAsync(d_urow_ptr, 0, ((size_t)Nrb + 2) * sizeof(int), stream));
+  TMI_HIP(hipMemsetAsync(d_ucol_ptr, 0, ((size_t)Nrb + 2) * sizeof(int), stream));
+  TMI_HIP(hipMemsetAsync(d_spc_rptr, 0, ((size_t)Nrb + 2) * sizeof(int), stream));
+  v.urow_ptr = d_urow_ptr;
+  v.ucol_ptr = d_ucol_ptr;
+  v.spc_rptr = d_spc_rptr;
+  {
+    // placeholders; replaced below when the pair structure is built
+    int* pi;
+    long long* pl;
+    if ((rc = dev_alloc(s, &pi, 1))) return rc;
+    v.ub_i = v.ub_j = v.ucol_u = v.spc_row = v.spc_u0 = v.pair_i = v.pair_j = v.ub_order = pi;
+    if ((rc = dev_alloc(s, &pl, 2))) return rc;
+    TMI_HIP(hipMemsetAsync(pl, 0, 2 * sizeof(long long), stream));
+    v.pair_ptr = pl;
+  }
+  if (!want_pairs || Nrb == 0) return TMI_BA_OK;
+
+  // ---- block set of S: dense presence map -> sorted upper list
+  const long long n2 = (long long)Nrb * Nrb;
+  unsigned char* d_present;
+  int *d_pres_i, *d_pos, *d_blk_id;
+  TMI_HIP(tmp.get(&d_present, (size_t)n2));
+  TMI_HIP(tmp.get(&d_pres_i, (size_t)n2 + 1));
+  TMI_HIP(tmp.get(&d_pos, (size_t)n2 + 1));
+  TMI_HIP(tmp.get(&d_blk_id, (size_t)n2));
+  TMI_HIP(hipMemsetAsync(d_present, 0, (size_t)n2, stream));
+  TMI_HIP(hipMemsetAsync(d_pres_i, 0, ((size_t)n2 + 1) * sizeof(int), stream));
+  int n_long = 0;  // tracks are sorted by descending length
+  while (n_long < st.Np_pad && st.pt_k[n_long] >= kLongK) ++n_long;
+  if (n_long > 0)
+    hipLaunchKernelGGL(block_flags_kernel<64>, dim3((n_long + 3) / 4), dim3(256), 0, stream, 0, n_long, v.pt_k, v.pt_const,
+                       v.slice_ptr, d_obs_cam, d_cam_rb, Nrb, d_present);
+  if (st.Np_pad > n_long)
+    hipLaunchKernelGGL(block_flags_kernel<1>, nb(st.Np_pad - n_long), dim3(256), 0, stream, n_long, st.Np_pad, v.pt_k,
+                       v.pt_const, v.slice_ptr, d_obs_cam, d_cam_rb, Nrb, d_present);
+  hipLaunchKernelGGL(flags_to_int_kernel, nb(n2), dim3(256), 0, stream, d_present, n2, d_pres_i);
+  SG_EXCLUSIVE_SUM(d_pres_i, d_pos, n2 + 1);
+  int nub = 0;
+  TMI_HIP(hipMemcpyAsync(&nub, d_pos + n2, sizeof(int), hipMemcpyDeviceToHost, stream));
+  TMI_HIP(hipStreamSynchronize(stream));
+  st.nub = nub;
+  st.nnzb = 2 * (int64_t)nub + Nrb;
+  int *d_ub_i, *d_ub_j;
+  if ((rc = dev_alloc(s, &d_ub_i, (size_t)nub))) return rc;
+  if ((rc = dev_alloc(s, &d_ub_j, (size_t)nub))) return rc;
+  hipLaunchKernelGGL(block_list_kernel, nb(n2), dim3(256), 0, stream, d_present, d_pos, Nrb, d_ub_i, d_ub_j, d_blk_id);
+  v.ub_i = d_ub_i;
+  v.ub_j = d_ub_j;
+  lap("block set of S");
+
+  // ---- pair lists
+  long long *d_pcnt, *d_poff;
+  TMI_HIP(tmp.get(&d_pcnt, (size_t)st.Np_pad + 1));
+  TMI_HIP(tmp.get(&d_poff, (size_t)st.Np_pad + 1));
+  TMI_HIP(hipMemsetAsync(d_pcnt, 0, ((size_t)st.Np_pad + 1) * sizeof(long long), stream));
+  hipLaunchKernelGGL(pair_count_kernel, nb(st.Np_pad), dim3(256), 0, stream, st.Np_pad, v.pt_k, v.pt_const, v.slice_ptr,
+                     d_obs_cpos, d_pcnt);
+  SG_EXCLUSIVE_SUM(d_pcnt, d_poff, st.Np_pad + 1);
+  long long npairs = 0;
+  TMI_HIP(hipMemcpyAsync(&npairs, d_poff + st.Np_pad, sizeof(long long), hipMemcpyDeviceToHost, stream));
+  TMI_HIP(hipStreamSynchronize(stream));
+  if (npairs >= ((long long)1 << 31)) {
+    s->error = "too many observation pairs for the device-side structure build";
+    return TMI_BA_ERR_UNSUPPORTED;
+  }
+  st.npairs = npairs;
+  long long* d_pair_ptr;
+  int *d_pair_i, *d_pair_j;
+  if ((rc = dev_alloc(s, &d_pair_ptr, (size_t)nub + 2))) return rc;
+  if ((rc = dev_alloc(s, &d_pair_i, (size_t)npairs))) return rc;
+  if ((rc = dev_alloc(s, &d_pair_j, (size_t)npairs))) return rc;
+  {
+    TempPool ptmp;  // the pair staging arrays are the largest temporaries: release them early
+    unsigned *d_uk_in, *d_uk_out;
+    unsigned long long *d_pv_in, *d_pv_out;
+    TMI_HIP(ptmp.get(&d_uk_in, (size_t)npairs));
+    TMI_HIP(ptmp.get(&d_uk_out, (size_t)npairs));
+    TMI_HIP(ptmp.get(&d_pv_in, (size_t)npairs));
+    TMI_HIP(ptmp.get(&d_pv_out, (size_t)npairs));
+    if (n_long > 0)
+      hipLaunchKernelGGL(pair_emit_kernel<64>, dim3((n_long + 3) / 4), dim3(256), 0, stream, 0, n_long, v.pt_k, v.pt_const,
+                         v.slice_ptr, d_obs_cam, d_cam_rb, d_obs_cpos, d_blk_id, Nrb, d_poff, d_uk_in, d_pv_in);
+    if (st.Np_pad > n_long)
+      hipLaunchKernelGGL(pair_emit_kernel<1>, nb(st.Np_pad - n_long), dim3(256), 0, stream, n_long, st.Np_pad, v.pt_k,
+                         v.pt_const, v.slice_ptr, d_obs_cam, d_cam_rb, d_obs_cpos, d_blk_id, Nrb, d_poff, d_uk_in, d_pv_in);
+    if (npairs > 0) {
+      SG_SORT_PAIRS(d_uk_in, d_uk_out, d_pv_in, d_pv_out, npairs, bits_for((unsigned)std::max(nub, 1)));
+      hipLaunchKernelGGL(split_pairs_kernel, nb(npairs), dim3(256), 0, stream, d_pv_out, npairs, d_pair_i, d_pair_j);
+    }
+    hipLaunchKernelGGL((lower_bound_kernel<unsigned, long long>), nb(nub + 1), dim3(256), 0, stream, d_uk_out, npairs,
+                       (long long)nub, d_pair_ptr);
+    TMI_HIP(hipStreamSynchronize(stream));
+  }
+  v.pair_ptr = d_pair_ptr;
+  v.pair_i = d_pair_i;
+  v.pair_j = d_pair_j;
+  lap("pair lists");
+
+  // ---- row / column indices of the symmetric storage, SpMV chunks, launch order
+  hipLaunchKernelGGL((lower_bound_kernel<int, int>), nb(Nrb + 1), dim3(256), 0, stream, d_ub_i, (long long)nub,
+                     (long long)Nrb, d_urow_ptr);
+  {
+    unsigned *d_k_in, *d_k_out;
+    int *d_iota, *d_ucol_u;
+    TMI_HIP(tmp.get(&d_k_in, (size_t)nub));
+    TMI_HIP(tmp.get(&d_k_out, (size_t)nub));
+    TMI_HIP(tmp.get(&d_iota, (size_t)nub));
+    if ((rc = dev_alloc(s, &d_ucol_u, (size_t)nub))) return rc;
+    hipLaunchKernelGGL(iota_kernel, nb(nub), dim3(256), 0, stream, d_iota, nub);
+    if (nub > 0) {
+      TMI_HIP(hipMemcpyAsync(d_k_in, d_ub_j, (size_t)nub * sizeof(int), hipMemcpyDeviceToDevice, stream));
+      SG_SORT_PAIRS(d_k_in, d_k_out, d_iota, d_ucol_u, nub, bits_for((unsigned)Nrb));
+    }
+    hipLaunchKernelGGL((lower_bound_kernel<unsigned, int>), nb(Nrb + 1), dim3(256), 0, stream, d_k_out, (long long)nub,
+                       (long long)Nrb, d_ucol_ptr);
+    v.ucol_u = d_ucol_u;
+    // chunks
+    const int chunk = kSpmvTrips * (64 / std::max(st.D, 1));
+    int* d_cnt;
+    TMI_HIP(tmp.get(&d_cnt, (size_t)Nrb + 1));
+    TMI_HIP(hipMemsetAsync(d_cnt, 0, ((size_t)Nrb + 1) * sizeof(int), stream));
+    hipLaunchKernelGGL(spc_count_kernel, nb(Nrb), dim3(256), 0, stream, d_urow_ptr, Nrb, chunk, d_cnt);
+    SG_EXCLUSIVE_SUM(d_cnt, d_spc_rptr, Nrb + 1);
+    int n_spc = 0;
+    TMI_HIP(hipMemcpyAsync(&n_spc, d_spc_rptr + Nrb, sizeof(int), hipMemcpyDeviceToHost, stream));
+    TMI_HIP(hipStreamSynchronize(stream));
+    int *d_spc_row, *d_spc_u0;
+    if ((rc = dev_alloc(s, &d_spc_row, (size_t)n_spc))) return rc;
+    if ((rc = dev_alloc(s, &d_spc_u0, (size_t)n_spc))) return rc;
+    hipLaunchKernelGGL(spc_fill_kernel, nb(Nrb), dim3(256), 0, stream, d_urow_ptr, d_spc_rptr, Nrb, chunk, d_spc_row, d_spc_u0);
+    v.spc_row = d_spc_row;
+    v.spc_u0 = d_spc_u0;
+    s->n_spc_dev = n_spc;
+    // launch order: (row & 7, row, pair count descending, block index)
+    unsigned *d_k1_in, *d_k1_out, *d_k2_in, *d_k2_out;
+    int *d_u1, *d_u2;
+    long long* d_qstart;
+    TMI_HIP(tmp.get(&d_k1_in, (size_t)nub));
+    TMI_HIP(tmp.get(&d_k1_out, (size_t)nub));
+    TMI_HIP(tmp.get(&d_k2_in, (size_t)nub));
+    TMI_HIP(tmp.get(&d_k2_out, (size_t)nub));
+    TMI_HIP(tmp.get(&d_u1, (size_t)nub));
+    TMI_HIP(tmp.get(&d_u2, (size_t)nub));
+    TMI_HIP(tmp.get(&d_qstart, 16));
+    if (nub > 0) {
+      hipLaunchKernelGGL(order_key1_kernel, nb(nub), dim3(256), 0, stream, d_pair_ptr, nub, d_k1_in);
+      SG_SORT_PAIRS(d_k1_in, d_k1_out, d_iota, d_u1, nub, 32);
+      hipLaunchKernelGGL(order_key2_kernel, nb(nub), dim3(256), 0, stream, d_u1, d_ub_i, nub, d_k2_in);
+      SG_SORT_PAIRS(d_k2_in, d_k2_out, d_u1, d_u2, nub, 27);
+    }
+    hipLaunchKernelGGL(queue_start_kernel, dim3(1), dim3(64), 0, stream, d_k2_out, (long long)nub, d_qstart);
+    long long qstart[9];
+    TMI_HIP(hipMemcpyAsync(qstart, d_qstart, sizeof(qstart), hipMemcpyDeviceToHost, stream));
+    TMI_HIP(hipStreamSynchronize(stream));
+    long long longest = 0;
+    for (int x = 0; x < 8; ++x) longest = std::max(longest, qstart[x + 1] - qstart[x]);
+    const long long groups = (longest + 15) / 16;
+    const long long n_order = groups * 8 * 16;
+    int4* d_hdr;
+    if ((rc = dev_alloc(s, &d_hdr, (size_t)std::max<long long>(n_order, 1)))) return rc;
+    TMI_HIP(hipMemsetAsync(d_hdr, 0xff, (size_t)std::max<long long>(n_order, 1) * sizeof(int4), stream));
+    if (nub > 0)
+      hipLaunchKernelGGL(order_fill_kernel, nb(nub), dim3(256), 0, stream, d_u2, d_k2_out, nub, d_qstart, d_pair_ptr, d_hdr);
+    v.ub_order = reinterpret_cast<const int*>(d_hdr);
+    s->n_order_dev = (int)n_order;
+  }
+  TMI_HIP(hipStreamSynchronize(stream));
+  lap("indices, chunks, launch order");
+#undef SG_SORT_PAIRS
+#undef SG_EXCLUSIVE_SUM
+  return TMI_BA_OK;
+}
+
+// host copies of the layout arrays of a device-built structure, for the few host consumers
+static int materialize_host_layout(tmi_ba_solver* s) {
+  Structure& st = s->st;
+  if (!s->device_structure || !st.obs_cam.empty() || st.No_pad == 0) return TMI_BA_OK;
+  st.obs_cam.resize((size_t)st.No_pad);
+  st.obs_cpos.resize((size_t)st.No_pad);
+  st.obs_orig.resize((size_t)st.No_pad);
+  st.obs_xy.resize((size_t)2 * st.No_pad);
+  std::vector<long long> oo((size_t)st.No_pad);
+  TMI_HIP(hipMemcpy(st.obs_cam.data(), s->v.obs_cam, (size_t)st.No_pad * sizeof(int), hipMemcpyDeviceToHost));
+  TMI_HIP(hipMemcpy(st.obs_cpos.data(), s->v.obs_cpos, (size_t)st.No_pad * sizeof(int), hipMemcpyDeviceToHost));
+  TMI_HIP(hipMemcpy(st.obs_xy.data(), s->v.obs_xy, (size_t)2 * st.No_pad * sizeof(double), hipMemcpyDeviceToHost));
+  TMI_HIP(hipMemcpy(oo.data(), s->d_obs_orig, (size_t)st.No_pad * sizeof(long long), hipMemcpyDeviceToHost));
+  for (int64_t e = 0; e < st.No_pad; ++e) st.obs_orig[e] = oo[e];
+  return TMI_BA_OK;
+}
+
 // ---- C ABI -------------------------------------------------------------------------
 extern "C" {
 
@@ -620,19 +1056,37 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   // implicit needs an iterative solver; auto = explicit on one GPU, implicit on several
   s->implicit = iterative_type && (O->schur_mode == 2 || (O->schur_mode == 0 && world > 1));
   if (light) s->implicit = false;
-  int rc = build_structure(P, rank, world, &s->st, !s->implicit && !light);
+  TMI_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  const bool want_pairs = !s->implicit && !light;
+  const bool setup_timing = getenv("TMI_BA_SETUP_TIMING") != nullptr;
+  // the camera side on the host (tiny), then the observation-sized structure on the device when the
+  // problem shape allows it (structure_gpu.h), else on host threads (structure.cpp)
+  int rc = build_blocks(P, rank, world, &s->st);
   if (rc) {
     s->error = s->st.error;
     return rc;
   }
+  if (device_setup_possible(s->st, world, P->num_observations, want_pairs)) {
+    s->device_structure = true;
+    memset(&s->v, 0, sizeof(s->v));
+    rc = build_structure_device(s, P, want_pairs);
+    if (rc) return rc;
+  } else {
+    s->st = Structure();
+    rc = build_structure(P, rank, world, &s->st, want_pairs);
+    if (rc) {
+      s->error = s->st.error;
+      return rc;
+    }
+  }
   Structure& st = s->st;
-  const bool setup_timing = getenv("TMI_BA_SETUP_TIMING") != nullptr;
-  if (setup_timing) fprintf(stderr, "[tmi_ba setup] %-28s %.3f s\n", "build_structure total", now_s() - t0);
+  if (setup_timing)
+    fprintf(stderr, "[tmi_ba setup] %-28s %.3f s (%s)\n", "structure total", now_s() - t0,
+            s->device_structure ? "device" : "host");
   if (!get_launch(st.D, s->DP, st.has_shared, O->residual_precision == 32, &s->launch)) {
     s->error = "no kernel instantiation for this block size";
     return TMI_BA_ERR_UNSUPPORTED;
   }
-  TMI_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   // two slots: pcg_step of iteration `it` publishes into slot it & 1, so that the speculatively
   // launched next iteration can never overwrite scalars the host is still reading; every other
   // read-back uses slot 0
@@ -645,13 +1099,14 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
 
   const int D = st.D, DP = s->DP;
   DeviceView& v = s->v;
+  const DeviceView built = s->v;  // pointers of a device-built structure (all null otherwise)
   memset(&v, 0, sizeof(v));
   v.Nc = st.Nc; v.G = st.G; v.Np_pad = st.Np_pad; v.nslices = st.nslices; v.Nrb = st.Nrb;
   v.Ncam_rb = st.Ncam_rb; v.has_shared = st.has_shared ? 1 : 0;
   v.D = D; v.DP = DP; v.No_pad = (int)st.No_pad; v.Nslots = (int)st.Nslots;
   v.nub = (int)st.nub; v.nnzb = (int)st.nnzb; v.npairs = st.npairs;
-  v.n_order = (int)st.ub_order.size();
-  v.n_spc = (int)st.spc_row.size();
+  v.n_order = s->device_structure ? s->n_order_dev : (int)st.ub_order.size();
+  v.n_spc = s->device_structure ? s->n_spc_dev : (int)st.spc_row.size();
   s->RL = red_layout(st.nub, st.Nrb, D);
   s->n_intr = st.G ? P->group_offset[st.G] : 0;
 
@@ -692,11 +1147,22 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   {
     int* p; unsigned* pu; unsigned char* pc; signed char* ps; long long* pl; double* pd;
 #define UPI(dst, vec) if ((rc = dev_upload(s, &p, vec))) return rc; dst = p;
-    UPI(v.slice_ptr, st.slice_ptr) UPI(v.pt_k, st.pt_k) UPI(v.obs_cam, st.obs_cam)
-    UPI(v.obs_cpos, st.obs_cpos) UPI(v.cam_grp, cam_grp) UPI(v.cam_rb, st.cam_rb)
+    // camera-side arrays (small, built on the host in both paths)
+    UPI(v.cam_grp, cam_grp) UPI(v.cam_rb, st.cam_rb)
     UPI(v.grp_model, grp_model) UPI(v.grp_off, grp_off) UPI(v.rb_cam, st.rb_cam) UPI(v.rb_grp, st.rb_grp)
-    UPI(v.cam_grb, st.cam_grb) UPI(v.obs_gslot, st.obs_gslot) UPI(v.cam_cross_u, st.cam_cross_u)
+    UPI(v.cam_grb, st.cam_grb) UPI(v.cam_cross_u, st.cam_cross_u)
     UPI(v.grp_cam_ptr, st.grp_cam_ptr) UPI(v.grp_cams, st.grp_cams)
+    if (s->device_structure) {
+      // observation-sized arrays were built in HBM (structure_gpu.h)
+      v.slice_ptr = built.slice_ptr; v.pt_k = built.pt_k; v.pt_const = built.pt_const;
+      v.obs_cam = built.obs_cam; v.obs_xy = built.obs_xy; v.obs_cpos = built.obs_cpos; v.cam_ptr = built.cam_ptr;
+      v.urow_ptr = built.urow_ptr; v.ub_i = built.ub_i; v.ub_j = built.ub_j; v.ucol_ptr = built.ucol_ptr;
+      v.ucol_u = built.ucol_u; v.spc_row = built.spc_row; v.spc_u0 = built.spc_u0; v.spc_rptr = built.spc_rptr;
+      v.pair_ptr = built.pair_ptr; v.pair_i = built.pair_i; v.pair_j = built.pair_j; v.ub_order = built.ub_order;
+      UPI(v.obs_gslot, st.obs_gslot)  // empty (no shared intrinsics blocks on this path)
+    } else {
+    UPI(v.slice_ptr, st.slice_ptr) UPI(v.pt_k, st.pt_k) UPI(v.obs_cam, st.obs_cam)
+    UPI(v.obs_cpos, st.obs_cpos) UPI(v.obs_gslot, st.obs_gslot)
     UPI(v.cam_ptr, st.cam_ptr) UPI(v.urow_ptr, st.urow_ptr) UPI(v.ub_i, st.ub_i) UPI(v.ub_j, st.ub_j)
     UPI(v.ucol_ptr, st.ucol_ptr) UPI(v.ucol_u, st.ucol_u)
     UPI(v.spc_row, st.spc_row) UPI(v.spc_u0, st.spc_u0) UPI(v.spc_rptr, st.spc_rptr)
@@ -715,6 +1181,7 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
       }
       UPI(v.ub_order, hdr)
     }
+    }
 #undef UPI
     if ((rc = dev_upload(s, &pu, st.cam_mask))) return rc; v.cam_mask = pu;
     {
@@ -729,11 +1196,13 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
     }
     if ((rc = dev_upload(s, &pu, st.grp_mask))) return rc; v.grp_mask = pu;
     if ((rc = dev_upload(s, &pc, st.obs_gflag))) return rc; v.obs_gflag = pc;
-    if ((rc = dev_upload(s, &pc, st.pt_const))) return rc; v.pt_const = pc;
     if ((rc = dev_upload(s, &ps, rb_cols))) return rc; v.rb_cols = ps;
-    if ((rc = dev_upload(s, &pl, pair_ptr))) return rc; v.pair_ptr = pl;
-    if ((rc = dev_upload(s, &pd, st.obs_xy))) return rc; v.obs_xy = pd;
-    if ((rc = dev_upload(s, &p, st.pt_orig))) return rc; s->d_pt_orig = p;
+    if (!s->device_structure) {
+      if ((rc = dev_upload(s, &pc, st.pt_const))) return rc; v.pt_const = pc;
+      if ((rc = dev_upload(s, &pl, pair_ptr))) return rc; v.pair_ptr = pl;
+      if ((rc = dev_upload(s, &pd, st.obs_xy))) return rc; v.obs_xy = pd;
+      if ((rc = dev_upload(s, &p, st.pt_orig))) return rc; s->d_pt_orig = p;
+    }
   }
 #undef UP
   const size_t N = (size_t)st.No_pad, NP = (size_t)st.Np_pad;
@@ -761,7 +1230,7 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   AL(v.prep, (size_t)std::max(st.Nc, 1) * kPrepStride) AL(v.prep_c, (size_t)std::max(st.Nc, 1) * kPrepStride)
   AL(v.Vinv, NP * NS) AL(v.gp, NP * DP) AL(v.diag_p, NP * DP) AL(v.yp, NP * DP)
   AL(v.red, s->RL.total) AL(v.Sdiag, (size_t)std::max(st.Nrb, 1) * D * D)
-  AL(v.tbuf, (size_t)std::max<int64_t>(st.nub, 1) * D) AL(v.rbuf, (size_t)std::max<size_t>(st.spc_row.size(), 1) * D) AL(v.Minv, (size_t)std::max(st.Nrb, 1) * D * D)
+  AL(v.tbuf, (size_t)std::max<int64_t>(st.nub, 1) * D) AL(v.rbuf, (size_t)std::max(v.n_spc, 1) * D) AL(v.Minv, (size_t)std::max(st.Nrb, 1) * D * D)
   AL(v.rhs, std::max(n_r, 1)) AL(v.yc, std::max(n_r, 1)) AL(v.cg_r, std::max(n_r, 1))
   AL(v.cg_z, std::max(n_r, 1)) AL(v.cg_p, std::max(n_r, 1)) AL(v.cg_q, n_r + 8)
   AL(v.dotbuf, st.Nrb + 8) AL(v.ticket, 4 * kTicketStride) AL(v.pcg_done, 1)
@@ -1094,8 +1563,9 @@ static int ensure_track_outputs(tmi_ba_solver* s);
 static int ensure_inner(tmi_ba_solver* s) {
   tmi_ba_solver::InnerCtx& I = s->inner;
   if (I.ready) return TMI_BA_OK;
-  const Structure& st = s->st;
   int rc;
+  if ((rc = materialize_host_layout(s))) return rc;
+  const Structure& st = s->st;
   // view-major observation index from the track-major layout
   std::vector<int> vo_ptr((size_t)st.Nc + 2, 0), vo_e((size_t)st.No), vo_lp((size_t)st.No);
   for (int64_t e = 0; e < st.No_pad; ++e)
@@ -2255,11 +2725,56 @@ int32_t tmi_ba_structure_stats(const tmi_ba_problem* P, int32_t rank, int32_t wo
   return TMI_BA_OK;
 }
 
+// Test hook: FNV-1a checksums of the static structure as it sits in HBM (whoever built it), so
+// that the device builder can be compared with the host builder array for array.
+//   out[0] setup path (1 device, 0 host), [1] slice_ptr, [2] pt_k, [3] pt_const, [4] obs_cam,
+//   [5] obs_xy, [6] obs_cpos, [7] cam_ptr, [8] ub_i, [9] ub_j, [10] urow_ptr, [11] ucol_ptr,
+//   [12] ucol_u, [13] spc_row, [14] spc_u0, [15] spc_rptr, [16] pair_ptr, [17] pair_i, [18] pair_j,
+//   [19] launch headers, [20] pt_orig, [21] n_order, [22] n_spc, [23] Nslots
+int32_t tmi_ba_solver_structure_checksums(tmi_ba_solver* s, uint64_t out[24]) {
+  if (!s || !out) return TMI_BA_ERR_INVALID_ARGUMENT;
+  TMI_HIP(hipSetDevice(s->device));
+  TMI_HIP(hipStreamSynchronize(s->stream));
+  const Structure& st = s->st;
+  const DeviceView& v = s->v;
+  auto sum = [&](const void* dev, size_t bytes, uint64_t* dst) -> int {
+    std::vector<unsigned char> h(bytes);
+    if (bytes) TMI_HIP(hipMemcpy(h.data(), dev, bytes, hipMemcpyDeviceToHost));
+    uint64_t x = 1469598103934665603ULL;
+    for (unsigned char c : h) x = (x ^ c) * 1099511628211ULL;
+    *dst = x;
+    return TMI_BA_OK;
+  };
+  int rc;
+  memset(out, 0, 24 * sizeof(uint64_t));
+  out[0] = s->device_structure ? 1 : 0;
+  const size_t Npad = (size_t)st.Np_pad, Nop = (size_t)st.No_pad, Nrb = (size_t)st.Nrb, nub = (size_t)st.nub;
+#define CS(i, ptr, n, T) if ((rc = sum(ptr, (size_t)(n) * sizeof(T), &out[i]))) return rc;
+  CS(1, v.slice_ptr, st.nslices + 1, int) CS(2, v.pt_k, Npad, int) CS(3, v.pt_const, Npad, unsigned char)
+  CS(4, v.obs_cam, Nop, int) CS(5, v.obs_xy, 2 * Nop, double) CS(6, v.obs_cpos, Nop, int)
+  CS(7, v.cam_ptr, Nrb + 1, int) CS(20, s->d_pt_orig, Npad, int)
+  if (!s->light && !s->implicit) {
+    CS(8, v.ub_i, nub, int) CS(9, v.ub_j, nub, int) CS(10, v.urow_ptr, Nrb + 1, int) CS(11, v.ucol_ptr, Nrb + 1, int)
+    CS(12, v.ucol_u, nub, int) CS(13, v.spc_row, v.n_spc, int) CS(14, v.spc_u0, v.n_spc, int)
+    CS(15, v.spc_rptr, Nrb + 1, int) CS(16, v.pair_ptr, nub + 1, long long) CS(17, v.pair_i, st.npairs, int)
+    CS(18, v.pair_j, st.npairs, int) CS(19, v.ub_order, (size_t)v.n_order * 4, int)
+  }
+#undef CS
+  out[21] = (uint64_t)v.n_order;
+  out[22] = (uint64_t)v.n_spc;
+  out[23] = (uint64_t)st.Nslots;
+  return TMI_BA_OK;
+}
+
 int32_t tmi_ba_solver_evaluate(tmi_ba_solver* s, double* residuals, double* jac_camera,
                                double* jac_shared, double* jac_point, uint8_t* valid,
                                int32_t* block_dim) {
   if (!s || s->light) return TMI_BA_ERR_INVALID_ARGUMENT;
   TMI_HIP(hipSetDevice(s->device));
+  {
+    const int rcm = materialize_host_layout(s);
+    if (rcm) return rcm;
+  }
   DeviceView& v = s->v;
   Structure& st = s->st;
   const int D = st.D, DP = s->DP;

@@ -88,15 +88,10 @@ double wall_s() {
 }
 }  // namespace
 
-int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, bool want_pairs) {
-  const bool timing = std::getenv("TMI_BA_SETUP_TIMING") != nullptr;
-  double t_phase = wall_s();
-  auto lap = [&](const char* what) {
-    if (!timing) return;
-    const double now = wall_s();
-    fprintf(stderr, "[tmi_ba setup] %-28s %.3f s\n", what, now - t_phase);
-    t_phase = now;
-  };
+// The camera side of the structure: argument checks that do not touch the observations, the
+// reduced blocks and their column maps.  Shared by the host builder below and the device
+// builder (structure_gpu.h), which sorts and scans the observation-sized arrays in HBM.
+int build_blocks(const tmi_ba_problem* P, int rank, int world, Structure* S) {
   Structure& s = *S;
   if (!P || world < 1 || rank < 0 || rank >= world) {
     s.error = "null problem or bad rank/world";
@@ -115,7 +110,6 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, 
   s.Nc = P->num_cameras;
   s.G = P->num_groups;
   s.Np_total = P->num_points;
-  const int64_t No_all = P->num_observations;
   for (int c = 0; c < s.Nc; ++c)
     if (P->camera_group[c] < 0 || P->camera_group[c] >= s.G) {
       s.error = "camera_group out of range";
@@ -128,13 +122,6 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, 
       return TMI_BA_ERR_INVALID_ARGUMENT;
     }
   }
-  for (int64_t i = 0; i < No_all; ++i)
-    if (P->obs_camera[i] < 0 || P->obs_camera[i] >= s.Nc || P->obs_point[i] < 0 ||
-        P->obs_point[i] >= s.Np_total) {
-      s.error = "observation index out of range";
-      return TMI_BA_ERR_INVALID_ARGUMENT;
-    }
-
   // ---- reduced camera blocks --------------------------------------------------
   // A view whose intrinsics group is private gets ONE block [free extrinsics | free
   // intrinsics].  Free intrinsics SHARED by several views (one Ceres block per group,
@@ -202,6 +189,30 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, 
       if (m & (1u << b)) s.rb_cols[(size_t)rb * s.D + col++] = (int8_t)b;
   }
 
+  return TMI_BA_OK;
+}
+
+int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, bool want_pairs) {
+  const bool timing = std::getenv("TMI_BA_SETUP_TIMING") != nullptr;
+  double t_phase = wall_s();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    const double now = wall_s();
+    fprintf(stderr, "[tmi_ba setup] %-28s %.3f s\n", what, now - t_phase);
+    t_phase = now;
+  };
+  {
+    const int rc = build_blocks(P, rank, world, S);
+    if (rc) return rc;
+  }
+  Structure& s = *S;
+  const int64_t No_all = P->num_observations;
+  for (int64_t i = 0; i < No_all; ++i)
+    if (P->obs_camera[i] < 0 || P->obs_camera[i] >= s.Nc || P->obs_point[i] < 0 ||
+        P->obs_point[i] >= s.Np_total) {
+      s.error = "observation index out of range";
+      return TMI_BA_ERR_INVALID_ARGUMENT;
+    }
   lap("reduced blocks");
   // ---- tracks: lengths, order by descending length, shard ------------------------
   std::vector<int> klen(s.Np_total, 0);

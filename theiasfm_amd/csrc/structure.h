@@ -93,6 +93,9 @@ struct Structure {
   std::string error;
 };
 
+// Camera-side part only (argument checks, reduced blocks, column maps); used by both builders.
+int build_blocks(const tmi_ba_problem* P, int rank, int world, Structure* out);
+
 // Returns TMI_BA_OK or an error status (message in out->error).
 // want_pairs = false skips the block structure of S and the pair lists (implicit Schur
 // operator: S is never formed).

@@ -169,6 +169,9 @@ void BundleAdjuster::AddViews(const std::vector<ViewId>& view_ids) {
         if (track_estimated_.Get(kv.first) == 1) out.push_back(Residual{view_id, kv.first, kv.second.x(), kv.second.y()});
     }
   });
+  if (std::getenv("TMI_BA_SETUP_TIMING") != nullptr)
+    std::fprintf(stderr, "[tmi_ba shim] %-28s %.3f s\n", "AddViews: feature tables",
+                 std::chrono::duration<double>(std::chrono::steady_clock::now() - timer_start_).count());
   size_t total = residuals_.size();
   for (const auto& l : local) total += l.size();
   residuals_.reserve(total);
@@ -177,11 +180,19 @@ void BundleAdjuster::AddViews(const std::vector<ViewId>& view_ids) {
     for (const Residual& r : l) track_constant_.Set(r.track, 1);
     residuals_.insert(residuals_.end(), l.begin(), l.end());
   }
+  if (std::getenv("TMI_BA_SETUP_TIMING") != nullptr)
+    std::fprintf(stderr, "[tmi_ba shim] %-28s %.3f s\n", "AddViews: total",
+                 std::chrono::duration<double>(std::chrono::steady_clock::now() - timer_start_).count());
 }
 
 void BundleAdjuster::AddTracks(const std::vector<TrackId>& track_ids) {
+  const auto t0 = std::chrono::steady_clock::now();
   optimized_tracks_.reserve(optimized_tracks_.size() + track_ids.size());
   for (const TrackId t : track_ids) AddTrack(t);
+  if (std::getenv("TMI_BA_SETUP_TIMING") != nullptr)
+    std::fprintf(stderr, "[tmi_ba shim] %-28s %.3f s (since construction %.3f s)\n", "AddTracks",
+                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(),
+                 std::chrono::duration<double>(std::chrono::steady_clock::now() - timer_start_).count());
 }
 
 // bundle_adjuster.cc:223-240

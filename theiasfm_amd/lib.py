@@ -30,7 +30,7 @@ EXPORTS = (
     "tmi_ba_solver_filter_outlier_tracks", "tmi_ba_filter_outlier_tracks",
     "tmi_ba_solver_adjust_tracks", "tmi_ba_adjust_tracks",
     "tmi_ba_solver_select_good_tracks", "tmi_ba_select_good_tracks",
-    "tmi_ba_adjust_two_views",
+    "tmi_ba_adjust_two_views", "tmi_ba_solver_structure_checksums",
 )
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
@@ -113,6 +113,8 @@ def load():
     L.tmi_ba_adjust_two_views.argtypes = [C.POINTER(abi.CTwoViewBatch), C.c_int32, C.c_int32, C.c_int32,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, TS]
     L.tmi_ba_adjust_two_views.restype = C.c_int32
+    L.tmi_ba_solver_structure_checksums.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.tmi_ba_solver_structure_checksums.restype = C.c_int32
     SS = C.POINTER(abi.CSelectSummary)
     L.tmi_ba_solver_select_good_tracks.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, SS]
@@ -357,6 +359,14 @@ class Solver:
         if st != 0:
             raise EngineError(st, "tmi_ba_solver_adjust_tracks")
         return term, iters, c0, c1, ts
+
+    def structure_checksums(self):
+        """Test hook: [24] uint64 checksums of the static structure arrays in HBM ([0] = built on the device)."""
+        out = (C.c_uint64 * 24)()
+        st = self._L.tmi_ba_solver_structure_checksums(self._h, out)
+        if st != 0:
+            raise EngineError(st, "tmi_ba_solver_structure_checksums")
+        return list(out)
 
     @property
     def stream(self) -> int:
