@@ -90,7 +90,6 @@ class BundleAdjuster {
   std::chrono::steady_clock::time_point timer_start_;
 
   std::unordered_set<ViewId> optimized_views_;
-  std::unordered_set<TrackId> optimized_tracks_;
   std::unordered_set<CameraIntrinsicsGroupId> optimized_camera_intrinsics_groups_;
   std::unordered_set<CameraIntrinsicsGroupId> potentially_constant_camera_intrinsics_groups_;
 
@@ -138,6 +137,7 @@ class BundleAdjuster {
   IdState track_constant_;   // 1 constant / 0 variable for the tracks that take part
   IdState track_estimated_;  // memo of Track::IsEstimated for the tracks AddView met
   IdState view_optimized_;   // flat mirror of optimized_views_ (AddTrack tests it per observation)
+  IdState track_optimized_;  // the reference's optimized_tracks_ set (1 = AddTrack took the track)
   std::unordered_map<CameraIntrinsicsGroupId, std::vector<uint8_t> > intrinsics_constant_;
   tmi_ba_summary device_summary_;
 };

@@ -97,15 +97,31 @@ typedef enum tmi_ba_linear_solver {
   TMI_BA_CGNR = 6
 } tmi_ba_linear_solver;
 
-/* ceres::PreconditionerType (bundle_adjustment.h:87).  The device path has
- * SCHUR_JACOBI (block diagonal of the reduced camera matrix); JACOBI maps to
- * it, the cluster preconditioners are accepted and mapped to SCHUR_JACOBI.  */
+/* ceres::PreconditionerType (bundle_adjustment.h:87).  Substitutions made by the device
+ * path, all of them in the PRECONDITIONER only (the reduced system that PCG solves, its
+ * stopping rule and therefore the LM step it converges to are the same in every mode; what
+ * changes is the number of PCG iterations an LM step takes and the low-order bits of the
+ * truncated solve):
+ *   SCHUR_JACOBI (Theia's default): the inverse of the block diagonal of the reduced camera
+ *     matrix S with ONE block per view = [extrinsics | private intrinsics] merged (up to
+ *     16 x 16).  Ceres builds its block diagonal per PARAMETER block, i.e. a 6 x 6
+ *     extrinsics block and a separate N x N intrinsics block per view
+ *     (schur_jacobi_preconditioner.cc); the merged block keeps the extrinsics-intrinsics
+ *     coupling of a view, is a strictly stronger preconditioner and costs the same to apply.
+ *   SCHUR_JACOBI_PARAMETER_BLOCKS (extension value, not a ceres enumerator): exactly Ceres's
+ *     shape -- the cross terms between a view's extrinsics and intrinsics columns are dropped
+ *     before the inversion.  Meant for block-for-block comparisons of PCG trajectories with
+ *     real Ceres output (tests/test_ceres_golden.py); slower to converge than the default.
+ *   JACOBI maps to SCHUR_JACOBI; CLUSTER_JACOBI / CLUSTER_TRIDIAGONAL (visibility-clustered
+ *     preconditioners) are accepted and mapped to SCHUR_JACOBI as well.
+ *   Intrinsics shared by several views form their own reduced block in every mode.  */
 typedef enum tmi_ba_preconditioner {
   TMI_BA_PRECOND_IDENTITY = 0,
   TMI_BA_PRECOND_JACOBI = 1,
   TMI_BA_PRECOND_SCHUR_JACOBI = 2,
   TMI_BA_PRECOND_CLUSTER_JACOBI = 3,
-  TMI_BA_PRECOND_CLUSTER_TRIDIAGONAL = 4
+  TMI_BA_PRECOND_CLUSTER_TRIDIAGONAL = 4,
+  TMI_BA_PRECOND_SCHUR_JACOBI_PARAMETER_BLOCKS = 18
 } tmi_ba_preconditioner;
 
 /* OptimizeIntrinsicsType bit flags, reference: bundle_adjustment.h:65-76 */

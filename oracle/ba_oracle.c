@@ -453,6 +453,7 @@ typedef struct {
   /* reduced blocks */
   int nrb, nr;
   int *rb_dim, *rb_off;
+  int* rb_split; /* columns of a view's block that belong to the extrinsics parameter block */
   int *cam_rb, *grp_rb; /* -1 = none */
   /* observations sorted by point */
   int64_t* order;  /* sorted position -> caller index */
@@ -961,6 +962,14 @@ static int solve_pcg(ost* s) {
       double* M = Minv + (int64_t)b * MAXC * MAXC;
       for (int a = 0; a < nb * nb; ++a) M[a] = 0.0;
       for (int a = 0; a < nb; ++a) M[a * nb + a] = 1.0;
+    } else if (s->O->preconditioner_type == TMI_BA_PRECOND_SCHUR_JACOBI_PARAMETER_BLOCKS) {
+      /* ceres/schur_jacobi_preconditioner.cc: the block diagonal has one block per
+       * e-eliminated PARAMETER block, i.e. extrinsics and intrinsics of a view apart */
+      double T[MAXC * MAXC];
+      const int sp = s->rb_split[b];
+      for (int i = 0; i < nb; ++i)
+        for (int j = 0; j < nb; ++j) T[i * nb + j] = ((i < sp) != (j < sp)) ? 0.0 : B[i * nb + j];
+      if (!block_inverse(nb, T, Minv + (int64_t)b * MAXC * MAXC)) ok = 0;
     } else if (!block_inverse(nb, B, Minv + (int64_t)b * MAXC * MAXC)) {
       ok = 0;
     }
@@ -1140,7 +1149,7 @@ static double back_substitute(ost* s) {
 static void free_state(ost* s) {
   free(s->ext); free(s->intr); free(s->pts);
   free(s->n_ext); free(s->ext_idx); free(s->n_intr); free(s->intr_idx); free(s->grp_private);
-  free(s->rb_dim); free(s->rb_off); free(s->cam_rb); free(s->grp_rb);
+  free(s->rb_dim); free(s->rb_off); free(s->rb_split); free(s->cam_rb); free(s->grp_rb);
   free(s->order); free(s->pt_ptr);
   free(s->r); free(s->Jc); free(s->Jp); free(s->Ep);
   free(s->scale_c); free(s->scale_p); free(s->diag_c); free(s->diag_p);
@@ -1418,6 +1427,7 @@ int32_t oracle_ba_solve(tmi_ba_problem* P, const tmi_ba_options* O, tmi_ba_summa
   s->grp_rb = (int*)malloc(sizeof(int) * (size_t)(s->G + 1));
   s->rb_dim = (int*)malloc(sizeof(int) * (size_t)(s->Nc + s->G + 1));
   s->rb_off = (int*)malloc(sizeof(int) * (size_t)(s->Nc + s->G + 2));
+  s->rb_split = (int*)malloc(sizeof(int) * (size_t)(s->Nc + s->G + 1));
   s->nrb = 0;
   s->nr = 0;
   for (int c = 0; c < s->Nc; ++c) {
@@ -1426,6 +1436,7 @@ int32_t oracle_ba_solve(tmi_ba_problem* P, const tmi_ba_options* O, tmi_ba_summa
     if (d > 0) {
       s->cam_rb[c] = s->nrb;
       s->rb_dim[s->nrb] = d;
+      s->rb_split[s->nrb] = s->n_ext[c];
       s->rb_off[s->nrb] = s->nr;
       s->nr += d;
       s->nrb++;
@@ -1437,6 +1448,7 @@ int32_t oracle_ba_solve(tmi_ba_problem* P, const tmi_ba_options* O, tmi_ba_summa
     if (!s->grp_private[g] && s->n_intr[g] > 0) {
       s->grp_rb[g] = s->nrb;
       s->rb_dim[s->nrb] = s->n_intr[g];
+      s->rb_split[s->nrb] = 0;
       s->rb_off[s->nrb] = s->nr;
       s->nr += s->n_intr[g];
       s->nrb++;

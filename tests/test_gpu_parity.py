@@ -142,6 +142,21 @@ def test_lm_matches_oracle_ladybug49(solver, mode):
     assert (dev[1].num_schur_pairs == 0) == (mode == abi.SCHUR_IMPLICIT)
 
 
+@pytest.mark.parametrize("mode", [abi.SCHUR_EXPLICIT, abi.SCHUR_IMPLICIT])
+def test_parameter_block_schur_jacobi_matches_oracle(mode):
+    # the Ceres-shaped preconditioner (schur_jacobi_preconditioner.cc: one 6x6 extrinsics and
+    # one NxN intrinsics block per view) against the oracle's, and against the merged default:
+    # same LM step up to the PCG truncation, more PCG iterations to get there
+    prob = synth.config("ladybug49")
+    opt = dict(linear_solver_type=abi.ITERATIVE_SCHUR, point_dof=3, schur_mode=mode)
+    dev, ora = run_both(prob, preconditioner_type=abi.PRECOND_SCHUR_JACOBI_PARAMETER_BLOCKS, **opt)
+    assert_same_solution(dev, ora, scale=100.0)
+    assert dev[1].num_linear_solver_iterations == ora[1].num_linear_solver_iterations
+    merged, _ = run_both(prob, **opt)
+    assert merged[1].num_linear_solver_iterations < dev[1].num_linear_solver_iterations
+    assert abs(merged[1].final_cost - dev[1].final_cost) <= 1e-4 * dev[1].final_cost
+
+
 def test_lm_matches_oracle_mixed_models_and_huber():
     prob = synth.make_problem(
         24, 1500, 9000, seed=33, scene="ring", spread=0.4,

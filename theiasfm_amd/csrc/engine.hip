@@ -142,8 +142,8 @@ Launch make_launch(bool fp32) {
       hipLaunchKernelGGL((finish_diag_kernel<D>), dim3((n2 + 255) / 256), dim3(256), 0, st, v, R, ir,
                          lo, hi, want_gmax);
   };
-  L.precond = [](const DeviceView& v, hipStream_t st, int identity) {
-    if (v.Nrb) hipLaunchKernelGGL((precond_invert_kernel<D>), dim3(v.Nrb), dim3(64), 0, st, v, identity);
+  L.precond = [](const DeviceView& v, hipStream_t st, int mode) {
+    if (v.Nrb) hipLaunchKernelGGL((precond_invert_kernel<D>), dim3(v.Nrb), dim3(64), 0, st, v, mode);
   };
   L.spmv = [](const DeviceView& v, hipStream_t st, const double* ub, const double* x, double* y, int dot, int spec) {
     if (!v.Nrb) return;
@@ -797,8 +797,18 @@ static int build_structure_device(tmi_ba_solver* s, const tmi_ba_problem* P, boo
     TMI_HIP(ptmp.get(&d_pv_in, (size_t)npairs));
     TMI_HIP(ptmp.get(&d_pv_out, (size_t)npairs));
     if (n_long > 0)
-      hipLaunchKernelGGL(pair_emit_kernel<64>, dim3((n_long + 3) / 4), dim3(256), 0, stream, 0, n_long, v.pt_k, v.pt_const,
-                         v.slice_ptr, d_obs_cam, d_cam_rb, d_obs_cpos, d_blk_id, Nrb, d_poff, d_uk_in, d_pv_in);
+    {
+      // tracks are sorted by descending length: [0, n_huge) do not fit the LDS-staged kernel
+      int n_huge = 0;
+      while (n_huge < n_long && st.pt_k[n_huge] > kEmitCap) ++n_huge;
+      if (n_huge > 0)
+        hipLaunchKernelGGL(pair_emit_kernel<64>, dim3((n_huge + 3) / 4), dim3(256), 0, stream, 0, n_huge, v.pt_k,
+                           v.pt_const, v.slice_ptr, d_obs_cam, d_cam_rb, d_obs_cpos, d_blk_id, Nrb, d_poff, d_uk_in, d_pv_in);
+      if (n_long > n_huge)
+        hipLaunchKernelGGL(pair_emit_long_kernel, dim3((n_long - n_huge + 3) / 4), dim3(256), 0, stream, n_huge, n_long,
+                           v.pt_k, v.pt_const, v.slice_ptr, d_obs_cam, d_cam_rb, d_obs_cpos, d_blk_id, Nrb, d_poff, d_uk_in,
+                           d_pv_in);
+    }
     if (st.Np_pad > n_long)
       hipLaunchKernelGGL(pair_emit_kernel<1>, nb(st.Np_pad - n_long), dim3(256), 0, stream, n_long, st.Np_pad, v.pt_k,
                          v.pt_const, v.slice_ptr, d_obs_cam, d_cam_rb, d_obs_cpos, d_blk_id, Nrb, d_poff, d_uk_in, d_pv_in);
@@ -1940,7 +1950,9 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
     if (iterative) {
       {
         Timed t(s, TMI_BA_K_PRECONDITIONER);
-        s->launch.precond(v, stream, O->preconditioner_type == TMI_BA_PRECOND_IDENTITY);
+        s->launch.precond(v, stream,
+                          O->preconditioner_type == TMI_BA_PRECOND_IDENTITY ? 1
+                          : O->preconditioner_type == TMI_BA_PRECOND_SCHUR_JACOBI_PARAMETER_BLOCKS ? 2 : 0);
       }
       CK(solve_reduced_pcg(s, O, &usable, &pcg_iters));
     } else {

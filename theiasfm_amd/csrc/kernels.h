@@ -1368,16 +1368,28 @@ __global__ __launch_bounds__(256) void finish_diag_kernel(DeviceView v, RedLayou
 // blocks of S, one wavefront per block, matrix staged in LDS.
 // ------------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(64) void precond_invert_kernel(DeviceView v, int identity) {
+__global__ __launch_bounds__(64) void precond_invert_kernel(DeviceView v, int mode) {
+  // mode 0: merged [extrinsics | intrinsics] block per view, 1: identity, 2: one block per
+  // PARAMETER block as ceres's SchurJacobiPreconditioner builds it (the extrinsics x intrinsics
+  // cross terms of a view are dropped before the inversion)
   __shared__ double M[D * D];
   __shared__ int bad;
   const int rb = blockIdx.x;
   const int t = threadIdx.x;
   const double* src = v.Sdiag + (size_t)rb * D * D;
-  for (int e = t; e < D * D; e += 64) M[e] = src[e];
+  const signed char* cols = v.rb_cols + (size_t)rb * D;
+  for (int e = t; e < D * D; e += 64) {
+    double m = src[e];
+    if (mode == 2) {
+      const int ci = cols[e / D], cj = cols[e % D];
+      if (ci >= 0 && cj >= 0 && ((ci < 6) != (cj < 6))) m = 0.0;
+    }
+    M[e] = m;
+  }
   if (t == 0) bad = 0;
   __syncthreads();
   double* out = v.Minv + (size_t)rb * D * D;
+  const int identity = mode == 1;
   if (identity) {
     for (int e = t; e < D * D; e += 64) out[e] = (e / D == e % D) ? 1.0 : 0.0;
     return;

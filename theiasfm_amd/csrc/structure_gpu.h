@@ -237,6 +237,58 @@ __global__ __launch_bounds__(256) void pair_emit_kernel(int lp0, int lp1, const 
   }
 }
 
+// pair_emit for long tracks, one wavefront per track: the slotted observations (slot, block) are
+// compacted into LDS first, then row ia of the pair triangle is written 64 pairs at a time.  (The
+// generic kernel above walks the whole a x b triangle with one global load per step -- 36 ms for the
+// few hundred-view tracks of a Venice-sized problem, against 0.2 ms here.)
+constexpr int kEmitCap = 2048;  // slotted observations of a track held in LDS; longer tracks take the generic kernel
+__global__ __launch_bounds__(256) void pair_emit_long_kernel(int lp0, int lp1, const int* __restrict__ pt_k,
+                                                             const unsigned char* __restrict__ pt_const,
+                                                             const int* __restrict__ slice_ptr,
+                                                             const int* __restrict__ obs_cam, const int* __restrict__ cam_rb,
+                                                             const int* __restrict__ obs_cpos, const int* __restrict__ blk_id,
+                                                             int Nrb, const long long* __restrict__ pair_off,
+                                                             unsigned* __restrict__ ukey, unsigned long long* __restrict__ pval) {
+  __shared__ int s_slot[4][kEmitCap];
+  __shared__ int s_blk[4][kEmitCap];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lp = lp0 + blockIdx.x * 4 + w;
+  if (lp >= lp1) return;
+  const int k = pt_k[lp];
+  if (k < 2 || k > kEmitCap || pt_const[lp]) return;
+  const long long base = (long long)slice_ptr[lp >> 6] + (lp & 63);
+  int m = 0;
+  for (int a0 = 0; a0 < k; a0 += 64) {
+    const int a = a0 + lane;
+    int sa = -1, ra = -1;
+    if (a < k) {
+      const long long ea = base + (long long)a * 64;
+      sa = obs_cpos[ea];
+      if (sa >= 0) ra = cam_rb[obs_cam[ea]];
+    }
+    const unsigned long long mask = __ballot(sa >= 0);
+    if (sa >= 0) {
+      const int pos = m + __popcll(mask & ((1ull << lane) - 1ull));
+      s_slot[w][pos] = sa;
+      s_blk[w][pos] = ra;
+    }
+    m += __popcll(mask);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const long long out = pair_off[lp];
+  for (int ia = 0; ia + 1 < m; ++ia) {
+    const int sa = s_slot[w][ia], ra = s_blk[w][ia];
+    const long long row0 = out + (long long)ia * (2 * m - ia - 1) / 2;
+    for (int ib = ia + 1 + lane; ib < m; ib += 64) {
+      const long long q = row0 + (ib - ia - 1);
+      ukey[q] = (unsigned)blk_id[(size_t)ra * Nrb + s_blk[w][ib]];
+      pval[q] = (unsigned long long)(unsigned)sa | ((unsigned long long)(unsigned)s_slot[w][ib] << 32);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void split_pairs_kernel(const unsigned long long* __restrict__ pval, long long n,
                                                           int* __restrict__ pi, int* __restrict__ pj) {
   const long long q = (long long)blockIdx.x * 256 + threadIdx.x;

@@ -96,8 +96,8 @@ void BundleAdjuster::AddView(const ViewId view_id) {
 void BundleAdjuster::AddTrack(const TrackId track_id) {
   Track* track = reconstruction_ ? reconstruction_->MutableTrack(track_id) : nullptr;
   if (track == nullptr) return;
-  if (!track->IsEstimated() || optimized_tracks_.count(track_id)) return;
-  optimized_tracks_.emplace(track_id);
+  if (!track->IsEstimated() || track_optimized_.Get(track_id) == 1) return;
+  track_optimized_.Set(track_id, 1);
   for (const ViewId view_id : track->ViewIds()) {
     View* view = reconstruction_->MutableView(view_id);
     if (view == nullptr) continue;
@@ -187,8 +187,39 @@ void BundleAdjuster::AddViews(const std::vector<ViewId>& view_ids) {
 
 void BundleAdjuster::AddTracks(const std::vector<TrackId>& track_ids) {
   const auto t0 = std::chrono::steady_clock::now();
-  optimized_tracks_.reserve(optimized_tracks_.size() + track_ids.size());
-  for (const TrackId t : track_ids) AddTrack(t);
+  if (reconstruction_ == nullptr) return;
+  uint32_t max_track = 0;
+  for (const TrackId t : track_ids) max_track = std::max<uint32_t>(max_track, t);
+  // one-at-a-time for subclasses (their hooks must see every call) and for ids beyond the flat tables
+  if (typeid(*this) != typeid(BundleAdjuster) || !track_optimized_.Reserve(max_track) ||
+      !track_constant_.Reserve(max_track)) {
+    for (const TrackId t : track_ids) AddTrack(t);
+    return;
+  }
+  // read-only pass, threads own disjoint index ranges: 0 = AddTrack returns at once, 1 = every view
+  // of the track is already optimised (AddTrack only marks the track variable), 2 = AddTrack has
+  // residuals to add (views outside the optimised set)
+  std::vector<uint8_t> kind(track_ids.size(), 0);
+  const int n_threads = HostThreads(4 * track_ids.size());
+  RunThreads(n_threads, [&](int t) {
+    const size_t i0 = track_ids.size() * t / n_threads, i1 = track_ids.size() * (t + 1) / n_threads;
+    for (size_t i = i0; i < i1; ++i) {
+      const Track* track = reconstruction_->Track(track_ids[i]);
+      if (track == nullptr || !track->IsEstimated()) continue;
+      uint8_t k = 1;
+      for (const ViewId view_id : track->ViewIds())
+        if (view_optimized_.Get(view_id) != 1) { k = 2; break; }
+      kind[i] = k;
+    }
+  });
+  for (size_t i = 0; i < track_ids.size(); ++i) {
+    const TrackId id = track_ids[i];
+    if (kind[i] == 0) continue;
+    if (kind[i] == 2) { AddTrack(id); continue; }
+    if (track_optimized_.Get(id) == 1) continue;
+    track_optimized_.Set(id, 1);
+    track_constant_.Set(id, 0);  // SetTrackVariable
+  }
   if (std::getenv("TMI_BA_SETUP_TIMING") != nullptr)
     std::fprintf(stderr, "[tmi_ba shim] %-28s %.3f s (since construction %.3f s)\n", "AddTracks",
                  std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(),
@@ -535,10 +566,15 @@ BundleAdjustmentSummary BundleAdjuster::Optimize() {
     std::copy(flat.intrinsics.begin() + flat.group_offset[g], flat.intrinsics.begin() + flat.group_offset[g + 1],
               intr->mutable_parameters());
   }
-  for (size_t t = 0; t < flat.track_ids.size(); ++t) {
-    double* X = reconstruction_->MutableTrack(flat.track_ids[t])->MutablePoint()->data();
-    std::copy(flat.points.begin() + 4 * t, flat.points.begin() + 4 * t + 4, X);
-  }
+  // distinct tracks, read-only look-ups in the reconstruction's maps: safe to split over threads
+  const int n_threads = HostThreads(4 * flat.track_ids.size());
+  RunThreads(n_threads, [&](int th) {
+    const size_t t0 = flat.track_ids.size() * th / n_threads, t1 = flat.track_ids.size() * (th + 1) / n_threads;
+    for (size_t t = t0; t < t1; ++t) {
+      double* X = reconstruction_->MutableTrack(flat.track_ids[t])->MutablePoint()->data();
+      std::copy(flat.points.begin() + 4 * t, flat.points.begin() + 4 * t + 4, X);
+    }
+  });
   return summary;
 }
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 runs of bench.py into profiles/<tag>_summary.{md,json}.
 
-  python tools/summarize_profile.py <tag> <stats_dir> [<fetch_dir> <write_dir>]
+  python tools/summarize_profile.py <tag> <stats_dir> [<fetch_dir> <write_dir>] [--workload NAME]
 
 * <stats_dir>: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py`
 * <fetch_dir>/<write_dir>: separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes.
@@ -45,6 +45,11 @@ def read_counter(d, counter):
 
 
 def main():
+    workload = "venice1778_heavy"  # bench.py's default
+    if "--workload" in sys.argv:
+        i = sys.argv.index("--workload")
+        workload = sys.argv[i + 1]
+        del sys.argv[i:i + 2]
     tag, stats_dir = sys.argv[1], sys.argv[2]
     rows, stats_file = read_stats(stats_dir)
     fetch = read_counter(sys.argv[3], "FETCH_SIZE") if len(sys.argv) > 3 else {}
@@ -59,7 +64,7 @@ def main():
             r["hbm_GBs_x2fetch"] = r["hbm_bytes_x2fetch"] / (r["avg_us"] * 1e-6) / 1e9
     json.dump(rows, open(os.path.join(out_dir, f"{tag}_summary.json"), "w"), indent=1)
     with open(os.path.join(out_dir, f"{tag}_summary.md"), "w") as fh:
-        fh.write(f"# rocprofv3 summary `{tag}` (bench.py, venice1778-synthetic, 1 x MI355X)\n\n")
+        fh.write(f"# rocprofv3 summary `{tag}` (bench.py, workload {workload}, synthetic, 1 x MI355X)\n\n")
         fh.write("| kernel | calls | avg us | % time | FETCH_SIZE MB/launch (raw) | WRITE_SIZE MB/launch | HBM GB/s (2 x fetch + write) |\n")
         fh.write("|---|---|---|---|---|---|---|\n")
         for r in rows:
@@ -76,13 +81,15 @@ def main():
               "spmv_cols_kernel": "spmv", "back_substitute_kernel": "back_substitute",
               "implicit_tracks_kernel": "spmv", "implicit_cameras_kernel": "spmv",
               "cost_kernel": "update_cost", "update_points_kernel": "update_cost",
-              "update_cameras_kernel": "update_cost"}
+              "update_cameras_kernel": "update_cost", "schur_offdiag_gather_kernel": "schur_offdiag",
+              "pcg_step_kernel": "pcg_vector", "pcg_p_kernel": "pcg_vector", "pcg_init_kernel": "pcg_vector",
+              "camera_prepare_kernel": "linearize"}
     classes = {}
     for r in rows:
         base = r["kernel"].split("<")[0]
         if base in cls_of and "hbm_bytes_x2fetch" in r:
             classes[cls_of[base]] = classes.get(cls_of[base], 0.0) + r["hbm_bytes_x2fetch"]
-    json.dump(dict(tag=tag, workload="venice1778", correction="2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes",
+    json.dump(dict(tag=tag, workload=workload, correction="2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes",
                    classes=classes), open(os.path.join(out_dir, "pmc_latest.json"), "w"), indent=1)
     print(open(os.path.join(out_dir, f"{tag}_summary.md")).read())
 
