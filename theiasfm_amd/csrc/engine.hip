@@ -133,8 +133,16 @@ Launch make_launch(bool fp32) {
     };
   else
     L.schur_offdiag = [](const DeviceView& v, hipStream_t st, RedLayout R) {
-      if (v.nub)
-        hipLaunchKernelGGL((schur_offdiag_kernel<D, DP>), dim3((v.n_order + 4 * kSchurBlocksPerWave - 1) / (4 * kSchurBlocksPerWave)), dim3(256), 0, st, v, R);
+      if (!v.nub) return;
+        const dim3 grid((v.n_order + 4 * kSchurBlocksPerWave - 1) / (4 * kSchurBlocksPerWave));
+#ifdef TMI_BA_SCHUR_EXPERIMENTS
+        static const int exp_mode = getenv("TMI_BA_EXP") ? atoi(getenv("TMI_BA_EXP")) : 0;
+        if (exp_mode == 1) { hipLaunchKernelGGL((schur_offdiag_kernel<D, DP, 1>), grid, dim3(256), 0, st, v, R); return; }
+        if (exp_mode == 2) { hipLaunchKernelGGL((schur_offdiag_kernel<D, DP, 2>), grid, dim3(256), 0, st, v, R); return; }
+        if (exp_mode == 3) { hipLaunchKernelGGL((schur_offdiag_kernel<D, DP, 3>), grid, dim3(256), 0, st, v, R); return; }
+        if (exp_mode == 4) { hipLaunchKernelGGL((schur_offdiag_kernel<D, DP, 4>), grid, dim3(256), 0, st, v, R); return; }
+#endif
+        hipLaunchKernelGGL((schur_offdiag_kernel<D, DP>), grid, dim3(256), 0, st, v, R);
     };
   L.expand = [](const DeviceView& v, hipStream_t st, RedLayout R, double ir, double lo, double hi, int want_gmax) {
     const int n2 = v.Nrb * D * D;

@@ -1162,35 +1162,49 @@ __global__ __launch_bounds__(256) void schur_offdiag_gather_kernel(DeviceView v,
 // consecutive lanes cover consecutive parts of a record (7 load instructions per 16 pairs for
 // 9 x 3 records), and the MFMA operands are read from LDS.  The loads of chunk t + 1 are in flight
 // in registers and the pair indices of chunk t + 2 are being fetched while chunk t is contracted.
+//
+// The chunk sequence of a wave runs across its R launch slots; its state is two SGPRs (slot r,
+// first pair c0) and the slot headers stay in the lanes they were loaded into (lane r = slot r,
+// v_readlane with a scalar lane select).  Records of pairs past the end of a block are zero-filled
+// in LDS, so the contraction runs whole groups of four MFMA steps without per-step branches and
+// the operand reads of a group are issued together.  (An earlier version kept the headers in
+// scalar arrays picked by select chains and branched around every MFMA step: it spent 1.36 ms of
+// its 1.82 ms on venice1778_heavy with the record loads switched OFF, profiles/r02_l.)
 constexpr int kSchurPairsPerChunk = 16;
 
-template <int D, int DP>
+template <int D, int DP, int EXP = 0>
 __global__ __launch_bounds__(256) void schur_offdiag_kernel(DeviceView v, RedLayout L) {
-  constexpr int YS = ys_of(D, DP);
+  // EXP: timing experiments only (results are garbage; built with -DTMI_BA_SCHUR_EXPERIMENTS,
+  // picked with TMI_BA_EXP): 1 = one 128-byte line per record, 2 = no contraction, 3 = no record
+  // loads, 4 = half the resident workgroups.  Findings: profiles/r02_l_schur_ablation.md.
+  constexpr int YS = EXP == 1 ? 16 : ys_of(D, DP);
   constexpr int R = kSchurBlocksPerWave;
   constexpr int PC = kSchurPairsPerChunk;
-  constexpr int PARTS = (D * DP + 1) / 2;          // 16-byte parts of a record that carry data
-  constexpr int PITCH = YS + 2;                    // doubles; keeps the 16-byte parts aligned
+  constexpr int PARTS = EXP == 1 ? 8 : (D * DP + 1) / 2;  // 16-byte parts of a record that carry data
+  constexpr int PITCH = ys_of(D, DP) + 2;          // doubles; keeps the 16-byte parts aligned
   constexpr int NL = (2 * PC * PARTS + 63) / 64;   // 16-byte loads per lane per chunk
   constexpr int STEPS = PC * DP / 4;               // MFMA steps (K = 4 each) of a full chunk
-  static_assert((PC * DP) % 4 == 0, "chunk K must be a multiple of the MFMA K");
+  constexpr int GS = 4;                            // MFMA steps per group (uniform branch per group)
+  static_assert((PC * DP) % 4 == 0 && STEPS % GS == 0, "chunk K must be whole groups of MFMA steps");
+  static_assert(R <= 64, "slot headers live one per lane");
   __shared__ __attribute__((aligned(16))) double lds_all[4][2 * PC * PITCH];
+  __shared__ double lds_pad[EXP == 4 ? 3000 : 1];  // EXP 4: 2 workgroups per CU instead of 4
   const int lane = threadIdx.x & 63;
   double* lds = lds_all[threadIdx.x >> 6];
+  if (EXP == 4 && v.n_order < 0) lds_pad[threadIdx.x] = 1.0;
   const long long first = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
   if (first >= v.n_order) return;  // wave-uniform; no workgroup barrier below
+  // lane r holds launch slot r: {block, #pairs, first pair lo, first pair hi}
   int4 hq = make_int4(-1, 0, 0, 0);
   if (lane < R && first + lane < v.n_order) hq = reinterpret_cast<const int4*>(v.ub_order)[first + lane];
-  // headers of the R launch slots as wave-uniform scalars
-  int hu[R], hn[R];
-  long long hp[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    hu[r] = __builtin_amdgcn_readlane(hq.x, r);
-    hn[r] = hu[r] >= 0 ? __builtin_amdgcn_readlane(hq.y, r) : 0;
-    hp[r] = ((long long)(unsigned)__builtin_amdgcn_readlane(hq.z, r)) |
-            ((long long)__builtin_amdgcn_readlane(hq.w, r) << 32);
-  }
+  // chunks a slot contributes, in pairs: a block without pairs on this rank (sharded solves) still
+  // has ONE chunk, of zero pairs, so that its zeros get written
+  const int vspan = hq.x >= 0 ? max(hq.y, 1) : 0;
+  auto slot_span = [&](int r) { return __builtin_amdgcn_readlane(vspan, r); };
+  auto slot_pairs = [&](int r) { return __builtin_amdgcn_readlane(hq.y, r); };
+  auto slot_first = [&](int r) {
+    return ((long long)(unsigned)__builtin_amdgcn_readlane(hq.z, r)) | ((long long)__builtin_amdgcn_readlane(hq.w, r) << 32);
+  };
   // per-lane LDS offsets of the MFMA operands of step h: K index k = 4 h + (lane >> 4) is
   // (pair k / DP, component k % DP); row / column = lane & 15
   const int i = lane & 15, kk = lane >> 4;
@@ -1202,46 +1216,28 @@ __global__ __launch_bounds__(256) void schur_offdiag_kernel(DeviceView v, RedLay
     const int pr = k / DP;
     koff[h] = pr * PITCH + (row_ok ? i : 0) * DP + (k - pr * DP);
   }
-  // chunk iterator over (slot r, first pair c0): wave-uniform.  A block without pairs on this
-  // rank (sharded solves) still has ONE chunk, of zero pairs, so that its zeros get written.
+  // chunk = (slot r, first pair c0, pairs n); r = R past the end.  All wave-uniform.
   struct Chunk {
-    int r, c0, n;  // launch slot (R = past the end), first pair, pairs in this chunk
+    int r, c0, n;
   };
-  auto hn_of = [&](int r) {
-    int n = 0;
-#pragma unroll
-    for (int q = 0; q < R; ++q) n = (q == r) ? hn[q] : n;
-    return n;
-  };
-  auto hu_of = [&](int r) {
-    int u = -1;
-#pragma unroll
-    for (int q = 0; q < R; ++q) u = (q == r) ? hu[q] : u;
-    return u;
-  };
-  auto hp_of = [&](int r) {
-    long long p0 = 0;
-#pragma unroll
-    for (int q = 0; q < R; ++q) p0 = (q == r) ? hp[q] : p0;
-    return p0;
-  };
-  auto span_of = [&](int r) { return hu_of(r) >= 0 ? max(hn_of(r), 1) : 0; };
   auto make_chunk = [&](int r, int c0) {
-    Chunk c;
-    while (r < R && c0 >= span_of(r)) {
+    r = __builtin_amdgcn_readfirstlane(r);
+    c0 = __builtin_amdgcn_readfirstlane(c0);
+    while (r < R && c0 >= slot_span(r)) {
       ++r;
       c0 = 0;
     }
+    Chunk c;
     c.r = r;
     c.c0 = c0;
-    c.n = r < R ? max(0, min(PC, hn_of(r) - c0)) : 0;
+    c.n = r < R ? max(0, min(PC, slot_pairs(r) - c0)) : 0;
     return c;
   };
   // lanes [0, PC) hold the i-side slots of the chunk's pairs, lanes [PC, 2 PC) the j-side slots
   auto load_slots = [&](const Chunk& c) {
     int sl = 0;
     if (c.n > 0) {
-      const long long q = hp_of(c.r) + c.c0;
+      const long long q = slot_first(c.r) + c.c0;
       if (lane < c.n) sl = v.pair_i[q + lane];
       else if (lane >= PC && lane < PC + c.n) sl = v.pair_j[q + lane - PC];
     }
@@ -1249,15 +1245,21 @@ __global__ __launch_bounds__(256) void schur_offdiag_kernel(DeviceView v, RedLay
   };
   double2 pf[NL];
   auto issue_loads = [&](const Chunk& c, int slots) {
+    // all cross-lane slot reads first, then the loads back to back
+    int sl[NL];
+#pragma unroll
+    for (int it = 0; it < NL; ++it) {
+      const int rec = (it * 64 + lane) / PARTS;
+      sl[it] = __shfl(slots, rec < 2 * PC ? rec : 0, 64);
+    }
 #pragma unroll
     for (int it = 0; it < NL; ++it) {
       const int f = it * 64 + lane;
       const int rec = f / PARTS, part = f - rec * PARTS;
       const int pr = rec >= PC ? rec - PC : rec;
-      const int sl = __shfl(slots, rec < 2 * PC ? rec : 0, 64);
       double2 t = make_double2(0.0, 0.0);
-      if (rec < 2 * PC && pr < c.n)
-        t = *reinterpret_cast<const double2*>(v.cm_Y + (size_t)sl * YS + 2 * part);
+      if (EXP != 3 && rec < 2 * PC && pr < c.n)
+        t = *reinterpret_cast<const double2*>(v.cm_Y + (size_t)sl[it] * YS + 2 * part);
       pf[it] = t;
     }
   };
@@ -1287,18 +1289,26 @@ __global__ __launch_bounds__(256) void schur_offdiag_kernel(DeviceView v, RedLay
     if (A.c0 == 0) acc = (v4f64){0.0, 0.0, 0.0, 0.0};
     const int ksteps = (A.n * DP + 3) / 4;
 #pragma unroll
-    for (int h = 0; h < STEPS; ++h) {
-      if (h < ksteps) {
-        double a = lds[koff[h]];
-        double b = lds[PC * PITCH + koff[h]];
-        a = row_ok ? a : 0.0;
-        b = row_ok ? b : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    for (int g = 0; g < STEPS / GS; ++g) {
+      if (EXP != 2 && g * GS < ksteps) {
+        double a[GS], b[GS];
+#pragma unroll
+        for (int h = 0; h < GS; ++h) {
+          a[h] = lds[koff[g * GS + h]];
+          b[h] = lds[PC * PITCH + koff[g * GS + h]];
+        }
+#pragma unroll
+        for (int h = 0; h < GS; ++h) {
+          a[h] = row_ok ? a[h] : 0.0;
+          b[h] = row_ok ? b[h] : 0.0;
+        }
+#pragma unroll
+        for (int h = 0; h < GS; ++h) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[h], b[h], acc, 0, 0, 0);
       }
     }
-    if (A.c0 + PC >= span_of(A.r)) {
+    if (A.c0 + PC >= slot_span(A.r)) {
       // last chunk of the block: write it out
-      double* out = v.red + L.ub + (size_t)hu_of(A.r) * D * D;
+      double* out = v.red + L.ub + (size_t)__builtin_amdgcn_readlane(hq.x, A.r) * D * D;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int row = (lane >> 4) + 4 * q;
