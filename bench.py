@@ -495,6 +495,30 @@ def main():
             first_call_ms=round(ss0.seconds * 1e3, 2),
             cpu_port_ms=round(t_s * 1e3, 1), selected=int(ss.num_selected), of=int(ss.num_tracks),
             selection_equal=bool((sel_d == sel_o).all()))
+        # batched BundleAdjustTwoViews (bundle_adjust_two_views.cc:113-191): 20 000 view pairs, 5-300 correspondences
+        from theiasfm_amd import lib as _lib
+        tvb = synth.make_two_view_batch(20000, 5, max_corr=300)
+        _lib.adjust_two_views(tvb.copy(), 4)  # first call: module load, allocations
+        tv_d = tvb.copy()
+        tc = time.perf_counter()
+        term_d, it_d, _, c1_d, tvs = _lib.adjust_two_views(tv_d, 4)
+        t_call = time.perf_counter() - tc
+        n_cpu = 2000
+        tv_s = tvb.head(n_cpu)
+        if True:
+            tc = time.perf_counter()
+            term_o, it_o, _, c1_o = oracle.adjust_two_views(tv_s, 4)
+            t_o = time.perf_counter() - tc
+            sm = slice(0, n_cpu)
+            ok = term_o >= 0
+            side["batched_two_view_ba"] = dict(
+                kernel_ms=round(tvs.kernel_seconds * 1e3, 3), call_ms=round(t_call * 1e3, 2), pairs=int(tvb.num_pairs),
+                correspondences=int(tvb.correspondence_ptr[-1]), lm_iterations=int(tvs.total_iterations),
+                pairs_per_s=tvb.num_pairs / tvs.kernel_seconds, cpu_port_pairs_per_s=n_cpu / t_o,
+                cpu_port_sample=f"first {n_cpu} pairs, {oracle.num_threads()} threads",
+                termination_mismatches=int((term_d[sm] != term_o).sum()),
+                iteration_mismatches=int((it_d[sm] != it_o).sum()),
+                final_cost_rel_diff_above_1e6=int((np.abs(c1_d[sm][ok] - c1_o[ok]) > 1e-6 * np.maximum(c1_o[ok], 1e-12)).sum()))
         out["side_kernels"] = side
     solver.close()
 

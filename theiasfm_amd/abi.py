@@ -421,6 +421,16 @@ class TwoViewBatch:
             "constant_intrinsics1", "constant_intrinsics2", "correspondence_ptr", "features1", "features2",
             "points")])
 
+    def head(self, n: int) -> "TwoViewBatch":
+        """the first n pairs (copies)"""
+        n = min(int(n), self.num_pairs)
+        m = int(self.correspondence_ptr[n])
+        return TwoViewBatch(self.extrinsics1[:n].copy(), self.extrinsics2[:n].copy(), self.model1[:n].copy(),
+                            self.model2[:n].copy(), self.intrinsics1[:n].copy(), self.intrinsics2[:n].copy(),
+                            self.constant_intrinsics1[:n].copy(), self.constant_intrinsics2[:n].copy(),
+                            self.correspondence_ptr[:n + 1].copy(), self.features1[:m].copy(),
+                            self.features2[:m].copy(), self.points[:m].copy())
+
     def as_c(self) -> CTwoViewBatch:
         b = CTwoViewBatch()
         b.num_pairs = self.num_pairs
