@@ -1,0 +1,120 @@
+// Cross-check helper (CPU only): load a reconstruction from a plain dump, register it with
+// theia::BundleAdjuster exactly as BundleAdjustReconstruction does (bundle_adjustment.cc:66-80)
+// and write out the flattened problem Optimize() would send to the device.
+// tests/test_shim_flatten.py compares it with theiasfm_amd.io.flatten_reconstruction.
+//
+//   flatten_dump <in.bin> <out.bin> [bulk 0|1] [intrinsics_to_optimize]
+// in.bin (little endian): int64 Nv, Ng, Nt, No
+//   views  : u32 id | u8 estimated | i32 group | f64 ext[6]            (ascending id)
+//   groups : i32 model | i32 nparams | f64 params[10]
+//   tracks : u32 id | u8 estimated | f64 point[4]                       (ascending id)
+//   obs    : u32 view id | u32 track id | f64 x | f64 y
+// out.bin: int64 Nc, G, Np, No, n_intr | ext | camera_group | camera_flags | group_model |
+//          group_offset | intrinsics | intrinsics_constant | points | point_constant |
+//          obs_camera | obs_point | obs_xy | view ids (u32) | track ids (u32)
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "theia/sfm/bundle_adjustment/bundle_adjuster.h"
+#include "theia/sfm/reconstruction.h"
+
+using namespace theia;
+
+template <class T>
+static T rd(FILE* f) {
+  T v;
+  if (fread(&v, sizeof(T), 1, f) != 1) {
+    fprintf(stderr, "short input\n");
+    exit(2);
+  }
+  return v;
+}
+template <class T>
+static void wr(FILE* f, const std::vector<T>& v) {
+  if (!v.empty()) fwrite(v.data(), sizeof(T), v.size(), f);
+}
+
+int main(int argc, char** argv) {
+  if (argc < 3) return 2;
+  const bool bulk = argc > 3 ? atoi(argv[3]) != 0 : true;
+  FILE* f = fopen(argv[1], "rb");
+  if (!f) return 2;
+  const int64_t Nv = rd<int64_t>(f), Ng = rd<int64_t>(f), Nt = rd<int64_t>(f), No = rd<int64_t>(f);
+  struct V { uint32_t id; uint8_t est; int32_t grp; double ext[6]; };
+  struct G { int32_t model, n; double p[10]; };
+  std::vector<V> views(Nv);
+  std::vector<G> groups(Ng);
+  for (auto& v : views) {
+    v.id = rd<uint32_t>(f); v.est = rd<uint8_t>(f); v.grp = rd<int32_t>(f);
+    for (double& e : v.ext) e = rd<double>(f);
+  }
+  for (auto& g : groups) {
+    g.model = rd<int32_t>(f); g.n = rd<int32_t>(f);
+    for (double& p : g.p) p = rd<double>(f);
+  }
+  Reconstruction rec;
+  for (const V& v : views) {
+    const ViewId id = rec.AddView("view" + std::to_string(v.id), static_cast<CameraIntrinsicsGroupId>(v.grp));
+    if (id != v.id) {
+      fprintf(stderr, "view ids must be consecutive from 0 (got %u for %u)\n", id, v.id);
+      return 2;
+    }
+    View* view = rec.MutableView(id);
+    Camera* cam = view->MutableCamera();
+    const G& g = groups[v.grp];
+    // the first view of a group owns the intrinsics object, later views share it (reconstruction.cc:113-124)
+    if (cam->GetCameraIntrinsicsModelType() != static_cast<CameraIntrinsicsModelType>(g.model))
+      cam->SetCameraIntrinsicsModelType(static_cast<CameraIntrinsicsModelType>(g.model));
+    for (int a = 0; a < g.n; ++a) cam->mutable_intrinsics()[a] = g.p[a];
+    for (int a = 0; a < 6; ++a) cam->mutable_extrinsics()[a] = v.ext[a];
+    view->SetEstimated(v.est != 0);
+  }
+  for (int64_t t = 0; t < Nt; ++t) {
+    const uint32_t want = rd<uint32_t>(f);
+    const uint8_t est = rd<uint8_t>(f);
+    const TrackId id = rec.AddTrack();
+    if (id != want) {
+      fprintf(stderr, "track ids must be consecutive from 0\n");
+      return 2;
+    }
+    Track* tr = rec.MutableTrack(id);
+    for (int a = 0; a < 4; ++a) (*tr->MutablePoint())[a] = rd<double>(f);
+    tr->SetEstimated(est != 0);
+  }
+  for (int64_t i = 0; i < No; ++i) {
+    const uint32_t v = rd<uint32_t>(f), t = rd<uint32_t>(f);
+    const double x = rd<double>(f), y = rd<double>(f);
+    if (!rec.AddObservation(v, t, Feature(x, y))) {
+      fprintf(stderr, "AddObservation(%u, %u) failed\n", v, t);
+      return 2;
+    }
+  }
+  fclose(f);
+
+  BundleAdjustmentOptions options;
+  if (argc > 4) options.intrinsics_to_optimize = static_cast<OptimizeIntrinsicsType>(atoi(argv[4]));
+  BundleAdjuster ba(options, &rec);
+  if (bulk) {
+    ba.AddViews(rec.ViewIds());
+    ba.AddTracks(rec.TrackIds());
+  } else {
+    for (const ViewId v : rec.ViewIds()) ba.AddView(v);
+    for (const TrackId t : rec.TrackIds()) ba.AddTrack(t);
+  }
+  FlattenedBundleAdjustmentProblem flat;
+  if (!ba.Flatten(&flat)) return 1;
+  FILE* o = fopen(argv[2], "wb");
+  if (!o) return 2;
+  const int64_t hdr[5] = {(int64_t)flat.view_ids.size(), (int64_t)flat.group_ids.size(), (int64_t)flat.track_ids.size(),
+                          (int64_t)flat.obs_camera.size(), (int64_t)flat.intrinsics.size()};
+  fwrite(hdr, sizeof(int64_t), 5, o);
+  wr(o, flat.extrinsics); wr(o, flat.camera_group); wr(o, flat.camera_flags); wr(o, flat.group_model);
+  wr(o, flat.group_offset); wr(o, flat.intrinsics); wr(o, flat.intrinsics_constant); wr(o, flat.points);
+  wr(o, flat.point_constant); wr(o, flat.obs_camera); wr(o, flat.obs_point); wr(o, flat.obs_xy);
+  wr(o, flat.view_ids); wr(o, flat.track_ids);
+  fclose(o);
+  return 0;
+}

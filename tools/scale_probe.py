@@ -11,7 +11,11 @@ import torch  # noqa: E402
 
 from theiasfm_amd import abi, dist, lib, synth  # noqa: E402
 
-prob = synth.config("venice1778")
+import os  # noqa: E402
+
+workload = os.environ.get("TMI_PROBE_WORKLOAD", "venice1778_heavy")
+profile = int(os.environ.get("TMI_PROBE_PROFILE", "1"))  # 0: no per-class HIP events (the timing bench.py sees)
+prob = synth.config(workload)
 steps = 10
 worlds = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
 for world in worlds:
@@ -39,7 +43,7 @@ for world in worlds:
             s.set_allreduce(hook)
         s.solve(o)
         s.reset()
-        ot = abi.default_options(max_num_iterations=steps, profile_kernels=1, **base)
+        ot = abi.default_options(max_num_iterations=steps, profile_kernels=profile, **base)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         st, sm = s.solve(ot)
@@ -47,7 +51,7 @@ for world in worlds:
         el = time.perf_counter() - t0
         d = sm.as_dict()
         ks = {n: (l, round(1e3 * sec, 3)) for n, l, sec in zip(abi.KERNEL_CLASS_NAMES, d["kernel_launches"], d["kernel_seconds"]) if l}
-        print(json.dumps(dict(world=world, schur_mode=["auto", "explicit"][mode], its=int(sm.num_iterations),
+        print(json.dumps(dict(workload=workload, profile_kernels=profile, world=world, schur_mode=["auto", "explicit"][mode], its=int(sm.num_iterations),
                               ms_per_iter=round(1e3 * el / max(1, sm.num_iterations), 3),
                               pcg=int(sm.num_linear_solver_iterations), kernel_ms_total=round(sum(v[1] for v in ks.values()), 2),
                               kernels=ks)))
