@@ -1234,18 +1234,22 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   v.n_track_blocks = 4 * st.n_wide + (st.nslices - st.n_wide + kSlicesPerBlock - 1) / kSlicesPerBlock;
   s->nblocks_tracks = std::max(v.n_track_blocks, 1);
   const int nbmax = std::max(std::max(s->nblocks_slices, s->nblocks_tracks), s->nblocks_points);
+#define AL(ptr, n) if ((rc = dev_alloc(s, &ptr, (size_t)(n)))) return rc;
+  // the prepared camera records serve the side kernels of a light handle too (their scale part is
+  // only meaningful inside a solve)
+  AL(v.scale_cam, (size_t)std::max(st.Nc, 1) * 16)
+  AL(v.prep, (size_t)std::max(st.Nc, 1) * kPrepStride) AL(v.prep_c, (size_t)std::max(st.Nc, 1) * kPrepStride)
+  TMI_HIP(hipMemsetAsync(v.scale_cam, 0, (size_t)std::max(st.Nc, 1) * 16 * sizeof(double), s->stream));
   if (light) {
     TMI_HIP(hipStreamSynchronize(s->stream));
     s->setup_seconds = now_s() - t0;
     return TMI_BA_OK;
   }
-#define AL(ptr, n) if ((rc = dev_alloc(s, &ptr, (size_t)(n)))) return rc;
   AL(v.pm_r, 2 * N) AL(v.pm_A, 2 * D * N) AL(v.pm_Jp, 2 * DP * N) AL(s->d_pm_u, 2 * N)
   AL(s->d_cm_t, s->implicit ? (size_t)std::max<int64_t>(st.Nslots, 1) * 2 : 1)
   AL(v.pm_A1, st.has_shared ? 2 * D * N : 1) AL(v.cam_part, (size_t)std::max(st.Ncam_rb, 1) * (2 * D * D + 3 * D))
   AL(v.cm_Y, (size_t)std::max<int64_t>(st.Nslots, 1) * YS) AL(v.cm_A, (size_t)std::max<int64_t>(st.Nslots, 1) * AS)
-  AL(v.scale_c, std::max(n_r, 1)) AL(v.scale_cam, (size_t)std::max(st.Nc, 1) * 16) AL(v.scale_p, NP * DP)
-  AL(v.prep, (size_t)std::max(st.Nc, 1) * kPrepStride) AL(v.prep_c, (size_t)std::max(st.Nc, 1) * kPrepStride)
+  AL(v.scale_c, std::max(n_r, 1)) AL(v.scale_p, NP * DP)
   AL(v.Vinv, NP * NS) AL(v.gp, NP * DP) AL(v.diag_p, NP * DP) AL(v.yp, NP * DP)
   AL(v.red, s->RL.total) AL(v.Sdiag, (size_t)std::max(st.Nrb, 1) * D * D)
   AL(v.tbuf, (size_t)std::max<int64_t>(st.nub, 1) * D) AL(v.rbuf, (size_t)std::max(v.n_spc, 1) * D) AL(v.Minv, (size_t)std::max(st.Nrb, 1) * D * D)
@@ -1582,30 +1586,46 @@ static int ensure_inner(tmi_ba_solver* s) {
   tmi_ba_solver::InnerCtx& I = s->inner;
   if (I.ready) return TMI_BA_OK;
   int rc;
-  if ((rc = materialize_host_layout(s))) return rc;
   const Structure& st = s->st;
-  // view-major observation index from the track-major layout
-  std::vector<int> vo_ptr((size_t)st.Nc + 2, 0), vo_e((size_t)st.No), vo_lp((size_t)st.No);
-  for (int64_t e = 0; e < st.No_pad; ++e)
-    if (st.obs_cam[e] >= 0) vo_ptr[st.obs_cam[e] + 2]++;
-  for (int c = 0; c < st.Nc; ++c) vo_ptr[c + 2] += vo_ptr[c + 1];
-  for (int sl = 0; sl < st.nslices; ++sl) {
-    const int K = (st.slice_ptr[sl + 1] - st.slice_ptr[sl]) >> 6;
-    for (int j = 0; j < K; ++j)
-      for (int t = 0; t < 64; ++t) {
-        const int64_t e = (int64_t)st.slice_ptr[sl] + 64 * j + t;
-        const int cam = st.obs_cam[e];
-        if (cam < 0) continue;
-        const int q = vo_ptr[cam + 1]++;
-        vo_e[q] = (int)e;
-        vo_lp[q] = sl * 64 + t;
-      }
-  }
-  vo_ptr.pop_back();
+  // view-major observation index from the track-major layout, built on the device: a stable radix
+  // sort of the layout's elements by camera (within a view: ascending element, as the host loop
+  // it replaces produced), the view pointers by binary search, the track of every element alongside
   int *d_vo_ptr, *d_vo_e, *d_vo_lp;
-  if ((rc = dev_upload(s, &d_vo_ptr, vo_ptr))) return rc;
-  if ((rc = dev_upload(s, &d_vo_e, vo_e))) return rc;
-  if ((rc = dev_upload(s, &d_vo_lp, vo_lp))) return rc;
+  if ((rc = dev_alloc(s, &d_vo_ptr, (size_t)st.Nc + 2))) return rc;
+  if ((rc = dev_alloc(s, &d_vo_e, (size_t)std::max<int64_t>(st.No_pad, 1)))) return rc;
+  if ((rc = dev_alloc(s, &d_vo_lp, (size_t)std::max<int64_t>(st.No_pad, 1)))) return rc;
+  if (st.No_pad >= ((int64_t)1 << 31)) {
+    s->error = "inner iterations: more than 2^31 layout elements";
+    return TMI_BA_ERR_UNSUPPORTED;
+  }
+  {
+    using namespace tmi::sg;
+    hipStream_t stream = s->stream;
+    TempPool tmp;
+    unsigned *d_key_in, *d_key_out;
+    int *d_val_in, *d_elem_lp;
+    const size_t n = (size_t)std::max<int64_t>(st.No_pad, 1);
+    TMI_HIP(tmp.get(&d_key_in, n));
+    TMI_HIP(tmp.get(&d_key_out, n));
+    TMI_HIP(tmp.get(&d_val_in, n));
+    TMI_HIP(tmp.get(&d_elem_lp, n));
+    if (st.No_pad > 0) {
+      hipLaunchKernelGGL(view_index_keys_kernel, dim3((st.Np_pad + 255) / 256), dim3(256), 0, stream, st.Np_pad, s->v.pt_k,
+                         s->v.slice_ptr, s->v.obs_cam, st.Nc, d_key_in, d_elem_lp);
+      hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((st.No_pad + 255) / 256)), dim3(256), 0, stream, d_val_in, (int)st.No_pad);
+      size_t bytes = 0;
+      const int bits = bits_for((unsigned)st.Nc + 1);
+      TMI_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, d_key_in, d_key_out, d_val_in, d_vo_e, (int)st.No_pad, 0, bits, stream));
+      void* cub_tmp = nullptr;
+      TMI_HIP(tmp.get((char**)&cub_tmp, std::max<size_t>(bytes, 16)));
+      TMI_HIP(hipcub::DeviceRadixSort::SortPairs(cub_tmp, bytes, d_key_in, d_key_out, d_val_in, d_vo_e, (int)st.No_pad, 0, bits, stream));
+      hipLaunchKernelGGL(gather_int_kernel, dim3((unsigned)((st.No_pad + 255) / 256)), dim3(256), 0, stream, d_vo_e,
+                         (long long)st.No_pad, d_elem_lp, d_vo_lp);
+    }
+    hipLaunchKernelGGL((lower_bound_kernel<unsigned, int>), dim3((st.Nc + 1 + 255) / 256), dim3(256), 0, stream, d_key_out,
+                       (long long)st.No_pad, (long long)st.Nc, d_vo_ptr);
+    TMI_HIP(hipStreamSynchronize(stream));
+  }
   double* d_part;
   if ((rc = dev_alloc(s, &d_part, (size_t)std::max(st.Nc, 1) * kInnerPart))) return rc;
   if ((rc = dev_alloc(s, &I.d_active, 1))) return rc;
@@ -1764,11 +1784,12 @@ static int run_inner_sweep(tmi_ba_solver* s, const tmi_ba_options* O) {
     vc.intr = v.intr_c;
     vc.pts = v.pts_c;
     Timed t(s, TMI_BA_K_LINEARIZE);
+    prepare_cameras(s, v.ext_c, v.intr_c, v.prep_c);  // the two view sets moved the candidate cameras
     if (s->DP == 3)
-      hipLaunchKernelGGL(track_lm_kernel<3>, dim3(s->nblocks_slices), dim3(256), 0, stream, vc, A, s->d_trk_term,
+      hipLaunchKernelGGL(track_lm_kernel<3>, dim3(s->nblocks_tracks), dim3(256), 0, stream, vc, v.prep_c, A, s->d_trk_term,
                          s->d_trk_iter, s->d_trk_c0, s->d_trk_c1);
     else
-      hipLaunchKernelGGL(track_lm_kernel<4>, dim3(s->nblocks_slices), dim3(256), 0, stream, vc, A, s->d_trk_term,
+      hipLaunchKernelGGL(track_lm_kernel<4>, dim3(s->nblocks_tracks), dim3(256), 0, stream, vc, v.prep_c, A, s->d_trk_term,
                          s->d_trk_iter, s->d_trk_c0, s->d_trk_c1);
   }
   return TMI_BA_OK;
@@ -2318,12 +2339,13 @@ int32_t tmi_ba_solver_adjust_tracks(tmi_ba_solver* s, const tmi_ba_options* O, i
   TMI_HIP(hipEventCreate(&ea));
   TMI_HIP(hipEventCreate(&eb));
   TMI_HIP(hipEventRecord(ea, s->stream));
+  prepare_cameras(s, s->v.ext, s->v.intr, s->v.prep);  // (inside the timed region: part of the call's device work)
   if (st.nslices > 0) {
     if (s->DP == 3)
-      hipLaunchKernelGGL(track_lm_kernel<3>, dim3(s->nblocks_slices), dim3(256), 0, s->stream, s->v, A,
+      hipLaunchKernelGGL(track_lm_kernel<3>, dim3(s->nblocks_tracks), dim3(256), 0, s->stream, s->v, s->v.prep, A,
                          s->d_trk_term, s->d_trk_iter, s->d_trk_c0, s->d_trk_c1);
     else
-      hipLaunchKernelGGL(track_lm_kernel<4>, dim3(s->nblocks_slices), dim3(256), 0, s->stream, s->v, A,
+      hipLaunchKernelGGL(track_lm_kernel<4>, dim3(s->nblocks_tracks), dim3(256), 0, s->stream, s->v, s->v.prep, A,
                          s->d_trk_term, s->d_trk_iter, s->d_trk_c0, s->d_trk_c1);
   }
   TMI_HIP(hipEventRecord(eb, s->stream));

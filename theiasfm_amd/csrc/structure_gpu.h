@@ -368,4 +368,30 @@ __global__ __launch_bounds__(256) void spc_fill_kernel(const int* __restrict__ u
 }
 
 }  // namespace sg
+// view-major observation index for the inner iterations: keys (camera, Nc for padding) and
+// values (element, track) of every element of the SELL layout
+__global__ __launch_bounds__(256) void view_index_keys_kernel(int Np_pad, const int* __restrict__ pt_k,
+                                                              const int* __restrict__ slice_ptr,
+                                                              const int* __restrict__ obs_cam, int Nc,
+                                                              unsigned* __restrict__ key, int* __restrict__ elem_lp) {
+  const int lp = blockIdx.x * 256 + threadIdx.x;
+  if (lp >= Np_pad) return;
+  const int sl = lp >> 6;
+  const int K = (slice_ptr[sl + 1] - slice_ptr[sl]) >> 6;
+  const long long base = (long long)slice_ptr[sl] + (lp & 63);
+  const int k = pt_k[lp];
+  for (int j = 0; j < K; ++j) {
+    const long long e = base + (long long)j * 64;
+    const int cam = j < k ? obs_cam[e] : -1;
+    key[e] = cam >= 0 ? (unsigned)cam : (unsigned)Nc;
+    elem_lp[e] = lp;
+  }
+}
+
+__global__ __launch_bounds__(256) void gather_int_kernel(const int* __restrict__ idx, long long n,
+                                                         const int* __restrict__ src, int* __restrict__ dst) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
+}
+
 }  // namespace tmi

@@ -157,33 +157,32 @@ struct TrackLmArgs {
 // One pass over a track's observations at point X: robustified, column-scaled point
 // Jacobian accumulated into V0 = sum Jp^T Jp (packed upper), g = sum Jp^T r, cost.
 // Returns false if any residual cannot be evaluated.
+// The cameras are constant here, so both passes read the PREPARED camera records (camera_models.h:
+// R, C, K evaluated once per camera) instead of running Rodrigues' formula per observation and per LM
+// iteration.  tm: thread per track, or 16 lanes per track on the long slices (kernels.h track_map) --
+// the sums are then finished over the 16 lanes with a fixed butterfly and every lane of the group holds
+// the same totals, so the trust-region loop below runs replicated and never diverges inside a group.
 template <int DP>
-__device__ __forceinline__ bool track_linearize(const DeviceView& v, size_t base, int k, const double X[4],
-                                                const double sp[DP], int loss_type, double loss_width,
-                                                double V0[sym_size(DP)], double g[DP], double* cost) {
+__device__ __forceinline__ bool track_linearize(const DeviceView& v, const double* __restrict__ prep,
+                                                const TrackMap& tm, const double X[4], const double sp[DP],
+                                                int loss_type, double loss_width, double V0[sym_size(DP)],
+                                                double g[DP], double* cost) {
   constexpr int NS = sym_size(DP);
 #pragma unroll
   for (int i = 0; i < NS; ++i) V0[i] = 0.0;
 #pragma unroll
   for (int a = 0; a < DP; ++a) g[a] = 0.0;
   double c = 0.0;
-  bool ok_all = true;
-  for (int j = 0; j < k; ++j) {
-    const size_t e = base + (size_t)j * 64;
+  double bad = 0.0;
+  for (int j = tm.j0; j < tm.k; j += tm.jstep) {
+    const size_t e = tm.base + (size_t)j * 64;
     const int cam = v.obs_cam[e];
-    const int grp = v.cam_grp[cam];
-    const double* Kp = v.intr + v.grp_off[grp];
-    const int nk = v.grp_off[grp + 1] - v.grp_off[grp];
-    double Kv[10], E[6];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) Kv[i] = (i < nk) ? Kp[i] : 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) E[i] = v.ext[(size_t)cam * 6 + i];
+    const double* P = prep + (size_t)cam * kPrepStride;
     double r[2], Jext[2][6], Jint[2][10], Jpt[2][4];
-    const bool ok = reprojection_error<true, double>(v.grp_model[grp], E, Kv, X, v.obs_xy[2 * e],
-                                                     v.obs_xy[2 * e + 1], r, Jext, Jint, Jpt);
+    const bool ok = reprojection_error_prepared<true, double>(v.cam_rec[cam].x, P, X, v.obs_xy[2 * e],
+                                                              v.obs_xy[2 * e + 1], r, Jext, Jint, Jpt);
     if (!ok) {
-      ok_all = false;
+      bad = 1.0;
       continue;
     }
     const double sq = r[0] * r[0] + r[1] * r[1];
@@ -223,33 +222,30 @@ __device__ __forceinline__ bool track_linearize(const DeviceView& v, size_t base
       g[a] += J0[a] * r0 + J1[a] * r1;
     }
   }
-  *cost = c;
-  return ok_all;
+#pragma unroll
+  for (int i = 0; i < NS; ++i) V0[i] = group_sum(V0[i], tm.wide);
+#pragma unroll
+  for (int a = 0; a < DP; ++a) g[a] = group_sum(g[a], tm.wide);
+  *cost = group_sum(c, tm.wide);
+  return group_sum(bad, tm.wide) == 0.0;
 }
 
-__device__ __forceinline__ bool track_cost(const DeviceView& v, size_t base, int k, const double X[4],
-                                           int loss_type, double loss_width, double* cost) {
+__device__ __forceinline__ bool track_cost(const DeviceView& v, const double* __restrict__ prep, const TrackMap& tm,
+                                           const double X[4], int loss_type, double loss_width, double* cost) {
   double c = 0.0;
-  bool ok_all = true;
-  for (int j = 0; j < k; ++j) {
-    const size_t e = base + (size_t)j * 64;
+  double bad = 0.0;
+  for (int j = tm.j0; j < tm.k; j += tm.jstep) {
+    const size_t e = tm.base + (size_t)j * 64;
     const int cam = v.obs_cam[e];
-    const int grp = v.cam_grp[cam];
-    const double* Kp = v.intr + v.grp_off[grp];
-    const int nk = v.grp_off[grp + 1] - v.grp_off[grp];
-    double Kv[10], E[6];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) Kv[i] = (i < nk) ? Kp[i] : 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) E[i] = v.ext[(size_t)cam * 6 + i];
+    const double* P = prep + (size_t)cam * kPrepStride;
     double r[2];
     double (*nul6)[6] = nullptr;
     double Jint[2][10];
     double (*nul4)[4] = nullptr;
-    const bool ok = reprojection_error<false, double>(v.grp_model[grp], E, Kv, X, v.obs_xy[2 * e],
-                                                      v.obs_xy[2 * e + 1], r, nul6, Jint, nul4);
+    const bool ok = reprojection_error_prepared<false, double>(v.cam_rec[cam].x, P, X, v.obs_xy[2 * e],
+                                                               v.obs_xy[2 * e + 1], r, nul6, Jint, nul4);
     if (!ok) {
-      ok_all = false;
+      bad = 1.0;
       continue;
     }
     const double sq = r[0] * r[0] + r[1] * r[1];
@@ -261,8 +257,8 @@ __device__ __forceinline__ bool track_cost(const DeviceView& v, size_t base, int
       c += 0.5 * sq;
     }
   }
-  *cost = c;
-  return ok_all;
+  *cost = group_sum(c, tm.wide);
+  return group_sum(bad, tm.wide) == 0.0;
 }
 
 // termination[lp]: 0 CONVERGENCE, 1 NO_CONVERGENCE (iteration limit), 2 FAILURE,
@@ -272,23 +268,23 @@ __device__ __forceinline__ bool track_cost(const DeviceView& v, size_t base, int
 // full solver runs (engine.hip / Ceres 1.14 TrustRegionMinimizer) with an empty camera
 // side: the step is -(V + D)^-1 g on the track's own 2k x DP Jacobian.
 template <int DP>
-__global__ __launch_bounds__(256) void track_lm_kernel(DeviceView v, TrackLmArgs A,
+__global__ __launch_bounds__(256) void track_lm_kernel(DeviceView v, const double* __restrict__ prep, TrackLmArgs A,
                                                        signed char* __restrict__ termination,
                                                        int* __restrict__ iterations,
                                                        double* __restrict__ initial_cost,
                                                        double* __restrict__ final_cost) {
   constexpr int NS = sym_size(DP);
-  const int lane = threadIdx.x & 63;
-  const int s = blockIdx.x * kSlicesPerBlock + (threadIdx.x >> 6);
-  if (s >= v.nslices) return;
-  const int lp = s * 64 + lane;
-  const int k = v.pt_k[lp];
-  const size_t base = (size_t)v.slice_ptr[s] + lane;
-  if (k == 0 || v.pt_const[lp]) {
-    termination[lp] = -1;
-    iterations[lp] = 0;
-    initial_cost[lp] = 0.0;
-    final_cost[lp] = 0.0;
+  const TrackMap tm = track_map(v);
+  if (!tm.valid) return;
+  const int lp = tm.lp;
+  const int k = tm.k;
+  if (k == 0 || v.pt_const[lp]) {  // uniform over the lanes that share a track
+    if (tm.leader) {
+      termination[lp] = -1;
+      iterations[lp] = 0;
+      initial_cost[lp] = 0.0;
+      final_cost[lp] = 0.0;
+    }
     return;
   }
   double X[4];
@@ -299,12 +295,14 @@ __global__ __launch_bounds__(256) void track_lm_kernel(DeviceView v, TrackLmArgs
   for (int a = 0; a < DP; ++a) sp[a] = 1.0;
   double V0[NS], g[DP], cost;
   // iteration zero
-  bool ok = track_linearize<DP>(v, base, k, X, sp, A.loss_type, A.loss_width, V0, g, &cost);
-  initial_cost[lp] = cost;
+  bool ok = track_linearize<DP>(v, prep, tm, X, sp, A.loss_type, A.loss_width, V0, g, &cost);
+  if (tm.leader) initial_cost[lp] = cost;
   if (!ok) {
-    termination[lp] = 3;
-    iterations[lp] = 0;
-    final_cost[lp] = cost;
+    if (tm.leader) {
+      termination[lp] = 3;
+      iterations[lp] = 0;
+      final_cost[lp] = cost;
+    }
     return;
   }
   double gmax = 0.0;
@@ -313,7 +311,7 @@ __global__ __launch_bounds__(256) void track_lm_kernel(DeviceView v, TrackLmArgs
   if (A.jacobi_scaling) {
 #pragma unroll
     for (int a = 0; a < DP; ++a) sp[a] = 1.0 / (1.0 + sqrt(V0[sym_idx(a, a, DP)]));
-    track_linearize<DP>(v, base, k, X, sp, A.loss_type, A.loss_width, V0, g, &cost);
+    track_linearize<DP>(v, prep, tm, X, sp, A.loss_type, A.loss_width, V0, g, &cost);
   }
   double x_norm = sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2] + X[3] * X[3]);
   double radius = A.initial_radius, decrease_factor = 2.0;
@@ -403,7 +401,7 @@ __global__ __launch_bounds__(256) void track_lm_kernel(DeviceView v, TrackLmArgs
         step_sq += d * d;
       }
       double cand_cost;
-      if (!track_cost(v, base, k, Xc, A.loss_type, A.loss_width, &cand_cost)) cand_cost = 1.7976931348623157e308;
+      if (!track_cost(v, prep, tm, Xc, A.loss_type, A.loss_width, &cand_cost)) cand_cost = 1.7976931348623157e308;
       if (sqrt(step_sq) <= A.parameter_tolerance * (x_norm + A.parameter_tolerance)) {
         term = 0;
         break;
@@ -418,7 +416,7 @@ __global__ __launch_bounds__(256) void track_lm_kernel(DeviceView v, TrackLmArgs
 #pragma unroll
         for (int i = 0; i < 4; ++i) X[i] = Xc[i];
         x_norm = sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2] + X[3] * X[3]);
-        track_linearize<DP>(v, base, k, X, sp, A.loss_type, A.loss_width, V0, g, &cost);
+        track_linearize<DP>(v, prep, tm, X, sp, A.loss_type, A.loss_width, V0, g, &cost);
         gmax = 0.0;
 #pragma unroll
         for (int a = 0; a < DP; ++a) gmax = fmax(gmax, fabs(g[a] / sp[a]));
@@ -439,6 +437,7 @@ __global__ __launch_bounds__(256) void track_lm_kernel(DeviceView v, TrackLmArgs
       }
     }
   }
+  if (!tm.leader) return;
   termination[lp] = (signed char)term;
   iterations[lp] = iter;
   final_cost[lp] = cost;
