@@ -96,6 +96,17 @@ __global__ __launch_bounds__(256) void inner_eval_kernel(DeviceView v, InnerSet 
 #pragma unroll
     for (int i = 0; i < 10; ++i) Kv[i] = (i < nk) ? Kp[i] : 0.0;
   }
+  // the view's camera is fixed over this pass: its prepared record (camera_models.h: R, C, K and the
+  // left Jacobian of SO(3), unit column scales) is built once per workgroup instead of running
+  // Rodrigues' formula per observation
+  __shared__ double Pcam[kPrepStride];
+  if (threadIdx.x == 0) {
+    double ones[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ones[i] = 1.0;
+    prepare_camera_record(E, Kv, 10, ones, Pcam);
+  }
+  __syncthreads();
   signed char cols[NMAX];
 #pragma unroll
   for (int a = 0; a < NMAX; ++a) cols[a] = (a < n) ? S.blk_cols[b * kInnerMaxN + a] : (signed char)0;
@@ -110,8 +121,8 @@ __global__ __launch_bounds__(256) void inner_eval_kernel(DeviceView v, InnerSet 
 #pragma unroll
     for (int i = 0; i < 4; ++i) X[i] = v.pts_c[(size_t)lp * 4 + i];
     double r[2], Jext[2][6], Jint[2][10], Jpt[2][4];
-    const bool ok = reprojection_error<JAC, double>(model, E, Kv, X, v.obs_xy[2 * (size_t)e],
-                                                    v.obs_xy[2 * (size_t)e + 1], r, Jext, Jint, Jpt);
+    const bool ok = reprojection_error_prepared<JAC, double>(model, Pcam, X, v.obs_xy[2 * (size_t)e],
+                                                             v.obs_xy[2 * (size_t)e + 1], r, Jext, Jint, Jpt);
     if (!ok) {
       bad = true;
       continue;
