@@ -570,6 +570,19 @@ __device__ __forceinline__ double project_point_depth(int model, const double* e
   return q[2] / X[3];
 }
 
+// Camera::ProjectPoint on a prepared record (R, C, K): pixel only, no degenerate-point test
+__device__ __forceinline__ void project_point_prepared(int model, const double* P, const double* X, double px[2]) {
+  const double a[3] = {X[0] - X[3] * P[9], X[1] - X[3] * P[10], X[2] - X[3] * P[11]};
+  double q[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) q[i] = P[3 * i] * a[0] + P[3 * i + 1] * a[1] + P[3 * i + 2] * a[2];
+  double Kt[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) Kt[i] = P[12 + i];
+  double dpdq[2][3], dpdK[2][10];
+  project<false, double>(model, Kt, q, px, dpdq, dpdK);
+}
+
 // ceres/loss_function.cc (1.x) restated for the device: rho, rho', rho''.
 __device__ __forceinline__ void loss_eval(int type, double a, double s, double rho[3]) {
   switch (type) {

@@ -328,6 +328,7 @@ struct tmi_ba_solver {
   unsigned long long* d_vt_keys = nullptr;  // [No_pad] (view << 32 | track) sorted; static per handle
   long long* d_vt_ptr = nullptr;          // [Nc + 1]
   unsigned char* d_view_mask = nullptr;   // [Nc]
+  int* d_vcount = nullptr;                // [2 Nc]: selected tracks per view after the grid phase | views needing a top-up
   // device-built structure (structure_gpu.h): the big layout arrays exist in HBM only; host copies
   // are fetched on demand (inner iterations, tmi_ba_solver_evaluate)
   bool device_structure = false;
@@ -2435,8 +2436,9 @@ int32_t tmi_ba_solver_select_good_tracks(tmi_ba_solver* s, int32_t long_track_le
   TMI_HIP(hipEventCreate(&ea));
   TMI_HIP(hipEventCreate(&eb));
   TMI_HIP(hipEventRecord(ea, s->stream));
+  prepare_cameras(s, s->v.ext, s->v.intr, s->v.prep);
   if (st.nslices > 0)
-    hipLaunchKernelGGL(track_stats_kernel, dim3(s->nblocks_slices), dim3(256), 0, s->stream, s->v,
+    hipLaunchKernelGGL(track_stats_kernel, dim3(s->nblocks_tracks), dim3(256), 0, s->stream, s->v, s->v.prep,
                        s->d_trk_iter, s->d_trk_mean);
   TMI_HIP(hipEventRecord(eb, s->stream));
   const int Np = st.Np_total, Nc = st.Nc;
@@ -2449,6 +2451,7 @@ int32_t tmi_ba_solver_select_good_tracks(tmi_ba_solver* s, int32_t long_track_le
     if ((rc = dev_alloc(s, &s->d_cell_off, (size_t)Nc + 2))) return rc;
     if ((rc = dev_alloc(s, &s->d_sel, (size_t)std::max(Np, 1)))) return rc;
     if ((rc = dev_alloc(s, &s->d_view_mask, (size_t)std::max(Nc, 1)))) return rc;
+    if ((rc = dev_alloc(s, &s->d_vcount, (size_t)2 * std::max(Nc, 1)))) return rc;
     if (st.No_pad > 0) {
       unsigned long long* keys_in = nullptr;
       TMI_HIP(hipMalloc((void**)&keys_in, (size_t)st.No_pad * sizeof(unsigned long long)));
@@ -2485,7 +2488,7 @@ int32_t tmi_ba_solver_select_good_tracks(tmi_ba_solver* s, int32_t long_track_le
   S.counters = s->d_counters;
   const int nb_init = (std::max(std::max(Nc, Np), 4) + 255) / 256;
   hipLaunchKernelGGL(select_init_kernel, dim3(nb_init), dim3(256), 0, stream, S);
-  if (st.nslices > 0) hipLaunchKernelGGL(select_bounds_kernel, dim3(s->nblocks_slices), dim3(256), 0, stream, s->v, S);
+  if (st.nslices > 0) hipLaunchKernelGGL(select_bounds_kernel, dim3(s->nblocks_tracks), dim3(256), 0, stream, s->v, S);
   hipLaunchKernelGGL(select_offsets_kernel, dim3(1), dim3(1024), 0, stream, S);
   TMI_HIP(hipMemcpyAsync(s->h_cell_total, s->d_cell_off + Nc, sizeof(long long), hipMemcpyDeviceToHost, stream));
   TMI_HIP(hipStreamSynchronize(stream));
@@ -2516,14 +2519,29 @@ int32_t tmi_ba_solver_select_good_tracks(tmi_ba_solver* s, int32_t long_track_le
   if (ncells > 0) {
     const unsigned nbc = (unsigned)((ncells + 255) / 256);
     hipLaunchKernelGGL(select_fill_cells_kernel, dim3(nbc), dim3(256), 0, stream, S, ncells);
-    hipLaunchKernelGGL(select_cells_kernel<1>, dim3(s->nblocks_slices), dim3(256), 0, stream, s->v, S);
-    hipLaunchKernelGGL(select_cells_kernel<2>, dim3(s->nblocks_slices), dim3(256), 0, stream, s->v, S);
-    hipLaunchKernelGGL(select_cells_kernel<3>, dim3(s->nblocks_slices), dim3(256), 0, stream, s->v, S);
+    hipLaunchKernelGGL(select_cells_kernel<1>, dim3(s->nblocks_tracks), dim3(256), 0, stream, s->v, S);
+    hipLaunchKernelGGL(select_cells_kernel<2>, dim3(s->nblocks_tracks), dim3(256), 0, stream, s->v, S);
+    hipLaunchKernelGGL(select_cells_kernel<3>, dim3(s->nblocks_tracks), dim3(256), 0, stream, s->v, S);
     hipLaunchKernelGGL(select_mark_kernel, dim3(nbc), dim3(256), 0, stream, S, ncells);
   }
-  if (Nc > 0 && st.No_pad > 0)
-    hipLaunchKernelGGL(select_topup_kernel, dim3(1), dim3(kTopupThreads), 0, stream, S, s->d_vt_keys, s->d_vt_ptr,
-                       min_num_optimized_tracks_per_view);
+  if (Nc > 0 && st.No_pad > 0) {
+    hipLaunchKernelGGL(select_view_count_kernel, dim3(Nc), dim3(256), 0, stream, S, s->d_vt_keys, s->d_vt_ptr, s->d_vcount);
+    // the flags of all tracks as a bit vector in LDS when they fit beside the kernel's static 4 KB
+    const size_t bit_bytes = ((size_t)Np + 31) / 32 * 4;
+    if (bit_bytes <= 152 * 1024) {
+      static bool attr_set = false;
+      if (!attr_set) {
+        TMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&select_topup_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(select_topup_kernel<true>, dim3(1), dim3(kTopupThreads), bit_bytes, stream, S, s->d_vt_keys,
+                         s->d_vt_ptr, s->d_vcount, s->d_vcount + Nc, min_num_optimized_tracks_per_view);
+    } else {
+      hipLaunchKernelGGL(select_topup_kernel<false>, dim3(1), dim3(kTopupThreads), 0, stream, S, s->d_vt_keys, s->d_vt_ptr,
+                         s->d_vcount, s->d_vcount + Nc, min_num_optimized_tracks_per_view);
+    }
+  }
   if (Np > 0) hipLaunchKernelGGL(select_finish_kernel, dim3((Np + 255) / 256), dim3(256), 0, stream, S, s->d_out_u8);
   if ((stats_len || stats_err) && st.Np_pad > 0) {
     // tracks without observations keep length 0 / NaN error

@@ -59,22 +59,21 @@ __global__ __launch_bounds__(256) void select_init_kernel(SelectView S) {
 
 // pass 0: cell bounding box of every view
 __global__ __launch_bounds__(256) void select_bounds_kernel(DeviceView v, SelectView S) {
-  const int lane = threadIdx.x & 63;
-  const int s = blockIdx.x * kSlicesPerBlock + (threadIdx.x >> 6);
-  if (s >= v.nslices) return;
-  const int lp = s * 64 + lane;
-  const int k = v.pt_k[lp];
-  const size_t base = (size_t)v.slice_ptr[s] + lane;
-  for (int j = 0; j < k; ++j) {
-    const size_t e = base + (size_t)j * 64;
+  const TrackMap tm = track_map(v);
+  if (!tm.valid) return;
+  for (int j = tm.j0; j < tm.k; j += tm.jstep) {
+    const size_t e = tm.base + (size_t)j * 64;
     const int cam = v.obs_cam[e];
     if (S.view_mask && !S.view_mask[cam]) continue;
     int cx, cy;
     feature_cell(v, S, e, &cx, &cy);
-    atomicMin(&S.vbox[4 * cam + 0], cx);
-    atomicMax(&S.vbox[4 * cam + 1], cx);
-    atomicMin(&S.vbox[4 * cam + 2], cy);
-    atomicMax(&S.vbox[4 * cam + 3], cy);
+    // the boxes settle after a few hundred observations: look before the atomic (a stale value only
+    // costs an atomic that changes nothing)
+    int* box = S.vbox + 4 * cam;
+    if (cx < __atomic_load_n(box + 0, __ATOMIC_RELAXED)) atomicMin(box + 0, cx);
+    if (cx > __atomic_load_n(box + 1, __ATOMIC_RELAXED)) atomicMax(box + 1, cx);
+    if (cy < __atomic_load_n(box + 2, __ATOMIC_RELAXED)) atomicMin(box + 2, cy);
+    if (cy > __atomic_load_n(box + 3, __ATOMIC_RELAXED)) atomicMax(box + 3, cy);
   }
 }
 
@@ -117,17 +116,16 @@ __global__ __launch_bounds__(256) void select_fill_cells_kernel(SelectView S, lo
 // passes 1..3: lexicographic minimum of (truncated length, mean error, track index) per cell
 template <int PASS>
 __global__ __launch_bounds__(256) void select_cells_kernel(DeviceView v, SelectView S) {
-  const int lane = threadIdx.x & 63;
-  const int s = blockIdx.x * kSlicesPerBlock + (threadIdx.x >> 6);
-  if (s >= v.nslices) return;
-  const int lp = s * 64 + lane;
-  const int k = v.pt_k[lp];
+  const TrackMap tm = track_map(v);
+  if (!tm.valid) return;
+  const int lp = tm.lp;
+  const int k = tm.k;
   if (k == 0) return;
   const int p = S.pt_orig[lp];
   const unsigned tlen = (unsigned)min(S.cnt[lp], S.long_thr);
   const unsigned long long ebits = (unsigned long long)__double_as_longlong(S.mean[lp]);
-  const size_t base = (size_t)v.slice_ptr[s] + lane;
-  for (int j = 0; j < k; ++j) {
+  const size_t base = tm.base;
+  for (int j = tm.j0; j < k; j += tm.jstep) {
     const size_t e = base + (size_t)j * 64;
     const int cam = v.obs_cam[e];
     if (S.view_mask && !S.view_mask[cam]) continue;
@@ -135,12 +133,16 @@ __global__ __launch_bounds__(256) void select_cells_kernel(DeviceView v, SelectV
     feature_cell(v, S, e, &cx, &cy);
     const long long w = (long long)S.vbox[4 * cam + 1] - S.vbox[4 * cam + 0] + 1;
     const long long slot = S.cell_off[cam] + (long long)(cy - S.vbox[4 * cam + 2]) * w + (cx - S.vbox[4 * cam + 0]);
+    // look before the atomic: most candidates lose against what the cell already holds
     if (PASS == 1) {
-      atomicMin(&S.cell_len[slot], tlen);
+      if (tlen < __atomic_load_n(&S.cell_len[slot], __ATOMIC_RELAXED)) atomicMin(&S.cell_len[slot], tlen);
     } else if (PASS == 2) {
-      if (S.cell_len[slot] == tlen) atomicMin(&S.cell_err[slot], ebits);
+      if (S.cell_len[slot] == tlen && ebits < __atomic_load_n(&S.cell_err[slot], __ATOMIC_RELAXED))
+        atomicMin(&S.cell_err[slot], ebits);
     } else {
-      if (S.cell_len[slot] == tlen && S.cell_err[slot] == ebits) atomicMin(&S.cell_trk[slot], (unsigned)p);
+      if (S.cell_len[slot] == tlen && S.cell_err[slot] == ebits &&
+          (unsigned)p < __atomic_load_n(&S.cell_trk[slot], __ATOMIC_RELAXED))
+        atomicMin(&S.cell_trk[slot], (unsigned)p);
     }
   }
 }
@@ -187,12 +189,34 @@ __global__ __launch_bounds__(256) void select_view_ptr_kernel(const unsigned lon
 // Top-up (:201-249): ONE workgroup visits the views in ascending order; a view with fewer than
 // min_opt selected tracks (and unselected ones left) takes its lowest-index unselected tracks.
 constexpr int kTopupThreads = 1024;
-constexpr int kTopupPerThread = 8;  // views with more than 8192 tracks loop in chunks
+constexpr int kTopupPerThread = 8;  // slow path (views beyond the one-pass size): chunks of kTopupThreads * 8 tracks
 
+// Selected tracks per view after the grid phase (one workgroup per view).  Selections only grow, so a
+// view that already has its minimum here never needs the sequential top-up below.
+__global__ __launch_bounds__(256) void select_view_count_kernel(SelectView S, const unsigned long long* __restrict__ keys,
+                                                                const long long* __restrict__ vt_ptr,
+                                                                int* __restrict__ vcount) {
+  __shared__ int ws[4];
+  const int c = blockIdx.x;
+  const long long b = vt_ptr[c], e = vt_ptr[c + 1];
+  int mine = 0;
+  for (long long q = b + threadIdx.x; q < e; q += 256) mine += (int)S.sel[(unsigned)(keys[q] & 0xffffffffu)];
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) vcount[c] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// BITS: the selection flags of all tracks live in LDS as a bit vector for the duration of the kernel
+// (Np / 8 bytes of dynamic LDS: 124 KB for a million tracks; the host picks the variant by size), so the
+// per-view gather of flags -- the latency that sets the pace of this one-workgroup kernel -- never
+// leaves the CU.  New selections are also stored to the global flags (write-only here).
+template <bool BITS>
 __global__ __launch_bounds__(kTopupThreads) void select_topup_kernel(SelectView S,
                                                                      const unsigned long long* __restrict__ keys,
                                                                      const long long* __restrict__ vt_ptr,
-                                                                     int min_opt) {
+                                                                     const int* __restrict__ vcount,
+                                                                     int* __restrict__ needy, int min_opt) {
   __shared__ int wsum[kTopupThreads / 64];
   __shared__ int sh_total;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -223,14 +247,112 @@ __global__ __launch_bounds__(kTopupThreads) void select_topup_kernel(SelectView 
     *total = tot;
     return before + inc - x;
   };
-  for (int c = 0; c < S.Nc; ++c) {
-    if (S.view_mask && !S.view_mask[c]) continue;
+  extern __shared__ unsigned sel_bits[];
+  if (BITS) {
+    const int nwords = (S.Np_total + 31) / 32;
+    for (int wd = tid; wd < nwords; wd += kTopupThreads) {
+      unsigned m = 0;
+      const int p0 = wd * 32;
+      if (p0 + 32 <= S.Np_total) {
+        const uint4* src = reinterpret_cast<const uint4*>(S.sel + p0);  // 32 flags of 4 bytes, 16-byte aligned
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+          const uint4 u = src[h];
+          if (u.x) m |= 1u << (4 * h);
+          if (u.y) m |= 1u << (4 * h + 1);
+          if (u.z) m |= 1u << (4 * h + 2);
+          if (u.w) m |= 1u << (4 * h + 3);
+        }
+      } else {
+        for (int i = 0; p0 + i < S.Np_total; ++i)
+          if (S.sel[p0 + i]) m |= 1u << i;
+      }
+      sel_bits[wd] = m;
+    }
+    __syncthreads();
+  }
+  auto is_selected = [&](unsigned t) -> bool {
+    return BITS ? ((sel_bits[t >> 5] >> (t & 31)) & 1u) != 0 : S.sel[t] != 0;
+  };
+  auto select = [&](unsigned t) {
+    if (BITS) atomicOr(&sel_bits[t >> 5], 1u << (t & 31));
+    S.sel[t] = 1u;
+  };
+  // the views that may need a top-up, ascending: everything else is skipped without touching memory
+  __shared__ int n_needy_sh;
+  int n_needy = 0;
+  for (int c0 = 0; c0 < S.Nc; c0 += kTopupThreads) {
+    const int c = c0 + tid;
+    int want = 0;
+    if (c < S.Nc && !(S.view_mask && !S.view_mask[c])) {
+      const int n = (int)(vt_ptr[c + 1] - vt_ptr[c]);
+      want = (n > 0 && vcount[c] < min_opt && vcount[c] < n) ? 1 : 0;
+    }
+    int total = 0;
+    const int pos = block_scan(want, &total);
+    if (want) needy[n_needy + pos] = c;
+    n_needy += total;
+  }
+  if (tid == 0) n_needy_sh = n_needy;
+  __threadfence_block();
+  __syncthreads();
+  n_needy = n_needy_sh;
+  // Views of up to kTopupThreads * kTopupFast tracks take ONE pass: every thread holds its tracks and
+  // their flags in registers, one block scan gives both the count of selected tracks and the ranks of
+  // the unselected ones; the track ids of the next view are fetched while this one is decided (they do
+  // not depend on the flags).  The views are a dependent chain (a top-up changes the counts of the views
+  // after it), so this kernel is one workgroup and its time is views x (one gather + one scan).
+  constexpr int kTopupFast = 4;
+  unsigned nx_trk[kTopupFast];
+  auto fetch = [&](int w, unsigned (&trk)[kTopupFast]) {
+#pragma unroll
+    for (int i = 0; i < kTopupFast; ++i) trk[i] = 0xffffffffu;
+    if (w >= n_needy) return;
+    const int c = needy[w];
+    const long long b = vt_ptr[c], e = vt_ptr[c + 1];
+    if (e - b > (long long)kTopupThreads * kTopupFast) return;
+#pragma unroll
+    for (int i = 0; i < kTopupFast; ++i) {
+      const long long q = b + (long long)tid * kTopupFast + i;
+      if (q < e) trk[i] = (unsigned)(keys[q] & 0xffffffffu);
+    }
+  };
+  fetch(0, nx_trk);
+  for (int w = 0; w < n_needy; ++w) {
+    const int c = needy[w];
     const long long b = vt_ptr[c], e = vt_ptr[c + 1];
     const int n = (int)(e - b);
-    if (n == 0) continue;
+    if (n <= kTopupThreads * kTopupFast) {
+      unsigned trk[kTopupFast];
+      int uns[kTopupFast], local = 0;
+#pragma unroll
+      for (int i = 0; i < kTopupFast; ++i) {
+        trk[i] = nx_trk[i];
+        uns[i] = (trk[i] != 0xffffffffu && !is_selected(trk[i])) ? 1 : 0;
+        local += uns[i];
+      }
+      fetch(w + 1, nx_trk);
+      int total = 0;
+      int rank = block_scan(local, &total);
+      const int num_opt = n - total;
+      if (num_opt < min_opt && total > 0) {
+        const int needed = min(min_opt - num_opt, total);
+#pragma unroll
+        for (int i = 0; i < kTopupFast; ++i) {
+          if (uns[i]) {
+            if (rank < needed) select(trk[i]);
+            ++rank;
+          }
+        }
+      }
+      __threadfence_block();
+      __syncthreads();
+      continue;
+    }
+    fetch(w + 1, nx_trk);
     // count the selected tracks of the view
     int mine = 0;
-    for (long long q = b + tid; q < e; q += kTopupThreads) mine += (int)S.sel[(unsigned)(keys[q] & 0xffffffffu)];
+    for (long long q = b + tid; q < e; q += kTopupThreads) mine += is_selected((unsigned)(keys[q] & 0xffffffffu)) ? 1 : 0;
     const int num_opt = block_sum(mine);
     if (num_opt >= min_opt || num_opt == n) continue;
     int needed = min(min_opt - num_opt, n - num_opt);
@@ -245,7 +367,7 @@ __global__ __launch_bounds__(kTopupThreads) void select_topup_kernel(SelectView 
         uns[i] = 0;
         if (q < e) {
           trk[i] = (unsigned)(keys[q] & 0xffffffffu);
-          uns[i] = S.sel[trk[i]] ? 0 : 1;
+          uns[i] = is_selected(trk[i]) ? 0 : 1;
         }
         local += uns[i];
       }
@@ -254,7 +376,7 @@ __global__ __launch_bounds__(kTopupThreads) void select_topup_kernel(SelectView 
 #pragma unroll
       for (int i = 0; i < kTopupPerThread; ++i) {
         if (uns[i]) {
-          if (rank < needed) S.sel[trk[i]] = 1u;
+          if (rank < needed) select(trk[i]);
           ++rank;
         }
       }
@@ -275,7 +397,13 @@ __global__ __launch_bounds__(256) void select_finish_kernel(SelectView S, unsign
     out_sel[p] = (unsigned char)one;
   }
   for (int o = 32; o > 0; o >>= 1) one += __shfl_xor(one, o, 64);
-  if ((threadIdx.x & 63) == 0 && one) atomicAdd(&S.counters[1], one);
+  __shared__ int ws[4];
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = one;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int t = ws[0] + ws[1] + ws[2] + ws[3];
+    if (t) atomicAdd(&S.counters[1], t);
+  }
 }
 
 __global__ __launch_bounds__(256) void scatter_track_stats_kernel(const int* __restrict__ pt_orig, int n_pad,

@@ -108,35 +108,31 @@ __global__ __launch_bounds__(256) void outlier_filter_kernel(DeviceView v, doubl
 // (select_good_tracks_for_bundle_adjustment.cc:81-110): number of observations and mean
 // squared reprojection error per track -- every observation counts, no cheirality test.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void track_stats_kernel(DeviceView v, int* __restrict__ count,
-                                                          double* __restrict__ mean_sq) {
-  const int lane = threadIdx.x & 63;
-  const int s = blockIdx.x * kSlicesPerBlock + (threadIdx.x >> 6);
-  if (s >= v.nslices) return;
-  const int lp = s * 64 + lane;
-  const int k = v.pt_k[lp];
-  const size_t base = (size_t)v.slice_ptr[s] + lane;
+__global__ __launch_bounds__(256) void track_stats_kernel(DeviceView v, const double* __restrict__ prep,
+                                                          int* __restrict__ count, double* __restrict__ mean_sq) {
+  // thread per track, 16 lanes per track on the long slices (kernels.h track_map); cameras from their
+  // prepared records (the rotation matrix instead of Rodrigues per observation)
+  const TrackMap tm = track_map(v);
+  if (!tm.valid) return;
+  const int lp = tm.lp;
+  const int k = tm.k;
   double X[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) X[i] = v.pts[(size_t)lp * 4 + i];
   double sum = 0.0;
-  for (int j = 0; j < k; ++j) {
-    const size_t e = base + (size_t)j * 64;
+  for (int j = tm.j0; j < k; j += tm.jstep) {
+    const size_t e = tm.base + (size_t)j * 64;
     const int cam = v.obs_cam[e];
-    const int grp = v.cam_grp[cam];
-    const double* Kp = v.intr + v.grp_off[grp];
-    const int nk = v.grp_off[grp + 1] - v.grp_off[grp];
-    double Kv[10], E[6], px[2];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) Kv[i] = (i < nk) ? Kp[i] : 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) E[i] = v.ext[(size_t)cam * 6 + i];
-    project_point_depth(v.grp_model[grp], E, Kv, X, px);
+    double px[2];
+    project_point_prepared(v.cam_rec[cam].x, prep + (size_t)cam * kPrepStride, X, px);
     const double dx = px[0] - v.obs_xy[2 * e], dy = px[1] - v.obs_xy[2 * e + 1];
     sum += dx * dx + dy * dy;
   }
-  count[lp] = k;
-  mean_sq[lp] = sum / (double)k;
+  sum = group_sum(sum, tm.wide);
+  if (tm.leader) {
+    count[lp] = k;
+    mean_sq[lp] = sum / (double)k;
+  }
 }
 
 // ------------------------------------------------------------------------------------
