@@ -75,6 +75,7 @@ struct DeviceView {
   const int* grp_cam_ptr;      // views of each shared block
   const int* grp_cams;
   const signed char* rb_cols;  // [Nrb][D]
+  int write_y;                 // point_eliminate writes the Y records (explicit S, or shared intrinsics blocks)
   const int* cam_ptr;
   const int* urow_ptr;
   const int* ub_i;

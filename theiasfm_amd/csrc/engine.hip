@@ -1249,7 +1249,8 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   AL(v.pm_r, 2 * N) AL(v.pm_A, 2 * D * N) AL(v.pm_Jp, 2 * DP * N) AL(s->d_pm_u, 2 * N)
   AL(s->d_cm_t, s->implicit ? (size_t)std::max<int64_t>(st.Nslots, 1) * 2 : 1)
   AL(v.pm_A1, st.has_shared ? 2 * D * N : 1) AL(v.cam_part, (size_t)std::max(st.Ncam_rb, 1) * (2 * D * D + 3 * D))
-  AL(v.cm_Y, (size_t)std::max<int64_t>(st.Nslots, 1) * YS) AL(v.cm_A, (size_t)std::max<int64_t>(st.Nslots, 1) * AS)
+  v.write_y = (!s->implicit || st.has_shared) ? 1 : 0;
+  AL(v.cm_Y, v.write_y ? (size_t)std::max<int64_t>(st.Nslots, 1) * YS : 1) AL(v.cm_A, (size_t)std::max<int64_t>(st.Nslots, 1) * AS)
   AL(v.scale_c, std::max(n_r, 1)) AL(v.scale_p, NP * DP)
   AL(v.Vinv, NP * NS) AL(v.gp, NP * DP) AL(v.diag_p, NP * DP) AL(v.yp, NP * DP)
   AL(v.red, s->RL.total) AL(v.Sdiag, (size_t)std::max(st.Nrb, 1) * D * D)
@@ -1267,7 +1268,7 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   TMI_HIP(hipMemsetAsync(v.cg_q, 0, (size_t)(n_r + 8) * sizeof(double), s->stream));
   TMI_HIP(hipMemsetAsync(v.yc, 0, std::max(n_r, 1) * sizeof(double), s->stream));
   TMI_HIP(hipMemsetAsync(v.red, 0, s->RL.total * sizeof(double), s->stream));
-  TMI_HIP(hipMemsetAsync(v.cm_Y, 0, (size_t)std::max<int64_t>(st.Nslots, 1) * YS * sizeof(double), s->stream));
+  TMI_HIP(hipMemsetAsync(v.cm_Y, 0, (v.write_y ? (size_t)std::max<int64_t>(st.Nslots, 1) * YS : 1) * sizeof(double), s->stream));
   TMI_HIP(hipMemsetAsync(v.cm_A, 0, (size_t)std::max<int64_t>(st.Nslots, 1) * AS * sizeof(double), s->stream));
   TMI_HIP(hipStreamSynchronize(s->stream));
   s->setup_seconds = now_s() - t0;

@@ -871,10 +871,11 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
       }
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
-        // Y records of lanes [32 half, 32 half + 32)
+        // Y records of lanes [32 half, 32 half + 32) -- only the explicit Schur complement (and the
+        // shared-block sums) read them; the matrix-free operator works from the A records
         if ((lane >> 5) == half) {
           scp[lane & 31] = cpos;
-          if (cpos >= 0) {
+          if (cpos >= 0 && v.write_y) {
 #pragma unroll
             for (int i = 0; i < YS; i += 2)
               *reinterpret_cast<double2*>(st + (lane & 31) * STP + i) = make_double2(Yv[i], Yv[i + 1]);
@@ -883,11 +884,13 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int c = lane; c < 32 * (YS / 2); c += 64) {
-          const int rec = c / (YS / 2), part = c - rec * (YS / 2);
-          const int cp = scp[rec];
-          if (cp >= 0)
-            store_nt(v.cm_Y + (size_t)cp * YS + 2 * part, st + rec * STP + 2 * part);
+        if (v.write_y) {
+          for (int c = lane; c < 32 * (YS / 2); c += 64) {
+            const int rec = c / (YS / 2), part = c - rec * (YS / 2);
+            const int cp = scp[rec];
+            if (cp >= 0)
+              store_nt(v.cm_Y + (size_t)cp * YS + 2 * part, st + rec * STP + 2 * part);
+          }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
