@@ -31,11 +31,14 @@ constexpr int kSpmvTrips = 8;
 // >= 5000 slices (structure.cpp)
 constexpr int kWideK = 12;
 constexpr int kWideKLarge = 20;
+// ... and slices whose longest track has at least this many with 64 lanes (a whole wavefront) per track
+constexpr int kUltraK = 96;
 
 struct DeviceView {
   int Nc, G, Np_pad, nslices, Nrb, D, DP;
-  int n_wide;          // leading slices run with 16 lanes per track
-  int n_track_blocks;  // grid of the per-track kernels: 4 n_wide + ceil((nslices - n_wide) / 4)
+  int n_ultra;         // leading slices run with 64 lanes per track (n_ultra <= n_wide)
+  int n_wide;          // leading slices run with 16 (the first n_ultra: 64) lanes per track
+  int n_track_blocks;  // grid of the per-track kernels: 16 n_ultra + 4 (n_wide - n_ultra) + ceil((nslices - n_wide) / 4)
   int Ncam_rb;     // blocks [0, Ncam_rb) are cameras, [Ncam_rb, Nrb) shared intrinsics groups
   int has_shared;
   int No_pad;

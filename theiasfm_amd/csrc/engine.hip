@@ -658,6 +658,10 @@ static int build_structure_device(tmi_ba_solver* s, const tmi_ba_problem* P, boo
     int wide_k = st.nslices >= 5000 ? kWideKLarge : kWideK;
     if (const char* e = getenv("TMI_BA_WIDE_K")) wide_k = std::max(1, atoi(e));
     while (st.n_wide < st.nslices && ((st.slice_ptr[st.n_wide + 1] - st.slice_ptr[st.n_wide]) >> 6) >= wide_k) ++st.n_wide;
+    int ultra_k = kUltraK;
+    if (const char* e = getenv("TMI_BA_ULTRA_K")) ultra_k = std::max(1, atoi(e));
+    st.n_ultra = 0;
+    while (st.n_ultra < st.n_wide && ((st.slice_ptr[st.n_ultra + 1] - st.slice_ptr[st.n_ultra]) >> 6) >= ultra_k) ++st.n_ultra;
   }
   st.No_pad = st.slice_ptr[st.nslices];
   st.No = No;
@@ -1232,7 +1236,8 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   s->nblocks_points = (st.Np_pad + 255) / 256;
   if (s->nblocks_points < 1) s->nblocks_points = 1;
   v.n_wide = st.n_wide;
-  v.n_track_blocks = 4 * st.n_wide + (st.nslices - st.n_wide + kSlicesPerBlock - 1) / kSlicesPerBlock;
+  v.n_ultra = st.n_ultra;
+  v.n_track_blocks = 16 * st.n_ultra + 4 * (st.n_wide - st.n_ultra) + (st.nslices - st.n_wide + kSlicesPerBlock - 1) / kSlicesPerBlock;
   s->nblocks_tracks = std::max(v.n_track_blocks, 1);
   const int nbmax = std::max(std::max(s->nblocks_slices, s->nblocks_tracks), s->nblocks_points);
 #define AL(ptr, n) if ((rc = dev_alloc(s, &ptr, (size_t)(n)))) return rc;

@@ -120,9 +120,13 @@ __device__ __forceinline__ bool take_ticket(int* ticket, int nblocks) {
 // longest track has >= kWideK observations) are therefore run "wide": a track is shared by
 // 16 consecutive lanes (lane i takes observations i, i + 16, ...), per-track sums are
 // finished with a fixed 16-lane butterfly, and a 256-thread workgroup covers a quarter of a
-// slice.  All other slices keep the thread-per-track mapping (workgroup = 4 slices).
-//   grid = 4 * n_wide + ceil((nslices - n_wide) / 4)        (DeviceView::n_track_blocks)
-// Which slices are wide depends on the slice only (never on the rank count), so the
+// slice.  The first v.n_ultra of those (longest track >= kUltraK) give every track a whole
+// wavefront (lane i takes observations i, i + 64, ...; a workgroup covers four tracks): a
+// 400-view track is 7 trips instead of 25, which is what the per-track kernels cost once the
+// tracks are spread over 8 GPUs.  All other slices keep the thread-per-track mapping
+// (workgroup = 4 slices).
+//   grid = 16 n_ultra + 4 (n_wide - n_ultra) + ceil((nslices - n_wide) / 4)   (DeviceView::n_track_blocks)
+// Which mapping a slice gets depends on the slice only (never on the rank count), so the
 // summation order of a track is the same in a sharded and an unsharded run.
 // ------------------------------------------------------------------------------
 constexpr int kWideLanes = 16;
@@ -134,23 +138,33 @@ struct TrackMap {
   size_t base;  // element of observation 0: slice_ptr[s] + t; observation j at base + 64 j
   int j0, jstep;  // this lane's observations j0, j0 + jstep, ...
   int trips;    // wave-uniform trip count covering the slice
-  bool wide, leader, valid;
+  int wide;     // 0: thread per track, 1: 16 lanes per track, 2: 64 lanes per track
+  bool leader, valid;
 };
 
 __device__ __forceinline__ TrackMap track_map(const DeviceView& v) {
   TrackMap m;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int nwb = 4 * v.n_wide;
+  const int nub = 16 * v.n_ultra;
+  const int nwb = nub + 4 * (v.n_wide - v.n_ultra);
   int t;
-  if ((int)blockIdx.x < nwb) {
-    m.wide = true;
-    m.s = blockIdx.x >> 2;
-    t = 16 * (blockIdx.x & 3) + 4 * w + (lane >> 4);
+  if ((int)blockIdx.x < nub) {
+    m.wide = 2;
+    m.s = blockIdx.x >> 4;
+    t = 4 * (blockIdx.x & 15) + w;
+    m.j0 = lane;
+    m.jstep = 64;
+    m.leader = lane == 0;
+  } else if ((int)blockIdx.x < nwb) {
+    m.wide = 1;
+    const int bw = (int)blockIdx.x - nub;
+    m.s = v.n_ultra + (bw >> 2);
+    t = 16 * (bw & 3) + 4 * w + (lane >> 4);
     m.j0 = lane & (kWideLanes - 1);
     m.jstep = kWideLanes;
     m.leader = m.j0 == 0;
   } else {
-    m.wide = false;
+    m.wide = 0;
     m.s = v.n_wide + ((int)blockIdx.x - nwb) * kSlicesPerBlock + w;
     t = lane;
     m.j0 = 0;
@@ -167,19 +181,23 @@ __device__ __forceinline__ TrackMap track_map(const DeviceView& v) {
     const int sp0 = v.slice_ptr[m.s];
     m.base = (size_t)sp0 + t;
     const int K = (v.slice_ptr[m.s + 1] - sp0) >> 6;
-    m.trips = m.wide ? (K + kWideLanes - 1) / kWideLanes : K;
+    m.trips = m.wide == 2 ? (K + 63) / 64 : m.wide == 1 ? (K + kWideLanes - 1) / kWideLanes : K;
   }
   return m;
 }
 
 // sum over the 16 lanes that share a track (identity for thread-per-track slices); every lane
 // of the group receives the total; fixed butterfly => reproducible
-__device__ __forceinline__ double group_sum(double x, bool wide) {
+__device__ __forceinline__ double group_sum(double x, int wide) {
   if (wide) {
     x += __shfl_xor(x, 1, 64);
     x += __shfl_xor(x, 2, 64);
     x += __shfl_xor(x, 4, 64);
     x += __shfl_xor(x, 8, 64);
+    if (wide == 2) {
+      x += __shfl_xor(x, 16, 64);
+      x += __shfl_xor(x, 32, 64);
+    }
   }
   return x;
 }

@@ -339,6 +339,12 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, 
     if (!s.has_shared)
       while (s.n_wide < s.nslices && ((s.slice_ptr[s.n_wide + 1] - s.slice_ptr[s.n_wide]) >> 6) >= wide_k)
         ++s.n_wide;
+    // the very long tracks take a whole wavefront each: a 400-view track is 25 dependent trips with 16
+    // lanes, which alone is the run time of the per-track kernels once the tracks are spread over 8 GPUs
+    int ultra_k = kUltraK;
+    if (const char* e = std::getenv("TMI_BA_ULTRA_K")) ultra_k = std::max(1, std::atoi(e));
+    s.n_ultra = 0;
+    while (s.n_ultra < s.n_wide && ((s.slice_ptr[s.n_ultra + 1] - s.slice_ptr[s.n_ultra]) >> 6) >= ultra_k) ++s.n_ultra;
   }
   s.No_pad = s.slice_ptr[s.nslices];
   s.obs_cam.assign(s.No_pad, -1);

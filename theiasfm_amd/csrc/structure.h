@@ -62,6 +62,7 @@ struct Structure {
   std::vector<int> pt_k;          // [Np_pad] track length (0 = padding)
   std::vector<int> slice_ptr;     // [nslices+1]
   int n_wide = 0;                 // leading slices with >= kWideK observations per track (device_view.h)
+  int n_ultra = 0;                // leading slices with >= kUltraK observations per track (64 lanes per track)
   std::vector<int> obs_cam;       // [No_pad] camera or -1 (padding)
   std::vector<double> obs_xy;     // [2*No_pad]
   std::vector<int> obs_cpos;      // [No_pad] camera-major slot or -1
