@@ -70,3 +70,29 @@ def test_device_setup_reports_bad_input():
     r.obs_camera[3] = 99
     with pytest.raises(lib.EngineError):
         lib.Solver(r, abi.default_options(point_dof=3))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_device_built_shards_equal_host_built(world, monkeypatch):
+    """Sharded handles with the matrix-free operator (the default for world > 1) build their rank's
+    layout on the device: the same slices, the same arrays as structure.cpp's deal."""
+    p = synth.make_problem(40, 3000, 26000, seed=5, scene="ring", spread=0.5, heavy_tail=0.01)
+    p.point_constant[::13] = 1
+    keep = p.obs_point != 21  # an unobserved track: rank 0 answers for it
+    p.obs_camera, p.obs_point, p.obs_xy = p.obs_camera[keep].copy(), p.obs_point[keep].copy(), p.obs_xy[keep].copy()
+    opts = abi.default_options(point_dof=3, linear_solver_type=abi.ITERATIVE_SCHUR, schur_mode=abi.SCHUR_AUTO,
+                               use_inner_iterations=0)
+    total_tracks = 0
+    for rank in range(world):
+        monkeypatch.setenv("TMI_BA_HOST_SETUP", "1")
+        sh = lib.Solver(p.copy(), opts, rank, world)
+        cs_h = sh.structure_checksums()
+        sh.close()
+        monkeypatch.delenv("TMI_BA_HOST_SETUP")
+        sd = lib.Solver(p.copy(), opts, rank, world)
+        cs_d = sd.structure_checksums()
+        sd.close()
+        assert cs_h[0] == 0 and cs_d[0] == 1
+        for i in range(1, 24):
+            assert cs_h[i] == cs_d[i], f"rank {rank}/{world}: {NAMES[i]} differs between the host and the device builder"
+    del total_tracks

@@ -510,7 +510,9 @@ struct TempPool {
 
 static bool device_setup_possible(const Structure& st, int world, int64_t No, bool want_pairs) {
   if (getenv("TMI_BA_HOST_SETUP")) return false;
-  if (world != 1 || st.has_shared || st.Nc < 1 || st.Np_total < 1 || No < 1) return false;
+  // sharded handles: the block set of S is global, which the device pass over the local layout does not
+  // see -- they take the device path when S is not formed (the matrix-free operator, the default for world > 1)
+  if ((world != 1 && want_pairs) || st.has_shared || st.Nc < 1 || st.Np_total < 1 || No < 1) return false;
   if (No >= (int64_t)1 << 31) return false;
   if (want_pairs && (int64_t)st.Nrb * st.Nrb > ((int64_t)1 << 26)) return false;
   if (bits_for((unsigned)st.Nc) + bits_for((unsigned)st.Np_total) > 62) return false;
@@ -627,23 +629,54 @@ static int build_structure_device(tmi_ba_solver* s, const tmi_ba_problem* P, boo
     s->error = "a track is observed twice by the same view";
     return TMI_BA_ERR_INVALID_ARGUMENT;
   }
-  // ---- host: slices (O(#tracks))
+  // ---- host: slices (O(#tracks)); a sharded handle keeps the slices the longest-processing-time-first
+  // deal of structure.cpp gives its rank (same rule, same result)
   int n_active = 0;
   while (n_active < Np && klen[order[n_active]] > 0) ++n_active;
-  st.unobserved.assign(order.begin() + n_active, order.end());  // ascending (stable sort)
-  st.nslices = (n_active + 63) / 64;
+  st.unobserved.clear();
+  if (st.rank == 0) st.unobserved.assign(order.begin() + n_active, order.end());  // ascending (stable sort)
+  const int gslices = (n_active + 63) / 64;
+  std::vector<int> local_slices;
+  if (st.world > 1) {
+    std::vector<double> load((size_t)st.world, 0.0);
+    for (int gs = 0; gs < gslices; ++gs) {
+      double w = 0.0;
+      for (int t = 0; t < 64; ++t) {
+        const int idx = gs * 64 + t;
+        if (idx < n_active) {
+          const double k = klen[order[idx]];
+          w += 0.5 * k * (k - 1.0) + 5.0 * k;
+        }
+      }
+      int best = 0;
+      for (int r = 1; r < st.world; ++r)
+        if (load[r] < load[best]) best = r;
+      if (best == st.rank) local_slices.push_back(gs);
+      load[best] += w;
+    }
+  } else {
+    local_slices.resize((size_t)gslices);
+    for (int gs = 0; gs < gslices; ++gs) local_slices[gs] = gs;
+  }
+  st.nslices = (int)local_slices.size();
   st.Np_pad = st.nslices * 64;
-  st.Np = n_active;
+  st.Np = 0;
+  int64_t No_loc = 0;
   st.pt_orig.assign(st.Np_pad, -1);
   st.pt_k.assign(st.Np_pad, 0);
   st.pt_const.assign(st.Np_pad, 0);
   st.slice_ptr.assign(st.nslices + 1, 0);
-  for (int lp = 0; lp < n_active; ++lp) {
-    const int p = order[lp];
-    st.pt_orig[lp] = p;
-    st.pt_k[lp] = klen[p];
-    st.pt_const[lp] = (P->point_constant && P->point_constant[p]) ? 1 : 0;
-  }
+  for (int sl = 0; sl < st.nslices; ++sl)
+    for (int t = 0; t < 64; ++t) {
+      const int idx = local_slices[sl] * 64 + t;
+      if (idx >= n_active) continue;
+      const int p = order[idx], lp = sl * 64 + t;
+      st.pt_orig[lp] = p;
+      st.pt_k[lp] = klen[p];
+      st.pt_const[lp] = (P->point_constant && P->point_constant[p]) ? 1 : 0;
+      st.Np++;
+      No_loc += klen[p];
+    }
   for (int sl = 0; sl < st.nslices; ++sl) {
     const int K = st.pt_k[sl * 64];  // sorted by descending length: the slice's first track is its longest
     const int64_t next = (int64_t)st.slice_ptr[sl] + (int64_t)K * 64;
@@ -664,7 +697,7 @@ static int build_structure_device(tmi_ba_solver* s, const tmi_ba_problem* P, boo
     while (st.n_ultra < st.n_wide && ((st.slice_ptr[st.n_ultra + 1] - st.slice_ptr[st.n_ultra]) >> 6) >= ultra_k) ++st.n_ultra;
   }
   st.No_pad = st.slice_ptr[st.nslices];
-  st.No = No;
+  st.No = No_loc;
   const int64_t Npad = st.No_pad;
   {
     int* pi;
@@ -706,9 +739,9 @@ static int build_structure_device(tmi_ba_solver* s, const tmi_ba_problem* P, boo
   hipLaunchKernelGGL(layout_kernel, nb(st.Np_pad), dim3(256), 0, stream, st.Np_pad, s->d_pt_orig, v.pt_k, v.slice_ptr,
                      d_tptr, d_tobs, d_ocam, d_oxy, d_cam_rb, Nrb, d_tstart, d_obs_cam, d_obs_xy, s->d_obs_orig,
                      d_sk_in, d_se_in);
-  SG_SORT_PAIRS(d_sk_in, d_sk_out, d_se_in, d_se_out, No, bits_for((unsigned)Nrb + 1));
-  hipLaunchKernelGGL(slot_assign_kernel, nb(No), dim3(256), 0, stream, d_sk_out, d_se_out, (long long)No, Nrb, d_obs_cpos);
-  hipLaunchKernelGGL((lower_bound_kernel<unsigned, int>), nb(Nrb + 1), dim3(256), 0, stream, d_sk_out, (long long)No,
+  SG_SORT_PAIRS(d_sk_in, d_sk_out, d_se_in, d_se_out, No_loc, bits_for((unsigned)Nrb + 1));
+  hipLaunchKernelGGL(slot_assign_kernel, nb(No_loc), dim3(256), 0, stream, d_sk_out, d_se_out, (long long)No_loc, Nrb, d_obs_cpos);
+  hipLaunchKernelGGL((lower_bound_kernel<unsigned, int>), nb(Nrb + 1), dim3(256), 0, stream, d_sk_out, (long long)No_loc,
                      (long long)Nrb, d_cam_ptr);
   int nslots = 0;
   TMI_HIP(hipMemcpyAsync(&nslots, d_cam_ptr + Nrb, sizeof(int), hipMemcpyDeviceToHost, stream));
