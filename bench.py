@@ -318,7 +318,11 @@ def main():
                     solves=f"{-(-args.steps // max(1, args.solve_length))} x <= {args.solve_length} iterations from the "
                            "perturbed start, device-side reset in between (inside the timed region)",
                     schur_mode=args.schur_mode,
-                    schur_operator=("explicit block-sparse S" if explicit else "implicit (matrix-free)"),
+                    schur_operator=(("explicit block-sparse S; LM iterations whose forecast PCG length is below the "
+                                     "break-even of forming S run matrix-free (schur_mode auto on one rank)"
+                                     if (world == 1 and args.schur_mode == "auto" and solver_type == abi.ITERATIVE_SCHUR
+                                         and not os.environ.get("TMI_BA_NO_ADAPTIVE"))
+                                     else "explicit block-sparse S") if explicit else "implicit (matrix-free)"),
                     parallelism=f"tracks sharded x{world}", transport=m["transport"]),
         lm_iterations_per_sec=steps_run / elapsed,
         pcg_iterations=int(m["pcg"]),

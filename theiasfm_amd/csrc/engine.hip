@@ -266,6 +266,11 @@ struct tmi_ba_solver {
   double* d_pm_u = nullptr;
   double* d_cm_t = nullptr;   // implicit Schur operator: t_i per camera-major slot
   bool implicit = false;      // S is never formed (schur_mode)
+  bool adaptive = false;      // schur_mode auto on one rank: both operators are resident and every LM iteration
+                              // takes the cheaper one for the PCG length it expects (see solve)
+  bool implicit_now = false;  // the operator of the current LM iteration
+  int n_implicit_iterations = 0;
+  int adaptive_break_even = 4;  // PCG iterations up to which the matrix-free operator is the cheaper one
   double cur_inv_radius = 0.0;
   double time_vote = 0.0;     // this rank's "solver time exceeded" vote (source of a small async copy)
   const tmi_ba_options* cur_opts = nullptr;
@@ -1112,6 +1117,8 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   // implicit needs an iterative solver; auto = explicit on one GPU, implicit on several
   s->implicit = iterative_type && (O->schur_mode == 2 || (O->schur_mode == 0 && world > 1));
   if (light) s->implicit = false;
+  s->adaptive = !light && iterative_type && O->schur_mode == 0 && world == 1 && getenv("TMI_BA_NO_ADAPTIVE") == nullptr;
+  s->implicit_now = s->implicit;
   TMI_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   const bool want_pairs = !s->implicit && !light;
   const bool setup_timing = getenv("TMI_BA_SETUP_TIMING") != nullptr;
@@ -1285,9 +1292,15 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
     return TMI_BA_OK;
   }
   AL(v.pm_r, 2 * N) AL(v.pm_A, 2 * D * N) AL(v.pm_Jp, 2 * DP * N) AL(s->d_pm_u, 2 * N)
-  AL(s->d_cm_t, s->implicit ? (size_t)std::max<int64_t>(st.Nslots, 1) * 2 : 1)
+  AL(s->d_cm_t, (s->implicit || s->adaptive) ? (size_t)std::max<int64_t>(st.Nslots, 1) * 2 : 1)
   AL(v.pm_A1, st.has_shared ? 2 * D * N : 1) AL(v.cam_part, (size_t)std::max(st.Ncam_rb, 1) * (2 * D * D + 3 * D))
   v.write_y = (!s->implicit || st.has_shared) ? 1 : 0;
+  if (s->adaptive) {
+    // cost model measured on MI355X (profiles/r02_r): forming S ~69 ps per pair, a product with S ~192 ps per
+    // upper block, a matrix-free product ~135 ps per observation (0.60 - 0.68 ms at 5 M observations)
+    const double form = 69.0 * (double)st.npairs, with_s = 192.0 * (double)st.nub, free = 135.0 * (double)st.No;
+    s->adaptive_break_even = free > with_s ? (int)std::min(64.0, form / (free - with_s)) : 0;
+  }
   AL(v.cm_Y, v.write_y ? (size_t)std::max<int64_t>(st.Nslots, 1) * YS : 1) AL(v.cm_A, (size_t)std::max<int64_t>(st.Nslots, 1) * AS)
   AL(v.scale_c, std::max(n_r, 1)) AL(v.scale_p, NP * DP)
   AL(v.Vinv, NP * NS) AL(v.gp, NP * DP) AL(v.diag_p, NP * DP) AL(v.yp, NP * DP)
@@ -1452,7 +1465,7 @@ static void prepare_cameras(tmi_ba_solver* s, const double* ext, const double* i
 static int apply_schur(tmi_ba_solver* s, const double* x, double* y, int dot = 0, int spec = 0) {
   DeviceView& v = s->v;
   const int n = v.Nrb * v.D;
-  if (!s->implicit) {
+  if (!s->implicit_now) {
     Timed t(s, TMI_BA_K_SPMV);
     s->launch.spmv(v, s->stream, v.red + s->RL.ub, x, y, dot, spec);
     return TMI_BA_OK;
@@ -1984,6 +1997,7 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
   int termination = 1;
   const char* why = "maximum number of iterations reached";
   int64_t pcg_iters = 0;
+  int last_pcg_len = 0;  // PCG iterations of the previous LM iteration (0: none yet)
   bool need_gradient_check = true;  // after the first build and after every accepted step
   bool inner_enabled = O->use_inner_iterations != 0;
   bool time_up = false;
@@ -2002,8 +2016,17 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
     CKH(hipMemsetAsync(v.flags, 0, FL_COUNT * sizeof(int), stream));
     CKH(hipMemsetAsync(d_sc, 0, 8 * sizeof(double), stream));
     s->cur_inv_radius = inv_radius;
+    if (s->adaptive && iterative && !s->st.has_shared) {
+      // Forming S pays off after adaptive_break_even products (set at create from the sizes): short PCG
+      // solves -- the first LM iterations, small trust regions -- run matrix-free, and point_eliminate then
+      // skips the Y records.  The forecast is the previous iteration's PCG length; both operators give the
+      // same product to round-off.
+      s->implicit_now = last_pcg_len <= s->adaptive_break_even;
+      v.write_y = s->implicit_now ? 0 : 1;
+      if (s->implicit_now) s->n_implicit_iterations++;
+    }
     build_camera_side(inv_radius);
-    if (!s->implicit) {
+    if (!s->implicit_now) {
       Timed t(s, TMI_BA_K_SCHUR_OFFDIAG);
       s->launch.schur_offdiag(v, stream, RL);
       s->launch.cross_add(v, stream, RL);
@@ -2023,7 +2046,9 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
                           O->preconditioner_type == TMI_BA_PRECOND_IDENTITY ? 1
                           : O->preconditioner_type == TMI_BA_PRECOND_SCHUR_JACOBI_PARAMETER_BLOCKS ? 2 : 0);
       }
+      const int64_t before = pcg_iters;
       CK(solve_reduced_pcg(s, O, &usable, &pcg_iters));
+      last_pcg_len = (int)(pcg_iters - before);
     } else {
       CK(solve_reduced_dense(s, &usable));
     }

@@ -1,15 +1,13 @@
 #!/bin/bash
-R=$GRAFT_REPO_ROOT
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 cd $R
-python - <<'PY' 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -30
-import sys
-sys.path.insert(0,'.')
-from theiasfm_amd import abi, lib, synth
-P = synth.config("venice1778_heavy")
-o = abi.default_options(point_dof=3, linear_solver_type=abi.ITERATIVE_SCHUR, use_inner_iterations=0, max_num_iterations=12, verbose=1,
-                        function_tolerance=-1.0, gradient_tolerance=-1.0, parameter_tolerance=-1.0)
-s = lib.Solver(P, o)
-st, sm = s.solve(o)
-print("pcg total", sm.num_linear_solver_iterations, "its", sm.num_iterations)
-s.close()
-PY
+timeout 900 python -m pytest tests -m gpu -q --tb=short -x 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -6
+for e in 0 1; do
+if [ $e = 1 ]; then export TMI_BA_NO_ADAPTIVE=1; fi
+python bench.py --steps 20 --no-cpu-baseline --no-extras 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); print('no_adaptive=$e', d['ms_per_step'], d['pcg_iterations'], d['final_cost'], {k['kernel']:(k['launches'],k['avg_us']) for k in d['kernels'] if k['kernel'] in ('schur_offdiag','spmv','point_eliminate')})"
+python bench.py --workload venice1778 --steps 20 --no-cpu-baseline --no-extras 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); print('plain no_adaptive=$e', d['ms_per_step'], d['pcg_iterations'], d['final_cost'])"
+done
