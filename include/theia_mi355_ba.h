@@ -240,7 +240,10 @@ typedef struct tmi_ba_options {
                               PCG product walks the observations (Ceres'
                               ImplicitSchurComplement), with several GPUs one small
                               all-reduce (the reduced vector) per PCG iteration.
-                              0 = auto: explicit on one GPU, implicit on several.    */
+                              0 = auto: implicit on several GPUs; on one GPU both
+                              operators are kept resident and every LM iteration takes
+                              the cheaper one for the PCG length it expects (forming S
+                              pays off after a few products; same result to round-off). */
 } tmi_ba_options;
 
 /* ---- summary: BundleAdjustmentSummary + device-path extras --------------- */
