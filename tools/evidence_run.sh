@@ -1,5 +1,6 @@
 #!/bin/bash
-# round-2 evidence run: tests, e2e, default bench, kernel trace, PMC passes, scale probe
+# evidence run of a round (on the GPU box, via gpurun): tests, smoke, e2e, default bench line, kernel trace,
+# PMC passes, scale probe.  The tag (r02_r) names the files copied into profiles/ afterwards.
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 cd $R
 timeout 900 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -20 > $O/r02_r_pytest.log
