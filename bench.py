@@ -333,6 +333,7 @@ def main():
                     parallelism=f"tracks sharded x{world}", transport=m["transport"]),
         lm_iterations_per_sec=steps_run / elapsed,
         pcg_iterations=int(m["pcg"]),
+        matrix_free_lm_iterations_in_last_solve=int(s.num_matrix_free_iterations),
         initial_cost=s.initial_cost, final_cost=s.final_cost, initial_rmse=s.initial_rmse,
         final_rmse=s.final_rmse, accepted_steps=int(m["accepted"]),
         schur_blocks_upper=nnzb, schur_pairs=int(s.num_schur_pairs),

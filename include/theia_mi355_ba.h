@@ -271,7 +271,8 @@ typedef struct tmi_ba_summary {
                                     upper triangle incl. diagonal            */
   int64_t num_schur_pairs;       /* observation pairs feeding off-diagonal S */
   int32_t num_inner_iteration_steps; /* LM iterations that ran an inner-iteration sweep */
-  int32_t reserved0;
+  int32_t num_matrix_free_iterations; /* LM iterations whose PCG ran on the matrix-free operator
+                                         (all of them with schur_mode 2; some with auto on one rank) */
   /* per kernel class (index = tmi_ba_kernel_class): launches and total
    * device time from HIP events; filled when options.profile_kernels != 0   */
   int64_t kernel_launches[TMI_BA_NUM_KERNEL_CLASSES];

@@ -129,7 +129,7 @@ class CSummary(C.Structure):
         ("num_schur_blocks", C.c_int64),
         ("num_schur_pairs", C.c_int64),
         ("num_inner_iteration_steps", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("num_matrix_free_iterations", C.c_int32),
         ("kernel_launches", C.c_int64 * NUM_KERNEL_CLASSES),
         ("kernel_seconds", C.c_double * NUM_KERNEL_CLASSES),
         ("message", C.c_char * 192),

@@ -1997,6 +1997,7 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
   int termination = 1;
   const char* why = "maximum number of iterations reached";
   int64_t pcg_iters = 0;
+  s->n_implicit_iterations = 0;
   int last_pcg_len = 0;  // PCG iterations of the previous LM iteration (0: none yet)
   bool need_gradient_check = true;  // after the first build and after every accepted step
   bool inner_enabled = O->use_inner_iterations != 0;
@@ -2024,6 +2025,8 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
       s->implicit_now = last_pcg_len <= s->adaptive_break_even;
       v.write_y = s->implicit_now ? 0 : 1;
       if (s->implicit_now) s->n_implicit_iterations++;
+    } else if (s->implicit && iterative) {
+      s->n_implicit_iterations++;
     }
     build_camera_side(inv_radius);
     if (!s->implicit_now) {
@@ -2213,6 +2216,7 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
   sum->termination = termination;
   sum->num_iterations = iter;
   sum->num_linear_solver_iterations = pcg_iters;
+  sum->num_matrix_free_iterations = s->n_implicit_iterations;
   sum->final_cost = cost;
   sum->final_rmse = n_obs_global > 0 ? std::sqrt(final_ss / n_obs_global) : 0.0;
   sum->success = (termination != 2);
