@@ -519,7 +519,14 @@ static bool device_setup_possible(const Structure& st, int world, int64_t No, bo
   // see -- they take the device path when S is not formed (the matrix-free operator, the default for world > 1)
   if ((world != 1 && want_pairs) || st.has_shared || st.Nc < 1 || st.Np_total < 1 || No < 1) return false;
   if (No >= (int64_t)1 << 31) return false;
-  if (want_pairs && (int64_t)st.Nrb * st.Nrb > ((int64_t)1 << 26)) return false;
+  if (want_pairs) {
+    // the block set of S goes through an Nrb x Nrb presence map (13 bytes per entry in flags, scan and
+    // ids): fine up to tens of thousands of views on a 288 GB device, 32-bit scans bound it at 46 340
+    const int64_t n2 = (int64_t)st.Nrb * st.Nrb;
+    if (n2 >= 2000000000LL) return false;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double)free_b < 16.0 * (double)n2 + 4e9) return false;
+  }
   if (bits_for((unsigned)st.Nc) + bits_for((unsigned)st.Np_total) > 62) return false;
   return true;
 }
@@ -1299,7 +1306,9 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
     // cost model measured on MI355X (profiles/r02_r): forming S ~69 ps per pair, a product with S ~192 ps per
     // upper block, a matrix-free product ~135 ps per observation (0.60 - 0.68 ms at 5 M observations)
     const double form = 69.0 * (double)st.npairs, with_s = 192.0 * (double)st.nub, free = 135.0 * (double)st.No;
-    s->adaptive_break_even = free > with_s ? (int)std::min(64.0, form / (free - with_s)) : 0;
+    // (a product with S that costs more than a matrix-free one -- many views, little co-visibility: S has more
+    // blocks than there are observations to walk -- never pays off: always matrix-free)
+    s->adaptive_break_even = free > with_s ? (int)std::min(1.0e6, form / (free - with_s)) : 1 << 30;
   }
   AL(v.cm_Y, v.write_y ? (size_t)std::max<int64_t>(st.Nslots, 1) * YS : 1) AL(v.cm_A, (size_t)std::max<int64_t>(st.Nslots, 1) * AS)
   AL(v.scale_c, std::max(n_r, 1)) AL(v.scale_p, NP * DP)
