@@ -41,7 +41,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def algorithmic_bytes(cls: str, n_obs: int, n_cam: int, n_pts: int, dc: int, dp: int, nnzb: int):
+def algorithmic_bytes(cls: str, n_obs: int, n_cam: int, n_pts: int, dc: int, dp: int, nnzb: int, mf_frac: float = 0.0):
     """Algorithmic HBM bytes of ONE launch of a kernel class, SURVEY 8(d):
     observations stream 24 B (u, v, 2 x int32), parameters 8 B per scalar,
     normal-equation blocks once, 8 d_c^2 B per structurally non-zero upper block
@@ -57,7 +57,12 @@ def algorithmic_bytes(cls: str, n_obs: int, n_cam: int, n_pts: int, dc: int, dp:
     if cls == "schur_offdiag":
         return 2 * nnzb * 8 * dc * dc
     if cls == "spmv":
-        return nnzb * 8 * dc * dc + 2 * n_cam * 8 * dc
+        # a product with the formed S reads every upper block once; a matrix-free product walks the
+        # observations twice (tracks pass, cameras pass) and reads the per-track inverse blocks; mf_frac =
+        # share of the LM iterations whose PCG ran matrix-free (all of them on sharded runs)
+        with_s = nnzb * 8 * dc * dc + 2 * n_cam * 8 * dc
+        matrix_free = 2 * n_obs * 24 + 4 * n_cam * 8 * dc + n_pts * 8 * sym(dp)
+        return int((1.0 - mf_frac) * with_s + mf_frac * matrix_free)
     if cls == "pcg_vector":
         return 4 * n_cam * 8 * dc
     if cls == "back_substitute":
@@ -263,13 +268,15 @@ def main():
     dc, dp = int(s.reduced_block_dim), 3
     nnzb = int(s.num_schur_blocks)
 
+    mf_frac = float(s.num_matrix_free_iterations) / max(1, int(s.num_iterations))
+
     def table(launch_list, sec_list):
         rows = []
         for name, launches, sec in zip(abi.KERNEL_CLASS_NAMES, launch_list, sec_list):
             if launches == 0 or sec <= 0.0:
                 continue
             # per-rank launch: this rank's share of the observations / tracks
-            ab = algorithmic_bytes(name, n_obs // world, n_cam, n_pts // world, dc, dp, nnzb)
+            ab = algorithmic_bytes(name, n_obs // world, n_cam, n_pts // world, dc, dp, nnzb, mf_frac)
             avg = sec / launches
             rows.append(dict(kernel=name, launches=int(launches), total_ms=round(sec * 1e3, 4),
                              avg_us=round(avg * 1e6, 2), algorithmic_bytes_per_launch=int(ab),

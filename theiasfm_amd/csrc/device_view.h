@@ -102,6 +102,7 @@ struct DeviceView {
   double* cam_part; // [Ncam_rb][2 D^2 + 3 D] per-view sums for the shared blocks
   double* cm_Y;
   double* cm_A;
+  double* cm_R;  // tail records {N, r~, r} when there are no shared intrinsics blocks (kernels.h asa_of)
   double* scale_c;  // [Nrb][D]
   double* scale_cam; // [Nc][16] scale_c expanded to the columns [ext(6) | intr(10)] of every view
                      //   (0 on constant columns): linearize indexes it statically

@@ -1303,14 +1303,17 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   AL(v.pm_A1, st.has_shared ? 2 * D * N : 1) AL(v.cam_part, (size_t)std::max(st.Ncam_rb, 1) * (2 * D * D + 3 * D))
   v.write_y = (!s->implicit || st.has_shared) ? 1 : 0;
   if (s->adaptive) {
-    // cost model measured on MI355X (profiles/r02_r): forming S ~69 ps per pair, a product with S ~192 ps per
-    // upper block, a matrix-free product ~135 ps per observation (0.60 - 0.68 ms at 5 M observations)
-    const double form = 69.0 * (double)st.npairs, with_s = 192.0 * (double)st.nub, free = 135.0 * (double)st.No;
+    // cost model measured on MI355X (profiles/r02_r, r02_u): forming S ~69 ps per pair plus the Y records
+    // point_eliminate then writes (~24 ps per observation), a product with S ~192 ps per upper block, a
+    // matrix-free product ~110 ps per observation
+    const double form = 69.0 * (double)st.npairs + 24.0 * (double)st.No, with_s = 192.0 * (double)st.nub,
+                 free = 110.0 * (double)st.No;
     // (a product with S that costs more than a matrix-free one -- many views, little co-visibility: S has more
     // blocks than there are observations to walk -- never pays off: always matrix-free)
     s->adaptive_break_even = free > with_s ? (int)std::min(1.0e6, form / (free - with_s)) : 1 << 30;
   }
   AL(v.cm_Y, v.write_y ? (size_t)std::max<int64_t>(st.Nslots, 1) * YS : 1) AL(v.cm_A, (size_t)std::max<int64_t>(st.Nslots, 1) * AS)
+  v.cm_R = v.cm_A + (size_t)std::max<int64_t>(st.Nslots, 1) * asa_of(D);  // used when !has_shared (AS >= asa + tail)
   AL(v.scale_c, std::max(n_r, 1)) AL(v.scale_p, NP * DP)
   AL(v.Vinv, NP * NS) AL(v.gp, NP * DP) AL(v.diag_p, NP * DP) AL(v.yp, NP * DP)
   AL(v.red, s->RL.total) AL(v.Sdiag, (size_t)std::max(st.Nrb, 1) * D * D)

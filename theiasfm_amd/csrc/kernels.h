@@ -57,6 +57,12 @@ __host__ __device__ constexpr int a_off_n(int D) { return 2 * D; }
 __host__ __device__ constexpr int a_off_rt(int D) { return 2 * D + 3; }
 __host__ __device__ constexpr int a_off_r(int D) { return 2 * D + 5; }
 __host__ __device__ constexpr int a_off_sh(int D) { return 2 * D + 7; }
+// Without shared intrinsics blocks the A record is kept as TWO arrays in the same allocation: the A rows
+// alone (stride asa_of(D): 192 B for D = 9, what the cameras pass of the matrix-free product streams 4-5
+// times per LM iteration) and the 64-byte tail {N, r~, r} (cm_R) that only camera_diag reads.  Same bytes
+// written by point_eliminate and read by camera_diag as the one 256-byte record they replace.
+__host__ __device__ constexpr int asa_of(int D) { return (2 * D + 7) & ~7; }
+constexpr int kRecTail = 8;  // doubles of the tail record
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -922,11 +928,28 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int c = lane; c < 32 * (AS / 2); c += 64) {
-          const int rec = c / (AS / 2), part = c - rec * (AS / 2);
-          const int cp = scp[rec];
-          if (cp >= 0)
-            store_nt(v.cm_A + (size_t)cp * AS + 2 * part, st + rec * STP + 2 * part);
+        if (SH) {
+          for (int c = lane; c < 32 * (AS / 2); c += 64) {
+            const int rec = c / (AS / 2), part = c - rec * (AS / 2);
+            const int cp = scp[rec];
+            if (cp >= 0)
+              store_nt(v.cm_A + (size_t)cp * AS + 2 * part, st + rec * STP + 2 * part);
+          }
+        } else {
+          // A rows (whole sectors: the few doubles past 2 D repeat the head of the tail) and the tail
+          constexpr int ASA = asa_of(D);
+          for (int c = lane; c < 32 * (ASA / 2); c += 64) {
+            const int rec = c / (ASA / 2), part = c - rec * (ASA / 2);
+            const int cp = scp[rec];
+            if (cp >= 0)
+              store_nt(v.cm_A + (size_t)cp * ASA + 2 * part, st + rec * STP + 2 * part);
+          }
+          for (int c = lane; c < 32 * (kRecTail / 2); c += 64) {
+            const int rec = c / (kRecTail / 2), part = c - rec * (kRecTail / 2);
+            const int cp = scp[rec];
+            if (cp >= 0)
+              store_nt(v.cm_R + (size_t)cp * kRecTail + 2 * part, st + rec * STP + 2 * D + 2 * part);
+          }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1029,13 +1052,30 @@ __global__ __launch_bounds__(64) void camera_diag_kernel(DeviceView v, RedLayout
     }
   } else
   for (int s = v.cam_ptr[rb] + threadIdx.x; s < v.cam_ptr[rb + 1]; s += 64) {
-    const double* arec = v.cm_A + (size_t)s * AS;
     double rec[2 * D + 8];
+    if (SH) {
+      const double* arec = v.cm_A + (size_t)s * AS;
 #pragma unroll
-    for (int i = 0; i < 2 * D + 8; i += 2) {
-      const double2 t = *reinterpret_cast<const double2*>(arec + i);
-      rec[i] = t.x;
-      rec[i + 1] = t.y;
+      for (int i = 0; i < 2 * D + 8; i += 2) {
+        const double2 t = *reinterpret_cast<const double2*>(arec + i);
+        rec[i] = t.x;
+        rec[i + 1] = t.y;
+      }
+    } else {
+      const double* arec = v.cm_A + (size_t)s * asa_of(D);
+      const double* trec = v.cm_R + (size_t)s * kRecTail;
+#pragma unroll
+      for (int i = 0; i < 2 * D; i += 2) {
+        const double2 t = *reinterpret_cast<const double2*>(arec + i);
+        rec[i] = t.x;
+        rec[i + 1] = t.y;
+      }
+#pragma unroll
+      for (int i = 0; i < kRecTail; i += 2) {
+        const double2 t = *reinterpret_cast<const double2*>(trec + i);
+        rec[2 * D + i] = t.x;
+        rec[2 * D + i + 1] = t.y;
+      }
     }
     const double n00 = rec[a_off_n(D)], n01 = rec[a_off_n(D) + 1], n11 = rec[a_off_n(D) + 2];
     const double rt0 = rec[a_off_rt(D)], rt1 = rec[a_off_rt(D) + 1];
@@ -1736,7 +1776,7 @@ __global__ __launch_bounds__(64) void implicit_cameras_kernel(DeviceView v, RedL
 #pragma unroll
   for (int a = 0; a < (SH ? D : 1); ++a) acc1[a] = 0.0;
   for (int s = v.cam_ptr[rb] + threadIdx.x; s < v.cam_ptr[rb + 1]; s += 64) {
-    const double* arec = v.cm_A + (size_t)s * AS;
+    const double* arec = v.cm_A + (size_t)s * (SH ? AS : asa_of(D));
     const double2 t = *reinterpret_cast<const double2*>(cm_t + (size_t)s * 2);
 #pragma unroll
     for (int a = 0; a < D; ++a) acc[a] += arec[a] * t.x + arec[D + a] * t.y;
