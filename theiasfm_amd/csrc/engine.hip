@@ -2034,7 +2034,9 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
       // solves -- the first LM iterations, small trust regions -- run matrix-free, and point_eliminate then
       // skips the Y records.  The forecast is the previous iteration's PCG length; both operators give the
       // same product to round-off.
-      s->implicit_now = last_pcg_len <= s->adaptive_break_even;
+      // ... by a clear margin only (forecast at most half the break-even): near the break-even the two cost the
+      // same and the formed S stays the default
+      s->implicit_now = last_pcg_len <= s->adaptive_break_even / 2;
       v.write_y = s->implicit_now ? 0 : 1;
       if (s->implicit_now) s->n_implicit_iterations++;
     } else if (s->implicit && iterative) {
