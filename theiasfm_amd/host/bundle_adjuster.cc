@@ -25,7 +25,11 @@ namespace {
 int HostThreads(size_t work) {
   if (const char* e = std::getenv("TMI_BA_HOST_THREADS")) return std::max(1, std::atoi(e));  // tests
   if (work < 200000) return 1;
-  return static_cast<int>(std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u));
+  // one thread per ~100 k items of hash-container walking, at most half the hardware threads and at
+  // most 64 (Venice size on a 256-thread host: AddViews 0.092 s with 16 threads, 0.052 s with 50)
+  const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
+  const unsigned want = static_cast<unsigned>(std::min<size_t>(work / 100000 + 1, 64));
+  return static_cast<int>(std::max(1u, std::min(want, hw / 2)));
 }
 template <class Body>
 void RunThreads(int n_threads, Body&& body) {

@@ -1,9 +1,15 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-timeout 600 python tools/auto_probe.py 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl\|amdgpu.ids" | grep auto
-for w in venice1778_heavy venice1778; do
-for m in auto explicit; do
-python bench.py --workload $w --steps 20 --no-cpu-baseline --no-extras --schur-mode $m 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.readline()); print('$w $m', round(d['ms_per_step'],3), d['pcg_iterations'], d['final_cost'], d.get('matrix_free_lm_iterations_in_last_solve'), d['roofline']['kernel'], d['roofline']['frac'])"
-done; done
+python - <<'PY'
+import sys
+sys.path.insert(0,'.')
+from theiasfm_amd import synth
+import bench
+p=synth.config("venice1778_heavy")
+bench.write_problem_file(p, "/tmp/venice_heavy.bin")
+PY
+nproc
+for t in 16 32 64; do
+echo "threads $t"
+TMI_BA_HOST_THREADS=$t TMI_BA_SETUP_TIMING=1 ./tools/e2e_bench /tmp/venice_heavy.bin 10 0 3 2>&1 | grep -i "AddViews: total\|AddTracks\|observation order\|wall_seconds" | tail -4 | cut -c1-200
+done
