@@ -560,6 +560,18 @@ def main():
                 linear_solver=solver_policy(pa.num_cameras)[1],
                 ms_per_step=round(1e3 * ma["elapsed"] / max(ma["steps_run"], 1), 4), steps=ma["steps_run"],
                 value=pa.num_observations * ma["steps_run"] / ma["elapsed"], final_rmse=ma["summary"].final_rmse)
+            # the shim's default point parameterisation: 4 free homogeneous coordinates per point, as the
+            # reference leaves them (bundle_adjuster.cc:379-385); the headline uses 3 (w fixed, the north-star's 2x3 blocks)
+            o4 = dict(point_dof=4, linear_solver_type=abi.ITERATIVE_SCHUR, use_inner_iterations=0,
+                      function_tolerance=-1.0, gradient_tolerance=-1.0, parameter_tolerance=-1.0)
+            s4 = lib.Solver(prob0.copy(), abi.default_options(max_num_iterations=2, **o4))
+            s4.solve(abi.default_options(max_num_iterations=2, **o4))
+            s4.reset()
+            _, sm4 = s4.solve(abi.default_options(max_num_iterations=10, **o4))
+            s4.close()
+            out["variants"]["venice1778_heavy_point_dof4-synthetic"] = dict(
+                steps=int(sm4.num_iterations), ms_per_step=round(1e3 * sm4.solve_time_in_seconds / max(1, sm4.num_iterations), 3),
+                pcg_iterations=int(sm4.num_linear_solver_iterations), final_rmse=sm4.final_rmse)
             # BASELINE config 5 at Venice size: mixed camera models, intrinsics shared by groups of 8 views,
             # fp32 residual evaluation (fp64 accumulation); one solve of 8 LM iterations, ~41 PCG iterations each
             bits = (abi.INTRINSICS_FOCAL_LENGTH | abi.INTRINSICS_PRINCIPAL_POINTS | abi.INTRINSICS_RADIAL_DISTORTION
