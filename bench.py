@@ -538,6 +538,23 @@ def main():
                 termination_mismatches=int((term_d[sm] != term_o).sum()),
                 iteration_mismatches=int((it_d[sm] != it_o).sum()),
                 final_cost_rel_diff_above_1e6=int((np.abs(c1_d[sm][ok] - c1_o[ok]) > 1e-6 * np.maximum(c1_o[ok], 1e-12)).sum()))
+        # batched BundleAdjustTwoViewsAngular (bundle_adjust_two_views.cc:193-240): relative pose of 20 000 pairs
+        tab, _, _ = synth.make_two_view_angular_batch(20000, 5, max_corr=300)
+        _lib.adjust_two_views_angular(tab.copy())
+        ta_d = tab.copy()
+        tc = time.perf_counter()
+        term_d, it_d, _, c1_d, tas = _lib.adjust_two_views_angular(ta_d)
+        t_call = time.perf_counter() - tc
+        ta_o = tab.copy()
+        tc = time.perf_counter()
+        term_o, it_o, _, c1_o = oracle.adjust_two_views_angular(ta_o)
+        t_o = time.perf_counter() - tc
+        side["batched_two_view_angular_ba"] = dict(
+            kernel_ms=round(tas.kernel_seconds * 1e3, 3), call_ms=round(t_call * 1e3, 2), pairs=int(tab.num_pairs),
+            correspondences=int(tab.correspondence_ptr[-1]), lm_iterations=int(tas.total_iterations),
+            pairs_per_s=tab.num_pairs / tas.kernel_seconds, cpu_port_pairs_per_s=tab.num_pairs / t_o,
+            cpu_port_sample=f"all pairs, {oracle.num_threads()} threads",
+            termination_mismatches=int((term_d != term_o).sum()), iteration_mismatches=int((it_d != it_o).sum()))
         out["side_kernels"] = side
     solver.close()
 

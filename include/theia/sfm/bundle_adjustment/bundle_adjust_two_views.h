@@ -11,6 +11,7 @@
 #include "theia/matching/feature_correspondence.h"
 #include "theia/sfm/bundle_adjustment/bundle_adjustment.h"
 #include "theia/sfm/camera/camera.h"
+#include "theia/sfm/twoview_info.h"
 #include "theia/util/eigen_lite.h"
 
 namespace theia {
@@ -25,6 +26,20 @@ BundleAdjustmentSummary BundleAdjustTwoViews(const TwoViewBundleAdjustmentOption
                                              const std::vector<FeatureCorrespondence>& correspondences,
                                              Camera* camera1, Camera* camera2,
                                              std::vector<Eigen::Vector4d>* points3d);
+
+// reference: bundle_adjust_two_views.h:77-84, bundle_adjust_two_views.cc:193-240 -- the relative pose
+// (info->rotation_2, info->position_2 kept at unit norm) from the angular epipolar error of the
+// correspondences (features in normalised image coordinates); only options.device is read.
+BundleAdjustmentSummary BundleAdjustTwoViewsAngular(const BundleAdjustmentOptions& options,
+                                                    const std::vector<FeatureCorrespondence>& correspondences,
+                                                    TwoViewInfo* info);
+// Extension of the MI355X path: many pairs in one launch (one wavefront per pair).
+struct TwoViewAngularProblem {
+  const std::vector<FeatureCorrespondence>* correspondences = nullptr;
+  TwoViewInfo* info = nullptr;
+};
+std::vector<BundleAdjustmentSummary> BundleAdjustTwoViewsAngularBatch(const BundleAdjustmentOptions& options,
+                                                                      std::vector<TwoViewAngularProblem>* problems);
 
 // One entry per view pair; every pointer must stay valid for the call.
 struct TwoViewBundleAdjustmentProblem {

@@ -25,6 +25,7 @@ struct LiteVector {
   T* data() { return v; }
   const T* data() const { return v; }
   static constexpr int size() { return N; }
+  static LiteVector Zero() { return LiteVector(); }
 };
 typedef LiteVector<double, 2> Vector2d;
 typedef LiteVector<double, 3> Vector3d;

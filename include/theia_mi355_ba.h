@@ -529,6 +529,30 @@ int32_t tmi_ba_adjust_two_views(tmi_ba_two_view_batch* batch, int32_t point_dof,
                                 double* pair_initial_cost, double* pair_final_cost,
                                 tmi_ba_track_batch_summary* summary);
 
+/* ---- batched BundleAdjustTwoViewsAngular --------------------------------------------------
+ * reference: bundle_adjust_two_views.cc:193-240 -- the relative pose of a view pair from
+ * its correspondences alone: parameters TwoViewInfo::rotation_2 (angle-axis, 3) and
+ * TwoViewInfo::position_2 (3, kept on the unit sphere by
+ * AutoDiffLocalParameterization<UnitNormThreeVectorParameterization, 3, 3>,
+ * unit_norm_three_vector_parameterization.h:45-63), one AngularEpipolarError residual per
+ * correspondence (angular_epipolar_error.h:47-89; features in normalised image coordinates), no
+ * loss, DENSE_SCHUR with the ordering left to Ceres, at most 200 iterations, Ceres' default
+ * tolerances.  One wavefront per pair on the device.  Termination codes as for
+ * tmi_ba_adjust_two_views; rotation2 / position2 are written back for usable solutions. */
+typedef struct tmi_ba_two_view_angular_batch {
+  int32_t num_pairs;
+  double* rotation2;                    /* [3 * num_pairs] in/out                              */
+  double* position2;                    /* [3 * num_pairs] in/out, unit norm                   */
+  const int64_t* correspondence_ptr;    /* [num_pairs + 1] ranges into the arrays below        */
+  const double* features1;              /* [2 * N] normalised image coordinates in view 1      */
+  const double* features2;              /* [2 * N] ... in view 2                               */
+} tmi_ba_two_view_angular_batch;
+
+int32_t tmi_ba_adjust_two_views_angular(tmi_ba_two_view_angular_batch* batch, int32_t max_num_iterations,
+                                        int32_t device, int8_t* pair_termination, int32_t* pair_iterations,
+                                        double* pair_initial_cost, double* pair_final_cost,
+                                        tmi_ba_track_batch_summary* summary);
+
 /* Test hook: FNV-1a checksums of the static structure arrays resident in HBM -- built in HBM by
  * sort / scan kernels (one rank, no shared intrinsics blocks; TMI_BA_HOST_SETUP=1 disables) or on
  * host threads otherwise.  out[0] = 1 when the device built it; the other slots are documented at

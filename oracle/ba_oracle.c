@@ -2146,3 +2146,323 @@ int32_t oracle_adjust_two_views(tmi_ba_two_view_batch* B, int32_t point_dof, int
   }
   return TMI_BA_OK;
 }
+
+/* ==========================================================================================
+ * BundleAdjustTwoViewsAngular (bundle_adjust_two_views.cc:193-240): relative rotation (angle
+ * axis) and unit-norm relative position of a view pair from AngularEpipolarError residuals.
+ * The functor (angular_epipolar_error.h:47-89) and the parameterization
+ * (unit_norm_three_vector_parameterization.h:45-63) are evaluated on dual numbers, as Ceres'
+ * AutoDiffCostFunction / AutoDiffLocalParameterization do; jet slots 0-2 = rotation, 3-5 =
+ * position (or the local increment).  ceres::AngleAxisToRotationMatrix restated from the
+ * published ceres/rotation.h (1.x): Rodrigues above theta^2 = DBL_EPSILON, first order below.
+ * The trust-region loop is the one of the full solver (Ceres 1.14 TrustRegionMinimizer
+ * semantics) on a dense 6-column local Jacobian; with two parameter blocks that
+ * meet in every residual DENSE_SCHUR eliminates one 3-block and solves for the other, i.e. it
+ * solves the same 6 x 6 damped normal equations.
+ * ========================================================================================== */
+static void aa_to_rotation_jet(const jet aa[3], jet R[3][3]) {
+  const jet one = jet_const(1.0);
+  const jet theta2 = jet_add(jet_add(jet_mul(aa[0], aa[0]), jet_mul(aa[1], aa[1])), jet_mul(aa[2], aa[2]));
+  if (theta2.a > 2.220446049250313e-16) {
+    const jet theta = jet_sqrt(theta2);
+    const jet wx = jet_div(aa[0], theta), wy = jet_div(aa[1], theta), wz = jet_div(aa[2], theta);
+    const jet c = jet_cos(theta), s = jet_sin(theta), omc = jet_sub(one, c);
+    R[0][0] = jet_add(c, jet_mul(jet_mul(wx, wx), omc));
+    R[1][0] = jet_add(jet_mul(wz, s), jet_mul(jet_mul(wx, wy), omc));
+    R[2][0] = jet_add(jet_neg(jet_mul(wy, s)), jet_mul(jet_mul(wx, wz), omc));
+    R[0][1] = jet_sub(jet_mul(jet_mul(wx, wy), omc), jet_mul(wz, s));
+    R[1][1] = jet_add(c, jet_mul(jet_mul(wy, wy), omc));
+    R[2][1] = jet_add(jet_mul(wx, s), jet_mul(jet_mul(wy, wz), omc));
+    R[0][2] = jet_add(jet_mul(wy, s), jet_mul(jet_mul(wx, wz), omc));
+    R[1][2] = jet_add(jet_neg(jet_mul(wx, s)), jet_mul(jet_mul(wy, wz), omc));
+    R[2][2] = jet_add(c, jet_mul(jet_mul(wz, wz), omc));
+  } else {
+    R[0][0] = one;          R[0][1] = jet_neg(aa[2]); R[0][2] = aa[1];
+    R[1][0] = aa[2];        R[1][1] = one;            R[1][2] = jet_neg(aa[0]);
+    R[2][0] = jet_neg(aa[1]); R[2][1] = aa[0];        R[2][2] = one;
+  }
+}
+
+/* angular_epipolar_error.h:52-84 on jets.  Returns 0 where the functor returns false. */
+static int angular_error_jet(const jet rot[3], const jet t[3], const double f1d[2], const double f2d[2], jet* out) {
+  const jet f1[3] = {jet_const(f1d[0]), jet_const(f1d[1]), jet_const(1.0)};
+  const jet f2[3] = {jet_const(f2d[0]), jet_const(f2d[1]), jet_const(1.0)};
+  jet R[3][3];
+  aa_to_rotation_jet(rot, R);
+  /* translation_term = I - t t^T */
+  jet T[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) T[i][j] = jet_sub(jet_const(i == j ? 1.0 : 0.0), jet_mul(t[i], t[j]));
+  jet Rf2[3], Rtf2[3], Tf1[3], TRtf2[3];
+  for (int i = 0; i < 3; ++i) {
+    Rf2[i] = jet_add(jet_add(jet_mul(R[i][0], f2[0]), jet_mul(R[i][1], f2[1])), jet_mul(R[i][2], f2[2]));
+    Rtf2[i] = jet_add(jet_add(jet_mul(R[0][i], f2[0]), jet_mul(R[1][i], f2[1])), jet_mul(R[2][i], f2[2]));
+  }
+  for (int i = 0; i < 3; ++i) {
+    Tf1[i] = jet_add(jet_add(jet_mul(T[i][0], f1[0]), jet_mul(T[i][1], f1[1])), jet_mul(T[i][2], f1[2]));
+    TRtf2[i] = jet_add(jet_add(jet_mul(T[i][0], Rtf2[0]), jet_mul(T[i][1], Rtf2[1])), jet_mul(T[i][2], Rtf2[2]));
+  }
+  jet a = jet_const(0.0);
+  for (int i = 0; i < 3; ++i) a = jet_add(a, jet_mul(f1[i], Tf1[i]));
+  for (int i = 0; i < 3; ++i) a = jet_add(a, jet_mul(Rf2[i], TRtf2[i]));
+  /* b_sqrt = t . (f1 x R^T f2) */
+  const jet cx = jet_sub(jet_mul(f1[1], Rtf2[2]), jet_mul(f1[2], Rtf2[1]));
+  const jet cy = jet_sub(jet_mul(f1[2], Rtf2[0]), jet_mul(f1[0], Rtf2[2]));
+  const jet cz = jet_sub(jet_mul(f1[0], Rtf2[1]), jet_mul(f1[1], Rtf2[0]));
+  const jet b = jet_add(jet_add(jet_mul(t[0], cx), jet_mul(t[1], cy)), jet_mul(t[2], cz));
+  const jet sq = jet_sub(jet_div(jet_mul(a, a), jet_const(4.0)), jet_mul(b, b));
+  if (sq.a < 0.0) return 0;
+  *out = jet_sub(jet_div(a, jet_const(2.0)), jet_sqrt(sq));
+  return 1;
+}
+
+int32_t oracle_angular_epipolar_error(const double* rotation, const double* position, const double* f1,
+                                      const double* f2, double* residual) {
+  jet r[3], t[3], e;
+  for (int i = 0; i < 3; ++i) {
+    r[i] = jet_const(rotation[i]);
+    t[i] = jet_const(position[i]);
+  }
+  if (!angular_error_jet(r, t, f1, f2, &e)) return 0;
+  *residual = e.a;
+  return 1;
+}
+
+/* UnitNormThreeVectorParameterization::operator() on plain doubles */
+static void unit_norm_plus(const double x[3], const double d[3], double out[3]) {
+  for (int i = 0; i < 3; ++i) out[i] = x[i] + d[i];
+  const double sq = out[0] * out[0] + out[1] * out[1] + out[2] * out[2];
+  if (sq > 0.0) {
+    const double nrm = sqrt(sq);
+    for (int i = 0; i < 3; ++i) out[i] /= nrm;
+  }
+}
+
+/* residuals (and, if H, the scaled local normal equations H = Js^T Js packed upper, g = Js^T r) at
+ * x = [rotation | position]; sc = column scales of the local Jacobian.  Returns 0 on evaluation failure. */
+static int angular_linearize(const double x[6], const double* f1, const double* f2, int64_t n, const double sc[6],
+                             double* H, double* g, double* cost) {
+  /* local parameterization Jacobian of the position block: d Plus(x, delta) / d delta at 0, by jets
+   * (AutoDiffLocalParameterization) */
+  double P[3][3];
+  {
+    jet xp[3];
+    for (int i = 0; i < 3; ++i) xp[i] = jet_add(jet_const(x[3 + i]), jet_var(0.0, i));
+    const jet sq = jet_add(jet_add(jet_mul(xp[0], xp[0]), jet_mul(xp[1], xp[1])), jet_mul(xp[2], xp[2]));
+    if (sq.a > 0.0) {
+      const jet nrm = jet_sqrt(sq);
+      for (int i = 0; i < 3; ++i) xp[i] = jet_div(xp[i], nrm);
+    }
+    for (int i = 0; i < 3; ++i)
+      for (int k = 0; k < 3; ++k) P[i][k] = xp[i].v[k];
+  }
+  jet rot[3], t[3];
+  for (int i = 0; i < 3; ++i) {
+    rot[i] = jet_var(x[i], i);
+    t[i] = jet_var(x[3 + i], 3 + i);
+  }
+  if (H) {
+    for (int i = 0; i < 21; ++i) H[i] = 0.0;
+    for (int i = 0; i < 6; ++i) g[i] = 0.0;
+  }
+  double c = 0.0;
+  for (int64_t q = 0; q < n; ++q) {
+    jet e;
+    if (!angular_error_jet(rot, t, f1 + 2 * q, f2 + 2 * q, &e)) return 0;
+    c += 0.5 * e.a * e.a;
+    if (!H) continue;
+    double J[6];
+    for (int k = 0; k < 3; ++k) J[k] = e.v[k] * sc[k];
+    for (int k = 0; k < 3; ++k)
+      J[3 + k] = (e.v[3] * P[0][k] + e.v[4] * P[1][k] + e.v[5] * P[2][k]) * sc[3 + k];
+    int idx = 0;
+    for (int a = 0; a < 6; ++a) {
+      for (int b = a; b < 6; ++b) H[idx++] += J[a] * J[b];
+      g[a] += J[a] * e.a;
+    }
+  }
+  *cost = c;
+  return 1;
+}
+
+static int chol6_solve(const double* H, const double* diag_add, const double* g, double* y) {
+  double A[6][6], L[6][6];
+  int idx = 0;
+  for (int a = 0; a < 6; ++a)
+    for (int b = a; b < 6; ++b) {
+      A[a][b] = A[b][a] = H[idx++];
+    }
+  for (int a = 0; a < 6; ++a) A[a][a] += diag_add[a];
+  for (int j = 0; j < 6; ++j) {
+    double d = A[j][j];
+    for (int m = 0; m < j; ++m) d -= L[j][m] * L[j][m];
+    if (!(d > 0.0)) return 0;
+    L[j][j] = sqrt(d);
+    for (int i = j + 1; i < 6; ++i) {
+      double t = A[i][j];
+      for (int m = 0; m < j; ++m) t -= L[i][m] * L[j][m];
+      L[i][j] = t / L[j][j];
+    }
+  }
+  double z[6];
+  for (int i = 0; i < 6; ++i) {
+    double t = g[i];
+    for (int m = 0; m < i; ++m) t -= L[i][m] * z[m];
+    z[i] = t / L[i][i];
+  }
+  for (int i = 5; i >= 0; --i) {
+    double t = z[i];
+    for (int m = i + 1; m < 6; ++m) t -= L[m][i] * y[m];
+    y[i] = t / L[i][i];
+  }
+  return 1;
+}
+
+int32_t oracle_adjust_two_views_angular(tmi_ba_two_view_angular_batch* B, int32_t max_num_iterations,
+                                        int8_t* termination, int32_t* iterations, double* initial_cost,
+                                        double* final_cost) {
+  if (!B || B->num_pairs < 0) return TMI_BA_ERR_INVALID_ARGUMENT;
+  const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
+  const double max_radius = 1e16, min_radius = 1e-32, min_relative_decrease = 1e-3, lm_lo = 1e-6, lm_hi = 1e32;
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int p = 0; p < B->num_pairs; ++p) {
+    const int64_t c0 = B->correspondence_ptr[p], n = B->correspondence_ptr[p + 1] - c0;
+    int8_t term = 1;
+    int iter = 0;
+    double cost = 0.0, cost0 = 0.0;
+    if (n <= 0) {
+      term = -1;
+    } else {
+      const double *f1 = B->features1 + 2 * c0, *f2 = B->features2 + 2 * c0;
+      double x[6];
+      for (int i = 0; i < 3; ++i) {
+        x[i] = B->rotation2[3 * (size_t)p + i];
+        x[3 + i] = B->position2[3 * (size_t)p + i];
+      }
+      double sc[6] = {1, 1, 1, 1, 1, 1}, H[21], g[6];
+      if (!angular_linearize(x, f1, f2, n, sc, H, g, &cost)) {
+        term = 3;
+        cost0 = cost;
+      } else {
+        cost0 = cost;
+        double gmax = 0.0;
+        for (int a = 0; a < 6; ++a) gmax = fmax(gmax, fabs(g[a]));
+        {
+          /* Jacobi scaling from the start point: 1 / (1 + ||column||) */
+          int idx = 0;
+          for (int a = 0; a < 6; ++a) {
+            sc[a] = 1.0 / (1.0 + sqrt(H[idx]));
+            idx += 6 - a;
+          }
+          angular_linearize(x, f1, f2, n, sc, H, g, &cost);
+        }
+        double x_norm = 0.0;
+        for (int a = 0; a < 6; ++a) x_norm += x[a] * x[a];
+        x_norm = sqrt(x_norm);
+        double radius = 1e4, decrease_factor = 2.0;
+        int invalid_run = 0;
+        if (gmax <= gradient_tolerance) {
+          term = 0;
+        } else {
+          for (;;) {
+            if (iter >= max_num_iterations) break;
+            ++iter;
+            double dadd[6], y[6];
+            {
+              int idx = 0;
+              for (int a = 0; a < 6; ++a) {
+                dadd[a] = fmin(fmax(H[idx], lm_lo), lm_hi) / radius;
+                idx += 6 - a;
+              }
+            }
+            int step_ok = chol6_solve(H, dadd, g, y);
+            double mcc = 0.0;
+            if (step_ok) {
+              double yg = 0.0, yHy = 0.0, Hf[6][6];
+              int idx = 0;
+              for (int a = 0; a < 6; ++a)
+                for (int b = a; b < 6; ++b) Hf[a][b] = Hf[b][a] = H[idx++];
+              for (int a = 0; a < 6; ++a) {
+                yg += y[a] * g[a];
+                double t = 0.0;
+                for (int b = 0; b < 6; ++b) t += Hf[a][b] * y[b];
+                yHy += y[a] * t;
+              }
+              mcc = yg - 0.5 * yHy;
+              if (!(mcc > 0.0)) step_ok = 0;
+            }
+            if (!step_ok) {
+              if (++invalid_run >= 5) {
+                term = 2;
+                break;
+              }
+              radius /= decrease_factor;
+              decrease_factor *= 2.0;
+              if (radius < min_radius) {
+                term = 0;
+                break;
+              }
+              continue;
+            }
+            invalid_run = 0;
+            double xc[6], d[6];
+            for (int a = 0; a < 6; ++a) d[a] = -y[a] * sc[a];
+            for (int a = 0; a < 3; ++a) xc[a] = x[a] + d[a];
+            unit_norm_plus(x + 3, d + 3, xc + 3);
+            double step_sq = 0.0;
+            for (int a = 0; a < 6; ++a) step_sq += (xc[a] - x[a]) * (xc[a] - x[a]);
+            double cand;
+            if (!angular_linearize(xc, f1, f2, n, sc, NULL, NULL, &cand)) cand = 1.7976931348623157e308;
+            if (sqrt(step_sq) <= parameter_tolerance * (x_norm + parameter_tolerance)) {
+              term = 0;
+              break;
+            }
+            const double cost_change = cost - cand;
+            if (fabs(cost_change) <= function_tolerance * cost) {
+              term = 0;
+              break;
+            }
+            const double rd = cost_change / mcc;
+            if (rd > min_relative_decrease) {
+              for (int a = 0; a < 6; ++a) x[a] = xc[a];
+              x_norm = 0.0;
+              for (int a = 0; a < 6; ++a) x_norm += x[a] * x[a];
+              x_norm = sqrt(x_norm);
+              if (!angular_linearize(x, f1, f2, n, sc, H, g, &cost)) {
+                term = 2;
+                break;
+              }
+              gmax = 0.0;
+              for (int a = 0; a < 6; ++a) gmax = fmax(gmax, fabs(g[a] / sc[a]));
+              radius = radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rd - 1.0, 3.0));
+              radius = fmin(max_radius, radius);
+              decrease_factor = 2.0;
+              if (gmax <= gradient_tolerance) {
+                term = 0;
+                break;
+              }
+            } else {
+              radius /= decrease_factor;
+              decrease_factor *= 2.0;
+            }
+            if (radius < min_radius) {
+              term = 0;
+              break;
+            }
+          }
+        }
+        if (term != 2) {
+          for (int i = 0; i < 3; ++i) {
+            B->rotation2[3 * (size_t)p + i] = x[i];
+            B->position2[3 * (size_t)p + i] = x[3 + i];
+          }
+        }
+      }
+    }
+    if (termination) termination[p] = term;
+    if (iterations) iterations[p] = iter;
+    if (initial_cost) initial_cost[p] = cost0;
+    if (final_cost) final_cost[p] = cost;
+  }
+  return TMI_BA_OK;
+}

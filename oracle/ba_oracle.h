@@ -126,6 +126,15 @@ int32_t oracle_adjust_two_views(tmi_ba_two_view_batch* batch, int32_t point_dof,
                                 int8_t* termination, int32_t* iterations, double* initial_cost,
                                 double* final_cost);
 
+/* BundleAdjustTwoViewsAngular pair by pair (bundle_adjust_two_views.cc:193-240,
+ * angular_epipolar_error.h:47-89, unit_norm_three_vector_parameterization.h:45-63). */
+int32_t oracle_adjust_two_views_angular(tmi_ba_two_view_angular_batch* batch, int32_t max_num_iterations,
+                                        int8_t* termination, int32_t* iterations, double* initial_cost,
+                                        double* final_cost);
+/* residual of one correspondence at (rotation, position): returns 0 where the functor returns false */
+int32_t oracle_angular_epipolar_error(const double* rotation, const double* position, const double* f1,
+                                      const double* f2, double* residual);
+
 int32_t oracle_num_threads(void);
 /* OpenMP threads used by the calls that follow (bench.py: single-thread baseline). */
 void oracle_set_num_threads(int32_t n);

@@ -71,6 +71,11 @@ def lib():
         L.oracle_adjust_two_views.argtypes = [C.POINTER(abi.CTwoViewBatch), C.c_int32, C.c_int32,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_adjust_two_views.restype = C.c_int32
+        L.oracle_adjust_two_views_angular.argtypes = [C.POINTER(abi.CTwoViewAngularBatch), C.c_int32,
+                                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_adjust_two_views_angular.restype = C.c_int32
+        L.oracle_angular_epipolar_error.argtypes = [C.c_void_p] * 5
+        L.oracle_angular_epipolar_error.restype = C.c_int32
         L.oracle_sufficient_triangulation_angle.argtypes = [C.c_void_p, C.c_int64, C.c_double]
         L.oracle_sufficient_triangulation_angle.restype = C.c_int32
         L.oracle_filter_outlier_tracks.argtypes = [C.POINTER(abi.CProblem), C.c_double, C.c_double,
@@ -220,6 +225,28 @@ def adjust_two_views(batch: abi.TwoViewBatch, point_dof: int = 4, max_num_iterat
                                        iters.ctypes.data, c0.ctypes.data, c1.ctypes.data)
     assert st == 0, st
     return term, iters, c0, c1
+
+
+def adjust_two_views_angular(batch: abi.TwoViewAngularBatch, max_num_iterations: int = 200):
+    """BundleAdjustTwoViewsAngular pair by pair on the CPU; the batch is updated in place."""
+    n = batch.num_pairs
+    term = np.full(n, -1, dtype=np.int8)
+    iters = np.zeros(n, dtype=np.int32)
+    c0 = np.zeros(n)
+    c1 = np.zeros(n)
+    cb = batch.as_c()
+    st = lib().oracle_adjust_two_views_angular(C.byref(cb), int(max_num_iterations), term.ctypes.data,
+                                               iters.ctypes.data, c0.ctypes.data, c1.ctypes.data)
+    assert st == 0, st
+    return term, iters, c0, c1
+
+
+def angular_epipolar_error(rotation, position, f1, f2):
+    """AngularEpipolarError of one correspondence; None where the functor returns false."""
+    a = [np.ascontiguousarray(v, dtype=np.float64) for v in (rotation, position, f1, f2)]
+    out = np.zeros(1)
+    ok = lib().oracle_angular_epipolar_error(*[v.ctypes.data for v in a], out.ctypes.data)
+    return float(out[0]) if ok else None
 
 
 def select_good_tracks(problem: abi.Problem, long_track_length_threshold: int,

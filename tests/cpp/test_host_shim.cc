@@ -351,6 +351,61 @@ static void TestTrackOpsGpu() {
 }
 
 // BundleAdjustTwoViews (bundle_adjust_two_views.cc:113-191) and its batched form through the shim.
+// BundleAdjustTwoViewsAngular through the shim: normalised coordinates of exact correspondences, the
+// relative pose started off the truth; single calls equal the batched call
+static void TestTwoViewsAngularGpu() {
+  unsigned s = 99;
+  const int P = 4;
+  std::vector<TwoViewInfo> info(P), infob(P);
+  std::vector<std::vector<FeatureCorrespondence>> corr(P);
+  for (int p = 0; p < P; ++p) {
+    const double aa[3] = {0.04 * urand(&s), -0.05 * urand(&s), 0.02};
+    double c[3] = {1.0 + 0.3 * urand(&s), 0.2 * urand(&s), 0.2 * urand(&s)};
+    const double cn = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    for (double& v : c) v /= cn;
+    for (int i = 0; i < 80 + 30 * p; ++i) {
+      const double X[3] = {4 * (urand(&s) - 0.5), 4 * (urand(&s) - 0.5), 4 + 5 * urand(&s)};
+      const double a[3] = {X[0] - c[0], X[1] - c[1], X[2] - c[2]};
+      double q[3];
+      Rodrigues(aa, a, q);
+      corr[p].emplace_back(Feature(X[0] / X[2], X[1] / X[2]), Feature(q[0] / q[2], q[1] / q[2]));
+    }
+    info[p].rotation_2 = Eigen::Vector3d(aa[0] + 0.02, aa[1] - 0.015, aa[2] + 0.01);
+    double c0[3] = {c[0] + 0.05, c[1] - 0.04, c[2] + 0.03};
+    const double n0 = std::sqrt(c0[0] * c0[0] + c0[1] * c0[1] + c0[2] * c0[2]);
+    info[p].position_2 = Eigen::Vector3d(c0[0] / n0, c0[1] / n0, c0[2] / n0);
+    infob[p] = info[p];
+  }
+  BundleAdjustmentOptions o;
+  std::vector<BundleAdjustmentSummary> single(P);
+  for (int p = 0; p < P; ++p) {
+    single[p] = BundleAdjustTwoViewsAngular(o, corr[p], &info[p]);
+    EXPECT(single[p].success && single[p].final_cost < 1e-3 * single[p].initial_cost);
+    const Eigen::Vector3d& t = info[p].position_2;
+    EXPECT(std::fabs(t[0] * t[0] + t[1] * t[1] + t[2] * t[2] - 1.0) < 1e-12);
+  }
+  std::vector<TwoViewAngularProblem> batch(P);
+  for (int p = 0; p < P; ++p) {
+    batch[p].correspondences = &corr[p];
+    batch[p].info = &infob[p];
+  }
+  const std::vector<BundleAdjustmentSummary> all = BundleAdjustTwoViewsAngularBatch(o, &batch);
+  EXPECT(all.size() == static_cast<size_t>(P));
+  double worst = 0.0;
+  for (int p = 0; p < P && all.size() == static_cast<size_t>(P); ++p) {
+    EXPECT(all[p].final_cost == single[p].final_cost);
+    for (int a = 0; a < 3; ++a) {
+      worst = std::fmax(worst, std::fabs(info[p].rotation_2[a] - infob[p].rotation_2[a]));
+      worst = std::fmax(worst, std::fabs(info[p].position_2[a] - infob[p].position_2[a]));
+    }
+  }
+  std::printf("two-view angular BA: %d pairs, cost %.4e -> %.4e (pair 0), batched vs single max |d| %.2e\n", P,
+              single[0].initial_cost, single[0].final_cost, worst);
+  EXPECT(worst == 0.0);
+  const BundleAdjustmentSummary bad = BundleAdjustTwoViewsAngular(o, corr[0], nullptr);
+  EXPECT(!bad.success);
+}
+
 static void TestTwoViewsGpu() {
   unsigned s = 77;
   auto make_pair = [&](Camera* c1, Camera* c2, std::vector<FeatureCorrespondence>* corr,
@@ -435,6 +490,7 @@ int main(int argc, char** argv) {
     TestGpu();
     TestTrackOpsGpu();
     TestTwoViewsGpu();
+    TestTwoViewsAngularGpu();
   }
   std::printf("%s: %d failure(s)\n", mode.c_str(), g_fail);
   return g_fail ? 1 : 0;

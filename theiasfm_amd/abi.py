@@ -185,6 +185,17 @@ class CTwoViewBatch(C.Structure):
     ]
 
 
+class CTwoViewAngularBatch(C.Structure):
+    _fields_ = [
+        ("num_pairs", C.c_int32),
+        ("rotation2", C.POINTER(C.c_double)),
+        ("position2", C.POINTER(C.c_double)),
+        ("correspondence_ptr", C.POINTER(C.c_int64)),
+        ("features1", C.POINTER(C.c_double)),
+        ("features2", C.POINTER(C.c_double)),
+    ]
+
+
 class CSelectSummary(C.Structure):
     _fields_ = [
         ("num_tracks", C.c_int64),
@@ -446,4 +457,41 @@ class TwoViewBatch:
         b.features1 = _ptr(self.features1, C.c_double)
         b.features2 = _ptr(self.features2, C.c_double)
         b.points = _ptr(self.points, C.c_double)
+        return b
+
+
+@dataclass
+class TwoViewAngularBatch:
+    """View pairs for the batched BundleAdjustTwoViewsAngular (``tmi_ba_two_view_angular_batch``)."""
+
+    rotation2: np.ndarray              # [P, 3] angle-axis, in/out
+    position2: np.ndarray              # [P, 3] unit norm, in/out
+    correspondence_ptr: np.ndarray     # [P + 1] int64
+    features1: np.ndarray              # [N, 2] normalised image coordinates
+    features2: np.ndarray
+
+    def __post_init__(self):
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+        self.rotation2 = f64(self.rotation2).reshape(-1, 3)
+        self.position2 = f64(self.position2).reshape(-1, 3)
+        self.correspondence_ptr = np.ascontiguousarray(self.correspondence_ptr, dtype=np.int64)
+        self.features1 = f64(self.features1).reshape(-1, 2)
+        self.features2 = f64(self.features2).reshape(-1, 2)
+
+    @property
+    def num_pairs(self) -> int:
+        return self.rotation2.shape[0]
+
+    def copy(self) -> "TwoViewAngularBatch":
+        return TwoViewAngularBatch(self.rotation2.copy(), self.position2.copy(), self.correspondence_ptr.copy(),
+                                   self.features1.copy(), self.features2.copy())
+
+    def as_c(self) -> CTwoViewAngularBatch:
+        b = CTwoViewAngularBatch()
+        b.num_pairs = self.num_pairs
+        b.rotation2 = _ptr(self.rotation2, C.c_double)
+        b.position2 = _ptr(self.position2, C.c_double)
+        b.correspondence_ptr = _ptr(self.correspondence_ptr, C.c_int64)
+        b.features1 = _ptr(self.features1, C.c_double)
+        b.features2 = _ptr(self.features2, C.c_double)
         return b

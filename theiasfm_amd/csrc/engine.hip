@@ -2494,6 +2494,133 @@ int32_t tmi_ba_adjust_tracks(tmi_ba_problem* P, const tmi_ba_options* O, int8_t*
   return rc;
 }
 
+// BundleAdjustTwoViewsAngular for a batch of view pairs (two_view_kernels.h)
+int32_t tmi_ba_adjust_two_views_angular(tmi_ba_two_view_angular_batch* Bh, int32_t max_num_iterations, int32_t device,
+                                        int8_t* pair_termination, int32_t* pair_iterations,
+                                        double* pair_initial_cost, double* pair_final_cost,
+                                        tmi_ba_track_batch_summary* sum) {
+  if (!Bh || !sum) return TMI_BA_ERR_INVALID_ARGUMENT;
+  memset(sum, 0, sizeof(*sum));
+  if (Bh->num_pairs < 0 || max_num_iterations < 0) return TMI_BA_ERR_INVALID_ARGUMENT;
+  const int P = Bh->num_pairs;
+  if (P > 0 && (!Bh->rotation2 || !Bh->position2 || !Bh->correspondence_ptr)) return TMI_BA_ERR_INVALID_ARGUMENT;
+  const double t0 = now_s();
+  const int64_t N = P ? Bh->correspondence_ptr[P] : 0;
+  for (int p = 0; p < P; ++p)
+    if (Bh->correspondence_ptr[p + 1] < Bh->correspondence_ptr[p]) return TMI_BA_ERR_INVALID_ARGUMENT;
+  if (N > 0 && (!Bh->features1 || !Bh->features2)) return TMI_BA_ERR_INVALID_ARGUMENT;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    g_last_error = "no HIP device visible (the device path has no CPU fallback)";
+    return TMI_BA_ERR_NO_DEVICE;
+  }
+  if (device >= ndev) return TMI_BA_ERR_INVALID_ARGUMENT;
+  if (P == 0) return TMI_BA_OK;
+  tmi_ba_solver* s = new tmi_ba_solver();  // holder of the allocations (freed by tmi_ba_solver_destroy)
+  s->light = true;
+  auto done = [&](int rc) {
+    if (rc != TMI_BA_OK) g_last_error = s->error;
+    tmi_ba_solver_destroy(s);
+    sum->seconds = now_s() - t0;
+    return rc;
+  };
+  if (device >= 0) s->device = device;
+  else if (hipGetDevice(&s->device) != hipSuccess) return done(TMI_BA_ERR_DEVICE);
+  if (hipSetDevice(s->device) != hipSuccess) return done(TMI_BA_ERR_DEVICE);
+  if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return done(TMI_BA_ERR_DEVICE);
+  int rc;
+  auto up = [&](double** dst, const double* src, size_t n) -> int {
+    double* d = nullptr;
+    int r = dev_alloc(s, &d, n);
+    if (r) return r;
+    if (n && hipMemcpyAsync(d, src, n * sizeof(double), hipMemcpyHostToDevice, s->stream) != hipSuccess) {
+      s->error = "hipMemcpyAsync failed";
+      return TMI_BA_ERR_DEVICE;
+    }
+    *dst = d;
+    return TMI_BA_OK;
+  };
+  std::vector<long long> cptr(Bh->correspondence_ptr, Bh->correspondence_ptr + P + 1);
+  TwoViewAngularBatch B;
+  memset(&B, 0, sizeof(B));
+  B.num_pairs = P;
+  double *d_rot, *d_pos, *d_f1, *d_f2;
+  long long* d_cptr = nullptr;
+  if ((rc = up(&d_rot, Bh->rotation2, (size_t)3 * P))) return done(rc);
+  if ((rc = up(&d_pos, Bh->position2, (size_t)3 * P))) return done(rc);
+  if ((rc = up(&d_f1, Bh->features1, (size_t)2 * N))) return done(rc);
+  if ((rc = up(&d_f2, Bh->features2, (size_t)2 * N))) return done(rc);
+  if ((rc = dev_alloc(s, &d_cptr, (size_t)P + 1))) return done(rc);
+  if (hipMemcpyAsync(d_cptr, cptr.data(), ((size_t)P + 1) * sizeof(long long), hipMemcpyHostToDevice, s->stream) != hipSuccess)
+    return done(TMI_BA_ERR_DEVICE);
+  B.rot2 = d_rot; B.pos2 = d_pos; B.corr_ptr = d_cptr; B.feat1 = d_f1; B.feat2 = d_f2;
+  signed char* d_term;
+  int* d_iter;
+  double *d_c0, *d_cf;
+  if ((rc = dev_alloc(s, &d_term, (size_t)P))) return done(rc);
+  if ((rc = dev_alloc(s, &d_iter, (size_t)P))) return done(rc);
+  if ((rc = dev_alloc(s, &d_c0, (size_t)P))) return done(rc);
+  if ((rc = dev_alloc(s, &d_cf, (size_t)P))) return done(rc);
+  TwoViewArgs A;
+  memset(&A, 0, sizeof(A));
+  A.max_num_iterations = max_num_iterations;
+  A.jacobi_scaling = 1;
+  // Ceres Solver::Options defaults (SetSolverOptions, bundle_adjust_two_views.cc:57-69, overrides none of these)
+  A.function_tolerance = 1e-6;
+  A.gradient_tolerance = 1e-10;
+  A.parameter_tolerance = 1e-8;
+  A.initial_radius = 1e4;
+  A.max_radius = 1e16;
+  A.min_radius = 1e-32;
+  A.min_relative_decrease = 1e-3;
+  A.lm_lo = 1e-6;
+  A.lm_hi = 1e32;
+  A.max_num_consecutive_invalid_steps = 5;
+  hipEvent_t ea, eb;
+  if (hipEventCreate(&ea) != hipSuccess || hipEventCreate(&eb) != hipSuccess) return done(TMI_BA_ERR_DEVICE);
+  hipEventRecord(ea, s->stream);
+  hipLaunchKernelGGL(two_view_angular_kernel, dim3((P + 3) / 4), dim3(256), 0, s->stream, B, A, d_term, d_iter, d_c0, d_cf);
+  hipEventRecord(eb, s->stream);
+  std::vector<signed char> term((size_t)P);
+  std::vector<int> iters((size_t)P);
+  std::vector<double> c0((size_t)P), cf((size_t)P), rot((size_t)3 * P), pos((size_t)3 * P);
+  bool okc = hipMemcpyAsync(term.data(), d_term, (size_t)P, hipMemcpyDeviceToHost, s->stream) == hipSuccess;
+  okc = okc && hipMemcpyAsync(iters.data(), d_iter, (size_t)P * sizeof(int), hipMemcpyDeviceToHost, s->stream) == hipSuccess;
+  okc = okc && hipMemcpyAsync(c0.data(), d_c0, (size_t)P * 8, hipMemcpyDeviceToHost, s->stream) == hipSuccess;
+  okc = okc && hipMemcpyAsync(cf.data(), d_cf, (size_t)P * 8, hipMemcpyDeviceToHost, s->stream) == hipSuccess;
+  okc = okc && hipMemcpyAsync(rot.data(), d_rot, rot.size() * 8, hipMemcpyDeviceToHost, s->stream) == hipSuccess;
+  okc = okc && hipMemcpyAsync(pos.data(), d_pos, pos.size() * 8, hipMemcpyDeviceToHost, s->stream) == hipSuccess;
+  const hipError_t se = hipStreamSynchronize(s->stream);
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, ea, eb);
+  hipEventDestroy(ea);
+  hipEventDestroy(eb);
+  if (!okc || se != hipSuccess) {
+    s->error = std::string("angular two-view batch failed on the device: ") + hipGetErrorString(se);
+    return done(TMI_BA_ERR_DEVICE);
+  }
+  for (int p = 0; p < P; ++p) {
+    const int t = term[p];
+    if (t >= 0) {
+      sum->num_tracks++;
+      if (t == 0 || t == 1) sum->num_success++;
+      sum->total_iterations += iters[p];
+    }
+    if (t == 0 || t == 1) {  // termination != FAILURE: write back
+      for (int a = 0; a < 3; ++a) {
+        Bh->rotation2[(size_t)3 * p + a] = rot[(size_t)3 * p + a];
+        Bh->position2[(size_t)3 * p + a] = pos[(size_t)3 * p + a];
+      }
+    }
+    if (pair_termination) pair_termination[p] = (int8_t)t;
+    if (pair_iterations) pair_iterations[p] = iters[p];
+    if (pair_initial_cost) pair_initial_cost[p] = c0[p];
+    if (pair_final_cost) pair_final_cost[p] = cf[p];
+  }
+  sum->kernel_seconds = ms * 1e-3;
+  return done(TMI_BA_OK);
+}
+
 // SelectGoodTracksForBundleAdjustment (select_good_tracks_for_bundle_adjustment.cc:251-327):
 // the projections (track statistics) run on the device, the per-view grid / ranking logic --
 // integer compares over the view's feature list -- on the host.

@@ -586,4 +586,439 @@ __global__ __launch_bounds__(256) void two_view_lm_kernel(TwoViewBatch B, TwoVie
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Batched theia::BundleAdjustTwoViewsAngular (bundle_adjust_two_views.cc:193-240): relative
+// rotation (angle-axis) and unit-norm relative position of a view pair from one AngularEpipolarError
+// residual per correspondence (angular_epipolar_error.h:47-89), position on the unit sphere through
+// AutoDiffLocalParameterization<UnitNormThreeVectorParameterization, 3, 3>
+// (unit_norm_three_vector_parameterization.h:45-63).  ONE WAVEFRONT PER PAIR: lanes walk the
+// correspondences, residual and its 6 derivatives come from forward-mode dual numbers (what Ceres'
+// autodiff evaluates), J^T J / J^T r are reduced over the wave and every lane solves the 6 x 6 damped
+// system itself, so the trust-region state machine (Ceres 1.14 semantics, the loop of track_lm_kernel)
+// runs replicated without divergence.
+// ------------------------------------------------------------------------------------------------
+namespace tva {
+struct D6 {
+  double a;
+  double v[6];
+};
+__device__ __forceinline__ D6 cst(double c) {
+  D6 r;
+  r.a = c;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) r.v[i] = 0.0;
+  return r;
+}
+__device__ __forceinline__ D6 var(double c, int k) {
+  D6 r = cst(c);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) r.v[i] = (i == k) ? 1.0 : 0.0;
+  return r;
+}
+__device__ __forceinline__ D6 operator+(const D6& f, const D6& g) {
+  D6 r;
+  r.a = f.a + g.a;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) r.v[i] = f.v[i] + g.v[i];
+  return r;
+}
+__device__ __forceinline__ D6 operator-(const D6& f, const D6& g) {
+  D6 r;
+  r.a = f.a - g.a;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) r.v[i] = f.v[i] - g.v[i];
+  return r;
+}
+__device__ __forceinline__ D6 operator-(const D6& f) {
+  D6 r;
+  r.a = -f.a;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) r.v[i] = -f.v[i];
+  return r;
+}
+__device__ __forceinline__ D6 operator*(const D6& f, const D6& g) {
+  D6 r;
+  r.a = f.a * g.a;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) r.v[i] = f.a * g.v[i] + f.v[i] * g.a;
+  return r;
+}
+__device__ __forceinline__ D6 operator*(const D6& f, double c) {
+  D6 r;
+  r.a = f.a * c;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) r.v[i] = f.v[i] * c;
+  return r;
+}
+__device__ __forceinline__ D6 operator/(const D6& f, const D6& g) {
+  D6 r;
+  const double gi = 1.0 / g.a;
+  const double fr = f.a * gi;
+  r.a = fr;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) r.v[i] = (f.v[i] - fr * g.v[i]) * gi;
+  return r;
+}
+__device__ __forceinline__ D6 dsqrt(const D6& f) {
+  D6 r;
+  const double t = sqrt(f.a);
+  const double s = 1.0 / (2.0 * t);
+  r.a = t;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) r.v[i] = f.v[i] * s;
+  return r;
+}
+__device__ __forceinline__ void dsincos(const D6& f, D6* s, D6* c) {
+  double sv, cv;
+  sincos(f.a, &sv, &cv);
+  s->a = sv;
+  c->a = cv;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    s->v[i] = cv * f.v[i];
+    c->v[i] = -sv * f.v[i];
+  }
+}
+
+// ceres::AngleAxisToRotationMatrix (published ceres/rotation.h, 1.x) on duals
+__device__ __forceinline__ void rotation(const D6 (&aa)[3], D6 (&R)[3][3]) {
+  const D6 one = cst(1.0);
+  const D6 theta2 = aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2];
+  if (theta2.a > kDblEpsilon) {
+    const D6 theta = dsqrt(theta2);
+    const D6 wx = aa[0] / theta, wy = aa[1] / theta, wz = aa[2] / theta;
+    D6 s, c;
+    dsincos(theta, &s, &c);
+    const D6 omc = one - c;
+    R[0][0] = c + wx * wx * omc;
+    R[1][0] = wz * s + wx * wy * omc;
+    R[2][0] = -(wy * s) + wx * wz * omc;
+    R[0][1] = wx * wy * omc - wz * s;
+    R[1][1] = c + wy * wy * omc;
+    R[2][1] = wx * s + wy * wz * omc;
+    R[0][2] = wy * s + wx * wz * omc;
+    R[1][2] = -(wx * s) + wy * wz * omc;
+    R[2][2] = c + wz * wz * omc;
+  } else {
+    R[0][0] = one;    R[0][1] = -aa[2]; R[0][2] = aa[1];
+    R[1][0] = aa[2];  R[1][1] = one;    R[1][2] = -aa[0];
+    R[2][0] = -aa[1]; R[2][1] = aa[0];  R[2][2] = one;
+  }
+}
+
+// angular_epipolar_error.h:52-84 with R and T = I - t t^T already formed.  false where the functor is.
+__device__ __forceinline__ bool residual(const D6 (&R)[3][3], const D6 (&T)[3][3], const D6 (&t)[3], double f1x,
+                                         double f1y, double f2x, double f2y, D6* out) {
+  const double f1[3] = {f1x, f1y, 1.0}, f2[3] = {f2x, f2y, 1.0};
+  D6 Rf2[3], Rtf2[3], Tf1[3], TRtf2[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    Rf2[i] = R[i][0] * f2[0] + R[i][1] * f2[1] + R[i][2] * f2[2];
+    Rtf2[i] = R[0][i] * f2[0] + R[1][i] * f2[1] + R[2][i] * f2[2];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    Tf1[i] = T[i][0] * f1[0] + T[i][1] * f1[1] + T[i][2] * f1[2];
+    TRtf2[i] = T[i][0] * Rtf2[0] + T[i][1] * Rtf2[1] + T[i][2] * Rtf2[2];
+  }
+  D6 a = Tf1[0] * f1[0] + Tf1[1] * f1[1] + Tf1[2] * f1[2];
+  a = a + Rf2[0] * TRtf2[0] + Rf2[1] * TRtf2[1] + Rf2[2] * TRtf2[2];
+  const D6 cx = Rtf2[2] * f1[1] - Rtf2[1] * f1[2];
+  const D6 cy = Rtf2[0] * f1[2] - Rtf2[2] * f1[0];
+  const D6 cz = Rtf2[1] * f1[0] - Rtf2[0] * f1[1];
+  const D6 b = t[0] * cx + t[1] * cy + t[2] * cz;
+  const D6 sq = (a * a) * 0.25 - b * b;
+  if (sq.a < 0.0) return false;
+  *out = a * 0.5 - dsqrt(sq);
+  return true;
+}
+
+// UnitNormThreeVectorParameterization::operator()
+__device__ __forceinline__ void unit_plus(const double x[3], const double d[3], double out[3]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) out[i] = x[i] + d[i];
+  const double sq = out[0] * out[0] + out[1] * out[1] + out[2] * out[2];
+  if (sq > 0.0) {
+    const double nrm = sqrt(sq);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out[i] /= nrm;
+  }
+}
+
+// One pass over the pair's correspondences at x = [rotation | position].  JAC: also H = Js^T Js (packed
+// upper), g = Js^T r of the SCALED LOCAL Jacobian.  All lanes return the same sums.  false on failure.
+template <bool JAC>
+__device__ __forceinline__ bool linearize(const double (&x)[6], const double* __restrict__ f1,
+                                          const double* __restrict__ f2, long long n, const double (&sc)[6],
+                                          double (&H)[21], double (&g)[6], double* cost, int lane) {
+  // d Plus(x, delta) / d delta at 0 of the position block, by duals (AutoDiffLocalParameterization)
+  double P[3][3];
+  if (JAC) {
+    D6 xp[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xp[i] = var(x[3 + i], i);
+    const D6 sq = xp[0] * xp[0] + xp[1] * xp[1] + xp[2] * xp[2];
+    if (sq.a > 0.0) {
+      const D6 nrm = dsqrt(sq);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) xp[i] = xp[i] / nrm;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) P[i][k] = xp[i].v[k];
+  }
+  D6 rot[3], t[3], R[3][3], T[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    rot[i] = JAC ? var(x[i], i) : cst(x[i]);
+    t[i] = JAC ? var(x[3 + i], 3 + i) : cst(x[3 + i]);
+  }
+  rotation(rot, R);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) T[i][j] = cst(i == j ? 1.0 : 0.0) - t[i] * t[j];
+  double Ha[21], ga[6], c = 0.0, bad = 0.0;
+#pragma unroll
+  for (int i = 0; i < 21; ++i) Ha[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) ga[i] = 0.0;
+  for (long long q = lane; q < n; q += 64) {
+    D6 e;
+    if (!residual(R, T, t, f1[2 * q], f1[2 * q + 1], f2[2 * q], f2[2 * q + 1], &e)) {
+      bad = 1.0;
+      continue;
+    }
+    c += 0.5 * e.a * e.a;
+    if (JAC) {
+      double J[6];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) J[k] = e.v[k] * sc[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) J[3 + k] = (e.v[3] * P[0][k] + e.v[4] * P[1][k] + e.v[5] * P[2][k]) * sc[3 + k];
+      int idx = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+#pragma unroll
+        for (int b = a; b < 6; ++b) Ha[idx++] += J[a] * J[b];
+        ga[a] += J[a] * e.a;
+      }
+    }
+  }
+  if (JAC) {
+#pragma unroll
+    for (int i = 0; i < 21; ++i) H[i] = wave_sum(Ha[i]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) g[i] = wave_sum(ga[i]);
+  }
+  *cost = wave_sum(c);
+  return wave_sum(bad) == 0.0;
+}
+
+// (H + diag) y = g by Cholesky in registers; false if not positive definite
+__device__ __forceinline__ bool solve6(const double (&H)[21], const double (&dadd)[6], const double (&g)[6],
+                                       double (&y)[6]) {
+  double L[6][6];
+  bool pd = true;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double d = H[sym_idx(j, j, 6)] + dadd[j];
+#pragma unroll
+    for (int m = 0; m < j; ++m) d -= L[j][m] * L[j][m];
+    if (!(d > 0.0)) {
+      pd = false;
+      d = 1.0;
+    }
+    const double l = sqrt(d);
+    L[j][j] = l;
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      double t = H[sym_idx(j, i, 6)];
+#pragma unroll
+      for (int m = 0; m < j; ++m) t -= L[i][m] * L[j][m];
+      L[i][j] = t / l;
+    }
+  }
+  double z[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double t = g[i];
+#pragma unroll
+    for (int m = 0; m < i; ++m) t -= L[i][m] * z[m];
+    z[i] = t / L[i][i];
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    double t = z[i];
+#pragma unroll
+    for (int m = i + 1; m < 6; ++m) t -= L[m][i] * y[m];
+    y[i] = t / L[i][i];
+  }
+  return pd;
+}
+}  // namespace tva
+
+struct TwoViewAngularBatch {
+  int num_pairs;
+  double* rot2;             // [3 P] in/out
+  double* pos2;             // [3 P] in/out
+  const long long* corr_ptr;
+  const double* feat1;      // [2 N]
+  const double* feat2;
+};
+
+__global__ __launch_bounds__(256) void two_view_angular_kernel(TwoViewAngularBatch B, TwoViewArgs A,
+                                                               signed char* __restrict__ termination,
+                                                               int* __restrict__ iterations,
+                                                               double* __restrict__ initial_cost,
+                                                               double* __restrict__ final_cost) {
+  const int lane = threadIdx.x & 63;
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= B.num_pairs) return;
+  const long long c0 = B.corr_ptr[p], n = B.corr_ptr[p + 1] - c0;
+  if (n <= 0) {
+    if (lane == 0) {
+      termination[p] = -1;
+      iterations[p] = 0;
+      initial_cost[p] = 0.0;
+      final_cost[p] = 0.0;
+    }
+    return;
+  }
+  const double* f1 = B.feat1 + 2 * c0;
+  const double* f2 = B.feat2 + 2 * c0;
+  double x[6];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    x[i] = B.rot2[3 * (size_t)p + i];
+    x[3 + i] = B.pos2[3 * (size_t)p + i];
+  }
+  double sc[6] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0}, H[21], g[6], cost = 0.0;
+  if (!tva::linearize<true>(x, f1, f2, n, sc, H, g, &cost, lane)) {
+    if (lane == 0) {
+      termination[p] = 3;
+      iterations[p] = 0;
+      initial_cost[p] = 0.0;
+      final_cost[p] = 0.0;
+    }
+    return;
+  }
+  if (lane == 0) initial_cost[p] = cost;
+  double gmax = 0.0;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) gmax = fmax(gmax, fabs(g[a]));
+#pragma unroll
+  for (int a = 0; a < 6; ++a) sc[a] = 1.0 / (1.0 + sqrt(H[sym_idx(a, a, 6)]));
+  tva::linearize<true>(x, f1, f2, n, sc, H, g, &cost, lane);
+  double x_norm = 0.0;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) x_norm += x[a] * x[a];
+  x_norm = sqrt(x_norm);
+  double radius = A.initial_radius, decrease_factor = 2.0;
+  int invalid_run = 0, iter = 0, term = 1;
+  if (gmax <= A.gradient_tolerance) {
+    term = 0;
+  } else {
+    for (;;) {
+      if (iter >= A.max_num_iterations) break;
+      ++iter;
+      double dadd[6], y[6];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) dadd[a] = fmin(fmax(H[sym_idx(a, a, 6)], A.lm_lo), A.lm_hi) / radius;
+      bool step_ok = tva::solve6(H, dadd, g, y);
+      double mcc = 0.0;
+      if (step_ok) {
+        double yg = 0.0, yHy = 0.0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          yg += y[a] * g[a];
+          double t = 0.0;
+#pragma unroll
+          for (int b = 0; b < 6; ++b) t += H[a <= b ? sym_idx(a, b, 6) : sym_idx(b, a, 6)] * y[b];
+          yHy += y[a] * t;
+        }
+        mcc = yg - 0.5 * yHy;
+        if (!(mcc > 0.0)) step_ok = false;
+      }
+      if (!step_ok) {
+        if (++invalid_run >= A.max_num_consecutive_invalid_steps) {
+          term = 2;
+          break;
+        }
+        radius /= decrease_factor;
+        decrease_factor *= 2.0;
+        if (radius < A.min_radius) {
+          term = 0;
+          break;
+        }
+        continue;
+      }
+      invalid_run = 0;
+      double xc[6], d[6];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) d[a] = -y[a] * sc[a];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) xc[a] = x[a] + d[a];
+      tva::unit_plus(x + 3, d + 3, xc + 3);
+      double step_sq = 0.0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) step_sq += (xc[a] - x[a]) * (xc[a] - x[a]);
+      double cand, Hd[21], gd[6];
+      if (!tva::linearize<false>(xc, f1, f2, n, sc, Hd, gd, &cand, lane)) cand = 1.7976931348623157e308;
+      if (sqrt(step_sq) <= A.parameter_tolerance * (x_norm + A.parameter_tolerance)) {
+        term = 0;
+        break;
+      }
+      const double cost_change = cost - cand;
+      if (fabs(cost_change) <= A.function_tolerance * cost) {
+        term = 0;
+        break;
+      }
+      const double rd = cost_change / mcc;
+      if (rd > A.min_relative_decrease) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) x[a] = xc[a];
+        x_norm = 0.0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) x_norm += x[a] * x[a];
+        x_norm = sqrt(x_norm);
+        if (!tva::linearize<true>(x, f1, f2, n, sc, H, g, &cost, lane)) {
+          term = 2;
+          break;
+        }
+        gmax = 0.0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) gmax = fmax(gmax, fabs(g[a] / sc[a]));
+        radius = radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rd - 1.0, 3.0));
+        radius = fmin(A.max_radius, radius);
+        decrease_factor = 2.0;
+        if (gmax <= A.gradient_tolerance) {
+          term = 0;
+          break;
+        }
+      } else {
+        radius /= decrease_factor;
+        decrease_factor *= 2.0;
+      }
+      if (radius < A.min_radius) {
+        term = 0;
+        break;
+      }
+    }
+  }
+  if (lane != 0) return;
+  termination[p] = (signed char)term;
+  iterations[p] = iter;
+  final_cost[p] = cost;
+  if (term != 2) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      B.rot2[3 * (size_t)p + i] = x[i];
+      B.pos2[3 * (size_t)p + i] = x[3 + i];
+    }
+  }
+}
+
 }  // namespace tmi

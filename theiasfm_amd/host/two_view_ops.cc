@@ -112,4 +112,78 @@ BundleAdjustmentSummary BundleAdjustTwoViews(const TwoViewBundleAdjustmentOption
   return r.empty() ? BundleAdjustmentSummary() : r[0];
 }
 
+// ---- BundleAdjustTwoViewsAngular (bundle_adjust_two_views.cc:193-240) ---------------------------
+std::vector<BundleAdjustmentSummary> BundleAdjustTwoViewsAngularBatch(const BundleAdjustmentOptions& options,
+                                                                      std::vector<TwoViewAngularProblem>* problems) {
+  std::vector<BundleAdjustmentSummary> out;
+  if (problems == nullptr || problems->empty()) return out;
+  const auto t0 = std::chrono::steady_clock::now();
+  const size_t P = problems->size();
+  out.resize(P);
+  std::vector<double> rot(3 * P, 0.0), pos(3 * P, 0.0), f1, f2;
+  std::vector<int64_t> ptr(P + 1, 0);
+  std::vector<char> valid(P, 0);
+  for (size_t p = 0; p < P; ++p) {
+    const TwoViewAngularProblem& q = (*problems)[p];
+    ptr[p + 1] = ptr[p];
+    if (!q.info || !q.correspondences) continue;  // the reference CHECK-fails; the shim reports failure
+    valid[p] = 1;
+    for (int a = 0; a < 3; ++a) {
+      rot[3 * p + a] = q.info->rotation_2[a];
+      pos[3 * p + a] = q.info->position_2[a];
+    }
+    for (const FeatureCorrespondence& m : *q.correspondences) {
+      f1.push_back(m.feature1.x());
+      f1.push_back(m.feature1.y());
+      f2.push_back(m.feature2.x());
+      f2.push_back(m.feature2.y());
+    }
+    ptr[p + 1] = ptr[p] + static_cast<int64_t>(q.correspondences->size());
+  }
+  tmi_ba_two_view_angular_batch B;
+  B.num_pairs = static_cast<int32_t>(P);
+  B.rotation2 = rot.data();
+  B.position2 = pos.data();
+  B.correspondence_ptr = ptr.data();
+  B.features1 = f1.data();
+  B.features2 = f2.data();
+  std::vector<int8_t> term(P, -1);
+  std::vector<int32_t> iters(P, 0);
+  std::vector<double> c0(P, 0.0), cf(P, 0.0);
+  tmi_ba_track_batch_summary bs;
+  const double setup = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  const int rc = tmi_ba_adjust_two_views_angular(&B, 200 /* SetSolverOptions :64 */, options.device, term.data(),
+                                                 iters.data(), c0.data(), cf.data(), &bs);
+  if (rc != TMI_BA_OK) {
+    std::fprintf(stderr, "[theia::BundleAdjustTwoViewsAngular] device batch failed: %s\n", tmi_ba_last_error());
+    return out;  // success = false everywhere
+  }
+  for (size_t p = 0; p < P; ++p) {
+    BundleAdjustmentSummary& s = out[p];
+    s.setup_time_in_seconds = setup / static_cast<double>(P);
+    s.solve_time_in_seconds = bs.seconds / static_cast<double>(P);
+    if (!valid[p]) continue;
+    s.initial_cost = c0[p];
+    s.final_cost = cf[p];
+    s.success = term[p] == 0 || term[p] == 1 || term[p] == -1;  // termination_type != FAILURE (:236-238)
+    if (term[p] != 0 && term[p] != 1) continue;
+    TwoViewInfo* info = (*problems)[p].info;
+    for (int a = 0; a < 3; ++a) {
+      info->rotation_2[a] = rot[3 * p + a];
+      info->position_2[a] = pos[3 * p + a];
+    }
+  }
+  return out;
+}
+
+BundleAdjustmentSummary BundleAdjustTwoViewsAngular(const BundleAdjustmentOptions& options,
+                                                    const std::vector<FeatureCorrespondence>& correspondences,
+                                                    TwoViewInfo* info) {
+  std::vector<TwoViewAngularProblem> one(1);
+  one[0].correspondences = &correspondences;
+  one[0].info = info;
+  const std::vector<BundleAdjustmentSummary> r = BundleAdjustTwoViewsAngularBatch(options, &one);
+  return r.empty() ? BundleAdjustmentSummary() : r[0];
+}
+
 }  // namespace theia

@@ -30,7 +30,7 @@ EXPORTS = (
     "tmi_ba_solver_filter_outlier_tracks", "tmi_ba_filter_outlier_tracks",
     "tmi_ba_solver_adjust_tracks", "tmi_ba_adjust_tracks",
     "tmi_ba_solver_select_good_tracks", "tmi_ba_select_good_tracks",
-    "tmi_ba_adjust_two_views", "tmi_ba_solver_structure_checksums",
+    "tmi_ba_adjust_two_views", "tmi_ba_adjust_two_views_angular", "tmi_ba_solver_structure_checksums",
 )
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
@@ -113,6 +113,10 @@ def load():
     L.tmi_ba_adjust_two_views.argtypes = [C.POINTER(abi.CTwoViewBatch), C.c_int32, C.c_int32, C.c_int32,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, TS]
     L.tmi_ba_adjust_two_views.restype = C.c_int32
+    L.tmi_ba_adjust_two_views_angular.argtypes = [C.POINTER(abi.CTwoViewAngularBatch), C.c_int32, C.c_int32,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.POINTER(abi.CTrackBatchSummary)]
+    L.tmi_ba_adjust_two_views_angular.restype = C.c_int32
     L.tmi_ba_solver_structure_checksums.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.tmi_ba_solver_structure_checksums.restype = C.c_int32
     SS = C.POINTER(abi.CSelectSummary)
@@ -245,6 +249,25 @@ def adjust_two_views(batch: abi.TwoViewBatch, point_dof: int = 4, max_num_iterat
                                    C.byref(ts))
     if st != 0:
         raise EngineError(st, "tmi_ba_adjust_two_views")
+    return term, iters, c0, c1, ts
+
+
+def adjust_two_views_angular(batch: abi.TwoViewAngularBatch, max_num_iterations: int = 200, device: int = -1):
+    """Batched BundleAdjustTwoViewsAngular; batch.rotation2 / position2 are updated in place for the usable
+    pairs.  Returns (termination [P] int8, iterations [P] int32, initial cost [P], final cost [P],
+    CTrackBatchSummary)."""
+    L = load()
+    cb = batch.as_c()
+    n = batch.num_pairs
+    term = np.full(n, -1, dtype=np.int8)
+    iters = np.zeros(n, dtype=np.int32)
+    c0 = np.zeros(n)
+    c1 = np.zeros(n)
+    ts = abi.CTrackBatchSummary()
+    st = L.tmi_ba_adjust_two_views_angular(C.byref(cb), int(max_num_iterations), int(device), term.ctypes.data,
+                                           iters.ctypes.data, c0.ctypes.data, c1.ctypes.data, C.byref(ts))
+    if st != 0:
+        raise EngineError(st, "tmi_ba_adjust_two_views_angular")
     return term, iters, c0, c1, ts
 
 

@@ -358,3 +358,38 @@ def make_two_view_batch(n_pairs: int, seed: int, *, min_corr: int = 30, max_corr
     k1_0[free, 0] *= 1.01
     k2_0[free, 0] *= 0.99
     return abi.TwoViewBatch(e1, e2_0, m1, m2, k1_0, k2_0, c1, c2, ptr, f1, f2, pts)
+
+
+def make_two_view_angular_batch(n_pairs: int, seed: int, *, min_corr: int = 30, max_corr: int = 300,
+                                noise: float = 1e-3, rotation_error: float = 0.03, position_error: float = 0.08,
+                                rotation_scale: float = 0.05):
+    """Seeded view pairs for BundleAdjustTwoViewsAngular: view 1 at the origin, view 2 at a unit-norm
+    position with a small rotation, points 3-9 units in front of both; features are NORMALISED image
+    coordinates (angular_epipolar_error.h works on calibrated rays) with Gaussian noise; the starting
+    relative pose is the true one perturbed.  Returns (batch, true rotation [P, 3], true position [P, 3])."""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(seed)
+    counts = rng.integers(min_corr, max_corr + 1, n_pairs)
+    ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    N = int(ptr[-1])
+    # small relative rotations: the functor's second term is (R f2) . T (R^T f2) as the reference writes it
+    # (angular_epipolar_error.h:71-72), which only stays positive -- and the residual zero at the true pose --
+    # while R f2 and R^T f2 are close
+    rot_true = rotation_scale * rng.normal(size=(n_pairs, 3))
+    pos_true = rng.normal(size=(n_pairs, 3)) * [1.0, 0.3, 0.3] + [1.5, 0, 0]
+    pos_true /= np.linalg.norm(pos_true, axis=1, keepdims=True)
+    f1 = np.zeros((N, 2))
+    f2 = np.zeros((N, 2))
+    for p in range(n_pairs):
+        n = int(counts[p])
+        X = np.stack([rng.uniform(-2.5, 2.5, n), rng.uniform(-2.0, 2.0, n), rng.uniform(3.0, 9.0, n)], 1)
+        R = Rotation.from_rotvec(rot_true[p])
+        X2 = R.apply(X - pos_true[p])
+        f1[ptr[p]:ptr[p + 1]] = X[:, :2] / X[:, 2:3]
+        f2[ptr[p]:ptr[p + 1]] = X2[:, :2] / X2[:, 2:3]
+    f1 += noise * rng.normal(size=f1.shape)
+    f2 += noise * rng.normal(size=f2.shape)
+    rot0 = rot_true + rotation_error * rng.normal(size=rot_true.shape)
+    pos0 = pos_true + position_error * rng.normal(size=pos_true.shape)
+    pos0 /= np.linalg.norm(pos0, axis=1, keepdims=True)
+    return abi.TwoViewAngularBatch(rot0, pos0, ptr, f1, f2), rot_true, pos_true
