@@ -545,15 +545,17 @@ def main():
         tc = time.perf_counter()
         term_d, it_d, _, c1_d, tas = _lib.adjust_two_views_angular(ta_d)
         t_call = time.perf_counter() - tc
-        ta_o = tab.copy()
+        n_cpu_a = 3000
+        ta_o = tab.head(n_cpu_a)
         tc = time.perf_counter()
         term_o, it_o, _, c1_o = oracle.adjust_two_views_angular(ta_o)
         t_o = time.perf_counter() - tc
+        term_d, it_d = term_d[:n_cpu_a], it_d[:n_cpu_a]
         side["batched_two_view_angular_ba"] = dict(
             kernel_ms=round(tas.kernel_seconds * 1e3, 3), call_ms=round(t_call * 1e3, 2), pairs=int(tab.num_pairs),
             correspondences=int(tab.correspondence_ptr[-1]), lm_iterations=int(tas.total_iterations),
-            pairs_per_s=tab.num_pairs / tas.kernel_seconds, cpu_port_pairs_per_s=tab.num_pairs / t_o,
-            cpu_port_sample=f"all pairs, {oracle.num_threads()} threads",
+            pairs_per_s=tab.num_pairs / tas.kernel_seconds, cpu_port_pairs_per_s=n_cpu_a / t_o,
+            cpu_port_sample=f"first {n_cpu_a} pairs, {oracle.num_threads()} threads",
             termination_mismatches=int((term_d != term_o).sum()), iteration_mismatches=int((it_d != it_o).sum()))
         out["side_kernels"] = side
     solver.close()

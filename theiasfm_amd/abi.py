@@ -486,6 +486,14 @@ class TwoViewAngularBatch:
         return TwoViewAngularBatch(self.rotation2.copy(), self.position2.copy(), self.correspondence_ptr.copy(),
                                    self.features1.copy(), self.features2.copy())
 
+    def head(self, n: int) -> "TwoViewAngularBatch":
+        """the first n pairs (copies)"""
+        n = min(int(n), self.num_pairs)
+        m = int(self.correspondence_ptr[n])
+        return TwoViewAngularBatch(self.rotation2[:n].copy(), self.position2[:n].copy(),
+                                   self.correspondence_ptr[:n + 1].copy(), self.features1[:m].copy(),
+                                   self.features2[:m].copy())
+
     def as_c(self) -> CTwoViewAngularBatch:
         b = CTwoViewAngularBatch()
         b.num_pairs = self.num_pairs
