@@ -104,7 +104,7 @@ def run_both(prob, **opt):
     return (st_d, s_d, a), (st_o, s_o, b)
 
 
-def assert_same_solution(dev, ora, scale, cost_rel=1e-9, rmse_abs=1e-9, param_rel=1e-6):
+def assert_same_solution(dev, ora, scale, cost_rel=1e-9, rmse_abs=1e-9, param_rel=1e-6, projective=False):
     (st_d, s_d, a), (st_o, s_o, b) = dev, ora
     assert st_d == st_o == 0, (st_d, s_d.message, st_o, s_o.message)
     assert s_d.success == 1 and s_o.success == 1
@@ -115,7 +115,13 @@ def assert_same_solution(dev, ora, scale, cost_rel=1e-9, rmse_abs=1e-9, param_re
     assert s_d.num_iterations == s_o.num_iterations
     assert s_d.num_successful_steps == s_o.num_successful_steps
     assert np.abs(a.extrinsics - b.extrinsics).max() <= param_rel * scale
-    assert np.abs(a.points - b.points).max() <= param_rel * scale
+    if projective:
+        # point_dof = 4: the scale of a homogeneous point is a gauge direction (J X = 0) along which two correct
+        # solvers drift apart by rounding noise over the LM diagonal; the point itself is X[:3] / X[3]
+        pa, pb = a.points[:, :3] / a.points[:, 3:4], b.points[:, :3] / b.points[:, 3:4]
+        assert np.abs(pa - pb).max() <= param_rel * scale
+    else:
+        assert np.abs(a.points - b.points).max() <= param_rel * scale
     assert np.abs(a.intrinsics - b.intrinsics).max() <= param_rel * max(1.0, np.abs(b.intrinsics).max())
 
 
@@ -171,7 +177,7 @@ def test_lm_matches_oracle_mixed_models_and_huber():
         # point_dof = 4 + PCG + a robust loss: the free scale of every homogeneous point turns
         # summation-order rounding into ~1e-8 differences; BASELINE.json's
         # bar is 1e-6
-        assert_same_solution(dev, ora, scale=100.0, cost_rel=1e-7, rmse_abs=1e-7, param_rel=1e-5)
+        assert_same_solution(dev, ora, scale=100.0, cost_rel=1e-7, rmse_abs=1e-7, param_rel=1e-5, projective=True)
 
 
 def test_constant_blocks_are_untouched():

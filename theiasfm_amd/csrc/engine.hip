@@ -142,7 +142,9 @@ Launch make_launch(bool fp32) {
         if (exp_mode == 3) { hipLaunchKernelGGL((schur_offdiag_kernel<D, DP, 3>), grid, dim3(256), 0, st, v, R); return; }
         if (exp_mode == 4) { hipLaunchKernelGGL((schur_offdiag_kernel<D, DP, 4>), grid, dim3(256), 0, st, v, R); return; }
 #endif
-        hipLaunchKernelGGL((schur_offdiag_kernel<D, DP>), grid, dim3(256), 0, st, v, R);
+        // without shared intrinsics blocks: the [A | Q] records (no Y record exists unless asked for)
+        if (!SH && !v.write_y) hipLaunchKernelGGL((schur_offdiag_aq_kernel<D, DP>), grid, dim3(256), 0, st, v, R);
+        else hipLaunchKernelGGL((schur_offdiag_kernel<D, DP>), grid, dim3(256), 0, st, v, R);
     };
   L.expand = [](const DeviceView& v, hipStream_t st, RedLayout R, double ir, double lo, double hi, int want_gmax) {
     const int n2 = v.Nrb * D * D;
@@ -269,6 +271,7 @@ struct tmi_ba_solver {
   bool adaptive = false;      // schur_mode auto on one rank: both operators are resident and every LM iteration
                               // takes the cheaper one for the PCG length it expects (see solve)
   bool implicit_now = false;  // the operator of the current LM iteration
+  bool y_records = false;     // point_eliminate writes Y records (shared blocks, or the older Schur kernels by env)
   int n_implicit_iterations = 0;
   int adaptive_break_even = 4;  // PCG iterations up to which the matrix-free operator is the cheaper one
   double cur_inv_radius = 0.0;
@@ -1276,7 +1279,7 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   }
 #undef UP
   const size_t N = (size_t)st.No_pad, NP = (size_t)st.Np_pad;
-  const int YS = ys_of(D, DP), AS = as_of(D, st.has_shared), NS = sym_size(DP);
+  const int YS = ys_of(D, DP), AS = a_alloc_of(D, DP, st.has_shared), NS = sym_size(DP);
   const int n_r = st.Nrb * D;
   s->nblocks_slices = (st.nslices + kSlicesPerBlock - 1) / kSlicesPerBlock;
   if (s->nblocks_slices < 1) s->nblocks_slices = 1;
@@ -1301,19 +1304,20 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   AL(v.pm_r, 2 * N) AL(v.pm_A, 2 * D * N) AL(v.pm_Jp, 2 * DP * N) AL(s->d_pm_u, 2 * N)
   AL(s->d_cm_t, (s->implicit || s->adaptive) ? (size_t)std::max<int64_t>(st.Nslots, 1) * 2 : 1)
   AL(v.pm_A1, st.has_shared ? 2 * D * N : 1) AL(v.cam_part, (size_t)std::max(st.Ncam_rb, 1) * (2 * D * D + 3 * D))
-  v.write_y = (!s->implicit || st.has_shared) ? 1 : 0;
+  // Y records: the shared-block sums need them; without shared blocks the Schur complement works from the
+  // [A | Q] records and Y exists only for the A/B switches that select the older kernels
+  s->y_records = st.has_shared || getenv("TMI_BA_SCHUR_GATHER") != nullptr || getenv("TMI_BA_SCHUR_Y") != nullptr;
+  v.write_y = (s->y_records && (!s->implicit || st.has_shared)) ? 1 : 0;
   if (s->adaptive) {
-    // cost model measured on MI355X (profiles/r02_r, r02_u): forming S ~69 ps per pair plus the Y records
-    // point_eliminate then writes (~24 ps per observation), a product with S ~192 ps per upper block, a
-    // matrix-free product ~110 ps per observation
-    const double form = 69.0 * (double)st.npairs + 24.0 * (double)st.No, with_s = 192.0 * (double)st.nub,
-                 free = 110.0 * (double)st.No;
+    // cost model measured on MI355X (profiles/r02_r, r02_u): forming S ~69 ps per pair, a product with S
+    // ~192 ps per upper block, a matrix-free product ~110 ps per observation
+    const double form = 69.0 * (double)st.npairs, with_s = 192.0 * (double)st.nub, free = 110.0 * (double)st.No;
     // (a product with S that costs more than a matrix-free one -- many views, little co-visibility: S has more
     // blocks than there are observations to walk -- never pays off: always matrix-free)
     s->adaptive_break_even = free > with_s ? (int)std::min(1.0e6, form / (free - with_s)) : 1 << 30;
   }
   AL(v.cm_Y, v.write_y ? (size_t)std::max<int64_t>(st.Nslots, 1) * YS : 1) AL(v.cm_A, (size_t)std::max<int64_t>(st.Nslots, 1) * AS)
-  v.cm_R = v.cm_A + (size_t)std::max<int64_t>(st.Nslots, 1) * asa_of(D);  // used when !has_shared (AS >= asa + tail)
+  v.cm_R = v.cm_A + (size_t)std::max<int64_t>(st.Nslots, 1) * asa_of(D, DP);  // tails behind the [A | Q] records (!has_shared)
   AL(v.scale_c, std::max(n_r, 1)) AL(v.scale_p, NP * DP)
   AL(v.Vinv, NP * NS) AL(v.gp, NP * DP) AL(v.diag_p, NP * DP) AL(v.yp, NP * DP)
   AL(v.red, s->RL.total) AL(v.Sdiag, (size_t)std::max(st.Nrb, 1) * D * D)
@@ -2037,7 +2041,7 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
       // ... by a clear margin only (forecast at most half the break-even): near the break-even the two cost the
       // same and the formed S stays the default
       s->implicit_now = last_pcg_len <= s->adaptive_break_even / 2;
-      v.write_y = s->implicit_now ? 0 : 1;
+      if (s->y_records) v.write_y = s->implicit_now ? 0 : 1;
       if (s->implicit_now) s->n_implicit_iterations++;
     } else if (s->implicit && iterative) {
       s->n_implicit_iterations++;

@@ -61,8 +61,15 @@ __host__ __device__ constexpr int a_off_sh(int D) { return 2 * D + 7; }
 // alone (stride asa_of(D): 192 B for D = 9, what the cameras pass of the matrix-free product streams 4-5
 // times per LM iteration) and the 64-byte tail {N, r~, r} (cm_R) that only camera_diag reads.  Same bytes
 // written by point_eliminate and read by camera_diag as the one 256-byte record they replace.
-__host__ __device__ constexpr int asa_of(int D) { return (2 * D + 7) & ~7; }
+// The A rows are followed by Q = Jp L^-T (2 x DP) in the same record: Y Y'^T = A^T (Q Q'^T) A', so the Schur
+// complement gathers these [A | Q] records (192 B for 9 x 3, two lines -- what a 216-byte Y record costs as
+// well; 256 B against 320 B and three lines for 9 x 4) and no Y record is written at all.
+__host__ __device__ constexpr int asa_of(int D, int DP) { return (2 * D + 2 * DP + 7) & ~7; }
 constexpr int kRecTail = 8;  // doubles of the tail record
+// doubles of cm_A per slot: one record with shared blocks, rows + tail otherwise
+__host__ __device__ constexpr int a_alloc_of(int D, int DP, bool SH) {
+  return SH ? as_of(D, true) : asa_of(D, DP) + kRecTail;
+}
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -675,7 +682,10 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
                                                               double* partial_max, double* singular_vote) {
   constexpr int NS = sym_size(DP);
   constexpr int YS = ys_of(D, DP);
-  constexpr int AS = as_of(D, SH);
+  constexpr int ASA = asa_of(D, DP);
+  constexpr int AS = SH ? as_of(D, true) : ASA + kRecTail;  // staged A record: [A rows | Q | pad][N r~ r] without
+                                                          // shared blocks, the one record of as_of otherwise
+  constexpr int TO = SH ? 2 * D : ASA;                    // where {N, r~, r} start in it
   constexpr int STP = (YS > AS ? YS : AS) + 2;  // LDS record pitch, +2 doubles: conflict-free b64/b128
   __shared__ __attribute__((aligned(16))) double stage[kSlicesPerBlock][32][STP];
   __shared__ int stage_cpos[kSlicesPerBlock][32];
@@ -859,14 +869,24 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
             n01 -= Q0[b] * Q1[b];
             n11 -= Q1[b] * Q1[b];
           }
-          Av[a_off_n(D)] = n00;
-          Av[a_off_n(D) + 1] = n01;
-          Av[a_off_n(D) + 2] = n11;
+          Av[TO] = n00;
+          Av[TO + 1] = n01;
+          Av[TO + 2] = n11;
         }
-        Av[a_off_rt(D)] = rt0;
-        Av[a_off_rt(D) + 1] = rt1;
-        Av[a_off_r(D)] = r0;
-        Av[a_off_r(D) + 1] = r1;
+        Av[TO + 3] = rt0;
+        Av[TO + 4] = rt1;
+        Av[TO + 5] = r0;
+        Av[TO + 6] = r1;
+        if (!SH) {
+#pragma unroll
+          for (int b = 0; b < DP; ++b) {
+            Av[2 * D + b] = Q0[b];
+            Av[2 * D + DP + b] = Q1[b];
+          }
+#pragma unroll
+          for (int i = 2 * D + 2 * DP; i < ASA; ++i) Av[i] = 0.0;
+          Av[TO + 7] = 0.0;
+        }
         if (SH) {
           // shared intrinsics block: Y1 = A1^T Q summed over the track's observations of
           // that block (they are adjacent); A1 rides in the A record for the per-view sums
@@ -888,9 +908,6 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
           }
 #pragma unroll
           for (int i = 4 * D + 7; i < AS; ++i) Av[i] = 0.0;
-        } else {
-#pragma unroll
-          for (int i = 2 * D + 7; i < AS; ++i) Av[i] = 0.0;
         }
       }
 #pragma unroll
@@ -936,8 +953,7 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
               store_nt(v.cm_A + (size_t)cp * AS + 2 * part, st + rec * STP + 2 * part);
           }
         } else {
-          // A rows (whole sectors: the few doubles past 2 D repeat the head of the tail) and the tail
-          constexpr int ASA = asa_of(D);
+          // [A rows | Q] (whole sectors) and the tail
           for (int c = lane; c < 32 * (ASA / 2); c += 64) {
             const int rec = c / (ASA / 2), part = c - rec * (ASA / 2);
             const int cp = scp[rec];
@@ -948,7 +964,7 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
             const int rec = c / (kRecTail / 2), part = c - rec * (kRecTail / 2);
             const int cp = scp[rec];
             if (cp >= 0)
-              store_nt(v.cm_R + (size_t)cp * kRecTail + 2 * part, st + rec * STP + 2 * D + 2 * part);
+              store_nt(v.cm_R + (size_t)cp * kRecTail + 2 * part, st + rec * STP + ASA + 2 * part);
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1062,7 +1078,7 @@ __global__ __launch_bounds__(64) void camera_diag_kernel(DeviceView v, RedLayout
         rec[i + 1] = t.y;
       }
     } else {
-      const double* arec = v.cm_A + (size_t)s * asa_of(D);
+      const double* arec = v.cm_A + (size_t)s * asa_of(D, DP);
       const double* trec = v.cm_R + (size_t)s * kRecTail;
 #pragma unroll
       for (int i = 0; i < 2 * D; i += 2) {
@@ -1369,6 +1385,168 @@ __global__ __launch_bounds__(256) void schur_offdiag_kernel(DeviceView v, RedLay
     }
     if (A.c0 + PC >= slot_span(A.r)) {
       // last chunk of the block: write it out
+      double* out = v.red + L.ub + (size_t)__builtin_amdgcn_readlane(hq.x, A.r) * D * D;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = (lane >> 4) + 4 * q;
+        if (row < D && i < D) out[row * D + i] = -acc[q];
+      }
+    }
+    A = B;
+    B = C;
+    slots_b = slots_c;
+  }
+}
+
+// schur_offdiag on the [A | Q] records (default without shared intrinsics blocks):
+//   S_ij = - sum_pairs Y_i Y_j^T = - sum_pairs A_i^T (Q_i Q_j^T) A_j,
+// a K = 2 per pair contraction: A operand = the two rows of A_i, B operand = M A_j with the 2 x 2
+// M = Q_i Q_j^T of the pair.  Same launch slots, chunking (16 pairs), software pipeline and record
+// staging as schur_offdiag_kernel above; after a chunk's records are in LDS lanes 0..15 form the
+// chunk's M matrices, then 8 MFMA steps (instead of 12 for 9 x 3, 16 for 9 x 4) run with the B
+// operand assembled from two A_j entries and one row of M.  No Y record exists on this path:
+// point_eliminate writes 256 B less per observation and the gathered record is 192 B (9 x 3) or
+// 256 B (9 x 4: two lines where the Y record takes three).
+template <int D, int DP>
+__global__ __launch_bounds__(256) void schur_offdiag_aq_kernel(DeviceView v, RedLayout L) {
+  constexpr int RS = asa_of(D, DP);                 // record stride in cm_A (doubles)
+  constexpr int R = kSchurBlocksPerWave;
+  constexpr int PC = kSchurPairsPerChunk;
+  constexpr int PARTS = (2 * D + 2 * DP + 1) / 2;   // 16-byte parts of a record that carry data
+  constexpr int PITCH = RS + 2;                     // LDS pitch (doubles), keeps 16-byte alignment
+  constexpr int NL = (2 * PC * PARTS + 63) / 64;
+  constexpr int STEPS = PC * 2 / 4;                 // MFMA steps (K = 4 = two pairs) of a full chunk
+  constexpr int GS = 4;
+  static_assert(STEPS % GS == 0, "whole groups of MFMA steps");
+  __shared__ __attribute__((aligned(16))) double lds_all[4][2 * PC * PITCH + 4 * PC];
+  const int lane = threadIdx.x & 63;
+  double* lds = lds_all[threadIdx.x >> 6];
+  double* ldsM = lds + 2 * PC * PITCH;              // [PC][2][2]
+  const long long first = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  if (first >= v.n_order) return;
+  int4 hq = make_int4(-1, 0, 0, 0);
+  if (lane < R && first + lane < v.n_order) hq = reinterpret_cast<const int4*>(v.ub_order)[first + lane];
+  const int vspan = hq.x >= 0 ? max(hq.y, 1) : 0;
+  auto slot_span = [&](int r) { return __builtin_amdgcn_readlane(vspan, r); };
+  auto slot_pairs = [&](int r) { return __builtin_amdgcn_readlane(hq.y, r); };
+  auto slot_first = [&](int r) {
+    return ((long long)(unsigned)__builtin_amdgcn_readlane(hq.z, r)) | ((long long)__builtin_amdgcn_readlane(hq.w, r) << 32);
+  };
+  // MFMA operand addressing: K index k = 4 h + kk is (pair 2 h + (kk >> 1), row r = kk & 1)
+  const int i = lane & 15, kk = lane >> 4;
+  const bool row_ok = i < D;
+  const int ic = row_ok ? i : 0;
+  const int pr0 = kk >> 1, rr = kk & 1;
+  const int off_a = pr0 * PITCH + rr * D + ic;          // + 2 h PITCH: A_i[pair][r][i]
+  const int off_j = (PC + pr0) * PITCH + ic;            // + 2 h PITCH: A_j[pair][0][i], + D: row 1
+  const int off_m = pr0 * 4 + 2 * rr;                   // + 8 h: M[pair][r][0 .. 1]
+  struct Chunk {
+    int r, c0, n;
+  };
+  auto make_chunk = [&](int r, int c0) {
+    r = __builtin_amdgcn_readfirstlane(r);
+    c0 = __builtin_amdgcn_readfirstlane(c0);
+    while (r < R && c0 >= slot_span(r)) {
+      ++r;
+      c0 = 0;
+    }
+    Chunk c;
+    c.r = r;
+    c.c0 = c0;
+    c.n = r < R ? max(0, min(PC, slot_pairs(r) - c0)) : 0;
+    return c;
+  };
+  auto load_slots = [&](const Chunk& c) {
+    int sl = 0;
+    if (c.n > 0) {
+      const long long q = slot_first(c.r) + c.c0;
+      if (lane < c.n) sl = v.pair_i[q + lane];
+      else if (lane >= PC && lane < PC + c.n) sl = v.pair_j[q + lane - PC];
+    }
+    return sl;
+  };
+  double2 pf[NL];
+  auto issue_loads = [&](const Chunk& c, int slots) {
+    int sl[NL];
+#pragma unroll
+    for (int it = 0; it < NL; ++it) {
+      const int rec = (it * 64 + lane) / PARTS;
+      sl[it] = __shfl(slots, rec < 2 * PC ? rec : 0, 64);
+    }
+#pragma unroll
+    for (int it = 0; it < NL; ++it) {
+      const int f = it * 64 + lane;
+      const int rec = f / PARTS, part = f - rec * PARTS;
+      const int pr = rec >= PC ? rec - PC : rec;
+      double2 t = make_double2(0.0, 0.0);
+      if (rec < 2 * PC && pr < c.n) t = *reinterpret_cast<const double2*>(v.cm_A + (size_t)sl[it] * RS + 2 * part);
+      pf[it] = t;
+    }
+  };
+  Chunk A = make_chunk(0, 0);
+  int slots_a = load_slots(A);
+  issue_loads(A, slots_a);
+  Chunk B = make_chunk(A.r, A.c0 + PC);
+  int slots_b = load_slots(B);
+  v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+  while (A.r < R) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < NL; ++it) {
+      const int f = it * 64 + lane;
+      const int rec = f / PARTS, part = f - rec * PARTS;
+      if (rec < 2 * PC) *reinterpret_cast<double2*>(lds + rec * PITCH + 2 * part) = pf[it];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (B.n > 0) issue_loads(B, slots_b);
+    const Chunk C = make_chunk(B.r, B.c0 + PC);
+    const int slots_c = load_slots(C);
+    // M = Q_i Q_j^T of every pair of the chunk (zero records give zero)
+    if (lane < PC) {
+      const double* qi = lds + lane * PITCH + 2 * D;
+      const double* qj = lds + (PC + lane) * PITCH + 2 * D;
+      double m00 = 0.0, m01 = 0.0, m10 = 0.0, m11 = 0.0;
+#pragma unroll
+      for (int c = 0; c < DP; ++c) {
+        const double a0 = qi[c], a1 = qi[DP + c], b0 = qj[c], b1 = qj[DP + c];
+        m00 += a0 * b0;
+        m01 += a0 * b1;
+        m10 += a1 * b0;
+        m11 += a1 * b1;
+      }
+      *reinterpret_cast<double2*>(ldsM + 4 * lane) = make_double2(m00, m01);
+      *reinterpret_cast<double2*>(ldsM + 4 * lane + 2) = make_double2(m10, m11);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (A.c0 == 0) acc = (v4f64){0.0, 0.0, 0.0, 0.0};
+    const int ksteps = (A.n * 2 + 3) / 4;
+#pragma unroll
+    for (int g = 0; g < STEPS / GS; ++g) {
+      if (g * GS < ksteps) {
+        double a[GS], b[GS];
+#pragma unroll
+        for (int h = 0; h < GS; ++h) {
+          const int hh = g * GS + h;
+          a[h] = lds[off_a + 2 * hh * PITCH];
+          const double2 m = *reinterpret_cast<const double2*>(ldsM + off_m + 8 * hh);
+          const double j0 = lds[off_j + 2 * hh * PITCH], j1 = lds[off_j + 2 * hh * PITCH + D];
+          b[h] = m.x * j0 + m.y * j1;
+        }
+#pragma unroll
+        for (int h = 0; h < GS; ++h) {
+          a[h] = row_ok ? a[h] : 0.0;
+          b[h] = row_ok ? b[h] : 0.0;
+        }
+#pragma unroll
+        for (int h = 0; h < GS; ++h) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[h], b[h], acc, 0, 0, 0);
+      }
+    }
+    if (A.c0 + PC >= slot_span(A.r)) {
       double* out = v.red + L.ub + (size_t)__builtin_amdgcn_readlane(hq.x, A.r) * D * D;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -1776,7 +1954,7 @@ __global__ __launch_bounds__(64) void implicit_cameras_kernel(DeviceView v, RedL
 #pragma unroll
   for (int a = 0; a < (SH ? D : 1); ++a) acc1[a] = 0.0;
   for (int s = v.cam_ptr[rb] + threadIdx.x; s < v.cam_ptr[rb + 1]; s += 64) {
-    const double* arec = v.cm_A + (size_t)s * (SH ? AS : asa_of(D));
+    const double* arec = v.cm_A + (size_t)s * (SH ? AS : asa_of(D, DP));
     const double2 t = *reinterpret_cast<const double2*>(cm_t + (size_t)s * 2);
 #pragma unroll
     for (int a = 0; a < D; ++a) acc[a] += arec[a] * t.x + arec[D + a] * t.y;
