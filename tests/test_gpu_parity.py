@@ -607,3 +607,22 @@ def test_very_long_tracks(solver, mode):
                         use_inner_iterations=0)
     assert_same_solution(dev, ora, scale=30.0)
     assert dev[1].num_schur_blocks == 150 * 151 // 2 or mode == abi.SCHUR_IMPLICIT
+
+
+@pytest.mark.parametrize("dof", [3, 4])
+def test_schur_complement_from_aq_records_equals_the_y_record_path(dof, monkeypatch):
+    # S_ij = -sum A_i^T (Q_i Q_j^T) A_j on the [A | Q] records (default) against -sum Y_i Y_j^T on Y records
+    # (TMI_BA_SCHUR_Y=1, the kernel shared-intrinsics problems still use): the same matrix to round-off
+    prob = synth.make_problem(40, 4000, 30000, seed=12, scene="ring", spread=0.4, heavy_tail=0.01)
+    opt = abi.default_options(linear_solver_type=abi.ITERATIVE_SCHUR, schur_mode=abi.SCHUR_EXPLICIT, point_dof=dof,
+                              max_num_iterations=8, use_inner_iterations=0)
+    a = prob.copy()
+    st_a, s_a = lib.solve(a, opt)
+    monkeypatch.setenv("TMI_BA_SCHUR_Y", "1")
+    b = prob.copy()
+    st_b, s_b = lib.solve(b, opt)
+    assert st_a == st_b == 0
+    assert s_a.num_iterations == s_b.num_iterations
+    assert s_a.num_linear_solver_iterations == s_b.num_linear_solver_iterations
+    assert abs(s_a.final_cost - s_b.final_cost) <= 1e-11 * s_b.final_cost
+    np.testing.assert_allclose(a.extrinsics, b.extrinsics, rtol=0, atol=1e-8)
