@@ -113,7 +113,7 @@ struct DeviceView {
   double* prep_c;   // ... of the candidate (ext_c, intr_c); swapped with prep on acceptance
   double* Vinv;     // [DP(DP+1)/2][Np_pad]  planes, symmetric inverse of V + Dp
   double* gp;       // [DP][Np_pad]
-  double* diag_p;   // [DP][Np_pad] squared column norms of the point Jacobian
+  double* Vraw;     // [DP(DP+1)/2][Np_pad]  planes, V = Jp^T Jp without the damping
   double* yp;       // [DP][Np_pad]
   double* red;      // all-reduce buffer
   double* Sdiag;    // [Nrb][D*D] diagonal blocks + LM diagonal

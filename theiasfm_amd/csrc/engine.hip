@@ -74,7 +74,7 @@ struct Launch {
                    int max_it, const double* red8, HostMirror* mirror, unsigned long long seq);
   void (*pcg_a)(const DeviceView&, hipStream_t, int, int);
   void (*pcg_b2)(const DeviceView&, hipStream_t, const double*, int, int, double*);
-  void (*back_substitute)(const DeviceView&, hipStream_t, double*, int, double*, double* sums);
+  void (*back_substitute)(const DeviceView&, hipStream_t, int, double*, double* sums);
   void (*update_points)(const DeviceView&, hipStream_t, int, double*, double* sums);
   void (*update_cameras)(const DeviceView&, hipStream_t, double* out, double* prep_c);
   void (*pcg_init)(const DeviceView&, hipStream_t, const double* b, int nb);
@@ -184,8 +184,8 @@ Launch make_launch(bool fp32) {
   L.pcg_b2 = [](const DeviceView& v, hipStream_t st, const double* b, int mode, int nb, double* partial) {
     hipLaunchKernelGGL((pcg_b2_kernel<D>), dim3(nb), dim3(256), 0, st, v, b, mode, nb, partial);
   };
-  L.back_substitute = [](const DeviceView& v, hipStream_t st, double* pm_u, int nb, double* partial, double* sums) {
-    hipLaunchKernelGGL((back_substitute_kernel<D, DP, SH>), dim3(nb), dim3(256), 0, st, v, pm_u, nb, partial, sums);
+  L.back_substitute = [](const DeviceView& v, hipStream_t st, int nb, double* partial, double* sums) {
+    hipLaunchKernelGGL((back_substitute_kernel<D, DP, SH>), dim3(nb), dim3(256), 0, st, v, nb, partial, sums);
   };
   L.update_points = [](const DeviceView& v, hipStream_t st, int nb, double* partial, double* sums) {
     hipLaunchKernelGGL((update_points_kernel<DP>), dim3(nb), dim3(256), 0, st, v, nb, partial, sums);
@@ -1327,7 +1327,7 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   }
   v.cm_R = v.cm_A + (size_t)std::max<int64_t>(st.Nslots, 1) * asa_of(D, DP);  // tails behind the [A | Q] records (!has_shared)
   AL(v.scale_c, std::max(n_r, 1)) AL(v.scale_p, NP * DP)
-  AL(v.Vinv, NP * NS) AL(v.gp, NP * DP) AL(v.diag_p, NP * DP) AL(v.yp, NP * DP)
+  AL(v.Vinv, NP * NS) AL(v.gp, NP * DP) AL(v.Vraw, NP * NS) AL(v.yp, NP * DP)
   AL(v.red, s->RL.total) AL(v.Sdiag, (size_t)std::max(st.Nrb, 1) * D * D)
   AL(v.tbuf, (size_t)std::max<int64_t>(st.nub, 1) * D) AL(v.rbuf, (size_t)std::max(v.n_spc, 1) * D) AL(v.Minv, (size_t)std::max(st.Nrb, 1) * D * D)
   AL(v.rhs, std::max(n_r, 1)) AL(v.yc, std::max(n_r, 1)) AL(v.cg_r, std::max(n_r, 1))
@@ -2110,7 +2110,7 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
     if (usable) {
       {
         Timed t(s, TMI_BA_K_BACK_SUBSTITUTE);
-        s->launch.back_substitute(v, stream, s->d_pm_u, nbs, v.partial, d_sc + 0);
+        s->launch.back_substitute(v, stream, nbs, v.partial, d_sc + 0);
       }
       {
         Timed t(s, TMI_BA_K_UPDATE_COST);

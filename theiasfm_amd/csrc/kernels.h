@@ -728,13 +728,17 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
       for (int i = 0; i < NS; ++i) V[i] = group_sum(V[i], tm.wide);
 #pragma unroll
       for (int a = 0; a < DP; ++a) g[a] = group_sum(g[a], tm.wide);
+      // the undamped V = Jp^T Jp is kept for the model cost change (back_substitute_kernel)
+      if (tm.leader) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) v.Vraw[(size_t)i * NP + lp] = V[i];
+      }
       // LM damping and Cholesky V + Dp = L L^T (L lower, packed by rows into Lm[a][b], b <= a)
       double Lm[DP][DP];
       bool pd = true;
 #pragma unroll
       for (int a = 0; a < DP; ++a) {
         const double d = V[sym_idx(a, a, DP)];
-        if (tm.leader) v.diag_p[(size_t)a * NP + lp] = d;
         V[sym_idx(a, a, DP)] = d + fmin(fmax(d, lm_lo), lm_hi) * inv_radius;
         if (tm.leader) v.gp[(size_t)a * NP + lp] = g[a];
         gmax = fmax(gmax, fabs(g[a] / v.scale_p[(size_t)lp * DP + a]));
@@ -2519,11 +2523,15 @@ __global__ __launch_bounds__(256) void cross_add_kernel(DeviceView v, RedLayout 
 
 // ------------------------------------------------------------------------------
 // back_substitute (kernel class 8): y_p = (V+Dp)^-1 (g_p - W^T y_c) per track and
-// the model cost change -(J d).(r + J d / 2), d = -y (TrustRegionMinimizer).
+// the model cost change -(J d).(r + J d / 2), d = -y (TrustRegionMinimizer), in ONE sweep over
+// the track's observations.  With u_i = A_i y_c and t_i = u_i + Jp_i y_p = -(J d)_i:
+//   sum_i t_i.r_i - |t_i|^2 / 2
+//     = sum_i (u_i.r_i - |u_i|^2 / 2)  +  y_p.g_p - y_p.(sum_i Jp_i^T u_i) - y_p^T V y_p / 2
+// -- g_p and the undamped V = sum Jp^T Jp are point_eliminate's, sum Jp^T u is g_p - w -- so the
+// second sweep (u written and read back, Jp and r read again) is not needed.
 // ------------------------------------------------------------------------------
 template <int D, int DP, bool SH>
-__global__ __launch_bounds__(256) void back_substitute_kernel(DeviceView v, double* __restrict__ pm_u,
-                                                              int nblocks, double* partial,
+__global__ __launch_bounds__(256) void back_substitute_kernel(DeviceView v, int nblocks, double* partial,
                                                               double* __restrict__ sums) {
   constexpr int NS = sym_size(DP);
   const TrackMap tm = track_map(v);
@@ -2532,12 +2540,12 @@ __global__ __launch_bounds__(256) void back_substitute_kernel(DeviceView v, doub
     const int lp = tm.lp;
     const int k = tm.k;
     const size_t base = tm.base;
-    const size_t N = (size_t)v.No_pad;
     const size_t NP = (size_t)v.Np_pad;
     if (k > 0) {
       double w[DP];
 #pragma unroll
       for (int a = 0; a < DP; ++a) w[a] = tm.leader ? v.gp[(size_t)a * NP + lp] : 0.0;
+      double ur = 0.0, uu = 0.0;
       for (int j = tm.j0; j < k; j += tm.jstep) {
         const size_t e = base + (size_t)j * 64;
         const int cam = v.obs_cam[e];
@@ -2564,36 +2572,41 @@ __global__ __launch_bounds__(256) void back_substitute_kernel(DeviceView v, doub
             }
           }
         }
-        pm_u[pidx<2>(0, e)] = u0;
-        pm_u[pidx<2>(1, e)] = u1;
+        ur += u0 * v.pm_r[pidx<2>(0, e)] + u1 * v.pm_r[pidx<2>(1, e)];
+        uu += u0 * u0 + u1 * u1;
 #pragma unroll
         for (int a = 0; a < DP; ++a)
           w[a] -= v.pm_Jp[pidx<2 * DP>((2 * a), e)] * u0 + v.pm_Jp[pidx<2 * DP>((2 * a + 1), e)] * u1;
       }
+      acc[0] = ur - 0.5 * uu;
 #pragma unroll
       for (int a = 0; a < DP; ++a) w[a] = group_sum(w[a], tm.wide);
-      double Vi[NS], yp[DP];
+      if (tm.leader) {
+        double Vi[NS], Vr[NS], yp[DP];
 #pragma unroll
-      for (int i = 0; i < NS; ++i) Vi[i] = v.Vinv[(size_t)i * NP + lp];
-#pragma unroll
-      for (int a = 0; a < DP; ++a) {
-        double t = 0.0;
-#pragma unroll
-        for (int b = 0; b < DP; ++b) t += Vi[a <= b ? sym_idx(a, b, DP) : sym_idx(b, a, DP)] * w[b];
-        yp[a] = t;
-        if (tm.leader) v.yp[(size_t)a * NP + lp] = t;
-      }
-      for (int j = tm.j0; j < k; j += tm.jstep) {
-        const size_t e = base + (size_t)j * 64;
-        double m0 = pm_u[pidx<2>(0, e)], m1 = pm_u[pidx<2>(1, e)];
+        for (int i = 0; i < NS; ++i) {
+          Vi[i] = v.Vinv[(size_t)i * NP + lp];
+          Vr[i] = v.Vraw[(size_t)i * NP + lp];
+        }
 #pragma unroll
         for (int a = 0; a < DP; ++a) {
-          m0 += v.pm_Jp[pidx<2 * DP>((2 * a), e)] * yp[a];
-          m1 += v.pm_Jp[pidx<2 * DP>((2 * a + 1), e)] * yp[a];
+          double t = 0.0;
+#pragma unroll
+          for (int b = 0; b < DP; ++b) t += Vi[a <= b ? sym_idx(a, b, DP) : sym_idx(b, a, DP)] * w[b];
+          yp[a] = t;
+          v.yp[(size_t)a * NP + lp] = t;
         }
-        m0 = -m0;
-        m1 = -m1;
-        acc[0] -= m0 * (v.pm_r[pidx<2>(0, e)] + 0.5 * m0) + m1 * (v.pm_r[pidx<2>(1, e)] + 0.5 * m1);
+        double lin = 0.0, quad = 0.0;
+#pragma unroll
+        for (int a = 0; a < DP; ++a) {
+          // y_p.g_p - y_p.(g_p - w) = y_p.w
+          lin += yp[a] * w[a];
+          double t = 0.0;
+#pragma unroll
+          for (int b = 0; b < DP; ++b) t += Vr[a <= b ? sym_idx(a, b, DP) : sym_idx(b, a, DP)] * yp[b];
+          quad += yp[a] * t;
+        }
+        acc[0] += lin - 0.5 * quad;
       }
     }
   }
