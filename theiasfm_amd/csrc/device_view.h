@@ -85,8 +85,6 @@ struct DeviceView {
   const int* ub_j;
   const int* ucol_ptr;
   const int* ucol_u;
-  const int* ucol_rank;  // inverse of ucol_u: position of an upper block in column order (where the SpMV rows pass
-                         // leaves its transposed product, so that the columns pass reads contiguous memory)
   const int* spc_row;   // SpMV rows pass work list: chunk -> block row, first upper block
   const int* spc_u0;
   const int* spc_rptr;  // [Nrb+1] chunks of a block row

@@ -1317,14 +1317,6 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
     s->adaptive_break_even = free > with_s ? (int)std::min(1.0e6, form / (free - with_s)) : 1 << 30;
   }
   AL(v.cm_Y, v.write_y ? (size_t)std::max<int64_t>(st.Nslots, 1) * YS : 1) AL(v.cm_A, (size_t)std::max<int64_t>(st.Nslots, 1) * AS)
-  {
-    int* rk;
-    if ((rc = dev_alloc(s, &rk, (size_t)std::max<int64_t>(st.nub, 1)))) return rc;
-    if (st.nub > 0)
-      hipLaunchKernelGGL(inverse_permutation_kernel, dim3((unsigned)((st.nub + 255) / 256)), dim3(256), 0, s->stream, v.ucol_u,
-                         (int)st.nub, rk);
-    v.ucol_rank = rk;
-  }
   v.cm_R = v.cm_A + (size_t)std::max<int64_t>(st.Nslots, 1) * asa_of(D, DP);  // tails behind the [A | Q] records (!has_shared)
   AL(v.scale_c, std::max(n_r, 1)) AL(v.scale_p, NP * DP)
   AL(v.Vinv, NP * NS) AL(v.gp, NP * DP) AL(v.Vraw, NP * NS) AL(v.yp, NP * DP)

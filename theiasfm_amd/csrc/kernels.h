@@ -1735,7 +1735,6 @@ __global__ __launch_bounds__(256) void spmv_rows_kernel(DeviceView v, const doub
 
   double2_a8 ld[NLD];
   double xjc = 0.0;
-  int rkc = 0;  // column-order position of this lane's block of the trip in flight
   auto fetch = [&](int ub0) {
     const int nv = max(0, min(G, u1 - ub0)) * BLK;  // valid doubles of this trip
     const double* src = ub + (size_t)ub0 * BLK;
@@ -1752,7 +1751,6 @@ __global__ __launch_bounds__(256) void spmv_rows_kernel(DeviceView v, const doub
     }
     const int u = ub0 + g;
     xjc = (g < G && u < u1) ? x[(size_t)v.ub_j[u] * D + c] : 0.0;
-    rkc = (g < G && u < u1) ? v.ucol_rank[u] : 0;
   };
   fetch(u0);
 #pragma unroll 1
@@ -1765,7 +1763,6 @@ __global__ __launch_bounds__(256) void spmv_rows_kernel(DeviceView v, const doub
       if (e < PITCH) *reinterpret_cast<double2_a8*>(&sblk[w][e]) = ld[i];
     }
     const double xj = xjc;
-    const int rk = rkc;
     __builtin_amdgcn_wave_barrier();
     if (ub0 + G < u1) fetch(ub0 + G);  // the next trip's loads fly while this one is consumed
     const int u = ub0 + g;
@@ -1778,7 +1775,7 @@ __global__ __launch_bounds__(256) void spmv_rows_kernel(DeviceView v, const doub
         tt += e * xi[r];
         a[r] += e * xj;
       }
-      tb[(size_t)rk * D + c] = tt;  // in column order: the columns pass then streams
+      tb[(size_t)u * D + c] = tt;
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -1789,11 +1786,6 @@ __global__ __launch_bounds__(256) void spmv_rows_kernel(DeviceView v, const doub
 #pragma unroll
     for (int r = 0; r < D; ++r) v.rbuf[(size_t)cidx * D + r] = a[r];
   }
-}
-
-__global__ __launch_bounds__(256) void inverse_permutation_kernel(const int* __restrict__ perm, int n, int* __restrict__ inv) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k < n) inv[perm[k]] = k;
 }
 
 // Deterministic grid-wide sum of one value per workgroup without a second launch: every
@@ -1836,7 +1828,7 @@ __global__ __launch_bounds__(256) void spmv_cols_kernel(DeviceView v, const doub
   if (g < G) {
     double acc = 0.0;
     const int k0 = v.ucol_ptr[col], k1 = v.ucol_ptr[col + 1];
-    for (int k = k0 + w * G + g; k < k1; k += 4 * G) acc += v.tbuf[(size_t)k * D + r];
+    for (int k = k0 + w * G + g; k < k1; k += 4 * G) acc += v.tbuf[(size_t)v.ucol_u[k] * D + r];
     part[w][g][r] = acc;
   }
   __syncthreads();
