@@ -57,11 +57,15 @@ def algorithmic_bytes(cls: str, n_obs: int, n_cam: int, n_pts: int, dc: int, dp:
     if cls == "schur_offdiag":
         return 2 * nnzb * 8 * dc * dc
     if cls == "spmv":
-        # a product with the formed S reads every upper block once; a matrix-free product walks the
-        # observations twice (tracks pass, cameras pass) and reads the per-track inverse blocks; mf_frac =
-        # share of the LM iterations whose PCG ran matrix-free (all of them on sharded runs)
+        # A product with an operator reads the operator's blocks once.  Formed S: every upper block once.
+        # Matrix-free: S = U - W V^-1 W^T is applied through the Jacobian blocks, so the blocks read once are
+        # the 2 x dc camera and 2 x dp point Jacobian blocks of every observation (16 (dc + dp) B), its two
+        # int32 indices, the per-track factor L^-1 and the vectors.  (The kernels read the camera blocks twice
+        # -- track-major in the tracks pass, camera-major in the cameras pass -- because summing over tracks and
+        # over cameras without atomics needs both orders; that factor is in `traffic`, not here.)
+        # mf_frac = share of the LM iterations whose PCG ran matrix-free (all of them on sharded runs).
         with_s = nnzb * 8 * dc * dc + 2 * n_cam * 8 * dc
-        matrix_free = 2 * n_obs * 24 + 4 * n_cam * 8 * dc + n_pts * 8 * sym(dp)
+        matrix_free = n_obs * (16 * (dc + dp) + 8) + 4 * n_cam * 8 * dc + n_pts * 8 * sym(dp)
         return int((1.0 - mf_frac) * with_s + mf_frac * matrix_free)
     if cls == "pcg_vector":
         return 4 * n_cam * 8 * dc
@@ -72,7 +76,7 @@ def algorithmic_bytes(cls: str, n_obs: int, n_cam: int, n_pts: int, dc: int, dp:
     return 0
 
 
-def pmc_traffic(kernel_class: str, workload: str, world: int):
+def pmc_traffic(kernel_class: str, workload: str, world: int, mf_frac: float = 0.0):
     """HBM bytes per launch of the kernel class from the committed rocprofv3 PMC passes
     (profiles/pmc_latest.json, written by tools/summarize_profile.py from separate
     --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command).  Correction per
@@ -87,6 +91,12 @@ def pmc_traffic(kernel_class: str, workload: str, world: int):
     if d.get("workload") != workload or world != 1:
         return None
     v = d.get("classes", {}).get(kernel_class)
+    if kernel_class == "spmv" and mf_frac > 0.0:
+        # the class holds both operators' products: blend as algorithmic_bytes does
+        f = d.get("classes", {}).get("spmv_matrix_free")
+        if f is None:
+            return None
+        v = (1.0 - mf_frac) * (v or 0.0) + mf_frac * f
     return None if v is None else int(v)
 
 
@@ -290,7 +300,7 @@ def main():
                                                key=lambda k: k["total_ms"])
     roofline = dict(bound="hbm", kernel=dom["kernel"], achieved=dom["achieved_GBs"], peak=HBM_PEAK_GBS,
                     unit="GB/s", frac=round(dom["achieved_GBs"] / HBM_PEAK_GBS, 5),
-                    traffic=pmc_traffic(dom["kernel"], args.workload, world),
+                    traffic=pmc_traffic(dom["kernel"], args.workload, world, mf_frac),
                     traffic_source="profiles/pmc_latest.json: rocprofv3 --pmc passes of this command, committed "
                                    "(counters cannot be read from inside the process)",
                     launches=dom["launches"], avg_us=dom["avg_us"],
@@ -300,7 +310,7 @@ def main():
     # operator choice took it out of the short PCG solves): same definition, for comparison across rounds
     roofline["other_classes"] = {
         k["kernel"]: dict(achieved=k["achieved_GBs"], frac=round(k["achieved_GBs"] / HBM_PEAK_GBS, 5), launches=k["launches"],
-                          avg_us=k["avg_us"], traffic=pmc_traffic(k["kernel"], args.workload, world))
+                          avg_us=k["avg_us"], traffic=pmc_traffic(k["kernel"], args.workload, world, mf_frac))
         for k in kernels  # the separate pass with every class timed (kernels_note)
         if k["kernel"] in ("schur_offdiag", "spmv", "point_eliminate", "linearize") and k["kernel"] != dom["kernel"]}
 
@@ -332,8 +342,9 @@ def main():
                     solves=f"{-(-args.steps // max(1, args.solve_length))} x <= {args.solve_length} iterations from the "
                            "perturbed start, device-side reset in between (inside the timed region)",
                     schur_mode=args.schur_mode,
-                    schur_operator=(("explicit block-sparse S; LM iterations whose forecast PCG length is below the "
-                                     "break-even of forming S run matrix-free (schur_mode auto on one rank)"
+                    schur_operator=(("per LM iteration: matrix-free when the forecast PCG length is below the "
+                                     "break-even of forming S, the explicit block-sparse S otherwise (schur_mode "
+                                     "auto on one rank; both resident)"
                                      if (world == 1 and args.schur_mode == "auto" and solver_type == abi.ITERATIVE_SCHUR
                                          and not os.environ.get("TMI_BA_NO_ADAPTIVE"))
                                      else "explicit block-sparse S") if explicit else "implicit (matrix-free)"),

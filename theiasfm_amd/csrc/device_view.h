@@ -62,6 +62,8 @@ struct DeviceView {
   const int* obs_cam;
   const double* obs_xy;  // [No_pad][2]
   const int* obs_cpos;
+  const int* slot_track;  // [Nslots] track (position in the rank's slice order) of a camera-major slot
+                          //   (matrix-free product without shared blocks; null otherwise)
   const int* cam_grp;
   const int4* cam_rec;         // [Nc] {camera model, intrinsics offset, #intrinsics, free-column mask}
   const int* cam_rb;
@@ -111,6 +113,7 @@ struct DeviceView {
   double* prep_c;   // ... of the candidate (ext_c, intr_c); swapped with prep on acceptance
   double* Vinv;     // [DP(DP+1)/2][Np_pad]  planes, symmetric inverse of V + Dp
   double* gp;       // [DP][Np_pad]
+  double* Linv;     // [DP(DP+1)/2][Np_pad]  planes, L^-1 (lower; plane sym_idx(a, b), a <= b, holds element (b, a))
   double* Vraw;     // [DP(DP+1)/2][Np_pad]  planes, V = Jp^T Jp without the damping
   double* yp;       // [DP][Np_pad]
   double* red;      // all-reduce buffer

@@ -166,13 +166,20 @@ Launch make_launch(bool fp32) {
                        max_it, red8, mirror, seq);
   };
   L.implicit_spmv = [](const DeviceView& v, hipStream_t st, RedLayout R, const double* x, double* y,
-                       double* pm_u, double* cm_t, double ir, double lo, double hi, int add_diag, int nb, int dot,
+                       double* w1, double* w2, double ir, double lo, double hi, int add_diag, int nb, int dot,
                        int spec) {
+    // work arrays: with shared intrinsics blocks w1 = u planes, w2 = t records; without, w1 = zhat (w2 unused)
     if (!v.Nrb) return;
-    hipLaunchKernelGGL((implicit_tracks_kernel<D, DP, SH>), dim3(nb), dim3(256), 0, st, v, x, pm_u, cm_t, spec);
+    if (!SH) {
+      hipLaunchKernelGGL((implicit_tracks_q_kernel<D, DP>), dim3(nb), dim3(256), 0, st, v, x, w1, spec);
+      hipLaunchKernelGGL((implicit_cameras_q_kernel<D, DP>), dim3(v.Nrb), dim3(64), 0, st, v, R, x, w1, y, ir, lo, hi,
+                         add_diag, dot, spec);
+      return;
+    }
+    hipLaunchKernelGGL((implicit_tracks_kernel<D, DP, SH>), dim3(nb), dim3(256), 0, st, v, x, w1, w2, spec);
     // cam_part is free between two builds of the normal equations: the per-view partial
     // products of the shared intrinsics blocks live in its head
-    hipLaunchKernelGGL((implicit_cameras_kernel<D, DP, SH>), dim3(v.Nrb), dim3(64), 0, st, v, R, x, cm_t, y,
+    hipLaunchKernelGGL((implicit_cameras_kernel<D, DP, SH>), dim3(v.Nrb), dim3(64), 0, st, v, R, x, w2, y,
                        ir, lo, hi, add_diag, v.cam_part, SH ? 0 : dot, spec);
     if (SH && v.Nrb > v.Ncam_rb)
       hipLaunchKernelGGL((implicit_groups_kernel<D>), dim3(v.Nrb - v.Ncam_rb), dim3(64), 0, st, v, R, x, v.cam_part,
@@ -266,7 +273,8 @@ struct tmi_ba_solver {
   int n_intr = 0;
   // extra device arrays not in the view
   double* d_pm_u = nullptr;
-  double* d_cm_t = nullptr;   // implicit Schur operator: t_i per camera-major slot
+  double* d_cm_t = nullptr;   // implicit Schur operator: t_i per camera-major slot (shared intrinsics blocks only)
+  bool need_slot_track = false;
   bool implicit = false;      // S is never formed (schur_mode)
   bool adaptive = false;      // schur_mode auto on one rank: both operators are resident and every LM iteration
                               // takes the cheaper one for the PCG length it expects (see solve)
@@ -1301,17 +1309,24 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
     s->setup_seconds = now_s() - t0;
     return TMI_BA_OK;
   }
-  AL(v.pm_r, 2 * N) AL(v.pm_A, 2 * D * N) AL(v.pm_Jp, 2 * DP * N) AL(s->d_pm_u, 2 * N)
-  AL(s->d_cm_t, (s->implicit || s->adaptive) ? (size_t)std::max<int64_t>(st.Nslots, 1) * 2 : 1)
+  AL(v.pm_r, 2 * N) AL(v.pm_A, 2 * D * N) AL(v.pm_Jp, 2 * DP * N)
+  {
+    // work arrays of the matrix-free product: u planes + t records with shared intrinsics blocks, zhat
+    // (4 doubles per track) + the slot -> track index without
+    const bool mf = s->implicit || s->adaptive;
+    AL(s->d_pm_u, mf ? (st.has_shared ? 2 * N : 4 * NP) : 1)
+    AL(s->d_cm_t, (mf && st.has_shared) ? (size_t)std::max<int64_t>(st.Nslots, 1) * 2 : 1)
+    s->need_slot_track = mf && !st.has_shared;
+  }
   AL(v.pm_A1, st.has_shared ? 2 * D * N : 1) AL(v.cam_part, (size_t)std::max(st.Ncam_rb, 1) * (2 * D * D + 3 * D))
   // Y records: the shared-block sums need them; without shared blocks the Schur complement works from the
   // [A | Q] records and Y exists only for the A/B switches that select the older kernels
   s->y_records = st.has_shared || getenv("TMI_BA_SCHUR_GATHER") != nullptr || getenv("TMI_BA_SCHUR_Y") != nullptr;
   v.write_y = (s->y_records && (!s->implicit || st.has_shared)) ? 1 : 0;
   if (s->adaptive) {
-    // cost model measured on MI355X (profiles/r02_y): forming S ~61 ps per pair, a product with S ~192 ps per
-    // upper block, a matrix-free product ~110 ps per observation
-    const double form = 61.0 * (double)st.npairs, with_s = 192.0 * (double)st.nub, free = 110.0 * (double)st.No;
+    // cost model measured on MI355X (profiles/r02_z): forming S ~61 ps per pair, a product with S ~192 ps per
+    // upper block, a matrix-free product ~98 ps per observation
+    const double form = 61.0 * (double)st.npairs, with_s = 192.0 * (double)st.nub, free = 98.0 * (double)st.No;
     // (a product with S that costs more than a matrix-free one -- many views, little co-visibility: S has more
     // blocks than there are observations to walk -- never pays off: always matrix-free)
     s->adaptive_break_even = free > with_s ? (int)std::min(1.0e6, form / (free - with_s)) : 1 << 30;
@@ -1319,7 +1334,7 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   AL(v.cm_Y, v.write_y ? (size_t)std::max<int64_t>(st.Nslots, 1) * YS : 1) AL(v.cm_A, (size_t)std::max<int64_t>(st.Nslots, 1) * AS)
   v.cm_R = v.cm_A + (size_t)std::max<int64_t>(st.Nslots, 1) * asa_of(D, DP);  // tails behind the [A | Q] records (!has_shared)
   AL(v.scale_c, std::max(n_r, 1)) AL(v.scale_p, NP * DP)
-  AL(v.Vinv, NP * NS) AL(v.gp, NP * DP) AL(v.Vraw, NP * NS) AL(v.yp, NP * DP)
+  AL(v.Vinv, NP * NS) AL(v.Linv, NP * NS) AL(v.gp, NP * DP) AL(v.Vraw, NP * NS) AL(v.yp, NP * DP)
   AL(v.red, s->RL.total) AL(v.Sdiag, (size_t)std::max(st.Nrb, 1) * D * D)
   AL(v.tbuf, (size_t)std::max<int64_t>(st.nub, 1) * D) AL(v.rbuf, (size_t)std::max(v.n_spc, 1) * D) AL(v.Minv, (size_t)std::max(st.Nrb, 1) * D * D)
   AL(v.rhs, std::max(n_r, 1)) AL(v.yc, std::max(n_r, 1)) AL(v.cg_r, std::max(n_r, 1))
@@ -1337,6 +1352,12 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   TMI_HIP(hipMemsetAsync(v.red, 0, s->RL.total * sizeof(double), s->stream));
   TMI_HIP(hipMemsetAsync(v.cm_Y, 0, (v.write_y ? (size_t)std::max<int64_t>(st.Nslots, 1) * YS : 1) * sizeof(double), s->stream));
   TMI_HIP(hipMemsetAsync(v.cm_A, 0, (size_t)std::max<int64_t>(st.Nslots, 1) * AS * sizeof(double), s->stream));
+  if (s->need_slot_track) {
+    int* stt;
+    if ((rc = dev_alloc(s, &stt, (size_t)std::max<int64_t>(st.Nslots, 1)))) return rc;
+    hipLaunchKernelGGL(slot_track_kernel, dim3(s->nblocks_tracks), dim3(256), 0, s->stream, v, stt);
+    v.slot_track = stt;
+  }
   TMI_HIP(hipStreamSynchronize(s->stream));
   s->setup_seconds = now_s() - t0;
   if (setup_timing) fprintf(stderr, "[tmi_ba setup] %-28s %.3f s\n", "create total (incl. upload)", s->setup_seconds);
@@ -2038,9 +2059,7 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
       // solves -- the first LM iterations, small trust regions -- run matrix-free, and point_eliminate then
       // skips the Y records.  The forecast is the previous iteration's PCG length; both operators give the
       // same product to round-off.
-      // ... by a clear margin only (forecast at most half the break-even): near the break-even the two cost the
-      // same and the formed S stays the default
-      s->implicit_now = last_pcg_len <= s->adaptive_break_even / 2;
+      s->implicit_now = last_pcg_len <= s->adaptive_break_even;
       if (s->y_records) v.write_y = s->implicit_now ? 0 : 1;
       if (s->implicit_now) s->n_implicit_iterations++;
     } else if (s->implicit && iterative) {

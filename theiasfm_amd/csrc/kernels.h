@@ -780,6 +780,13 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
           Li[i][j] = t / Lm[i][i];
         }
       }
+      // L^-1 itself serves the matrix-free product (zhat = L^-1 sum Jp^T u, implicit_tracks_q_kernel)
+      if (tm.leader) {
+#pragma unroll
+        for (int a = 0; a < DP; ++a)
+#pragma unroll
+          for (int b = a; b < DP; ++b) v.Linv[(size_t)sym_idx(a, b, DP) * NP + lp] = Li[b][a];
+      }
       // Vinv = Li^T Li (symmetric), t_p = Vinv g
       double Vi[NS], tp[DP];
 #pragma unroll
@@ -1938,6 +1945,142 @@ __global__ __launch_bounds__(256) void implicit_tracks_kernel(DeviceView v, cons
       t1 -= v.pm_Jp[pidx<2 * DP>((2 * a + 1), e)] * z[a];
     }
     *reinterpret_cast<double2*>(cm_t + (size_t)cpos * 2) = make_double2(t0, t1);
+  }
+}
+
+// ------------------------------------------------------------------------------
+// The matrix-free product without shared intrinsics blocks, from the [A | Q] records:
+//   S x = sum_i A_i^T (A_i x_c(i) - Q_i zhat_t(i)) + D_c x,   zhat_t = sum_{i in t} Q_i^T A_i x_c(i) = L^-1 sum Jp_i^T u_i
+// (Q = Jp L^-T, so Jp (V+D)^-1 Jp^T = Q Q^T).  The tracks pass is ONE sweep over the planes that
+// leaves 32 bytes per track (zhat); the cameras pass streams the records it streams anyway (Q rides
+// in them), recomputes u_i = A_i x_c -- x_c is the workgroup's own block -- and gathers zhat of the
+// slot's track.  No u planes, no t records, no second sweep over the track's observations:
+// 196 + ~230 bytes per observation instead of 310 + 224.
+// ------------------------------------------------------------------------------
+template <int D, int DP>
+__global__ __launch_bounds__(256) void implicit_tracks_q_kernel(DeviceView v, const double* __restrict__ x,
+                                                                double* __restrict__ zhat, int spec) {
+  if (spec && *v.pcg_done) return;
+  const TrackMap tm = track_map(v);
+  if (!tm.valid) return;
+  const int lp = tm.lp;
+  const int k = tm.k;
+  if (k == 0) return;  // uniform over the lanes that share a track
+  const size_t base = tm.base;
+  const size_t NP = (size_t)v.Np_pad;
+  double w[DP];
+#pragma unroll
+  for (int a = 0; a < DP; ++a) w[a] = 0.0;
+  for (int j = tm.j0; j < k; j += tm.jstep) {
+    const size_t e = base + (size_t)j * 64;
+    const int rb = v.cam_rb[v.obs_cam[e]];
+    if (rb < 0) continue;
+    const double* xc = x + (size_t)rb * D;
+    double u0 = 0.0, u1 = 0.0;
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      const double xa = xc[a];
+      u0 += v.pm_A[pidx<2 * D>((2 * a), e)] * xa;
+      u1 += v.pm_A[pidx<2 * D>((2 * a + 1), e)] * xa;
+    }
+#pragma unroll
+    for (int a = 0; a < DP; ++a)
+      w[a] += v.pm_Jp[pidx<2 * DP>((2 * a), e)] * u0 + v.pm_Jp[pidx<2 * DP>((2 * a + 1), e)] * u1;
+  }
+#pragma unroll
+  for (int a = 0; a < DP; ++a) w[a] = group_sum(w[a], tm.wide);
+  if (tm.leader) {
+    double z[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int b = 0; b < DP; ++b) {
+      double t = 0.0;
+#pragma unroll
+      for (int a = 0; a <= b; ++a) t += v.Linv[(size_t)sym_idx(a, b, DP) * NP + lp] * w[a];
+      z[b] = t;
+    }
+    *reinterpret_cast<double2*>(zhat + (size_t)lp * 4) = make_double2(z[0], z[1]);
+    *reinterpret_cast<double2*>(zhat + (size_t)lp * 4 + 2) = make_double2(z[2], z[3]);
+  }
+}
+
+// slot -> track of the rank's camera-major records (built once per structure)
+__global__ __launch_bounds__(256) void slot_track_kernel(DeviceView v, int* __restrict__ slot_track) {
+  const TrackMap tm = track_map(v);
+  if (!tm.valid) return;
+  for (int j = tm.j0; j < tm.k; j += tm.jstep) {
+    const int cpos = v.obs_cpos[tm.base + (size_t)j * 64];
+    if (cpos >= 0) slot_track[cpos] = tm.lp;
+  }
+}
+
+template <int D, int DP>
+__global__ __launch_bounds__(64) void implicit_cameras_q_kernel(DeviceView v, RedLayout L,
+                                                                const double* __restrict__ x,
+                                                                const double* __restrict__ zhat,
+                                                                double* __restrict__ y, double inv_radius,
+                                                                double lm_lo, double lm_hi, int add_diag, int dot,
+                                                                int spec) {
+  constexpr int ASA = asa_of(D, DP);
+  if (spec && *v.pcg_done) return;
+  const int rb = blockIdx.x;
+  double xc[D], acc[D];
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    xc[a] = x[(size_t)rb * D + a];
+    acc[a] = 0.0;
+  }
+  for (int s = v.cam_ptr[rb] + threadIdx.x; s < v.cam_ptr[rb + 1]; s += 64) {
+    const double* arec = v.cm_A + (size_t)s * ASA;
+    double rec[2 * D + 2 * DP];
+#pragma unroll
+    for (int i = 0; i < 2 * D + 2 * DP; i += 2) {
+      const double2 t = *reinterpret_cast<const double2*>(arec + i);
+      rec[i] = t.x;
+      rec[i + 1] = t.y;
+    }
+    const double* zt = zhat + (size_t)v.slot_track[s] * 4;
+    const double2 z01 = *reinterpret_cast<const double2*>(zt);
+    const double2 z23 = *reinterpret_cast<const double2*>(zt + 2);
+    const double z[4] = {z01.x, z01.y, z23.x, z23.y};
+    double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      t0 += rec[a] * xc[a];
+      t1 += rec[D + a] * xc[a];
+    }
+#pragma unroll
+    for (int b = 0; b < DP; ++b) {
+      t0 -= rec[2 * D + b] * z[b];
+      t1 -= rec[2 * D + DP + b] * z[b];
+    }
+#pragma unroll
+    for (int a = 0; a < D; ++a) acc[a] += rec[a] * t0 + rec[D + a] * t1;
+  }
+  double my_dot = 0.0;
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    double tot = wave_sum(acc[a]);
+    if (threadIdx.x == 0) {
+      // the damping (and the identity on padding rows) enters once: on rank 0 when the
+      // product is all-reduced afterwards
+      if (add_diag) {
+        if (v.rb_cols[(size_t)rb * D + a] < 0) {
+          tot = xc[a];
+        } else {
+          const double d = v.red[L.udiag + (size_t)rb * D + a];
+          tot += fmin(fmax(d, lm_lo), lm_hi) * inv_radius * xc[a];
+        }
+      } else if (v.rb_cols[(size_t)rb * D + a] < 0) {
+        tot = 0.0;
+      }
+      y[(size_t)rb * D + a] = tot;
+      my_dot += tot * xc[a];
+    }
+  }
+  if (dot) {
+    // this rank's share of x . y rides behind the product vector and is all-reduced with it
+    double total;
+    if (last_block_sum<64>(my_dot, v.dotbuf, v.ticket, &total) && threadIdx.x == 0) y[(size_t)v.Nrb * D] = total;
   }
 }
 
