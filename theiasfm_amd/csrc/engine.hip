@@ -629,14 +629,15 @@ static int build_structure_device(tmi_ba_solver* s, const tmi_ba_problem* P, boo
   hipLaunchKernelGGL(widen_kernel, nb(Np + 1), dim3(256), 0, stream, d_klen, Np + 1, d_klen64);
   SG_EXCLUSIVE_SUM(d_klen64, d_tptr, Np + 1);
   // ---- tracks by descending length (stable)
-  unsigned *d_tk_in, *d_tk_out;
+  unsigned long long *d_tk_in, *d_tk_out;
   int *d_tv_in, *d_order;
   TMI_HIP(tmp.get(&d_tk_in, (size_t)Np));
   TMI_HIP(tmp.get(&d_tk_out, (size_t)Np));
   TMI_HIP(tmp.get(&d_tv_in, (size_t)Np));
   TMI_HIP(tmp.get(&d_order, (size_t)Np));
-  hipLaunchKernelGGL(track_keys_kernel, nb(Np), dim3(256), 0, stream, d_klen, Np, d_tk_in, d_tv_in);
-  SG_SORT_PAIRS(d_tk_in, d_tk_out, d_tv_in, d_order, Np, 32);
+  hipLaunchKernelGGL(track_keys_kernel, nb(Np), dim3(256), 0, stream, d_klen, Np, d_tptr, d_ok_out, cam_bits,
+                     track_order_plain() ? 1 : 0, d_tk_in, d_tv_in);
+  SG_SORT_PAIRS(d_tk_in, d_tk_out, d_tv_in, d_order, Np, 32 + cam_bits);
   std::vector<int> order((size_t)Np), klen((size_t)Np);
   int bad = 0;
   TMI_HIP(hipMemcpyAsync(order.data(), d_order, (size_t)Np * sizeof(int), hipMemcpyDeviceToHost, stream));

@@ -16,6 +16,11 @@
 #include <thread>
 
 namespace tmi {
+
+bool track_order_plain() {
+  static const bool plain = getenv("TMI_BA_TRACK_ORDER_PLAIN") != nullptr;
+  return plain;
+}
 namespace {
 
 int model_size(int m) {
@@ -243,22 +248,42 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, 
         return TMI_BA_ERR_INVALID_ARGUMENT;
       }
   }
-  // counting sort by descending length; tracks without observations take no part
+  // Order: descending length, then the track's lowest view index, then its index (two stable counting
+  // sorts).  Tracks seen from the same views share slices, so a wave's parameter gathers and the gathers of a
+  // view's slots in the matrix-free product touch neighbouring memory.  Tracks without observations take no part.
   std::vector<int> order;
   order.reserve(s.Np_total);
   {
+    std::vector<int> by_cam;
+    by_cam.reserve(s.Np_total);
+    if (track_order_plain()) {
+      for (int p = 0; p < s.Np_total; ++p)
+        if (klen[p] > 0) by_cam.push_back(p);
+    } else {
+      std::vector<int> first_cam(s.Np_total, 0);
+      for (int p = 0; p < s.Np_total; ++p) {
+        int c = s.Nc;
+        for (int64_t q = tptr[p]; q < tptr[p + 1]; ++q) c = std::min(c, (int)P->obs_camera[tobs[q]]);
+        first_cam[p] = c;
+      }
+      std::vector<int> cpos(s.Nc + 2, 0);
+      int total = 0;
+      for (int p = 0; p < s.Np_total; ++p)
+        if (klen[p] > 0) {
+          cpos[first_cam[p] + 1]++;
+          ++total;
+        }
+      for (int c = 0; c <= s.Nc; ++c) cpos[c + 1] += cpos[c];
+      by_cam.assign(total, 0);
+      for (int p = 0; p < s.Np_total; ++p)
+        if (klen[p] > 0) by_cam[cpos[first_cam[p]]++] = p;
+    }
     // bucket b = kmax - k  (b = 0 holds the longest tracks)
     std::vector<int> pos(kmax + 2, 0);
-    int total = 0;
-    for (int p = 0; p < s.Np_total; ++p)
-      if (klen[p] > 0) {
-        pos[kmax - klen[p] + 1]++;
-        ++total;
-      }
+    for (int p : by_cam) pos[kmax - klen[p] + 1]++;
     for (int b = 0; b <= kmax; ++b) pos[b + 1] += pos[b];
-    order.assign(total, 0);
-    for (int p = 0; p < s.Np_total; ++p)
-      if (klen[p] > 0) order[pos[kmax - klen[p]]++] = p;
+    order.assign(by_cam.size(), 0);
+    for (int p : by_cam) order[pos[kmax - klen[p]]++] = p;
   }
   const int n_active = (int)order.size();
   // tracks without observations are in no slice; rank 0 answers for them in the

@@ -100,6 +100,9 @@ int build_blocks(const tmi_ba_problem* P, int rank, int world, Structure* out);
 // Returns TMI_BA_OK or an error status (message in out->error).
 // want_pairs = false skips the block structure of S and the pair lists (implicit Schur
 // operator: S is never formed).
+// A/B switch (TMI_BA_TRACK_ORDER_PLAIN): ties of the length order by track index only, as before round 2
+bool track_order_plain();
+
 int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* out,
                     bool want_pairs = true);
 

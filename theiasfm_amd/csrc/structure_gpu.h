@@ -56,11 +56,20 @@ __global__ __launch_bounds__(256) void dup_check_kernel(const unsigned long long
   if (i + 1 < n && keys[i] == keys[i + 1]) *bad = 2;
 }
 
+// tracks by descending length, then by their lowest view index, then by index (structure.cpp): tracks seen from
+// the same views end up in the same slices, so a wave's parameter gathers and the zhat gathers of a view's slots
+// touch neighbouring memory.  okeys = the observation keys sorted by (track, view).
 __global__ __launch_bounds__(256) void track_keys_kernel(const int* __restrict__ klen, int Np,
-                                                         unsigned* __restrict__ keys, int* __restrict__ vals) {
+                                                         const long long* __restrict__ tptr,
+                                                         const unsigned long long* __restrict__ okeys, int cam_bits,
+                                                         int plain, unsigned long long* __restrict__ keys,
+                                                         int* __restrict__ vals) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= Np) return;
-  keys[p] = ~(unsigned)klen[p];  // ascending ~k = descending k; k = 0 sorts last
+  unsigned cam = 0;
+  if (!plain && klen[p] > 0) cam = (unsigned)(okeys[tptr[p]] & ((1ull << cam_bits) - 1ull));
+  // ascending ~k = descending k; k = 0 sorts last
+  keys[p] = ((unsigned long long)(~(unsigned)klen[p]) << cam_bits) | cam;
   vals[p] = p;
 }
 
