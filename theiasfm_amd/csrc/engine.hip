@@ -172,7 +172,7 @@ Launch make_launch(bool fp32) {
     if (!v.Nrb) return;
     if (!SH) {
       hipLaunchKernelGGL((implicit_tracks_q_kernel<D, DP>), dim3(nb), dim3(256), 0, st, v, x, w1, spec);
-      hipLaunchKernelGGL((implicit_cameras_q_kernel<D, DP>), dim3(v.Nrb), dim3(64), 0, st, v, R, x, w1, y, ir, lo, hi,
+      hipLaunchKernelGGL((implicit_cameras_q_kernel<D, DP>), dim3(8 * ((v.Nrb + 7) / 8)), dim3(64), 0, st, v, R, x, w1, y, ir, lo, hi,
                          add_diag, dot, spec);
       return;
     }

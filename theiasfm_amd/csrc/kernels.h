@@ -2022,14 +2022,20 @@ __global__ __launch_bounds__(64) void implicit_cameras_q_kernel(DeviceView v, Re
                                                                 int spec) {
   constexpr int ASA = asa_of(D, DP);
   if (spec && *v.pcg_done) return;
-  const int rb = blockIdx.x;
+  // Workgroups are dealt to the 8 XCDs round-robin: XCD x takes the views [x chunk, (x + 1) chunk), so the views
+  // in flight on one XCD are neighbours and the zhat lines of the tracks they share are fetched into that XCD's
+  // L2 once (the track order keeps the tracks of neighbouring views together).  Grid = 8 chunk workgroups.
+  const int chunk = ((int)gridDim.x) >> 3;
+  const int rb = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
+  const bool live = rb < v.Nrb;  // the padding workgroups still take part in the dot product's ticket
   double xc[D], acc[D];
 #pragma unroll
   for (int a = 0; a < D; ++a) {
-    xc[a] = x[(size_t)rb * D + a];
+    xc[a] = live ? x[(size_t)rb * D + a] : 0.0;
     acc[a] = 0.0;
   }
-  for (int s = v.cam_ptr[rb] + threadIdx.x; s < v.cam_ptr[rb + 1]; s += 64) {
+  const int s_end = live ? v.cam_ptr[rb + 1] : 0;
+  for (int s = (live ? v.cam_ptr[rb] : 0) + threadIdx.x; s < s_end; s += 64) {
     const double* arec = v.cm_A + (size_t)s * ASA;
     double rec[2 * D + 2 * DP];
 #pragma unroll
@@ -2060,7 +2066,7 @@ __global__ __launch_bounds__(64) void implicit_cameras_q_kernel(DeviceView v, Re
 #pragma unroll
   for (int a = 0; a < D; ++a) {
     double tot = wave_sum(acc[a]);
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && live) {
       // the damping (and the identity on padding rows) enters once: on rank 0 when the
       // product is all-reduced afterwards
       if (add_diag) {
