@@ -62,6 +62,8 @@ struct DeviceView {
   const int* obs_cam;
   const double* obs_xy;  // [No_pad][2]
   const int* obs_cpos;
+  const int* obs_rb;      // [No_pad] reduced block of the observation's view (cam_rb[obs_cam], -1: constant view):
+                          //   one dependent load less in the per-track sweeps that only need the block
   const int* slot_track;  // [Nslots] track (position in the rank's slice order) of a camera-major slot
                           //   (matrix-free product without shared blocks; null otherwise)
   const int* cam_grp;

@@ -1353,6 +1353,14 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   TMI_HIP(hipMemsetAsync(v.red, 0, s->RL.total * sizeof(double), s->stream));
   TMI_HIP(hipMemsetAsync(v.cm_Y, 0, (v.write_y ? (size_t)std::max<int64_t>(st.Nslots, 1) * YS : 1) * sizeof(double), s->stream));
   TMI_HIP(hipMemsetAsync(v.cm_A, 0, (size_t)std::max<int64_t>(st.Nslots, 1) * AS * sizeof(double), s->stream));
+  {
+    int* orb;
+    if ((rc = dev_alloc(s, &orb, (size_t)std::max<int64_t>(st.No_pad, 1)))) return rc;
+    if (st.No_pad > 0)
+      hipLaunchKernelGGL(obs_rb_kernel, dim3((unsigned)((st.No_pad + 255) / 256)), dim3(256), 0, s->stream, v.obs_cam, v.cam_rb,
+                         st.Nc, (long long)st.No_pad, orb);
+    v.obs_rb = orb;
+  }
   if (s->need_slot_track) {
     int* stt;
     if ((rc = dev_alloc(s, &stt, (size_t)std::max<int64_t>(st.Nslots, 1)))) return rc;

@@ -1971,9 +1971,13 @@ __global__ __launch_bounds__(256) void implicit_tracks_q_kernel(DeviceView v, co
   double w[DP];
 #pragma unroll
   for (int a = 0; a < DP; ++a) w[a] = 0.0;
+  // the block index of the NEXT observation is fetched while this one is processed, so an iteration
+  // is one memory round trip (planes + the block's x, all independent) instead of three dependent ones
+  int rb_next = (tm.j0 < k) ? v.obs_rb[base + (size_t)tm.j0 * 64] : -1;
   for (int j = tm.j0; j < k; j += tm.jstep) {
     const size_t e = base + (size_t)j * 64;
-    const int rb = v.cam_rb[v.obs_cam[e]];
+    const int rb = rb_next;
+    if (j + tm.jstep < k) rb_next = v.obs_rb[e + (size_t)tm.jstep * 64];
     if (rb < 0) continue;
     const double* xc = x + (size_t)rb * D;
     double u0 = 0.0, u1 = 0.0;
@@ -2001,6 +2005,15 @@ __global__ __launch_bounds__(256) void implicit_tracks_q_kernel(DeviceView v, co
     *reinterpret_cast<double2*>(zhat + (size_t)lp * 4) = make_double2(z[0], z[1]);
     *reinterpret_cast<double2*>(zhat + (size_t)lp * 4 + 2) = make_double2(z[2], z[3]);
   }
+}
+
+// reduced block of every observation's view (built once per structure)
+__global__ __launch_bounds__(256) void obs_rb_kernel(const int* __restrict__ obs_cam, const int* __restrict__ cam_rb,
+                                                     int Nc, long long n, int* __restrict__ obs_rb) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const int cam = obs_cam[e];
+  obs_rb[e] = (cam >= 0 && cam < Nc) ? cam_rb[cam] : -1;
 }
 
 // slot -> track of the rank's camera-major records (built once per structure)
@@ -2687,10 +2700,13 @@ __global__ __launch_bounds__(256) void back_substitute_kernel(DeviceView v, int 
 #pragma unroll
       for (int a = 0; a < DP; ++a) w[a] = tm.leader ? v.gp[(size_t)a * NP + lp] : 0.0;
       double ur = 0.0, uu = 0.0;
+      // (the block index of the next observation is in flight while this one is processed)
+      int rb_next = (tm.j0 < k) ? v.obs_rb[base + (size_t)tm.j0 * 64] : -1;
       for (int j = tm.j0; j < k; j += tm.jstep) {
         const size_t e = base + (size_t)j * 64;
-        const int cam = v.obs_cam[e];
-        const int rb = v.cam_rb[cam];
+        const int rb = rb_next;
+        if (j + tm.jstep < k) rb_next = v.obs_rb[e + (size_t)tm.jstep * 64];
+        const int cam = SH ? v.obs_cam[e] : 0;
         double u0 = 0.0, u1 = 0.0;
         if (rb >= 0) {
           const double* yc = v.yc + (size_t)rb * D;
