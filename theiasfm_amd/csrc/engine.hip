@@ -1326,8 +1326,8 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   v.write_y = (s->y_records && (!s->implicit || st.has_shared)) ? 1 : 0;
   if (s->adaptive) {
     // cost model measured on MI355X (profiles/r02_z): forming S ~61 ps per pair, a product with S ~192 ps per
-    // upper block, a matrix-free product ~98 ps per observation
-    const double form = 61.0 * (double)st.npairs, with_s = 192.0 * (double)st.nub, free = 98.0 * (double)st.No;
+    // upper block, a matrix-free product ~85 ps per observation
+    const double form = 61.0 * (double)st.npairs, with_s = 192.0 * (double)st.nub, free = 85.0 * (double)st.No;
     // (a product with S that costs more than a matrix-free one -- many views, little co-visibility: S has more
     // blocks than there are observations to walk -- never pays off: always matrix-free)
     s->adaptive_break_even = free > with_s ? (int)std::min(1.0e6, form / (free - with_s)) : 1 << 30;
