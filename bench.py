@@ -590,6 +590,16 @@ def main():
                 linear_solver=solver_policy(pa.num_cameras)[1],
                 ms_per_step=round(1e3 * ma["elapsed"] / max(ma["steps_run"], 1), 4), steps=ma["steps_run"],
                 value=pa.num_observations * ma["steps_run"] / ma["elapsed"], final_rmse=ma["summary"].final_rmse)
+            # BASELINE config 1 (49 views, 31.8 k observations): DENSE_SCHUR by the reference's policy; a problem
+            # this small is bound by launch and read-back latency, not by bytes
+            ml = measure("ladybug49", args.steps, args.warmup, False)
+            ml["solver"].close()
+            pl = ml["prob"]
+            out["variants"]["ladybug49-synthetic"] = dict(
+                cameras=pl.num_cameras, tracks=pl.num_points, observations=pl.num_observations,
+                linear_solver=solver_policy(pl.num_cameras)[1],
+                ms_per_step=round(1e3 * ml["elapsed"] / max(ml["steps_run"], 1), 4), steps=ml["steps_run"],
+                value=pl.num_observations * ml["steps_run"] / ml["elapsed"], final_rmse=ml["summary"].final_rmse)
             # the shim's default point parameterisation: 4 free homogeneous coordinates per point, as the
             # reference leaves them (bundle_adjuster.cc:379-385); the headline uses 3 (w fixed, the north-star's 2x3 blocks)
             o4 = dict(point_dof=4, linear_solver_type=abi.ITERATIVE_SCHUR, use_inner_iterations=0,

@@ -199,6 +199,33 @@ def test_constant_blocks_are_untouched():
     assert (K0[:, 1:] == K1[:, 1:]).all() and (K0[:, 0] != K1[:, 0]).all()
 
 
+@pytest.mark.parametrize("dof", [3, 4])
+def test_matrix_free_product_with_constant_blocks(dof):
+    """The matrix-free Schur product from the [A | Q] records (zhat per track, gathered by the cameras pass)
+    on a problem with constant points, a fully constant view, views with a locked position or orientation
+    and a robust loss: same trajectory as the oracle, and as the formed S to round-off."""
+    prob = synth.make_problem(14, 700, 4200, seed=23, scene="ring", spread=0.5)
+    prob.camera_flags[0] = abi.CAMERA_POSITION_CONSTANT | abi.CAMERA_ORIENTATION_CONSTANT
+    prob.camera_flags[3] = abi.CAMERA_POSITION_CONSTANT
+    prob.camera_flags[5] = abi.CAMERA_ORIENTATION_CONSTANT
+    prob.point_constant[::9] = 1
+    prob.obs_xy[::61] += 25.0
+    opt = dict(linear_solver_type=abi.ITERATIVE_SCHUR, point_dof=dof, loss_function_type=abi.LOSS_HUBER,
+               robust_loss_width=2.0, max_num_iterations=12, use_inner_iterations=0)
+    before = prob.copy()
+    dev_i, ora = run_both(prob, schur_mode=abi.SCHUR_IMPLICIT, **opt)
+    assert_same_solution(dev_i, ora, scale=30.0, cost_rel=1e-7, rmse_abs=1e-7, param_rel=1e-5, projective=(dof == 4))
+    dev_e, _ = run_both(prob, schur_mode=abi.SCHUR_EXPLICIT, **opt)
+    assert dev_i[1].num_iterations == dev_e[1].num_iterations
+    assert dev_i[1].num_linear_solver_iterations == dev_e[1].num_linear_solver_iterations
+    assert abs(dev_i[1].final_cost - dev_e[1].final_cost) <= 1e-9 * dev_e[1].final_cost
+    a = dev_i[2]
+    assert (a.extrinsics[0] == before.extrinsics[0]).all()
+    assert (a.extrinsics[3, :3] == before.extrinsics[3, :3]).all()
+    assert (a.extrinsics[5, 3:] == before.extrinsics[5, 3:]).all()
+    assert (a.points[::9] == before.points[::9]).all()
+
+
 def test_fountain11_fixture_known_answer_and_ba(golden_dir):
     # the reference's own golden data (data/sfm/fountain11.bin, SURVEY section 4): 11 views
     # sharing ONE intrinsics group; default options free {f, k1, k2} of that shared block
