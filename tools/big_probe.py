@@ -1,5 +1,5 @@
 """GPU: a problem several times the Venice size through create + a few LM iterations (headroom check:
-32-bit index limits, memory, set-up time).  python tools/big_probe.py [cameras tracks observations]"""
+32-bit index limits, memory, set-up time).  python tools/big_probe.py [cameras tracks observations [auto]]"""
 import sys
 import time
 
@@ -10,7 +10,10 @@ nc, npt, nobs = (int(a) for a in sys.argv[1:4]) if len(sys.argv) >= 4 else (4000
 t = time.time()
 P = synth.make_problem(nc, npt, nobs, seed=7, scene="ring", spread=0.08, heavy_tail=0.002)
 print("generated", P.num_cameras, P.num_points, P.num_observations, "in %.1f s" % (time.time() - t), flush=True)
-for mode, name in ((abi.SCHUR_EXPLICIT, "explicit"), (abi.SCHUR_IMPLICIT, "implicit")):
+modes = ((abi.SCHUR_EXPLICIT, "explicit"), (abi.SCHUR_IMPLICIT, "implicit"))
+if len(sys.argv) >= 5 and sys.argv[4] == "auto":
+    modes = ((abi.SCHUR_AUTO, "auto"),)
+for mode, name in modes:
     o = abi.default_options(point_dof=3, linear_solver_type=abi.ITERATIVE_SCHUR, use_inner_iterations=0, max_num_iterations=5,
                             schur_mode=mode, function_tolerance=-1.0, gradient_tolerance=-1.0, parameter_tolerance=-1.0)
     t = time.time()
