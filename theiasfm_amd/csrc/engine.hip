@@ -60,7 +60,8 @@ struct Launch {
   void (*point_scale)(const DeviceView&, hipStream_t, int);
   void (*shared_blocks)(const DeviceView&, hipStream_t, RedLayout);
   void (*cross_add)(const DeviceView&, hipStream_t, RedLayout);
-  void (*point_eliminate)(const DeviceView&, hipStream_t, double, double, double, int, double*, double*);
+  void (*point_eliminate)(const DeviceView&, hipStream_t, double, double, double, int, double*, double*, double,
+                          double*);
   void (*camera_diag)(const DeviceView&, hipStream_t, RedLayout);
   void (*schur_offdiag)(const DeviceView&, hipStream_t, RedLayout);
   void (*expand_scale)(const DeviceView&, hipStream_t);
@@ -115,9 +116,9 @@ Launch make_launch(bool fp32) {
     hipLaunchKernelGGL((cross_add_kernel<D>), dim3((n + 255) / 256), dim3(256), 0, st, v, R);
   };
   L.point_eliminate = [](const DeviceView& v, hipStream_t st, double ir, double lo, double hi, int nb,
-                         double* pm, double* vote) {
+                         double* pm, double* vote, double gtol, double* gvote) {
     hipLaunchKernelGGL((point_eliminate_kernel<D, DP, SH>), dim3(nb), dim3(256), 0, st, v, ir, lo, hi, nb, pm,
-                       vote);
+                       vote, gtol, gvote);
   };
   L.camera_diag = [](const DeviceView& v, hipStream_t st, RedLayout R) {
     if (v.Nrb) hipLaunchKernelGGL((camera_diag_kernel<D, DP, SH>), dim3(v.Nrb), dim3(64), 0, st, v, R);
@@ -1992,7 +1993,7 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
     {
       Timed t(s, TMI_BA_K_POINT_ELIMINATE);
       s->launch.point_eliminate(v, stream, inv_radius, O->min_lm_diagonal, O->max_lm_diagonal, nbs,
-                                s->d_partial_max, d_sc + 6);
+                                s->d_partial_max, d_sc + 6, O->gradient_tolerance, st.world > 1 ? d_sc + 0 : nullptr);
     }
     {
       Timed t(s, TMI_BA_K_CAMERA_DIAG);
@@ -2106,18 +2107,17 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
     // singular track blocks are voted on by every rank (summed in the all-reduce)
     if (s->h_red[6] > 0.0 || s->h_flags[FL_SINGULAR_BLOCK]) usable = 0;
     if (need_gradient_check) {
-      // gradient tolerance: every rank votes, the vote is summed
-      double vote[8] = {0};
-      const double gmax_local = std::fmax(s->h_scal[SC_GMAX], s->h_scal[SC_GMAX_P]);
-      vote[0] = (gmax_local > O->gradient_tolerance) ? 1.0 : 0.0;
-      if (st.world > 1) {
-        CKH(hipMemcpyAsync(d_sc, vote, sizeof(vote), hipMemcpyHostToDevice, stream));
-        CK(do_allreduce(s, d_sc, 8));
-        CKH(hipMemcpyAsync(vote, d_sc, sizeof(vote), hipMemcpyDeviceToHost, stream));
-        CKH(hipStreamSynchronize(stream));
-      }
+      // Gradient tolerance.  The camera part of the gradient is all-reduced, so max |g_c| is the same number on
+      // every rank; the track part is this rank's own, and on a sharded solve every rank's vote on it was summed
+      // by the all-reduce of the reduced system (point_eliminate left it in the scalar tail, which the mirror
+      // still shows: nothing has written there since) -- no collective and no synchronisation of its own.
+      double vote = (s->h_scal[SC_GMAX] > O->gradient_tolerance) ? 1.0 : 0.0;
+      if (st.world > 1)
+        vote += s->h_red[0];
+      else
+        vote += (s->h_scal[SC_GMAX_P] > O->gradient_tolerance) ? 1.0 : 0.0;
       need_gradient_check = false;
-      if (vote[0] == 0.0) {
+      if (vote == 0.0) {
         termination = 0;
         why = "gradient tolerance reached";
         --iter;

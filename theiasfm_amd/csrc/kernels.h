@@ -679,7 +679,8 @@ __global__ void camera_scale_finish_kernel(double* scale_c, int n) {
 template <int D, int DP, bool SH>
 __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, double inv_radius,
                                                               double lm_lo, double lm_hi, int nblocks,
-                                                              double* partial_max, double* singular_vote) {
+                                                              double* partial_max, double* singular_vote,
+                                                              double grad_tol, double* grad_vote) {
   constexpr int NS = sym_size(DP);
   constexpr int YS = ys_of(D, DP);
   constexpr int ASA = asa_of(D, DP);
@@ -1033,6 +1034,10 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
       double t = shm[0];
       for (int i = 1; i < kSlicesPerBlock; ++i) t = fmax(t, shm[i]);
       v.scal[SC_GMAX_P] = t;
+      // sharded solves: this rank's vote in the gradient-tolerance test rides in the scalar tail of the reduced
+      // system and is summed by the all-reduce that follows (the camera part of the gradient is all-reduced
+      // itself, so its maximum needs no vote)
+      if (grad_vote) *grad_vote = (t > grad_tol) ? 1.0 : 0.0;
     }
   }
 }
