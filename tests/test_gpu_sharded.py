@@ -119,6 +119,68 @@ def test_sharded_solve_matches_single_rank(world, solver_type, mode, inner, shar
     assert np.abs(merged.points - single.points).max() < 1e-6 * 100.0
 
 
+def _run_sharded(prob, opts, world):
+    emu = EmulatedAllReduce(world)
+    solvers = []
+    for r in range(world):
+        sv = lib.Solver(prob.copy(), opts, rank=r, world=world)
+        sv.set_allreduce(emu.hook(r))
+        solvers.append(sv)
+    results = [None] * world
+
+    def run(r):
+        results[r] = solvers[r].solve(opts)
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert all(not t.is_alive() for t in threads)
+    for sv in solvers:
+        sv.close()
+    return results
+
+
+@pytest.mark.parametrize("mode", [abi.SCHUR_EXPLICIT, abi.SCHUR_IMPLICIT])
+def test_sharded_ranks_leave_the_solve_together(mode):
+    """Termination decisions on a sharded solve come from all-reduced data only: the gradient-tolerance
+    vote rides in the scalar tail of the reduced system's all-reduce, the time limit in the tail of the
+    trial-step scalars.  Every rank must stop in the same iteration for the same reason (a rank that left
+    alone would leave the others in a collective)."""
+    import torch
+    torch.cuda.init()
+    prob = synth.config("ladybug49")
+    base = dict(linear_solver_type=abi.ITERATIVE_SCHUR, point_dof=3, schur_mode=mode, use_inner_iterations=0)
+    # (a) a gradient tolerance every start point satisfies: zero iterations, as on one rank
+    o = abi.default_options(gradient_tolerance=1e30, **base)
+    st1, s1 = lib.solve(prob.copy(), o)
+    assert st1 == 0 and s1.num_iterations == 0 and b"gradient tolerance" in s1.message
+    for st_r, s_r in _run_sharded(prob, o, 2):
+        assert st_r == 0 and s_r.num_iterations == 0 and b"gradient tolerance" in s_r.message
+        assert s_r.final_cost == s1.final_cost or abs(s_r.final_cost - s1.final_cost) <= 1e-12 * s1.final_cost
+    # (b) a tolerance reached after a few steps: same iteration count on every rank and on one rank
+    o = None
+    for tol in (1e2, 1e1, 1.0, 1e-1, 1e-2, 1e-3, 1e-4, 1e-5, 1e-6):
+        o = abi.default_options(gradient_tolerance=tol, function_tolerance=-1.0, parameter_tolerance=-1.0,
+                                max_num_iterations=40, **base)
+        st1, s1 = lib.solve(prob.copy(), o)
+        if st1 == 0 and b"gradient tolerance" in s1.message and 0 < s1.num_iterations < 40:
+            break
+    else:
+        pytest.fail("no gradient tolerance in the ladder stops the single-rank solve after a few iterations")
+    for st_r, s_r in _run_sharded(prob, o, 2):
+        assert st_r == 0 and b"gradient tolerance" in s_r.message
+        assert s_r.num_iterations == s1.num_iterations
+    # (c) a time limit that has already passed when the first trial step is evaluated
+    o = abi.default_options(max_solver_time_in_seconds=0.0, max_num_iterations=20, **base)
+    res = _run_sharded(prob, o, 2)
+    assert all(st_r == 0 for st_r, _ in res)
+    assert len({int(s_r.num_iterations) for _, s_r in res}) == 1
+    assert all(b"maximum solver time" in s_r.message for _, s_r in res)
+    assert res[0][1].num_iterations <= 2
+
+
 def test_rccl_hook_single_rank_group():
     """The production hook: torch.distributed backend nccl (= RCCL), a raw device
     pointer aliased as a tensor, enqueued on a foreign HIP stream."""

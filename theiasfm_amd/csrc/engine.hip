@@ -2140,8 +2140,10 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
         //        track votes, time-limit votes]
         s->launch.cost(v, stream, v.prep_c, v.pts_c, lt, lw, FL_INVALID, nbs, v.partial, d_sc + 3, d_sc + 5);
       }
-      if (st.world > 1) {
-        s->time_vote = (now_s() - t_start >= O->max_solver_time_in_seconds) ? 1.0 : 0.0;
+      if (st.world > 1 && now_s() - t_start >= O->max_solver_time_in_seconds) {
+        // this rank's clock says the time limit has passed: its vote (the slot is zero otherwise, cleared at the
+        // top of the iteration) is summed with the trial-step scalars below
+        s->time_vote = 1.0;
         CKH(hipMemcpyAsync(d_sc + 7, &s->time_vote, sizeof(double), hipMemcpyHostToDevice, stream));
       }
       CK(do_allreduce(s, d_sc, 8));
