@@ -226,6 +226,27 @@ def test_matrix_free_product_with_constant_blocks(dof):
     assert (a.points[::9] == before.points[::9]).all()
 
 
+@pytest.mark.parametrize("bits,models,dim", [
+    (abi.INTRINSICS_NONE, [(abi.PINHOLE, 1.0)], 6),
+    (abi.INTRINSICS_DEFAULT, [(abi.PINHOLE, 1.0)], 9),
+    (abi.INTRINSICS_FOCAL_LENGTH | abi.INTRINSICS_PRINCIPAL_POINTS | abi.INTRINSICS_RADIAL_DISTORTION,
+     [(abi.PINHOLE, 1.0)], 12),
+    (abi.INTRINSICS_ALL, [(abi.PINHOLE_RADIAL_TANGENTIAL, 1.0)], 16)])
+@pytest.mark.parametrize("dof", [3, 4])
+def test_matrix_free_product_every_block_size(bits, models, dim, dof):
+    """The one-sweep matrix-free product at every reduced block size the engine instantiates (6, 9, 12, 16) and both
+    point parameterisations: same LM trajectory as the oracle, same PCG iteration count as the formed S."""
+    prob = synth.make_problem(16, 900, 5400, seed=91, scene="ring", spread=0.5, models=models,
+                              intrinsics_to_optimize=bits)
+    opt = dict(linear_solver_type=abi.ITERATIVE_SCHUR, point_dof=dof, max_num_iterations=10, use_inner_iterations=0)
+    dev_i, ora = run_both(prob, schur_mode=abi.SCHUR_IMPLICIT, **opt)
+    assert dev_i[1].reduced_block_dim == dim
+    assert_same_solution(dev_i, ora, scale=30.0, cost_rel=1e-7, rmse_abs=1e-7, param_rel=1e-5, projective=(dof == 4))
+    dev_e, _ = run_both(prob, schur_mode=abi.SCHUR_EXPLICIT, **opt)
+    assert dev_i[1].num_linear_solver_iterations == dev_e[1].num_linear_solver_iterations
+    assert abs(dev_i[1].final_cost - dev_e[1].final_cost) <= 1e-9 * dev_e[1].final_cost
+
+
 def test_fountain11_fixture_known_answer_and_ba(golden_dir):
     # the reference's own golden data (data/sfm/fountain11.bin, SURVEY section 4): 11 views
     # sharing ONE intrinsics group; default options free {f, k1, k2} of that shared block
