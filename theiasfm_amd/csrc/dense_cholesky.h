@@ -4,8 +4,9 @@
 // 1000-view switch to ITERATIVE_SCHUR, reconstruction_estimator_utils.cc:110-133)
 // and factored with a blocked right-looking Cholesky (lower triangle).  Panels are 32 columns
 // wide: the 32 x 32 diagonal block is factored by ONE wavefront out of registers (lane i owns row
-// i, pivots and multipliers travel by v_readlane -- no LDS, no barriers: a 256-thread version
-// with three __syncthreads per column took 23 us), the panel below it by a thread per row.  The
+// i, pivots and multipliers travel by v_readlane -- no barriers: a 256-thread version
+// with three __syncthreads per column took 23 us), the panel below it by a thread per row, both in
+// ONE launch per panel (every workgroup factors the diagonal block itself, chol_panel_kernel).  The
 // trailing update -- all of the n^3 / 3 flops -- runs once per PAIR of panels as a rank-64 update
 // on the f64 matrix cores (v_mfma_f64_16x16x4, 64 x 64 tiles), the second panel of a pair seeing
 // the first through a narrow rank-32 update of its own 32 columns.  Forward / backward
@@ -58,44 +59,49 @@ __device__ __forceinline__ double lane_bcast(double v, int src_lane) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 
-// diagonal block (kPanel x kPanel): one wavefront, lane i holds row i in registers.  Entries above
-// the diagonal carry garbage that is never read.
-__global__ __launch_bounds__(64) void chol_potrf_tile_kernel(double* __restrict__ A, int n, int k0,
-                                                             int* __restrict__ flag) {
-  const int nb = min(kPanel, n - k0);
-  const int lane = threadIdx.x;
-  double r[kPanel];
-#pragma unroll
-  for (int c = 0; c < kPanel; ++c)
-    r[c] = (lane < nb && c < nb && c <= lane) ? A[(size_t)(k0 + lane) * n + k0 + c] : (c == lane ? 1.0 : 0.0);
-  bool bad = false;
-#pragma unroll
-  for (int j = 0; j < kPanel; ++j) {
-    double d = lane_bcast(r[j], j);
-    if (!(d > 0.0) || !isfinite(d)) {
-      bad = true;
-      d = 1.0;
-    }
-    const double dj = sqrt(d);
-    r[j] = (lane == j) ? dj : r[j] / dj;
-#pragma unroll
-    for (int m = j + 1; m < kPanel; ++m) r[m] -= r[j] * lane_bcast(r[j], m);
-  }
-  if (bad && lane == 0) *flag = 1;
-  if (lane < nb) {
-#pragma unroll
-    for (int c = 0; c < kPanel; ++c)
-      if (c <= lane && c < nb) A[(size_t)(k0 + lane) * n + k0 + c] = r[c];
-  }
-}
-
-// rows i >= k0 + nb:  A[i, k0:k0+nb] <- A[i, k0:k0+nb] L_kk^-T   (thread per row, L_kk in LDS)
-__global__ __launch_bounds__(256) void chol_trsm_kernel(double* __restrict__ A, int n, int k0) {
+// One panel in ONE launch: every workgroup factors the kPanel x kPanel diagonal block itself (wave 0: lane i holds row i of the block in registers,
+// pivots and multipliers by v_readlane, on a copy in LDS -- a dependent chain of ~6 us that costs the same wherever
+// it runs) and then solves its 256 rows of the panel against it, so the diagonal factor never crosses workgroups
+// inside the launch.  The factored diagonal block goes to `diag` (kPanel x kPanel per panel), NOT back into A:
+// other workgroups may still be reading the unfactored block there; chol_diag_store_kernel puts all of them
+// into A once the factorisation is over.  Same arithmetic in the same order as the two-kernel form.
+__global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A, int n, int k0,
+                                                         double* __restrict__ diag, int* __restrict__ flag) {
   __shared__ double L[kPanel][kPanel + 1];
   const int nb = min(kPanel, n - k0);
   for (int e = threadIdx.x; e < kPanel * kPanel; e += 256) {
     const int r = e / kPanel, c = e - r * kPanel;
-    L[r][c] = (r < nb && c <= r) ? A[(size_t)(k0 + r) * n + k0 + c] : (r == c ? 1.0 : 0.0);
+    L[r][c] = (r < nb && c < nb && c <= r) ? A[(size_t)(k0 + r) * n + k0 + c] : (r == c ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    double r[kPanel];
+#pragma unroll
+    for (int c = 0; c < kPanel; ++c) r[c] = (lane < kPanel && c <= lane) ? L[lane][c] : 0.0;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < kPanel; ++j) {
+      double d = lane_bcast(r[j], j);
+      if (!(d > 0.0) || !isfinite(d)) {
+        bad = true;
+        d = 1.0;
+      }
+      const double dj = sqrt(d);
+      r[j] = (lane == j) ? dj : r[j] / dj;
+#pragma unroll
+      for (int m = j + 1; m < kPanel; ++m) r[m] -= r[j] * lane_bcast(r[j], m);
+    }
+    if (bad && lane == 0 && blockIdx.x == 0) *flag = 1;
+    if (lane < kPanel) {
+      double* dst = diag + (size_t)(k0 / kPanel) * kPanel * kPanel + lane * kPanel;
+#pragma unroll
+      for (int c = 0; c < kPanel; ++c)
+        if (c <= lane) {
+          L[lane][c] = r[c];
+          if (blockIdx.x == 0) dst[c] = r[c];
+        }
+    }
   }
   __syncthreads();
   const int i = k0 + nb + blockIdx.x * 256 + threadIdx.x;
@@ -116,6 +122,16 @@ __global__ __launch_bounds__(256) void chol_trsm_kernel(double* __restrict__ A, 
 #pragma unroll
   for (int c = 0; c < kPanel; ++c)
     if (c < nb) row[c] = x[c];
+}
+
+// the factored diagonal blocks of every panel, from the side buffer into A
+__global__ __launch_bounds__(256) void chol_diag_store_kernel(double* __restrict__ A, int n,
+                                                              const double* __restrict__ diag) {
+  const int e = blockIdx.x * 256 + threadIdx.x;  // element (row i, column c of its panel)
+  if (e >= n * kPanel) return;
+  const int i = e / kPanel, c = e - i * kPanel;
+  const int p = i / kPanel, r = i - p * kPanel;
+  if (c <= r && p * kPanel + c < n) A[(size_t)i * n + p * kPanel + c] = diag[(size_t)p * kPanel * kPanel + r * kPanel + c];
 }
 
 // Rank-kw update on the f64 matrix cores: A[i, j] -= sum_{k < kw} A[i, kp + k] A[j, kp + k] for the
@@ -218,13 +234,13 @@ __global__ __launch_bounds__(256) void chol_subst_kernel(const double* __restric
 
 // A (n x n, symmetric, row major) is overwritten by its Cholesky factor (lower);
 // x <- A^-1 b.  *flag is set when a pivot is not positive.  tmp: n doubles of scratch.
-inline void dense_cholesky_solve(double* A, int n, const double* b, double* x, double* tmp, int* flag,
+// diag: kPanel * (n rounded up to kPanel) doubles of scratch for the factored diagonal blocks.
+inline void dense_cholesky_solve(double* A, int n, const double* b, double* x, double* tmp, double* diag, int* flag,
                                  hipStream_t st) {
   auto panel = [&](int k0) {  // factor columns [k0, k0 + kPanel) given all earlier updates
     const int nb = (n - k0 < kPanel) ? n - k0 : kPanel;
-    hipLaunchKernelGGL(chol_potrf_tile_kernel, dim3(1), dim3(64), 0, st, A, n, k0, flag);
     const int rem = n - k0 - nb;
-    if (rem > 0) hipLaunchKernelGGL(chol_trsm_kernel, dim3((rem + 255) / 256), dim3(256), 0, st, A, n, k0);
+    hipLaunchKernelGGL(chol_panel_kernel, dim3(rem > 0 ? (rem + 255) / 256 : 1), dim3(256), 0, st, A, n, k0, diag, flag);
   };
   for (int k0 = 0; k0 < n; k0 += kTile) {
     panel(k0);
@@ -241,6 +257,7 @@ inline void dense_cholesky_solve(double* A, int n, const double* b, double* x, d
     const int nt = (n - k2 + kTile - 1) / kTile;
     hipLaunchKernelGGL(chol_syrk_kernel, dim3(nt, nt), dim3(256), 0, st, A, n, k0, kTile, k2, n);
   }
+  hipLaunchKernelGGL(chol_diag_store_kernel, dim3((n * kPanel + 255) / 256), dim3(256), 0, st, A, n, diag);
   // forward on x (working) -> tmp (solved y), backward on tmp (working) -> x
   hipMemcpyAsync(x, b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st);
   for (int k0 = 0; k0 < n; k0 += kTile) {

@@ -1669,13 +1669,15 @@ static int solve_reduced_dense(tmi_ba_solver* s, int* usable) {
   *usable = 1;
   if (n == 0) return TMI_BA_OK;
   if (!s->d_dense) {
-    int rc = dev_alloc(s, &s->d_dense, (size_t)n * n);
+    // + the side buffer of the factored diagonal blocks (dense_cholesky.h)
+    int rc = dev_alloc(s, &s->d_dense, (size_t)n * n + (size_t)kPanel * (n + kPanel));
     if (rc) return rc;
   }
   Timed t(s, TMI_BA_K_CHOLESKY);
   TMI_HIP(hipMemsetAsync(s->d_dense, 0, (size_t)n * n * sizeof(double), s->stream));
   s->launch.dense_gather(v, s->stream, v.red + s->RL.ub, s->d_dense, n);
-  dense_cholesky_solve(s->d_dense, n, v.red + s->RL.gt, v.yc, v.cg_t, v.flags + FL_SINGULAR_BLOCK, s->stream);
+  dense_cholesky_solve(s->d_dense, n, v.red + s->RL.gt, v.yc, v.cg_t, s->d_dense + (size_t)n * n,
+                       v.flags + FL_SINGULAR_BLOCK, s->stream);
   return TMI_BA_OK;
 }
 
