@@ -57,16 +57,10 @@ def algorithmic_bytes(cls: str, n_obs: int, n_cam: int, n_pts: int, dc: int, dp:
     if cls == "schur_offdiag":
         return 2 * nnzb * 8 * dc * dc
     if cls == "spmv":
-        # A product with an operator reads the operator's blocks once.  Formed S: every upper block once.
-        # Matrix-free: S = U - W V^-1 W^T is applied through the Jacobian blocks, so the blocks read once are
-        # the 2 x dc camera and 2 x dp point Jacobian blocks of every observation (16 (dc + dp) B), its two
-        # int32 indices, the per-track factor L^-1 and the vectors.  (The kernels read the camera blocks twice
-        # -- track-major in the tracks pass, camera-major in the cameras pass -- because summing over tracks and
-        # over cameras without atomics needs both orders; that factor is in `traffic`, not here.)
-        # mf_frac = share of the LM iterations whose PCG ran matrix-free (all of them on sharded runs).
-        with_s = nnzb * 8 * dc * dc + 2 * n_cam * 8 * dc
-        matrix_free = n_obs * (16 * (dc + dp) + 8) + 4 * n_cam * 8 * dc + n_pts * 8 * sym(dp)
-        return int((1.0 - mf_frac) * with_s + mf_frac * matrix_free)
+        # SURVEY 8(d), B_pcg per PCG iteration: every structurally non-zero upper block of S once plus the vectors,
+        # WHICHEVER operator applies S (Jacobian blocks are recomputable, hence not algorithmic).  The bytes the
+        # matrix-free product cannot avoid in this repository's layout are reported beside it as `layout_floor`.
+        return nnzb * 8 * dc * dc + 6 * n_cam * 8 * dc
     if cls == "pcg_vector":
         return 4 * n_cam * 8 * dc
     if cls == "back_substitute":
@@ -74,6 +68,54 @@ def algorithmic_bytes(cls: str, n_obs: int, n_cam: int, n_pts: int, dc: int, dp:
     if cls == "update_cost":
         return n_obs * 24 + n_cam * 8 * dc + n_pts * 8 * dp
     return 0
+
+
+def matrix_free_layout_floor(n_obs: int, n_cam: int, n_pts: int, dc: int, dp: int):
+    """Bytes ONE matrix-free product must read in the layout of DESIGN.md section 3 when every stored block is read
+    once: the 2 x dc camera and 2 x dp point Jacobian blocks of every observation, its two int32 indices, the
+    per-track factor and the vectors.  NOT SURVEY 8(d)'s figure (that one counts S blocks); a different key in the
+    bench line."""
+    return n_obs * (16 * (dc + dp) + 8) + 4 * n_cam * 8 * dc + n_pts * 8 * (dp * (dp + 1) // 2)
+
+
+def engine_source_sha():
+    """Stamp of the engine sources a PMC pass was taken with (the GPU box has no .git)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "theiasfm_amd", "csrc", "*"))):
+        if f.endswith((".h", ".hip", ".cpp")):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def ceres_probe():
+    """SURVEY 8(d) CPU-baseline plan, step 1: is a real Ceres / Eigen / TheiaSfM on this box?  (If so,
+    tools/ceres_golden_main.cc can be built against it and `kind` becomes "reference"; otherwise the port.)"""
+    import fnmatch
+    import subprocess
+    pats = dict(ceres_lib="libceres*", ceres_header="ceres.h", eigen="*/Eigen/Core", theia_lib="libtheia.*",
+                glog="libglog*", suitesparse="libcholmod*")
+    found = {k: None for k in pats}
+    roots = [d for d in ("/usr", "/opt", "/usr/local", "/root", "/home") if os.path.isdir(d)]
+    expr = []
+    for pat in pats.values():
+        expr += ["-o", "-path" if "/" in pat else "-name", pat]
+    try:  # one walk of the file system for all six patterns
+        r = subprocess.run(["find"] + roots + ["-xdev", "-not", "-path", "*/repo/*", "-not", "-path", "*/torch/*",
+                                               "-not", "-path", "/root/reference/*", "("] + expr[1:] + [")", "-print"],
+                           capture_output=True, text=True, timeout=90)
+        for line in r.stdout.splitlines():
+            for key, pat in pats.items():
+                if found[key] is None and (fnmatch.fnmatch(line, pat) or fnmatch.fnmatch(os.path.basename(line), pat)):
+                    found[key] = line
+    except (OSError, subprocess.TimeoutExpired):
+        found = {k: "probe failed" for k in pats}
+    usable = bool(found.get("ceres_lib") and found.get("ceres_header") and found.get("eigen") and found.get("theia_lib"))
+    return dict(found=found, reference_buildable=usable,
+                note="TheiaSfM's BundleAdjustReconstruction needs all of Ceres, Eigen, glog and libtheia"
+                     + ("" if usable else "; not on this box, so cpu_baseline.kind stays 'port'"))
 
 
 def pmc_traffic(kernel_class: str, workload: str, world: int, mf_frac: float = 0.0):
@@ -90,6 +132,8 @@ def pmc_traffic(kernel_class: str, workload: str, world: int, mf_frac: float = 0
         return None
     if d.get("workload") != workload or world != 1:
         return None
+    if d.get("engine_source_sha") != engine_source_sha():
+        return None  # taken with another build of the kernels: refuse rather than quote stale bytes
     v = d.get("classes", {}).get(kernel_class)
     if kernel_class == "spmv" and mf_frac > 0.0:
         # the class holds both operators' products: blend as algorithmic_bytes does
@@ -98,6 +142,16 @@ def pmc_traffic(kernel_class: str, workload: str, world: int, mf_frac: float = 0
             return None
         v = (1.0 - mf_frac) * (v or 0.0) + mf_frac * f
     return None if v is None else int(v)
+
+
+def pmc_build():
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+    except (OSError, ValueError):
+        return None
+    return dict(tag=d.get("tag"), engine_source_sha=d.get("engine_source_sha"), git_head=d.get("git_head"),
+                current_engine_source_sha=engine_source_sha(),
+                stale=d.get("engine_source_sha") != engine_source_sha())
 
 
 def write_problem_file(prob, path):
@@ -197,7 +251,7 @@ def main():
         left, done = steps, 0
         secs = [0.0] * abi.NUM_KERNEL_CLASSES
         launches = [0] * abi.NUM_KERNEL_CLASSES
-        pcg = acc = 0
+        pcg = acc = mf = 0
         s = None
         while left > 0:
             n = min(left, max(1, args.solve_length))
@@ -207,6 +261,7 @@ def main():
             done += int(s.num_iterations)
             pcg += int(s.num_linear_solver_iterations)
             acc += int(s.num_successful_steps)
+            mf += int(s.num_matrix_free_iterations)
             for i in range(abi.NUM_KERNEL_CLASSES):
                 secs[i] += s.kernel_seconds[i]
                 launches[i] += s.kernel_launches[i]
@@ -215,7 +270,7 @@ def main():
                 break  # a failure mode (invalid steps, minimum radius): reported through steps != K
             if left > 0:
                 solver.reset()
-        return done, secs, launches, s, pcg, acc
+        return done, secs, launches, s, pcg, acc, mf
 
     def measure(workload, steps, warmup, with_transport):
         """creates the resident solver, warms up, profiles, times; returns a dict of raw results"""
@@ -247,14 +302,14 @@ def main():
         # untimed pass of the same iterations with every kernel class timed (HIP events on the engine's
         # stream): the per-class table, and which class dominates.  The timed region carries events for
         # THAT class only (two event records per launch of every class cost a few % of an iteration).
-        _, secs_p, launches_p, _, _, _ = run_chunks(solver, base, steps, 1)
+        _, secs_p, launches_p, _, _, _, _ = run_chunks(solver, base, steps, 1)
         secs_nc = list(secs_p)
         secs_nc[abi.KERNEL_CLASS_NAMES.index("allreduce")] = 0.0
         dom_idx = max(range(len(secs_nc)), key=lambda i: secs_nc[i])
         solver.reset()
         sync_all()
         t0 = time.perf_counter()
-        done, secs_t, launches_t, s, pcg, acc = run_chunks(solver, base, steps, (1 << dom_idx) if dom_idx > 0 else 1)
+        done, secs_t, launches_t, s, pcg, acc, mf = run_chunks(solver, base, steps, (1 << dom_idx) if dom_idx > 0 else 1)
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         if world > 1:
@@ -263,7 +318,7 @@ def main():
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             elapsed = float(t.item())
         return dict(prob=prob, prob0=prob0, base=base, solver=solver, transport=transport, t_gen=t_gen,
-                    t_create=t_create, steps_run=done, elapsed=elapsed, summary=s, pcg=pcg, accepted=acc,
+                    t_create=t_create, steps_run=done, elapsed=elapsed, summary=s, pcg=pcg, accepted=acc, matrix_free=mf,
                     secs_p=secs_p, launches_p=launches_p, secs_t=secs_t, launches_t=launches_t, dom_idx=dom_idx)
 
     m = measure(args.workload, args.steps, args.warmup, True)
@@ -278,7 +333,7 @@ def main():
     dc, dp = int(s.reduced_block_dim), 3
     nnzb = int(s.num_schur_blocks)
 
-    mf_frac = float(s.num_matrix_free_iterations) / max(1, int(s.num_iterations))
+    mf_frac = float(m["matrix_free"]) / max(1, steps_run)  # share of the timed LM iterations whose PCG ran matrix-free
 
     def table(launch_list, sec_list):
         rows = []
@@ -302,10 +357,25 @@ def main():
                     unit="GB/s", frac=round(dom["achieved_GBs"] / HBM_PEAK_GBS, 5),
                     traffic=pmc_traffic(dom["kernel"], args.workload, world, mf_frac),
                     traffic_source="profiles/pmc_latest.json: rocprofv3 --pmc passes of this command, committed "
-                                   "(counters cannot be read from inside the process)",
+                                   "(counters cannot be read from inside the process); null when that pass was "
+                                   "taken with other kernel sources (traffic_build.stale)",
+                    traffic_build=pmc_build(),
                     launches=dom["launches"], avg_us=dom["avg_us"],
                     algorithmic_bytes_per_launch=dom["algorithmic_bytes_per_launch"],
+                    algorithmic_bytes_definition="SURVEY 8(d): per product nnzb * 8 d_c^2 + 6 N_c 8 d_c (S blocks once, "
+                                                 "whichever operator applies S); per-observation classes 24 B/observation "
+                                                 "+ parameters + normal-equation blocks",
                     measured="HIP events on the engine's stream inside the timed region")
+    if dom["kernel"] == "spmv" and mf_frac > 0.0:
+        # beside the contract's figure, under its own key: what a matrix-free product has to read in this layout
+        lf = matrix_free_layout_floor(n_obs // world, n_cam, n_pts // world, dc, dp)
+        roofline["kernel"] = ("spmv (one product q = S p; matrix-free in %d of %d timed LM iterations: implicit_tracks_q "
+                              "+ implicit_cameras_q)" % (m["matrix_free"], steps_run))
+        roofline["layout_floor"] = dict(
+            bytes_per_launch=int(lf), achieved=round(lf / (dom["avg_us"] * 1e-6) / 1e9, 2),
+            frac=round(lf / (dom["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
+            note="matrix-free product, every stored Jacobian block read once (NOT SURVEY 8(d)'s bytes; round 2 "
+                 "quoted this figure as roofline.frac)")
     # the other large classes of the same timed region (schur_offdiag was the dominant one until the adaptive
     # operator choice took it out of the short PCG solves): same definition, for comparison across rounds
     roofline["other_classes"] = {
@@ -371,13 +441,20 @@ def main():
     b_pcg = n_pcg * (nnzb * 8 * dc * dc + 6 * n_cam * 8 * dc)
     b_back = n_obs * 24 + n_cam * 8 * dc + n_pts * 8 * (sym(dp) + 2 * dp)
     b_cost = n_obs * 24 + n_cam * 8 * dc + n_pts * 8 * dp
-    b_iter = b_lin + b_schur + b_pcg + b_back + b_cost
+    # S is formed only in the LM iterations that ran PCG on it (schur_mode auto picks per iteration): B_schur counts
+    # for those and not for the matrix-free ones
+    formed_frac = (1.0 - mf_frac) if solver_type == abi.ITERATIVE_SCHUR else 1.0
+    b_iter = b_lin + formed_frac * b_schur + b_pcg + b_back + b_cost
+    b_iter_all = b_lin + b_schur + b_pcg + b_back + b_cost
     out["iteration_roofline"] = dict(
         algorithmic_bytes_per_lm_iteration=int(b_iter), pcg_iterations_per_lm_iteration=round(n_pcg, 2),
+        lm_iterations_that_formed_S=int(round(formed_frac * steps_run)), of=steps_run,
         achieved_GBs=round(b_iter * steps_run / elapsed / 1e9, 1), peak_GBs=HBM_PEAK_GBS * world,
         frac=round(b_iter * steps_run / elapsed / 1e9 / (HBM_PEAK_GBS * world), 5),
-        note="SURVEY 8(d) formula; the kernels move several times these bytes (profiles/) because Jacobian blocks "
-             "and the per-observation Schur factors are stored and gathered rather than recomputed")
+        frac_if_S_counted_every_iteration=round(b_iter_all * steps_run / elapsed / 1e9 / (HBM_PEAK_GBS * world), 5),
+        note="SURVEY 8(d) formula, B_schur only for the iterations that formed S; the kernels move several times these "
+             "bytes (profiles/) because Jacobian blocks and the per-observation Schur factors are stored and gathered "
+             "rather than recomputed")
 
     extras = world == 1 and not args.no_extras
     if extras:
@@ -415,7 +492,7 @@ def main():
         st_d, s_d = solver.solve(dev_opts)
         out["cpu_baseline"] = dict(
             value=n_obs * int(s_o.num_iterations) / s_o.solve_time_in_seconds, unit="observations/s",
-            cores=oracle.num_threads(), kind="port",
+            cores=oracle.num_threads(), kind="port", ceres_probe=ceres_probe(),
             sample=f"{int(s_o.num_iterations)} LM iterations of the full {args.workload} problem, same options "
                    f"(solve {s_o.solve_time_in_seconds:.2f} s + setup {s_o.setup_time_in_seconds:.2f} s, wall {t_cpu:.2f} s)",
             final_cost=s_o.final_cost, final_rmse=s_o.final_rmse)
