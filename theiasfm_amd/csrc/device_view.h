@@ -189,6 +189,6 @@ enum {
   SC_COUNT = 32
 };
 // DeviceView::flags
-enum { FL_INVALID = 0, FL_SINGULAR_POINT = 1, FL_SINGULAR_BLOCK = 2, FL_PCG_FAIL = 3, FL_COUNT = 8 };
+enum { FL_INVALID = 0, FL_SINGULAR_POINT = 1, FL_SINGULAR_BLOCK = 2, FL_PCG_FAIL = 3, FL_CHOL_ABORT = 4, FL_COUNT = 8 };
 
 }  // namespace tmi

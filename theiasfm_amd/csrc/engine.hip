@@ -23,6 +23,7 @@
 
 #include "../../include/theia_mi355_ba.h"
 #include "dense_cholesky.h"
+#include "dense_cholesky_df.h"
 #include "kernels.h"
 #include "track_kernels.h"
 #include "inner_kernels.h"
@@ -80,6 +81,7 @@ struct Launch {
   void (*update_cameras)(const DeviceView&, hipStream_t, double* out, double* prep_c);
   void (*pcg_init)(const DeviceView&, hipStream_t, const double* b, int nb);
   void (*dense_gather)(const DeviceView&, hipStream_t, const double*, double*, int);
+  void (*tile_gather)(const DeviceView&, hipStream_t, const double*, const double*, double*, int);
 };
 
 template <int D, int DP, bool SH>
@@ -208,6 +210,12 @@ Launch make_launch(bool fp32) {
   L.pcg_init = [](const DeviceView& v, hipStream_t st, const double* b, int nb) {
     hipLaunchKernelGGL((pcg_init_kernel<D>), dim3(nb), dim3(kPcgStepThreads), 0, st, v, b, nb);
   };
+  L.tile_gather = [](const DeviceView& v, hipStream_t st, const double* ub, const double* rhs, double* tiles, int n) {
+    const long long total = ((long long)v.nub + v.Nrb) * D * D + n;
+    if (total)
+      hipLaunchKernelGGL((cdf::tile_gather_kernel<D>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                         st, v, ub, rhs, tiles, n);
+  };
   L.dense_gather = [](const DeviceView& v, hipStream_t st, const double* ub, double* A, int n) {
     const long long total = ((long long)v.nub + v.Nrb) * D * D;
     if (total)
@@ -287,7 +295,13 @@ struct tmi_ba_solver {
   double time_vote = 0.0;     // this rank's "solver time exceeded" vote (source of a small async copy)
   const tmi_ba_options* cur_opts = nullptr;
   double* d_partial_max = nullptr;
-  double* d_dense = nullptr;  // n_r x n_r when an exact solve is requested
+  double* d_dense = nullptr;  // n_r x n_r when an exact solve is requested (launch-per-panel path)
+  // tile-dataflow Cholesky (dense_cholesky_df.h): tiles, inverse diagonal factors, flags; one epoch per solve
+  double* d_df_tiles = nullptr;
+  double* d_df_linv = nullptr;
+  int* d_df_flags = nullptr;
+  int df_epoch = 0;
+  int num_cus = 0;
   int nblocks_slices = 0;     // ceil(nslices / 4): grid of the thread-per-track side kernels
   int nblocks_tracks = 0;     // grid of the per-track kernels of the solve (DeviceView::n_track_blocks)
   int nblocks_points = 0;
@@ -1663,21 +1677,85 @@ static int solve_reduced_pcg(tmi_ba_solver* s, const tmi_ba_options* O, int* usa
   return TMI_BA_OK;
 }
 
-static int solve_reduced_dense(tmi_ba_solver* s, int* usable) {
+// big dataflow launches of one process on one device run one after the other: two of them racing for the same CUs could
+// each hold a part of the device and wait for the rest (dense_cholesky_df.h); the dependency is enqueued, the host
+// does not wait
+static std::mutex g_df_mutex;
+static hipEvent_t g_df_event[64] = {};
+
+static int solve_reduced_dense_panels(tmi_ba_solver* s) {
   DeviceView& v = s->v;
   const int n = v.Nrb * v.D;
-  *usable = 1;
-  if (n == 0) return TMI_BA_OK;
   if (!s->d_dense) {
     // + the side buffer of the factored diagonal blocks (dense_cholesky.h)
     int rc = dev_alloc(s, &s->d_dense, (size_t)n * n + (size_t)kPanel * (n + kPanel));
     if (rc) return rc;
   }
-  Timed t(s, TMI_BA_K_CHOLESKY);
   TMI_HIP(hipMemsetAsync(s->d_dense, 0, (size_t)n * n * sizeof(double), s->stream));
   s->launch.dense_gather(v, s->stream, v.red + s->RL.ub, s->d_dense, n);
   dense_cholesky_solve(s->d_dense, n, v.red + s->RL.gt, v.yc, v.cg_t, s->d_dense + (size_t)n * n,
                        v.flags + FL_SINGULAR_BLOCK, s->stream);
+  return TMI_BA_OK;
+}
+
+static int solve_reduced_dense(tmi_ba_solver* s, int* usable) {
+  DeviceView& v = s->v;
+  const int n = v.Nrb * v.D;
+  *usable = 1;
+  if (n == 0) return TMI_BA_OK;
+  Timed t(s, TMI_BA_K_CHOLESKY);
+  static const bool panels_only = getenv("TMI_BA_CHOL_PANELS") != nullptr;
+  if (panels_only) return solve_reduced_dense_panels(s);
+  if (!s->num_cus) {
+    hipDeviceProp_t prop;
+    TMI_HIP(hipGetDeviceProperties(&prop, s->device));
+    s->num_cus = prop.multiProcessorCount;
+  }
+  const cdf::Plan plan = cdf::make_plan(n, s->num_cus);
+  if (!s->d_df_tiles) {
+    int rc;
+    if ((rc = dev_alloc(s, &s->d_df_tiles, plan.tile_doubles))) return rc;
+    if ((rc = dev_alloc(s, &s->d_df_linv, plan.linv_doubles))) return rc;
+    if ((rc = dev_alloc(s, &s->d_df_flags, plan.flag_ints))) return rc;
+    TMI_HIP(hipMemsetAsync(s->d_df_flags, 0, plan.flag_ints * sizeof(int), s->stream));
+    s->df_epoch = 0;
+  }
+  if (++s->df_epoch == 0x7fffffff) {  // flags compare against the epoch: start over long before it wraps
+    TMI_HIP(hipMemsetAsync(s->d_df_flags, 0, plan.flag_ints * sizeof(int), s->stream));
+    s->df_epoch = 1;
+  }
+  TMI_HIP(hipMemsetAsync(s->d_df_tiles, 0, plan.tile_doubles * sizeof(double), s->stream));
+  s->launch.tile_gather(v, s->stream, v.red + s->RL.ub, v.red + s->RL.gt, s->d_df_tiles, n);
+  cdf::Args a;
+  const size_t ntiles = cdf::tile_index(plan.T - 1, plan.T - 1) + 1;
+  a.tiles = s->d_df_tiles;
+  a.linv = s->d_df_linv;
+  a.tflag = s->d_df_flags;
+  a.dflag = s->d_df_flags + ntiles;
+  a.xflag = a.dflag + plan.T;
+  a.x = v.yc;
+  a.ctrl = v.flags + FL_CHOL_ABORT;
+  a.singular = v.flags + FL_SINGULAR_BLOCK;
+  a.n = n;
+  a.T = plan.T;
+  a.epoch = s->df_epoch;
+  a.band = plan.band;
+  a.team = plan.team;
+  a.G = plan.G;
+  const bool big = 2 * plan.G > s->num_cus && s->device >= 0 && s->device < 64;
+  if (big) {
+    std::lock_guard<std::mutex> lock(g_df_mutex);
+    hipEvent_t& ev = g_df_event[s->device];
+    if (ev) {
+      TMI_HIP(hipStreamWaitEvent(s->stream, ev, 0));
+    } else {
+      TMI_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    hipLaunchKernelGGL(cdf::chol_dataflow_kernel, dim3(plan.G), dim3(256), 0, s->stream, a);
+    TMI_HIP(hipEventRecord(ev, s->stream));
+  } else {
+    hipLaunchKernelGGL(cdf::chol_dataflow_kernel, dim3(plan.G), dim3(256), 0, s->stream, a);
+  }
   return TMI_BA_OK;
 }
 
@@ -2105,7 +2183,19 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
       CK(solve_reduced_dense(s, &usable));
     }
     // the PCG loop ends on a readback and launches nothing after it: the mirror is current
-    if (!(iterative && n_r > 0)) CK(readback(s));
+    if (!(iterative && n_r > 0)) {
+      CK(readback(s));
+      if (!iterative && s->h_flags[FL_CHOL_ABORT]) {
+        // the dataflow launch could not become co-resident (another process holds part of the device): clear the
+        // flag and take the launch-per-panel path for this solve
+        TMI_HIP(hipMemsetAsync(v.flags + FL_CHOL_ABORT, 0, sizeof(int), stream));
+        {
+          Timed t(s, TMI_BA_K_CHOLESKY);
+          CK(solve_reduced_dense_panels(s));
+        }
+        CK(readback(s));
+      }
+    }
     // singular track blocks are voted on by every rank (summed in the all-reduce)
     if (s->h_red[6] > 0.0 || s->h_flags[FL_SINGULAR_BLOCK]) usable = 0;
     if (need_gradient_check) {
