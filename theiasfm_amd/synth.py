@@ -171,7 +171,7 @@ def _look_at(C, target, up=np.array([0.0, 1.0, 0.0])):
 
 def make_problem(n_cameras: int, n_points: int, n_obs: int, seed: int, *,
                  scene: str = "ring", spread: float = 0.12, pixel_noise: float = 0.5,
-                 perturb: float = 1.0, models=None, shared_group_size: int = 1,
+                 perturb: float = 1.0, models=None, shared_group_size: int = 1, shared_group_sizes=None,
                  intrinsics_to_optimize: int = abi.INTRINSICS_DEFAULT, heavy_tail: float = 0.0) -> Problem:
     """Build a seeded synthetic problem.
 
@@ -179,6 +179,8 @@ def make_problem(n_cameras: int, n_points: int, n_obs: int, seed: int, *,
     scene "ring":   landmark scene with windowed visibility (configs 2-4).
     models: optional list of (camera_model, fraction); default all PINHOLE.
     shared_group_size: >1 makes consecutive cameras share an intrinsics group.
+    shared_group_sizes: (lo, hi) -- groups of consecutive cameras with sizes drawn log-uniformly from [lo, hi]
+             ("intrinsics groups of 1-200 views"; a group of one view is a private group).
     perturb: scale of the initial perturbation away from the generating
              parameters (1.0 = SURVEY 8d: points/positions 0.25 % of the scene
              depth, angle-axis 0.005 rad)."""
@@ -218,7 +220,18 @@ def make_problem(n_cameras: int, n_points: int, n_obs: int, seed: int, *,
         raise ValueError(scene)
 
     # intrinsics groups
-    if shared_group_size > 1:
+    if shared_group_sizes is not None:
+        lo, hi = shared_group_sizes
+        grng = np.random.default_rng(seed + 7919)  # its own stream: the scene does not depend on the grouping
+        camera_group = np.empty(n_cameras, dtype=np.int32)
+        c = g = 0
+        while c < n_cameras:
+            size = int(round(np.exp(grng.uniform(np.log(lo), np.log(hi)))))
+            size = max(lo, min(hi, size, n_cameras - c))
+            camera_group[c:c + size] = g
+            c += size
+            g += 1
+    elif shared_group_size > 1:
         camera_group = (np.arange(n_cameras) // shared_group_size).astype(np.int32)
     else:
         camera_group = np.arange(n_cameras, dtype=np.int32)
