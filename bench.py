@@ -540,8 +540,12 @@ def main():
                 solver.close()  # free the HBM of the resident solver first
                 solver = None
                 e2e = {}
-                for key, inner in (("inner_iterations_off", 0), ("inner_iterations_on", 1)):
-                    p = subprocess.run([exe, path, str(args.solve_length), str(inner), "2"],  # best of two: the first call of a process loads the code objects (~0.25 s)
+                # merged = 1: the device path's merged per-view preconditioner block (what the headline uses through the
+                # C ABI); merged = 0: Ceres' per-parameter-block SCHUR_JACOBI, which the shim passes by default.  Every
+                # line also carries `second_call`: the same Reconstruction adjusted again, served by the resident session.
+                for key, inner, merged in (("inner_iterations_off", 0, 1), ("inner_iterations_on", 1, 1),
+                                           ("shim_default_preconditioner_inner_off", 0, 0)):
+                    p = subprocess.run([exe, path, str(args.solve_length), str(inner), "2", str(merged)],  # best of two: the first call of a process loads the code objects (~0.25 s)
                                        capture_output=True, text=True, timeout=900)
                     try:
                         e2e[key] = json.loads(p.stdout.strip().splitlines()[-1])

@@ -66,6 +66,11 @@ class BundleAdjuster {
 
   // Extension: the flattened problem (what Optimize() sends to the device).
   bool Flatten(FlattenedBundleAdjustmentProblem* flat);
+  // Extension: Optimize() that leaves the problem resident -- the flattened arrays and the tmi_ba_solver handle
+  // (created, solved, downloaded; the caller owns both and calls tmi_ba_solver_destroy).  *solver stays nullptr when
+  // there was nothing to optimise or the device refused the problem.  BundleAdjustReconstruction keeps them for the
+  // next call on the same Reconstruction (bundle_adjustment.h, "resident session").
+  BundleAdjustmentSummary OptimizeResident(FlattenedBundleAdjustmentProblem* flat, tmi_ba_solver** solver);
   // Extension: the full device summary of the last Optimize().
   const tmi_ba_summary& DeviceSummary() const { return device_summary_; }
 

@@ -62,6 +62,16 @@ struct BundleAdjustmentOptions {
   //   4 = optimise the homogeneous point as the reference does, 3 = hold w fixed.
   int point_dof = 4;
   int device = -1;  // HIP device ordinal, -1 = current
+  //   ceres::SCHUR_JACOBI builds its block diagonal per PARAMETER block: a 6 x 6 extrinsics block and a separate
+  //   intrinsics block per view (ceres/schur_jacobi_preconditioner.cc).  That is what preconditioner_type = SCHUR_JACOBI
+  //   means here too (false).  true = ONE merged [extrinsics | private intrinsics] block per view: a strictly stronger
+  //   preconditioner at the same cost per application (several times fewer PCG iterations, the same reduced system
+  //   and stopping rule) -- the device path's fast mode, and an explicit opt-in because it is not Ceres' trajectory.
+  bool merged_view_blocks_in_preconditioner = false;
+  //   BundleAdjustReconstruction keeps the flattened problem and the device-resident solver of its last call; the next
+  //   call on the same Reconstruction with an unchanged residual set re-uses them (only parameter values travel).
+  //   false = build and free everything inside the call, as the one-shot path always did.
+  bool keep_problem_resident = true;
 };
 
 // bundle_adjustment.h:125-133
@@ -72,6 +82,10 @@ struct BundleAdjustmentSummary {
   double setup_time_in_seconds = 0.0;
   double solve_time_in_seconds = 0.0;
 };
+
+// Extensions: the resident session BundleAdjustReconstruction keeps (one per process; it holds the problem's HBM).
+void ReleaseBundleAdjustmentSession();
+bool BundleAdjustmentSessionIsResident(const Reconstruction* reconstruction);
 
 // bundle_adjustment.h:136-155
 BundleAdjustmentSummary BundleAdjustReconstruction(const BundleAdjustmentOptions& options,

@@ -28,6 +28,7 @@ class Reconstruction {
   }
   ViewId AddView(const std::string& view_name, const CameraIntrinsicsGroupId group_id) {
     if (view_name.empty() || view_name_to_id_.count(view_name)) return kInvalidViewId;
+    internal::BumpDataModelEpoch();
     class View new_view(view_name);
     auto& group = camera_intrinsics_groups_[group_id];
     if (!group.empty()) {
@@ -68,6 +69,7 @@ class Reconstruction {
   int NumCameraIntrinsicGroups() const { return static_cast<int>(camera_intrinsics_groups_.size()); }
 
   TrackId AddTrack() {
+    internal::BumpDataModelEpoch();
     class Track new_track;
     tracks_.emplace(next_track_id_, new_track);
     return next_track_id_++;
@@ -106,7 +108,11 @@ class Reconstruction {
     return ids;
   }
 
+  // Extension: identity of this object for the shim's resident-session cache (types.h)
+  std::uint64_t Uid() const { return uid_.value; }
+
  private:
+  internal::ObjectUid uid_;
   TrackId next_track_id_;
   ViewId next_view_id_;
   CameraIntrinsicsGroupId next_camera_intrinsics_group_id_;

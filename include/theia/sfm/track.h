@@ -9,12 +9,21 @@ class Track {
  public:
   Track() : is_estimated_(false) { point_[3] = 1.0; }
   int NumViews() const { return static_cast<int>(view_ids_.size()); }
-  void SetEstimated(const bool is_estimated) { is_estimated_ = is_estimated; }
+  void SetEstimated(const bool is_estimated) {
+    if (is_estimated != is_estimated_) internal::BumpDataModelEpoch();
+    is_estimated_ = is_estimated;
+  }
   bool IsEstimated() const { return is_estimated_; }
   const Eigen::Vector4d& Point() const { return point_; }
   Eigen::Vector4d* MutablePoint() { return &point_; }
-  void AddView(const ViewId view_id) { view_ids_.insert(view_id); }
-  bool RemoveView(const ViewId view_id) { return view_ids_.erase(view_id) > 0; }
+  void AddView(const ViewId view_id) {
+    internal::BumpDataModelEpoch();
+    view_ids_.insert(view_id);
+  }
+  bool RemoveView(const ViewId view_id) {
+    internal::BumpDataModelEpoch();
+    return view_ids_.erase(view_id) > 0;
+  }
   const std::unordered_set<ViewId>& ViewIds() const { return view_ids_; }
 
  private:

@@ -13,7 +13,10 @@ class View {
   View() : name_(""), is_estimated_(false) {}
   explicit View(const std::string& name) : name_(name), is_estimated_(false) {}
   const std::string& Name() const { return name_; }
-  void SetEstimated(bool is_estimated) { is_estimated_ = is_estimated; }
+  void SetEstimated(bool is_estimated) {
+    if (is_estimated != is_estimated_) internal::BumpDataModelEpoch();
+    is_estimated_ = is_estimated;
+  }
   bool IsEstimated() const { return is_estimated_; }
   const class Camera& Camera() const { return camera_; }
   class Camera* MutableCamera() { return &camera_; }
@@ -31,8 +34,14 @@ class View {
   // Extension: the (track id -> feature) table itself, for callers that walk every feature
   // (the reference's TrackIds() + GetFeature() pair costs a copy and a look-up per feature).
   const std::unordered_map<TrackId, Feature>& Features() const { return features_; }
-  void AddFeature(const TrackId track_id, const Feature& feature) { features_[track_id] = feature; }
-  bool RemoveFeature(const TrackId track_id) { return features_.erase(track_id) > 0; }
+  void AddFeature(const TrackId track_id, const Feature& feature) {
+    internal::BumpDataModelEpoch();
+    features_[track_id] = feature;
+  }
+  bool RemoveFeature(const TrackId track_id) {
+    internal::BumpDataModelEpoch();
+    return features_.erase(track_id) > 0;
+  }
 
  private:
   std::string name_;

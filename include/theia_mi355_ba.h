@@ -343,7 +343,11 @@ int32_t tmi_ba_solve(tmi_ba_problem* problem, const tmi_ba_options* options,
  *              upload.  `rank`/`world` select the contiguous shard of tracks
  *              this process owns (0/1 for single GPU).
  *   solve    : run LM on the resident parameters (may be called repeatedly).
- *   reset    : restore the parameters uploaded at create time.
+ *   reset    : restore the parameters uploaded at create time (or by the last set_parameters).
+ *   set_parameters : new values of extrinsics / intrinsics / points for the SAME residual set and
+ *              constancy flags (the caller moved cameras or re-triangulated tracks between two
+ *              BAs): uploads them and makes them what `reset` restores; the structure, the
+ *              layouts and every buffer stay resident.
  *   download : copy the current parameters into the caller's in/out arrays.  */
 int32_t tmi_ba_solver_create(const tmi_ba_problem* problem,
                              const tmi_ba_options* options, int32_t rank,
@@ -367,6 +371,7 @@ int32_t tmi_ba_solver_debug_allreduce(tmi_ba_solver* s, double value, double* ou
 int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* options,
                             tmi_ba_summary* summary);
 int32_t tmi_ba_solver_reset(tmi_ba_solver* s);
+int32_t tmi_ba_solver_set_parameters(tmi_ba_solver* s, const tmi_ba_problem* problem);
 int32_t tmi_ba_solver_download(tmi_ba_solver* s, tmi_ba_problem* problem);
 /* The HIP stream the engine launches on (so callers can record their own
  * events on it). */

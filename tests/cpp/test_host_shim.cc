@@ -195,6 +195,25 @@ static void TestSemantics() {
   // option defaults (bundle_adjustment.h:78-122)
   EXPECT(opt.max_num_iterations == 100 && opt.use_inner_iterations && opt.robust_loss_width == 2.0);
   EXPECT(opt.linear_solver_type == ceres::SPARSE_SCHUR && opt.preconditioner_type == ceres::SCHUR_JACOBI);
+  // what the shim hands the device for the reference's default preconditioner: Ceres' block shape (one block per
+  // parameter block, schur_jacobi_preconditioner.cc); the merged per-view block only when asked for; IDENTITY as is
+  {
+    tmi_ba_options o;
+    BundleAdjustmentOptions d;
+    ToDeviceOptions(d, &o);
+    EXPECT(o.preconditioner_type == TMI_BA_PRECOND_SCHUR_JACOBI_PARAMETER_BLOCKS);
+    d.preconditioner_type = ceres::CLUSTER_JACOBI;
+    ToDeviceOptions(d, &o);
+    EXPECT(o.preconditioner_type == TMI_BA_PRECOND_SCHUR_JACOBI_PARAMETER_BLOCKS);
+    d.preconditioner_type = ceres::SCHUR_JACOBI;
+    d.merged_view_blocks_in_preconditioner = true;
+    ToDeviceOptions(d, &o);
+    EXPECT(o.preconditioner_type == TMI_BA_PRECOND_SCHUR_JACOBI);
+    d.preconditioner_type = ceres::IDENTITY;
+    ToDeviceOptions(d, &o);
+    EXPECT(o.preconditioner_type == TMI_BA_PRECOND_IDENTITY);
+    EXPECT(o.use_inner_iterations == 1 && o.point_dof == 4 && o.max_num_iterations == 100);
+  }
 }
 
 static double Rmse(const BundleAdjuster& ba) { return ba.DeviceSummary().final_rmse; }
@@ -265,6 +284,81 @@ static void TestGpu() {
     const BundleAdjustmentSummary st2 = BundleAdjustTrack(opt, 111, &rec);
     EXPECT(sv2.success && st2.success);
   }
+}
+
+// The resident session of BundleAdjustReconstruction: a second call on the same Reconstruction re-uses the
+// flattened problem and the device handle, and must give exactly what a from-scratch call gives; anything that can
+// change the residual set drops the session.
+static void TestResidentSessionGpu() {
+  BundleAdjustmentOptions opt;
+  opt.linear_solver_type = ceres::ITERATIVE_SCHUR;
+  opt.max_num_iterations = 4;  // stop early so that the second call still has work to do
+  opt.function_tolerance = -1.0;
+  opt.gradient_tolerance = -1.0;
+  opt.parameter_tolerance = -1.0;
+  auto snapshot = [](const Reconstruction& r) {
+    std::vector<double> v;
+    for (ViewId id = 0; id < (ViewId)r.NumViews(); ++id)
+      for (int a = 0; a < 6; ++a) v.push_back(r.View(id)->Camera().extrinsics()[a]);
+    for (TrackId id = 0; id < (TrackId)r.NumTracks(); ++id)
+      for (int a = 0; a < 4; ++a) v.push_back(r.Track(id)->Point()[a]);
+    for (ViewId id = 0; id < (ViewId)r.NumViews(); ++id)
+      for (int a = 0; a < 7; ++a) v.push_back(r.View(id)->Camera().intrinsics()[a]);
+    return v;
+  };
+  for (const bool shared : {false, true}) {
+    ReleaseBundleAdjustmentSession();
+    // A: two calls through the session.  B: the same two calls with the session switched off.
+    Reconstruction A, B;
+    BuildScene(&A, 7, 260, shared, 31, 0.3);
+    BuildScene(&B, 7, 260, shared, 31, 0.3);
+    BundleAdjustmentOptions one_shot = opt;
+    one_shot.keep_problem_resident = false;
+    const BundleAdjustmentSummary a1 = BundleAdjustReconstruction(opt, &A);
+    EXPECT(a1.success && BundleAdjustmentSessionIsResident(&A));
+    const BundleAdjustmentSummary a2 = BundleAdjustReconstruction(opt, &A);
+    EXPECT(a2.success && BundleAdjustmentSessionIsResident(&A));
+    const BundleAdjustmentSummary b1 = BundleAdjustReconstruction(one_shot, &B);
+    const BundleAdjustmentSummary b2 = BundleAdjustReconstruction(one_shot, &B);
+    EXPECT(b1.success && b2.success && !BundleAdjustmentSessionIsResident(&B));
+    EXPECT(a1.final_cost == b1.final_cost && a2.initial_cost == b2.initial_cost && a2.final_cost == b2.final_cost);
+    EXPECT(a2.final_cost < a2.initial_cost);
+    EXPECT(snapshot(A) == snapshot(B));  // bit for bit
+    std::printf("resident session (%s intrinsics): first %.6e -> %.6e, second %.6e -> %.6e, one-shot second %.6e -> %.6e\n",
+                shared ? "shared" : "private", a1.initial_cost, a1.final_cost, a2.initial_cost, a2.final_cost,
+                b2.initial_cost, b2.final_cost);
+    // parameter VALUES may change between calls (re-triangulation, a pose refinement): picked up
+    (*A.MutableTrack(5)->MutablePoint())[0] += 0.05;
+    (*B.MutableTrack(5)->MutablePoint())[0] += 0.05;
+    A.MutableView(2)->MutableCamera()->mutable_extrinsics()[1] += 0.01;
+    B.MutableView(2)->MutableCamera()->mutable_extrinsics()[1] += 0.01;
+    EXPECT(BundleAdjustmentSessionIsResident(&A));
+    const BundleAdjustmentSummary a3 = BundleAdjustReconstruction(opt, &A);
+    const BundleAdjustmentSummary b3 = BundleAdjustReconstruction(one_shot, &B);
+    EXPECT(a3.success && a3.initial_cost == b3.initial_cost && a3.final_cost == b3.final_cost && snapshot(A) == snapshot(B));
+    // the residual set changes: the session must go
+    A.MutableTrack(9)->SetEstimated(false);
+    B.MutableTrack(9)->SetEstimated(false);
+    EXPECT(!BundleAdjustmentSessionIsResident(&A));
+    const double frozen = A.Track(9)->Point()[2];
+    const BundleAdjustmentSummary a4 = BundleAdjustReconstruction(opt, &A);
+    const BundleAdjustmentSummary b4 = BundleAdjustReconstruction(one_shot, &B);
+    EXPECT(a4.success && a4.final_cost == b4.final_cost && A.Track(9)->Point()[2] == frozen);
+    EXPECT(BundleAdjustmentSessionIsResident(&A));
+    // other problem-shaping options: rebuilt, not served from the session
+    BundleAdjustmentOptions other = opt;
+    other.constant_camera_position = true;
+    BundleAdjustmentOptions other_one_shot = other;
+    other_one_shot.keep_problem_resident = false;
+    const Eigen::Vector3d pos = A.View(1)->Camera().GetPosition();
+    const BundleAdjustmentSummary a5 = BundleAdjustReconstruction(other, &A);
+    const BundleAdjustmentSummary b5 = BundleAdjustReconstruction(other_one_shot, &B);
+    EXPECT(a5.success && a5.final_cost == b5.final_cost && A.View(1)->Camera().GetPosition()[0] == pos[0]);
+    // a copy is a different object even though it starts out identical
+    Reconstruction C = A;
+    EXPECT(!BundleAdjustmentSessionIsResident(&C));
+  }
+  ReleaseBundleAdjustmentSession();
 }
 
 // SetOutlierTracksToUnestimated (set_outlier_tracks_to_unestimated.cc:62-133) and the batched
@@ -488,6 +582,7 @@ int main(int argc, char** argv) {
   TestSemantics();
   if (mode == "gpu") {
     TestGpu();
+    TestResidentSessionGpu();
     TestTrackOpsGpu();
     TestTwoViewsGpu();
     TestTwoViewsAngularGpu();

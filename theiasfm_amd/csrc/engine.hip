@@ -1492,6 +1492,35 @@ int32_t tmi_ba_solver_reset(tmi_ba_solver* s) {
   return TMI_BA_OK;
 }
 
+// New parameter values for the resident problem (same structure): what `reset` restores from then on.
+int32_t tmi_ba_solver_set_parameters(tmi_ba_solver* s, const tmi_ba_problem* P) {
+  if (!s || !P) return TMI_BA_ERR_INVALID_ARGUMENT;
+  const Structure& st = s->st;
+  if (P->num_cameras != st.Nc || P->num_points != st.Np_total || P->num_groups != st.G ||
+      (st.G && P->group_offset[st.G] != s->n_intr) || (st.Nc && !P->extrinsics) || (st.Np_total && !P->points) ||
+      (s->n_intr && !P->intrinsics)) {
+    s->error = "set_parameters: the problem does not have the shape the solver was created with";
+    return TMI_BA_ERR_INVALID_ARGUMENT;
+  }
+  TMI_HIP(hipSetDevice(s->device));
+  if (st.Nc) s->ext0.assign(P->extrinsics, P->extrinsics + (size_t)6 * st.Nc);
+  if (s->n_intr) s->intr0.assign(P->intrinsics, P->intrinsics + s->n_intr);
+  for (int lp = 0; lp < st.Np_pad; ++lp) {
+    const int p = st.pt_orig[lp];
+    if (p < 0) continue;
+    for (int a = 0; a < 4; ++a) s->pts0[(size_t)4 * lp + a] = P->points[(size_t)4 * p + a];
+  }
+  if (s->d_ext0) {
+    if (!s->ext0.empty())
+      TMI_HIP(hipMemcpyAsync(s->d_ext0, s->ext0.data(), s->ext0.size() * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    if (!s->intr0.empty())
+      TMI_HIP(hipMemcpyAsync(s->d_intr0, s->intr0.data(), s->intr0.size() * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    if (!s->pts0.empty())
+      TMI_HIP(hipMemcpyAsync(s->d_pts0, s->pts0.data(), s->pts0.size() * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  }
+  return tmi_ba_solver_reset(s);
+}
+
 int32_t tmi_ba_solver_download(tmi_ba_solver* s, tmi_ba_problem* P) {
   if (!s || !P) return TMI_BA_ERR_INVALID_ARGUMENT;
   if (P->num_cameras != s->st.Nc || P->num_points != s->st.Np_total) return TMI_BA_ERR_INVALID_ARGUMENT;

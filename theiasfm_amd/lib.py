@@ -24,7 +24,7 @@ EXPORTS = (
     "tmi_ba_options_init",
     "tmi_ba_intrinsics_size", "tmi_ba_intrinsics_constant_mask", "tmi_ba_solve",
     "tmi_ba_solver_create", "tmi_ba_solver_set_allreduce", "tmi_ba_solver_solve",
-    "tmi_ba_solver_reset", "tmi_ba_solver_download", "tmi_ba_solver_stream",
+    "tmi_ba_solver_reset", "tmi_ba_solver_set_parameters", "tmi_ba_solver_download", "tmi_ba_solver_stream",
     "tmi_ba_solver_destroy", "tmi_ba_solver_evaluate", "tmi_ba_structure_stats",
     "tmi_ba_rccl_unique_id", "tmi_ba_solver_init_rccl", "tmi_ba_solver_debug_allreduce",
     "tmi_ba_solver_filter_outlier_tracks", "tmi_ba_filter_outlier_tracks",
@@ -81,6 +81,8 @@ def load():
     L.tmi_ba_solver_solve.restype = C.c_int32
     L.tmi_ba_solver_reset.argtypes = [C.c_void_p]
     L.tmi_ba_solver_reset.restype = C.c_int32
+    L.tmi_ba_solver_set_parameters.argtypes = [C.c_void_p, C.c_void_p]
+    L.tmi_ba_solver_set_parameters.restype = C.c_int32
     L.tmi_ba_solver_download.argtypes = [C.c_void_p, P]
     L.tmi_ba_solver_download.restype = C.c_int32
     L.tmi_ba_solver_stream.argtypes = [C.c_void_p]
@@ -330,6 +332,14 @@ class Solver:
         st = self._L.tmi_ba_solver_reset(self._h)
         if st != 0:
             raise EngineError(st, "tmi_ba_solver_reset")
+
+    def set_parameters(self, prob: abi.Problem):
+        """new extrinsics / intrinsics / points for the resident structure (what reset() restores from then on)"""
+        self._keep = prob  # the C view points into its arrays
+        cp = prob.as_c()
+        st = self._L.tmi_ba_solver_set_parameters(self._h, C.byref(cp))
+        if st != 0:
+            raise EngineError(st, "tmi_ba_solver_set_parameters")
 
     def download(self):
         st = self._L.tmi_ba_solver_download(self._h, C.byref(self._cp))
