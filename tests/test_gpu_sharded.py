@@ -219,19 +219,29 @@ def test_native_rccl_transport_single_rank():
     sv.close()
 
 
-@pytest.mark.parametrize("mode", [abi.SCHUR_EXPLICIT, abi.SCHUR_AUTO])
-def test_two_processes_one_gpu(mode):
+@pytest.mark.parametrize("mode,solver,inner,shared", [
+    (abi.SCHUR_EXPLICIT, abi.ITERATIVE_SCHUR, 0, 0), (abi.SCHUR_AUTO, abi.ITERATIVE_SCHUR, 0, 0),
+    (abi.SCHUR_EXPLICIT, abi.ITERATIVE_SCHUR, 1, 0), (abi.SCHUR_AUTO, abi.ITERATIVE_SCHUR, 1, 0),
+    (abi.SCHUR_AUTO, abi.DENSE_SCHUR, 1, 0), (abi.SCHUR_AUTO, abi.ITERATIVE_SCHUR, 1, 1),
+    (abi.SCHUR_EXPLICIT, abi.ITERATIVE_SCHUR, 0, 1)])
+def test_two_processes_one_gpu(mode, solver, inner, shared):
     """Real separate processes (RANK / WORLD_SIZE from the environment, as torchrun sets
     them), each owning its shard of the tracks; they share cuda:0 so the sums travel
-    through gloo instead of RCCL.  AUTO picks the implicit operator for world > 1."""
-    prob = synth.config("ladybug49")
+    through gloo (host-staged hook) instead of RCCL.  AUTO picks the implicit operator for world > 1.
+    Both Schur operators, the exact solver, inner iterations (their per-view sums are all-reduced as well) and
+    shared intrinsics blocks; every rank must end where the single-rank solve ends."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import mp_sharded_worker as worker
+    prob = worker.problem(shared)
     single = prob.copy()
-    st, s1 = lib.solve(single, abi.default_options(linear_solver_type=abi.ITERATIVE_SCHUR, point_dof=3,
-                                                   use_inner_iterations=0))
+    st, s1 = lib.solve(single, worker.options(mode if solver != abi.ITERATIVE_SCHUR or mode == abi.SCHUR_EXPLICIT else abi.SCHUR_IMPLICIT,
+                                              solver, inner))
     assert st == 0
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29540 + mode), WORLD_SIZE="2")
-    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "mp_sharded_worker.py"), str(mode)],
+    port = 29540 + mode + 4 * inner + 8 * shared + (16 if solver != abi.ITERATIVE_SCHUR else 0)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "mp_sharded_worker.py"), str(mode), str(solver),
+                               str(inner), str(shared)],
                               env=dict(env, RANK=str(r), LOCAL_RANK="0"), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=600)[0] for p in procs]
@@ -239,8 +249,11 @@ def test_two_processes_one_gpu(mode):
     res = [json.loads([ln for ln in o.splitlines() if ln.startswith("RESULT ")][0][7:]) for o in outs]
     for r in res:
         assert r["status"] == 0 and r["iters"] == s1.num_iterations
+        assert r["pcg"] == s1.num_linear_solver_iterations and r["inner_sweeps"] == s1.num_inner_iteration_steps
         assert abs(r["cost"] - s1.final_cost) <= 1e-9 * s1.final_cost
         assert abs(r["rmse"] - s1.final_rmse) <= 1e-9
-        assert np.abs(np.array(r["ext0"]) - single.extrinsics[0]).max() < 1e-6 * 100.0
-        assert (r["pairs"] == 0) == (mode == abi.SCHUR_AUTO)
-    assert res[0]["cost"] == res[1]["cost"] and res[0]["ext0"] == res[1]["ext0"]
+        assert np.abs(np.array(r["ext"]) - single.extrinsics).max() < 1e-6 * 100.0
+        assert np.abs(np.array(r["intr"]) - single.intrinsics).max() < 1e-6 * max(1.0, np.abs(single.intrinsics).max())
+        if solver == abi.ITERATIVE_SCHUR:
+            assert (r["pairs"] == 0) == (mode == abi.SCHUR_AUTO)
+    assert res[0]["cost"] == res[1]["cost"] and res[0]["ext"] == res[1]["ext"]
