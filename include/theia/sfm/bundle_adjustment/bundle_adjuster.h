@@ -108,16 +108,21 @@ class BundleAdjuster {
    public:
     // -1 = absent
     int Get(uint32_t id) const {
-      if (id < flat_.size()) return flat_[id];
+      if (id < flat_.size() && flat_[id] >= 0) return flat_[id];
+      if (sparse_.empty()) return -1;  // (an id hashed earlier can lie below a table that grew since)
       auto it = sparse_.find(id);
       return it == sparse_.end() ? -1 : it->second;
     }
     void Set(uint32_t id, int value) {
-      if (id < kFlatLimit) {
+      // flat while the table stays dense enough (at most ~8 slots per id on top of a 1 M floor), hashed beyond
+      if (id < kFlatLimit && !sparse_.count(id) &&
+          (id < flat_.size() || static_cast<uint64_t>(id) <= 8ull * (count_ + 1) + (1u << 20))) {
         if (id >= flat_.size()) flat_.resize(static_cast<size_t>(id) + 1 + flat_.size() / 2, -1);
+        if (flat_[id] < 0) ++count_;
         flat_[id] = static_cast<int16_t>(value);
       } else {
-        sparse_[id] = static_cast<int16_t>(value);
+        if (sparse_.emplace(id, static_cast<int16_t>(value)).second) ++count_;
+        else sparse_[id] = static_cast<int16_t>(value);
       }
     }
     void SetIfAbsent(uint32_t id, int value) {
@@ -125,8 +130,11 @@ class BundleAdjuster {
     }
     // make ids 0..max_id flat-addressable up front (so that concurrent readers never see a resize);
     // false if max_id is beyond the flat range
-    bool Reserve(uint32_t max_id) {
+    // ... or so far above the number of ids that a dense table would be mostly holes (sub-reconstructions, merged
+    // id spaces): the caller then takes the hash-map path, O(#ids) memory
+    bool Reserve(uint32_t max_id, size_t num_ids = SIZE_MAX) {
       if (max_id >= kFlatLimit) return false;
+      if (num_ids != SIZE_MAX && static_cast<uint64_t>(max_id) > 8ull * num_ids + (1u << 20)) return false;
       if (max_id >= flat_.size()) flat_.resize(static_cast<size_t>(max_id) + 1, -1);
       return true;
     }
@@ -135,6 +143,7 @@ class BundleAdjuster {
 
    private:
     static constexpr uint32_t kFlatLimit = 1u << 27;
+    size_t count_ = 0;  // ids present
     std::vector<int16_t> flat_;
     std::unordered_map<uint32_t, int16_t> sparse_;
   };

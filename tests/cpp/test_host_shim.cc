@@ -3,6 +3,7 @@
 //   ./test_host_shim gpu   end-to-end BundleAdjustReconstruction / partial BA
 // The expectations restate the AddView / AddTrack rules of
 // /root/reference/src/theia/sfm/bundle_adjustment/bundle_adjuster.cc:102-180,242-287.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -191,6 +192,31 @@ static void TestSemantics() {
     EXPECT(f.obs_camera.empty());
     const BundleAdjustmentSummary s = ba.Optimize();
     EXPECT(s.success);
+  }
+  {
+    // an estimated view none of whose tracks is estimated: its parameter blocks never enter the reference's
+    // ceres::Problem (they are added by AddReprojectionErrorResidual only) -- it must not become a camera block
+    Reconstruction rec;
+    BuildScene(&rec, 4, 20, /*share_groups=*/false, 3, 0.0);
+    const ViewId lonely = rec.AddView("lonely");
+    rec.MutableView(lonely)->SetEstimated(true);
+    const TrackId t = rec.AddTrack();  // stays un-estimated
+    rec.AddObservation(lonely, t, Feature(1.0, 2.0));
+    rec.AddObservation(0, t, Feature(3.0, 4.0));
+    for (const bool bulk : {false, true}) {
+      BundleAdjuster ba(opt, &rec);
+      if (bulk) {
+        ba.AddViews(rec.ViewIds());
+        ba.AddTracks(rec.TrackIds());
+      } else {
+        for (ViewId v : rec.ViewIds()) ba.AddView(v);
+        for (TrackId tr : rec.TrackIds()) ba.AddTrack(tr);
+      }
+      FlattenedBundleAdjustmentProblem f;
+      EXPECT(ba.Flatten(&f));
+      EXPECT(f.view_ids.size() == 4 && std::find(f.view_ids.begin(), f.view_ids.end(), lonely) == f.view_ids.end());
+      EXPECT(f.track_ids.size() == 20 && f.obs_camera.size() == 80);
+    }
   }
   // option defaults (bundle_adjustment.h:78-122)
   EXPECT(opt.max_num_iterations == 100 && opt.use_inner_iterations && opt.robust_loss_width == 2.0);

@@ -128,7 +128,7 @@ void BundleAdjuster::AddViews(const std::vector<ViewId>& view_ids) {
   if (flat_ok) {
     all_tracks = reconstruction_->TrackIds();
     for (const TrackId t : all_tracks) max_track = std::max<uint32_t>(max_track, t);
-    flat_ok = track_estimated_.Reserve(max_track) && track_constant_.Reserve(max_track);
+    flat_ok = track_estimated_.Reserve(max_track, all_tracks.size()) && track_constant_.Reserve(max_track, all_tracks.size());
   }
   if (!flat_ok) {
     for (const ViewId v : view_ids) AddView(v);
@@ -196,8 +196,8 @@ void BundleAdjuster::AddTracks(const std::vector<TrackId>& track_ids) {
   uint32_t max_track = 0;
   for (const TrackId t : track_ids) max_track = std::max<uint32_t>(max_track, t);
   // one-at-a-time for subclasses (their hooks must see every call) and for ids beyond the flat tables
-  if (typeid(*this) != typeid(BundleAdjuster) || !track_optimized_.Reserve(max_track) ||
-      !track_constant_.Reserve(max_track)) {
+  if (typeid(*this) != typeid(BundleAdjuster) || !track_optimized_.Reserve(max_track, track_ids.size()) ||
+      !track_constant_.Reserve(max_track, track_ids.size())) {
     for (const TrackId t : track_ids) AddTrack(t);
     return;
   }
@@ -287,7 +287,8 @@ std::vector<uint32_t> BundleAdjuster::IdState::Ids() const {
   if (!sparse_.empty()) {
     const size_t first = ids.size();
     for (const auto& kv : sparse_) ids.push_back(kv.first);
-    std::sort(ids.begin() + first, ids.end());  // sparse ids are all above the flat range
+    std::sort(ids.begin() + first, ids.end());
+    std::inplace_merge(ids.begin(), ids.begin() + first, ids.end());  // a hashed id can lie below a table that grew since
   }
   return ids;
 }
@@ -346,10 +347,24 @@ bool BundleAdjuster::Flatten(FlattenedBundleAdjustmentProblem* f) {
   IdIndex<TrackId> pt_index;
   IdIndex<CameraIntrinsicsGroupId> grp_index;
   {
-    // every view / track of a residual went through AddReprojectionErrorResidual, which
-    // registered it in the state tables: their ids, ascending
+    // every view / track of a residual is registered in the state tables: their ids, ascending.  AddView registers
+    // its view up front, so an estimated view none of whose tracks is estimated sits in the table without a
+    // residual; in the reference its parameter blocks never enter the ceres::Problem (bundle_adjuster.cc:373-386
+    // is the only place that adds them) -- it is dropped here
     std::vector<ViewId> v = camera_flags_.Ids();
     std::vector<TrackId> t = track_constant_.Ids();
+    if (!v.empty()) {
+      std::vector<uint8_t> seen;
+      std::unordered_set<ViewId> seen_sparse;
+      const bool compact = static_cast<uint64_t>(v.back()) < 8ull * v.size() + (1u << 20);
+      if (compact) seen.assign(static_cast<size_t>(v.back()) + 1, 0);
+      for (const Residual& r : residuals_) {
+        if (compact) seen[r.view] = 1;
+        else seen_sparse.insert(r.view);
+      }
+      v.erase(std::remove_if(v.begin(), v.end(), [&](ViewId id) { return compact ? !seen[id] : !seen_sparse.count(id); }),
+              v.end());
+    }
     cam_index.Build(&v);
     pt_index.Build(&t);
     std::vector<CameraIntrinsicsGroupId> g;

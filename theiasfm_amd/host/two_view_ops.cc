@@ -21,18 +21,24 @@ std::vector<BundleAdjustmentSummary> BundleAdjustTwoViewsBatch(std::vector<TwoVi
   std::vector<uint8_t> c1(P), c2(P);
   std::vector<int64_t> ptr(P + 1, 0);
   std::vector<char> valid(P, 0);
+  // point_dof / device of the batch: those of its first VALID problem; a problem that asks for others is reported as
+  // failed instead of being solved with options it did not ask for (split such a batch)
   int point_dof = 4, device = -1;
+  bool have_options = false;
   for (size_t p = 0; p < P; ++p) {
     const TwoViewBundleAdjustmentProblem& q = (*problems)[p];
     ptr[p + 1] = ptr[p];
     // the reference CHECK-fails on null arguments / a size mismatch; the shim reports failure
     if (!q.camera1 || !q.camera2 || !q.points3d || !q.correspondences || q.points3d->size() != q.correspondences->size())
       continue;
-    valid[p] = 1;
-    if (p == 0) {
+    if (!have_options) {
       point_dof = q.options.ba_options.point_dof;
       device = q.options.ba_options.device;
+      have_options = true;
+    } else if (q.options.ba_options.point_dof != point_dof || q.options.ba_options.device != device) {
+      continue;
     }
+    valid[p] = 1;
     for (int a = 0; a < 6; ++a) {
       e1[6 * p + a] = q.camera1->extrinsics()[a];
       e2[6 * p + a] = q.camera2->extrinsics()[a];
