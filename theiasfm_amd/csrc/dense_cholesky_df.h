@@ -26,6 +26,10 @@
 
 #include "device_view.h"
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "the flag hand-over below (write-through stores + s_waitcnt, no fences) is validated for gfx950 only"
+#endif
+
 namespace tmi {
 namespace cdf {
 

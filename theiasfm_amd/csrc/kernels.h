@@ -93,6 +93,14 @@ __device__ __forceinline__ double wave_max(double v) {
 // (s_waitcnt, no cache maintenance).  Anything bigger than a handful of scalars per workgroup
 // must cross a kernel boundary instead.
 // ------------------------------------------------------------------------------
+// HARDWARE ASSUMPTION (gfx950): an agent-scope relaxed atomic store is a write-through store (sc1) and is complete --
+// visible to agent-scope atomic loads from any XCD -- once s_waitcnt vmcnt(0) has drained it, which the workgroup-scope
+// release before the ticket does.  The HIP memory model does not promise that ordering across workgroups; another
+// target (or the threadgroup-split mode) would need an agent-scope release on the ticket instead.  Refuse to build
+// for anything else rather than corrupt cost / gradient / dot-product scalars silently.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "the fence-free grid hand-over of kernels.h / dense_cholesky_df.h is validated for gfx950 only"
+#endif
 __device__ __forceinline__ void st_agent(double* p, double v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
