@@ -979,6 +979,73 @@ static int solve_pcg(ost* s) {
     free(Minv);
     return 0;
   }
+  /* CLUSTER_JACOBI (ceres::CLUSTER_JACOBI, bundle_adjustment.h:87-89) on a problem with shared intrinsics blocks: Ceres
+   * clusters the cameras by visibility and inverts the block diagonal of S over the clusters exactly; here a cluster
+   * is a shared intrinsics block together with the views that share it (theia_mi355_ba.h) -- the principal submatrix
+   * of S over {views of g, g}, factored densely (Cholesky), views of private groups keep their own block.  A
+   * cluster whose matrix is not positive definite falls back to its diagonal blocks. */
+  const int clustered = s->O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_JACOBI ||
+                        s->O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_TRIDIAGONAL;
+  int ncl = 0;
+  int* cl_ptr = NULL;     /* [ncl + 1] into cl_rb */
+  int* cl_rb = NULL;      /* member reduced blocks: the views of the group ascending, then the group's block */
+  int* cl_ok = NULL;
+  double** cl_L = NULL;   /* dense lower factors */
+  int* cl_n = NULL;
+  if (clustered) {
+    cl_ptr = (int*)calloc((size_t)s->G + 2, sizeof(int));
+    cl_rb = (int*)malloc(sizeof(int) * (size_t)(s->Nc + s->G + 1));
+    cl_ok = (int*)calloc((size_t)s->G + 1, sizeof(int));
+    cl_L = (double**)calloc((size_t)s->G + 1, sizeof(double*));
+    cl_n = (int*)calloc((size_t)s->G + 1, sizeof(int));
+    for (int g = 0; g < s->G; ++g) {
+      if (s->grp_rb[g] < 0) continue;
+      int m = cl_ptr[ncl];
+      for (int c = 0; c < s->Nc; ++c)
+        if (s->P->camera_group[c] == g && s->cam_rb[c] >= 0) cl_rb[m++] = s->cam_rb[c];
+      cl_rb[m++] = s->grp_rb[g];
+      cl_ptr[ncl + 1] = m;
+      int nc = 0;
+      for (int a = cl_ptr[ncl]; a < m; ++a) nc += s->rb_dim[cl_rb[a]];
+      cl_n[ncl] = nc;
+      double* C = (double*)calloc((size_t)nc * nc, sizeof(double));
+      int oi = 0;
+      for (int a = cl_ptr[ncl]; a < m; ++a) {
+        const int bi = cl_rb[a], ni = s->rb_dim[bi];
+        int oj = 0;
+        for (int bb = cl_ptr[ncl]; bb <= a; ++bb) {
+          const int bj = cl_rb[bb], nj = s->rb_dim[bj];
+          const int64_t q = block_lookup(s, bi, bj);
+          if (q >= 0) {
+            const double* B = s->S + s->blk_off[q];
+            for (int i = 0; i < ni; ++i)
+              for (int j = 0; j < nj; ++j) C[(int64_t)(oi + i) * nc + oj + j] = B[i * nj + j];
+          }
+          oj += nj;
+        }
+        oi += ni;
+      }
+      /* in-place lower Cholesky */
+      int pd = 1;
+      for (int j = 0; j < nc && pd; ++j) {
+        double* Cj = C + (int64_t)j * nc;
+        double d = Cj[j];
+        for (int k = 0; k < j; ++k) d -= Cj[k] * Cj[k];
+        if (!(d > 0.0) || !isfinite(d)) { pd = 0; break; }
+        const double ljj = sqrt(d);
+        Cj[j] = ljj;
+        for (int i = j + 1; i < nc; ++i) {
+          double* Ci = C + (int64_t)i * nc;
+          double v = Ci[j];
+          for (int k = 0; k < j; ++k) v -= Ci[k] * Cj[k];
+          Ci[j] = v / ljj;
+        }
+      }
+      cl_ok[ncl] = pd;
+      cl_L[ncl] = C;
+      ++ncl;
+    }
+  }
   const double* bref = s->rhs;
   memset(x, 0, sizeof(double) * (size_t)n);
   memcpy(r, bref, sizeof(double) * (size_t)n); /* r = b - A*0 */
@@ -1000,6 +1067,33 @@ static int solve_pcg(ost* s) {
         double v = 0.0;
         for (int c = 0; c < nb; ++c) v += M[a * nb + c] * r[off + c];
         z[off + a] = v;
+      }
+    }
+    for (int c = 0; c < ncl; ++c) {
+      if (!cl_ok[c]) continue;
+      const int nc = cl_n[c];
+      const double* L = cl_L[c];
+      double* y = tmp; /* scratch (free between the residual resets) */
+      int o = 0;
+      for (int a = cl_ptr[c]; a < cl_ptr[c + 1]; ++a) {
+        const int b = cl_rb[a];
+        for (int i = 0; i < s->rb_dim[b]; ++i) y[o++] = r[s->rb_off[b] + i];
+      }
+      for (int i = 0; i < nc; ++i) {
+        double v = y[i];
+        const double* Li = L + (int64_t)i * nc;
+        for (int k = 0; k < i; ++k) v -= Li[k] * y[k];
+        y[i] = v / Li[i];
+      }
+      for (int i = nc - 1; i >= 0; --i) {
+        double v = y[i];
+        for (int k = i + 1; k < nc; ++k) v -= L[(int64_t)k * nc + i] * y[k];
+        y[i] = v / L[(int64_t)i * nc + i];
+      }
+      o = 0;
+      for (int a = cl_ptr[c]; a < cl_ptr[c + 1]; ++a) {
+        const int b = cl_rb[a];
+        for (int i = 0; i < s->rb_dim[b]; ++i) z[s->rb_off[b] + i] = y[o++];
       }
     }
     const double last_rho = rho;
@@ -1036,6 +1130,8 @@ static int solve_pcg(ost* s) {
   s->pcg_iters += it;
   free(r);
   free(Minv);
+  for (int c = 0; c < ncl; ++c) free(cl_L[c]);
+  free(cl_ptr); free(cl_rb); free(cl_ok); free(cl_L); free(cl_n);
   return ok;
 }
 

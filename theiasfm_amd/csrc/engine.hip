@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -24,6 +25,7 @@
 #include "../../include/theia_mi355_ba.h"
 #include "dense_cholesky.h"
 #include "dense_cholesky_df.h"
+#include "cluster_precond.h"
 #include "kernels.h"
 #include "track_kernels.h"
 #include "inner_kernels.h"
@@ -68,6 +70,8 @@ struct Launch {
   void (*expand_scale)(const DeviceView&, hipStream_t);
   void (*expand)(const DeviceView&, hipStream_t, RedLayout, double, double, double, int want_gmax);
   void (*precond)(const DeviceView&, hipStream_t, int);
+  void (*cluster_gather)(hipStream_t, const clp::GatherEntry*, int, const clp::ClusterDesc*, const double*, const double*, double*);
+  void (*cluster_rz)(const DeviceView&, hipStream_t, int, double*);
   // dot: the product kernel also leaves x . y at y[Nrb D]; spec: return at once if PCG stopped
   void (*spmv)(const DeviceView&, hipStream_t, const double*, const double*, double*, int dot, int spec);
   void (*implicit_spmv)(const DeviceView&, hipStream_t, RedLayout, const double*, double*, double*,
@@ -154,6 +158,13 @@ Launch make_launch(bool fp32) {
     if (n2)
       hipLaunchKernelGGL((finish_diag_kernel<D>), dim3((n2 + 255) / 256), dim3(256), 0, st, v, R, ir,
                          lo, hi, want_gmax);
+  };
+  L.cluster_gather = [](hipStream_t st, const clp::GatherEntry* ge, int n, const clp::ClusterDesc* desc, const double* ub,
+                        const double* Sdiag, double* tiles) {
+    if (n) hipLaunchKernelGGL((clp::cluster_gather_kernel<D>), dim3((n + 3) / 4), dim3(256), 0, st, ge, n, desc, ub, Sdiag, tiles);
+  };
+  L.cluster_rz = [](const DeviceView& v, hipStream_t st, int nb, double* partial) {
+    hipLaunchKernelGGL((clp::cluster_rz_kernel<D>), dim3(nb), dim3(256), 0, st, v, nb, partial);
   };
   L.precond = [](const DeviceView& v, hipStream_t st, int mode) {
     if (v.Nrb) hipLaunchKernelGGL((precond_invert_kernel<D>), dim3(v.Nrb), dim3(64), 0, st, v, mode);
@@ -302,6 +313,16 @@ struct tmi_ba_solver {
   int* d_df_flags = nullptr;
   int df_epoch = 0;
   int num_cus = 0;
+  // CLUSTER_JACOBI over the shared intrinsics blocks (cluster_precond.h)
+  clp::Plan cl_plan;
+  bool cl_built = false;      // plan + device buffers exist
+  bool cl_active = false;     // the current LM iteration's PCG applies it
+  clp::ClusterDesc* d_cl_desc = nullptr;
+  clp::GatherEntry* d_cl_ge = nullptr;
+  int* d_cl_idx = nullptr;
+  double *d_cl_tiles = nullptr, *d_cl_linv = nullptr, *d_cl_vec = nullptr;
+  int *d_cl_flags = nullptr, *d_cl_bad = nullptr;
+  int cl_epoch = 0;
   int nblocks_slices = 0;     // ceil(nslices / 4): grid of the thread-per-track side kernels
   int nblocks_tracks = 0;     // grid of the per-track kernels of the solve (DeviceView::n_track_blocks)
   int nblocks_points = 0;
@@ -1608,6 +1629,102 @@ static int wait_mirror(tmi_ba_solver* s, int slot, unsigned long long seq) {
   return TMI_BA_OK;
 }
 
+// big dataflow launches of one process on one device run one after the other: two of them racing for the same CUs could
+// each hold a part of the device and wait for the rest (dense_cholesky_df.h); the dependency is enqueued, the host
+// does not wait
+static std::mutex g_df_mutex;
+static hipEvent_t g_df_event[64] = {};
+static int launch_coresident(tmi_ba_solver* s, int grid, const std::function<void()>& launch) {
+  if (!s->num_cus) {
+    hipDeviceProp_t prop;
+    TMI_HIP(hipGetDeviceProperties(&prop, s->device));
+    s->num_cus = prop.multiProcessorCount;
+  }
+  const bool big = 2 * grid > s->num_cus && s->device >= 0 && s->device < 64;
+  if (!big) {
+    launch();
+    return TMI_BA_OK;
+  }
+  std::lock_guard<std::mutex> lock(g_df_mutex);
+  hipEvent_t& ev = g_df_event[s->device];
+  if (ev) {
+    TMI_HIP(hipStreamWaitEvent(s->stream, ev, 0));
+  } else {
+    TMI_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  }
+  launch();
+  TMI_HIP(hipEventRecord(ev, s->stream));
+  return TMI_BA_OK;
+}
+
+// ---- CLUSTER_JACOBI over the shared intrinsics blocks (cluster_precond.h) ------------------------------------
+static int ensure_clusters(tmi_ba_solver* s) {
+  if (s->cl_built) return TMI_BA_OK;
+  const Structure& st = s->st;
+  if (!s->num_cus) {
+    hipDeviceProp_t prop;
+    TMI_HIP(hipGetDeviceProperties(&prop, s->device));
+    s->num_cus = prop.multiProcessorCount;
+  }
+  std::vector<std::vector<int> > members;
+  for (int g = 0; g < st.Nrb - st.Ncam_rb; ++g) {
+    std::vector<int> m;
+    for (int k = st.grp_cam_ptr[g]; k < st.grp_cam_ptr[g + 1]; ++k) m.push_back(st.cam_rb[st.grp_cams[k]]);
+    std::sort(m.begin(), m.end());
+    m.push_back(st.Ncam_rb + g);
+    members.push_back(m);
+  }
+  auto lookup = [&](int bi, int bj) -> int {
+    const int* b = st.ub_j.data() + st.urow_ptr[bi];
+    const int* e = st.ub_j.data() + st.urow_ptr[bi + 1];
+    const int* it = std::lower_bound(b, e, bj);
+    return (it != e && *it == bj) ? (int)(it - st.ub_j.data()) : -1;
+  };
+  s->cl_plan = clp::make_plan(members, st.rb_dim, st.D, lookup, s->num_cus);
+  const clp::Plan& p = s->cl_plan;
+  int rc;
+  if ((rc = dev_upload(s, &s->d_cl_desc, p.desc))) return rc;
+  if ((rc = dev_upload(s, &s->d_cl_ge, p.entries))) return rc;
+  if ((rc = dev_upload(s, &s->d_cl_idx, p.idx))) return rc;
+  if ((rc = dev_alloc(s, &s->d_cl_tiles, (size_t)p.n_tiles * cdf::TILE))) return rc;
+  if ((rc = dev_alloc(s, &s->d_cl_linv, (size_t)p.n_linv * cdf::TILE))) return rc;
+  if ((rc = dev_alloc(s, &s->d_cl_vec, (size_t)std::max(p.n_vec, 1)))) return rc;
+  if ((rc = dev_alloc(s, &s->d_cl_flags, (size_t)std::max(p.n_flags, 1)))) return rc;
+  if ((rc = dev_alloc(s, &s->d_cl_bad, (size_t)std::max(p.ncl, 1)))) return rc;
+  TMI_HIP(hipMemsetAsync(s->d_cl_flags, 0, (size_t)std::max(p.n_flags, 1) * sizeof(int), s->stream));
+  s->cl_epoch = 0;
+  s->cl_built = true;
+  return TMI_BA_OK;
+}
+
+// the clusters' matrices from the blocks of S (diagonal blocks with the LM diagonal already added), factored
+static int factor_clusters(tmi_ba_solver* s) {
+  int rc = ensure_clusters(s);
+  if (rc) return rc;
+  const clp::Plan& p = s->cl_plan;
+  if (p.ncl == 0) return TMI_BA_OK;
+  DeviceView& v = s->v;
+  TMI_HIP(hipMemsetAsync(s->d_cl_tiles, 0, (size_t)p.n_tiles * cdf::TILE * sizeof(double), s->stream));
+  TMI_HIP(hipMemsetAsync(s->d_cl_bad, 0, (size_t)p.ncl * sizeof(int), s->stream));
+  s->launch.cluster_gather(s->stream, s->d_cl_ge, (int)p.entries.size(), s->d_cl_desc, v.red + s->RL.ub, v.Sdiag, s->d_cl_tiles);
+  const int epoch = ++s->cl_epoch;
+  return launch_coresident(s, p.grid, [&] {
+    hipLaunchKernelGGL(clp::cluster_factor_kernel, dim3(p.grid), dim3(256), 0, s->stream, s->d_cl_desc, p.ncl, s->d_cl_tiles,
+                       s->d_cl_linv, s->d_cl_flags, epoch, v.flags + FL_CHOL_ABORT, s->d_cl_bad);
+  });
+}
+
+// z <- C^-1 r on the clustered entries (the others keep their block-Jacobi values)
+static int apply_clusters(tmi_ba_solver* s, const double* r, double* z) {
+  const clp::Plan& p = s->cl_plan;
+  if (p.ncl == 0) return TMI_BA_OK;
+  const int epoch = ++s->cl_epoch;
+  return launch_coresident(s, p.grid, [&] {
+    hipLaunchKernelGGL(clp::cluster_apply_kernel, dim3(p.grid), dim3(256), 0, s->stream, s->d_cl_desc, p.ncl, s->d_cl_tiles,
+                       s->d_cl_linv, s->d_cl_flags, epoch, s->v.flags + FL_CHOL_ABORT, s->d_cl_bad, s->d_cl_idx, s->d_cl_vec, r, z);
+  });
+}
+
 static int solve_reduced_pcg(tmi_ba_solver* s, const tmi_ba_options* O, int* usable, int64_t* iters) {
   DeviceView& v = s->v;
   const int n = v.Nrb * v.D;
@@ -1618,6 +1735,11 @@ static int solve_reduced_pcg(tmi_ba_solver* s, const tmi_ba_options* O, int* usa
     // x = 0, r = b, z = M^-1 b, p = z, rho: one multi-workgroup launch
     Timed t(s, TMI_BA_K_PCG_VECTOR);
     s->launch.pcg_init(v, s->stream, b, (v.Nrb + kPcgStepThreads / 64 - 1) / (kPcgStepThreads / 64));
+    if (s->cl_active) {
+      const int rcc = apply_clusters(s, v.cg_r, v.cg_z);
+      if (rcc) return rcc;
+      hipLaunchKernelGGL(clp::cluster_init_fix_kernel, dim3(1), dim3(1024), 0, s->stream, v, n);
+    }
   }
   // Fused path (no shared intrinsics blocks): an iteration is  product (+ p.q) -> [all-reduce] ->
   // pcg_step, and the NEXT iteration's launches are enqueued before this one's scalars are read
@@ -1675,12 +1797,22 @@ static int solve_reduced_pcg(tmi_ba_solver* s, const tmi_ba_options* O, int* usa
         Timed t(s, TMI_BA_K_PCG_VECTOR);
         hipLaunchKernelGGL(pcg_b1_kernel, dim3(1), dim3(1024), 0, s->stream, v, n);
         s->launch.pcg_b2(v, s->stream, b, reset ? 1 : 0, nbv, v.partial);
+        if (s->cl_active && !reset) {
+          const int rcc = apply_clusters(s, v.cg_r, v.cg_z);
+          if (rcc) return rcc;
+          s->launch.cluster_rz(v, s->stream, nbv, v.partial);
+        }
       }
       if (reset) {
         const int rcs = apply_schur(s, v.yc, v.cg_t);
         if (rcs) return rcs;
         Timed t(s, TMI_BA_K_PCG_VECTOR);
         s->launch.pcg_b2(v, s->stream, b, 2, nbv, v.partial);
+        if (s->cl_active) {
+          const int rcc = apply_clusters(s, v.cg_r, v.cg_z);
+          if (rcc) return rcc;
+          s->launch.cluster_rz(v, s->stream, nbv, v.partial);
+        }
       }
       {
         // Q1, zeta, and z / rho / p of iteration it + 1
@@ -1705,12 +1837,6 @@ static int solve_reduced_pcg(tmi_ba_solver* s, const tmi_ba_options* O, int* usa
   *iters += it;
   return TMI_BA_OK;
 }
-
-// big dataflow launches of one process on one device run one after the other: two of them racing for the same CUs could
-// each hold a part of the device and wait for the rest (dense_cholesky_df.h); the dependency is enqueued, the host
-// does not wait
-static std::mutex g_df_mutex;
-static hipEvent_t g_df_event[64] = {};
 
 static int solve_reduced_dense_panels(tmi_ba_solver* s) {
   DeviceView& v = s->v;
@@ -1771,19 +1897,11 @@ static int solve_reduced_dense(tmi_ba_solver* s, int* usable) {
   a.band = plan.band;
   a.team = plan.team;
   a.G = plan.G;
-  const bool big = 2 * plan.G > s->num_cus && s->device >= 0 && s->device < 64;
-  if (big) {
-    std::lock_guard<std::mutex> lock(g_df_mutex);
-    hipEvent_t& ev = g_df_event[s->device];
-    if (ev) {
-      TMI_HIP(hipStreamWaitEvent(s->stream, ev, 0));
-    } else {
-      TMI_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    }
-    hipLaunchKernelGGL(cdf::chol_dataflow_kernel, dim3(plan.G), dim3(256), 0, s->stream, a);
-    TMI_HIP(hipEventRecord(ev, s->stream));
-  } else {
-    hipLaunchKernelGGL(cdf::chol_dataflow_kernel, dim3(plan.G), dim3(256), 0, s->stream, a);
+  {
+    const int rcl = launch_coresident(s, plan.G, [&] {
+      hipLaunchKernelGGL(cdf::chol_dataflow_kernel, dim3(plan.G), dim3(256), 0, s->stream, a);
+    });
+    if (rcl) return rcl;
   }
   return TMI_BA_OK;
 }
@@ -2204,6 +2322,12 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
         s->launch.precond(v, stream,
                           O->preconditioner_type == TMI_BA_PRECOND_IDENTITY ? 1
                           : O->preconditioner_type == TMI_BA_PRECOND_SCHUR_JACOBI_PARAMETER_BLOCKS ? 2 : 0);
+        // CLUSTER_JACOBI / CLUSTER_TRIDIAGONAL on a problem with shared intrinsics blocks: the exact inverse of every
+        // {shared block, its views} cluster (needs the cluster's blocks of S: the formed operator)
+        s->cl_active = (O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_JACOBI ||
+                        O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_TRIDIAGONAL) &&
+                       s->st.has_shared && !s->implicit_now && n_r > 0;
+        if (s->cl_active) CK(factor_clusters(s));
       }
       const int64_t before = pcg_iters;
       CK(solve_reduced_pcg(s, O, &usable, &pcg_iters));
