@@ -93,13 +93,38 @@ def test_device_cluster_jacobi_matches_oracle(case):
 
 
 @pytest.mark.gpu
-def test_device_cluster_jacobi_falls_back_with_the_matrix_free_operator():
+@pytest.mark.parametrize("mode", [abi.SCHUR_IMPLICIT, abi.SCHUR_AUTO])
+def test_device_cluster_jacobi_with_the_matrix_free_operator(mode):
+    """schur_mode auto / implicit: the operator is matrix-free and only the blocks INSIDE the clusters are formed for the
+    preconditioner to factor; same PCG, same trajectory as with the formed S."""
+    from theiasfm_amd import lib
+    prob = shared_problem()
+    a, b, c = prob.copy(), prob.copy(), prob.copy()
+    st_d, s_d = lib.solve(a, options(abi.PRECOND_CLUSTER_JACOBI, schur_mode=mode))
+    st_e, s_e = lib.solve(c, options(abi.PRECOND_CLUSTER_JACOBI, schur_mode=abi.SCHUR_EXPLICIT))
+    st_o, s_o = oracle.solve(b, options(abi.PRECOND_CLUSTER_JACOBI))
+    assert st_d == st_e == st_o == 0, (s_d.message, s_o.message)
+    assert s_d.num_matrix_free_iterations == s_d.num_iterations and s_e.num_matrix_free_iterations == 0
+    assert 0 < s_d.num_schur_blocks < s_e.num_schur_blocks       # the clusters' blocks only
+    assert s_d.num_iterations == s_o.num_iterations and s_d.num_successful_steps == s_o.num_successful_steps
+    assert abs(int(s_d.num_linear_solver_iterations) - int(s_o.num_linear_solver_iterations)) <= 1
+    assert abs(s_d.final_cost - s_o.final_cost) <= 1e-9 * s_o.final_cost
+    assert abs(s_d.final_cost - s_e.final_cost) <= 1e-9 * s_e.final_cost
+    assert np.abs(a.extrinsics - b.extrinsics).max() <= 1e-6 * 100.0
+
+
+@pytest.mark.gpu
+def test_device_cluster_jacobi_needs_its_blocks():
+    """a handle created for SCHUR_JACOBI with the matrix-free operator has no blocks of S at all: asking that handle for
+    CLUSTER_JACOBI at solve time falls back to SCHUR_JACOBI instead of failing"""
     from theiasfm_amd import lib
     prob = shared_problem(n_views=30, groups=(2, 8), seed=2)
-    outs = []
-    for pre in (abi.PRECOND_SCHUR_JACOBI, abi.PRECOND_CLUSTER_JACOBI):
-        p = prob.copy()
-        st, s = lib.solve(p, options(pre, schur_mode=abi.SCHUR_IMPLICIT, max_num_iterations=4))
-        assert st == 0
-        outs.append((s.final_cost, int(s.num_linear_solver_iterations)))
-    assert outs[0] == outs[1]
+    o_j = options(abi.PRECOND_SCHUR_JACOBI, schur_mode=abi.SCHUR_IMPLICIT, max_num_iterations=4)
+    o_c = options(abi.PRECOND_CLUSTER_JACOBI, schur_mode=abi.SCHUR_IMPLICIT, max_num_iterations=4)
+    sv = lib.Solver(prob.copy(), o_j)
+    st1, s1 = sv.solve(o_j)
+    sv.reset()
+    st2, s2 = sv.solve(o_c)
+    sv.close()
+    assert st1 == st2 == 0
+    assert s1.final_cost == s2.final_cost and s1.num_linear_solver_iterations == s2.num_linear_solver_iterations

@@ -315,6 +315,7 @@ struct tmi_ba_solver {
   int num_cus = 0;
   // CLUSTER_JACOBI over the shared intrinsics blocks (cluster_precond.h)
   clp::Plan cl_plan;
+  bool cluster_blocks = false;  // the matrix-free operator with the clusters' blocks of S formed beside it
   bool cl_built = false;      // plan + device buffers exist
   bool cl_active = false;     // the current LM iteration's PCG applies it
   clp::ClusterDesc* d_cl_desc = nullptr;
@@ -1175,7 +1176,7 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   s->adaptive = !light && iterative_type && O->schur_mode == 0 && world == 1 && getenv("TMI_BA_NO_ADAPTIVE") == nullptr;
   s->implicit_now = s->implicit;
   TMI_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-  const bool want_pairs = !s->implicit && !light;
+  bool want_pairs = !s->implicit && !light;
   const bool setup_timing = getenv("TMI_BA_SETUP_TIMING") != nullptr;
   // the camera side on the host (tiny), then the observation-sized structure on the device when the
   // problem shape allows it (structure_gpu.h), else on host threads (structure.cpp)
@@ -1184,6 +1185,16 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
     s->error = s->st.error;
     return rc;
   }
+  // CLUSTER_JACOBI on a problem with shared intrinsics blocks (cluster_precond.h): with schur_mode auto the operator is
+  // the matrix-free one and only the blocks INSIDE the clusters are formed (what the preconditioner factors); an
+  // explicit request for the formed / the matrix-free operator is honoured, the latter with the cluster blocks as well
+  const bool cluster_pre = O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_JACOBI ||
+                           O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_TRIDIAGONAL;
+  if (cluster_pre && s->st.has_shared && iterative_type && !light) {
+    if (O->schur_mode == 0) s->implicit = s->implicit_now = true;
+    s->cluster_blocks = s->implicit;
+    want_pairs = !s->implicit;
+  }
   if (device_setup_possible(s->st, world, P->num_observations, want_pairs)) {
     s->device_structure = true;
     memset(&s->v, 0, sizeof(s->v));
@@ -1191,7 +1202,7 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
     if (rc) return rc;
   } else {
     s->st = Structure();
-    rc = build_structure(P, rank, world, &s->st, want_pairs);
+    rc = build_structure(P, rank, world, &s->st, want_pairs ? 1 : (s->cluster_blocks ? 2 : 0));
     if (rc) {
       s->error = s->st.error;
       return rc;
@@ -2303,7 +2314,7 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
       s->n_implicit_iterations++;
     }
     build_camera_side(inv_radius);
-    if (!s->implicit_now) {
+    if (!s->implicit_now || s->cluster_blocks) {
       Timed t(s, TMI_BA_K_SCHUR_OFFDIAG);
       s->launch.schur_offdiag(v, stream, RL);
       s->launch.cross_add(v, stream, RL);
@@ -2326,7 +2337,7 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
         // {shared block, its views} cluster (needs the cluster's blocks of S: the formed operator)
         s->cl_active = (O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_JACOBI ||
                         O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_TRIDIAGONAL) &&
-                       s->st.has_shared && !s->implicit_now && n_r > 0;
+                       s->st.has_shared && (!s->implicit_now || s->cluster_blocks) && n_r > 0;
         if (s->cl_active) CK(factor_clusters(s));
       }
       const int64_t before = pcg_iters;

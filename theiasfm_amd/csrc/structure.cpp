@@ -197,7 +197,7 @@ int build_blocks(const tmi_ba_problem* P, int rank, int world, Structure* S) {
   return TMI_BA_OK;
 }
 
-int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, bool want_pairs) {
+int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, int want_pairs_mode) {
   const bool timing = std::getenv("TMI_BA_SETUP_TIMING") != nullptr;
   double t_phase = wall_s();
   auto lap = [&](const char* what) {
@@ -211,6 +211,16 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, 
     if (rc) return rc;
   }
   Structure& s = *S;
+  // cluster-only blocks (want_pairs 2): a block (a, b) is kept when a and b lie in the same cluster {shared block, its views}
+  const bool cluster_only = want_pairs_mode == 2 && s.has_shared;
+  const bool want_pairs = want_pairs_mode == 1 || cluster_only;
+  std::vector<int> cluster_of(s.Nrb, -1);
+  if (cluster_only) {
+    for (int c = 0; c < s.Nc; ++c)
+      if (s.cam_rb[c] >= 0) cluster_of[s.cam_rb[c]] = s.cam_grb[c];
+    for (int rb = s.Ncam_rb; rb < s.Nrb; ++rb) cluster_of[rb] = rb;
+  }
+  auto keep_block = [&](int a, int b) { return !cluster_only || (cluster_of[a] >= 0 && cluster_of[a] == cluster_of[b]); };
   const int64_t No_all = P->num_observations;
   for (int64_t i = 0; i < No_all; ++i)
     if (P->obs_camera[i] < 0 || P->obs_camera[i] >= s.Nc || P->obs_point[i] < 0 ||
@@ -490,7 +500,8 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, 
         track_blocks(rbs, [&](int j) { return P->obs_camera[tobs[tptr[p] + j]]; }, klen[p]);
         for (size_t a = 0; a < rbs.size(); ++a)
           for (size_t b = a + 1; b < rbs.size(); ++b)
-            __atomic_store_n(&present[(size_t)rbs[a] * s.Nrb + rbs[b]], (uint8_t)1, __ATOMIC_RELAXED);
+            if (keep_block(rbs[a], rbs[b]))
+              __atomic_store_n(&present[(size_t)rbs[a] * s.Nrb + rbs[b]], (uint8_t)1, __ATOMIC_RELAXED);
       }
     });
     for (int a = 0; a < s.Nrb; ++a)
@@ -504,7 +515,7 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, 
       track_blocks(rbs, [&](int j) { return P->obs_camera[tobs[tptr[p] + j]]; }, klen[p]);
       for (size_t a = 0; a < rbs.size(); ++a)
         for (size_t b = a + 1; b < rbs.size(); ++b)
-          blocks.put(((uint64_t)rbs[a] << 32) | (uint32_t)rbs[b], 0);
+          if (keep_block(rbs[a], rbs[b])) blocks.put(((uint64_t)rbs[a] << 32) | (uint32_t)rbs[b], 0);
     }
   }
   // J_c^T J_c couples a view's extrinsics with its shared intrinsics block even when
@@ -595,6 +606,7 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, 
       std::sort(rs.begin(), rs.end());
       for (size_t a = 0; a < rs.size(); ++a)
         for (size_t b = a + 1; b < rs.size(); ++b) {
+          if (!keep_block(rs[a].first, rs[b].first)) continue;
           const int u = blk_id.empty() ? *blocks.find(((uint64_t)rs[a].first << 32) | (uint32_t)rs[b].first)
                                        : blk_id[(size_t)rs[a].first * s.Nrb + rs[b].first];
           fn(u, rs[a].second, rs[b].second);

@@ -103,7 +103,9 @@ int build_blocks(const tmi_ba_problem* P, int rank, int world, Structure* out);
 // A/B switch (TMI_BA_TRACK_ORDER_PLAIN): ties of the length order by track index only, as before round 2
 bool track_order_plain();
 
+// want_pairs = 2: only the blocks INSIDE a cluster {shared intrinsics block, its views} and their pair lists -- what
+// CLUSTER_JACOBI needs when the operator itself is matrix-free (cluster_precond.h); without shared blocks: none.
 int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* out,
-                    bool want_pairs = true);
+                    int want_pairs = 1);
 
 }  // namespace tmi

@@ -9,12 +9,13 @@ bits = abi.INTRINSICS_FOCAL_LENGTH | abi.INTRINSICS_PRINCIPAL_POINTS | abi.INTRI
 a = [int(x) for x in sys.argv[1:]]
 kw = dict(shared_group_sizes=(a[0], a[1])) if len(a) >= 2 and a[1] > 0 else dict(shared_group_size=(a[0] if a else 8))
 prec = a[2] if len(a) > 2 else 32
+pre = a[4] if len(a) > 4 else 2
 mode = a[3] if len(a) > 3 else 0
 t0 = time.time()
 P = synth.config("venice1778", models=[(abi.PINHOLE, 0.5), (abi.PINHOLE_RADIAL_TANGENTIAL, 0.25), (abi.FISHEYE, 0.25)],
                  intrinsics_to_optimize=bits, **kw)
 t_gen = time.time() - t0
-o = dict(point_dof=3, linear_solver_type=abi.ITERATIVE_SCHUR, residual_precision=prec, use_inner_iterations=0, schur_mode=mode,
+o = dict(point_dof=3, linear_solver_type=abi.ITERATIVE_SCHUR, residual_precision=prec, use_inner_iterations=0, schur_mode=mode, preconditioner_type=pre,
          function_tolerance=-1.0, gradient_tolerance=-1.0, parameter_tolerance=-1.0)
 t0 = time.time()
 s = lib.Solver(P, abi.default_options(max_num_iterations=2, **o))
