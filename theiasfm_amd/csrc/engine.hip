@@ -65,7 +65,7 @@ struct Launch {
   void (*cross_add)(const DeviceView&, hipStream_t, RedLayout);
   void (*point_eliminate)(const DeviceView&, hipStream_t, double, double, double, int, double*, double*, double,
                           double*);
-  void (*camera_diag)(const DeviceView&, hipStream_t, RedLayout);
+  void (*camera_diag)(const DeviceView&, hipStream_t, RedLayout, int, double*);
   void (*schur_offdiag)(const DeviceView&, hipStream_t, RedLayout);
   void (*expand_scale)(const DeviceView&, hipStream_t);
   void (*expand)(const DeviceView&, hipStream_t, RedLayout, double, double, double, int want_gmax);
@@ -126,8 +126,15 @@ Launch make_launch(bool fp32) {
     hipLaunchKernelGGL((point_eliminate_kernel<D, DP, SH>), dim3(nb), dim3(256), 0, st, v, ir, lo, hi, nb, pm,
                        vote, gtol, gvote);
   };
-  L.camera_diag = [](const DeviceView& v, hipStream_t st, RedLayout R) {
-    if (v.Nrb) hipLaunchKernelGGL((camera_diag_kernel<D, DP, SH>), dim3(v.Nrb), dim3(64), 0, st, v, R);
+  L.camera_diag = [](const DeviceView& v, hipStream_t st, RedLayout R, int max_chunks, double* chunk_partial) {
+    // max_chunks > 0: the shared blocks' raw diagonals come from the chunked kernels (big shared blocks)
+    const bool chunked = SH && max_chunks > 0 && v.Nrb > v.Ncam_rb;
+    if (v.Nrb) hipLaunchKernelGGL((camera_diag_kernel<D, DP, SH>), dim3(v.Nrb), dim3(64), 0, st, v, R, chunked ? 1 : 0);
+    if (chunked) {
+      const int ns = v.Nrb - v.Ncam_rb;
+      hipLaunchKernelGGL((shared_diag_partial_kernel<D, DP>), dim3(ns * max_chunks), dim3(64), 0, st, v, max_chunks, chunk_partial);
+      hipLaunchKernelGGL((shared_diag_reduce_kernel<D>), dim3(ns), dim3(64), 0, st, v, R, max_chunks, chunk_partial);
+    }
   };
   L.expand_scale = [](const DeviceView& v, hipStream_t st) {
     if (v.Nc) hipLaunchKernelGGL((expand_camera_scale_kernel<D>), dim3((v.Nc + 255) / 256), dim3(256), 0, st, v);
@@ -315,6 +322,8 @@ struct tmi_ba_solver {
   int num_cus = 0;
   // CLUSTER_JACOBI over the shared intrinsics blocks (cluster_precond.h)
   clp::Plan cl_plan;
+  int shared_diag_chunks = 0;   // > 0: chunks per shared block of the two-step raw diagonal (kernels.h, shared_diag_*)
+  double* d_shared_diag_partial = nullptr;
   bool cluster_blocks = false;  // the matrix-free operator with the clusters' blocks of S formed beside it
   bool cl_built = false;      // plan + device buffers exist
   bool cl_active = false;     // the current LM iteration's PCG applies it
@@ -1369,6 +1378,15 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   AL(v.pm_A1, st.has_shared ? 2 * D * N : 1) AL(v.cam_part, (size_t)std::max(st.Ncam_rb, 1) * (2 * D * D + 3 * D))
   // Y records: the shared-block sums need them; without shared blocks the Schur complement works from the
   // [A | Q] records and Y exists only for the A/B switches that select the older kernels
+  if (st.has_shared) {
+    // a shared block with more records than one wavefront should walk alone: the chunked raw diagonal (kernels.h)
+    int64_t most = 0;
+    for (int rb = st.Ncam_rb; rb < st.Nrb; ++rb) most = std::max<int64_t>(most, (int64_t)st.cam_ptr[rb + 1] - st.cam_ptr[rb]);
+    if (most > 2 * kSharedDiagChunk) {
+      s->shared_diag_chunks = (int)((most + kSharedDiagChunk - 1) / kSharedDiagChunk);
+      AL(s->d_shared_diag_partial, (size_t)(st.Nrb - st.Ncam_rb) * s->shared_diag_chunks * sym_size(D))
+    }
+  }
   s->y_records = st.has_shared || getenv("TMI_BA_SCHUR_GATHER") != nullptr || getenv("TMI_BA_SCHUR_Y") != nullptr;
   v.write_y = (s->y_records && (!s->implicit || st.has_shared)) ? 1 : 0;
   if (s->adaptive) {
@@ -2235,7 +2253,7 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
     }
     {
       Timed t(s, TMI_BA_K_CAMERA_DIAG);
-      s->launch.camera_diag(v, stream, RL);
+      s->launch.camera_diag(v, stream, RL, s->shared_diag_chunks, s->d_shared_diag_partial);
       s->launch.shared_blocks(v, stream, RL);
     }
   };

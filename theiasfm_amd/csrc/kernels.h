@@ -1056,8 +1056,67 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
 //   S_cc(raw) = sum A^T N A (= sum A^T A - Y Y^T),  U diag = sum diag(A^T A),
 //   g~ = sum A^T r~  (reduced gradient),  g_c = sum A^T r  (camera gradient).
 // ------------------------------------------------------------------------------
+// Raw diagonal of a SHARED intrinsics block, - sum Y Y^T over its (track, block) records, in two steps: a block
+// shared by 200 views has 10^5-10^6 records and ONE wavefront walking them (camera_diag's way) takes milliseconds, so
+// the records are cut into chunks of kSharedDiagChunk, a wavefront per chunk leaves its partial sum, and a second
+// launch adds the partials in chunk order (fixed order: bit-reproducible) -- camera_diag then skips those blocks.
+constexpr int kSharedDiagChunk = 4096;
+template <int D, int DP>
+__global__ __launch_bounds__(64) void shared_diag_partial_kernel(DeviceView v, int max_chunks, double* __restrict__ partial) {
+  constexpr int NS = sym_size(D);
+  constexpr int YS = ys_of(D, DP);
+  const int g = blockIdx.x / max_chunks, ch = blockIdx.x - g * max_chunks;
+  const int rb = v.Ncam_rb + g;
+  const int s0 = v.cam_ptr[rb] + ch * kSharedDiagChunk;
+  const int s1 = min(s0 + kSharedDiagChunk, v.cam_ptr[rb + 1]);
+  if (s0 >= s1) return;
+  double Ss[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) Ss[i] = 0.0;
+  for (int s = s0 + threadIdx.x; s < s1; s += 64) {
+    const double* yrec = v.cm_Y + (size_t)s * YS;
+    double Y[YS];
+#pragma unroll
+    for (int i = 0; i < YS; i += 2) {
+      const double2 t = *reinterpret_cast<const double2*>(yrec + i);
+      Y[i] = t.x;
+      Y[i + 1] = t.y;
+    }
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int b = a; b < D; ++b) {
+        double t = 0.0;
+#pragma unroll
+        for (int c = 0; c < DP; ++c) t -= Y[a * DP + c] * Y[b * DP + c];
+        Ss[sym_idx(a, b, D)] += t;
+      }
+  }
+  double* out = partial + (size_t)blockIdx.x * NS;
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const double t = wave_sum(Ss[i]);
+    if (threadIdx.x == 0) out[i] = t;
+  }
+}
+template <int D>
+__global__ __launch_bounds__(64) void shared_diag_reduce_kernel(DeviceView v, RedLayout L, int max_chunks,
+                                                                const double* __restrict__ partial) {
+  constexpr int NS = sym_size(D);
+  const int g = blockIdx.x, rb = v.Ncam_rb + g;
+  const int nch = (v.cam_ptr[rb + 1] - v.cam_ptr[rb] + kSharedDiagChunk - 1) / kSharedDiagChunk;
+  double* diag = v.red + L.diag + (size_t)rb * D * D;
+  for (int a = 0; a < D; ++a)
+    for (int b = a + (int)threadIdx.x; b < D; b += 64) {
+      double t = 0.0;
+      for (int ch = 0; ch < nch; ++ch) t += partial[((size_t)g * max_chunks + ch) * NS + sym_idx(a, b, D)];
+      diag[a * D + b] = t;
+      diag[b * D + a] = t;
+    }
+}
+
 template <int D, int DP, bool SH>
-__global__ __launch_bounds__(64) void camera_diag_kernel(DeviceView v, RedLayout L) {
+__global__ __launch_bounds__(64) void camera_diag_kernel(DeviceView v, RedLayout L, int shared_elsewhere) {
   constexpr int NS = sym_size(D);
   constexpr int AS = as_of(D, SH);
   const int rb = blockIdx.x;
@@ -1069,9 +1128,10 @@ __global__ __launch_bounds__(64) void camera_diag_kernel(DeviceView v, RedLayout
   if (SH && rb >= v.Ncam_rb) {
     // shared intrinsics block: its slots are (track, block) records whose Y is a SUM over the
     // track's observations of the block (point_eliminate), so Y Y^T has no per-observation
-    // N form; the J^T J part arrives through group_reduce.  Raw diagonal = - sum Y Y^T.
+    // N form; the J^T J part arrives through group_reduce.  Raw diagonal = - sum Y Y^T
+    // (by shared_diag_partial / shared_diag_reduce when the blocks are big: shared_elsewhere).
     constexpr int YS = ys_of(D, DP);
-    for (int s = v.cam_ptr[rb] + threadIdx.x; s < v.cam_ptr[rb + 1]; s += 64) {
+    for (int s = v.cam_ptr[rb] + threadIdx.x; s < v.cam_ptr[rb + 1] && !shared_elsewhere; s += 64) {
       const double* yrec = v.cm_Y + (size_t)s * YS;
       double Y[YS];
 #pragma unroll
