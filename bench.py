@@ -693,24 +693,29 @@ def main():
             out["variants"]["venice1778_heavy_point_dof4-synthetic"] = dict(
                 steps=int(sm4.num_iterations), ms_per_step=round(1e3 * sm4.solve_time_in_seconds / max(1, sm4.num_iterations), 3),
                 pcg_iterations=int(sm4.num_linear_solver_iterations), final_rmse=sm4.final_rmse)
-            # BASELINE config 5 at Venice size: mixed camera models, intrinsics shared by groups of 8 views,
-            # fp32 residual evaluation (fp64 accumulation); one solve of 8 LM iterations, ~41 PCG iterations each
-            bits = (abi.INTRINSICS_FOCAL_LENGTH | abi.INTRINSICS_PRINCIPAL_POINTS | abi.INTRINSICS_RADIAL_DISTORTION
-                    | abi.INTRINSICS_TANGENTIAL_DISTORTION)
-            p5 = synth.config("venice1778", models=[(abi.PINHOLE, 0.5), (abi.PINHOLE_RADIAL_TANGENTIAL, 0.25),
-                                                    (abi.FISHEYE, 0.25)], shared_group_size=8, intrinsics_to_optimize=bits)
+            # BASELINE config 5 at Venice size (synth.config5): mixed camera models, intrinsics shared by 33 groups of 2-200
+            # views, fp32 residual evaluation (fp64 accumulation); CLUSTER_JACOBI over {shared block, its views} with the
+            # matrix-free operator (schur_mode auto), and SCHUR_JACOBI -- round 2's operating point -- beside it
+            p5 = synth.config5()
             o5 = dict(point_dof=3, linear_solver_type=abi.ITERATIVE_SCHUR, residual_precision=32, use_inner_iterations=0,
                       function_tolerance=-1.0, gradient_tolerance=-1.0, parameter_tolerance=-1.0)
-            s5 = lib.Solver(p5, abi.default_options(max_num_iterations=2, **o5))
-            s5.solve(abi.default_options(max_num_iterations=2, **o5))
-            s5.reset()
-            _, sm5 = s5.solve(abi.default_options(max_num_iterations=8, **o5))
-            s5.close()
-            out["variants"]["config5_mixed_models_shared_intrinsics_fp32-synthetic"] = dict(
-                cameras=p5.num_cameras, shared_intrinsics_blocks=int(sm5.num_reduced_blocks) - p5.num_cameras,
-                observations=p5.num_observations, steps=int(sm5.num_iterations),
-                ms_per_step=round(1e3 * sm5.solve_time_in_seconds / max(1, sm5.num_iterations), 3),
-                pcg_iterations=int(sm5.num_linear_solver_iterations), final_rmse=sm5.final_rmse)
+            v5 = dict(cameras=p5.num_cameras, observations=p5.num_observations, shared_intrinsics_groups=int(p5.num_groups),
+                      largest_group=int(np.bincount(p5.camera_group).max()))
+            for key, pre in (("cluster_jacobi", abi.PRECOND_CLUSTER_JACOBI), ("schur_jacobi", abi.PRECOND_SCHUR_JACOBI)):
+                t0 = time.perf_counter()
+                s5 = lib.Solver(p5.copy(), abi.default_options(max_num_iterations=2, preconditioner_type=pre, **o5))
+                t_create5 = time.perf_counter() - t0
+                s5.solve(abi.default_options(max_num_iterations=2, preconditioner_type=pre, **o5))
+                s5.reset()
+                _, sm5 = s5.solve(abi.default_options(max_num_iterations=8, preconditioner_type=pre, **o5))
+                s5.close()
+                v5[key] = dict(steps=int(sm5.num_iterations),
+                               ms_per_step=round(1e3 * sm5.solve_time_in_seconds / max(1, sm5.num_iterations), 3),
+                               pcg_iterations=int(sm5.num_linear_solver_iterations),
+                               matrix_free_iterations=int(sm5.num_matrix_free_iterations),
+                               schur_blocks_formed=int(sm5.num_schur_blocks), final_rmse=sm5.final_rmse,
+                               create_seconds=round(t_create5, 3))
+            out["variants"]["config5_mixed_models_shared_intrinsics_fp32-synthetic"] = v5
     print(json.dumps(out))
 
 

@@ -287,6 +287,21 @@ def make_problem(n_cameras: int, n_points: int, n_obs: int, seed: int, *,
     return prob
 
 
+CONFIG5_INTRINSICS = (abi.INTRINSICS_FOCAL_LENGTH | abi.INTRINSICS_PRINCIPAL_POINTS | abi.INTRINSICS_RADIAL_DISTORTION
+                      | abi.INTRINSICS_TANGENTIAL_DISTORTION)
+
+
+def config5(**kw) -> Problem:
+    """BASELINE.json configs[4] / SURVEY 8(d) config 5: the config-4 topology (1778 views, 993 923 tracks, 5 001 946
+    observations), cameras 50 % PINHOLE / 25 % PINHOLE_RADIAL_TANGENTIAL / 25 % FISHEYE, shared intrinsics groups of 2-200
+    consecutive views (log-uniform sizes; "groups of 1-200 views (shared)" -- a group of one is not shared),
+    intrinsics_to_optimize = ALL minus skew and aspect ratio."""
+    kw.setdefault("models", [(abi.PINHOLE, 0.5), (abi.PINHOLE_RADIAL_TANGENTIAL, 0.25), (abi.FISHEYE, 0.25)])
+    kw.setdefault("shared_group_sizes", (2, 200))
+    kw.setdefault("intrinsics_to_optimize", CONFIG5_INTRINSICS)
+    return config("venice1778", **kw)
+
+
 def config(name: str, **kw) -> Problem:
     """The BASELINE.json configurations by name."""
     nc, npt, nobs = CONFIG_SIZES[name]

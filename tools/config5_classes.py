@@ -12,7 +12,7 @@ prec = a[2] if len(a) > 2 else 32
 pre = a[4] if len(a) > 4 else 2
 mode = a[3] if len(a) > 3 else 0
 t0 = time.time()
-P = synth.config("venice1778", models=[(abi.PINHOLE, 0.5), (abi.PINHOLE_RADIAL_TANGENTIAL, 0.25), (abi.FISHEYE, 0.25)],
+P = synth.config5(**kw) if "shared_group_sizes" in kw else synth.config("venice1778", models=[(abi.PINHOLE, 0.5), (abi.PINHOLE_RADIAL_TANGENTIAL, 0.25), (abi.FISHEYE, 0.25)],
                  intrinsics_to_optimize=bits, **kw)
 t_gen = time.time() - t0
 o = dict(point_dof=3, linear_solver_type=abi.ITERATIVE_SCHUR, residual_precision=prec, use_inner_iterations=0, schur_mode=mode, preconditioner_type=pre,
