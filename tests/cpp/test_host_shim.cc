@@ -228,7 +228,10 @@ static void TestSemantics() {
     BundleAdjustmentOptions d;
     ToDeviceOptions(d, &o);
     EXPECT(o.preconditioner_type == TMI_BA_PRECOND_SCHUR_JACOBI_PARAMETER_BLOCKS);
-    d.preconditioner_type = ceres::CLUSTER_JACOBI;
+    d.preconditioner_type = ceres::CLUSTER_JACOBI;  // clusters = shared intrinsics blocks + their views on the device
+    ToDeviceOptions(d, &o);
+    EXPECT(o.preconditioner_type == TMI_BA_PRECOND_CLUSTER_JACOBI);
+    d.preconditioner_type = ceres::JACOBI;
     ToDeviceOptions(d, &o);
     EXPECT(o.preconditioner_type == TMI_BA_PRECOND_SCHUR_JACOBI_PARAMETER_BLOCKS);
     d.preconditioner_type = ceres::SCHUR_JACOBI;

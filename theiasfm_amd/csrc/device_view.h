@@ -8,8 +8,8 @@
 //    pm_Jp  [2 DP][No_pad]   plane 2*col+row: point Jacobian
 //  camera-major (slot = obs_cpos[e], contiguous per reduced block)
 //    cm_Y   [Nslots][YS]     Y = A^T Jp L^-T  (D x DP row-major, YS = D*DP rounded up to even)
-//    cm_A   [Nslots][AS]     A row 0 (D), A row 1 (D), N = I - Q Q^T (3), r~(2), r(2) [, A1 row 0 (D),
-//                            A1 row 1 (D) when free intrinsics are shared between views]
+//    cm_A   [Nslots][AS]     A row 0 (D), A row 1 (D), N = I - Q Q^T (3), r~(2), r(2); when free intrinsics are shared
+//                            between views: A rows, Q rows (2 x 4), r~, r, A1 row 0 (D), A1 row 1 (D)  (kernels.h, sh_off_*)
 //  reduced system
 //    red    [nub*D*D | Nrb*D*D | Nrb*D | Nrb*D | Nrb*D | 8]   the all-reduce buffer:
 //           upper blocks, raw diagonal blocks, U diagonal, reduced gradient g~,

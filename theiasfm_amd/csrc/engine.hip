@@ -189,7 +189,7 @@ Launch make_launch(bool fp32) {
   L.implicit_spmv = [](const DeviceView& v, hipStream_t st, RedLayout R, const double* x, double* y,
                        double* w1, double* w2, double ir, double lo, double hi, int add_diag, int nb, int dot,
                        int spec) {
-    // work arrays: with shared intrinsics blocks w1 = u planes, w2 = t records; without, w1 = zhat (w2 unused)
+    // work array: w1 = zhat, 4 doubles per track (w2 unused)
     if (!v.Nrb) return;
     if (!SH) {
       hipLaunchKernelGGL((implicit_tracks_q_kernel<D, DP>), dim3(nb), dim3(256), 0, st, v, x, w1, spec);
@@ -197,12 +197,12 @@ Launch make_launch(bool fp32) {
                          add_diag, dot, spec);
       return;
     }
-    hipLaunchKernelGGL((implicit_tracks_kernel<D, DP, SH>), dim3(nb), dim3(256), 0, st, v, x, w1, w2, spec);
+    hipLaunchKernelGGL((implicit_tracks_sq_kernel<D, DP>), dim3(nb), dim3(256), 0, st, v, x, w1, spec);
     // cam_part is free between two builds of the normal equations: the per-view partial
     // products of the shared intrinsics blocks live in its head
-    hipLaunchKernelGGL((implicit_cameras_kernel<D, DP, SH>), dim3(v.Nrb), dim3(64), 0, st, v, R, x, w2, y,
-                       ir, lo, hi, add_diag, v.cam_part, SH ? 0 : dot, spec);
-    if (SH && v.Nrb > v.Ncam_rb)
+    hipLaunchKernelGGL((implicit_cameras_sq_kernel<D, DP>), dim3(v.Ncam_rb), dim3(64), 0, st, v, R, x, w1, y,
+                       ir, lo, hi, add_diag, v.cam_part, spec);
+    if (v.Nrb > v.Ncam_rb)
       hipLaunchKernelGGL((implicit_groups_kernel<D>), dim3(v.Nrb - v.Ncam_rb), dim3(64), 0, st, v, R, x, v.cam_part,
                          y, ir, lo, hi, add_diag);
   };
@@ -1368,12 +1368,11 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   }
   AL(v.pm_r, 2 * N) AL(v.pm_A, 2 * D * N) AL(v.pm_Jp, 2 * DP * N)
   {
-    // work arrays of the matrix-free product: u planes + t records with shared intrinsics blocks, zhat
-    // (4 doubles per track) + the slot -> track index without
+    // work arrays of the matrix-free product: zhat (4 doubles per track) + the slot -> track index
     const bool mf = s->implicit || s->adaptive;
-    AL(s->d_pm_u, mf ? (st.has_shared ? 2 * N : 4 * NP) : 1)
-    AL(s->d_cm_t, (mf && st.has_shared) ? (size_t)std::max<int64_t>(st.Nslots, 1) * 2 : 1)
-    s->need_slot_track = mf && !st.has_shared;
+    AL(s->d_pm_u, mf ? 4 * NP : 1)
+    AL(s->d_cm_t, 1)
+    s->need_slot_track = mf;
   }
   AL(v.pm_A1, st.has_shared ? 2 * D * N : 1) AL(v.cam_part, (size_t)std::max(st.Ncam_rb, 1) * (2 * D * D + 3 * D))
   // Y records: the shared-block sums need them; without shared blocks the Schur complement works from the

@@ -49,14 +49,21 @@ __host__ __device__ __forceinline__ size_t pidx(int plane, size_t e) {
 // camera-major record strides in doubles, rounded up to whole 64-byte sectors so that a
 // record never straddles an extra sector (gathers) and is written as full sectors
 __host__ __device__ constexpr int ys_of(int D, int DP) { return (D * DP + 7) & ~7; }
-__host__ __device__ constexpr int as_of(int D, bool SH = false) { return ((SH ? 4 : 2) * D + 7 + 7) & ~7; }
-// camera-major A record: [A row 0 (D) | A row 1 (D) | N00 N01 N11 | r~ (2) | r (2) | A1 rows (2 D, SH)]
+__host__ __device__ constexpr int as_of(int D, bool SH = false) { return SH ? ((4 * D + 12 + 7) & ~7) : ((2 * D + 7 + 7) & ~7); }
+// camera-major A record without shared blocks: [A row 0 (D) | A row 1 (D) | N00 N01 N11 | r~ (2) | r (2)]
 // N = I - Q Q^T (Q = Jp L^-T, 2 x DP): sum A^T N A = sum (A^T A - Y Y^T), so the per-camera
 // reductions read this record only and never the Y record.
+// With shared intrinsics blocks (SH) ONE record per observation:
+//   [A row 0 (D) | A row 1 (D) | Q row 0 (4) | Q row 1 (4) | r~ (2) | r (2) | A1 row 0 (D) | A1 row 1 (D)]
+// (A1 = the Jacobian w.r.t. the view's SHARED intrinsics; N is recomputed from Q by the per-camera sums; Q is what the
+// one-sweep matrix-free product needs: S x = sum A^T (A x_c + A1 x_g - Q zhat) ...) -- 48 doubles for D = 9.
+__host__ __device__ constexpr int sh_off_q(int D) { return 2 * D; }
+__host__ __device__ constexpr int sh_off_rt(int D) { return 2 * D + 8; }
+__host__ __device__ constexpr int sh_off_r(int D) { return 2 * D + 10; }
+__host__ __device__ constexpr int sh_off_a1(int D) { return 2 * D + 12; }
 __host__ __device__ constexpr int a_off_n(int D) { return 2 * D; }
 __host__ __device__ constexpr int a_off_rt(int D) { return 2 * D + 3; }
 __host__ __device__ constexpr int a_off_r(int D) { return 2 * D + 5; }
-__host__ __device__ constexpr int a_off_sh(int D) { return 2 * D + 7; }
 // Without shared intrinsics blocks the A record is kept as TWO arrays in the same allocation: the A rows
 // alone (stride asa_of(D): 192 B for D = 9, what the cameras pass of the matrix-free product streams 4-5
 // times per LM iteration) and the 64-byte tail {N, r~, r} (cm_R) that only camera_diag reads.  Same bytes
@@ -881,7 +888,7 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
         }
 #pragma unroll
         for (int i = D * DP; i < YS; ++i) Yv[i] = 0.0;
-        {
+        if (!SH) {
           double n00 = 1.0, n01 = 0.0, n11 = 1.0;
 #pragma unroll
           for (int b = 0; b < DP; ++b) {
@@ -892,11 +899,21 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
           Av[TO] = n00;
           Av[TO + 1] = n01;
           Av[TO + 2] = n11;
+          Av[TO + 3] = rt0;
+          Av[TO + 4] = rt1;
+          Av[TO + 5] = r0;
+          Av[TO + 6] = r1;
+        } else {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            Av[sh_off_q(D) + b] = b < DP ? Q0[b < DP ? b : 0] : 0.0;
+            Av[sh_off_q(D) + 4 + b] = b < DP ? Q1[b < DP ? b : 0] : 0.0;
+          }
+          Av[sh_off_rt(D)] = rt0;
+          Av[sh_off_rt(D) + 1] = rt1;
+          Av[sh_off_r(D)] = r0;
+          Av[sh_off_r(D) + 1] = r1;
         }
-        Av[TO + 3] = rt0;
-        Av[TO + 4] = rt1;
-        Av[TO + 5] = r0;
-        Av[TO + 6] = r1;
         if (!SH) {
 #pragma unroll
           for (int b = 0; b < DP; ++b) {
@@ -921,13 +938,13 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
               a0 = v.pm_A1[pidx<2 * D>((2 * a), e)];
               a1 = v.pm_A1[pidx<2 * D>((2 * a + 1), e)];
             }
-            Av[a_off_sh(D) + a] = a0;
-            Av[a_off_sh(D) + D + a] = a1;
+            Av[sh_off_a1(D) + a] = a0;
+            Av[sh_off_a1(D) + D + a] = a1;
 #pragma unroll
             for (int b = 0; b < DP; ++b) Yg[a * DP + b] += a0 * Q0[b] + a1 * Q1[b];
           }
 #pragma unroll
-          for (int i = 4 * D + 7; i < AS; ++i) Av[i] = 0.0;
+          for (int i = 4 * D + 12; i < AS; ++i) Av[i] = 0.0;
         }
       }
 #pragma unroll
@@ -1154,13 +1171,35 @@ __global__ __launch_bounds__(64) void camera_diag_kernel(DeviceView v, RedLayout
   for (int s = v.cam_ptr[rb] + threadIdx.x; s < v.cam_ptr[rb + 1]; s += 64) {
     double rec[2 * D + 8];
     if (SH) {
+      // [A rows | Q | r~ | r | ...]: N = I - Q Q^T is formed here, the tail goes where the other layout has it
       const double* arec = v.cm_A + (size_t)s * AS;
+      double w12[12];
 #pragma unroll
-      for (int i = 0; i < 2 * D + 8; i += 2) {
+      for (int i = 0; i < 2 * D; i += 2) {
         const double2 t = *reinterpret_cast<const double2*>(arec + i);
         rec[i] = t.x;
         rec[i + 1] = t.y;
       }
+#pragma unroll
+      for (int i = 0; i < 12; i += 2) {
+        const double2 t = *reinterpret_cast<const double2*>(arec + 2 * D + i);
+        w12[i] = t.x;
+        w12[i + 1] = t.y;
+      }
+      double n00 = 1.0, n01 = 0.0, n11 = 1.0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        n00 -= w12[b] * w12[b];
+        n01 -= w12[b] * w12[4 + b];
+        n11 -= w12[4 + b] * w12[4 + b];
+      }
+      rec[a_off_n(D)] = n00;
+      rec[a_off_n(D) + 1] = n01;
+      rec[a_off_n(D) + 2] = n11;
+      rec[a_off_rt(D)] = w12[8];
+      rec[a_off_rt(D) + 1] = w12[9];
+      rec[a_off_r(D)] = w12[10];
+      rec[a_off_r(D) + 1] = w12[11];
     } else {
       const double* arec = v.cm_A + (size_t)s * asa_of(D, DP);
       const double* trec = v.cm_R + (size_t)s * kRecTail;
@@ -1945,11 +1984,13 @@ __global__ __launch_bounds__(256) void spmv_cols_kernel(DeviceView v, const doub
 // Every product streams the observations once (track-major planes) plus the camera-major
 // A records; with several GPUs only the reduced vector q is all-reduced.
 // ------------------------------------------------------------------------------
-template <int D, int DP, bool SH>
-__global__ __launch_bounds__(256) void implicit_tracks_kernel(DeviceView v, const double* __restrict__ x,
-                                                              double* __restrict__ pm_u,
-                                                              double* __restrict__ cm_t, int spec) {
-  constexpr int NS = sym_size(DP);
+// With shared intrinsics blocks the same ONE sweep (round 2 walked a track's observations twice, kept u planes and
+// scattered 16-byte t records): u_i = A_i x_c(i) + A1_i x_g(i) with x_g the view's shared block, zhat as below; the
+// cameras pass recomputes u_i from its record (which carries A, A1 and Q) and leaves the view's partial of the shared
+// block for implicit_groups to add up in the block's view order.
+template <int D, int DP>
+__global__ __launch_bounds__(256) void implicit_tracks_sq_kernel(DeviceView v, const double* __restrict__ x,
+                                                                 double* __restrict__ zhat, int spec) {
   if (spec && *v.pcg_done) return;
   const TrackMap tm = track_map(v);
   if (!tm.valid) return;
@@ -1957,15 +1998,17 @@ __global__ __launch_bounds__(256) void implicit_tracks_kernel(DeviceView v, cons
   const int k = tm.k;
   if (k == 0) return;  // uniform over the lanes that share a track
   const size_t base = tm.base;
-  const size_t N = (size_t)v.No_pad;
   const size_t NP = (size_t)v.Np_pad;
   double w[DP];
 #pragma unroll
   for (int a = 0; a < DP; ++a) w[a] = 0.0;
+  int cam_next = (tm.j0 < k) ? v.obs_cam[base + (size_t)tm.j0 * 64] : -1;
   for (int j = tm.j0; j < k; j += tm.jstep) {
     const size_t e = base + (size_t)j * 64;
-    const int cam = v.obs_cam[e];
-    const int rb = v.cam_rb[cam];
+    const int cam = cam_next;
+    if (j + tm.jstep < k) cam_next = v.obs_cam[e + (size_t)tm.jstep * 64];
+    if (cam < 0) continue;
+    const int rb = v.cam_rb[cam], grb = v.cam_grb[cam];
     double u0 = 0.0, u1 = 0.0;
     if (rb >= 0) {
       const double* xc = x + (size_t)rb * D;
@@ -1976,48 +2019,32 @@ __global__ __launch_bounds__(256) void implicit_tracks_kernel(DeviceView v, cons
         u1 += v.pm_A[pidx<2 * D>((2 * a + 1), e)] * xa;
       }
     }
-    if (SH) {
-      // columns of the view's shared intrinsics block
-      const int grb = v.cam_grb[cam];
-      if (grb >= 0) {
-        const double* xg = x + (size_t)grb * D;
+    if (grb >= 0) {
+      const double* xg = x + (size_t)grb * D;
 #pragma unroll
-        for (int a = 0; a < D; ++a) {
-          const double xa = xg[a];
-          u0 += v.pm_A1[pidx<2 * D>((2 * a), e)] * xa;
-          u1 += v.pm_A1[pidx<2 * D>((2 * a + 1), e)] * xa;
-        }
+      for (int a = 0; a < D; ++a) {
+        const double xa = xg[a];
+        u0 += v.pm_A1[pidx<2 * D>((2 * a), e)] * xa;
+        u1 += v.pm_A1[pidx<2 * D>((2 * a + 1), e)] * xa;
       }
     }
-    pm_u[pidx<2>(0, e)] = u0;
-    pm_u[pidx<2>(1, e)] = u1;
 #pragma unroll
     for (int a = 0; a < DP; ++a)
       w[a] += v.pm_Jp[pidx<2 * DP>((2 * a), e)] * u0 + v.pm_Jp[pidx<2 * DP>((2 * a + 1), e)] * u1;
   }
 #pragma unroll
   for (int a = 0; a < DP; ++a) w[a] = group_sum(w[a], tm.wide);
-  double Vi[NS], z[DP];
+  if (tm.leader) {
+    double z[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int i = 0; i < NS; ++i) Vi[i] = v.Vinv[(size_t)i * NP + lp];
+    for (int b = 0; b < DP; ++b) {
+      double t = 0.0;
 #pragma unroll
-  for (int a = 0; a < DP; ++a) {
-    double t = 0.0;
-#pragma unroll
-    for (int b = 0; b < DP; ++b) t += Vi[a <= b ? sym_idx(a, b, DP) : sym_idx(b, a, DP)] * w[b];
-    z[a] = t;
-  }
-  for (int j = tm.j0; j < k; j += tm.jstep) {
-    const size_t e = base + (size_t)j * 64;
-    const int cpos = v.obs_cpos[e];
-    if (cpos < 0) continue;
-    double t0 = pm_u[pidx<2>(0, e)], t1 = pm_u[pidx<2>(1, e)];
-#pragma unroll
-    for (int a = 0; a < DP; ++a) {
-      t0 -= v.pm_Jp[pidx<2 * DP>((2 * a), e)] * z[a];
-      t1 -= v.pm_Jp[pidx<2 * DP>((2 * a + 1), e)] * z[a];
+      for (int a = 0; a <= b; ++a) t += v.Linv[(size_t)sym_idx(a, b, DP) * NP + lp] * w[a];
+      z[b] = t;
     }
-    *reinterpret_cast<double2*>(cm_t + (size_t)cpos * 2) = make_double2(t0, t1);
+    *reinterpret_cast<double2*>(zhat + (size_t)lp * 4) = make_double2(z[0], z[1]);
+    *reinterpret_cast<double2*>(zhat + (size_t)lp * 4 + 2) = make_double2(z[2], z[3]);
   }
 }
 
@@ -2176,41 +2203,62 @@ __global__ __launch_bounds__(64) void implicit_cameras_q_kernel(DeviceView v, Re
   }
 }
 
-template <int D, int DP, bool SH>
-__global__ __launch_bounds__(64) void implicit_cameras_kernel(DeviceView v, RedLayout L,
-                                                              const double* __restrict__ x,
-                                                              const double* __restrict__ cm_t,
-                                                              double* __restrict__ y, double inv_radius,
-                                                              double lm_lo, double lm_hi, int add_diag,
-                                                              double* __restrict__ grp_part, int dot, int spec) {
-  constexpr int AS = as_of(D, SH);
+// cameras pass with shared intrinsics blocks: one wave per VIEW block (shared blocks: implicit_groups_kernel)
+template <int D, int DP>
+__global__ __launch_bounds__(64) void implicit_cameras_sq_kernel(DeviceView v, RedLayout L,
+                                                                 const double* __restrict__ x,
+                                                                 const double* __restrict__ zhat,
+                                                                 double* __restrict__ y, double inv_radius,
+                                                                 double lm_lo, double lm_hi, int add_diag,
+                                                                 double* __restrict__ grp_part, int spec) {
+  constexpr int AS = as_of(D, true);
   if (spec && *v.pcg_done) return;
   const int rb = blockIdx.x;
-  if (SH && rb >= v.Ncam_rb) return;  // shared blocks: implicit_groups_kernel (dot is not used with SH)
-  double acc[D], acc1[SH ? D : 1];
+  if (rb >= v.Ncam_rb) return;
+  const int cam = v.rb_cam[rb];
+  const int grb = cam >= 0 ? v.cam_grb[cam] : -1;
+  double xc[D], xg[D], acc[D], acc1[D];
 #pragma unroll
-  for (int a = 0; a < D; ++a) acc[a] = 0.0;
-#pragma unroll
-  for (int a = 0; a < (SH ? D : 1); ++a) acc1[a] = 0.0;
-  for (int s = v.cam_ptr[rb] + threadIdx.x; s < v.cam_ptr[rb + 1]; s += 64) {
-    const double* arec = v.cm_A + (size_t)s * (SH ? AS : asa_of(D, DP));
-    const double2 t = *reinterpret_cast<const double2*>(cm_t + (size_t)s * 2);
-#pragma unroll
-    for (int a = 0; a < D; ++a) acc[a] += arec[a] * t.x + arec[D + a] * t.y;
-    if (SH) {
-      // the view's rows of the shared intrinsics block ride in the same record
-#pragma unroll
-      for (int a = 0; a < D; ++a) acc1[a] += arec[a_off_sh(D) + a] * t.x + arec[a_off_sh(D) + D + a] * t.y;
-    }
+  for (int a = 0; a < D; ++a) {
+    xc[a] = x[(size_t)rb * D + a];
+    xg[a] = grb >= 0 ? x[(size_t)grb * D + a] : 0.0;
+    acc[a] = acc1[a] = 0.0;
   }
-  if (SH) {
+  for (int s = v.cam_ptr[rb] + threadIdx.x; s < v.cam_ptr[rb + 1]; s += 64) {
+    const double* arec = v.cm_A + (size_t)s * AS;
+    double rec[4 * D + 12];
+#pragma unroll
+    for (int i = 0; i < 4 * D + 12; i += 2) {
+      const double2 t = *reinterpret_cast<const double2*>(arec + i);
+      rec[i] = t.x;
+      rec[i + 1] = t.y;
+    }
+    const double* zt = zhat + (size_t)v.slot_track[s] * 4;
+    const double2 z01 = *reinterpret_cast<const double2*>(zt);
+    const double2 z23 = *reinterpret_cast<const double2*>(zt + 2);
+    const double z[4] = {z01.x, z01.y, z23.x, z23.y};
+    double t0 = 0.0, t1 = 0.0;
 #pragma unroll
     for (int a = 0; a < D; ++a) {
-      const double tot1 = wave_sum(acc1[a]);
-      if (threadIdx.x == 0) grp_part[(size_t)rb * D + a] = tot1;
+      t0 += rec[a] * xc[a] + rec[sh_off_a1(D) + a] * xg[a];
+      t1 += rec[D + a] * xc[a] + rec[sh_off_a1(D) + D + a] * xg[a];
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      t0 -= rec[sh_off_q(D) + b] * z[b];
+      t1 -= rec[sh_off_q(D) + 4 + b] * z[b];
+    }
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      acc[a] += rec[a] * t0 + rec[D + a] * t1;
+      acc1[a] += rec[sh_off_a1(D) + a] * t0 + rec[sh_off_a1(D) + D + a] * t1;
     }
   }
-  double my_dot = 0.0;
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    const double tot1 = wave_sum(acc1[a]);
+    if (threadIdx.x == 0) grp_part[(size_t)rb * D + a] = tot1;
+  }
 #pragma unroll
   for (int a = 0; a < D; ++a) {
     double tot = wave_sum(acc[a]);
@@ -2218,24 +2266,17 @@ __global__ __launch_bounds__(64) void implicit_cameras_kernel(DeviceView v, RedL
       // the damping (and the identity on padding rows) enters once: on rank 0 when the
       // product is all-reduced afterwards
       if (add_diag) {
-        const double xa = x[(size_t)rb * D + a];
         if (v.rb_cols[(size_t)rb * D + a] < 0) {
-          tot = xa;
+          tot = xc[a];
         } else {
           const double d = v.red[L.udiag + (size_t)rb * D + a];
-          tot += fmin(fmax(d, lm_lo), lm_hi) * inv_radius * xa;
+          tot += fmin(fmax(d, lm_lo), lm_hi) * inv_radius * xc[a];
         }
       } else if (v.rb_cols[(size_t)rb * D + a] < 0) {
         tot = 0.0;
       }
       y[(size_t)rb * D + a] = tot;
-      my_dot += tot * x[(size_t)rb * D + a];
     }
-  }
-  if (dot) {
-    // this rank's share of x . y rides behind the product vector and is all-reduced with it
-    double total;
-    if (last_block_sum<64>(my_dot, v.dotbuf, v.ticket, &total) && threadIdx.x == 0) y[(size_t)v.Nrb * D] = total;
   }
 }
 
@@ -2654,8 +2695,8 @@ __global__ __launch_bounds__(64) void camera_group_partials_kernel(DeviceView v)
       for (int a = 0; a < D; ++a) {
         A0[0][a] = rec[a];
         A0[1][a] = rec[D + a];
-        A1[0][a] = rec[a_off_sh(D) + a];
-        A1[1][a] = rec[a_off_sh(D) + D + a];
+        A1[0][a] = rec[sh_off_a1(D) + a];
+        A1[1][a] = rec[sh_off_a1(D) + D + a];
       }
 #pragma unroll
       for (int a = 0; a < D; ++a)
@@ -2681,10 +2722,10 @@ __global__ __launch_bounds__(64) void camera_group_partials_kernel(DeviceView v)
       double A1[2][D];
 #pragma unroll
       for (int a = 0; a < D; ++a) {
-        A1[0][a] = rec[a_off_sh(D) + a];
-        A1[1][a] = rec[a_off_sh(D) + D + a];
+        A1[0][a] = rec[sh_off_a1(D) + a];
+        A1[1][a] = rec[sh_off_a1(D) + D + a];
       }
-      const double rt0 = rec[a_off_rt(D)], rt1 = rec[a_off_rt(D) + 1], r0 = rec[a_off_r(D)], r1 = rec[a_off_r(D) + 1];
+      const double rt0 = rec[sh_off_rt(D)], rt1 = rec[sh_off_rt(D) + 1], r0 = rec[sh_off_r(D)], r1 = rec[sh_off_r(D) + 1];
 #pragma unroll
       for (int a = 0; a < D; ++a) {
 #pragma unroll

@@ -535,10 +535,12 @@ void ToDeviceOptions(const BundleAdjustmentOptions& options, tmi_ba_options* o) 
   o->loss_function_type = static_cast<int32_t>(options.loss_function_type);
   o->robust_loss_width = options.robust_loss_width;
   o->linear_solver_type = ToAbiSolver(options.linear_solver_type);
-  // ceres::SCHUR_JACOBI (and JACOBI / CLUSTER_*, which the device path maps onto it) -> Ceres' own block shape, one
-  // block per parameter block; the merged per-view block only on request (bundle_adjustment.h, extensions)
+  // ceres::SCHUR_JACOBI (and JACOBI, which the device path maps onto it) -> Ceres' own block shape, one block per
+  // parameter block; the merged per-view block only on request (bundle_adjustment.h, extensions).  CLUSTER_JACOBI /
+  // CLUSTER_TRIDIAGONAL go through: clusters = the shared intrinsics blocks with their views (theia_mi355_ba.h).
   o->preconditioner_type = static_cast<int32_t>(options.preconditioner_type);
-  if (options.preconditioner_type != ceres::IDENTITY && !options.merged_view_blocks_in_preconditioner)
+  if ((options.preconditioner_type == ceres::SCHUR_JACOBI || options.preconditioner_type == ceres::JACOBI) &&
+      !options.merged_view_blocks_in_preconditioner)
     o->preconditioner_type = TMI_BA_PRECOND_SCHUR_JACOBI_PARAMETER_BLOCKS;
   o->verbose = options.verbose ? 1 : 0;
   o->num_threads = options.num_threads;
