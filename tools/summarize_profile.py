@@ -92,9 +92,10 @@ def main():
             classes[cls_of[base]] = classes.get(cls_of[base], 0.0) + r["hbm_bytes_x2fetch"]
     sys.path.insert(0, os.path.dirname(out_dir))
     import bench  # engine_source_sha(): the stamp bench.py checks before quoting these bytes
-    json.dump(dict(tag=tag, workload=workload, correction="2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes",
-                   engine_source_sha=bench.engine_source_sha(), git_head=os.environ.get("TMI_GIT_HEAD"),
-                   classes=classes), open(os.path.join(out_dir, "pmc_latest.json"), "w"), indent=1)
+    if fetch and write:  # only a run with both PMC passes replaces the traffic table
+      json.dump(dict(tag=tag, workload=workload, correction="2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes",
+                     engine_source_sha=bench.engine_source_sha(), git_head=os.environ.get("TMI_GIT_HEAD"),
+                     classes=classes), open(os.path.join(out_dir, "pmc_latest.json"), "w"), indent=1)
     print(open(os.path.join(out_dir, f"{tag}_summary.md")).read())
 
 
