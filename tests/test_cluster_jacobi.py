@@ -132,3 +132,30 @@ def test_device_cluster_jacobi_needs_its_blocks():
     sv.close()
     assert st1 == st2 == 0
     assert s1.final_cost == s2.final_cost and s1.num_linear_solver_iterations == s2.num_linear_solver_iterations
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("mode", [abi.SCHUR_AUTO, abi.SCHUR_EXPLICIT])
+def test_sharded_cluster_jacobi_matches_single_rank(world, mode):
+    """tracks sharded over `world` ranks (threads on one device, the all-reduce hook sums their buffers): the clusters'
+    blocks of S are partial sums on every rank and travel in the all-reduced system like the rest of it; every rank
+    factors the same clusters and ends where the single-rank solve ends"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_sharded import _run_sharded
+    from theiasfm_amd import lib
+    prob = shared_problem(n_views=40, groups=(2, 12), seed=4)
+    tol = dict(function_tolerance=1e-6, gradient_tolerance=1e-10, parameter_tolerance=1e-8, max_num_iterations=12)
+    o = options(abi.PRECOND_CLUSTER_JACOBI, schur_mode=mode, **tol)
+    single = prob.copy()
+    st1, s1 = lib.solve(single, o)
+    assert st1 == 0
+    results = _run_sharded(prob, o, world)
+    for st_r, s_r in results:
+        assert st_r == 0 and s_r.success == 1
+        assert s_r.num_iterations == s1.num_iterations and s_r.num_successful_steps == s1.num_successful_steps
+        assert abs(int(s_r.num_linear_solver_iterations) - int(s1.num_linear_solver_iterations)) <= 1
+        assert abs(s_r.final_cost - s1.final_cost) <= 1e-9 * s1.final_cost
+        assert s_r.final_cost == results[0][1].final_cost

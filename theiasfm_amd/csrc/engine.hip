@@ -1854,6 +1854,12 @@ static int solve_reduced_pcg(tmi_ba_solver* s, const tmi_ba_options* O, int* usa
       *usable = 0;
       break;
     }
+    if (s->cl_active && s->h_flags[FL_CHOL_ABORT]) {
+      // a dataflow launch of the cluster preconditioner could not become co-resident (another process holds part of
+      // the device) and gave up: its output is not to be trusted
+      s->error = "cluster preconditioner: a dataflow launch timed out waiting for the device";
+      return TMI_BA_ERR_DEVICE;
+    }
     if (!(s->h_scal[SC_PQ] > 0.0)) break;  // LINEAR_SOLVER_NO_CONVERGENCE, x kept
     if (s->h_scal[SC_ZETA] < O->eta && it >= O->min_linear_solver_iterations) break;
     if (it >= O->max_linear_solver_iterations) break;
