@@ -665,7 +665,10 @@ struct ResidentSession {
   }
 };
 std::mutex g_session_mutex;
-std::unique_ptr<ResidentSession> g_session;
+// Deliberately leaked holder: a static destructor would call into the HIP runtime after the runtime's own teardown at
+// process exit.  The session is released by an atexit handler registered when the first session is stored -- i.e. after
+// the first HIP call, so it runs before the runtime's exit handlers -- or explicitly (ReleaseBundleAdjustmentSession).
+std::unique_ptr<ResidentSession>& g_session = *new std::unique_ptr<ResidentSession>;
 
 bool SameShape(const BundleAdjustmentOptions& a, const BundleAdjustmentOptions& b) {
   return a.constant_camera_orientation == b.constant_camera_orientation &&
@@ -778,7 +781,17 @@ BundleAdjustmentSummary BundleAdjustReconstruction(const BundleAdjustmentOptions
     for (double* ptr : s->intrinsics_ptr) complete = complete && ptr != nullptr;
     s->point_ptr.resize(f.track_ids.size());
     for (size_t t = 0; t < f.track_ids.size(); ++t) s->point_ptr[t] = reconstruction->MutableTrack(f.track_ids[t])->MutablePoint()->data();
-    if (complete) g_session = std::move(s);
+    if (complete) {
+      static const bool registered = (std::atexit([] {
+        // no lock: the process is exiting single-threaded here; a BA still running in another thread owns the mutex
+        if (g_session_mutex.try_lock()) {
+          g_session.reset();
+          g_session_mutex.unlock();
+        }
+      }), true);
+      (void)registered;
+      g_session = std::move(s);
+    }
   }
   return summary;
 }
