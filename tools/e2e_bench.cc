@@ -117,7 +117,9 @@ int main(int argc, char** argv) {
       second_setup = sum2.setup_time_in_seconds;
       second_solve = sum2.solve_time_in_seconds;
     }
-    ReleaseBundleAdjustmentSession();
+    // (E2E_KEEP_SESSION=1 leaves the last session to the atexit handler: the exit path a caller that never
+    // releases takes)
+    if (!(std::getenv("E2E_KEEP_SESSION") && rep + 1 == repeat)) ReleaseBundleAdjustmentSession();
   }
   printf("{\"entry\": \"theia::BundleAdjustReconstruction\", \"cameras\": %lld, \"tracks\": %lld, "
          "\"observations\": %lld, \"max_num_iterations\": %d, \"use_inner_iterations\": %d, \"success\": %d, "
