@@ -13,6 +13,7 @@
 #include <chrono>
 #include <cstring>
 #include <numeric>
+#include <atomic>
 #include <thread>
 
 namespace tmi {
@@ -230,33 +231,59 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, 
     }
   lap("reduced blocks");
   // ---- tracks: lengths, order by descending length, shard ------------------------
+  // Host threads for the observation-sized passes of this phase (this builder serves the shapes the device builder
+  // does not: shared intrinsics blocks, sharded handles that form S).  Every result is independent of the thread
+  // count: concurrent passes only fill slots whose final order a sort or a per-thread prefix fixes afterwards.
+  const int n_early = (No_all < 200000) ? 1 : (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency() / 2));
+  auto run_early = [&](auto&& body) {
+    if (n_early == 1) {
+      body(0);
+      return;
+    }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < n_early; ++t) pool.emplace_back([&, t] { body(t); });
+    for (auto& th : pool) th.join();
+  };
   std::vector<int> klen(s.Np_total, 0);
-  for (int64_t i = 0; i < No_all; ++i) klen[P->obs_point[i]]++;
+  run_early([&](int t) {
+    const int64_t i0 = No_all * t / n_early, i1 = No_all * (t + 1) / n_early;
+    for (int64_t i = i0; i < i1; ++i) __atomic_fetch_add(&klen[P->obs_point[i]], 1, __ATOMIC_RELAXED);
+  });
   int kmax = 0;
   for (int p = 0; p < s.Np_total; ++p) kmax = std::max(kmax, klen[p]);
-  // CSR of observations by track (caller order preserved inside a track)
+  // CSR of observations by track (the order inside a track is fixed by the sort below)
   std::vector<int64_t> tptr(s.Np_total + 1, 0);
   for (int p = 0; p < s.Np_total; ++p) tptr[p + 1] = tptr[p] + klen[p];
   std::vector<int64_t> tobs(No_all);
   {
     std::vector<int64_t> fill(tptr.begin(), tptr.end() - 1);
-    for (int64_t i = 0; i < No_all; ++i) tobs[fill[P->obs_point[i]]++] = i;
+    run_early([&](int t) {
+      const int64_t i0 = No_all * t / n_early, i1 = No_all * (t + 1) / n_early;
+      for (int64_t i = i0; i < i1; ++i) tobs[__atomic_fetch_add(&fill[P->obs_point[i]], (int64_t)1, __ATOMIC_RELAXED)] = i;
+    });
   }
   // inside a track: a deterministic order; reject a view observing a track twice
-  for (int p = 0; p < s.Np_total; ++p) {
-    auto b = tobs.begin() + tptr[p], e = tobs.begin() + tptr[p + 1];
-    // observations of one shared intrinsics block are kept adjacent (their Y factors
-    // are summed on the fly), then ascending camera index
-    std::sort(b, e, [&](int64_t x, int64_t y) {
-      const int cx = P->obs_camera[x], cy = P->obs_camera[y];
-      if (s.cam_grb[cx] != s.cam_grb[cy]) return s.cam_grb[cx] < s.cam_grb[cy];
-      return cx != cy ? cx < cy : x < y;
-    });
-    for (auto it = b; it != e && it + 1 != e; ++it)
-      if (P->obs_camera[*it] == P->obs_camera[*(it + 1)]) {
-        s.error = "a track is observed twice by the same view";
-        return TMI_BA_ERR_INVALID_ARGUMENT;
+  {
+    std::atomic<int> twice(0);
+    run_early([&](int t) {
+      const int p0 = (int)((int64_t)s.Np_total * t / n_early), p1 = (int)((int64_t)s.Np_total * (t + 1) / n_early);
+      for (int p = p0; p < p1; ++p) {
+        auto b = tobs.begin() + tptr[p], e = tobs.begin() + tptr[p + 1];
+        // observations of one shared intrinsics block are kept adjacent (their Y factors
+        // are summed on the fly), then ascending camera index
+        std::sort(b, e, [&](int64_t x, int64_t y) {
+          const int cx = P->obs_camera[x], cy = P->obs_camera[y];
+          if (s.cam_grb[cx] != s.cam_grb[cy]) return s.cam_grb[cx] < s.cam_grb[cy];
+          return cx != cy ? cx < cy : x < y;
+        });
+        for (auto it = b; it != e && it + 1 != e; ++it)
+          if (P->obs_camera[*it] == P->obs_camera[*(it + 1)]) twice.store(1, std::memory_order_relaxed);
       }
+    });
+    if (twice.load()) {
+      s.error = "a track is observed twice by the same view";
+      return TMI_BA_ERR_INVALID_ARGUMENT;
+    }
   }
   // Order: descending length, then the track's lowest view index, then its index (two stable counting
   // sorts).  Tracks seen from the same views share slices, so a wave's parameter gathers and the gathers of a
@@ -271,11 +298,14 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, 
         if (klen[p] > 0) by_cam.push_back(p);
     } else {
       std::vector<int> first_cam(s.Np_total, 0);
-      for (int p = 0; p < s.Np_total; ++p) {
-        int c = s.Nc;
-        for (int64_t q = tptr[p]; q < tptr[p + 1]; ++q) c = std::min(c, (int)P->obs_camera[tobs[q]]);
-        first_cam[p] = c;
-      }
+      run_early([&](int t) {
+        const int p0 = (int)((int64_t)s.Np_total * t / n_early), p1 = (int)((int64_t)s.Np_total * (t + 1) / n_early);
+        for (int p = p0; p < p1; ++p) {
+          int c = s.Nc;
+          for (int64_t q = tptr[p]; q < tptr[p + 1]; ++q) c = std::min(c, (int)P->obs_camera[tobs[q]]);
+          first_cam[p] = c;
+        }
+      });
       std::vector<int> cpos(s.Nc + 2, 0);
       int total = 0;
       for (int p = 0; p < s.Np_total; ++p)
@@ -391,34 +421,52 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, 
   s.No = 0;
   // camera-major slot counts: one slot per observation in its camera's block, and one
   // slot per (track, shared intrinsics block) in that block
-  std::vector<int> slot_cnt(s.Nrb + 1, 0);
-  for (int lp = 0; lp < s.Np_pad; ++lp) {
-    const int p = s.pt_orig[lp];
-    if (p < 0) continue;
-    const int sl = lp >> 6, t = lp & 63;
-    int prev_g = -1;
-    for (int j = 0; j < klen[p]; ++j) {
-      const int64_t i = tobs[tptr[p] + j];
-      const int64_t e = (int64_t)s.slice_ptr[sl] + (int64_t)j * 64 + t;
-      const int c = P->obs_camera[i];
-      s.obs_cam[e] = c;
-      s.obs_xy[2 * e] = P->obs_xy[2 * i];
-      s.obs_xy[2 * e + 1] = P->obs_xy[2 * i + 1];
-      s.obs_orig[e] = i;
-      const int rb = s.cam_rb[c];
-      if (rb >= 0) slot_cnt[rb + 1]++;
-      const int g = s.cam_grb[c];
-      if (g >= 0 && g != prev_g) slot_cnt[g + 1]++;
-      prev_g = g;
-      s.No++;
+  // (threads own contiguous ranges of the layout; a slot's number = the block's first slot + the slots of the
+  // earlier threads in that block + the thread's own running count: the numbering of the sequential loop)
+  std::vector<std::vector<int>> slot_cnt_t(n_early, std::vector<int>(s.Nrb + 1, 0));
+  std::vector<int64_t> no_t(n_early, 0);
+  run_early([&](int th) {
+    std::vector<int>& slot_cnt = slot_cnt_t[th];
+    const int lp0 = (int)((int64_t)s.Np_pad * th / n_early), lp1 = (int)((int64_t)s.Np_pad * (th + 1) / n_early);
+    for (int lp = lp0; lp < lp1; ++lp) {
+      const int p = s.pt_orig[lp];
+      if (p < 0) continue;
+      const int sl = lp >> 6, t = lp & 63;
+      int prev_g = -1;
+      for (int j = 0; j < klen[p]; ++j) {
+        const int64_t i = tobs[tptr[p] + j];
+        const int64_t e = (int64_t)s.slice_ptr[sl] + (int64_t)j * 64 + t;
+        const int c = P->obs_camera[i];
+        s.obs_cam[e] = c;
+        s.obs_xy[2 * e] = P->obs_xy[2 * i];
+        s.obs_xy[2 * e + 1] = P->obs_xy[2 * i + 1];
+        s.obs_orig[e] = i;
+        const int rb = s.cam_rb[c];
+        if (rb >= 0) slot_cnt[rb + 1]++;
+        const int g = s.cam_grb[c];
+        if (g >= 0 && g != prev_g) slot_cnt[g + 1]++;
+        prev_g = g;
+        no_t[th]++;
+      }
     }
-  }
+  });
+  for (int th = 0; th < n_early; ++th) s.No += no_t[th];
   s.cam_ptr.assign(s.Nrb + 1, 0);
-  for (int rb = 0; rb < s.Nrb; ++rb) s.cam_ptr[rb + 1] = s.cam_ptr[rb] + slot_cnt[rb + 1];
+  for (int rb = 0; rb < s.Nrb; ++rb) {
+    int tot = 0;
+    for (int th = 0; th < n_early; ++th) {
+      const int c = slot_cnt_t[th][rb + 1];
+      slot_cnt_t[th][rb + 1] = tot;  // slots of this block owned by earlier threads
+      tot += c;
+    }
+    s.cam_ptr[rb + 1] = s.cam_ptr[rb] + tot;
+  }
   s.Nslots = s.cam_ptr[s.Nrb];
-  {
-    std::vector<int> fill(s.cam_ptr.begin(), s.cam_ptr.end() - 1);
-    for (int lp = 0; lp < s.Np_pad; ++lp) {
+  run_early([&](int th) {
+    std::vector<int> fill(s.Nrb, 0);
+    for (int rb = 0; rb < s.Nrb; ++rb) fill[rb] = s.cam_ptr[rb] + slot_cnt_t[th][rb + 1];
+    const int lp0 = (int)((int64_t)s.Np_pad * th / n_early), lp1 = (int)((int64_t)s.Np_pad * (th + 1) / n_early);
+    for (int lp = lp0; lp < lp1; ++lp) {
       const int p = s.pt_orig[lp];
       if (p < 0) continue;
       const int sl = lp >> 6, t = lp & 63;
@@ -449,7 +497,7 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, 
         prev_g = g;
       }
     }
-  }
+  });
 
   lap("track order, layout, slots");
   // ---- block structure of S from ALL tracks (rank independent) -------------------
