@@ -142,28 +142,30 @@ __global__ __launch_bounds__(256) void cluster_apply_kernel(const ClusterDesc* _
     for (int J = g; J < d.T; J += d.wgn) {
       const int row = tid >> 2, q = tid & 3;
       double acc = 0.0;
+      {  // X_J into LDS BEFORE the wait for the last y_K: off the chain  y_{J-1} -> y_J
+        cdf::v2d t[8];
+        cdf::tile_fetch(cl + (size_t)J * TILE, t);
+        cdf::tile_stage(t, X);
+      }
       for (int K = 0; K < J; ++K) {
+        // the factor's tile is static: fetched before the wait for y_K, so only the flag, 64 doubles and the FMAs
+        // sit between y_K and this row's partial sum
+        const cdf::v2d* p = reinterpret_cast<const cdf::v2d*>(ct + cdf::tile_index(J, K) * TILE + (size_t)row * TS + 16 * q);
+        cdf::v2d l[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) l[u] = p[u];
         if (tid == 0) sh[0] = cdf::spin_until(yflag + K, epoch, ctrl) ? 1 : 0;
         __syncthreads();
         if (!sh[0]) return;
         if (tid < TS) ws[tid] = cdf::ld_wt(y + TS * K + tid);
         __syncthreads();
-        const cdf::v2d* p = reinterpret_cast<const cdf::v2d*>(ct + cdf::tile_index(J, K) * TILE + (size_t)row * TS + 16 * q);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const cdf::v2d l = p[u];
-          acc += l[0] * ws[16 * q + 2 * u] + l[1] * ws[16 * q + 2 * u + 1];
-        }
+        for (int u = 0; u < 8; ++u) acc += l[u][0] * ws[16 * q + 2 * u] + l[u][1] * ws[16 * q + 2 * u + 1];
         __syncthreads();
       }
       acc += __shfl_xor(acc, 1, 64);
       acc += __shfl_xor(acc, 2, 64);
       if (q == 0) ws[row] = ((TS * J + row < d.n) ? r[map[TS * J + row]] : 0.0) - acc;
-      {
-        cdf::v2d t[8];
-        cdf::tile_fetch(cl + (size_t)J * TILE, t);
-        cdf::tile_stage(t, X);
-      }
       __syncthreads();
       {
         double s = 0.0;
@@ -182,19 +184,27 @@ __global__ __launch_bounds__(256) void cluster_apply_kernel(const ClusterDesc* _
     for (int J = Jlast; J >= 0; J -= d.wgn) {
       const int c2 = tid & 31, rg = tid >> 5;
       double s0 = 0.0, s1 = 0.0;
+      __syncthreads();  // (the previous row's reads of X are done)
+      {
+        cdf::v2d t[8];
+        cdf::tile_fetch(cl + (size_t)J * TILE, t);
+        cdf::tile_stage(t, X);
+      }
       for (int I = d.T - 1; I > J; --I) {
+        const cdf::v2d* p = reinterpret_cast<const cdf::v2d*>(ct + cdf::tile_index(I, J) * TILE);
+        cdf::v2d l[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) l[u] = p[(rg + 8 * u) * 32 + c2];
         if (tid == 0) sh[0] = cdf::spin_until(xflag + I, epoch, ctrl) ? 1 : 0;
         __syncthreads();
         if (!sh[0]) return;
         if (tid < TS) ws[tid] = cdf::ld_wt(x + TS * I + tid);
         __syncthreads();
-        const cdf::v2d* p = reinterpret_cast<const cdf::v2d*>(ct + cdf::tile_index(I, J) * TILE);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int row = rg + 8 * u;
-          const cdf::v2d l = p[row * 32 + c2];
-          s0 += l[0] * ws[row];
-          s1 += l[1] * ws[row];
+          s0 += l[u][0] * ws[row];
+          s1 += l[u][1] * ws[row];
         }
         __syncthreads();
       }
@@ -208,11 +218,6 @@ __global__ __launch_bounds__(256) void cluster_apply_kernel(const ClusterDesc* _
 #pragma unroll
         for (int k = 0; k < 8; ++k) wv -= part[k * TS + tid];
         ws[tid] = wv;
-      }
-      {
-        cdf::v2d t[8];
-        cdf::tile_fetch(cl + (size_t)J * TILE, t);
-        cdf::tile_stage(t, X);
       }
       __syncthreads();
       {
