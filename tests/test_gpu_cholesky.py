@@ -18,6 +18,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="module")
 def harness():
     import __graft_entry__ as entry
+    # torch first, as theiasfm_amd.lib does: the process must end up with ONE HIP runtime (torch ships its own
+    # libamdhip64; a library that pulls in /opt/rocm's before torch initialises leaves torch without a device)
+    import torch  # noqa: F401
     return C.CDLL(entry.build_chol_harness())
 
 

@@ -477,38 +477,47 @@ __device__ __forceinline__ bool substitute_block(const Args& a, int J, double (*
   const int rl = a.n - TS * (a.T - 1);  // local row of the right-hand side in the last tile row
   const int c2 = tid & 31, rg = tid >> 5;
   double s0 = 0.0, s1 = 0.0;  // partial sums of columns 2 c2, 2 c2 + 1 over rows rg, rg + 8, ...
+  // Everything that does not depend on x_I is fetched before the wait for it (the factor is final by now, the flags are
+  // still checked): X_J goes to LDS up front, a tile's loads are in flight while the flag of x_I is polled.
+  if (tid == 0) sh[0] = (spin_until(a.tflag + tile_index(a.T - 1, J), a.epoch, a.ctrl) && spin_until(a.dflag + J, a.epoch, a.ctrl)) ? 1 : 0;
+  __syncthreads();
+  if (!sh[0]) return false;
+  {
+    v2d r[8];
+    tile_fetch(a.linv + (size_t)J * TILE, r);
+    tile_stage(r, Pi);
+  }
   for (int I = Treal - 1; I > J; --I) {
-    if (tid == 0) sh[0] = (spin_until(a.xflag + I, a.epoch, a.ctrl) && spin_until(a.tflag + tile_index(I, J), a.epoch, a.ctrl)) ? 1 : 0;
+    __syncthreads();  // sh[0] / xs of the previous step are free
+    if (tid == 0) sh[0] = spin_until(a.tflag + tile_index(I, J), a.epoch, a.ctrl) ? 1 : 0;
     __syncthreads();
     if (!sh[0]) return false;
+    const v2d* p = reinterpret_cast<const v2d*>(a.tiles + tile_index(I, J) * TILE);
+    v2d l[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) l[u] = p[(rg + 8 * u) * 32 + c2];
+    if (tid == 0) sh[1] = spin_until(a.xflag + I, a.epoch, a.ctrl) ? 1 : 0;
+    __syncthreads();
+    if (!sh[1]) return false;
     if (tid < TS) xs[tid] = (TS * I + tid < a.n) ? ld_wt(a.x + TS * I + tid) : 0.0;
     __syncthreads();
-    const v2d* p = reinterpret_cast<const v2d*>(a.tiles + tile_index(I, J) * TILE);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int row = rg + 8 * u;
-      const v2d l = p[row * 32 + c2];
-      s0 += l[0] * xs[row];
-      s1 += l[1] * xs[row];
+      s0 += l[u][0] * xs[row];
+      s1 += l[u][1] * xs[row];
     }
-    __syncthreads();
   }
+  __syncthreads();
   // y_J: the right-hand-side row of the factor
-  if (tid == 0) sh[0] = (spin_until(a.tflag + tile_index(a.T - 1, J), a.epoch, a.ctrl) && spin_until(a.dflag + J, a.epoch, a.ctrl)) ? 1 : 0;
   part[rg * TS + 2 * c2] = s0;
   part[rg * TS + 2 * c2 + 1] = s1;
   __syncthreads();
-  if (!sh[0]) return false;
   if (tid < TS) {
     double wv = (TS * J + tid < a.n) ? ld_wt(a.tiles + tile_index(a.T - 1, J) * TILE + (size_t)rl * TS + tid) : 0.0;
 #pragma unroll
     for (int g = 0; g < 8; ++g) wv -= part[g * TS + tid];
     xs[tid] = wv;
-  }
-  {  // X_J into LDS
-    v2d r[8];
-    tile_fetch(a.linv + (size_t)J * TILE, r);
-    tile_stage(r, Pi);
   }
   __syncthreads();
   // x_J[c] = sum_{r >= c} X[r][c] w[r]; 4 threads per column

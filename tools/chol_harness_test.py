@@ -2,6 +2,10 @@
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Itheiasfm_amd/csrc -o tools/libcholh.so tools/chol_harness.hip
   python tools/chol_harness_test.py [n ...]"""
 import ctypes as C, numpy as np, sys, time
+try:
+    import torch  # noqa: F401  (one HIP runtime per process: torch ships its own libamdhip64)
+except ImportError:
+    pass
 L = C.CDLL("tools/libcholh.so" if len(sys.argv) < 2 or not sys.argv[1].endswith(".so") else sys.argv[1])
 def run(fn, A, b, reps=3):
     n = A.shape[0]; x = np.zeros(n); ms = C.c_double(); info = (C.c_int * 8)()
