@@ -128,6 +128,16 @@ class BundleAdjuster {
     void SetIfAbsent(uint32_t id, int value) {
       if (Get(id) < 0) Set(id, value);
     }
+    // For threads that write DISJOINT ids of a table Reserve() has pre-sized: touches flat_[id] and nothing else (no
+    // resize, no count_, no sparse_ -- Set() updates all three and must not run concurrently).  True when the id was
+    // absent; the caller sums those and reports them with NoteAdded() after the join.  sparse_ must not be mutated
+    // while such a pass runs (Get() reads it).
+    bool SetPresized(uint32_t id, int value) {
+      const bool fresh = flat_[id] < 0;
+      flat_[id] = static_cast<int16_t>(value);
+      return fresh;
+    }
+    void NoteAdded(size_t n) { count_ += n; }
     // make ids 0..max_id flat-addressable up front (so that concurrent readers never see a resize);
     // false if max_id is beyond the flat range
     // ... or so far above the number of ids that a dense table would be mostly holes (sub-reconstructions, merged

@@ -322,6 +322,8 @@ static void TestResidentSessionGpu() {
   BundleAdjustmentOptions opt;
   opt.linear_solver_type = ceres::ITERATIVE_SCHUR;
   opt.max_num_iterations = 4;  // stop early so that the second call still has work to do
+  opt.keep_problem_resident = true;  // an extension, off by default (bundle_adjustment.h)
+  EXPECT(!BundleAdjustmentOptions().keep_problem_resident);
   opt.function_tolerance = -1.0;
   opt.gradient_tolerance = -1.0;
   opt.parameter_tolerance = -1.0;
@@ -386,6 +388,28 @@ static void TestResidentSessionGpu() {
     // a copy is a different object even though it starts out identical
     Reconstruction C = A;
     EXPECT(!BundleAdjustmentSessionIsResident(&C));
+    // A residual-set change that NO stamped mutator saw (copy-assignment through MutableTrack(): what data-model
+    // classes without the hooks look like to the session): the structural fingerprint must catch it.  The shorter
+    // track is prepared BEFORE the session is built, so the stamp does not move afterwards.
+    {
+      Reconstruction E, F;
+      BuildScene(&E, 7, 260, shared, 33, 0.3);
+      BuildScene(&F, 7, 260, shared, 33, 0.3);
+      Track shorter = *E.Track(12);
+      const ViewId dropped = *shorter.ViewIds().begin();
+      shorter.RemoveView(dropped);
+      const BundleAdjustmentSummary e1 = BundleAdjustReconstruction(opt, &E);
+      const BundleAdjustmentSummary f1 = BundleAdjustReconstruction(one_shot, &F);
+      EXPECT(e1.success && f1.success && e1.final_cost == f1.final_cost && BundleAdjustmentSessionIsResident(&E));
+      *E.MutableTrack(12) = shorter;  // no stamp
+      *F.MutableTrack(12) = shorter;
+      EXPECT(BundleAdjustmentSessionIsResident(&E));  // the stamp alone still says "valid" ...
+      const BundleAdjustmentSummary e2 = BundleAdjustReconstruction(opt, &E);
+      const BundleAdjustmentSummary f2 = BundleAdjustReconstruction(one_shot, &F);
+      // ... the fingerprint does not: the call rebuilt the problem and equals the from-scratch one bit for bit
+      EXPECT(e2.success && e2.initial_cost == f2.initial_cost && e2.final_cost == f2.final_cost && snapshot(E) == snapshot(F));
+      EXPECT(e2.initial_cost != e1.final_cost);  // one residual fewer than the kept session would have solved
+    }
   }
   ReleaseBundleAdjustmentSession();
 }

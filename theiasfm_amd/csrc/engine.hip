@@ -27,6 +27,7 @@
 #include "dense_cholesky_df.h"
 #include "cluster_precond.h"
 #include "kernels.h"
+#include "mf_chunks.h"
 #include "track_kernels.h"
 #include "inner_kernels.h"
 #include "two_view_kernels.h"
@@ -76,6 +77,9 @@ struct Launch {
   void (*spmv)(const DeviceView&, hipStream_t, const double*, const double*, double*, int dot, int spec);
   void (*implicit_spmv)(const DeviceView&, hipStream_t, RedLayout, const double*, double*, double*,
                         double*, double, double, double, int, int, int dot, int spec);
+  // the one-sweep matrix-free product of mf_chunks.h (no shared intrinsics blocks)
+  void (*mf_product)(const DeviceView&, const mfc::View&, hipStream_t, RedLayout, const double*, double*, double, double,
+                     double, int, int dot, int spec);
   void (*pcg_step)(const DeviceView&, hipStream_t, const double* b, int it, int nb, double eta, int min_it,
                    int max_it, const double* red8, HostMirror* mirror, unsigned long long seq);
   void (*pcg_a)(const DeviceView&, hipStream_t, int, int);
@@ -206,6 +210,13 @@ Launch make_launch(bool fp32) {
       hipLaunchKernelGGL((implicit_groups_kernel<D>), dim3(v.Nrb - v.Ncam_rb), dim3(64), 0, st, v, R, x, v.cam_part,
                          y, ir, lo, hi, add_diag);
   };
+  L.mf_product = [](const DeviceView& v, const mfc::View& m, hipStream_t st, RedLayout R, const double* x, double* y,
+                    double ir, double lo, double hi, int add_diag, int dot, int spec) {
+    if (!v.Nrb) return;
+    if (m.n_items) hipLaunchKernelGGL((mfc::product_kernel<D, DP>), dim3(m.n_items), dim3(mfc::kThreads), 0, st, v, m, x, spec);
+    hipLaunchKernelGGL((mfc::reduce_kernel<D>), dim3(8 * ((v.Nrb + 7) / 8)), dim3(256), 0, st, v, m, R, x, y, ir, lo, hi,
+                       add_diag, dot, spec);
+  };
   L.pcg_a = [](const DeviceView& v, hipStream_t st, int n, int it) {
     hipLaunchKernelGGL((pcg_a_kernel<D>), dim3(1), dim3(1024), 0, st, v, n, it);
   };
@@ -302,6 +313,8 @@ struct tmi_ba_solver {
   double* d_pm_u = nullptr;
   double* d_cm_t = nullptr;   // implicit Schur operator: t_i per camera-major slot (shared intrinsics blocks only)
   bool need_slot_track = false;
+  mfc::View mf = {};          // one-sweep matrix-free product (mf_chunks.h); mf_ok: built and in use
+  bool mf_ok = false;
   bool implicit = false;      // S is never formed (schur_mode)
   bool adaptive = false;      // schur_mode auto on one rank: both operators are resident and every LM iteration
                               // takes the cheaper one for the PCG length it expects (see solve)
@@ -1145,6 +1158,251 @@ void tmi_ba_solver_destroy(tmi_ba_solver* s) {
   delete s;
 }
 
+
+// ---- static structure of the one-sweep matrix-free product (mf_chunks.h): units, runs, items, slots ----------
+// From the resident layout (slice_ptr, obs_rb): works for host- and device-built structures and for every rank of a
+// sharded handle.  Leaves s->mf_ok = false (the two-pass product of kernels.h stays in use) when the problem does not
+// fit the kernel: a thread-per-track slice longer than kMaxNarrowK rows.
+static int build_mf_chunks(tmi_ba_solver* s) {
+  using namespace tmi::mfc;
+  s->mf_ok = false;
+  if (getenv("TMI_BA_MF_TWO_PASS")) return TMI_BA_OK;  // A/B: round 3's two-pass product
+  Structure& st = s->st;
+  DeviceView& v = s->v;
+  hipStream_t stream = s->stream;
+  if (st.has_shared || st.Nrb == 0 || st.No_pad == 0 || st.nslices == 0) return TMI_BA_OK;
+  const int Nrb = st.Nrb, D = st.D;
+  const int nub = 16 * st.n_ultra, nwb = nub + 4 * (st.n_wide - st.n_ultra);
+  const int n_narrow = st.nslices - st.n_wide;
+  const int n_units = nwb + n_narrow;
+  auto rows_of = [&](int sl) { return (st.slice_ptr[sl + 1] - st.slice_ptr[sl]) >> 6; };
+  if (n_narrow > 0 && rows_of(st.n_wide) > kMaxNarrowK) return TMI_BA_OK;
+  if (!s->num_cus) {
+    hipDeviceProp_t prop;
+    TMI_HIP(hipGetDeviceProperties(&prop, s->device));
+    s->num_cus = prop.multiProcessorCount;
+  }
+  const long long n = st.No_pad;
+  TempPool tmp;
+  void* cub_tmp = nullptr;
+  size_t cub_cap = 0;
+  struct CubFree {
+    void** p;
+    ~CubFree() {
+      if (*p) hipFree(*p);
+    }
+  } cub_free{&cub_tmp};
+  auto cub_reserve = [&](size_t bytes) -> int {
+    if (bytes <= cub_cap) return TMI_BA_OK;
+    if (cub_tmp) hipFree(cub_tmp);
+    cub_tmp = nullptr;
+    cub_cap = 0;
+    TMI_HIP(hipMalloc(&cub_tmp, bytes + 256));
+    cub_cap = bytes + 256;
+    return TMI_BA_OK;
+  };
+  int rc;
+#define MF_SORT_PAIRS(kin, kout, vin, vout, cnt, bits)                                                      \
+  do {                                                                                                      \
+    size_t bytes_ = 0;                                                                                      \
+    TMI_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes_, kin, kout, vin, vout, (int)(cnt), 0, bits, stream)); \
+    if ((rc = cub_reserve(bytes_))) return rc;                                                              \
+    TMI_HIP(hipcub::DeviceRadixSort::SortPairs(cub_tmp, bytes_, kin, kout, vin, vout, (int)(cnt), 0, bits, stream)); \
+  } while (0)
+#define MF_EXCLUSIVE_SUM(in, out, cnt)                                                                      \
+  do {                                                                                                      \
+    size_t bytes_ = 0;                                                                                      \
+    TMI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes_, in, out, (int)(cnt), stream));                \
+    if ((rc = cub_reserve(bytes_))) return rc;                                                              \
+    TMI_HIP(hipcub::DeviceScan::ExclusiveSum(cub_tmp, bytes_, in, out, (int)(cnt), stream));                \
+  } while (0)
+  auto nb = [](long long c) { return dim3((unsigned)std::max<long long>((c + 255) / 256, 1)); };
+
+  // ---- runs: the observations sorted by (unit, view block)
+  const unsigned long long invalid = (unsigned long long)n_units * (unsigned)Nrb;
+  const int key_bits = bits_for(invalid + 1);
+  unsigned long long *d_k_in, *d_k_out;
+  int *d_v_in, *d_v_out, *d_head, *d_pos, *d_nvalid;
+  TMI_HIP(tmp.get(&d_k_in, (size_t)n));
+  TMI_HIP(tmp.get(&d_k_out, (size_t)n));
+  TMI_HIP(tmp.get(&d_v_in, (size_t)n));
+  TMI_HIP(tmp.get(&d_v_out, (size_t)n));
+  TMI_HIP(tmp.get(&d_head, (size_t)n + 1));
+  TMI_HIP(tmp.get(&d_pos, (size_t)n + 1));
+  TMI_HIP(tmp.get(&d_nvalid, 1));
+  hipLaunchKernelGGL(unit_keys_kernel, dim3(n_units), dim3(256), 0, stream, v, nub, nwb, Nrb, invalid, d_k_in, d_v_in);
+  MF_SORT_PAIRS(d_k_in, d_k_out, d_v_in, d_v_out, n, key_bits);
+  int n_valid = (int)n;
+  TMI_HIP(hipMemcpyAsync(d_nvalid, &n_valid, sizeof(int), hipMemcpyHostToDevice, stream));
+  hipLaunchKernelGGL(heads_kernel, nb(n + 1), dim3(256), 0, stream, d_k_out, n, invalid, d_head, d_nvalid);
+  MF_EXCLUSIVE_SUM(d_head, d_pos, n + 1);
+  int n_runs = 0;
+  TMI_HIP(hipMemcpyAsync(&n_runs, d_pos + n, sizeof(int), hipMemcpyDeviceToHost, stream));
+  TMI_HIP(hipMemcpyAsync(&n_valid, d_nvalid, sizeof(int), hipMemcpyDeviceToHost, stream));
+  TMI_HIP(hipStreamSynchronize(stream));
+  if (n_runs == 0) return TMI_BA_OK;
+  int *d_run_first, *d_unit_run_ptr;
+  unsigned long long* d_run_key;
+  TMI_HIP(tmp.get(&d_run_first, (size_t)n_runs + 1));
+  TMI_HIP(tmp.get(&d_run_key, (size_t)n_runs));
+  TMI_HIP(tmp.get(&d_unit_run_ptr, (size_t)n_units + 1));
+  hipLaunchKernelGGL(run_fill_kernel, nb(n), dim3(256), 0, stream, d_k_out, d_head, d_pos, n, d_run_first, d_run_key);
+  TMI_HIP(hipMemcpyAsync(d_run_first + n_runs, &n_valid, sizeof(int), hipMemcpyHostToDevice, stream));
+  hipLaunchKernelGGL(lower_bound_stride_kernel, nb(n_units + 1), dim3(256), 0, stream, d_run_key, (long long)n_runs,
+                     (unsigned long long)Nrb, n_units, d_unit_run_ptr);
+
+  // ---- items: wide / ultra units one each; the narrow slices in groups of about equal size, cut where the slice
+  // length changes (the track order restarts at the lowest view there) and regrouped smaller when an item sees more
+  // views than its accumulators hold
+  unsigned long long *d_sk_in, *d_sk_out, *d_slot_key;
+  int *d_sv_in, *d_sv_out, *d_head2, *d_pos2, *d_unit_item, *d_item_unit0, *d_run_slot, *d_slot_rb, *d_item_slot_ptr;
+  TMI_HIP(tmp.get(&d_sk_in, (size_t)n_runs));
+  TMI_HIP(tmp.get(&d_sk_out, (size_t)n_runs));
+  TMI_HIP(tmp.get(&d_sv_in, (size_t)n_runs));
+  TMI_HIP(tmp.get(&d_sv_out, (size_t)n_runs));
+  TMI_HIP(tmp.get(&d_head2, (size_t)n_runs + 1));
+  TMI_HIP(tmp.get(&d_pos2, (size_t)n_runs + 1));
+  TMI_HIP(tmp.get(&d_unit_item, (size_t)n_units));
+  TMI_HIP(tmp.get(&d_item_unit0, (size_t)n_units + 1));
+  TMI_HIP(tmp.get(&d_run_slot, (size_t)n_runs));
+  TMI_HIP(tmp.get(&d_slot_rb, (size_t)n_runs));
+  TMI_HIP(tmp.get(&d_slot_key, (size_t)n_runs));
+  TMI_HIP(tmp.get(&d_item_slot_ptr, (size_t)n_units + 1));
+  const long long narrow_elems = (long long)st.slice_ptr[st.nslices] - st.slice_ptr[st.n_wide];
+  long long target = std::max<long long>(64, std::min<long long>(4096, narrow_elems / std::max(1, 4 * s->num_cus)));
+  if (const char* e = getenv("TMI_BA_MF_ITEM")) target = std::max(64, atoi(e));  // A/B: elements per item
+  // narrow items as unit ranges: about `target` elements each, cut where the slice length changes
+  std::vector<std::pair<int, int>> groups;
+  {
+    long long have = 0;
+    int last_rows = -1;
+    for (int sl = st.n_wide; sl < st.nslices; ++sl) {
+      const int u = nwb + (sl - st.n_wide), rows = rows_of(sl);
+      if (last_rows < 0 || rows != last_rows || have >= target) {
+        groups.emplace_back(u, u + 1);
+        have = 0;
+      } else {
+        groups.back().second = u + 1;
+      }
+      have += (long long)rows * 64;
+      last_rows = rows;
+    }
+  }
+  std::vector<int> unit_item((size_t)n_units), item_unit0, item_slot_ptr;
+  int n_items = 0, n_slots = 0;
+  for (int attempt = 0;; ++attempt) {
+    item_unit0.clear();
+    for (int u = 0; u < nwb; ++u) {
+      item_unit0.push_back(u);
+      unit_item[u] = u;
+    }
+    for (const auto& g : groups) {
+      for (int u = g.first; u < g.second; ++u) unit_item[u] = (int)item_unit0.size();
+      item_unit0.push_back(g.first);
+    }
+    n_items = (int)item_unit0.size();
+    item_unit0.push_back(n_units);
+    TMI_HIP(hipMemcpyAsync(d_unit_item, unit_item.data(), (size_t)n_units * sizeof(int), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(slot_keys_kernel, nb(n_runs), dim3(256), 0, stream, d_run_key, n_runs, d_unit_item, Nrb, d_sk_in, d_sv_in);
+    MF_SORT_PAIRS(d_sk_in, d_sk_out, d_sv_in, d_sv_out, n_runs, bits_for((unsigned long long)n_items * (unsigned)Nrb + 1));
+    hipLaunchKernelGGL(heads_kernel, nb(n_runs + 1), dim3(256), 0, stream, d_sk_out, (long long)n_runs, ~0ull, d_head2, d_nvalid);
+    MF_EXCLUSIVE_SUM(d_head2, d_pos2, n_runs + 1);
+    TMI_HIP(hipMemcpyAsync(&n_slots, d_pos2 + n_runs, sizeof(int), hipMemcpyDeviceToHost, stream));
+    hipLaunchKernelGGL(slot_fill_kernel, nb(n_runs), dim3(256), 0, stream, d_sk_out, d_head2, d_pos2, d_sv_out, n_runs, Nrb,
+                       d_run_slot, d_slot_rb, d_slot_key);
+    TMI_HIP(hipStreamSynchronize(stream));
+    hipLaunchKernelGGL(lower_bound_stride_kernel, nb(n_items + 1), dim3(256), 0, stream, d_slot_key, (long long)n_slots,
+                       (unsigned long long)Nrb, n_items, d_item_slot_ptr);
+    item_slot_ptr.resize((size_t)n_items + 1);
+    TMI_HIP(hipMemcpyAsync(item_slot_ptr.data(), d_item_slot_ptr, ((size_t)n_items + 1) * sizeof(int), hipMemcpyDeviceToHost, stream));
+    TMI_HIP(hipStreamSynchronize(stream));
+    // an item of several slices that sees more views than the accumulators hold is cut in two (an item of one slice
+    // needs none: mf_chunks.h)
+    std::vector<std::pair<int, int>> next;
+    bool split = false;
+    for (size_t g = 0; g < groups.size(); ++g) {
+      const int i = nwb + (int)g, views = item_slot_ptr[i + 1] - item_slot_ptr[i];
+      const int u0 = groups[g].first, u1 = groups[g].second;
+      if (views > lc_max(D) && u1 - u0 > 1) {
+        const int mid = u0 + (u1 - u0) / 2;
+        next.emplace_back(u0, mid);
+        next.emplace_back(mid, u1);
+        split = true;
+      } else {
+        next.push_back(groups[g]);
+      }
+    }
+    if (!split) break;
+    if (attempt >= 16) return TMI_BA_OK;  // cannot happen (an item halves every round); the two-pass product serves
+    groups.swap(next);
+  }
+
+  // ---- persistent arrays
+  View& m = s->mf;
+  memset(&m, 0, sizeof(m));
+  m.n_items = n_items;
+  m.n_units = n_units;
+  m.n_runs = n_runs;
+  m.nub = nub;
+  m.nwb = nwb;
+  int *p_item_unit0, *p_unit_run_ptr, *p_run_obs_ptr, *p_run_obs, *p_run_slot, *p_item_slot_ptr, *p_slot_rb, *p_obs_pos,
+      *p_cam_slot_ptr, *p_cam_slots;
+  if ((rc = dev_upload(s, &p_item_unit0, item_unit0))) return rc;
+  if ((rc = dev_alloc(s, &p_unit_run_ptr, (size_t)n_units + 1))) return rc;
+  if ((rc = dev_alloc(s, &p_run_obs_ptr, (size_t)n_runs + 1))) return rc;
+  if ((rc = dev_alloc(s, &p_run_obs, (size_t)std::max(n_valid, 1)))) return rc;
+  if ((rc = dev_alloc(s, &p_run_slot, (size_t)n_runs))) return rc;
+  if ((rc = dev_alloc(s, &p_item_slot_ptr, (size_t)n_items + 1))) return rc;
+  if ((rc = dev_alloc(s, &p_slot_rb, (size_t)n_slots))) return rc;
+  if ((rc = dev_alloc(s, &p_obs_pos, (size_t)n))) return rc;
+  if ((rc = dev_alloc(s, &p_cam_slot_ptr, (size_t)Nrb + 1))) return rc;
+  if ((rc = dev_alloc(s, &p_cam_slots, (size_t)n_slots))) return rc;
+  TMI_HIP(hipMemcpyAsync(p_unit_run_ptr, d_unit_run_ptr, ((size_t)n_units + 1) * sizeof(int), hipMemcpyDeviceToDevice, stream));
+  TMI_HIP(hipMemcpyAsync(p_run_obs_ptr, d_run_first, ((size_t)n_runs + 1) * sizeof(int), hipMemcpyDeviceToDevice, stream));
+  TMI_HIP(hipMemcpyAsync(p_run_obs, d_v_out, (size_t)n_valid * sizeof(int), hipMemcpyDeviceToDevice, stream));
+  TMI_HIP(hipMemcpyAsync(p_run_slot, d_run_slot, (size_t)n_runs * sizeof(int), hipMemcpyDeviceToDevice, stream));
+  TMI_HIP(hipMemcpyAsync(p_item_slot_ptr, d_item_slot_ptr, ((size_t)n_items + 1) * sizeof(int), hipMemcpyDeviceToDevice, stream));
+  TMI_HIP(hipMemcpyAsync(p_slot_rb, d_slot_rb, (size_t)n_slots * sizeof(int), hipMemcpyDeviceToDevice, stream));
+  TMI_HIP(hipMemsetAsync(p_obs_pos, 0xff, (size_t)n * sizeof(int), stream));
+  hipLaunchKernelGGL(obs_pos_kernel, nb(n_valid), dim3(256), 0, stream, d_k_out, d_v_out, n_valid, Nrb, d_unit_run_ptr,
+                     d_run_first, p_obs_pos);
+  {
+    // slots of every view block, ascending: the order mfc::reduce_kernel adds them in
+    unsigned *d_ck_in, *d_ck_out;
+    int* d_cv_in;
+    TMI_HIP(tmp.get(&d_ck_in, (size_t)n_slots));
+    TMI_HIP(tmp.get(&d_ck_out, (size_t)n_slots));
+    TMI_HIP(tmp.get(&d_cv_in, (size_t)n_slots));
+    hipLaunchKernelGGL(slot_rb_keys_kernel, nb(n_slots), dim3(256), 0, stream, d_slot_rb, n_slots, d_ck_in, d_cv_in);
+    MF_SORT_PAIRS(d_ck_in, d_ck_out, d_cv_in, p_cam_slots, n_slots, bits_for((unsigned long long)Nrb + 1));
+    hipLaunchKernelGGL(lower_bound_u32_kernel, nb(Nrb + 1), dim3(256), 0, stream, d_ck_out, n_slots, Nrb, p_cam_slot_ptr);
+    TMI_HIP(hipStreamSynchronize(stream));
+  }
+#undef MF_SORT_PAIRS
+#undef MF_EXCLUSIVE_SUM
+  double *p_partial, *p_ut;
+  if ((rc = dev_alloc(s, &p_partial, (size_t)n_slots * D))) return rc;
+  if ((rc = dev_alloc(s, &p_ut, (size_t)2 * std::max(st.slice_ptr[st.n_wide], 1)))) return rc;
+  m.item_unit0 = p_item_unit0;
+  m.unit_run_ptr = p_unit_run_ptr;
+  m.run_obs_ptr = p_run_obs_ptr;
+  m.run_obs = p_run_obs;
+  m.run_slot = p_run_slot;
+  m.item_slot_ptr = p_item_slot_ptr;
+  m.slot_rb = p_slot_rb;
+  m.obs_pos = p_obs_pos;
+  m.cam_slot_ptr = p_cam_slot_ptr;
+  m.cam_slots = p_cam_slots;
+  m.partial = p_partial;
+  m.ut = p_ut;
+  TMI_HIP(hipStreamSynchronize(stream));
+  s->mf_ok = true;
+  if (getenv("TMI_BA_SETUP_TIMING"))
+    fprintf(stderr, "[tmi_ba setup] one-sweep product: %d units, %d items, %d runs, %d slots (%.1f MB of partials)\n", n_units,
+            n_items, n_runs, n_slots, 8e-6 * n_slots * D);
+  return TMI_BA_OK;
+}
+
 static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_options* O, int rank,
                        int world, bool light = false) {
   s->light = light;
@@ -1425,7 +1683,11 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
                          st.Nc, (long long)st.No_pad, orb);
     v.obs_rb = orb;
   }
-  if (s->need_slot_track) {
+  if (s->need_slot_track && !st.has_shared) {
+    rc = build_mf_chunks(s);
+    if (rc) return rc;
+  }
+  if (s->need_slot_track && !s->mf_ok) {
     int* stt;
     if ((rc = dev_alloc(s, &stt, (size_t)std::max<int64_t>(st.Nslots, 1)))) return rc;
     hipLaunchKernelGGL(slot_track_kernel, dim3(s->nblocks_tracks), dim3(256), 0, s->stream, v, stt);
@@ -1613,8 +1875,12 @@ static int apply_schur(tmi_ba_solver* s, const double* x, double* y, int dot = 0
     Timed t(s, TMI_BA_K_SPMV);
     const tmi_ba_options* O = s->cur_opts;
     const int add_diag = (s->st.world <= 1 || s->st.rank == 0) ? 1 : 0;
-    s->launch.implicit_spmv(v, s->stream, s->RL, x, y, s->d_pm_u, s->d_cm_t, s->cur_inv_radius,
-                            O->min_lm_diagonal, O->max_lm_diagonal, add_diag, s->nblocks_tracks, dot, spec);
+    if (s->mf_ok)
+      s->launch.mf_product(v, s->mf, s->stream, s->RL, x, y, s->cur_inv_radius, O->min_lm_diagonal, O->max_lm_diagonal,
+                           add_diag, dot, spec);
+    else
+      s->launch.implicit_spmv(v, s->stream, s->RL, x, y, s->d_pm_u, s->d_cm_t, s->cur_inv_radius,
+                              O->min_lm_diagonal, O->max_lm_diagonal, add_diag, s->nblocks_tracks, dot, spec);
   }
   // with the dot product fused, x . y (this rank's share) rides behind the vector
   return do_allreduce(s, y, n + (dot ? 1 : 0));

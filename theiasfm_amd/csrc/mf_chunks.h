@@ -1,0 +1,629 @@
+// The matrix-free Schur product q = S p in ONE sweep over the track-major planes (kernel class 5, schur_mode
+// implicit / auto; no shared intrinsics blocks).  Replaces Ceres' ImplicitSchurComplement::RightMultiply behind
+// ceres::Solve at src/theia/sfm/bundle_adjustment/bundle_adjuster.cc:205 (ITERATIVE_SCHUR).
+//
+//   S p = D_c p + sum_obs A_i^T t_i,   t_i = u_i - Jp_i z_track,   u_i = A_i p_cam(i),
+//   z = (V + D_p)^-1 sum_{i in track} Jp_i^T u_i = L^-T L^-1 w.
+//
+// Rounds 1-3 ran this as two launches -- a track-major pass over the planes (u, zhat) and a camera-major pass over
+// the [A | Q] records (A^T t summed per view) -- so the camera Jacobian blocks crossed HBM twice per product
+// (2.4 GB for 0.83 GB algorithmic at Venice size).  Summing A^T t per VIEW is what forced the second order.  Here
+// a workgroup streams a SELL slice ONCE: the lane that owns an observation keeps its A block in registers until
+// the track's z is known, forms v_i = A_i^T t_i and drops it into LDS at the observation's position in the
+// slice's VIEW order (a static index); one thread per "run" (the observations of the slice that share a view)
+// then sums consecutive LDS entries => a fixed order and no atomics, and adds the run sum into per-view
+// accumulators that stay in LDS while the workgroup walks an ITEM = a range of consecutive slices.  Tracks are ordered by (length, lowest view), so the slices of an
+// item see the same few hundred views; an item leaves one D-vector per distinct view ("slot") in HBM and
+// mfc_reduce sums a view's slots in item order and adds the damping and p.q.  Bytes per observation: the A and Jp
+// planes once (16 (D + DP)), two int32 indices, and ~2 % of partials, against twice the A blocks + a 128-byte
+// line per zhat gather before.
+//
+// Units: the pieces a workgroup handles between two barriers -- a narrow slice (64 tracks, thread-per-track
+// slices), a quarter of a wide slice (16 tracks, 16 lanes per track) or four tracks of an ultra slice (a wavefront
+// per track), exactly the workgroup shapes of track_map (kernels.h).  Wide / ultra units are items of their own:
+// their rows do not fit LDS, so u / t go through a global scratch and every run writes its slot directly.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device_view.h"
+#include "kernels.h"
+
+namespace tmi {
+namespace mfc {
+
+constexpr int kWaves = 4;  // two workgroups per CU (<= 80 KB of LDS each), two wavefronts per SIMD
+constexpr int kThreads = 64 * kWaves;
+constexpr int kMaxNarrowK = 20;               // longest thread-per-track slice (kWideKLarge)
+// a wavefront owns rows w, w + 4, ... of a slice; the first reg_rows(D) of them keep A, Jp and u in registers until
+// the track's z is known, the rest (one slice in four is that long) are evaluated again once z is there
+__host__ __device__ constexpr int reg_rows(int D) { return D <= 9 ? 2 : 1; }
+// distinct views an item of SEVERAL slices may see (its accumulators); an item of one slice writes its run sums
+// straight to its slots and has no limit
+__host__ __device__ constexpr int lc_max(int D) { return D <= 6 ? 768 : D <= 9 ? 512 : D <= 12 ? 384 : 288; }
+__host__ __device__ constexpr int vb_entries(int D) { return D <= 6 ? 640 : D <= 9 ? 448 : D <= 12 ? 320 : 224; }  // v_i per round
+
+struct View {
+  int n_items, n_units, n_runs;
+  int nub;  // units [0, nub): four tracks of an ultra slice each
+  int nwb;  // units [nub, nwb): a quarter of a wide slice each; [nwb, n_units): narrow slices
+  const int* item_unit0;     // [n_items + 1] units of an item (wide / ultra: one)
+  const int* unit_run_ptr;   // [n_units + 1]
+  const int* run_obs_ptr;    // [n_runs + 1]
+  const int* run_obs;        // element index e of every observation that has a view block, by (unit, view)
+  const int* run_slot;       // [n_runs] slot the run's sum goes to
+  const int* item_slot_ptr;  // [n_items + 1]
+  const int* slot_rb;        // [n_slots] view block of a slot
+  const int* obs_pos;        // [No_pad] position of the observation in its unit's view order, -1: no view block
+  const int* cam_slot_ptr;   // [Nrb + 1] slots of a view block ...
+  const int* cam_slots;      // ... ascending (item order)
+  double* partial;           // [n_slots][D]
+  double* ut;                // [elements of the wide slices][2]
+};
+
+struct UnitShape {
+  int s, t0, nt, K, sp0;
+};
+__device__ __forceinline__ UnitShape unit_shape(const DeviceView& v, int u, int nub, int nwb) {
+  UnitShape q;
+  if (u < nub) {
+    q.s = u >> 4;
+    q.t0 = 4 * (u & 15);
+    q.nt = 4;
+  } else if (u < nwb) {
+    const int b = u - nub;
+    q.s = v.n_ultra + (b >> 2);
+    q.t0 = 16 * (b & 3);
+    q.nt = 16;
+  } else {
+    q.s = v.n_wide + (u - nwb);
+    q.t0 = 0;
+    q.nt = 64;
+  }
+  q.sp0 = v.slice_ptr[q.s];
+  q.K = (v.slice_ptr[q.s + 1] - q.sp0) >> 6;
+  return q;
+}
+
+// ---- structure build (once per handle; radix sorts + scans driven by engine.hip) ---------------------------
+// key (unit, view block) of every element; elements without a view block sort last
+__global__ __launch_bounds__(256) void unit_keys_kernel(DeviceView v, int nub, int nwb, int Nrb,
+                                                        unsigned long long invalid,
+                                                        unsigned long long* __restrict__ keys, int* __restrict__ vals) {
+  const int u = blockIdx.x;
+  const UnitShape q = unit_shape(v, u, nub, nwb);
+  const int n = q.K * q.nt;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int j = i / q.nt, t = q.t0 + (i - j * q.nt);
+    const int e = q.sp0 + 64 * j + t;
+    const int rb = v.obs_rb[e];
+    keys[e] = rb >= 0 ? (unsigned long long)u * (unsigned)Nrb + (unsigned)rb : invalid;
+    vals[e] = e;
+  }
+}
+
+// head[i] = 1 where a new key starts among the valid keys (head[n] = 0 closes the scan)
+__global__ __launch_bounds__(256) void heads_kernel(const unsigned long long* __restrict__ skey, long long n,
+                                                    unsigned long long invalid, int* __restrict__ head,
+                                                    int* __restrict__ n_valid) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i > n) return;
+  if (i == n) {
+    head[i] = 0;
+    return;
+  }
+  const unsigned long long k = skey[i];
+  const bool valid = k != invalid;
+  head[i] = (valid && (i == 0 || skey[i - 1] != k)) ? 1 : 0;
+  if (!valid && (i == 0 || skey[i - 1] != invalid)) *n_valid = (int)i;
+}
+
+__global__ __launch_bounds__(256) void run_fill_kernel(const unsigned long long* __restrict__ skey,
+                                                       const int* __restrict__ head, const int* __restrict__ pos,
+                                                       long long n, int* __restrict__ run_first,
+                                                       unsigned long long* __restrict__ run_key) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n || !head[i]) return;
+  run_first[pos[i]] = (int)i;
+  run_key[pos[i]] = skey[i];
+}
+
+// out[i] = first index of the sorted keys whose key >= i * stride, i = 0..m
+__global__ __launch_bounds__(256) void lower_bound_stride_kernel(const unsigned long long* __restrict__ keys,
+                                                                 long long n, unsigned long long stride, int m,
+                                                                 int* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i > m) return;
+  const unsigned long long want = (unsigned long long)i * stride;
+  long long lo = 0, hi = n;
+  while (lo < hi) {
+    const long long mid = (lo + hi) >> 1;
+    if (keys[mid] < want) lo = mid + 1;
+    else hi = mid;
+  }
+  out[i] = (int)lo;
+}
+
+// (item, view block) of every run; value = the run
+__global__ __launch_bounds__(256) void slot_keys_kernel(const unsigned long long* __restrict__ run_key, int n_runs,
+                                                        const int* __restrict__ unit_item, int Nrb,
+                                                        unsigned long long* __restrict__ keys, int* __restrict__ vals) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= n_runs) return;
+  const unsigned long long k = run_key[r];
+  const unsigned long long u = k / (unsigned)Nrb;
+  keys[r] = (unsigned long long)unit_item[u] * (unsigned)Nrb + (k - u * (unsigned)Nrb);
+  vals[r] = r;
+}
+
+__global__ __launch_bounds__(256) void slot_fill_kernel(const unsigned long long* __restrict__ skey,
+                                                        const int* __restrict__ head, const int* __restrict__ pos,
+                                                        const int* __restrict__ srun, int n_runs, int Nrb,
+                                                        int* __restrict__ run_slot, int* __restrict__ slot_rb,
+                                                        unsigned long long* __restrict__ slot_key) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_runs) return;
+  const int slot = pos[i] + head[i] - 1;
+  run_slot[srun[i]] = slot;
+  if (head[i]) {
+    slot_rb[slot] = (int)(skey[i] % (unsigned)Nrb);
+    slot_key[slot] = skey[i];
+  }
+}
+
+// position of every observation with a view block in the view order of its unit (= its index in run_obs
+// minus the unit's first)
+__global__ __launch_bounds__(256) void obs_pos_kernel(const unsigned long long* __restrict__ skey,
+                                                      const int* __restrict__ sval, int n_valid, int Nrb,
+                                                      const int* __restrict__ unit_run_ptr,
+                                                      const int* __restrict__ run_first, int* __restrict__ obs_pos) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_valid) return;
+  const unsigned long long u = skey[i] / (unsigned)Nrb;
+  obs_pos[sval[i]] = i - run_first[unit_run_ptr[u]];
+}
+
+__global__ __launch_bounds__(256) void slot_rb_keys_kernel(const int* __restrict__ slot_rb, int n,
+                                                           unsigned* __restrict__ keys, int* __restrict__ vals) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  keys[i] = (unsigned)slot_rb[i];
+  vals[i] = i;
+}
+
+__global__ __launch_bounds__(256) void lower_bound_u32_kernel(const unsigned* __restrict__ keys, int n, int m,
+                                                              int* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i > m) return;
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (keys[mid] < (unsigned)i) lo = mid + 1;
+    else hi = mid;
+  }
+  out[i] = lo;
+}
+
+// ---- the product ---------------------------------------------------------------------------------------------
+// z = L^-T (L^-1 w) of track lp (Linv planes: sym_idx(a, b), a <= b, holds L^-1(b, a))
+template <int DP>
+__device__ __forceinline__ void track_solve(const DeviceView& v, int lp, const double (&w)[DP], double (&z)[DP]) {
+  const size_t NP = (size_t)v.Np_pad;
+  double Li[sym_size(DP)];
+#pragma unroll
+  for (int i = 0; i < sym_size(DP); ++i) Li[i] = v.Linv[(size_t)i * NP + lp];
+  double zh[DP];
+#pragma unroll
+  for (int b = 0; b < DP; ++b) {
+    double t = 0.0;
+#pragma unroll
+    for (int a = 0; a <= b; ++a) t += Li[sym_idx(a, b, DP)] * w[a];
+    zh[b] = t;
+  }
+#pragma unroll
+  for (int a = 0; a < DP; ++a) {
+    double t = 0.0;
+#pragma unroll
+    for (int b = a; b < DP; ++b) t += Li[sym_idx(a, b, DP)] * zh[b];
+    z[a] = t;
+  }
+}
+
+template <int D, int DP>
+__global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View m, const double* __restrict__ x,
+                                                              int spec) {
+  constexpr int LCM = lc_max(D);
+  constexpr int VB = vb_entries(D);
+  constexpr int ROWD = 2 * D * 64;  // doubles of one row (= one 64-observation tile) of the A planes
+  constexpr int ROWP = 2 * DP * 64;
+  __shared__ double vbuf[VB * D];
+  __shared__ double wpart[kWaves][DP][64];
+  __shared__ double zs[DP][64];
+  __shared__ double acc[LCM * D];
+  if (spec && *v.pcg_done) return;
+  const int item = blockIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+
+  if (item < m.nwb) {
+    // ---- a wide / ultra unit: 16 or 64 lanes per track, u and t through the global scratch
+    const UnitShape q = unit_shape(v, item, m.nub, m.nwb);
+    {
+      const bool ultra = item < m.nub;
+      const int L = ultra ? 64 : kWideLanes;
+      const int t = ultra ? q.t0 + w : q.t0 + 4 * w + (lane >> 4);
+      const int j0 = ultra ? lane : (lane & (kWideLanes - 1));
+      const int lp = q.s * 64 + t;
+      const int k = v.pt_k[lp];
+      const size_t base = (size_t)q.sp0 + t;
+      double wv[DP];
+#pragma unroll
+      for (int a = 0; a < DP; ++a) wv[a] = 0.0;
+      for (int j = j0; j < k; j += L) {
+        const size_t e = base + (size_t)j * 64;
+        const int rb = v.obs_rb[e];
+        if (rb < 0) continue;
+        const double* xc = x + (size_t)rb * D;
+        const double* ap = v.pm_A + (e >> 6) * (size_t)ROWD + ((e & 63) << 1);
+        const double* jp = v.pm_Jp + (e >> 6) * (size_t)ROWP + ((e & 63) << 1);
+        double u0 = 0.0, u1 = 0.0;
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+          const double2 aa = *reinterpret_cast<const double2*>(ap + a * 128);
+          const double xa = xc[a];
+          u0 += aa.x * xa;
+          u1 += aa.y * xa;
+        }
+#pragma unroll
+        for (int a = 0; a < DP; ++a) {
+          const double2 jj = *reinterpret_cast<const double2*>(jp + a * 128);
+          wv[a] += jj.x * u0 + jj.y * u1;
+        }
+        *reinterpret_cast<double2*>(m.ut + 2 * e) = make_double2(u0, u1);
+      }
+#pragma unroll
+      for (int a = 0; a < DP; ++a) wv[a] = group_sum(wv[a], ultra ? 2 : 1);
+      if (k > 0) {
+        double z[DP];
+        track_solve<DP>(v, lp, wv, z);
+        for (int j = j0; j < k; j += L) {
+          const size_t e = base + (size_t)j * 64;
+          if (v.obs_rb[e] < 0) continue;
+          const double* jp = v.pm_Jp + (e >> 6) * (size_t)ROWP + ((e & 63) << 1);
+          double2 ut = *reinterpret_cast<const double2*>(m.ut + 2 * e);
+#pragma unroll
+          for (int a = 0; a < DP; ++a) {
+            const double2 jj = *reinterpret_cast<const double2*>(jp + a * 128);
+            ut.x -= jj.x * z[a];
+            ut.y -= jj.y * z[a];
+          }
+          *reinterpret_cast<double2*>(m.ut + 2 * e) = ut;
+        }
+      }
+    }
+    __syncthreads();  // the t values of this workgroup's tracks are in the scratch
+    const int r1 = m.unit_run_ptr[item + 1];
+    for (int r = m.unit_run_ptr[item] + (int)threadIdx.x; r < r1; r += kThreads) {
+      double sum[D];
+#pragma unroll
+      for (int a = 0; a < D; ++a) sum[a] = 0.0;
+      const int o1 = m.run_obs_ptr[r + 1];
+      for (int o = m.run_obs_ptr[r]; o < o1; ++o) {
+        const size_t e = (size_t)m.run_obs[o];
+        const double2 t = *reinterpret_cast<const double2*>(m.ut + 2 * e);
+        const double* ap = v.pm_A + (e >> 6) * (size_t)ROWD + ((e & 63) << 1);
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+          const double2 aa = *reinterpret_cast<const double2*>(ap + a * 128);
+          sum[a] += aa.x * t.x + aa.y * t.y;
+        }
+      }
+      double* dst = m.partial + (size_t)m.run_slot[r] * D;
+#pragma unroll
+      for (int a = 0; a < D; ++a) dst[a] = sum[a];
+    }
+    return;
+  }
+
+  // ---- an item of narrow slices
+  // Every load a slice needs -- its rows of A and Jp, the x blocks of their views, L^-1 of its tracks, the run lists --
+  // is issued at the top of the iteration in one batch (the view indices arrived one slice ahead), so a slice costs
+  // ONE memory round trip; the phases behind it only touch registers and LDS.
+  constexpr int RR = reg_rows(D);
+  constexpr int J1 = RR * kWaves;  // first row of the tail
+  constexpr int NLI = sym_size(DP);
+  const int u0 = m.item_unit0[item], u1 = m.item_unit0[item + 1];
+  const int slot0 = m.item_slot_ptr[item];
+  const int nlc = m.item_slot_ptr[item + 1] - slot0;
+  // an item of ONE slice has a slot per run: the sums go straight to HBM (and it may see any number of views)
+  const bool direct = (u1 - u0) == 1;
+  if (!direct)
+    for (int i = threadIdx.x; i < nlc * D; i += kThreads) acc[i] = 0.0;
+  int nrb[RR], npos[RR];
+  auto load_index = [&](int u) {
+    const int s = v.n_wide + (u - m.nwb);
+    const int sp0 = v.slice_ptr[s];
+    const int K = (v.slice_ptr[s + 1] - sp0) >> 6;
+#pragma unroll
+    for (int rr = 0; rr < RR; ++rr) {
+      const int j = w + rr * kWaves;
+      nrb[rr] = npos[rr] = -1;
+      if (j < K) {
+        const size_t e = (size_t)sp0 + 64 * j + lane;
+        nrb[rr] = v.obs_rb[e];
+        npos[rr] = m.obs_pos[e];
+      }
+    }
+  };
+  load_index(u0);
+  int r0 = m.unit_run_ptr[u0];
+  int o0 = m.run_obs_ptr[r0];
+  for (int u = u0; u < u1; ++u) {
+    const int s = v.n_wide + (u - m.nwb);
+    const int sp0 = v.slice_ptr[s];
+    const int K = (v.slice_ptr[s + 1] - sp0) >> 6;
+    const size_t tile0 = (size_t)(sp0 >> 6);
+    const int r1 = m.unit_run_ptr[u + 1];
+    const int o1 = m.run_obs_ptr[r1];
+    double2 ar[RR][D], jr[RR][DP];
+    double xr[RR][D];
+    double uu[RR][2];
+    int pos[RR];
+    // ---- the batch of loads
+#pragma unroll
+    for (int rr = 0; rr < RR; ++rr) {
+      const int j = min(w + rr * kWaves, K - 1);  // (a row beyond the slice re-reads the last one; its result is dropped)
+      pos[rr] = nrb[rr] >= 0 ? npos[rr] : -1;
+      const double* xc = x + (size_t)max(nrb[rr], 0) * D;
+#pragma unroll
+      for (int a = 0; a < D; ++a) xr[rr][a] = xc[a];
+      const double* ap = v.pm_A + (tile0 + j) * ROWD + 2 * lane;
+      const double* jp = v.pm_Jp + (tile0 + j) * ROWP + 2 * lane;
+#pragma unroll
+      for (int a = 0; a < D; ++a) ar[rr][a] = *reinterpret_cast<const double2*>(ap + a * 128);
+#pragma unroll
+      for (int a = 0; a < DP; ++a) jr[rr][a] = *reinterpret_cast<const double2*>(jp + a * 128);
+    }
+    double Li[NLI];
+    if (w == 0) {
+      const size_t NP = (size_t)v.Np_pad;
+#pragma unroll
+      for (int i = 0; i < NLI; ++i) Li[i] = v.Linv[(size_t)i * NP + (size_t)s * 64 + lane];
+    }
+    int ma[2], mb[2], ms[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int r = min(r0 + (int)threadIdx.x + q * kThreads, m.n_runs - 1);
+      ma[q] = m.run_obs_ptr[r];
+      mb[q] = m.run_obs_ptr[r + 1];
+      ms[q] = m.run_slot[r];
+    }
+    if (u + 1 < u1) load_index(u + 1);
+    // ---- u_i = A_i x, this wavefront's share of w = sum Jp^T u
+    double wv[DP];
+#pragma unroll
+    for (int a = 0; a < DP; ++a) wv[a] = 0.0;
+#pragma unroll
+    for (int rr = 0; rr < RR; ++rr) {
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        s0 += ar[rr][a].x * xr[rr][a];
+        s1 += ar[rr][a].y * xr[rr][a];
+      }
+      if (pos[rr] < 0) {  // no observation here: whatever the loads fetched must not reach the sums
+        s0 = s1 = 0.0;
+#pragma unroll
+        for (int a = 0; a < DP; ++a) jr[rr][a] = make_double2(0.0, 0.0);
+      }
+      uu[rr][0] = s0;
+      uu[rr][1] = s1;
+#pragma unroll
+      for (int a = 0; a < DP; ++a) wv[a] += jr[rr][a].x * s0 + jr[rr][a].y * s1;
+    }
+#pragma unroll 1
+    for (int j = w + J1; j < K; j += kWaves) {
+      const size_t e = (size_t)sp0 + 64 * j + lane;
+      const int rb = v.obs_rb[e];
+      if (rb < 0) continue;
+      const double* ap = v.pm_A + (tile0 + j) * ROWD + 2 * lane;
+      const double* jp = v.pm_Jp + (tile0 + j) * ROWP + 2 * lane;
+      const double* xc = x + (size_t)rb * D;
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        const double2 aa = *reinterpret_cast<const double2*>(ap + a * 128);
+        const double xa = xc[a];
+        s0 += aa.x * xa;
+        s1 += aa.y * xa;
+      }
+#pragma unroll
+      for (int a = 0; a < DP; ++a) {
+        const double2 jj = *reinterpret_cast<const double2*>(jp + a * 128);
+        wv[a] += jj.x * s0 + jj.y * s1;
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < DP; ++a) wpart[w][a][lane] = wv[a];
+    __syncthreads();  // wpart (and: the previous slice's run sums have left vbuf)
+    if (w == 0) {
+      double wt[DP], zh[DP];
+#pragma unroll
+      for (int a = 0; a < DP; ++a) {
+        double t = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < kWaves; ++ww) t += wpart[ww][a][lane];
+        wt[a] = t;
+      }
+      // z = L^-T (L^-1 w)   (Linv planes: sym_idx(a, b), a <= b, holds L^-1(b, a))
+#pragma unroll
+      for (int bb = 0; bb < DP; ++bb) {
+        double t = 0.0;
+#pragma unroll
+        for (int a = 0; a <= bb; ++a) t += Li[sym_idx(a, bb, DP)] * wt[a];
+        zh[bb] = t;
+      }
+#pragma unroll
+      for (int a = 0; a < DP; ++a) {
+        double t = 0.0;
+#pragma unroll
+        for (int bb = a; bb < DP; ++bb) t += Li[sym_idx(a, bb, DP)] * zh[bb];
+        zs[a][lane] = t;
+      }
+    }
+    __syncthreads();  // zs
+    double z[DP];
+#pragma unroll
+    for (int a = 0; a < DP; ++a) z[a] = zs[a][lane];
+    // t_i = u_i - Jp_i z in place
+#pragma unroll
+    for (int rr = 0; rr < RR; ++rr) {
+#pragma unroll
+      for (int a = 0; a < DP; ++a) {
+        uu[rr][0] -= jr[rr][a].x * z[a];
+        uu[rr][1] -= jr[rr][a].y * z[a];
+      }
+    }
+    // v_i = A_i^T t_i into LDS in view order, VB at a time; a thread per run sums its (consecutive) entries
+    const int nv = o1 - o0;
+    for (int pb = 0; pb < nv; pb += VB) {
+      if (pb > 0) __syncthreads();  // the previous round's sums are taken
+#pragma unroll
+      for (int rr = 0; rr < RR; ++rr) {
+        const int p = pos[rr] - pb;
+        if (pos[rr] >= 0 && p >= 0 && p < VB) {
+          double* dst = &vbuf[p * D];
+#pragma unroll
+          for (int a = 0; a < D; ++a) dst[a] = ar[rr][a].x * uu[rr][0] + ar[rr][a].y * uu[rr][1];
+        }
+      }
+#pragma unroll 1
+      for (int j = w + J1; j < K; j += kWaves) {
+        const size_t e = (size_t)sp0 + 64 * j + lane;
+        const int p = m.obs_pos[e] - pb;
+        const int rb = v.obs_rb[e];
+        if (p < 0 || p >= VB || rb < 0) continue;
+        const double* ap = v.pm_A + (tile0 + j) * ROWD + 2 * lane;
+        const double* jp = v.pm_Jp + (tile0 + j) * ROWP + 2 * lane;
+        const double* xc = x + (size_t)rb * D;
+        double2 aa[D];
+        double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+          aa[a] = *reinterpret_cast<const double2*>(ap + a * 128);
+          const double xa = xc[a];
+          t0 += aa[a].x * xa;
+          t1 += aa[a].y * xa;
+        }
+#pragma unroll
+        for (int a = 0; a < DP; ++a) {
+          const double2 jj = *reinterpret_cast<const double2*>(jp + a * 128);
+          t0 -= jj.x * z[a];
+          t1 -= jj.y * z[a];
+        }
+        double* dst = &vbuf[p * D];
+#pragma unroll
+        for (int a = 0; a < D; ++a) dst[a] = aa[a].x * t0 + aa[a].y * t1;
+      }
+      __syncthreads();  // vbuf
+      auto take_run = [&](int first, int last, int slot) {
+        const int b = max(first - o0 - pb, 0), e = min(last - o0 - pb, VB);
+        if (b >= e) return;
+        double sum[D];
+#pragma unroll
+        for (int a = 0; a < D; ++a) sum[a] = 0.0;
+        for (int p = b; p < e; ++p) {
+#pragma unroll
+          for (int a = 0; a < D; ++a) sum[a] += vbuf[p * D + a];
+        }
+        if (direct) {
+          double* dst = m.partial + (size_t)slot * D;
+          if (first - o0 >= pb) {
+#pragma unroll
+            for (int a = 0; a < D; ++a) dst[a] = sum[a];
+          } else {  // the run began in the previous round (this thread wrote its first part)
+#pragma unroll
+            for (int a = 0; a < D; ++a) dst[a] += sum[a];
+          }
+        } else {
+          double* dst = &acc[(slot - slot0) * D];  // one run per view and slice: no other thread adds here
+#pragma unroll
+          for (int a = 0; a < D; ++a) dst[a] += sum[a];
+        }
+      };
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        if (r0 + (int)threadIdx.x + q * kThreads < r1) take_run(ma[q], mb[q], ms[q]);
+      for (int r = r0 + (int)threadIdx.x + 2 * kThreads; r < r1; r += kThreads)
+        take_run(m.run_obs_ptr[r], m.run_obs_ptr[r + 1], m.run_slot[r]);
+    }
+    r0 = r1;
+    o0 = o1;
+  }
+  if (direct) return;
+  __syncthreads();  // acc
+  double* out = m.partial + (size_t)slot0 * D;
+  for (int i = threadIdx.x; i < nlc * D; i += kThreads) out[i] = acc[i];
+}
+
+// y = D_c x + the sum of every view's slots (ascending = item order) [+ x . y behind the vector]
+template <int D>
+__global__ __launch_bounds__(256) void reduce_kernel(DeviceView v, View m, RedLayout L, const double* __restrict__ x,
+                                                     double* __restrict__ y, double inv_radius, double lm_lo,
+                                                     double lm_hi, int add_diag, int dot, int spec) {
+  __shared__ double sh[4][D];
+  __shared__ double prod[D];
+  if (spec && *v.pcg_done) return;
+  const int chunk = ((int)gridDim.x) >> 3;
+  const int rb = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
+  const bool live = rb < v.Nrb;  // the padding workgroups still take part in the dot product's ticket
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double a9[D];
+#pragma unroll
+  for (int a = 0; a < D; ++a) a9[a] = 0.0;
+  if (live) {
+    const int k1 = m.cam_slot_ptr[rb + 1];
+    for (int k = m.cam_slot_ptr[rb] + (int)threadIdx.x; k < k1; k += 256) {
+      const double* p = m.partial + (size_t)m.cam_slots[k] * D;
+#pragma unroll
+      for (int a = 0; a < D; ++a) a9[a] += p[a];
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    const double t = wave_sum(a9[a]);
+    if (lane == 0) sh[w][a] = t;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < D) {
+    const int a = threadIdx.x;
+    double tot = sh[0][a] + sh[1][a] + sh[2][a] + sh[3][a];
+    double pr = 0.0;
+    if (live) {
+      const double xa = x[(size_t)rb * D + a];
+      // the damping (and the identity on padding rows) enters once: on rank 0 when the product is all-reduced
+      if (add_diag) {
+        if (v.rb_cols[(size_t)rb * D + a] < 0) {
+          tot = xa;
+        } else {
+          const double d = v.red[L.udiag + (size_t)rb * D + a];
+          tot += fmin(fmax(d, lm_lo), lm_hi) * inv_radius * xa;
+        }
+      } else if (v.rb_cols[(size_t)rb * D + a] < 0) {
+        tot = 0.0;
+      }
+      y[(size_t)rb * D + a] = tot;
+      pr = tot * xa;
+    }
+    prod[a] = pr;
+  }
+  if (dot) {
+    __syncthreads();
+    double mine = 0.0;
+    if (threadIdx.x == 0)
+      for (int a = 0; a < D; ++a) mine += prod[a];
+    double total;
+    if (last_block_sum<256>(mine, v.dotbuf, v.ticket, &total) && threadIdx.x == 0) y[(size_t)v.Nrb * D] = total;
+  }
+}
+
+}  // namespace mfc
+}  // namespace tmi

@@ -151,16 +151,21 @@ void BundleAdjuster::AddViews(const std::vector<ViewId>& view_ids) {
     work += view->Features().size();
   }
   const int n_threads = HostThreads(work);
-  // Track::IsEstimated for every track, threads own disjoint id ranges (read-only look-ups)
+  // Track::IsEstimated for every track, threads own disjoint id ranges (read-only look-ups); the table was
+  // pre-sized by Reserve above, so a thread writes its own flat slots and nothing else (IdState::SetPresized)
+  std::vector<size_t> fresh(n_threads, 0);
   RunThreads(n_threads, [&](int t) {
     const size_t i0 = all_tracks.size() * t / n_threads, i1 = all_tracks.size() * (t + 1) / n_threads;
+    size_t mine = 0;
     for (size_t i = i0; i < i1; ++i) {
       const TrackId id = all_tracks[i];
       if (track_estimated_.Get(id) >= 0) continue;
       const Track* track = reconstruction_->Track(id);
-      track_estimated_.Set(id, (track != nullptr && track->IsEstimated()) ? 1 : 0);  // flat, pre-sized: no resize
+      if (track_estimated_.SetPresized(id, (track != nullptr && track->IsEstimated()) ? 1 : 0)) ++mine;
     }
+    fresh[t] = mine;
   });
+  for (const size_t f : fresh) track_estimated_.NoteAdded(f);
   // the feature tables, one view at a time per thread, into thread-local residual lists
   std::vector<std::vector<Residual> > local(n_threads);
   std::atomic<size_t> next(0);
@@ -660,6 +665,10 @@ struct ResidentSession {
   tmi_ba_solver* solver = nullptr;
   std::vector<double*> extrinsics_ptr, point_ptr, intrinsics_ptr;
   std::vector<const CameraIntrinsicsModel*> view_model;  // per camera: the intrinsics object its view pointed at
+  // structural fingerprint taken when the session was built (StructureFingerprint): catches residual-set changes
+  // that did not go through a stamped mutator (copy-assignment through MutableView() / MutableTrack(), data-model
+  // classes without the hooks)
+  std::uint64_t fingerprint[6] = {0, 0, 0, 0, 0, 0};
   ~ResidentSession() {
     if (solver) tmi_ba_solver_destroy(solver);
   }
@@ -670,10 +679,61 @@ std::mutex g_session_mutex;
 // the first HIP call, so it runs before the runtime's exit handlers -- or explicitly (ReleaseBundleAdjustmentSession).
 std::unique_ptr<ResidentSession>& g_session = *new std::unique_ptr<ResidentSession>;
 
+// options that shape the handle (tmi_ba_solver_create bakes them into the structure: the preconditioner type decides
+// which blocks of S exist and which operator applies it, engine.hip create_impl)
 bool SameShape(const BundleAdjustmentOptions& a, const BundleAdjustmentOptions& b) {
   return a.constant_camera_orientation == b.constant_camera_orientation &&
          a.constant_camera_position == b.constant_camera_position && a.intrinsics_to_optimize == b.intrinsics_to_optimize &&
-         a.linear_solver_type == b.linear_solver_type && a.point_dof == b.point_dof && a.device == b.device;
+         a.linear_solver_type == b.linear_solver_type && a.point_dof == b.point_dof && a.device == b.device &&
+         a.preconditioner_type == b.preconditioner_type &&
+         a.merged_view_blocks_in_preconditioner == b.merged_view_blocks_in_preconditioner;
+}
+
+// What the residual set of a full BA depends on, through public accessors only: container sizes, which of the
+// session's views / tracks are estimated, how many features / views they hold, and how many tracks are estimated
+// at all (a track that became estimated since belongs to the residual set and is in no cached list).
+// O(#views + #tracks) look-ups on the host's threads, no per-observation work: ~2 ms at Venice size.
+void StructureFingerprint(const Reconstruction& rec, const FlattenedBundleAdjustmentProblem& flat, std::uint64_t out[6]) {
+  out[0] = static_cast<std::uint64_t>(rec.NumViews());
+  out[1] = static_cast<std::uint64_t>(rec.NumTracks());
+  std::uint64_t est_views = 0, features = 0;
+  for (const ViewId id : flat.view_ids) {
+    const View* v = rec.View(id);
+    if (v == nullptr || !v->IsEstimated()) continue;
+    ++est_views;
+    features += static_cast<std::uint64_t>(v->NumFeatures());
+  }
+  out[2] = est_views;
+  out[3] = features;
+  const size_t nt = flat.track_ids.size();
+  const int n_threads = HostThreads(8 * nt);
+  std::vector<std::uint64_t> est(n_threads, 0), obs(n_threads, 0);
+  RunThreads(n_threads, [&](int th) {
+    std::uint64_t e = 0, o = 0;
+    for (size_t t = nt * th / n_threads; t < nt * (th + 1) / n_threads; ++t) {
+      const Track* tr = rec.Track(flat.track_ids[t]);
+      if (tr == nullptr || !tr->IsEstimated()) continue;
+      ++e;
+      o += static_cast<std::uint64_t>(tr->NumViews());
+    }
+    est[th] = e;
+    obs[th] = o;
+  });
+  std::uint64_t est_tracks = 0, observations = 0;
+  for (int th = 0; th < n_threads; ++th) {
+    est_tracks += est[th];
+    observations += obs[th];
+  }
+  if (static_cast<std::uint64_t>(rec.NumTracks()) != nt) {
+    // tracks outside the cached list exist (unestimated when the session was built): count the estimated ones
+    est_tracks = 0;
+    for (const TrackId id : rec.TrackIds()) {
+      const Track* tr = rec.Track(id);
+      if (tr != nullptr && tr->IsEstimated()) ++est_tracks;
+    }
+  }
+  out[4] = est_tracks;
+  out[5] = observations;
 }
 
 bool SessionMatches(const ResidentSession& s, const BundleAdjustmentOptions& options, Reconstruction* rec) {
@@ -687,7 +747,9 @@ bool SessionMatches(const ResidentSession& s, const BundleAdjustmentOptions& opt
         static_cast<int32_t>(v->Camera().GetCameraIntrinsicsModelType()) != s.flat.group_model[s.flat.camera_group[c]])
       return false;
   }
-  return true;
+  std::uint64_t now[6];
+  StructureFingerprint(*rec, s.flat, now);
+  return std::equal(now, now + 6, s.fingerprint);
 }
 
 BundleAdjustmentSummary RunSession(ResidentSession* s, const BundleAdjustmentOptions& options) {
@@ -754,9 +816,28 @@ BundleAdjustmentSummary BundleAdjustReconstruction(const BundleAdjustmentOptions
     bundle_adjuster.AddTracks(reconstruction->TrackIds());
     return bundle_adjuster.Optimize();
   }
-  std::lock_guard<std::mutex> lock(g_session_mutex);
-  if (g_session && SessionMatches(*g_session, options, reconstruction)) return RunSession(g_session.get(), options);
-  g_session.reset();  // its HBM goes before the new problem is built
+  // The mutex guards the HOLDER only: the session is taken out under the lock, used (flatten / solve) without it and
+  // put back, so full BAs of different Reconstructions on different threads do not serialise on each other -- a
+  // call that finds the holder empty (another thread is using the session) simply builds its own.
+  std::unique_ptr<ResidentSession> mine;
+  {
+    std::lock_guard<std::mutex> lock(g_session_mutex);
+    mine = std::move(g_session);
+  }
+  auto put_back = [](std::unique_ptr<ResidentSession> keep) {
+    std::unique_ptr<ResidentSession> old;  // destroyed (HBM freed) outside the lock
+    {
+      std::lock_guard<std::mutex> lock(g_session_mutex);
+      old = std::move(g_session);
+      g_session = std::move(keep);
+    }
+  };
+  if (mine && SessionMatches(*mine, options, reconstruction)) {
+    const BundleAdjustmentSummary summary = RunSession(mine.get(), options);
+    put_back(std::move(mine));
+    return summary;
+  }
+  mine.reset();  // its HBM goes before the new problem is built
   std::unique_ptr<ResidentSession> s(new ResidentSession);
   BundleAdjuster bundle_adjuster(options, reconstruction);
   bundle_adjuster.AddViews(reconstruction->ViewIds());
@@ -782,15 +863,16 @@ BundleAdjustmentSummary BundleAdjustReconstruction(const BundleAdjustmentOptions
     s->point_ptr.resize(f.track_ids.size());
     for (size_t t = 0; t < f.track_ids.size(); ++t) s->point_ptr[t] = reconstruction->MutableTrack(f.track_ids[t])->MutablePoint()->data();
     if (complete) {
+      StructureFingerprint(*reconstruction, s->flat, s->fingerprint);
       static const bool registered = (std::atexit([] {
-        // no lock: the process is exiting single-threaded here; a BA still running in another thread owns the mutex
+        // a BA still running in another thread holds its session itself; what sits in the holder is released
         if (g_session_mutex.try_lock()) {
           g_session.reset();
           g_session_mutex.unlock();
         }
       }), true);
       (void)registered;
-      g_session = std::move(s);
+      put_back(std::move(s));
     }
   }
   return summary;
