@@ -252,6 +252,7 @@ def main():
         secs = [0.0] * abi.NUM_KERNEL_CLASSES
         launches = [0] * abi.NUM_KERNEL_CLASSES
         pcg = acc = mf = 0
+        run_chunks.sweeps = 0
         s = None
         while left > 0:
             n = min(left, max(1, args.solve_length))
@@ -262,6 +263,7 @@ def main():
             pcg += int(s.num_linear_solver_iterations)
             acc += int(s.num_successful_steps)
             mf += int(s.num_matrix_free_iterations)
+            run_chunks.sweeps += int(s.num_inner_iteration_steps)
             for i in range(abi.NUM_KERNEL_CLASSES):
                 secs[i] += s.kernel_seconds[i]
                 launches[i] += s.kernel_launches[i]
@@ -272,12 +274,12 @@ def main():
                 solver.reset()
         return done, secs, launches, s, pcg, acc, mf
 
-    def measure(workload, steps, warmup, with_transport):
+    def measure(workload, steps, warmup, with_transport, overrides=None):
         """creates the resident solver, warms up, profiles, times; returns a dict of raw results"""
         t0 = time.perf_counter()
         prob = synth.config(workload)
         t_gen = time.perf_counter() - t0
-        base = base_options(prob.num_cameras)
+        base = {**base_options(prob.num_cameras), **(overrides or {})}
         prob0 = prob.copy() if rank == 0 else None  # Solver.download() writes into `prob`
         t0 = time.perf_counter()
         solver = lib.Solver(prob, abi.default_options(max_num_iterations=1, **base), rank, world)
@@ -317,7 +319,7 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.transport == "staged" else "cuda")
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             elapsed = float(t.item())
-        return dict(prob=prob, prob0=prob0, base=base, solver=solver, transport=transport, t_gen=t_gen,
+        return dict(prob=prob, prob0=prob0, base=base, solver=solver, transport=transport, t_gen=t_gen, sweeps=run_chunks.sweeps,
                     t_create=t_create, steps_run=done, elapsed=elapsed, summary=s, pcg=pcg, accepted=acc, matrix_free=mf,
                     secs_p=secs_p, launches_p=launches_p, secs_t=secs_t, launches_t=launches_t, dom_idx=dom_idx)
 
@@ -661,6 +663,43 @@ def main():
             value=n_obs * mp["steps_run"] / mp["elapsed"], schur_pairs=int(mp["summary"].num_schur_pairs),
             pcg_iterations=int(mp["pcg"]), final_rmse=mp["summary"].final_rmse)}
         if world == 1:
+            # ---- the reference-default operating point: what theia::BundleAdjustReconstruction solves for a caller who
+            # changes nothing -- Ceres' SCHUR_JACOBI block shape (one block per parameter block: 6x6 extrinsics + NxN
+            # intrinsics per view, bundle_adjustment.h:87), homogeneous points with four free coordinates
+            # (bundle_adjuster.cc:379-385), inner iterations on (bundle_adjustment.h:112,
+            # reconstruction_estimator_utils.cc:118).  Same problem, same timed-region rules as the headline.
+            rd = dict(point_dof=4, preconditioner_type=abi.PRECOND_SCHUR_JACOBI_PARAMETER_BLOCKS, use_inner_iterations=1)
+            mr = measure(args.workload, args.steps, args.warmup, False, overrides=rd)
+            mr["solver"].close()
+            sr = mr["summary"]
+            nnzb_r, dc_r = int(sr.num_schur_blocks), int(sr.reduced_block_dim)
+            mf_r = float(mr["matrix_free"]) / max(1, mr["steps_run"])
+            rows_r = []
+            for name, launches, sec in zip(abi.KERNEL_CLASS_NAMES, mr["launches_p"], mr["secs_p"]):
+                if launches == 0 or sec <= 0.0:
+                    continue
+                ab = algorithmic_bytes(name, n_obs, n_cam, n_pts, dc_r, 4, nnzb_r, mf_r)
+                rows_r.append(dict(kernel=name, launches=int(launches), ms_per_step=round(1e3 * sec / max(1, mr["steps_run"]), 4),
+                                   avg_us=round(1e6 * sec / launches, 2), algorithmic_bytes_per_launch=int(ab),
+                                   achieved_GBs=round(ab / (sec / launches) / 1e9, 2)))
+            dom_r = max((k for k in rows_r if k["kernel"] != "allreduce"), key=lambda k: k["ms_per_step"])
+            out["variants"]["reference_defaults"] = dict(
+                settings=dict(preconditioner="SCHUR_JACOBI, one block per parameter block (Ceres' shape)", point_dof=4,
+                              use_inner_iterations=1, linear_solver=solver_name, schur_mode=args.schur_mode),
+                ms_per_step=round(1e3 * mr["elapsed"] / max(mr["steps_run"], 1), 4), steps=mr["steps_run"],
+                value=n_obs * mr["steps_run"] / mr["elapsed"], pcg_iterations=int(mr["pcg"]),
+                pcg_iterations_per_lm_iteration=round(mr["pcg"] / max(1, mr["steps_run"]), 2),
+                operator_chosen_by_auto=dict(matrix_free_lm_iterations=int(mr["matrix_free"]),
+                                             formed_S_lm_iterations=int(mr["steps_run"] - mr["matrix_free"])),
+                coordinate_descent_sweeps=int(mr["sweeps"]), accepted_steps=int(mr["accepted"]),
+                final_cost=sr.final_cost, final_rmse=sr.final_rmse,
+                roofline=dict(bound="hbm", kernel=dom_r["kernel"], achieved=dom_r["achieved_GBs"], peak=HBM_PEAK_GBS,
+                              unit="GB/s", frac=round(dom_r["achieved_GBs"] / HBM_PEAK_GBS, 5), avg_us=dom_r["avg_us"],
+                              launches=dom_r["launches"], algorithmic_bytes_per_launch=dom_r["algorithmic_bytes_per_launch"],
+                              traffic=None, measured="HIP events on the engine's stream, separate pass with every class timed"),
+                kernels=rows_r,
+                note="the headline differs from this in three stated settings (merged 9x9 preconditioner block, w fixed, no "
+                     "sweeps); with Ceres' block shape PCG needs ~5x the iterations per LM iteration")
             # the reference's solver policy below 1000 views is an exact reduced solve
             # (reconstruction_estimator_utils.cc:110-133): SPARSE_SCHUR -> the tiled dense Cholesky of S
             ma = measure("alamo", args.steps, args.warmup, False)

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "theia/sfm/bundle_adjustment/bundle_adjuster.h"
@@ -630,6 +631,66 @@ static void TestTwoViewsGpu() {
   EXPECT(!bad.success);
 }
 
+// Distinct BundleAdjuster instances run concurrently from pool threads on disjoint tracks of ONE Reconstruction
+// (estimate_track.cc:166-204, 238-246: every worker calls BundleAdjustTrack with num_threads = 1) and full BAs of
+// different Reconstructions may overlap: the boundary must be re-entrant and the results those of the serial order.
+static void TestConcurrentCallersGpu() {
+  const int kThreads = 8, kTracksPerThread = 6;
+  Reconstruction serial, threaded;
+  BuildScene(&serial, 7, 120, /*share_groups=*/false, 41, 0.3);
+  BuildScene(&threaded, 7, 120, /*share_groups=*/false, 41, 0.3);
+  BundleAdjustmentOptions opt;
+  opt.max_num_iterations = 10;
+  opt.num_threads = 1;
+  std::vector<BundleAdjustmentSummary> a(kThreads * kTracksPerThread), b(kThreads * kTracksPerThread);
+  for (int i = 0; i < kThreads * kTracksPerThread; ++i) a[i] = BundleAdjustTrack(opt, (TrackId)i, &serial);
+  std::vector<std::thread> pool;
+  for (int t = 0; t < kThreads; ++t)
+    pool.emplace_back([&, t] {
+      for (int k = 0; k < kTracksPerThread; ++k) {
+        const int i = t * kTracksPerThread + k;  // disjoint tracks per thread
+        b[i] = BundleAdjustTrack(opt, (TrackId)i, &threaded);
+      }
+    });
+  for (auto& th : pool) th.join();
+  int same = 0;
+  for (int i = 0; i < kThreads * kTracksPerThread; ++i) {
+    bool eq = a[i].success == b[i].success && a[i].initial_cost == b[i].initial_cost && a[i].final_cost == b[i].final_cost;
+    for (int c = 0; c < 4; ++c) eq = eq && serial.Track(i)->Point()[c] == threaded.Track(i)->Point()[c];
+    same += eq ? 1 : 0;
+    EXPECT(b[i].success && b[i].final_cost <= b[i].initial_cost);
+  }
+  EXPECT(same == kThreads * kTracksPerThread);  // bit for bit the serial results
+  std::printf("concurrent BundleAdjustTrack: %d threads x %d tracks, %d of %d equal to the serial run\n", kThreads,
+              kTracksPerThread, same, kThreads * kTracksPerThread);
+  // full BAs of different Reconstructions from different threads (exact and iterative solvers side by side)
+  const int kRecs = 4;
+  std::vector<Reconstruction> one(kRecs), two(kRecs);
+  std::vector<BundleAdjustmentSummary> s1(kRecs), s2(kRecs);
+  BundleAdjustmentOptions full;
+  full.max_num_iterations = 5;
+  for (int r = 0; r < kRecs; ++r) {
+    BuildScene(&one[r], 6 + r, 150 + 20 * r, /*share_groups=*/r == 3, 51 + r, 0.3);
+    BuildScene(&two[r], 6 + r, 150 + 20 * r, /*share_groups=*/r == 3, 51 + r, 0.3);
+  }
+  auto options_of = [&](int r) {
+    BundleAdjustmentOptions o = full;
+    o.linear_solver_type = (r & 1) ? ceres::ITERATIVE_SCHUR : ceres::SPARSE_SCHUR;
+    o.use_inner_iterations = r == 2;
+    return o;
+  };
+  for (int r = 0; r < kRecs; ++r) s1[r] = BundleAdjustReconstruction(options_of(r), &one[r]);
+  pool.clear();
+  for (int r = 0; r < kRecs; ++r) pool.emplace_back([&, r] { s2[r] = BundleAdjustReconstruction(options_of(r), &two[r]); });
+  for (auto& th : pool) th.join();
+  for (int r = 0; r < kRecs; ++r) {
+    bool eq = s1[r].success && s2[r].success && s1[r].final_cost == s2[r].final_cost;
+    for (ViewId v = 0; v < (ViewId)one[r].NumViews(); ++v)
+      for (int c = 0; c < 6; ++c) eq = eq && one[r].View(v)->Camera().extrinsics()[c] == two[r].View(v)->Camera().extrinsics()[c];
+    EXPECT(eq);
+  }
+}
+
 int main(int argc, char** argv) {
   const std::string mode = argc > 1 ? argv[1] : "cpu";
   TestSemantics();
@@ -639,6 +700,7 @@ int main(int argc, char** argv) {
     TestTrackOpsGpu();
     TestTwoViewsGpu();
     TestTwoViewsAngularGpu();
+    TestConcurrentCallersGpu();
   }
   std::printf("%s: %d failure(s)\n", mode.c_str(), g_fail);
   return g_fail ? 1 : 0;

@@ -25,6 +25,11 @@ pytestmark = pytest.mark.gpu
 ORACLE_THREADS = min(64, os.cpu_count() or 16)
 
 
+# config 4 at the reference defaults: tolerances of the comparison (set from the measured agreement, see the test)
+REFDEF_COST_REL = 1e-9
+REFDEF_PCG_SLACK = 0
+
+
 def oracle_solve(prob, o):
     if hasattr(oracle, "set_num_threads"):
         oracle.set_num_threads(ORACLE_THREADS)
@@ -84,6 +89,40 @@ def test_config4_venice_iterative_schur_trajectory():
         if mode != abi.SCHUR_AUTO:
             assert s_d.num_matrix_free_iterations == (3 if mode == abi.SCHUR_IMPLICIT else 0)
         same_place((st_d, s_d, a), (st_o, s_o, b), scale=100.0)
+
+
+def test_config4_venice_reference_defaults_trajectory():
+    """Config 4 at the REFERENCE-DEFAULT operating point -- what theia::BundleAdjustReconstruction solves when the
+    caller changes nothing: Ceres' SCHUR_JACOBI block shape (one block per parameter block, bundle_adjustment.h:87),
+    homogeneous points with all four coordinates free (bundle_adjuster.cc:379-385, no parameterization) and inner
+    iterations on (bundle_adjustment.h:112, reconstruction_estimator_utils.cc:118).  Three trust-region iterations with
+    their coordinate-descent sweeps on both sides: identical iteration / accepted-step / PCG / sweep counts; cost,
+    RMSE and cameras to the usual 1e-9 / 1e-6, the points projectively (the free scale of a homogeneous point is a
+    gauge direction along which two correct solvers drift by rounding noise over the clamped LM diagonal, DESIGN.md
+    section 8: X[:3] / X[3] is compared)."""
+    prob = synth.config("venice1778_heavy")
+    kw = dict(linear_solver_type=abi.ITERATIVE_SCHUR, preconditioner_type=abi.PRECOND_SCHUR_JACOBI_PARAMETER_BLOCKS,
+              point_dof=4, max_num_iterations=3, use_inner_iterations=1)
+    b = prob.copy()
+    st_o, s_o = oracle_solve(b, abi.default_options(**kw))
+    assert st_o == 0 and s_o.num_inner_iteration_steps > 0
+    pb = b.points[:, :3] / b.points[:, 3:4]
+    for mode in (abi.SCHUR_AUTO, abi.SCHUR_EXPLICIT, abi.SCHUR_IMPLICIT):
+        a = prob.copy()
+        st_d, s_d = lib.solve(a, abi.default_options(schur_mode=mode, **kw))
+        assert st_d == 0, s_d.message
+        assert s_d.num_iterations == s_o.num_iterations == 3 and s_d.final_cost < 0.2 * s_d.initial_cost
+        assert s_d.num_successful_steps == s_o.num_successful_steps
+        assert s_d.num_inner_iteration_steps == s_o.num_inner_iteration_steps
+        assert abs(int(s_d.num_linear_solver_iterations) - int(s_o.num_linear_solver_iterations)) <= REFDEF_PCG_SLACK
+        if mode != abi.SCHUR_AUTO:
+            assert s_d.num_matrix_free_iterations == (3 if mode == abi.SCHUR_IMPLICIT else 0)
+        assert abs(s_d.final_cost - s_o.final_cost) <= REFDEF_COST_REL * s_o.final_cost, (s_d.final_cost, s_o.final_cost)
+        assert abs(s_d.final_rmse - s_o.final_rmse) <= REFDEF_COST_REL
+        assert np.abs(a.extrinsics - b.extrinsics).max() <= 1e-6 * 100.0
+        assert np.abs(a.intrinsics - b.intrinsics).max() <= 1e-6 * max(1.0, np.abs(b.intrinsics).max())
+        pa = a.points[:, :3] / a.points[:, 3:4]
+        assert np.abs(pa - pb).max() <= 1e-6 * 100.0
 
 
 def test_config5_mixed_models_shared_groups_fp32_trajectory():

@@ -63,3 +63,19 @@ def test_dataflow_cholesky_flags_an_indefinite_matrix(harness):
     A[150, 150] = -1.0
     _, _, info = run(harness.chol_df_solve, A, b, reps=1)
     assert info[0] == 0 and info[1] == 1
+
+
+def test_engine_fallback_path_matches_the_dataflow_solve(monkeypatch):
+    """The engine's fall-back for a dataflow launch that cannot become co-resident is the launch-per-panel Cholesky
+    (engine.hip solve_reduced_dense); TMI_BA_CHOL_PANELS selects it outright: same LM trajectory as the default."""
+    from theiasfm_amd import abi, lib, synth
+    prob = synth.make_problem(120, 20000, 110000, seed=13, scene="ring", spread=0.4)  # n = 1080: 17 tile rows
+    o = abi.default_options(linear_solver_type=abi.SPARSE_SCHUR, point_dof=3, max_num_iterations=5, use_inner_iterations=0)
+    a, b = prob.copy(), prob.copy()
+    st_a, s_a = lib.solve(a, o)
+    monkeypatch.setenv("TMI_BA_CHOL_PANELS", "1")
+    st_b, s_b = lib.solve(b, o)
+    assert st_a == st_b == 0 and s_a.num_iterations == s_b.num_iterations == 5
+    assert s_a.num_successful_steps == s_b.num_successful_steps
+    assert abs(s_a.final_cost - s_b.final_cost) <= 1e-10 * s_a.final_cost
+    assert np.abs(a.extrinsics - b.extrinsics).max() <= 1e-8 * 100.0

@@ -1,0 +1,77 @@
+"""-m gpu: the one-sweep matrix-free product (theiasfm_amd/csrc/mf_chunks.h, opt-in through TMI_BA_MF_ONE_SWEEP) against
+the two-pass product it is meant to replace and against the oracle: same operator q = S p (Ceres'
+ImplicitSchurComplement behind ceres::Solve, bundle_adjuster.cc:205), so identical PCG / LM iteration counts and
+results to round-off, over the shapes its work items take -- thread-per-track slices of every length up to the wide
+threshold (register rows and tail rows), 16- and 64-lane tracks (heavy tail), items of one slice and of several,
+constant cameras / tracks, block sizes 6 / 9 / 12 and both point parameterisations."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from theiasfm_amd import abi, lib, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def solve(prob, one_sweep, **kw):
+    old = os.environ.pop("TMI_BA_MF_ONE_SWEEP", None)
+    if one_sweep:
+        os.environ["TMI_BA_MF_ONE_SWEEP"] = "1"
+    try:
+        p = prob.copy()
+        st, s = lib.solve(p, abi.default_options(linear_solver_type=abi.ITERATIVE_SCHUR, schur_mode=abi.SCHUR_IMPLICIT, **kw))
+        return st, s, p
+    finally:
+        os.environ.pop("TMI_BA_MF_ONE_SWEEP", None)
+        if old is not None:
+            os.environ["TMI_BA_MF_ONE_SWEEP"] = old
+
+
+CASES = {
+    "ladybug49": lambda: (synth.config("ladybug49"), dict(point_dof=3)),
+    "dof4": lambda: (synth.make_problem(40, 6000, 30000, seed=5, scene="ring", spread=0.5), dict(point_dof=4)),
+    # tracks of 24-300 views: 16 and 64 lanes per track, slices with tail rows
+    "heavy_tail": lambda: (synth.make_problem(320, 30000, 190000, seed=7, scene="ring", spread=0.6, heavy_tail=0.01), dict(point_dof=3)),
+    # extrinsics only (D = 6), Huber
+    "d6_huber": lambda: (synth.make_problem(60, 9000, 50000, seed=9, scene="ring", spread=0.4, intrinsics_to_optimize=abi.INTRINSICS_NONE),
+                         dict(point_dof=3, loss_function_type=abi.LOSS_HUBER, robust_loss_width=2.0)),
+    # radial-tangential cameras with every intrinsic free but skew / aspect ratio: D = 6 + 8 -> 16
+    "d16": lambda: (synth.make_problem(30, 4000, 22000, seed=11, scene="ring", spread=0.5, models=[(abi.PINHOLE_RADIAL_TANGENTIAL, 1.0)],
+                                       intrinsics_to_optimize=abi.INTRINSICS_ALL & ~(abi.INTRINSICS_SKEW | abi.INTRINSICS_ASPECT_RATIO)),
+                    dict(point_dof=4)),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_one_sweep_product_equals_two_pass_and_oracle(name):
+    prob, kw = CASES[name]()
+    if name == "heavy_tail":
+        prob.camera_flags[0] = abi.CAMERA_POSITION_CONSTANT | abi.CAMERA_ORIENTATION_CONSTANT  # a view without a block
+        prob.point_constant[::7] = 1
+    kw = dict(max_num_iterations=6, use_inner_iterations=0, **kw)
+    st2, s2, p2 = solve(prob, False, **kw)
+    st1, s1, p1 = solve(prob, True, **kw)
+    assert st1 == st2 == 0, (s1.message, s2.message)
+    assert s1.num_matrix_free_iterations == s1.num_iterations == s2.num_iterations
+    assert s1.num_linear_solver_iterations == s2.num_linear_solver_iterations
+    assert s1.num_successful_steps == s2.num_successful_steps
+    assert abs(s1.final_cost - s2.final_cost) <= 1e-10 * s2.final_cost
+    scale = max(1.0, np.abs(p2.extrinsics).max())
+    assert np.abs(p1.extrinsics - p2.extrinsics).max() <= 1e-8 * scale
+    assert np.abs(p1.intrinsics - p2.intrinsics).max() <= 1e-8 * max(1.0, np.abs(p2.intrinsics).max())
+    if kw["point_dof"] == 3:
+        assert np.abs(p1.points - p2.points).max() <= 1e-7 * scale
+    b = prob.copy()
+    st_o, s_o = oracle.solve(b, abi.default_options(linear_solver_type=abi.ITERATIVE_SCHUR, **kw))
+    assert st_o == 0 and s_o.num_iterations == s1.num_iterations
+    assert abs(s1.final_cost - s_o.final_cost) <= 1e-9 * s_o.final_cost
+
+
+def test_one_sweep_product_is_reproducible_to_the_bit():
+    prob, kw = CASES["heavy_tail"]()
+    kw = dict(max_num_iterations=4, use_inner_iterations=0, **kw)
+    _, s_a, p_a = solve(prob, True, **kw)
+    _, s_b, p_b = solve(prob, True, **kw)
+    assert s_a.final_cost == s_b.final_cost and (p_a.extrinsics == p_b.extrinsics).all() and (p_a.points == p_b.points).all()

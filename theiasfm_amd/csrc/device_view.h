@@ -135,7 +135,7 @@ struct DeviceView {
   int* flags;       // device flags (invalid residual, singular block, ...)
   double* dotbuf;   // [Nrb] per-block partial dot products of the product kernels
   int* ticket;      // [4][kTicketStride] arrival counters of the "last workgroup finishes the reduction" kernels
-  int* pcg_done;    // set by pcg_step once PCG has stopped: speculatively enqueued kernels return at once
+  int* pcg_done;    // set by pcg_step once PCG has stopped: pcg_p, enqueued behind it, returns at once
 };
 
 // host-visible copy of the device scalars (pinned, mapped, coherent memory): published by a

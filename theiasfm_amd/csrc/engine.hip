@@ -73,13 +73,13 @@ struct Launch {
   void (*precond)(const DeviceView&, hipStream_t, int);
   void (*cluster_gather)(hipStream_t, const clp::GatherEntry*, int, const clp::ClusterDesc*, const double*, const double*, double*);
   void (*cluster_rz)(const DeviceView&, hipStream_t, int, double*);
-  // dot: the product kernel also leaves x . y at y[Nrb D]; spec: return at once if PCG stopped
-  void (*spmv)(const DeviceView&, hipStream_t, const double*, const double*, double*, int dot, int spec);
+  // dot: the product kernel also leaves x . y at y[Nrb D]
+  void (*spmv)(const DeviceView&, hipStream_t, const double*, const double*, double*, int dot);
   void (*implicit_spmv)(const DeviceView&, hipStream_t, RedLayout, const double*, double*, double*,
-                        double*, double, double, double, int, int, int dot, int spec);
+                        double*, double, double, double, int, int, int dot);
   // the one-sweep matrix-free product of mf_chunks.h (no shared intrinsics blocks)
   void (*mf_product)(const DeviceView&, const mfc::View&, hipStream_t, RedLayout, const double*, double*, double, double,
-                     double, int, int dot, int spec);
+                     double, int, int dot);
   void (*pcg_step)(const DeviceView&, hipStream_t, const double* b, int it, int nb, double eta, int min_it,
                    int max_it, const double* red8, HostMirror* mirror, unsigned long long seq);
   void (*pcg_a)(const DeviceView&, hipStream_t, int, int);
@@ -143,27 +143,13 @@ Launch make_launch(bool fp32) {
   L.expand_scale = [](const DeviceView& v, hipStream_t st) {
     if (v.Nc) hipLaunchKernelGGL((expand_camera_scale_kernel<D>), dim3((v.Nc + 255) / 256), dim3(256), 0, st, v);
   };
-  static const bool schur_gather = getenv("TMI_BA_SCHUR_GATHER") != nullptr;  // A/B: round 1's per-lane gathers
-  if (schur_gather)
-    L.schur_offdiag = [](const DeviceView& v, hipStream_t st, RedLayout R) {
-      if (v.nub)
-        hipLaunchKernelGGL((schur_offdiag_gather_kernel<D, DP>), dim3((v.n_order + 4 * kSchurBlocksPerWave - 1) / (4 * kSchurBlocksPerWave)), dim3(256), 0, st, v, R);
-    };
-  else
-    L.schur_offdiag = [](const DeviceView& v, hipStream_t st, RedLayout R) {
-      if (!v.nub) return;
-        const dim3 grid((v.n_order + 4 * kSchurBlocksPerWave - 1) / (4 * kSchurBlocksPerWave));
-#ifdef TMI_BA_SCHUR_EXPERIMENTS
-        static const int exp_mode = getenv("TMI_BA_EXP") ? atoi(getenv("TMI_BA_EXP")) : 0;
-        if (exp_mode == 1) { hipLaunchKernelGGL((schur_offdiag_kernel<D, DP, 1>), grid, dim3(256), 0, st, v, R); return; }
-        if (exp_mode == 2) { hipLaunchKernelGGL((schur_offdiag_kernel<D, DP, 2>), grid, dim3(256), 0, st, v, R); return; }
-        if (exp_mode == 3) { hipLaunchKernelGGL((schur_offdiag_kernel<D, DP, 3>), grid, dim3(256), 0, st, v, R); return; }
-        if (exp_mode == 4) { hipLaunchKernelGGL((schur_offdiag_kernel<D, DP, 4>), grid, dim3(256), 0, st, v, R); return; }
-#endif
-        // without shared intrinsics blocks: the [A | Q] records (no Y record exists unless asked for)
-        if (!SH && !v.write_y) hipLaunchKernelGGL((schur_offdiag_aq_kernel<D, DP>), grid, dim3(256), 0, st, v, R);
-        else hipLaunchKernelGGL((schur_offdiag_kernel<D, DP>), grid, dim3(256), 0, st, v, R);
-    };
+  L.schur_offdiag = [](const DeviceView& v, hipStream_t st, RedLayout R) {
+    if (!v.nub) return;
+    const dim3 grid((v.n_order + 4 * kSchurBlocksPerWave - 1) / (4 * kSchurBlocksPerWave));
+    // without shared intrinsics blocks: the [A | Q] records (no Y record exists unless asked for)
+    if (!SH && !v.write_y) hipLaunchKernelGGL((schur_offdiag_aq_kernel<D, DP>), grid, dim3(256), 0, st, v, R);
+    else hipLaunchKernelGGL((schur_offdiag_kernel<D, DP>), grid, dim3(256), 0, st, v, R);
+  };
   L.expand = [](const DeviceView& v, hipStream_t st, RedLayout R, double ir, double lo, double hi, int want_gmax) {
     const int n2 = v.Nrb * D * D;
     if (n2)
@@ -180,10 +166,10 @@ Launch make_launch(bool fp32) {
   L.precond = [](const DeviceView& v, hipStream_t st, int mode) {
     if (v.Nrb) hipLaunchKernelGGL((precond_invert_kernel<D>), dim3(v.Nrb), dim3(64), 0, st, v, mode);
   };
-  L.spmv = [](const DeviceView& v, hipStream_t st, const double* ub, const double* x, double* y, int dot, int spec) {
+  L.spmv = [](const DeviceView& v, hipStream_t st, const double* ub, const double* x, double* y, int dot) {
     if (!v.Nrb) return;
-    if (v.n_spc) hipLaunchKernelGGL((spmv_rows_kernel<D>), dim3((v.n_spc + 3) / 4), dim3(256), 0, st, v, ub, x, spec);
-    hipLaunchKernelGGL((spmv_cols_kernel<D>), dim3(v.Nrb), dim3(256), 0, st, v, x, y, dot, spec);
+    if (v.n_spc) hipLaunchKernelGGL((spmv_rows_kernel<D>), dim3((v.n_spc + 3) / 4), dim3(256), 0, st, v, ub, x);
+    hipLaunchKernelGGL((spmv_cols_kernel<D>), dim3(v.Nrb), dim3(256), 0, st, v, x, y, dot);
   };
   L.pcg_step = [](const DeviceView& v, hipStream_t st, const double* b, int it, int nb, double eta, int min_it,
                   int max_it, const double* red8, HostMirror* mirror, unsigned long long seq) {
@@ -191,31 +177,30 @@ Launch make_launch(bool fp32) {
                        max_it, red8, mirror, seq);
   };
   L.implicit_spmv = [](const DeviceView& v, hipStream_t st, RedLayout R, const double* x, double* y,
-                       double* w1, double* w2, double ir, double lo, double hi, int add_diag, int nb, int dot,
-                       int spec) {
+                       double* w1, double* w2, double ir, double lo, double hi, int add_diag, int nb, int dot) {
     // work array: w1 = zhat, 4 doubles per track (w2 unused)
     if (!v.Nrb) return;
     if (!SH) {
-      hipLaunchKernelGGL((implicit_tracks_q_kernel<D, DP>), dim3(nb), dim3(256), 0, st, v, x, w1, spec);
+      hipLaunchKernelGGL((implicit_tracks_q_kernel<D, DP>), dim3(nb), dim3(256), 0, st, v, x, w1);
       hipLaunchKernelGGL((implicit_cameras_q_kernel<D, DP>), dim3(8 * ((v.Nrb + 7) / 8)), dim3(64), 0, st, v, R, x, w1, y, ir, lo, hi,
-                         add_diag, dot, spec);
+                         add_diag, dot);
       return;
     }
-    hipLaunchKernelGGL((implicit_tracks_sq_kernel<D, DP>), dim3(nb), dim3(256), 0, st, v, x, w1, spec);
+    hipLaunchKernelGGL((implicit_tracks_sq_kernel<D, DP>), dim3(nb), dim3(256), 0, st, v, x, w1);
     // cam_part is free between two builds of the normal equations: the per-view partial
     // products of the shared intrinsics blocks live in its head
     hipLaunchKernelGGL((implicit_cameras_sq_kernel<D, DP>), dim3(v.Ncam_rb), dim3(64), 0, st, v, R, x, w1, y,
-                       ir, lo, hi, add_diag, v.cam_part, spec);
+                       ir, lo, hi, add_diag, v.cam_part);
     if (v.Nrb > v.Ncam_rb)
       hipLaunchKernelGGL((implicit_groups_kernel<D>), dim3(v.Nrb - v.Ncam_rb), dim3(64), 0, st, v, R, x, v.cam_part,
                          y, ir, lo, hi, add_diag);
   };
   L.mf_product = [](const DeviceView& v, const mfc::View& m, hipStream_t st, RedLayout R, const double* x, double* y,
-                    double ir, double lo, double hi, int add_diag, int dot, int spec) {
+                    double ir, double lo, double hi, int add_diag, int dot) {
     if (!v.Nrb) return;
-    if (m.n_items) hipLaunchKernelGGL((mfc::product_kernel<D, DP>), dim3(m.n_items), dim3(mfc::kThreads), 0, st, v, m, x, spec);
+    if (m.n_items) hipLaunchKernelGGL((mfc::product_kernel<D, DP>), dim3(m.n_items), dim3(mfc::kThreads), 0, st, v, m, x);
     hipLaunchKernelGGL((mfc::reduce_kernel<D>), dim3(8 * ((v.Nrb + 7) / 8)), dim3(256), 0, st, v, m, R, x, y, ir, lo, hi,
-                       add_diag, dot, spec);
+                       add_diag, dot);
   };
   L.pcg_a = [](const DeviceView& v, hipStream_t st, int n, int it) {
     hipLaunchKernelGGL((pcg_a_kernel<D>), dim3(1), dim3(1024), 0, st, v, n, it);
@@ -695,7 +680,7 @@ static int build_structure_device(tmi_ba_solver* s, const tmi_ba_problem* P, boo
   TMI_HIP(tmp.get(&d_tv_in, (size_t)Np));
   TMI_HIP(tmp.get(&d_order, (size_t)Np));
   hipLaunchKernelGGL(track_keys_kernel, nb(Np), dim3(256), 0, stream, d_klen, Np, d_tptr, d_ok_out, cam_bits,
-                     track_order_plain() ? 1 : 0, d_tk_in, d_tv_in);
+                     d_tk_in, d_tv_in);
   SG_SORT_PAIRS(d_tk_in, d_tk_out, d_tv_in, d_order, Np, 32 + cam_bits);
   std::vector<int> order((size_t)Np), klen((size_t)Np);
   int bad = 0;
@@ -1166,7 +1151,10 @@ void tmi_ba_solver_destroy(tmi_ba_solver* s) {
 static int build_mf_chunks(tmi_ba_solver* s) {
   using namespace tmi::mfc;
   s->mf_ok = false;
-  if (getenv("TMI_BA_MF_TWO_PASS")) return TMI_BA_OK;  // A/B: round 3's two-pass product
+  // Opt-in: measured on MI355X (profiles/r04_one_sweep_experiment.md) the one-sweep product reads half the bytes of the
+  // two-pass one and is no faster yet (0.45 + 0.04 ms against 0.21 + 0.25 ms per product at Venice size): every slice
+  // costs a workgroup a fixed ~8 us of dependent look-ups and barriers that two workgroups per CU do not hide.
+  if (!getenv("TMI_BA_MF_ONE_SWEEP")) return TMI_BA_OK;
   Structure& st = s->st;
   DeviceView& v = s->v;
   hipStream_t stream = s->stream;
@@ -1440,7 +1428,7 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   // implicit needs an iterative solver; auto = explicit on one GPU, implicit on several
   s->implicit = iterative_type && (O->schur_mode == 2 || (O->schur_mode == 0 && world > 1));
   if (light) s->implicit = false;
-  s->adaptive = !light && iterative_type && O->schur_mode == 0 && world == 1 && getenv("TMI_BA_NO_ADAPTIVE") == nullptr;
+  s->adaptive = !light && iterative_type && O->schur_mode == 0 && world == 1;
   s->implicit_now = s->implicit;
   TMI_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   bool want_pairs = !s->implicit && !light;
@@ -1644,7 +1632,9 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
       AL(s->d_shared_diag_partial, (size_t)(st.Nrb - st.Ncam_rb) * s->shared_diag_chunks * sym_size(D))
     }
   }
-  s->y_records = st.has_shared || getenv("TMI_BA_SCHUR_GATHER") != nullptr || getenv("TMI_BA_SCHUR_Y") != nullptr;
+  // (TMI_BA_SCHUR_Y: the Y-record kernel on a problem without shared blocks -- how tests/test_gpu_parity.py checks it
+  // against the [A | Q] kernel on the same matrix)
+  s->y_records = st.has_shared || getenv("TMI_BA_SCHUR_Y") != nullptr;
   v.write_y = (s->y_records && (!s->implicit || st.has_shared)) ? 1 : 0;
   if (s->adaptive) {
     // cost model measured on MI355X (profiles/r02_z): forming S ~61 ps per pair, a product with S ~192 ps per
@@ -1863,12 +1853,12 @@ static void prepare_cameras(tmi_ba_solver* s, const double* ext, const double* i
 // returns TMI_BA_OK; *usable = 0 for LINEAR_SOLVER_FAILURE
 // q = S x: explicit (symmetric block SpMV on the formed Schur complement) or implicit
 // (two passes over the observations; the reduced vector is all-reduced across ranks)
-static int apply_schur(tmi_ba_solver* s, const double* x, double* y, int dot = 0, int spec = 0) {
+static int apply_schur(tmi_ba_solver* s, const double* x, double* y, int dot = 0) {
   DeviceView& v = s->v;
   const int n = v.Nrb * v.D;
   if (!s->implicit_now) {
     Timed t(s, TMI_BA_K_SPMV);
-    s->launch.spmv(v, s->stream, v.red + s->RL.ub, x, y, dot, spec);
+    s->launch.spmv(v, s->stream, v.red + s->RL.ub, x, y, dot);
     return TMI_BA_OK;
   }
   {
@@ -1877,10 +1867,10 @@ static int apply_schur(tmi_ba_solver* s, const double* x, double* y, int dot = 0
     const int add_diag = (s->st.world <= 1 || s->st.rank == 0) ? 1 : 0;
     if (s->mf_ok)
       s->launch.mf_product(v, s->mf, s->stream, s->RL, x, y, s->cur_inv_radius, O->min_lm_diagonal, O->max_lm_diagonal,
-                           add_diag, dot, spec);
+                           add_diag, dot);
     else
       s->launch.implicit_spmv(v, s->stream, s->RL, x, y, s->d_pm_u, s->d_cm_t, s->cur_inv_radius,
-                              O->min_lm_diagonal, O->max_lm_diagonal, add_diag, s->nblocks_tracks, dot, spec);
+                              O->min_lm_diagonal, O->max_lm_diagonal, add_diag, s->nblocks_tracks, dot);
   }
   // with the dot product fused, x . y (this rank's share) rides behind the vector
   return do_allreduce(s, y, n + (dot ? 1 : 0));
@@ -2035,53 +2025,29 @@ static int solve_reduced_pcg(tmi_ba_solver* s, const tmi_ba_options* O, int* usa
       hipLaunchKernelGGL(clp::cluster_init_fix_kernel, dim3(1), dim3(1024), 0, s->stream, v, n);
     }
   }
-  // Fused path (no shared intrinsics blocks): an iteration is  product (+ p.q) -> [all-reduce] ->
-  // pcg_step, and the NEXT iteration's launches are enqueued before this one's scalars are read
-  // (they return at once if pcg_step finds that PCG has stopped), so neither the launch latency
-  // nor the host's poll sits between two iterations.  Every tenth iteration recomputes the
-  // residual (residual_reset_period) through the three-kernel path below.
-  static const bool legacy_pcg = getenv("TMI_BA_PCG_LEGACY") != nullptr;
-  // Speculative enqueue of the next iteration (its kernels return at once if pcg_step finds PCG has
-  // stopped) measured no gain on MI355X -- 5.02 vs 5.04 ms per LM iteration at one GPU, 1.57 vs 1.53 ms
-  // for an eighth of the tracks (profiles/r02_g) -- so it is opt-in.
-  static const bool no_spec = getenv("TMI_BA_PCG_SPEC") == nullptr;
-  const bool fused = !s->st.has_shared && !legacy_pcg;
+  // Fused path (no shared intrinsics blocks): an iteration is  product (+ p.q) -> [all-reduce] -> pcg_step -> pcg_p,
+  // four launches and one poll of the host mirror.  Every tenth iteration recomputes the residual
+  // (residual_reset_period) through the three-kernel path below.  (Enqueueing iteration it + 1 speculatively before
+  // the scalars of iteration it are read measured no gain on MI355X -- 5.02 vs 5.04 ms per LM iteration at one GPU,
+  // 1.57 vs 1.53 ms for an eighth of the tracks, profiles/r02_g -- and is gone.)
+  const bool fused = !s->st.has_shared;
   const int nbv = (v.Nrb + 3) / 4;
   const int nbs16 = (v.Nrb + kPcgStepThreads / 64 - 1) / (kPcgStepThreads / 64);  // workgroups of pcg_step
   int it;
-  bool enqueued = false;           // iteration `it` is already on the stream
-  unsigned long long enq_seq = 0;  // ... and will publish with this sequence number
-  auto enqueue_fused = [&](int iter, int spec) -> int {
-    const int rcs = apply_schur(s, v.cg_p, v.cg_q, /*dot=*/1, spec);
-    if (rcs) return rcs;
-    Timed t(s, TMI_BA_K_PCG_VECTOR);
-    enq_seq = ++s->mirror_seq;
-    s->launch.pcg_step(v, s->stream, b, iter, nbs16, O->eta, O->min_linear_solver_iterations,
-                       O->max_linear_solver_iterations, v.red + s->RL.scalars, s->d_mirror + (iter & 1), enq_seq);
-    hipLaunchKernelGGL(pcg_p_kernel, dim3((n + 255) / 256), dim3(256), 0, s->stream, v, n);
-    return TMI_BA_OK;
-  };
   for (it = 1;; ++it) {
     const bool reset = (it % 10 == 0);  // residual_reset_period
     int rc;
     if (fused && !reset) {
+      if ((rc = apply_schur(s, v.cg_p, v.cg_q, /*dot=*/1))) return rc;
       unsigned long long my_seq;
-      if (enqueued) {
-        my_seq = enq_seq;
-      } else {
-        if ((rc = enqueue_fused(it, 0))) return rc;
-        my_seq = enq_seq;
-      }
-      enqueued = false;
-      // speculate on the next iteration unless it is a reset iteration or past the limit
-      unsigned long long next_seq = 0;
-      if (!no_spec && (it + 1) % 10 != 0 && it < O->max_linear_solver_iterations) {
-        if ((rc = enqueue_fused(it + 1, 1))) return rc;
-        next_seq = enq_seq;
-        enqueued = true;
+      {
+        Timed t(s, TMI_BA_K_PCG_VECTOR);
+        my_seq = ++s->mirror_seq;
+        s->launch.pcg_step(v, s->stream, b, it, nbs16, O->eta, O->min_linear_solver_iterations,
+                           O->max_linear_solver_iterations, v.red + s->RL.scalars, s->d_mirror + (it & 1), my_seq);
+        hipLaunchKernelGGL(pcg_p_kernel, dim3((n + 255) / 256), dim3(256), 0, s->stream, v, n);
       }
       if ((rc = wait_mirror(s, it & 1, my_seq))) return rc;
-      enq_seq = next_seq;
     } else {
       {
         const int rcs = apply_schur(s, v.cg_p, v.cg_q);
@@ -2159,8 +2125,10 @@ static int solve_reduced_dense(tmi_ba_solver* s, int* usable) {
   *usable = 1;
   if (n == 0) return TMI_BA_OK;
   Timed t(s, TMI_BA_K_CHOLESKY);
-  static const bool panels_only = getenv("TMI_BA_CHOL_PANELS") != nullptr;
-  if (panels_only) return solve_reduced_dense_panels(s);
+  // the launch-per-panel Cholesky is the fall-back of the dataflow launch (a launch that cannot become co-resident,
+  // FL_CHOL_ABORT below); TMI_BA_CHOL_PANELS selects it outright so that tests/test_gpu_cholesky.py can hold it to
+  // the dataflow result
+  if (getenv("TMI_BA_CHOL_PANELS") != nullptr) return solve_reduced_dense_panels(s);
   if (!s->num_cus) {
     hipDeviceProp_t prop;
     TMI_HIP(hipGetDeviceProperties(&prop, s->device));

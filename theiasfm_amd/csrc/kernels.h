@@ -1266,92 +1266,6 @@ __global__ __launch_bounds__(64) void camera_diag_kernel(DeviceView v, RedLayout
 // ------------------------------------------------------------------------------
 constexpr int kSchurBlocksPerWave = 4;
 
-template <int D, int DP>
-__global__ __launch_bounds__(256) void schur_offdiag_gather_kernel(DeviceView v, RedLayout L) {
-  constexpr int YS = ys_of(D, DP);
-  constexpr int R = kSchurBlocksPerWave;
-  const int lane = threadIdx.x & 63;
-  // wave (workgroup w, wave t) owns the R consecutive launch slots starting at
-  // (w * 4 + t) * R; headers {block, #pairs, first pair lo, hi} come in with one load
-  const long long first = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
-  if (first >= v.n_order) return;
-  int4 hq = make_int4(-1, 0, 0, 0);
-  if (lane < R && first + lane < v.n_order) hq = reinterpret_cast<const int4*>(v.ub_order)[first + lane];
-  const int i = lane & 15, kk = lane >> 4;
-  const bool row_ok = i < D;
-  const int col = lane & 15;
-  // slot indices of the first chunk (<= 64 pairs) of the NEXT block are fetched while the
-  // current block is being contracted, so only the Y gathers themselves are exposed
-  int nx_si = 0, nx_sj = 0;
-  {
-    const int u0 = __shfl(hq.x, 0, 64), n0 = __shfl(hq.y, 0, 64);
-    const long long q0 = ((long long)(unsigned)__shfl(hq.z, 0, 64)) | ((long long)__shfl(hq.w, 0, 64) << 32);
-    if (u0 >= 0 && lane < min(64, n0)) {
-      nx_si = v.pair_i[q0 + lane];
-      nx_sj = v.pair_j[q0 + lane];
-    }
-  }
-#pragma unroll 1
-  for (int r = 0; r < R; ++r) {
-    const int u = __shfl(hq.x, r, 64);
-    const int npairs = __shfl(hq.y, r, 64);
-    const long long p0 = ((long long)(unsigned)__shfl(hq.z, r, 64)) | ((long long)__shfl(hq.w, r, 64) << 32);
-    int my_si = nx_si, my_sj = nx_sj;
-    if (r + 1 < R) {
-      const int u1 = __shfl(hq.x, r + 1, 64), n1 = __shfl(hq.y, r + 1, 64);
-      const long long q1 = ((long long)(unsigned)__shfl(hq.z, r + 1, 64)) | ((long long)__shfl(hq.w, r + 1, 64) << 32);
-      nx_si = 0;
-      nx_sj = 0;
-      if (u1 >= 0 && lane < min(64, n1)) {
-        nx_si = v.pair_i[q1 + lane];
-        nx_sj = v.pair_j[q1 + lane];
-      }
-    }
-    if (u < 0) continue;
-    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-    // Pairs are taken 64 at a time: lane l holds the slots of pair l, every Y gather
-    // address then comes from a cross-lane read, and eight gathers per lane are in
-    // flight per trip.  The flat K = DP * #pairs contraction runs on the f64 MFMA.
-    for (int c0 = 0; c0 < npairs; c0 += 64) {
-      const int nch = min(64, npairs - c0);
-      if (c0 > 0) {
-        my_si = 0;
-        my_sj = 0;
-        if (lane < nch) {
-          my_si = v.pair_i[p0 + c0 + lane];
-          my_sj = v.pair_j[p0 + c0 + lane];
-        }
-      }
-      const int Kc = nch * DP;
-      for (int k0 = 0; k0 < Kc; k0 += 16) {
-        double a[4], b[4];
-#pragma unroll
-        for (int h = 0; h < 4; ++h) {
-          const int k = k0 + 4 * h + kk;
-          const int pr = min(k / DP, 63);
-          const int c = k - (k / DP) * DP;
-          const int si = __shfl(my_si, pr, 64), sj = __shfl(my_sj, pr, 64);
-          a[h] = 0.0;
-          b[h] = 0.0;
-          if (row_ok && k < Kc) {
-            // (non-temporal hints on either side were measured: 12-50 % slower -- the three
-            // accesses to a record's lines stop hitting in the vector L1)
-            a[h] = v.cm_Y[(size_t)si * YS + i * DP + c];
-            b[h] = v.cm_Y[(size_t)sj * YS + i * DP + c];
-          }
-        }
-#pragma unroll
-        for (int h = 0; h < 4; ++h) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[h], b[h], acc, 0, 0, 0);
-      }
-    }
-    double* out = v.red + L.ub + (size_t)u * D * D;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int row = (lane >> 4) + 4 * q;
-      if (row < D && col < D) out[row * D + col] = -acc[q];
-    }
-  }
-}
 
 // schur_offdiag, LDS-staged version (default).  Same launch slots, headers, pair lists, MFMA
 // contraction and summation order as the gather kernel above; what changes is how the Y
@@ -1372,15 +1286,12 @@ __global__ __launch_bounds__(256) void schur_offdiag_gather_kernel(DeviceView v,
 // its 1.82 ms on venice1778_heavy with the record loads switched OFF, profiles/r02_l.)
 constexpr int kSchurPairsPerChunk = 16;
 
-template <int D, int DP, int EXP = 0>
+template <int D, int DP>
 __global__ __launch_bounds__(256) void schur_offdiag_kernel(DeviceView v, RedLayout L) {
-  // EXP: timing experiments only (results are garbage; built with -DTMI_BA_SCHUR_EXPERIMENTS,
-  // picked with TMI_BA_EXP): 1 = one 128-byte line per record, 2 = no contraction, 3 = no record
-  // loads, 4 = half the resident workgroups.  Findings: profiles/r02_l_schur_ablation.md.
-  constexpr int YS = EXP == 1 ? 16 : ys_of(D, DP);
+  constexpr int YS = ys_of(D, DP);
   constexpr int R = kSchurBlocksPerWave;
   constexpr int PC = kSchurPairsPerChunk;
-  constexpr int PARTS = EXP == 1 ? 8 : (D * DP + 1) / 2;  // 16-byte parts of a record that carry data
+  constexpr int PARTS = (D * DP + 1) / 2;  // 16-byte parts of a record that carry data
   constexpr int PITCH = ys_of(D, DP) + 2;          // doubles; keeps the 16-byte parts aligned
   constexpr int NL = (2 * PC * PARTS + 63) / 64;   // 16-byte loads per lane per chunk
   constexpr int STEPS = PC * DP / 4;               // MFMA steps (K = 4 each) of a full chunk
@@ -1388,10 +1299,8 @@ __global__ __launch_bounds__(256) void schur_offdiag_kernel(DeviceView v, RedLay
   static_assert((PC * DP) % 4 == 0 && STEPS % GS == 0, "chunk K must be whole groups of MFMA steps");
   static_assert(R <= 64, "slot headers live one per lane");
   __shared__ __attribute__((aligned(16))) double lds_all[4][2 * PC * PITCH];
-  __shared__ double lds_pad[EXP == 4 ? 3000 : 1];  // EXP 4: 2 workgroups per CU instead of 4
   const int lane = threadIdx.x & 63;
   double* lds = lds_all[threadIdx.x >> 6];
-  if (EXP == 4 && v.n_order < 0) lds_pad[threadIdx.x] = 1.0;
   const long long first = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
   if (first >= v.n_order) return;  // wave-uniform; no workgroup barrier below
   // lane r holds launch slot r: {block, #pairs, first pair lo, first pair hi}
@@ -1458,7 +1367,7 @@ __global__ __launch_bounds__(256) void schur_offdiag_kernel(DeviceView v, RedLay
       const int rec = f / PARTS, part = f - rec * PARTS;
       const int pr = rec >= PC ? rec - PC : rec;
       double2 t = make_double2(0.0, 0.0);
-      if (EXP != 3 && rec < 2 * PC && pr < c.n)
+      if (rec < 2 * PC && pr < c.n)
         t = *reinterpret_cast<const double2*>(v.cm_Y + (size_t)sl[it] * YS + 2 * part);
       pf[it] = t;
     }
@@ -1490,7 +1399,7 @@ __global__ __launch_bounds__(256) void schur_offdiag_kernel(DeviceView v, RedLay
     const int ksteps = (A.n * DP + 3) / 4;
 #pragma unroll
     for (int g = 0; g < STEPS / GS; ++g) {
-      if (EXP != 2 && g * GS < ksteps) {
+      if (g * GS < ksteps) {
         double a[GS], b[GS];
 #pragma unroll
         for (int h = 0; h < GS; ++h) {
@@ -1829,7 +1738,7 @@ __global__ __launch_bounds__(64) void precond_invert_kernel(DeviceView v, int mo
 // ------------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(256) void spmv_rows_kernel(DeviceView v, const double* __restrict__ ub,
-                                                        const double* __restrict__ x, int spec) {
+                                                        const double* __restrict__ x) {
   constexpr int G = 64 / D;
   constexpr int BLK = D * D;
   constexpr int NW = G * BLK;            // doubles per trip
@@ -1839,7 +1748,6 @@ __global__ __launch_bounds__(256) void spmv_rows_kernel(DeviceView v, const doub
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int cidx = blockIdx.x * 4 + w;
   if (cidx >= v.n_spc) return;  // no workgroup barrier below
-  if (spec && *v.pcg_done) return;
   const int row = v.spc_row[cidx];
   const int u0 = v.spc_u0[cidx];
   const int u1 = min(u0 + kSpmvTrips * G, v.urow_ptr[row + 1]);
@@ -1934,13 +1842,11 @@ __device__ __forceinline__ bool last_block_sum(double mine, double* __restrict__
 }
 
 // dot != 0: also y[Nrb D] = x . y (the p.q of a PCG iteration), summed by the last workgroup;
-// spec != 0: return at once when PCG has already stopped (speculative launch).
 template <int D>
 __global__ __launch_bounds__(256) void spmv_cols_kernel(DeviceView v, const double* __restrict__ x,
-                                                        double* __restrict__ y, int dot, int spec) {
+                                                        double* __restrict__ y, int dot) {
   constexpr int G = 64 / D;
   __shared__ double part[4][G][D];
-  if (spec && *v.pcg_done) return;
   const int col = blockIdx.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int g = lane / D, r = lane - g * D;
@@ -1990,8 +1896,7 @@ __global__ __launch_bounds__(256) void spmv_cols_kernel(DeviceView v, const doub
 // block for implicit_groups to add up in the block's view order.
 template <int D, int DP>
 __global__ __launch_bounds__(256) void implicit_tracks_sq_kernel(DeviceView v, const double* __restrict__ x,
-                                                                 double* __restrict__ zhat, int spec) {
-  if (spec && *v.pcg_done) return;
+                                                                 double* __restrict__ zhat) {
   const TrackMap tm = track_map(v);
   if (!tm.valid) return;
   const int lp = tm.lp;
@@ -2059,8 +1964,7 @@ __global__ __launch_bounds__(256) void implicit_tracks_sq_kernel(DeviceView v, c
 // ------------------------------------------------------------------------------
 template <int D, int DP>
 __global__ __launch_bounds__(256) void implicit_tracks_q_kernel(DeviceView v, const double* __restrict__ x,
-                                                                double* __restrict__ zhat, int spec) {
-  if (spec && *v.pcg_done) return;
+                                                                double* __restrict__ zhat) {
   const TrackMap tm = track_map(v);
   if (!tm.valid) return;
   const int lp = tm.lp;
@@ -2131,10 +2035,8 @@ __global__ __launch_bounds__(64) void implicit_cameras_q_kernel(DeviceView v, Re
                                                                 const double* __restrict__ x,
                                                                 const double* __restrict__ zhat,
                                                                 double* __restrict__ y, double inv_radius,
-                                                                double lm_lo, double lm_hi, int add_diag, int dot,
-                                                                int spec) {
+                                                                double lm_lo, double lm_hi, int add_diag, int dot) {
   constexpr int ASA = asa_of(D, DP);
-  if (spec && *v.pcg_done) return;
   // Workgroups are dealt to the 8 XCDs round-robin: XCD x takes the views [x chunk, (x + 1) chunk), so the views
   // in flight on one XCD are neighbours and the zhat lines of the tracks they share are fetched into that XCD's
   // L2 once (the track order keeps the tracks of neighbouring views together).  Grid = 8 chunk workgroups.
@@ -2210,9 +2112,8 @@ __global__ __launch_bounds__(64) void implicit_cameras_sq_kernel(DeviceView v, R
                                                                  const double* __restrict__ zhat,
                                                                  double* __restrict__ y, double inv_radius,
                                                                  double lm_lo, double lm_hi, int add_diag,
-                                                                 double* __restrict__ grp_part, int spec) {
+                                                                 double* __restrict__ grp_part) {
   constexpr int AS = as_of(D, true);
-  if (spec && *v.pcg_done) return;
   const int rb = blockIdx.x;
   if (rb >= v.Ncam_rb) return;
   const int cam = v.rb_cam[rb];
@@ -2480,7 +2381,6 @@ __global__ __launch_bounds__(kPcgStepThreads) void pcg_step_kernel(DeviceView v,
                                                        int nblocks, double eta, int min_it, int max_it,
                                                        const double* __restrict__ red8, HostMirror* mirror,
                                                        unsigned long long seq) {
-  if (*v.pcg_done) return;
   constexpr int T = kPcgStepThreads, W = T / 64;
   __shared__ double sh[2][T];
   __shared__ double shw[2][W];
@@ -2579,7 +2479,7 @@ __global__ __launch_bounds__(kPcgStepThreads) void pcg_step_kernel(DeviceView v,
       set(SC_RHO_BAD, rho_bad);
     }
     set(SC_ZETA, zeta);
-    // the host's stopping rules (solve_reduced_pcg), evaluated here for the speculative launches
+    // the host's stopping rules (solve_reduced_pcg): pcg_p, enqueued behind this kernel, has nothing to do once they hold
     const bool stop = pubf[FL_PCG_FAIL] != 0 || !ok || (zeta < eta && it >= min_it) || it >= max_it || rho_bad != 0.0;
     *v.pcg_done = stop ? 1 : 0;
   }

@@ -34,6 +34,7 @@ namespace mfc {
 constexpr int kWaves = 4;  // two workgroups per CU (<= 80 KB of LDS each), two wavefronts per SIMD
 constexpr int kThreads = 64 * kWaves;
 constexpr int kMaxNarrowK = 20;               // longest thread-per-track slice (kWideKLarge)
+constexpr int kLongRun = 12;                  // a run with more entries than this is summed by a whole wavefront
 // a wavefront owns rows w, w + 4, ... of a slice; the first reg_rows(D) of them keep A, Jp and u in registers until
 // the track's z is known, the rest (one slice in four is that long) are evaluated again once z is there
 __host__ __device__ constexpr int reg_rows(int D) { return D <= 9 ? 2 : 1; }
@@ -228,9 +229,16 @@ __device__ __forceinline__ void track_solve(const DeviceView& v, int lp, const d
   }
 }
 
+// workgroup barrier that orders LDS accesses only: loads from global memory stay in flight across it (__syncthreads
+// drains them: s_waitcnt vmcnt(0)).  Everything the wavefronts of the narrow path exchange goes through LDS.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 template <int D, int DP>
-__global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View m, const double* __restrict__ x,
-                                                              int spec) {
+__global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View m, const double* __restrict__ x) {
   constexpr int LCM = lc_max(D);
   constexpr int VB = vb_entries(D);
   constexpr int ROWD = 2 * D * 64;  // doubles of one row (= one 64-observation tile) of the A planes
@@ -239,7 +247,9 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
   __shared__ double wpart[kWaves][DP][64];
   __shared__ double zs[DP][64];
   __shared__ double acc[LCM * D];
-  if (spec && *v.pcg_done) return;
+  __shared__ int4 long_run[VB / kLongRun + 2];
+  __shared__ int n_long;
+  if (threadIdx.x == 0) n_long = 0;
   const int item = blockIdx.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 
@@ -338,10 +348,10 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
   if (!direct)
     for (int i = threadIdx.x; i < nlc * D; i += kThreads) acc[i] = 0.0;
   int nrb[RR], npos[RR];
-  auto load_index = [&](int u) {
-    const int s = v.n_wide + (u - m.nwb);
-    const int sp0 = v.slice_ptr[s];
-    const int K = (v.slice_ptr[s + 1] - sp0) >> 6;
+  // the slice geometry travels two slices ahead and the view indices one, so that the batch of loads of a slice
+  // can be issued the moment its iteration begins (no dependent look-up in front of it)
+  const int* sptr = v.slice_ptr + (v.n_wide - m.nwb);
+  auto load_index = [&](int sp0, int K) {
 #pragma unroll
     for (int rr = 0; rr < RR; ++rr) {
       const int j = w + rr * kWaves;
@@ -353,34 +363,51 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
       }
     }
   };
-  load_index(u0);
+  int sp0 = sptr[u0], sp1 = sptr[u0 + 1];
+  int sp2 = sptr[min(u0 + 2, m.n_units)];
+  load_index(sp0, (sp1 - sp0) >> 6);
   int r0 = m.unit_run_ptr[u0];
   int o0 = m.run_obs_ptr[r0];
   for (int u = u0; u < u1; ++u) {
     const int s = v.n_wide + (u - m.nwb);
-    const int sp0 = v.slice_ptr[s];
-    const int K = (v.slice_ptr[s + 1] - sp0) >> 6;
+    const int K = (sp1 - sp0) >> 6;
     const size_t tile0 = (size_t)(sp0 >> 6);
+    const int sp3 = sptr[min(u + 3, m.n_units)];
     const int r1 = m.unit_run_ptr[u + 1];
     const int o1 = m.run_obs_ptr[r1];
     double2 ar[RR][D], jr[RR][DP];
     double xr[RR][D];
     double uu[RR][2];
     int pos[RR];
-    // ---- the batch of loads
+    // ---- the batch of loads (rows beyond the slice: a wave-uniform skip)
 #pragma unroll
     for (int rr = 0; rr < RR; ++rr) {
-      const int j = min(w + rr * kWaves, K - 1);  // (a row beyond the slice re-reads the last one; its result is dropped)
+      const int j = w + rr * kWaves;
       pos[rr] = nrb[rr] >= 0 ? npos[rr] : -1;
-      const double* xc = x + (size_t)max(nrb[rr], 0) * D;
 #pragma unroll
-      for (int a = 0; a < D; ++a) xr[rr][a] = xc[a];
-      const double* ap = v.pm_A + (tile0 + j) * ROWD + 2 * lane;
-      const double* jp = v.pm_Jp + (tile0 + j) * ROWP + 2 * lane;
+      for (int a = 0; a < D; ++a) {
+        xr[rr][a] = 0.0;
+        ar[rr][a] = make_double2(0.0, 0.0);
+      }
 #pragma unroll
-      for (int a = 0; a < D; ++a) ar[rr][a] = *reinterpret_cast<const double2*>(ap + a * 128);
+      for (int a = 0; a < DP; ++a) jr[rr][a] = make_double2(0.0, 0.0);
+      if (j < K) {
+        // the view's block of x: D doubles at an 8-byte aligned address, fetched 16 bytes at a time
+        const double* xc = x + (size_t)max(nrb[rr], 0) * D;
 #pragma unroll
-      for (int a = 0; a < DP; ++a) jr[rr][a] = *reinterpret_cast<const double2*>(jp + a * 128);
+        for (int a = 0; a + 1 < D; a += 2) {
+          const double2_a8 t2 = *reinterpret_cast<const double2_a8*>(xc + a);
+          xr[rr][a] = t2.x;
+          xr[rr][a + 1] = t2.y;
+        }
+        if (D & 1) xr[rr][D - 1] = xc[D - 1];
+        const double* ap = v.pm_A + (tile0 + j) * ROWD + 2 * lane;
+        const double* jp = v.pm_Jp + (tile0 + j) * ROWP + 2 * lane;
+#pragma unroll
+        for (int a = 0; a < D; ++a) ar[rr][a] = *reinterpret_cast<const double2*>(ap + a * 128);
+#pragma unroll
+        for (int a = 0; a < DP; ++a) jr[rr][a] = *reinterpret_cast<const double2*>(jp + a * 128);
+      }
     }
     double Li[NLI];
     if (w == 0) {
@@ -396,7 +423,7 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
       mb[q] = m.run_obs_ptr[r + 1];
       ms[q] = m.run_slot[r];
     }
-    if (u + 1 < u1) load_index(u + 1);
+    if (u + 1 < u1) load_index(sp1, (sp2 - sp1) >> 6);
     // ---- u_i = A_i x, this wavefront's share of w = sum Jp^T u
     double wv[DP];
 #pragma unroll
@@ -443,7 +470,7 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
     }
 #pragma unroll
     for (int a = 0; a < DP; ++a) wpart[w][a][lane] = wv[a];
-    __syncthreads();  // wpart (and: the previous slice's run sums have left vbuf)
+    lds_barrier();  // wpart (and: the previous slice's run sums have left vbuf)
     if (w == 0) {
       double wt[DP], zh[DP];
 #pragma unroll
@@ -469,7 +496,7 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
         zs[a][lane] = t;
       }
     }
-    __syncthreads();  // zs
+    lds_barrier();  // zs
     double z[DP];
 #pragma unroll
     for (int a = 0; a < DP; ++a) z[a] = zs[a][lane];
@@ -485,7 +512,7 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
     // v_i = A_i^T t_i into LDS in view order, VB at a time; a thread per run sums its (consecutive) entries
     const int nv = o1 - o0;
     for (int pb = 0; pb < nv; pb += VB) {
-      if (pb > 0) __syncthreads();  // the previous round's sums are taken
+      if (pb > 0) lds_barrier();  // the previous round's sums are taken
 #pragma unroll
       for (int rr = 0; rr < RR; ++rr) {
         const int p = pos[rr] - pb;
@@ -523,10 +550,33 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
 #pragma unroll
         for (int a = 0; a < D; ++a) dst[a] = aa[a].x * t0 + aa[a].y * t1;
       }
-      __syncthreads();  // vbuf
+      lds_barrier();  // vbuf
+      auto put_sum = [&](const double (&sum)[D], int first, int slot) {
+        if (direct) {
+          double* dst = m.partial + (size_t)slot * D;
+          if (first - o0 >= pb) {
+#pragma unroll
+            for (int a = 0; a < D; ++a) dst[a] = sum[a];
+          } else {  // the run began in the previous round (its first part is there already)
+#pragma unroll
+            for (int a = 0; a < D; ++a) dst[a] += sum[a];
+          }
+        } else {
+          double* dst = &acc[(slot - slot0) * D];  // one run per view and slice: nobody else adds here
+#pragma unroll
+          for (int a = 0; a < D; ++a) dst[a] += sum[a];
+        }
+      };
       auto take_run = [&](int first, int last, int slot) {
         const int b = max(first - o0 - pb, 0), e = min(last - o0 - pb, VB);
         if (b >= e) return;
+        if (e - b > kLongRun) {
+          // a long run (the slice's tracks share their lowest view: 64 entries) would hold its wavefront for
+          // e - b dependent trips: a whole wavefront takes it after this loop
+          const int i = atomicAdd(&n_long, 1);
+          long_run[i] = make_int4(b, e, slot, first);
+          return;
+        }
         double sum[D];
 #pragma unroll
         for (int a = 0; a < D; ++a) sum[a] = 0.0;
@@ -534,29 +584,36 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
 #pragma unroll
           for (int a = 0; a < D; ++a) sum[a] += vbuf[p * D + a];
         }
-        if (direct) {
-          double* dst = m.partial + (size_t)slot * D;
-          if (first - o0 >= pb) {
-#pragma unroll
-            for (int a = 0; a < D; ++a) dst[a] = sum[a];
-          } else {  // the run began in the previous round (this thread wrote its first part)
-#pragma unroll
-            for (int a = 0; a < D; ++a) dst[a] += sum[a];
-          }
-        } else {
-          double* dst = &acc[(slot - slot0) * D];  // one run per view and slice: no other thread adds here
-#pragma unroll
-          for (int a = 0; a < D; ++a) dst[a] += sum[a];
-        }
+        put_sum(sum, first, slot);
       };
 #pragma unroll
       for (int q = 0; q < 2; ++q)
         if (r0 + (int)threadIdx.x + q * kThreads < r1) take_run(ma[q], mb[q], ms[q]);
       for (int r = r0 + (int)threadIdx.x + 2 * kThreads; r < r1; r += kThreads)
         take_run(m.run_obs_ptr[r], m.run_obs_ptr[r + 1], m.run_slot[r]);
+      lds_barrier();  // the list of long runs
+      const int nl = n_long;
+      for (int i = w; i < nl; i += kWaves) {
+        const int4 lr = long_run[i];
+        double sum[D];
+#pragma unroll
+        for (int a = 0; a < D; ++a) sum[a] = 0.0;
+        for (int p = lr.x + lane; p < lr.y; p += 64) {
+#pragma unroll
+          for (int a = 0; a < D; ++a) sum[a] += vbuf[p * D + a];
+        }
+#pragma unroll
+        for (int a = 0; a < D; ++a) sum[a] = wave_sum(sum[a]);  // fixed butterfly: reproducible
+        if (lane == 0) put_sum(sum, lr.w, lr.z);
+      }
+      lds_barrier();  // n_long is read
+      if (threadIdx.x == 0) n_long = 0;
     }
     r0 = r1;
     o0 = o1;
+    sp0 = sp1;
+    sp1 = sp2;
+    sp2 = sp3;
   }
   if (direct) return;
   __syncthreads();  // acc
@@ -568,10 +625,9 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
 template <int D>
 __global__ __launch_bounds__(256) void reduce_kernel(DeviceView v, View m, RedLayout L, const double* __restrict__ x,
                                                      double* __restrict__ y, double inv_radius, double lm_lo,
-                                                     double lm_hi, int add_diag, int dot, int spec) {
+                                                     double lm_hi, int add_diag, int dot) {
   __shared__ double sh[4][D];
   __shared__ double prod[D];
-  if (spec && *v.pcg_done) return;
   const int chunk = ((int)gridDim.x) >> 3;
   const int rb = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
   const bool live = rb < v.Nrb;  // the padding workgroups still take part in the dot product's ticket

@@ -18,10 +18,6 @@
 
 namespace tmi {
 
-bool track_order_plain() {
-  static const bool plain = getenv("TMI_BA_TRACK_ORDER_PLAIN") != nullptr;
-  return plain;
-}
 namespace {
 
 int model_size(int m) {
@@ -293,10 +289,7 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, 
   {
     std::vector<int> by_cam;
     by_cam.reserve(s.Np_total);
-    if (track_order_plain()) {
-      for (int p = 0; p < s.Np_total; ++p)
-        if (klen[p] > 0) by_cam.push_back(p);
-    } else {
+    {
       std::vector<int> first_cam(s.Np_total, 0);
       run_early([&](int t) {
         const int p0 = (int)((int64_t)s.Np_total * t / n_early), p1 = (int)((int64_t)s.Np_total * (t + 1) / n_early);

@@ -100,8 +100,6 @@ int build_blocks(const tmi_ba_problem* P, int rank, int world, Structure* out);
 // Returns TMI_BA_OK or an error status (message in out->error).
 // want_pairs = false skips the block structure of S and the pair lists (implicit Schur
 // operator: S is never formed).
-// A/B switch (TMI_BA_TRACK_ORDER_PLAIN): ties of the length order by track index only, as before round 2
-bool track_order_plain();
 
 // want_pairs = 2: only the blocks INSIDE a cluster {shared intrinsics block, its views} and their pair lists -- what
 // CLUSTER_JACOBI needs when the operator itself is matrix-free (cluster_precond.h); without shared blocks: none.

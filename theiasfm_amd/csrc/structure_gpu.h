@@ -62,12 +62,12 @@ __global__ __launch_bounds__(256) void dup_check_kernel(const unsigned long long
 __global__ __launch_bounds__(256) void track_keys_kernel(const int* __restrict__ klen, int Np,
                                                          const long long* __restrict__ tptr,
                                                          const unsigned long long* __restrict__ okeys, int cam_bits,
-                                                         int plain, unsigned long long* __restrict__ keys,
+                                                         unsigned long long* __restrict__ keys,
                                                          int* __restrict__ vals) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= Np) return;
   unsigned cam = 0;
-  if (!plain && klen[p] > 0) cam = (unsigned)(okeys[tptr[p]] & ((1ull << cam_bits) - 1ull));
+  if (klen[p] > 0) cam = (unsigned)(okeys[tptr[p]] & ((1ull << cam_bits) - 1ull));
   // ascending ~k = descending k; k = 0 sorts last
   keys[p] = ((unsigned long long)(~(unsigned)klen[p]) << cam_bits) | cam;
   vals[p] = p;
