@@ -70,7 +70,8 @@ def test_engine_fallback_path_matches_the_dataflow_solve(monkeypatch):
     (engine.hip solve_reduced_dense); TMI_BA_CHOL_PANELS selects it outright: same LM trajectory as the default."""
     from theiasfm_amd import abi, lib, synth
     prob = synth.make_problem(120, 20000, 110000, seed=13, scene="ring", spread=0.4)  # n = 1080: 17 tile rows
-    o = abi.default_options(linear_solver_type=abi.SPARSE_SCHUR, point_dof=3, max_num_iterations=5, use_inner_iterations=0)
+    o = abi.default_options(linear_solver_type=abi.SPARSE_SCHUR, point_dof=3, max_num_iterations=5, use_inner_iterations=0,
+                            function_tolerance=-1.0, gradient_tolerance=-1.0, parameter_tolerance=-1.0)
     a, b = prob.copy(), prob.copy()
     st_a, s_a = lib.solve(a, o)
     monkeypatch.setenv("TMI_BA_CHOL_PANELS", "1")

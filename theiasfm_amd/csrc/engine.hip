@@ -1124,6 +1124,20 @@ int32_t tmi_ba_intrinsics_constant_mask(int32_t model, int32_t bits, uint8_t* ma
 }
 
 void tmi_ba_solver_destroy(tmi_ba_solver* s) {
+#ifdef TMI_MF_PROFILE
+  if (s && s->mf_ok && s->mf.prof) {
+    std::vector<long long> h((size_t)s->mf.n_items * 8);
+    hipDeviceSynchronize();
+    hipMemcpy(h.data(), s->mf.prof, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+    double t[5] = {0, 0, 0, 0, 0}, units = 0;
+    for (int i = s->mf.nwb; i < s->mf.n_items; ++i) {
+      for (int k = 0; k < 5; ++k) t[k] += (double)h[(size_t)i * 8 + k];
+      units += (double)h[(size_t)i * 8 + 5];
+    }
+    fprintf(stderr, "[mf profile] last product, per narrow unit (cycles): batch+u %.0f | z %.0f | v %.0f | runs %.0f | long %.0f  (units %.0f)\n",
+            t[0] / units, t[1] / units, t[2] / units, t[3] / units, t[4] / units, units);
+  }
+#endif
   if (!s) return;
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
@@ -1151,10 +1165,18 @@ void tmi_ba_solver_destroy(tmi_ba_solver* s) {
 static int build_mf_chunks(tmi_ba_solver* s) {
   using namespace tmi::mfc;
   s->mf_ok = false;
-  // Opt-in: measured on MI355X (profiles/r04_one_sweep_experiment.md) the one-sweep product reads half the bytes of the
-  // two-pass one and is no faster yet (0.45 + 0.04 ms against 0.21 + 0.25 ms per product at Venice size): every slice
-  // costs a workgroup a fixed ~8 us of dependent look-ups and barriers that two workgroups per CU do not hide.
-  if (!getenv("TMI_BA_MF_ONE_SWEEP")) return TMI_BA_OK;
+  int rc_early = TMI_BA_OK;
+  // Which product: measured on MI355X (profiles/r04_one_sweep_experiment.md, same-box pairs on venice1778_heavy) the
+  // one-sweep product takes 4-13 % off the LM iteration when a rank holds the whole problem, a half or a quarter of it
+  // (3.80 / 2.20 / 1.24 ms against 4.00 / 2.35 / 1.42) and loses 5 % on an eighth (0.81 against 0.77 ms: 625 k
+  // observations are ~500 work items of ~40 us each, a single round, and the 16- / 64-lane units take ~100 us whatever
+  // the shard).  So: the one-sweep product from a million observations per rank, the two-pass product below;
+  // TMI_BA_MF_ONE_SWEEP=1 / =0 forces either (tests, A/B).
+  {
+    const char* e = getenv("TMI_BA_MF_ONE_SWEEP");
+    const bool want = e ? atoi(e) != 0 : s->st.No >= 1000000;
+    if (!want) return TMI_BA_OK;
+  }
   Structure& st = s->st;
   DeviceView& v = s->v;
   hipStream_t stream = s->stream;
@@ -1162,9 +1184,25 @@ static int build_mf_chunks(tmi_ba_solver* s) {
   const int Nrb = st.Nrb, D = st.D;
   const int nub = 16 * st.n_ultra, nwb = nub + 4 * (st.n_wide - st.n_ultra);
   const int n_narrow = st.nslices - st.n_wide;
-  const int n_units = nwb + n_narrow;
   auto rows_of = [&](int sl) { return (st.slice_ptr[sl + 1] - st.slice_ptr[sl]) >> 6; };
   if (n_narrow > 0 && rows_of(st.n_wide) > kMaxNarrowK) return TMI_BA_OK;
+  // narrow units: a slice, or a pack of consecutive slices of the same (small) length whose rows together fill the
+  // kWaves * reg_rows(D) row slots of the kernel
+  std::vector<int4> unit_desc;  // {first element, rows, rows of one slice, first slice}
+  {
+    const int slots = kWaves * reg_rows(D);
+    for (int sl = st.n_wide; sl < st.nslices;) {
+      const int K = rows_of(sl);
+      int G = 1;
+      if (K > 0 && 2 * K <= slots)
+        while (G < slots / K && sl + G < st.nslices && rows_of(sl + G) == K) ++G;
+      unit_desc.push_back(make_int4(st.slice_ptr[sl], G * K, K, sl));
+      sl += G;
+    }
+  }
+  const int n_units = nwb + (int)unit_desc.size();
+  int4* d_unit_desc;
+  if ((rc_early = dev_upload(s, &d_unit_desc, unit_desc))) return rc_early;
   if (!s->num_cus) {
     hipDeviceProp_t prop;
     TMI_HIP(hipGetDeviceProperties(&prop, s->device));
@@ -1218,7 +1256,7 @@ static int build_mf_chunks(tmi_ba_solver* s) {
   TMI_HIP(tmp.get(&d_head, (size_t)n + 1));
   TMI_HIP(tmp.get(&d_pos, (size_t)n + 1));
   TMI_HIP(tmp.get(&d_nvalid, 1));
-  hipLaunchKernelGGL(unit_keys_kernel, dim3(n_units), dim3(256), 0, stream, v, nub, nwb, Nrb, invalid, d_k_in, d_v_in);
+  hipLaunchKernelGGL(unit_keys_kernel, dim3(n_units), dim3(256), 0, stream, v, nub, nwb, Nrb, d_unit_desc, invalid, d_k_in, d_v_in);
   MF_SORT_PAIRS(d_k_in, d_k_out, d_v_in, d_v_out, n, key_bits);
   int n_valid = (int)n;
   TMI_HIP(hipMemcpyAsync(d_nvalid, &n_valid, sizeof(int), hipMemcpyHostToDevice, stream));
@@ -1264,15 +1302,15 @@ static int build_mf_chunks(tmi_ba_solver* s) {
   {
     long long have = 0;
     int last_rows = -1;
-    for (int sl = st.n_wide; sl < st.nslices; ++sl) {
-      const int u = nwb + (sl - st.n_wide), rows = rows_of(sl);
+    for (size_t i = 0; i < unit_desc.size(); ++i) {
+      const int u = nwb + (int)i, rows = unit_desc[i].z;
       if (last_rows < 0 || rows != last_rows || have >= target) {
         groups.emplace_back(u, u + 1);
         have = 0;
       } else {
         groups.back().second = u + 1;
       }
-      have += (long long)rows * 64;
+      have += (long long)unit_desc[i].y * 64;
       last_rows = rows;
     }
   }
@@ -1371,6 +1409,7 @@ static int build_mf_chunks(tmi_ba_solver* s) {
   double *p_partial, *p_ut;
   if ((rc = dev_alloc(s, &p_partial, (size_t)n_slots * D))) return rc;
   if ((rc = dev_alloc(s, &p_ut, (size_t)2 * std::max(st.slice_ptr[st.n_wide], 1)))) return rc;
+  m.unit_desc = d_unit_desc;
   m.item_unit0 = p_item_unit0;
   m.unit_run_ptr = p_unit_run_ptr;
   m.run_obs_ptr = p_run_obs_ptr;
@@ -1382,12 +1421,23 @@ static int build_mf_chunks(tmi_ba_solver* s) {
   m.cam_slot_ptr = p_cam_slot_ptr;
   m.cam_slots = p_cam_slots;
   m.partial = p_partial;
+#ifdef TMI_MF_PROFILE
+  {
+    long long* pp;
+    if ((rc = dev_alloc(s, &pp, (size_t)n_items * 8))) return rc;
+    TMI_HIP(hipMemsetAsync(pp, 0, (size_t)n_items * 8 * sizeof(long long), stream));
+    m.prof = pp;
+  }
+#endif
   m.ut = p_ut;
   TMI_HIP(hipStreamSynchronize(stream));
   s->mf_ok = true;
-  if (getenv("TMI_BA_SETUP_TIMING"))
-    fprintf(stderr, "[tmi_ba setup] one-sweep product: %d units, %d items, %d runs, %d slots (%.1f MB of partials)\n", n_units,
-            n_items, n_runs, n_slots, 8e-6 * n_slots * D);
+  if (getenv("TMI_BA_SETUP_TIMING")) {
+    int occ = -1;
+    if (D == 9 && s->DP == 3) hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, mfc::product_kernel<9, 3>, mfc::kThreads, 0);
+    fprintf(stderr, "[tmi_ba setup] one-sweep product: %d units, %d items, %d runs, %d slots (%.1f MB of partials), "
+                    "%d workgroups per CU\n", n_units, n_items, n_runs, n_slots, 8e-6 * n_slots * D, occ);
+  }
   return TMI_BA_OK;
 }
 

@@ -40,14 +40,16 @@ constexpr int kLongRun = 12;                  // a run with more entries than th
 __host__ __device__ constexpr int reg_rows(int D) { return D <= 9 ? 2 : 1; }
 // distinct views an item of SEVERAL slices may see (its accumulators); an item of one slice writes its run sums
 // straight to its slots and has no limit
-__host__ __device__ constexpr int lc_max(int D) { return D <= 6 ? 768 : D <= 9 ? 512 : D <= 12 ? 384 : 288; }
-__host__ __device__ constexpr int vb_entries(int D) { return D <= 6 ? 640 : D <= 9 ? 448 : D <= 12 ? 320 : 224; }  // v_i per round
+__host__ __device__ constexpr int lc_max(int D) { return D <= 6 ? 704 : D <= 9 ? 472 : D <= 12 ? 352 : 264; }
+// v_i per round: at least the kWaves * reg_rows(D) rows a pack keeps in registers
+__host__ __device__ constexpr int vb_entries(int D) { return D <= 9 ? 512 : 256; }
 
 struct View {
   int n_items, n_units, n_runs;
   int nub;  // units [0, nub): four tracks of an ultra slice each
   int nwb;  // units [nub, nwb): a quarter of a wide slice each; [nwb, n_units): narrow slices
   const int* item_unit0;     // [n_items + 1] units of an item (wide / ultra: one)
+  const int4* unit_desc;     // [n_units - nwb] narrow units: {first element, rows, rows of one slice, first slice}
   const int* unit_run_ptr;   // [n_units + 1]
   const int* run_obs_ptr;    // [n_runs + 1]
   const int* run_obs;        // element index e of every observation that has a view block, by (unit, view)
@@ -57,6 +59,7 @@ struct View {
   const int* obs_pos;        // [No_pad] position of the observation in its unit's view order, -1: no view block
   const int* cam_slot_ptr;   // [Nrb + 1] slots of a view block ...
   const int* cam_slots;      // ... ascending (item order)
+  long long* prof;           // TMI_MF_PROFILE builds: per item {cycles of 5 phases, units}
   double* partial;           // [n_slots][D]
   double* ut;                // [elements of the wide slices][2]
 };
@@ -84,14 +87,24 @@ __device__ __forceinline__ UnitShape unit_shape(const DeviceView& v, int u, int 
   q.K = (v.slice_ptr[q.s + 1] - q.sp0) >> 6;
   return q;
 }
+// (narrow units are slices or packs of slices: their shape comes from View::unit_desc)
 
 // ---- structure build (once per handle; radix sorts + scans driven by engine.hip) ---------------------------
 // key (unit, view block) of every element; elements without a view block sort last
 __global__ __launch_bounds__(256) void unit_keys_kernel(DeviceView v, int nub, int nwb, int Nrb,
-                                                        unsigned long long invalid,
+                                                        const int4* __restrict__ unit_desc, unsigned long long invalid,
                                                         unsigned long long* __restrict__ keys, int* __restrict__ vals) {
   const int u = blockIdx.x;
-  const UnitShape q = unit_shape(v, u, nub, nwb);
+  UnitShape q;
+  if (u < nwb) {
+    q = unit_shape(v, u, nub, nwb);
+  } else {  // a slice or a pack of slices: rows x 64 consecutive elements
+    const int4 d = unit_desc[u - nwb];
+    q.sp0 = d.x;
+    q.K = d.y;
+    q.t0 = 0;
+    q.nt = 64;
+  }
   const int n = q.K * q.nt;
   for (int i = threadIdx.x; i < n; i += 256) {
     const int j = i / q.nt, t = q.t0 + (i - j * q.nt);
@@ -243,9 +256,12 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
   constexpr int VB = vb_entries(D);
   constexpr int ROWD = 2 * D * 64;  // doubles of one row (= one 64-observation tile) of the A planes
   constexpr int ROWP = 2 * DP * 64;
+  // vbuf: the v_i of a round, in view order; the row slots' shares of w (wpart) live in the same memory: they are
+  // read before the z barrier, vbuf is written after it
   __shared__ double vbuf[VB * D];
-  __shared__ double wpart[kWaves][DP][64];
-  __shared__ double zs[DP][64];
+  static_assert(VB * D >= reg_rows(D) * kWaves * DP * 64, "wpart fits vbuf");
+  double (*wpart)[DP][64] = reinterpret_cast<double (*)[DP][64]>(vbuf);
+  __shared__ double zs[kWaves][DP][64];
   __shared__ double acc[LCM * D];
   __shared__ int4 long_run[VB / kLongRun + 2];
   __shared__ int n_long;
@@ -333,56 +349,86 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
     return;
   }
 
-  // ---- an item of narrow slices
-  // Every load a slice needs -- its rows of A and Jp, the x blocks of their views, L^-1 of its tracks, the run lists --
-  // is issued at the top of the iteration in one batch (the view indices arrived one slice ahead), so a slice costs
-  // ONE memory round trip; the phases behind it only touch registers and LDS.
+  // ---- an item of narrow units
+  // A narrow unit is a slice, or a PACK of 2-4 consecutive slices of <= 4 rows (59 % of the slices of the bench
+  // problem): their tiles are consecutive in memory, so a pack is walked like one slice of G K rows whose row R
+  // belongs to the tracks of slice R / K.  Four wavefronts x two rows then have work in (nearly) every iteration.
+  // Every load an iteration needs is either issued in ONE batch at its top (x, A, Jp: the only demand loads) or was
+  // issued an iteration earlier (geometry, view indices, L^-1, run lists); barriers order LDS only, so those stay
+  // in flight across them.
   constexpr int RR = reg_rows(D);
-  constexpr int J1 = RR * kWaves;  // first row of the tail
+  constexpr int J1 = RR * kWaves;  // rows a unit keeps in registers; beyond: the tail of a long single slice
   constexpr int NLI = sym_size(DP);
+  static_assert(VB >= J1 * 64, "the v_i of a pack fit one round");
   const int u0 = m.item_unit0[item], u1 = m.item_unit0[item + 1];
   const int slot0 = m.item_slot_ptr[item];
   const int nlc = m.item_slot_ptr[item + 1] - slot0;
-  // an item of ONE slice has a slot per run: the sums go straight to HBM (and it may see any number of views)
+  // an item of ONE unit has a slot per run: the sums go straight to HBM (and it may see any number of views)
   const bool direct = (u1 - u0) == 1;
   if (!direct)
     for (int i = threadIdx.x; i < nlc * D; i += kThreads) acc[i] = 0.0;
+  const int4* desc = m.unit_desc - m.nwb;  // {first element, rows, rows of one slice, first slice}
+  const int last_u = m.n_units - 1;
+  int4 d0 = desc[u0], d1 = desc[min(u0 + 1, last_u)], d2 = desc[min(u0 + 2, last_u)];
+  int r0 = m.unit_run_ptr[u0], r1 = m.unit_run_ptr[u0 + 1], r2 = m.unit_run_ptr[min(u0 + 2, m.n_units)];
+  int o0 = m.run_obs_ptr[r0], o1 = m.run_obs_ptr[r1];
   int nrb[RR], npos[RR];
-  // the slice geometry travels two slices ahead and the view indices one, so that the batch of loads of a slice
-  // can be issued the moment its iteration begins (no dependent look-up in front of it)
-  const int* sptr = v.slice_ptr + (v.n_wide - m.nwb);
-  auto load_index = [&](int sp0, int K) {
+  auto load_index = [&](int4 d) {
 #pragma unroll
     for (int rr = 0; rr < RR; ++rr) {
-      const int j = w + rr * kWaves;
+      const int R = w + rr * kWaves;
       nrb[rr] = npos[rr] = -1;
-      if (j < K) {
-        const size_t e = (size_t)sp0 + 64 * j + lane;
+      if (R < d.y) {
+        const size_t e = (size_t)d.x + 64 * R + lane;
         nrb[rr] = v.obs_rb[e];
         npos[rr] = m.obs_pos[e];
       }
     }
   };
-  int sp0 = sptr[u0], sp1 = sptr[u0 + 1];
-  int sp2 = sptr[min(u0 + 2, m.n_units)];
-  load_index(sp0, (sp1 - sp0) >> 6);
-  int r0 = m.unit_run_ptr[u0];
-  int o0 = m.run_obs_ptr[r0];
+  // L^-1 of the tracks wavefront w solves for: slice w of the pack
+  double Li[NLI];
+  auto load_linv = [&](int4 d) {
+    const int G = d.y > J1 ? 1 : d.y / d.z;
+    if (w < G) {
+      const size_t NP = (size_t)v.Np_pad;
+      const size_t lp = (size_t)(d.w + w) * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < NLI; ++i) Li[i] = v.Linv[(size_t)i * NP + lp];
+    }
+  };
+  int ma[2], mb[2], ms[2];
+  auto load_runs = [&](int first) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int r = min(first + (int)threadIdx.x + q * kThreads, m.n_runs - 1);
+      ma[q] = m.run_obs_ptr[r];
+      mb[q] = m.run_obs_ptr[r + 1];
+      ms[q] = m.run_slot[r];
+    }
+  };
+  load_index(d0);
+  load_linv(d0);
+  load_runs(r0);
+#ifdef TMI_MF_PROFILE
+  long long tp[5] = {0, 0, 0, 0, 0};
+  long long tc = clock64();
+#define MF_LAP(i) do { const long long n_ = clock64(); tp[i] += n_ - tc; tc = n_; } while (0)
+#else
+#define MF_LAP(i)
+#endif
   for (int u = u0; u < u1; ++u) {
-    const int s = v.n_wide + (u - m.nwb);
-    const int K = (sp1 - sp0) >> 6;
+    const int sp0 = d0.x, rows = d0.y, K = d0.z;
+    const bool packed = rows <= J1;         // every row in registers; G = rows / K slices (G = 1: one short slice)
+    const int G = packed ? rows / K : 1;
     const size_t tile0 = (size_t)(sp0 >> 6);
-    const int sp3 = sptr[min(u + 3, m.n_units)];
-    const int r1 = m.unit_run_ptr[u + 1];
-    const int o1 = m.run_obs_ptr[r1];
     double2 ar[RR][D], jr[RR][DP];
     double xr[RR][D];
     double uu[RR][2];
     int pos[RR];
-    // ---- the batch of loads (rows beyond the slice: a wave-uniform skip)
+    // ---- the batch of loads (row slots beyond the unit: a wave-uniform skip)
 #pragma unroll
     for (int rr = 0; rr < RR; ++rr) {
-      const int j = w + rr * kWaves;
+      const int R = w + rr * kWaves;
       pos[rr] = nrb[rr] >= 0 ? npos[rr] : -1;
 #pragma unroll
       for (int a = 0; a < D; ++a) {
@@ -391,7 +437,7 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
       }
 #pragma unroll
       for (int a = 0; a < DP; ++a) jr[rr][a] = make_double2(0.0, 0.0);
-      if (j < K) {
+      if (R < rows) {
         // the view's block of x: D doubles at an 8-byte aligned address, fetched 16 bytes at a time
         const double* xc = x + (size_t)max(nrb[rr], 0) * D;
 #pragma unroll
@@ -401,33 +447,21 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
           xr[rr][a + 1] = t2.y;
         }
         if (D & 1) xr[rr][D - 1] = xc[D - 1];
-        const double* ap = v.pm_A + (tile0 + j) * ROWD + 2 * lane;
-        const double* jp = v.pm_Jp + (tile0 + j) * ROWP + 2 * lane;
+        const double* ap = v.pm_A + (tile0 + R) * ROWD + 2 * lane;
+        const double* jp = v.pm_Jp + (tile0 + R) * ROWP + 2 * lane;
 #pragma unroll
         for (int a = 0; a < D; ++a) ar[rr][a] = *reinterpret_cast<const double2*>(ap + a * 128);
 #pragma unroll
         for (int a = 0; a < DP; ++a) jr[rr][a] = *reinterpret_cast<const double2*>(jp + a * 128);
       }
     }
-    double Li[NLI];
-    if (w == 0) {
-      const size_t NP = (size_t)v.Np_pad;
-#pragma unroll
-      for (int i = 0; i < NLI; ++i) Li[i] = v.Linv[(size_t)i * NP + (size_t)s * 64 + lane];
-    }
-    int ma[2], mb[2], ms[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int r = min(r0 + (int)threadIdx.x + q * kThreads, m.n_runs - 1);
-      ma[q] = m.run_obs_ptr[r];
-      mb[q] = m.run_obs_ptr[r + 1];
-      ms[q] = m.run_slot[r];
-    }
-    if (u + 1 < u1) load_index(sp1, (sp2 - sp1) >> 6);
-    // ---- u_i = A_i x, this wavefront's share of w = sum Jp^T u
-    double wv[DP];
-#pragma unroll
-    for (int a = 0; a < DP; ++a) wv[a] = 0.0;
+    // one unit ahead: the view indices; three / two ahead: geometry and run ranges (wave-uniform, tiny)
+    if (u + 1 < u1) load_index(d1);
+    const int4 d3 = desc[min(u + 3, last_u)];
+    const int r3 = m.unit_run_ptr[min(u + 3, m.n_units)];
+    const int o2 = m.run_obs_ptr[r2];
+    // ---- u_i = A_i x; w = sum Jp^T u per row slot
+    double wv[RR][DP];
 #pragma unroll
     for (int rr = 0; rr < RR; ++rr) {
       double s0 = 0.0, s1 = 0.0;
@@ -444,41 +478,48 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
       uu[rr][0] = s0;
       uu[rr][1] = s1;
 #pragma unroll
-      for (int a = 0; a < DP; ++a) wv[a] += jr[rr][a].x * s0 + jr[rr][a].y * s1;
+      for (int a = 0; a < DP; ++a) wv[rr][a] = jr[rr][a].x * s0 + jr[rr][a].y * s1;
     }
+    if (!packed) {
+      // the tail rows of a long slice (one slice in eight): straight from memory, added to this wave's first slot
 #pragma unroll 1
-    for (int j = w + J1; j < K; j += kWaves) {
-      const size_t e = (size_t)sp0 + 64 * j + lane;
-      const int rb = v.obs_rb[e];
-      if (rb < 0) continue;
-      const double* ap = v.pm_A + (tile0 + j) * ROWD + 2 * lane;
-      const double* jp = v.pm_Jp + (tile0 + j) * ROWP + 2 * lane;
-      const double* xc = x + (size_t)rb * D;
-      double s0 = 0.0, s1 = 0.0;
+      for (int j = w + J1; j < rows; j += kWaves) {
+        const size_t e = (size_t)sp0 + 64 * j + lane;
+        const int rb = v.obs_rb[e];
+        if (rb < 0) continue;
+        const double* ap = v.pm_A + (tile0 + j) * ROWD + 2 * lane;
+        const double* jp = v.pm_Jp + (tile0 + j) * ROWP + 2 * lane;
+        const double* xc = x + (size_t)rb * D;
+        double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-      for (int a = 0; a < D; ++a) {
-        const double2 aa = *reinterpret_cast<const double2*>(ap + a * 128);
-        const double xa = xc[a];
-        s0 += aa.x * xa;
-        s1 += aa.y * xa;
-      }
+        for (int a = 0; a < D; ++a) {
+          const double2 aa = *reinterpret_cast<const double2*>(ap + a * 128);
+          const double xa = xc[a];
+          s0 += aa.x * xa;
+          s1 += aa.y * xa;
+        }
 #pragma unroll
-      for (int a = 0; a < DP; ++a) {
-        const double2 jj = *reinterpret_cast<const double2*>(jp + a * 128);
-        wv[a] += jj.x * s0 + jj.y * s1;
+        for (int a = 0; a < DP; ++a) {
+          const double2 jj = *reinterpret_cast<const double2*>(jp + a * 128);
+          wv[0][a] += jj.x * s0 + jj.y * s1;
+        }
       }
     }
 #pragma unroll
-    for (int a = 0; a < DP; ++a) wpart[w][a][lane] = wv[a];
-    lds_barrier();  // wpart (and: the previous slice's run sums have left vbuf)
-    if (w == 0) {
+    for (int rr = 0; rr < RR; ++rr)
+#pragma unroll
+      for (int a = 0; a < DP; ++a) wpart[w + rr * kWaves][a][lane] = wv[rr][a];
+    MF_LAP(0);
+    lds_barrier();  // wpart (and: the previous unit's run sums have left vbuf, which wpart shares its memory with)
+    if (w < G) {
+      // slice w of the pack: its rows are the slots [w K, w K + K) (a single slice: every slot)
+      const int s_lo = packed ? w * K : 0, s_hi = packed ? w * K + K : J1;
       double wt[DP], zh[DP];
 #pragma unroll
-      for (int a = 0; a < DP; ++a) {
-        double t = 0.0;
+      for (int a = 0; a < DP; ++a) wt[a] = 0.0;
+      for (int sl = s_lo; sl < s_hi; ++sl) {
 #pragma unroll
-        for (int ww = 0; ww < kWaves; ++ww) t += wpart[ww][a][lane];
-        wt[a] = t;
+        for (int a = 0; a < DP; ++a) wt[a] += wpart[sl][a][lane];
       }
       // z = L^-T (L^-1 w)   (Linv planes: sym_idx(a, b), a <= b, holds L^-1(b, a))
 #pragma unroll
@@ -493,26 +534,30 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
         double t = 0.0;
 #pragma unroll
         for (int bb = a; bb < DP; ++bb) t += Li[sym_idx(a, bb, DP)] * zh[bb];
-        zs[a][lane] = t;
+        zs[w][a][lane] = t;
       }
     }
+    if (u + 1 < u1) load_linv(d1);  // consumed an iteration from now
     lds_barrier();  // zs
-    double z[DP];
-#pragma unroll
-    for (int a = 0; a < DP; ++a) z[a] = zs[a][lane];
+    MF_LAP(1);
     // t_i = u_i - Jp_i z in place
+    double z0[DP];  // of the single slice (tail rows)
+#pragma unroll
+    for (int a = 0; a < DP; ++a) z0[a] = zs[0][a][lane];
 #pragma unroll
     for (int rr = 0; rr < RR; ++rr) {
+      const int R = w + rr * kWaves;
+      const int g = packed ? min(R / K, G - 1) : 0;
 #pragma unroll
       for (int a = 0; a < DP; ++a) {
-        uu[rr][0] -= jr[rr][a].x * z[a];
-        uu[rr][1] -= jr[rr][a].y * z[a];
+        const double za = zs[g][a][lane];
+        uu[rr][0] -= jr[rr][a].x * za;
+        uu[rr][1] -= jr[rr][a].y * za;
       }
     }
     // v_i = A_i^T t_i into LDS in view order, VB at a time; a thread per run sums its (consecutive) entries
     const int nv = o1 - o0;
     for (int pb = 0; pb < nv; pb += VB) {
-      if (pb > 0) lds_barrier();  // the previous round's sums are taken
 #pragma unroll
       for (int rr = 0; rr < RR; ++rr) {
         const int p = pos[rr] - pb;
@@ -522,35 +567,38 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
           for (int a = 0; a < D; ++a) dst[a] = ar[rr][a].x * uu[rr][0] + ar[rr][a].y * uu[rr][1];
         }
       }
+      if (!packed) {
 #pragma unroll 1
-      for (int j = w + J1; j < K; j += kWaves) {
-        const size_t e = (size_t)sp0 + 64 * j + lane;
-        const int p = m.obs_pos[e] - pb;
-        const int rb = v.obs_rb[e];
-        if (p < 0 || p >= VB || rb < 0) continue;
-        const double* ap = v.pm_A + (tile0 + j) * ROWD + 2 * lane;
-        const double* jp = v.pm_Jp + (tile0 + j) * ROWP + 2 * lane;
-        const double* xc = x + (size_t)rb * D;
-        double2 aa[D];
-        double t0 = 0.0, t1 = 0.0;
+        for (int j = w + J1; j < rows; j += kWaves) {
+          const size_t e = (size_t)sp0 + 64 * j + lane;
+          const int p = m.obs_pos[e] - pb;
+          const int rb = v.obs_rb[e];
+          if (p < 0 || p >= VB || rb < 0) continue;
+          const double* ap = v.pm_A + (tile0 + j) * ROWD + 2 * lane;
+          const double* jp = v.pm_Jp + (tile0 + j) * ROWP + 2 * lane;
+          const double* xc = x + (size_t)rb * D;
+          double2 aa[D];
+          double t0 = 0.0, t1 = 0.0;
 #pragma unroll
-        for (int a = 0; a < D; ++a) {
-          aa[a] = *reinterpret_cast<const double2*>(ap + a * 128);
-          const double xa = xc[a];
-          t0 += aa[a].x * xa;
-          t1 += aa[a].y * xa;
+          for (int a = 0; a < D; ++a) {
+            aa[a] = *reinterpret_cast<const double2*>(ap + a * 128);
+            const double xa = xc[a];
+            t0 += aa[a].x * xa;
+            t1 += aa[a].y * xa;
+          }
+#pragma unroll
+          for (int a = 0; a < DP; ++a) {
+            const double2 jj = *reinterpret_cast<const double2*>(jp + a * 128);
+            t0 -= jj.x * z0[a];
+            t1 -= jj.y * z0[a];
+          }
+          double* dst = &vbuf[p * D];
+#pragma unroll
+          for (int a = 0; a < D; ++a) dst[a] = aa[a].x * t0 + aa[a].y * t1;
         }
-#pragma unroll
-        for (int a = 0; a < DP; ++a) {
-          const double2 jj = *reinterpret_cast<const double2*>(jp + a * 128);
-          t0 -= jj.x * z[a];
-          t1 -= jj.y * z[a];
-        }
-        double* dst = &vbuf[p * D];
-#pragma unroll
-        for (int a = 0; a < D; ++a) dst[a] = aa[a].x * t0 + aa[a].y * t1;
       }
       lds_barrier();  // vbuf
+      MF_LAP(2);
       auto put_sum = [&](const double (&sum)[D], int first, int slot) {
         if (direct) {
           double* dst = m.partial + (size_t)slot * D;
@@ -562,7 +610,7 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
             for (int a = 0; a < D; ++a) dst[a] += sum[a];
           }
         } else {
-          double* dst = &acc[(slot - slot0) * D];  // one run per view and slice: nobody else adds here
+          double* dst = &acc[(slot - slot0) * D];  // one run per view and unit: nobody else adds here
 #pragma unroll
           for (int a = 0; a < D; ++a) dst[a] += sum[a];
         }
@@ -571,7 +619,7 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
         const int b = max(first - o0 - pb, 0), e = min(last - o0 - pb, VB);
         if (b >= e) return;
         if (e - b > kLongRun) {
-          // a long run (the slice's tracks share their lowest view: 64 entries) would hold its wavefront for
+          // a long run (the tracks of a slice share their lowest view: 64 entries) would hold its wavefront for
           // e - b dependent trips: a whole wavefront takes it after this loop
           const int i = atomicAdd(&n_long, 1);
           long_run[i] = make_int4(b, e, slot, first);
@@ -591,6 +639,7 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
         if (r0 + (int)threadIdx.x + q * kThreads < r1) take_run(ma[q], mb[q], ms[q]);
       for (int r = r0 + (int)threadIdx.x + 2 * kThreads; r < r1; r += kThreads)
         take_run(m.run_obs_ptr[r], m.run_obs_ptr[r + 1], m.run_slot[r]);
+      MF_LAP(3);
       lds_barrier();  // the list of long runs
       const int nl = n_long;
       for (int i = w; i < nl; i += kWaves) {
@@ -606,15 +655,26 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
         for (int a = 0; a < D; ++a) sum[a] = wave_sum(sum[a]);  // fixed butterfly: reproducible
         if (lane == 0) put_sum(sum, lr.w, lr.z);
       }
-      lds_barrier();  // n_long is read
+      lds_barrier();  // n_long is read, vbuf is free
+      MF_LAP(4);
       if (threadIdx.x == 0) n_long = 0;
     }
+    if (u + 1 < u1) load_runs(r1);  // consumed an iteration from now
+    d0 = d1;
+    d1 = d2;
+    d2 = d3;
     r0 = r1;
+    r1 = r2;
+    r2 = r3;
     o0 = o1;
-    sp0 = sp1;
-    sp1 = sp2;
-    sp2 = sp3;
+    o1 = o2;
   }
+#ifdef TMI_MF_PROFILE
+  if (threadIdx.x == 0 && m.prof) {
+    for (int i = 0; i < 5; ++i) m.prof[(size_t)item * 8 + i] = tp[i];
+    m.prof[(size_t)item * 8 + 5] = u1 - u0;
+  }
+#endif
   if (direct) return;
   __syncthreads();  // acc
   double* out = m.partial + (size_t)slot0 * D;
