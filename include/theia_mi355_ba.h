@@ -120,9 +120,12 @@ typedef enum tmi_ba_linear_solver {
  *     applied with two triangular solves per PCG iteration; views of private groups keep their SCHUR_JACOBI block.
  *     Sharing intrinsics puts about three near-degenerate directions per shared block into the block-Jacobi
  *     preconditioned system (principal point against a coherent rotation of the block's views, ...): 45-80 PCG
- *     iterations per LM iteration with SCHUR_JACOBI, 4-5 with the clusters.  Needs the cluster's blocks of S, i.e.
- *     the formed operator (schur_mode explicit, or auto on one GPU); with the matrix-free operator and on problems
- *     without shared blocks both values fall back to SCHUR_JACOBI.
+ *     iterations per LM iteration with SCHUR_JACOBI, 4-5 with the clusters.  Needs the cluster's blocks of S only:
+ *     with schur_mode auto (and implicit) the operator PCG applies is the matrix-free one and just the block pairs
+ *     INSIDE a cluster are formed for the preconditioner; schur_mode explicit forms all of S.  On problems without
+ *     shared intrinsics blocks both values are SCHUR_JACOBI (clusters by visibility are not rebuilt, DESIGN.md
+ *     section 9).  A cluster launch that cannot become co-resident (device shared with another process) retires
+ *     the clusters for that solve: PCG continues with the SCHUR_JACOBI blocks.
  *   Intrinsics shared by several views form their own reduced block in every mode.  */
 typedef enum tmi_ba_preconditioner {
   TMI_BA_PRECOND_IDENTITY = 0,

@@ -325,6 +325,7 @@ struct tmi_ba_solver {
   bool cluster_blocks = false;  // the matrix-free operator with the clusters' blocks of S formed beside it
   bool cl_built = false;      // plan + device buffers exist
   bool cl_active = false;     // the current LM iteration's PCG applies it
+  bool cl_retired = false;    // a cluster launch gave up in this solve (device shared with another process): SCHUR_JACOBI for the rest of it
   clp::ClusterDesc* d_cl_desc = nullptr;
   clp::GatherEntry* d_cl_ge = nullptr;
   int* d_cl_idx = nullptr;
@@ -2041,6 +2042,10 @@ static int factor_clusters(tmi_ba_solver* s) {
   TMI_HIP(hipMemsetAsync(s->d_cl_tiles, 0, (size_t)p.n_tiles * cdf::TILE * sizeof(double), s->stream));
   TMI_HIP(hipMemsetAsync(s->d_cl_bad, 0, (size_t)p.ncl * sizeof(int), s->stream));
   s->launch.cluster_gather(s->stream, s->d_cl_ge, (int)p.entries.size(), s->d_cl_desc, v.red + s->RL.ub, v.Sdiag, s->d_cl_tiles);
+  if (s->cl_epoch >= 0x7ffffff0) {  // flags compare against the epoch: start over long before it wraps (as df_epoch)
+    TMI_HIP(hipMemsetAsync(s->d_cl_flags, 0, (size_t)std::max(p.n_flags, 1) * sizeof(int), s->stream));
+    s->cl_epoch = 0;
+  }
   const int epoch = ++s->cl_epoch;
   return launch_coresident(s, p.grid, [&] {
     hipLaunchKernelGGL(clp::cluster_factor_kernel, dim3(p.grid), dim3(256), 0, s->stream, s->d_cl_desc, p.ncl, s->d_cl_tiles,
@@ -2137,10 +2142,16 @@ static int solve_reduced_pcg(tmi_ba_solver* s, const tmi_ba_options* O, int* usa
       break;
     }
     if (s->cl_active && s->h_flags[FL_CHOL_ABORT]) {
-      // a dataflow launch of the cluster preconditioner could not become co-resident (another process holds part of
-      // the device) and gave up: its output is not to be trusted
-      s->error = "cluster preconditioner: a dataflow launch timed out waiting for the device";
-      return TMI_BA_ERR_DEVICE;
+      // A dataflow launch of the cluster preconditioner could not become co-resident (another process holds part of
+      // the device) and gave up: nothing it produced is to be trusted.  As the exact solver does (solve_reduced_dense),
+      // fall back instead of failing the solve: clear the flag, retire the clusters for this solve and run this LM
+      // iteration's PCG again with the SCHUR_JACOBI blocks (Minv holds them: clusters only override entries of z).
+      TMI_HIP(hipMemsetAsync(v.flags + FL_CHOL_ABORT, 0, sizeof(int), s->stream));
+      TMI_HIP(hipMemsetAsync(s->d_cl_flags, 0, (size_t)std::max(s->cl_plan.n_flags, 1) * sizeof(int), s->stream));
+      s->cl_epoch = 0;
+      s->cl_active = false;
+      s->cl_retired = true;
+      return solve_reduced_pcg(s, O, usable, iters);
     }
     if (!(s->h_scal[SC_PQ] > 0.0)) break;  // LINEAR_SOLVER_NO_CONVERGENCE, x kept
     if (s->h_scal[SC_ZETA] < O->eta && it >= O->min_linear_solver_iterations) break;
@@ -2471,6 +2482,7 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
   const int nbs = s->nblocks_tracks, nbp = s->nblocks_points;
   hipStream_t stream = s->stream;
   s->prof_mask = (O->profile_kernels == 1) ? 0xffffffffu : (unsigned)O->profile_kernels;
+  s->cl_retired = false;
   s->ev_used = 0;
   memset(s->launches, 0, sizeof(s->launches));
   sum->num_reduced_blocks = st.Nrb;
@@ -2644,7 +2656,7 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
         // {shared block, its views} cluster (needs the cluster's blocks of S: the formed operator)
         s->cl_active = (O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_JACOBI ||
                         O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_TRIDIAGONAL) &&
-                       s->st.has_shared && (!s->implicit_now || s->cluster_blocks) && n_r > 0;
+                       s->st.has_shared && (!s->implicit_now || s->cluster_blocks) && n_r > 0 && !s->cl_retired;
         if (s->cl_active) CK(factor_clusters(s));
       }
       const int64_t before = pcg_iters;

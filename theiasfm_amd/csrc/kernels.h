@@ -1851,9 +1851,23 @@ __global__ __launch_bounds__(256) void spmv_cols_kernel(DeviceView v, const doub
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int g = lane / D, r = lane - g * D;
   if (g < G) {
+    // the column's transposed products, gathered: every trip is two dependent loads (block index, then its entry of
+    // tbuf), so four trips are kept in flight -- a column of the bench problem is ~25 trips of 28 blocks, and one
+    // round trip per trip was the run time of this kernel (56 us; the sum order is unchanged)
     double acc = 0.0;
     const int k0 = v.ucol_ptr[col], k1 = v.ucol_ptr[col + 1];
-    for (int k = k0 + w * G + g; k < k1; k += 4 * G) acc += v.tbuf[(size_t)v.ucol_u[k] * D + r];
+    constexpr int STEP = 4 * G;
+    int k = k0 + w * G + g;
+    for (; k + 3 * STEP < k1; k += 4 * STEP) {
+      const int u0 = v.ucol_u[k], u1 = v.ucol_u[k + STEP], u2 = v.ucol_u[k + 2 * STEP], u3 = v.ucol_u[k + 3 * STEP];
+      const double t0 = v.tbuf[(size_t)u0 * D + r], t1 = v.tbuf[(size_t)u1 * D + r];
+      const double t2 = v.tbuf[(size_t)u2 * D + r], t3 = v.tbuf[(size_t)u3 * D + r];
+      acc += t0;
+      acc += t1;
+      acc += t2;
+      acc += t3;
+    }
+    for (; k < k1; k += STEP) acc += v.tbuf[(size_t)v.ucol_u[k] * D + r];
     part[w][g][r] = acc;
   }
   __syncthreads();

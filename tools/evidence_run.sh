@@ -1,11 +1,11 @@
 #!/bin/bash
 # evidence run of a round (on the GPU box, via gpurun): tests, smoke, default bench line, kernel trace, PMC passes,
 # alamo-variant kernel trace, config-5 kernel trace, scale probe.  usage: tools/evidence_run.sh <tag>   (e.g. r03_z)
-T=${1:-r03_z}
+T=${1:-r04_a}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 cd $R
 export TMI_GIT_HEAD=${TMI_GIT_HEAD:-unknown}
-timeout 1200 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -8 > $O/${T}_pytest.log
+timeout 2400 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -8 > $O/${T}_pytest.log
 grep -E "passed|failed" $O/${T}_pytest.log
 python -c "import __graft_entry__ as e; e.smoke(); print('smoke ok')" 2>&1 | tail -1
 SECONDS=0
@@ -21,6 +21,12 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python tools/summarize_profile.py $T $O/${T}_stats $O/${T}_pmc_FETCH_SIZE $O/${T}_pmc_WRITE_SIZE > $O/${T}_summary.txt 2>&1
 head -14 $O/${T}_summary.txt
+# the reference-default operating point: kernel trace
+rm -rf $O/${T}_refdef_stats
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_refdef_stats -- python tools/refdef_probe.py 10 refdef_auto > $O/${T}_refdef.log 2>&1
+python tools/summarize_profile.py ${T}_refdef $O/${T}_refdef_stats --workload venice1778_heavy_reference_defaults > $O/${T}_refdef_summary.txt 2>&1
+head -12 $O/${T}_refdef_summary.txt
+tail -1 $O/${T}_refdef.log | cut -c1-300
 # the exact-solver variant (config 3): kernel trace of the alamo-sized workload
 rm -rf $O/${T}_alamo_stats
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_alamo_stats -- python bench.py --workload alamo --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $O/${T}_alamo_stats.log 2>&1
@@ -33,6 +39,6 @@ python tools/summarize_profile.py ${T}_config5 $O/${T}_config5_stats --workload 
 head -12 $O/${T}_config5_summary.txt
 tail -1 $O/${T}_config5.log | cut -c1-400
 mkdir -p $O/profiles_out && cp profiles/${T}_* profiles/pmc_latest.json $O/profiles_out/ 2>/dev/null
-find $O/${T}_stats $O/${T}_pmc_FETCH_SIZE $O/${T}_pmc_WRITE_SIZE $O/${T}_alamo_stats $O/${T}_config5_stats -type f -size +4M -delete
+find $O/${T}_stats $O/${T}_pmc_FETCH_SIZE $O/${T}_pmc_WRITE_SIZE $O/${T}_alamo_stats $O/${T}_config5_stats $O/${T}_refdef_stats -type f -size +4M -delete
 TMI_PROBE_PROFILE=0 python tools/scale_probe.py 1 2 4 8 > $O/${T}_scale_probe.jsonl 2> $O/${T}_scale_probe.err
 cut -c1-200 $O/${T}_scale_probe.jsonl

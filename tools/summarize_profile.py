@@ -81,8 +81,9 @@ def main():
               "spmv_cols_kernel": "spmv", "back_substitute_kernel": "back_substitute",
               "implicit_tracks_kernel": "spmv_matrix_free", "implicit_cameras_kernel": "spmv_matrix_free",
               "implicit_tracks_q_kernel": "spmv_matrix_free", "implicit_cameras_q_kernel": "spmv_matrix_free",
+              "mfc::product_kernel": "spmv_matrix_free", "mfc::reduce_kernel": "spmv_matrix_free",
               "cost_kernel": "update_cost", "update_points_kernel": "update_cost",
-              "update_cameras_kernel": "update_cost", "schur_offdiag_gather_kernel": "schur_offdiag", "schur_offdiag_aq_kernel": "schur_offdiag",
+              "update_cameras_kernel": "update_cost", "schur_offdiag_aq_kernel": "schur_offdiag",
               "pcg_step_kernel": "pcg_vector", "pcg_p_kernel": "pcg_vector", "pcg_init_kernel": "pcg_vector",
               "camera_prepare_kernel": "linearize"}
     classes = {}
