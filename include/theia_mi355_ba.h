@@ -122,9 +122,15 @@ typedef enum tmi_ba_linear_solver {
  *     preconditioned system (principal point against a coherent rotation of the block's views, ...): 45-80 PCG
  *     iterations per LM iteration with SCHUR_JACOBI, 4-5 with the clusters.  Needs the cluster's blocks of S only:
  *     with schur_mode auto (and implicit) the operator PCG applies is the matrix-free one and just the block pairs
- *     INSIDE a cluster are formed for the preconditioner; schur_mode explicit forms all of S.  On problems without
- *     shared intrinsics blocks both values are SCHUR_JACOBI (clusters by visibility are not rebuilt, DESIGN.md
- *     section 9).  A cluster launch that cannot become co-resident (device shared with another process) retires
+ *     INSIDE a cluster are formed for the preconditioner; schur_mode explicit forms all of S.
+ *     On problems WITHOUT shared intrinsics blocks the views are clustered by visibility as Ceres'
+ *     VisibilityBasedPreconditioner does (visibility_clustering_type below: the Schur-complement graph with
+ *     edge weights |tracks seen by both| / sqrt(|tracks of a| |tracks of b|) over the parameter blocks, then
+ *     canonical views with size penalty 3 / similarity penalty 0 / at least 3 centres, or single linkage at 0.9;
+ *     restated from Ceres 1.14 -- parity unpinned like the rest of the Ceres layer) and every cluster's principal
+ *     submatrix of S is inverted exactly; this needs the formed S (schur_mode auto picks it; implicit is refused)
+ *     and one rank.  CLUSTER_TRIDIAGONAL is served as CLUSTER_JACOBI (no cluster-pair blocks).
+ *     A cluster launch that cannot become co-resident (device shared with another process) retires
  *     the clusters for that solve: PCG continues with the SCHUR_JACOBI blocks.
  *   Intrinsics shared by several views form their own reduced block in every mode.  */
 typedef enum tmi_ba_preconditioner {
@@ -256,6 +262,11 @@ typedef struct tmi_ba_options {
                               operators are kept resident and every LM iteration takes
                               the cheaper one for the PCG length it expects (forming S
                               pays off after a few products; same result to round-off). */
+  int32_t visibility_clustering_type;
+                           /* CLUSTER_JACOBI / CLUSTER_TRIDIAGONAL on a problem WITHOUT shared
+                              intrinsics blocks: how the views are clustered (ceres::
+                              VisibilityClusteringType, bundle_adjustment.h:88-89; Theia's default is
+                              CANONICAL_VIEWS).  0 = CANONICAL_VIEWS, 1 = SINGLE_LINKAGE.          */
 } tmi_ba_options;
 
 /* ---- summary: BundleAdjustmentSummary + device-path extras --------------- */

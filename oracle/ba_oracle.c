@@ -479,6 +479,10 @@ typedef struct {
   double *gc, *rhs, *yc, *yp;
   double* dense; /* nr*nr when an exact solve is requested */
   int64_t pcg_iters;
+  /* CLUSTER_JACOBI without shared intrinsics blocks: the visibility cluster of every reduced block (-1: none),
+   * computed at the first PCG solve (visibility_clusters) */
+  int* vis_cluster;
+  int vis_ncl;
 } ost;
 
 static int obs_parts(const ost* s, int c, int* rb0, int* n0, int* rb1, int* n1) {
@@ -944,6 +948,156 @@ static int block_inverse(int n, const double* A, double* Ainv) {
   return 1;
 }
 
+static int* g_last_vis = NULL;
+static int g_last_vis_n = 0;
+int32_t oracle_last_visibility_clusters(int32_t* out, int32_t n) {
+  if (!g_last_vis || n < g_last_vis_n) return -1;
+  for (int c = 0; c < g_last_vis_n; ++c) out[c] = g_last_vis[c];
+  return g_last_vis_n;
+}
+
+/* The views of a problem WITHOUT shared intrinsics blocks clustered by visibility, as
+ * ceres::VisibilityBasedPreconditioner::ClusterCameras does for CLUSTER_JACOBI / CLUSTER_TRIDIAGONAL (the reference only
+ * passes the two enums on: bundle_adjuster.cc:59-63, bundle_adjustment.h:86-89; Ceres 1.14 restated from its sources'
+ * published behaviour -- visibility.cc, canonical_views_clustering.cc, single_linkage_clustering.cc,
+ * visibility_based_preconditioner.cc; PARITY UNPINNED):
+ *   vertices: the camera-side parameter blocks -- the extrinsics of a view and, if it has free intrinsics, its
+ *   intrinsics block; every vertex carries a self edge of weight 1; two blocks are joined with weight
+ *   |points both see| / sqrt(|points of a| |points of b|) over the non-constant points, so the two blocks of one view
+ *   (same visibility) sit at similarity 1;
+ *   CANONICAL_VIEWS (type 0): centres are added greedily -- the vertex whose promotion raises the summed similarity
+ *   of its neighbours to their centre most, minus 3 per centre (kCanonicalViewsSizePenaltyWeight; the similarity
+ *   penalty is 0, the view score weight 0) -- until the best gain is <= 0 and there are at least 3 centres; a vertex
+ *   belongs to the centre it is most similar to, one that touches no centre to cluster (index mod #clusters);
+ *   SINGLE_LINKAGE (type 1): connected components of the edges with similarity >= 0.9.
+ * Ties: the lower index.  cluster[rb] = cluster of the view's blocks (they always share one).  Returns #clusters. */
+static int visibility_clusters(ost* s, int type, int* cluster) {
+  const int n = s->nrb;
+  double* ntr = (double*)calloc((size_t)n + 1, sizeof(double));
+  double* cnt = (double*)calloc((size_t)s->nblk + 1, sizeof(double)); /* per block (i, j), both orientations */
+  int* mult = (int*)calloc((size_t)n + 1, sizeof(int));
+  int* rbs = (int*)malloc(sizeof(int) * (size_t)(s->Nc + 1));
+  for (int p = 0; p < s->Np; ++p) {
+    if (s->P->point_constant && s->P->point_constant[p]) continue;
+    int m = 0;
+    for (int64_t k = s->pt_ptr[p]; k < s->pt_ptr[p + 1]; ++k) {
+      const int rb = s->cam_rb[s->P->obs_camera[s->order[k]]];
+      if (rb >= 0) rbs[m++] = rb;
+    }
+    for (int a = 0; a < m; ++a) {
+      ntr[rbs[a]] += 1.0;
+      for (int b = 0; b < m; ++b)
+        if (a != b) cnt[block_lookup(s, rbs[a], rbs[b])] += 1.0;
+    }
+  }
+  free(rbs);
+  for (int b = 0; b < n; ++b) mult[b] = (s->rb_split[b] > 0 ? 1 : 0) + (s->rb_dim[b] > s->rb_split[b] ? 1 : 0);
+  /* the neighbours of a vertex in ascending order (block rows are in insertion order): sums of similarities are then
+   * taken in a defined order, whatever built the block structure */
+  int64_t* nbr = (int64_t*)malloc(sizeof(int64_t) * (size_t)(s->nblk + 1));
+  memcpy(nbr, s->row_blk, sizeof(int64_t) * (size_t)s->nblk);
+  for (int i = 0; i < n; ++i) { /* insertion sort by column: rows are short or nearly sorted */
+    for (int64_t a = s->row_ptr[i] + 1; a < s->row_ptr[i + 1]; ++a) {
+      const int64_t q = nbr[a];
+      int64_t b = a - 1;
+      while (b >= s->row_ptr[i] && s->blk_j[nbr[b]] > s->blk_j[q]) {
+        nbr[b + 1] = nbr[b];
+        --b;
+      }
+      nbr[b + 1] = q;
+    }
+  }
+#define VC_W(q) (cnt[q] / sqrt(ntr[s->blk_i[q]] * ntr[s->blk_j[q]]))
+  int ncl = 0;
+  for (int b = 0; b < n; ++b) cluster[b] = -1;
+  if (type == 1) {
+    int* parent = (int*)malloc(sizeof(int) * (size_t)(n + 1));
+    for (int b = 0; b < n; ++b) parent[b] = b;
+    for (int i = 0; i < n; ++i)
+      for (int64_t e = s->row_ptr[i]; e < s->row_ptr[i + 1]; ++e) {
+        const int64_t q = nbr[e];
+        const int j = s->blk_j[q];
+        if (j <= i || cnt[q] <= 0.0 || VC_W(q) < 0.9) continue;
+        int a = i, b = j;
+        while (parent[a] != a) a = parent[a];
+        while (parent[b] != b) b = parent[b];
+        if (a != b) parent[a > b ? a : b] = a > b ? b : a;
+      }
+    int* id = (int*)malloc(sizeof(int) * (size_t)(n + 1));
+    for (int b = 0; b < n; ++b) id[b] = -1;
+    for (int b = 0; b < n; ++b) {
+      if (mult[b] == 0) continue;
+      int r = b;
+      while (parent[r] != r) r = parent[r];
+      if (id[r] < 0) id[r] = ncl++;
+      cluster[b] = id[r];
+    }
+    free(id);
+    free(parent);
+  } else {
+    double* sim = (double*)calloc((size_t)n + 1, sizeof(double));
+    int* to_center = (int*)malloc(sizeof(int) * (size_t)(n + 1));
+    int* promoted = (int*)calloc((size_t)n + 1, sizeof(int)); /* blocks of the view that are centres */
+    int* center_id = (int*)malloc(sizeof(int) * (size_t)(n + 1));
+    int n_centers = 0;
+    for (int b = 0; b < n; ++b) to_center[b] = center_id[b] = -1;
+    for (;;) {
+      int best = -1;
+      double best_gain = -DBL_MAX;
+      for (int v = 0; v < n; ++v) {
+        if (promoted[v] >= mult[v]) continue;
+        double gain = (1.0 > sim[v]) ? mult[v] * (1.0 - sim[v]) : 0.0; /* its self edge and its sibling block */
+        for (int64_t e = s->row_ptr[v]; e < s->row_ptr[v + 1]; ++e) {
+          const int64_t q = nbr[e];
+          const int u = s->blk_j[q];
+          if (u == v || cnt[q] <= 0.0) continue;
+          const double w = VC_W(q);
+          if (w > sim[u]) gain += mult[u] * (w - sim[u]);
+        }
+        gain -= 3.0;
+        if (gain > best_gain) {
+          best_gain = gain;
+          best = v;
+        }
+      }
+      if (best < 0) break;
+      if (best_gain <= 0.0 && n_centers >= 3) break;
+      ++n_centers;
+      ++promoted[best];
+      if (center_id[best] < 0) center_id[best] = ncl++;
+      if (1.0 > sim[best]) {
+        sim[best] = 1.0;
+        to_center[best] = best;
+      }
+      for (int64_t e = s->row_ptr[best]; e < s->row_ptr[best + 1]; ++e) {
+        const int64_t q = nbr[e];
+        const int u = s->blk_j[q];
+        if (u == best || cnt[q] <= 0.0) continue;
+        const double w = VC_W(q);
+        if (w > sim[u]) {
+          sim[u] = w;
+          to_center[u] = best;
+        }
+      }
+    }
+    if (ncl == 0) ncl = 1;
+    for (int b = 0; b < n; ++b) {
+      if (mult[b] == 0) continue;
+      cluster[b] = to_center[b] >= 0 ? center_id[to_center[b]] : b % ncl;
+    }
+    free(sim);
+    free(to_center);
+    free(promoted);
+    free(center_id);
+  }
+#undef VC_W
+  free(nbr);
+  free(ntr);
+  free(cnt);
+  free(mult);
+  return ncl;
+}
+
 /* ceres/conjugate_gradients_solver.cc (Ceres 1.14) restated, applied to the
  * explicit reduced system with the SCHUR_JACOBI preconditioner (inverse of
  * the diagonal blocks of S).  r_tolerance = -1, q_tolerance = eta
@@ -992,18 +1146,41 @@ static int solve_pcg(ost* s) {
   int* cl_ok = NULL;
   double** cl_L = NULL;   /* dense lower factors */
   int* cl_n = NULL;
+  /* Without shared intrinsics blocks the clusters are Ceres' visibility clusters of the views (visibility_clusters). */
+  int have_shared = 0;
+  for (int g = 0; g < s->G; ++g)
+    if (s->grp_rb[g] >= 0) have_shared = 1;
+  int n_cand = s->G; /* candidate clusters: one per group, or one per visibility cluster */
+  if (clustered && !have_shared) {
+    if (!s->vis_cluster) {
+      s->vis_cluster = (int*)malloc(sizeof(int) * (size_t)(s->nrb + 1));
+      s->vis_ncl = visibility_clusters(s, s->O->visibility_clustering_type, s->vis_cluster);
+      /* test hook (oracle_last_visibility_clusters): the cluster of every CAMERA of the last clustered solve */
+      free(g_last_vis);
+      g_last_vis = (int*)malloc(sizeof(int) * (size_t)(s->Nc + 1));
+      g_last_vis_n = s->Nc;
+      for (int c = 0; c < s->Nc; ++c) g_last_vis[c] = s->cam_rb[c] >= 0 ? s->vis_cluster[s->cam_rb[c]] : -1;
+    }
+    n_cand = s->vis_ncl;
+  }
   if (clustered) {
-    cl_ptr = (int*)calloc((size_t)s->G + 2, sizeof(int));
+    cl_ptr = (int*)calloc((size_t)n_cand + 2, sizeof(int));
     cl_rb = (int*)malloc(sizeof(int) * (size_t)(s->Nc + s->G + 1));
-    cl_ok = (int*)calloc((size_t)s->G + 1, sizeof(int));
-    cl_L = (double**)calloc((size_t)s->G + 1, sizeof(double*));
-    cl_n = (int*)calloc((size_t)s->G + 1, sizeof(int));
-    for (int g = 0; g < s->G; ++g) {
-      if (s->grp_rb[g] < 0) continue;
+    cl_ok = (int*)calloc((size_t)n_cand + 1, sizeof(int));
+    cl_L = (double**)calloc((size_t)n_cand + 1, sizeof(double*));
+    cl_n = (int*)calloc((size_t)n_cand + 1, sizeof(int));
+    for (int g = 0; g < n_cand; ++g) {
       int m = cl_ptr[ncl];
-      for (int c = 0; c < s->Nc; ++c)
-        if (s->P->camera_group[c] == g && s->cam_rb[c] >= 0) cl_rb[m++] = s->cam_rb[c];
-      cl_rb[m++] = s->grp_rb[g];
+      if (have_shared) {
+        if (s->grp_rb[g] < 0) continue;
+        for (int c = 0; c < s->Nc; ++c)
+          if (s->P->camera_group[c] == g && s->cam_rb[c] >= 0) cl_rb[m++] = s->cam_rb[c];
+        cl_rb[m++] = s->grp_rb[g];
+      } else {
+        for (int b = 0; b < s->nrb; ++b)
+          if (s->vis_cluster[b] == g) cl_rb[m++] = b;
+        if (m - cl_ptr[ncl] < 2) continue; /* a cluster of one view is its own (whole) block: Minv has it */
+      }
       cl_ptr[ncl + 1] = m;
       int nc = 0;
       for (int a = cl_ptr[ncl]; a < m; ++a) nc += s->rb_dim[cl_rb[a]];
@@ -1245,7 +1422,7 @@ static double back_substitute(ost* s) {
 static void free_state(ost* s) {
   free(s->ext); free(s->intr); free(s->pts);
   free(s->n_ext); free(s->ext_idx); free(s->n_intr); free(s->intr_idx); free(s->grp_private);
-  free(s->rb_dim); free(s->rb_off); free(s->rb_split); free(s->cam_rb); free(s->grp_rb);
+  free(s->rb_dim); free(s->rb_off); free(s->rb_split); free(s->cam_rb); free(s->grp_rb); free(s->vis_cluster);
   free(s->order); free(s->pt_ptr);
   free(s->r); free(s->Jc); free(s->Jp); free(s->Ep);
   free(s->scale_c); free(s->scale_p); free(s->diag_c); free(s->diag_p);

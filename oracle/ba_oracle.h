@@ -135,6 +135,9 @@ int32_t oracle_adjust_two_views_angular(tmi_ba_two_view_angular_batch* batch, in
 int32_t oracle_angular_epipolar_error(const double* rotation, const double* position, const double* f1,
                                       const double* f2, double* residual);
 
+/* test hook: the visibility cluster (CLUSTER_JACOBI without shared intrinsics blocks) of every camera in the last
+ * oracle_ba_solve that built them; returns the number of cameras or -1 */
+int32_t oracle_last_visibility_clusters(int32_t* out, int32_t n);
 int32_t oracle_num_threads(void);
 /* OpenMP threads used by the calls that follow (bench.py: single-thread baseline). */
 void oracle_set_num_threads(int32_t n);

@@ -93,6 +93,17 @@ def solve(problem: abi.Problem, options: abi.COptions):
     return st, s
 
 
+def last_visibility_clusters(num_cameras: int) -> np.ndarray:
+    """cluster of every camera in the last clustered solve (CLUSTER_JACOBI without shared intrinsics blocks)"""
+    out = np.full(num_cameras, -2, dtype=np.int32)
+    L = lib()
+    L.oracle_last_visibility_clusters.argtypes = [C.c_void_p, C.c_int32]
+    L.oracle_last_visibility_clusters.restype = C.c_int32
+    n = L.oracle_last_visibility_clusters(out.ctypes.data, num_cameras)
+    assert n == num_cameras, n
+    return out
+
+
 def inner_sweep(problem: abi.Problem, options: abi.COptions):
     """One coordinate-descent sweep (Ceres inner iterations) in place."""
     cp = problem.as_c()

@@ -1,5 +1,7 @@
-"""CLUSTER_JACOBI on problems with shared intrinsics blocks (theia_mi355_ba.h, cluster_precond.h): a cluster is a shared
-block together with the views that share it, inverted exactly.
+"""CLUSTER_JACOBI (theia_mi355_ba.h, cluster_precond.h).  With shared intrinsics blocks a cluster is a shared block
+together with the views that share it, inverted exactly; without them the views are clustered by visibility as Ceres'
+VisibilityBasedPreconditioner does (CANONICAL_VIEWS / SINGLE_LINKAGE, bundle_adjustment.h:86-89) -- second half of
+this file.
 
 CPU: the oracle's restatement -- far fewer PCG iterations than SCHUR_JACOBI, the same LM trajectory within the
 tolerance PCG's inexact solves allow, fall-back to SCHUR_JACOBI without shared blocks.
@@ -49,16 +51,181 @@ def test_oracle_cluster_jacobi_cuts_the_pcg_iterations():
     assert tri.num_linear_solver_iterations == clu.num_linear_solver_iterations
 
 
-def test_oracle_cluster_jacobi_without_shared_blocks_is_schur_jacobi():
+def test_single_linkage_without_similar_views_is_the_merged_block_jacobi():
+    """SINGLE_LINKAGE joins views whose visibility similarity is >= 0.9; the ring scene has none, every cluster is one
+    view and its exact inverse is the view's whole block: SCHUR_JACOBI with merged blocks, to the bit"""
     prob = synth.config("ladybug49")
     outs = []
-    for pre in (abi.PRECOND_SCHUR_JACOBI, abi.PRECOND_CLUSTER_JACOBI):
+    for pre, kw in ((abi.PRECOND_SCHUR_JACOBI, {}), (abi.PRECOND_CLUSTER_JACOBI, dict(visibility_clustering_type=abi.SINGLE_LINKAGE))):
         p = prob.copy()
-        st, s = oracle.solve(p, options(pre, max_num_iterations=5))
+        st, s = oracle.solve(p, options(pre, max_num_iterations=5, **kw))
         assert st == 0
         outs.append((s.final_cost, s.num_linear_solver_iterations, p.extrinsics.copy()))
     assert abs(outs[0][0] - outs[1][0]) <= 1e-12 * outs[0][0] and outs[0][1] == outs[1][1]
     assert np.abs(outs[0][2] - outs[1][2]).max() <= 1e-10
+    assert len(set(oracle.last_visibility_clusters(prob.num_cameras).tolist())) == prob.num_cameras
+
+
+# ---- clusters by visibility (no shared intrinsics blocks) ------------------------------------------------------------
+def schur_complement_graph(prob):
+    """Ceres' CreateSchurComplementGraph on the PARAMETER blocks, literally: vertex 2 c = extrinsics of camera c, 2 c + 1 =
+    its (private, free) intrinsics; weight |points both see| / sqrt(|points of a| |points of b|), self edges 1"""
+    nc = prob.num_cameras
+    free_intr = [bool((prob.intrinsics_constant[prob.group_offset[g]:prob.group_offset[g + 1]] == 0).any())
+                 for g in prob.camera_group]
+    verts = [2 * c for c in range(nc)] + [2 * c + 1 for c in range(nc) if free_intr[c]]
+    vis = {v: set() for v in verts}
+    for c, p in zip(prob.obs_camera, prob.obs_point):
+        if prob.point_constant[p]:
+            continue
+        vis[2 * c].add(int(p))
+        if free_intr[c]:
+            vis[2 * c + 1].add(int(p))
+    by_point = {}
+    for v in verts:
+        for p in vis[v]:
+            by_point.setdefault(p, []).append(v)
+    count = {}
+    for vs in by_point.values():
+        for a in vs:
+            for b in vs:
+                if a < b:
+                    count[(a, b)] = count.get((a, b), 0) + 1
+    w = {(v, v): 1.0 for v in verts}
+    nbr = {v: {v} for v in verts}
+    for (a, b), n in count.items():
+        w[(a, b)] = w[(b, a)] = n / np.sqrt(len(vis[a]) * len(vis[b]))
+        nbr[a].add(b)
+        nbr[b].add(a)
+    return sorted(verts), nbr, w
+
+
+def canonical_views(verts, nbr, w, size_penalty=3.0, similarity_penalty=0.0, min_views=3):
+    """canonical_views_clustering.cc, literally, with the preconditioner's constants; ties to the lower vertex"""
+    sim, assigned, centers, valid = {}, {}, [], list(verts)
+    while valid:
+        best, best_d = None, -np.inf
+        for v in valid:
+            d = sum(max(0.0, w[(n, v)] - sim.get(n, 0.0)) for n in nbr[v]) - size_penalty
+            d -= similarity_penalty * sum(w.get((c, v), 0.0) for c in centers)
+            if d > best_d:
+                best, best_d = v, d
+        if best_d <= 0 and len(centers) >= min_views:
+            break
+        centers.append(best)
+        valid.remove(best)
+        for n in sorted(nbr[best]):
+            if w[(n, best)] > sim.get(n, 0.0):
+                sim[n], assigned[n] = w[(n, best)], best
+    cid = {c: i for i, c in enumerate(centers)}
+    return {v: (cid[assigned[v]] if v in assigned else v % len(centers)) for v in verts}
+
+
+def same_partition(a, b):
+    """two labelings of the same items describe the same partition"""
+    m = {}
+    for x, y in zip(a, b):
+        if m.setdefault(x, y) != y:
+            return False
+    return len(set(m.values())) == len(m)
+
+
+@pytest.mark.parametrize("name", ["ladybug49", "constant_blocks"])
+def test_oracle_canonical_views_clusters_are_the_literal_algorithms(name):
+    """the oracle keeps its clustering state per VIEW (the blocks of a view always share a cluster); the literal
+    algorithm on the parameter-block graph, written here in Python from Ceres 1.14's sources as published, must give
+    the same partition of the cameras"""
+    prob = synth.config("ladybug49") if name == "ladybug49" else synth.make_problem(20, 1500, 7000, seed=23, scene="ring", spread=0.6)
+    if name == "constant_blocks":
+        prob.set_intrinsics_to_optimize(abi.INTRINSICS_NONE)              # extrinsics vertices only
+        prob.camera_flags[3] = abi.CAMERA_POSITION_CONSTANT | abi.CAMERA_ORIENTATION_CONSTANT   # a view without a block
+        prob.point_constant[::4] = 1                                       # constant points are no e-blocks
+    st, _ = oracle.solve(prob.copy(), options(abi.PRECOND_CLUSTER_JACOBI, max_num_iterations=1))
+    assert st == 0
+    got = oracle.last_visibility_clusters(prob.num_cameras)
+    verts, nbr, w = schur_complement_graph(prob)
+    if name == "constant_blocks":
+        verts = [v for v in verts if v != 6]
+        nbr = {v: {n for n in ns if n != 6} for v, ns in nbr.items() if v != 6}
+    want = canonical_views(verts, nbr, w)
+    cams = [c for c in range(prob.num_cameras) if 2 * c in want]
+    assert all(got[c] >= 0 for c in cams) and (name != "constant_blocks" or got[3] == -1)
+    # extrinsics and intrinsics of a view: one cluster
+    assert all(want[2 * c] == want[2 * c + 1] for c in cams if 2 * c + 1 in want)
+    assert same_partition([int(got[c]) for c in cams], [want[2 * c] for c in cams])
+    assert 3 <= len(set(want.values())) < len(cams)
+
+
+def test_oracle_single_linkage_joins_views_that_see_the_same_tracks():
+    """two views with (almost) identical visibility -- similarity >= 0.9 -- land in one cluster, nobody else does"""
+    prob = synth.make_problem(12, 900, 4200, seed=31, scene="ring", spread=0.6)
+    # view 7 becomes a second look at the tracks of view 2: drop 7's observations, copy 2's (a different pose sees them too)
+    keep = prob.obs_camera != 7
+    dup = prob.obs_camera == 2
+    prob.obs_camera = np.concatenate([prob.obs_camera[keep], np.full(int(dup.sum()), 7, dtype=prob.obs_camera.dtype)])
+    prob.obs_point = np.concatenate([prob.obs_point[keep], prob.obs_point[dup]])
+    prob.obs_xy = np.concatenate([prob.obs_xy[keep], prob.obs_xy[dup]])
+    st, s = oracle.solve(prob.copy(), options(abi.PRECOND_CLUSTER_JACOBI, max_num_iterations=2,
+                                              visibility_clustering_type=abi.SINGLE_LINKAGE))
+    assert st == 0
+    cl = oracle.last_visibility_clusters(prob.num_cameras)
+    assert cl[2] == cl[7] and len(set(cl.tolist())) == prob.num_cameras - 1
+
+
+def test_oracle_visibility_clusters_precondition_better_than_block_jacobi():
+    prob = synth.make_problem(60, 9000, 50000, seed=17, scene="ring", spread=0.3)
+    res = {}
+    for pre in (abi.PRECOND_SCHUR_JACOBI, abi.PRECOND_CLUSTER_JACOBI, abi.PRECOND_CLUSTER_TRIDIAGONAL):
+        st, s = oracle.solve(prob.copy(), options(pre, max_num_iterations=6))
+        assert st == 0 and s.success == 1
+        res[pre] = s
+    jac, clu, tri = res[abi.PRECOND_SCHUR_JACOBI], res[abi.PRECOND_CLUSTER_JACOBI], res[abi.PRECOND_CLUSTER_TRIDIAGONAL]
+    assert clu.num_linear_solver_iterations < jac.num_linear_solver_iterations
+    assert abs(clu.final_cost - jac.final_cost) < 1e-4 * jac.final_cost and clu.num_successful_steps == jac.num_successful_steps
+    assert tri.num_linear_solver_iterations == clu.num_linear_solver_iterations  # served as CLUSTER_JACOBI
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["ladybug49_canonical", "ladybug49_auto_mode", "bigger_canonical_huber_dof4", "single_linkage_pair"])
+def test_device_visibility_clusters_match_oracle(case):
+    from theiasfm_amd import lib
+    kw = dict(function_tolerance=1e-6, gradient_tolerance=1e-10, parameter_tolerance=1e-8, max_num_iterations=12)
+    if case.startswith("ladybug49"):
+        prob = synth.config("ladybug49")
+        if case == "ladybug49_auto_mode":
+            kw.update(schur_mode=abi.SCHUR_AUTO)  # auto must pick the formed S: the clusters are its submatrices
+    elif case == "bigger_canonical_huber_dof4":
+        prob = synth.make_problem(150, 24000, 130000, seed=29, scene="ring", spread=0.3)
+        kw.update(loss_function_type=abi.LOSS_HUBER, robust_loss_width=3.0, point_dof=4)
+    else:
+        prob = synth.make_problem(12, 900, 4200, seed=31, scene="ring", spread=0.6)
+        keep, dup = prob.obs_camera != 7, prob.obs_camera == 2
+        prob.obs_camera = np.concatenate([prob.obs_camera[keep], np.full(int(dup.sum()), 7, dtype=prob.obs_camera.dtype)])
+        prob.obs_point = np.concatenate([prob.obs_point[keep], prob.obs_point[dup]])
+        prob.obs_xy = np.concatenate([prob.obs_xy[keep], prob.obs_xy[dup]])
+        kw.update(visibility_clustering_type=abi.SINGLE_LINKAGE)
+    o = options(abi.PRECOND_CLUSTER_JACOBI, **kw)
+    a, b = prob.copy(), prob.copy()
+    st_d, s_d = lib.solve(a, o)
+    st_o, s_o = oracle.solve(b, o)
+    assert st_d == st_o == 0, (s_d.message, s_o.message)
+    assert s_d.num_matrix_free_iterations == 0
+    assert s_d.num_iterations == s_o.num_iterations and s_d.num_successful_steps == s_o.num_successful_steps
+    assert abs(int(s_d.num_linear_solver_iterations) - int(s_o.num_linear_solver_iterations)) <= 1
+    assert abs(s_d.final_cost - s_o.final_cost) <= 1e-9 * s_o.final_cost
+    assert np.abs(a.extrinsics - b.extrinsics).max() <= 1e-6 * 100.0
+    # and it is not block-Jacobi in disguise
+    st_j, s_j = lib.solve(prob.copy(), options(abi.PRECOND_SCHUR_JACOBI, **{k: v for k, v in kw.items() if k != "visibility_clustering_type"}))
+    if case != "single_linkage_pair":
+        assert s_d.num_linear_solver_iterations < s_j.num_linear_solver_iterations
+
+
+@pytest.mark.gpu
+def test_device_visibility_clusters_refuse_the_matrix_free_operator():
+    from theiasfm_amd import lib
+    prob = synth.config("ladybug49")
+    with pytest.raises(lib.EngineError):
+        lib.Solver(prob, options(abi.PRECOND_CLUSTER_JACOBI, schur_mode=abi.SCHUR_IMPLICIT))
 
 
 @pytest.mark.gpu

@@ -75,3 +75,49 @@ def test_one_sweep_product_is_reproducible_to_the_bit():
     _, s_a, p_a = solve(prob, True, **kw)
     _, s_b, p_b = solve(prob, True, **kw)
     assert s_a.final_cost == s_b.final_cost and (p_a.extrinsics == p_b.extrinsics).all() and (p_a.points == p_b.points).all()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_one_sweep_product_on_sharded_handles(world):
+    """Every rank of a sharded solve builds its own units / items / slots from its shard of the slices (the engine
+    switches the one-sweep product on per rank, from a million observations): `world` handles in threads on the one
+    device, the hook summing their buffers where RCCL would -- each rank ends where the single-rank solve ends."""
+    import threading
+
+    import torch
+
+    from test_gpu_sharded import EmulatedAllReduce
+    torch.cuda.init()
+    prob, kw = CASES["heavy_tail"]()
+    opts = abi.default_options(linear_solver_type=abi.ITERATIVE_SCHUR, schur_mode=abi.SCHUR_IMPLICIT, max_num_iterations=5,
+                               use_inner_iterations=0, **kw)
+    st1, s1, _ = solve(prob, True, max_num_iterations=5, use_inner_iterations=0, **kw)
+    assert st1 == 0
+    os.environ["TMI_BA_MF_ONE_SWEEP"] = "1"
+    try:
+        emu = EmulatedAllReduce(world)
+        solvers = []
+        for r in range(world):
+            sv = lib.Solver(prob.copy(), opts, rank=r, world=world)
+            sv.set_allreduce(emu.hook(r))
+            solvers.append(sv)
+    finally:
+        os.environ.pop("TMI_BA_MF_ONE_SWEEP", None)
+    results = [None] * world
+
+    def run(r):
+        results[r] = solvers[r].solve(opts)
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert all(not t.is_alive() for t in threads) and emu.calls > 0
+    for st_r, s_r in results:
+        assert st_r == 0 and s_r.num_iterations == s1.num_iterations
+        assert s_r.num_linear_solver_iterations == s1.num_linear_solver_iterations
+        assert abs(s_r.final_cost - s1.final_cost) <= 1e-9 * s1.final_cost
+        assert s_r.final_cost == results[0][1].final_cost
+    for sv in solvers:
+        sv.close()

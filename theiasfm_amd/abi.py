@@ -28,6 +28,7 @@ PRECOND_IDENTITY, PRECOND_JACOBI, PRECOND_SCHUR_JACOBI = 0, 1, 2
 PRECOND_CLUSTER_JACOBI, PRECOND_CLUSTER_TRIDIAGONAL = 3, 4  # clusters = shared intrinsics block + its views
 PRECOND_SCHUR_JACOBI_PARAMETER_BLOCKS = 18  # Ceres's own block shape (6x6 + NxN per view)
 SCHUR_AUTO, SCHUR_EXPLICIT, SCHUR_IMPLICIT = 0, 1, 2
+CANONICAL_VIEWS, SINGLE_LINKAGE = 0, 1  # ceres::VisibilityClusteringType
 
 INTRINSICS_NONE = 0x00
 INTRINSICS_FOCAL_LENGTH = 0x01
@@ -107,6 +108,7 @@ class COptions(C.Structure):
         ("profile_kernels", C.c_int32),
         ("residual_precision", C.c_int32),
         ("schur_mode", C.c_int32),
+        ("visibility_clustering_type", C.c_int32),
     ]
 
 
@@ -239,6 +241,7 @@ def default_options(**overrides) -> COptions:
     o.profile_kernels = 0
     o.residual_precision = 64
     o.schur_mode = 0
+    o.visibility_clustering_type = 0
     for k, v in overrides.items():
         if not hasattr(o, k):
             raise AttributeError(f"tmi_ba_options has no field {k!r}")

@@ -324,6 +324,8 @@ struct tmi_ba_solver {
   double* d_shared_diag_partial = nullptr;
   bool cluster_blocks = false;  // the matrix-free operator with the clusters' blocks of S formed beside it
   bool cl_built = false;      // plan + device buffers exist
+  bool vis_clusters = false;  // no shared intrinsics blocks: the clusters are Ceres' visibility clusters of the views
+  std::vector<std::vector<int> > vis_members;  // ... their reduced blocks, ascending (build_visibility_clusters)
   bool cl_active = false;     // the current LM iteration's PCG applies it
   bool cl_retired = false;    // a cluster launch gave up in this solve (device shared with another process): SCHUR_JACOBI for the rest of it
   clp::ClusterDesc* d_cl_desc = nullptr;
@@ -1093,6 +1095,7 @@ void tmi_ba_options_init(tmi_ba_options* o) {
   o->profile_kernels = 0;
   o->residual_precision = 64;
   o->schur_mode = 0;
+  o->visibility_clustering_type = 0;
 }
 
 int32_t tmi_ba_intrinsics_size(int32_t model) {
@@ -1442,6 +1445,164 @@ static int build_mf_chunks(tmi_ba_solver* s) {
   return TMI_BA_OK;
 }
 
+
+// ---- CLUSTER_JACOBI / CLUSTER_TRIDIAGONAL on a problem without shared intrinsics blocks: the views clustered by
+// visibility as ceres::VisibilityBasedPreconditioner::ClusterCameras does (Ceres is external to the reference --
+// bundle_adjuster.cc:59-63 only passes preconditioner_type and visibility_clustering_type on -- so this restates Ceres
+// 1.14: visibility.cc CreateSchurComplementGraph, canonical_views_clustering.cc, single_linkage_clustering.cc,
+// visibility_based_preconditioner.cc; parity unpinned like the rest of that layer).
+//   graph   : one vertex per camera-side PARAMETER block -- a view's extrinsics and, when it has free private
+//             intrinsics, its intrinsics block (identical visibility: similarity 1 between the two) --, a self edge of
+//             weight 1 on every vertex, and between two blocks the weight |tracks both see| / sqrt(|tracks of a| |tracks
+//             of b|) over the NON-constant tracks (constant points are no e-blocks);
+//   CANONICAL_VIEWS: greedily the view whose promotion to a centre gains most -- sum over its neighbours of the
+//             similarity they would win, minus size_penalty_weight = 3 (similarity_penalty_weight = 0, view_score_weight
+//             = 0: visibility_based_preconditioner.cc's constants) -- until the gain is <= 0 and there are >= 3 centres;
+//             every vertex joins the centre it is most similar to; a vertex that touches no centre goes to cluster
+//             (its index mod #clusters), as FlattenMembershipMap does;
+//   SINGLE_LINKAGE : the connected components of the edges with similarity >= 0.9.
+// Ties go to the lower vertex index (Ceres iterates hash sets: its order is the STL's).  The two blocks of a view end
+// up in one cluster by construction (similarity 1), so a cluster is a set of views = reduced blocks here.
+static int build_visibility_clusters(tmi_ba_solver* s, const tmi_ba_problem* P, int type) {
+  Structure& st = s->st;
+  const int Nrb = st.Nrb, D = st.D;
+  s->vis_members.clear();
+  if (Nrb == 0) return TMI_BA_OK;
+  // host copies of the block structure of S and of the pair counts
+  std::vector<long long> pair_ptr;
+  if (s->device_structure) {
+    st.urow_ptr.resize((size_t)Nrb + 1);
+    st.ub_j.resize((size_t)st.nub);
+    pair_ptr.resize((size_t)st.nub + 1);
+    TMI_HIP(hipMemcpy(st.urow_ptr.data(), s->v.urow_ptr, ((size_t)Nrb + 1) * sizeof(int), hipMemcpyDeviceToHost));
+    if (st.nub) {
+      TMI_HIP(hipMemcpy(st.ub_j.data(), s->v.ub_j, (size_t)st.nub * sizeof(int), hipMemcpyDeviceToHost));
+      TMI_HIP(hipMemcpy(pair_ptr.data(), s->v.pair_ptr, ((size_t)st.nub + 1) * sizeof(long long), hipMemcpyDeviceToHost));
+    }
+  } else {
+    pair_ptr.assign(st.pair_ptr.begin(), st.pair_ptr.end());
+  }
+  // tracks of a view (non-constant ones), parameter blocks of a view
+  std::vector<double> ntr((size_t)Nrb, 0.0);
+  for (int64_t i = 0; i < P->num_observations; ++i) {
+    const int rb = st.cam_rb[P->obs_camera[i]];
+    if (rb >= 0 && !(P->point_constant && P->point_constant[P->obs_point[i]])) ntr[rb] += 1.0;
+  }
+  std::vector<int> mult((size_t)Nrb, 0);
+  for (int rb = 0; rb < Nrb; ++rb) {
+    bool ext = false, intr = false;
+    for (int c = 0; c < D; ++c) {
+      const int b = st.rb_cols[(size_t)rb * D + c];
+      if (b >= 0 && b < 6) ext = true;
+      if (b >= 6) intr = true;
+    }
+    mult[rb] = (ext ? 1 : 0) + (intr ? 1 : 0);
+  }
+  // symmetric adjacency of the views: (neighbour, similarity)
+  std::vector<std::vector<std::pair<int, double> > > adj((size_t)Nrb);
+  for (int i = 0; i < Nrb; ++i)
+    for (int u = st.urow_ptr[i]; u < st.urow_ptr[i + 1]; ++u) {
+      const int j = st.ub_j[u];
+      const double cnt = (double)(pair_ptr[u + 1] - pair_ptr[u]);
+      if (cnt <= 0.0 || ntr[i] <= 0.0 || ntr[j] <= 0.0) continue;
+      const double w = cnt / std::sqrt(ntr[i] * ntr[j]);
+      adj[i].emplace_back(j, w);
+      adj[j].emplace_back(i, w);
+    }
+  std::vector<int> cluster((size_t)Nrb, -1);
+  int ncl = 0;
+  if (type == 1) {
+    // SINGLE_LINKAGE (kSingleLinkageMinSimilarity = 0.9)
+    std::vector<int> parent((size_t)Nrb);
+    for (int i = 0; i < Nrb; ++i) parent[i] = i;
+    std::function<int(int)> find = [&](int a) { return parent[a] == a ? a : parent[a] = find(parent[a]); };
+    for (int i = 0; i < Nrb; ++i)
+      for (const auto& e : adj[i])
+        if (e.first > i && e.second >= 0.9) {
+          const int a = find(i), b = find(e.first);
+          if (a != b) parent[std::max(a, b)] = std::min(a, b);
+        }
+    std::vector<int> id((size_t)Nrb, -1);
+    for (int i = 0; i < Nrb; ++i) {
+      if (mult[i] == 0) continue;
+      const int r = find(i);
+      if (id[r] < 0) id[r] = ncl++;
+      cluster[i] = id[r];
+    }
+  } else {
+    // CANONICAL_VIEWS on the parameter-block graph.  The blocks of a view have the same neighbours, so the state is
+    // kept per view: sim[u] = similarity of u's blocks to their centre, and a view's blocks count mult[u] times.
+    const double size_penalty = 3.0, similarity_penalty = 0.0;
+    const int min_views = 3;
+    std::vector<double> sim((size_t)Nrb, 0.0);
+    std::vector<int> to_center((size_t)Nrb, -1);
+    std::vector<int> centers_of_view((size_t)Nrb, 0);  // how many of the view's blocks are centres already
+    std::vector<int> centers;                          // views (a view can appear twice: both of its blocks)
+    for (;;) {
+      int best = -1;
+      double best_gain = -1.7976931348623157e308;
+      for (int vtx = 0; vtx < Nrb; ++vtx) {
+        if (centers_of_view[vtx] >= mult[vtx]) continue;  // no block of this view is left to promote
+        double gain = 0.0;
+        // its own blocks: the self edge and the edge between extrinsics and intrinsics, weight 1 each
+        if (1.0 > sim[vtx]) gain += mult[vtx] * (1.0 - sim[vtx]);
+        for (const auto& e : adj[vtx])
+          if (e.second > sim[e.first]) gain += mult[e.first] * (e.second - sim[e.first]);
+        gain -= size_penalty;
+        if (similarity_penalty != 0.0)
+          for (const int c : centers) {
+            if (c == vtx) { gain -= similarity_penalty; continue; }
+            for (const auto& e : adj[vtx])
+              if (e.first == c) gain -= similarity_penalty * e.second;
+          }
+        if (gain > best_gain) {
+          best_gain = gain;
+          best = vtx;
+        }
+      }
+      if (best < 0) break;  // every block is a centre
+      if (best_gain <= 0.0 && (int)centers.size() >= min_views) break;
+      centers.push_back(best);
+      ++centers_of_view[best];
+      if (1.0 > sim[best]) {
+        sim[best] = 1.0;
+        to_center[best] = best;
+      }
+      for (const auto& e : adj[best])
+        if (e.second > sim[e.first]) {
+          sim[e.first] = e.second;
+          to_center[e.first] = best;
+        }
+    }
+    // cluster ids: one per CENTRE VIEW (a view promoted twice is one cluster: its second block joined the first)
+    std::vector<int> id((size_t)Nrb, -1);
+    for (const int c : centers)
+      if (id[c] < 0) id[c] = ncl++;
+    for (int i = 0; i < Nrb; ++i) {
+      if (mult[i] == 0) continue;
+      cluster[i] = to_center[i] >= 0 ? id[to_center[i]] : (ncl > 0 ? i % ncl : 0);
+    }
+    if (ncl == 0) ncl = 1;
+  }
+  std::vector<std::vector<int> > members((size_t)ncl);
+  for (int i = 0; i < Nrb; ++i)
+    if (cluster[i] >= 0) members[cluster[i]].push_back(i);  // ascending
+  for (auto& m : members)
+    if (m.size() >= 2) s->vis_members.push_back(m);  // (a cluster of one view is its SCHUR_JACOBI block)
+  if (getenv("TMI_BA_SETUP_TIMING")) {
+    size_t big = 0;
+    for (const auto& m : s->vis_members) big = std::max(big, m.size());
+    fprintf(stderr, "[tmi_ba setup] visibility clusters (%s): %d clusters, %zu with more than one view, largest %zu views\n",
+            type == 1 ? "SINGLE_LINKAGE" : "CANONICAL_VIEWS", ncl, s->vis_members.size(), big);
+    if (Nrb <= 64) {
+      fprintf(stderr, "[tmi_ba setup]   cluster of every view block:");
+      for (int i = 0; i < Nrb; ++i) fprintf(stderr, " %d", cluster[i]);
+      fprintf(stderr, "\n");
+    }
+  }
+  return TMI_BA_OK;
+}
+
 static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_options* O, int rank,
                        int world, bool light = false) {
   s->light = light;
@@ -1500,6 +1661,20 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
     if (O->schur_mode == 0) s->implicit = s->implicit_now = true;
     s->cluster_blocks = s->implicit;
     want_pairs = !s->implicit;
+  }
+  // ... and on a problem WITHOUT shared blocks: Ceres' clusters of the views by visibility (build_visibility_clusters).
+  // They are principal submatrices of the formed S and come from the GLOBAL co-visibility counts, which a rank of a
+  // sharded handle does not have: one rank only (several ranks: SCHUR_JACOBI, as before round 4).
+  if (cluster_pre && !s->st.has_shared && iterative_type && !light && world == 1) {
+    if (O->schur_mode == 2) {
+      s->error = "CLUSTER_JACOBI / CLUSTER_TRIDIAGONAL over visibility clusters need the formed Schur complement "
+                 "(schur_mode auto or explicit)";
+      return TMI_BA_ERR_UNSUPPORTED;
+    }
+    s->vis_clusters = true;
+    s->implicit = s->implicit_now = false;
+    s->adaptive = false;
+    want_pairs = true;
   }
   if (device_setup_possible(s->st, world, P->num_observations, want_pairs)) {
     s->device_structure = true;
@@ -1728,6 +1903,7 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
     rc = build_mf_chunks(s);
     if (rc) return rc;
   }
+  if (s->vis_clusters && (rc = build_visibility_clusters(s, P, O->visibility_clustering_type))) return rc;
   if (s->need_slot_track && !s->mf_ok) {
     int* stt;
     if ((rc = dev_alloc(s, &stt, (size_t)std::max<int64_t>(st.Nslots, 1)))) return rc;
@@ -2001,8 +2177,8 @@ static int ensure_clusters(tmi_ba_solver* s) {
     TMI_HIP(hipGetDeviceProperties(&prop, s->device));
     s->num_cus = prop.multiProcessorCount;
   }
-  std::vector<std::vector<int> > members;
-  for (int g = 0; g < st.Nrb - st.Ncam_rb; ++g) {
+  std::vector<std::vector<int> > members = s->vis_members;  // (empty unless vis_clusters)
+  for (int g = 0; g < st.Nrb - st.Ncam_rb && !s->vis_clusters; ++g) {
     std::vector<int> m;
     for (int k = st.grp_cam_ptr[g]; k < st.grp_cam_ptr[g + 1]; ++k) m.push_back(st.cam_rb[st.grp_cams[k]]);
     std::sort(m.begin(), m.end());
@@ -2085,7 +2261,7 @@ static int solve_reduced_pcg(tmi_ba_solver* s, const tmi_ba_options* O, int* usa
   // (residual_reset_period) through the three-kernel path below.  (Enqueueing iteration it + 1 speculatively before
   // the scalars of iteration it are read measured no gain on MI355X -- 5.02 vs 5.04 ms per LM iteration at one GPU,
   // 1.57 vs 1.53 ms for an eighth of the tracks, profiles/r02_g -- and is gone.)
-  const bool fused = !s->st.has_shared;
+  const bool fused = !s->st.has_shared && !s->cl_active;  // (pcg_step applies the block inverses itself: no clusters)
   const int nbv = (v.Nrb + 3) / 4;
   const int nbs16 = (v.Nrb + kPcgStepThreads / 64 - 1) / (kPcgStepThreads / 64);  // workgroups of pcg_step
   int it;
@@ -2656,7 +2832,8 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
         // {shared block, its views} cluster (needs the cluster's blocks of S: the formed operator)
         s->cl_active = (O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_JACOBI ||
                         O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_TRIDIAGONAL) &&
-                       s->st.has_shared && (!s->implicit_now || s->cluster_blocks) && n_r > 0 && !s->cl_retired;
+                       (s->st.has_shared || s->vis_clusters) && (!s->implicit_now || s->cluster_blocks) && n_r > 0 &&
+                       !s->cl_retired;
         if (s->cl_active) CK(factor_clusters(s));
       }
       const int64_t before = pcg_iters;

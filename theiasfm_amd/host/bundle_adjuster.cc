@@ -558,6 +558,7 @@ void ToDeviceOptions(const BundleAdjustmentOptions& options, tmi_ba_options* o) 
   o->max_trust_region_radius = options.max_trust_region_radius;
   o->point_dof = options.point_dof;
   o->device = options.device;
+  o->visibility_clustering_type = static_cast<int32_t>(options.visibility_clustering_type);  // bundle_adjuster.cc:61
 }
 
 // bundle_adjuster.cc:182-221
