@@ -182,13 +182,29 @@ void BundleAdjuster::AddViews(const std::vector<ViewId>& view_ids) {
   if (std::getenv("TMI_BA_SETUP_TIMING") != nullptr)
     std::fprintf(stderr, "[tmi_ba shim] %-28s %.3f s\n", "AddViews: feature tables",
                  std::chrono::duration<double>(std::chrono::steady_clock::now() - timer_start_).count());
-  size_t total = residuals_.size();
-  for (const auto& l : local) total += l.size();
-  residuals_.reserve(total);
-  for (const auto& l : local) {
-    // AddReprojectionErrorResidual + SetTrackConstant of every residual (:127-137)
-    for (const Residual& r : l) track_constant_.Set(r.track, 1);
-    residuals_.insert(residuals_.end(), l.begin(), l.end());
+  // AddReprojectionErrorResidual + SetTrackConstant of every residual (:127-137).  The per-thread lists are copied to
+  // their final positions in parallel; the tracks of the residuals are exactly the estimated tracks that some added
+  // view sees, marked by threads that own disjoint ID ranges of the (pre-sized) table.
+  {
+    const size_t base = residuals_.size();
+    std::vector<size_t> first(local.size() + 1, base);
+    for (size_t l = 0; l < local.size(); ++l) first[l + 1] = first[l] + local[l].size();
+    residuals_.resize(first.back());
+    RunThreads(n_threads, [&](int t) { std::copy(local[t].begin(), local[t].end(), residuals_.begin() + first[t]); });
+    std::vector<uint8_t> touched(static_cast<size_t>(max_track) + 1, 0);
+    // (one byte per track id; equal values written by several threads: relaxed atomic stores)
+    RunThreads(n_threads, [&](int t) {
+      for (const Residual& r : local[t]) __atomic_store_n(&touched[r.track], static_cast<uint8_t>(1), __ATOMIC_RELAXED);
+    });
+    std::vector<size_t> fresh_c(n_threads, 0);
+    RunThreads(n_threads, [&](int t) {
+      const size_t i0 = touched.size() * t / n_threads, i1 = touched.size() * (t + 1) / n_threads;
+      size_t mine = 0;
+      for (size_t id = i0; id < i1; ++id)
+        if (touched[id] && track_constant_.SetPresized(static_cast<uint32_t>(id), 1)) ++mine;
+      fresh_c[t] = mine;
+    });
+    for (const size_t c : fresh_c) track_constant_.NoteAdded(c);
   }
   if (std::getenv("TMI_BA_SETUP_TIMING") != nullptr)
     std::fprintf(stderr, "[tmi_ba shim] %-28s %.3f s\n", "AddViews: total",
@@ -401,11 +417,20 @@ bool BundleAdjuster::Flatten(FlattenedBundleAdjustmentProblem* f) {
     f->camera_flags.push_back(static_cast<uint8_t>(std::max(camera_flags_.Get(id), 0)));
   }
   f->track_ids = pt_index.ids;
-  f->points.reserve(4 * f->track_ids.size());
-  for (const TrackId id : f->track_ids) {
-    const Eigen::Vector4d& X = reconstruction_->Track(id)->Point();
-    f->points.insert(f->points.end(), X.data(), X.data() + 4);
-    f->point_constant.push_back(track_constant_.Get(id) == 1 ? 1 : 0);
+  {
+    // read-only look-ups of distinct tracks into pre-sized arrays: split over threads
+    const size_t nt = f->track_ids.size();
+    f->points.resize(4 * nt);
+    f->point_constant.resize(nt);
+    const int nth = HostThreads(4 * nt);
+    RunThreads(nth, [&](int th) {
+      for (size_t t = nt * th / nth; t < nt * (th + 1) / nth; ++t) {
+        const TrackId id = f->track_ids[t];
+        const Eigen::Vector4d& X = reconstruction_->Track(id)->Point();
+        std::copy(X.data(), X.data() + 4, f->points.begin() + 4 * t);
+        f->point_constant[t] = track_constant_.Get(id) == 1 ? 1 : 0;
+      }
+    });
   }
   lap("parameters");
   // deterministic observation order: by (track, view).  Two stable counting sorts over compact
