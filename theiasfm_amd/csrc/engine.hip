@@ -1130,16 +1130,20 @@ int32_t tmi_ba_intrinsics_constant_mask(int32_t model, int32_t bits, uint8_t* ma
 void tmi_ba_solver_destroy(tmi_ba_solver* s) {
 #ifdef TMI_MF_PROFILE
   if (s && s->mf_ok && s->mf.prof) {
-    std::vector<long long> h((size_t)s->mf.n_items * 8);
+    std::vector<long long> h((size_t)s->mf.n_items * 16);
     hipDeviceSynchronize();
     hipMemcpy(h.data(), s->mf.prof, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
-    double t[5] = {0, 0, 0, 0, 0}, units = 0;
+    double t[13] = {0}, units = 0, items = 0;
     for (int i = s->mf.nwb; i < s->mf.n_items; ++i) {
-      for (int k = 0; k < 5; ++k) t[k] += (double)h[(size_t)i * 8 + k];
-      units += (double)h[(size_t)i * 8 + 5];
+      for (int k = 0; k < 10; ++k) t[k] += (double)h[(size_t)i * 16 + k];
+      t[11] += (double)h[(size_t)i * 16 + 11];
+      t[12] += (double)h[(size_t)i * 16 + 12];
+      units += (double)h[(size_t)i * 16 + 10];
+      items += 1;
     }
-    fprintf(stderr, "[mf profile] last product, per narrow unit (cycles): batch+u %.0f | z %.0f | v %.0f | runs %.0f | long %.0f  (units %.0f)\n",
-            t[0] / units, t[1] / units, t[2] / units, t[3] / units, t[4] / units, units);
+    fprintf(stderr, "[mf profile] per narrow unit (cycles): issue %.0f | wait+u+wpart %.0f | bar1 %.0f | z %.0f | bar2 %.0f | t,v %.0f | bar3 %.0f | runs %.0f | long+bar %.0f | bar5 %.0f  (units %.0f); per item: before loop %.0f, write-out %.0f\n",
+            t[0] / units, t[1] / units, t[2] / units, t[3] / units, t[4] / units, t[5] / units, t[6] / units, t[7] / units,
+            t[8] / units, t[9] / units, units, t[11] / items, t[12] / items);
   }
 #endif
   if (!s) return;
@@ -1192,11 +1196,20 @@ static int build_mf_chunks(tmi_ba_solver* s) {
   if (n_narrow > 0 && rows_of(st.n_wide) > kMaxNarrowK) return TMI_BA_OK;
   // narrow units: a slice, or a pack of consecutive slices of the same (small) length whose rows together fill the
   // kWaves * reg_rows(D) row slots of the kernel
-  std::vector<int4> unit_desc;  // {first element, rows, rows of one slice, first slice}
+  std::vector<int4> unit_desc;  // {first element, rows, rows of one slice | log2 L << 16, first slice}
   {
     const int slots = kWaves * reg_rows(D);
     for (int sl = st.n_wide; sl < st.nslices;) {
       const int K = rows_of(sl);
+      if (K > slots) {
+        // a long slice: L pieces of 64 / L tracks, L lanes per track (mf_chunks.h)
+        int lsh = 0;
+        while ((slots << lsh) < K) ++lsh;
+        for (int q = 0; q < (1 << lsh); ++q)
+          unit_desc.push_back(make_int4(st.slice_ptr[sl] + q * (64 >> lsh), K, K | (lsh << 16), sl));
+        ++sl;
+        continue;
+      }
       int G = 1;
       if (K > 0 && 2 * K <= slots)
         while (G < slots / K && sl + G < st.nslices && rows_of(sl + G) == K) ++G;
@@ -1314,7 +1327,7 @@ static int build_mf_chunks(tmi_ba_solver* s) {
       } else {
         groups.back().second = u + 1;
       }
-      have += (long long)unit_desc[i].y * 64;
+      have += (long long)unit_desc[i].y * (64 >> (unit_desc[i].z >> 16));
       last_rows = rows;
     }
   }
@@ -1428,8 +1441,8 @@ static int build_mf_chunks(tmi_ba_solver* s) {
 #ifdef TMI_MF_PROFILE
   {
     long long* pp;
-    if ((rc = dev_alloc(s, &pp, (size_t)n_items * 8))) return rc;
-    TMI_HIP(hipMemsetAsync(pp, 0, (size_t)n_items * 8 * sizeof(long long), stream));
+    if ((rc = dev_alloc(s, &pp, (size_t)n_items * 16))) return rc;
+    TMI_HIP(hipMemsetAsync(pp, 0, (size_t)n_items * 16 * sizeof(long long), stream));
     m.prof = pp;
   }
 #endif

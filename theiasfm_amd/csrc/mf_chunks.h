@@ -35,8 +35,8 @@ constexpr int kWaves = 4;  // two workgroups per CU (<= 80 KB of LDS each), two 
 constexpr int kThreads = 64 * kWaves;
 constexpr int kMaxNarrowK = 20;               // longest thread-per-track slice (kWideKLarge)
 constexpr int kLongRun = 12;                  // a run with more entries than this is summed by a whole wavefront
-// a wavefront owns rows w, w + 4, ... of a slice; the first reg_rows(D) of them keep A, Jp and u in registers until
-// the track's z is known, the rest (one slice in four is that long) are evaluated again once z is there
+// row slots of a workgroup: kWaves * reg_rows(D); a row slot keeps A, Jp and u of its rows in registers until the
+// track's z is known (see the narrow path of product_kernel for what a unit puts into them)
 __host__ __device__ constexpr int reg_rows(int D) { return D <= 9 ? 2 : 1; }
 // distinct views an item of SEVERAL slices may see (its accumulators); an item of one slice writes its run sums
 // straight to its slots and has no limit
@@ -49,7 +49,8 @@ struct View {
   int nub;  // units [0, nub): four tracks of an ultra slice each
   int nwb;  // units [nub, nwb): a quarter of a wide slice each; [nwb, n_units): narrow slices
   const int* item_unit0;     // [n_items + 1] units of an item (wide / ultra: one)
-  const int4* unit_desc;     // [n_units - nwb] narrow units: {first element, rows, rows of one slice, first slice}
+  const int4* unit_desc;     // [n_units - nwb] narrow units: {first element, rows, rows of one slice | log2 L << 16,
+                             //  first slice}; L > 1: one of the L pieces (64 / L tracks each) of a long slice
   const int* unit_run_ptr;   // [n_units + 1]
   const int* run_obs_ptr;    // [n_runs + 1]
   const int* run_obs;        // element index e of every observation that has a view block, by (unit, view)
@@ -100,10 +101,10 @@ __global__ __launch_bounds__(256) void unit_keys_kernel(DeviceView v, int nub, i
     q = unit_shape(v, u, nub, nwb);
   } else {  // a slice or a pack of slices: rows x 64 consecutive elements
     const int4 d = unit_desc[u - nwb];
-    q.sp0 = d.x;
+    q.sp0 = d.x;  // (the first track's column included)
     q.K = d.y;
     q.t0 = 0;
-    q.nt = 64;
+    q.nt = 64 >> (d.z >> 16);
   }
   const int n = q.K * q.nt;
   for (int i = threadIdx.x; i < n; i += 256) {
@@ -350,16 +351,25 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
   }
 
   // ---- an item of narrow units
-  // A narrow unit is a slice, or a PACK of 2-4 consecutive slices of <= 4 rows (59 % of the slices of the bench
-  // problem): their tiles are consecutive in memory, so a pack is walked like one slice of G K rows whose row R
-  // belongs to the tracks of slice R / K.  Four wavefronts x two rows then have work in (nearly) every iteration.
-  // Every load an iteration needs is either issued in ONE batch at its top (x, A, Jp: the only demand loads) or was
+  // A narrow unit fills the kWaves * reg_rows(D) ROW SLOTS of the workgroup: row slot (w, rr) belongs to wavefront w.
+  //   * a slice of at most that many rows, or a PACK of 2-4 consecutive slices of <= 4 rows (59 % of the slices of the
+  //     bench problem): their tiles are consecutive in memory, so a pack is walked like one slice of G K rows whose
+  //     row R belongs to the tracks of slice R / K; lane = track, a row slot holds one row;
+  //   * a longer slice (up to kMaxNarrowK rows) is cut into L = 2, 4, .. units of 64 / L tracks: L lanes per track,
+  //     lane = sub * (64 / L) + track, a row slot holds the L rows slot * L + sub.  (Before: the rows beyond the row
+  //     slots were demand loads in dependent trips, twice per unit -- 29 % of the observations sit in such slices and
+  //     their units took 45 % of the kernel's time.)
+  // So every row of every narrow unit is in registers from the batch to the v_i, the unit's v_i fit vbuf, and
+  // every load an iteration needs is either issued in ONE batch at its top (x, A, Jp: the only demand loads) or was
   // issued an iteration earlier (geometry, view indices, L^-1, run lists); barriers order LDS only, so those stay
   // in flight across them.
   constexpr int RR = reg_rows(D);
-  constexpr int J1 = RR * kWaves;  // rows a unit keeps in registers; beyond: the tail of a long single slice
+  constexpr int J1 = RR * kWaves;  // row slots
   constexpr int NLI = sym_size(DP);
-  static_assert(VB >= J1 * 64, "the v_i of a pack fit one round");
+  static_assert(VB >= J1 * 64, "the v_i of a unit fit vbuf");
+#ifdef TMI_MF_PROFILE
+  const long long tc0 = clock64();
+#endif
   const int u0 = m.item_unit0[item], u1 = m.item_unit0[item + 1];
   const int slot0 = m.item_slot_ptr[item];
   const int nlc = m.item_slot_ptr[item + 1] - slot0;
@@ -367,31 +377,33 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
   const bool direct = (u1 - u0) == 1;
   if (!direct)
     for (int i = threadIdx.x; i < nlc * D; i += kThreads) acc[i] = 0.0;
-  const int4* desc = m.unit_desc - m.nwb;  // {first element, rows, rows of one slice, first slice}
+  const int4* desc = m.unit_desc - m.nwb;  // {first element, rows, rows of one slice | log2 L << 16, first slice}
   const int last_u = m.n_units - 1;
   int4 d0 = desc[u0], d1 = desc[min(u0 + 1, last_u)], d2 = desc[min(u0 + 2, last_u)];
   int r0 = m.unit_run_ptr[u0], r1 = m.unit_run_ptr[u0 + 1], r2 = m.unit_run_ptr[min(u0 + 2, m.n_units)];
   int o0 = m.run_obs_ptr[r0], o1 = m.run_obs_ptr[r1];
   int nrb[RR], npos[RR];
   auto load_index = [&](int4 d) {
+    const int lsh = d.z >> 16, t = lane & ((64 >> lsh) - 1), sub = lane >> (6 - lsh);
 #pragma unroll
     for (int rr = 0; rr < RR; ++rr) {
-      const int R = w + rr * kWaves;
+      const int R = ((w + rr * kWaves) << lsh) + sub;
       nrb[rr] = npos[rr] = -1;
       if (R < d.y) {
-        const size_t e = (size_t)d.x + 64 * R + lane;
+        const size_t e = (size_t)d.x + 64 * R + t;
         nrb[rr] = v.obs_rb[e];
         npos[rr] = m.obs_pos[e];
       }
     }
   };
-  // L^-1 of the tracks wavefront w solves for: slice w of the pack
+  // L^-1 of the tracks wavefront w solves for: slice w of a pack; wavefront 0 for a cut slice
   double Li[NLI];
   auto load_linv = [&](int4 d) {
-    const int G = d.y > J1 ? 1 : d.y / d.z;
+    const int lsh = d.z >> 16;
+    const int G = lsh ? 1 : d.y / (d.z & 0xffff);
     if (w < G) {
       const size_t NP = (size_t)v.Np_pad;
-      const size_t lp = (size_t)(d.w + w) * 64 + lane;
+      const size_t lp = (size_t)(d.w + w) * 64 + (d.x & 63) + (lane & ((64 >> lsh) - 1));
 #pragma unroll
       for (int i = 0; i < NLI; ++i) Li[i] = v.Linv[(size_t)i * NP + lp];
     }
@@ -410,25 +422,27 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
   load_linv(d0);
   load_runs(r0);
 #ifdef TMI_MF_PROFILE
-  long long tp[5] = {0, 0, 0, 0, 0};
+  long long tp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const long long t_begin = tc0;
   long long tc = clock64();
 #define MF_LAP(i) do { const long long n_ = clock64(); tp[i] += n_ - tc; tc = n_; } while (0)
 #else
 #define MF_LAP(i)
 #endif
   for (int u = u0; u < u1; ++u) {
-    const int sp0 = d0.x, rows = d0.y, K = d0.z;
-    const bool packed = rows <= J1;         // every row in registers; G = rows / K slices (G = 1: one short slice)
-    const int G = packed ? rows / K : 1;
-    const size_t tile0 = (size_t)(sp0 >> 6);
+    const int rows = d0.y, K = d0.z & 0xffff, lsh = d0.z >> 16;
+    const int nt = 64 >> lsh, t = lane & (nt - 1), sub = lane >> (6 - lsh);
+    const int G = lsh ? 1 : rows / K;  // slices of a pack
+    const size_t tile0 = (size_t)(d0.x >> 6);
+    const int tl = (d0.x & 63) + t;  // the track's column of the tiles
     double2 ar[RR][D], jr[RR][DP];
     double xr[RR][D];
     double uu[RR][2];
     int pos[RR];
-    // ---- the batch of loads (row slots beyond the unit: a wave-uniform skip)
+    // ---- the batch of loads
 #pragma unroll
     for (int rr = 0; rr < RR; ++rr) {
-      const int R = w + rr * kWaves;
+      const int R = ((w + rr * kWaves) << lsh) + sub;
       pos[rr] = nrb[rr] >= 0 ? npos[rr] : -1;
 #pragma unroll
       for (int a = 0; a < D; ++a) {
@@ -447,21 +461,21 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
           xr[rr][a + 1] = t2.y;
         }
         if (D & 1) xr[rr][D - 1] = xc[D - 1];
-        const double* ap = v.pm_A + (tile0 + R) * ROWD + 2 * lane;
-        const double* jp = v.pm_Jp + (tile0 + R) * ROWP + 2 * lane;
+        const double* ap = v.pm_A + (tile0 + R) * ROWD + 2 * tl;
+        const double* jp = v.pm_Jp + (tile0 + R) * ROWP + 2 * tl;
 #pragma unroll
         for (int a = 0; a < D; ++a) ar[rr][a] = *reinterpret_cast<const double2*>(ap + a * 128);
 #pragma unroll
         for (int a = 0; a < DP; ++a) jr[rr][a] = *reinterpret_cast<const double2*>(jp + a * 128);
       }
     }
+    MF_LAP(0);
     // one unit ahead: the view indices; three / two ahead: geometry and run ranges (wave-uniform, tiny)
     if (u + 1 < u1) load_index(d1);
     const int4 d3 = desc[min(u + 3, last_u)];
     const int r3 = m.unit_run_ptr[min(u + 3, m.n_units)];
     const int o2 = m.run_obs_ptr[r2];
-    // ---- u_i = A_i x; w = sum Jp^T u per row slot
-    double wv[RR][DP];
+    // ---- u_i = A_i x; this lane's share of w = sum Jp^T u per row slot
 #pragma unroll
     for (int rr = 0; rr < RR; ++rr) {
       double s0 = 0.0, s1 = 0.0;
@@ -478,187 +492,116 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
       uu[rr][0] = s0;
       uu[rr][1] = s1;
 #pragma unroll
-      for (int a = 0; a < DP; ++a) wv[rr][a] = jr[rr][a].x * s0 + jr[rr][a].y * s1;
+      for (int a = 0; a < DP; ++a) wpart[w + rr * kWaves][a][lane] = jr[rr][a].x * s0 + jr[rr][a].y * s1;
     }
-    if (!packed) {
-      // the tail rows of a long slice (one slice in eight): straight from memory, added to this wave's first slot
-#pragma unroll 1
-      for (int j = w + J1; j < rows; j += kWaves) {
-        const size_t e = (size_t)sp0 + 64 * j + lane;
-        const int rb = v.obs_rb[e];
-        if (rb < 0) continue;
-        const double* ap = v.pm_A + (tile0 + j) * ROWD + 2 * lane;
-        const double* jp = v.pm_Jp + (tile0 + j) * ROWP + 2 * lane;
-        const double* xc = x + (size_t)rb * D;
-        double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-        for (int a = 0; a < D; ++a) {
-          const double2 aa = *reinterpret_cast<const double2*>(ap + a * 128);
-          const double xa = xc[a];
-          s0 += aa.x * xa;
-          s1 += aa.y * xa;
-        }
-#pragma unroll
-        for (int a = 0; a < DP; ++a) {
-          const double2 jj = *reinterpret_cast<const double2*>(jp + a * 128);
-          wv[0][a] += jj.x * s0 + jj.y * s1;
-        }
-      }
-    }
-#pragma unroll
-    for (int rr = 0; rr < RR; ++rr)
-#pragma unroll
-      for (int a = 0; a < DP; ++a) wpart[w + rr * kWaves][a][lane] = wv[rr][a];
-    MF_LAP(0);
+    MF_LAP(1);
     lds_barrier();  // wpart (and: the previous unit's run sums have left vbuf, which wpart shares its memory with)
+    MF_LAP(2);
     if (w < G) {
-      // slice w of the pack: its rows are the slots [w K, w K + K) (a single slice: every slot)
-      const int s_lo = packed ? w * K : 0, s_hi = packed ? w * K + K : J1;
+      // slice w of a pack: its rows are the slots [w K, w K + K); a cut slice: every slot, the L lanes of the track
+      const int s_lo = lsh ? 0 : w * K, s_hi = lsh ? J1 : w * K + K;
       double wt[DP], zh[DP];
 #pragma unroll
       for (int a = 0; a < DP; ++a) wt[a] = 0.0;
-      for (int sl = s_lo; sl < s_hi; ++sl) {
+      for (int sl = s_lo; sl < s_hi; ++sl)
+        for (int q = t; q < 64; q += nt) {
 #pragma unroll
-        for (int a = 0; a < DP; ++a) wt[a] += wpart[sl][a][lane];
-      }
+          for (int a = 0; a < DP; ++a) wt[a] += wpart[sl][a][q];
+        }
       // z = L^-T (L^-1 w)   (Linv planes: sym_idx(a, b), a <= b, holds L^-1(b, a))
 #pragma unroll
       for (int bb = 0; bb < DP; ++bb) {
-        double t = 0.0;
+        double tt = 0.0;
 #pragma unroll
-        for (int a = 0; a <= bb; ++a) t += Li[sym_idx(a, bb, DP)] * wt[a];
-        zh[bb] = t;
+        for (int a = 0; a <= bb; ++a) tt += Li[sym_idx(a, bb, DP)] * wt[a];
+        zh[bb] = tt;
       }
 #pragma unroll
       for (int a = 0; a < DP; ++a) {
-        double t = 0.0;
+        double tt = 0.0;
 #pragma unroll
-        for (int bb = a; bb < DP; ++bb) t += Li[sym_idx(a, bb, DP)] * zh[bb];
-        zs[w][a][lane] = t;
+        for (int bb = a; bb < DP; ++bb) tt += Li[sym_idx(a, bb, DP)] * zh[bb];
+        zs[w][a][lane] = tt;
       }
     }
     if (u + 1 < u1) load_linv(d1);  // consumed an iteration from now
+    MF_LAP(3);
     lds_barrier();  // zs
-    MF_LAP(1);
-    // t_i = u_i - Jp_i z in place
-    double z0[DP];  // of the single slice (tail rows)
-#pragma unroll
-    for (int a = 0; a < DP; ++a) z0[a] = zs[0][a][lane];
+    MF_LAP(4);
+    // t_i = u_i - Jp_i z, v_i = A_i^T t_i into LDS in the unit's view order
 #pragma unroll
     for (int rr = 0; rr < RR; ++rr) {
-      const int R = w + rr * kWaves;
-      const int g = packed ? min(R / K, G - 1) : 0;
+      const int g = lsh ? 0 : min((w + rr * kWaves) / K, G - 1);
 #pragma unroll
       for (int a = 0; a < DP; ++a) {
         const double za = zs[g][a][lane];
         uu[rr][0] -= jr[rr][a].x * za;
         uu[rr][1] -= jr[rr][a].y * za;
       }
+      if (pos[rr] >= 0) {
+        double* dst = &vbuf[pos[rr] * D];
+#pragma unroll
+        for (int a = 0; a < D; ++a) dst[a] = ar[rr][a].x * uu[rr][0] + ar[rr][a].y * uu[rr][1];
+      }
     }
-    // v_i = A_i^T t_i into LDS in view order, VB at a time; a thread per run sums its (consecutive) entries
-    const int nv = o1 - o0;
-    for (int pb = 0; pb < nv; pb += VB) {
+    MF_LAP(5);
+    lds_barrier();  // vbuf
+    MF_LAP(6);
+    // a thread per run sums its (consecutive) entries
+    auto put_sum = [&](const double (&sum)[D], int slot) {
+      if (direct) {
+        double* dst = m.partial + (size_t)slot * D;
 #pragma unroll
-      for (int rr = 0; rr < RR; ++rr) {
-        const int p = pos[rr] - pb;
-        if (pos[rr] >= 0 && p >= 0 && p < VB) {
-          double* dst = &vbuf[p * D];
+        for (int a = 0; a < D; ++a) dst[a] = sum[a];
+      } else {
+        double* dst = &acc[(slot - slot0) * D];  // one run per view and unit: nobody else adds here
 #pragma unroll
-          for (int a = 0; a < D; ++a) dst[a] = ar[rr][a].x * uu[rr][0] + ar[rr][a].y * uu[rr][1];
-        }
+        for (int a = 0; a < D; ++a) dst[a] += sum[a];
       }
-      if (!packed) {
-#pragma unroll 1
-        for (int j = w + J1; j < rows; j += kWaves) {
-          const size_t e = (size_t)sp0 + 64 * j + lane;
-          const int p = m.obs_pos[e] - pb;
-          const int rb = v.obs_rb[e];
-          if (p < 0 || p >= VB || rb < 0) continue;
-          const double* ap = v.pm_A + (tile0 + j) * ROWD + 2 * lane;
-          const double* jp = v.pm_Jp + (tile0 + j) * ROWP + 2 * lane;
-          const double* xc = x + (size_t)rb * D;
-          double2 aa[D];
-          double t0 = 0.0, t1 = 0.0;
-#pragma unroll
-          for (int a = 0; a < D; ++a) {
-            aa[a] = *reinterpret_cast<const double2*>(ap + a * 128);
-            const double xa = xc[a];
-            t0 += aa[a].x * xa;
-            t1 += aa[a].y * xa;
-          }
-#pragma unroll
-          for (int a = 0; a < DP; ++a) {
-            const double2 jj = *reinterpret_cast<const double2*>(jp + a * 128);
-            t0 -= jj.x * z0[a];
-            t1 -= jj.y * z0[a];
-          }
-          double* dst = &vbuf[p * D];
-#pragma unroll
-          for (int a = 0; a < D; ++a) dst[a] = aa[a].x * t0 + aa[a].y * t1;
-        }
+    };
+    auto take_run = [&](int first, int last, int slot) {
+      const int b = first - o0, e = last - o0;
+      if (e - b > kLongRun) {
+        // a long run (the tracks of a slice share their lowest view: 64 entries) would hold its wavefront for
+        // e - b dependent trips: a whole wavefront takes it after this loop
+        const int i = atomicAdd(&n_long, 1);
+        long_run[i] = make_int4(b, e, slot, 0);
+        return;
       }
-      lds_barrier();  // vbuf
-      MF_LAP(2);
-      auto put_sum = [&](const double (&sum)[D], int first, int slot) {
-        if (direct) {
-          double* dst = m.partial + (size_t)slot * D;
-          if (first - o0 >= pb) {
+      double sum[D];
 #pragma unroll
-            for (int a = 0; a < D; ++a) dst[a] = sum[a];
-          } else {  // the run began in the previous round (its first part is there already)
+      for (int a = 0; a < D; ++a) sum[a] = 0.0;
+      for (int p = b; p < e; ++p) {
 #pragma unroll
-            for (int a = 0; a < D; ++a) dst[a] += sum[a];
-          }
-        } else {
-          double* dst = &acc[(slot - slot0) * D];  // one run per view and unit: nobody else adds here
-#pragma unroll
-          for (int a = 0; a < D; ++a) dst[a] += sum[a];
-        }
-      };
-      auto take_run = [&](int first, int last, int slot) {
-        const int b = max(first - o0 - pb, 0), e = min(last - o0 - pb, VB);
-        if (b >= e) return;
-        if (e - b > kLongRun) {
-          // a long run (the tracks of a slice share their lowest view: 64 entries) would hold its wavefront for
-          // e - b dependent trips: a whole wavefront takes it after this loop
-          const int i = atomicAdd(&n_long, 1);
-          long_run[i] = make_int4(b, e, slot, first);
-          return;
-        }
-        double sum[D];
-#pragma unroll
-        for (int a = 0; a < D; ++a) sum[a] = 0.0;
-        for (int p = b; p < e; ++p) {
-#pragma unroll
-          for (int a = 0; a < D; ++a) sum[a] += vbuf[p * D + a];
-        }
-        put_sum(sum, first, slot);
-      };
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-        if (r0 + (int)threadIdx.x + q * kThreads < r1) take_run(ma[q], mb[q], ms[q]);
-      for (int r = r0 + (int)threadIdx.x + 2 * kThreads; r < r1; r += kThreads)
-        take_run(m.run_obs_ptr[r], m.run_obs_ptr[r + 1], m.run_slot[r]);
-      MF_LAP(3);
-      lds_barrier();  // the list of long runs
-      const int nl = n_long;
-      for (int i = w; i < nl; i += kWaves) {
-        const int4 lr = long_run[i];
-        double sum[D];
-#pragma unroll
-        for (int a = 0; a < D; ++a) sum[a] = 0.0;
-        for (int p = lr.x + lane; p < lr.y; p += 64) {
-#pragma unroll
-          for (int a = 0; a < D; ++a) sum[a] += vbuf[p * D + a];
-        }
-#pragma unroll
-        for (int a = 0; a < D; ++a) sum[a] = wave_sum(sum[a]);  // fixed butterfly: reproducible
-        if (lane == 0) put_sum(sum, lr.w, lr.z);
+        for (int a = 0; a < D; ++a) sum[a] += vbuf[p * D + a];
       }
-      lds_barrier();  // n_long is read, vbuf is free
-      MF_LAP(4);
-      if (threadIdx.x == 0) n_long = 0;
+      put_sum(sum, slot);
+    };
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (r0 + (int)threadIdx.x + q * kThreads < r1) take_run(ma[q], mb[q], ms[q]);
+    for (int r = r0 + (int)threadIdx.x + 2 * kThreads; r < r1; r += kThreads)
+      take_run(m.run_obs_ptr[r], m.run_obs_ptr[r + 1], m.run_slot[r]);
+    MF_LAP(7);
+    lds_barrier();  // the list of long runs
+    const int nl = n_long;
+    for (int i = w; i < nl; i += kWaves) {
+      const int4 lr = long_run[i];
+      double sum[D];
+#pragma unroll
+      for (int a = 0; a < D; ++a) sum[a] = 0.0;
+      for (int p = lr.x + lane; p < lr.y; p += 64) {
+#pragma unroll
+        for (int a = 0; a < D; ++a) sum[a] += vbuf[p * D + a];
+      }
+#pragma unroll
+      for (int a = 0; a < D; ++a) sum[a] = wave_sum(sum[a]);  // fixed butterfly: reproducible
+      if (lane == 0) put_sum(sum, lr.z);
     }
+    MF_LAP(8);
+    lds_barrier();  // n_long is read, vbuf is free
+    MF_LAP(9);
+    if (threadIdx.x == 0) n_long = 0;
     if (u + 1 < u1) load_runs(r1);  // consumed an iteration from now
     d0 = d1;
     d1 = d2;
@@ -670,15 +613,25 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
     o1 = o2;
   }
 #ifdef TMI_MF_PROFILE
+  const long long t_loop = clock64();
+#endif
+  if (!direct) {
+    __syncthreads();  // acc
+    double* out = m.partial + (size_t)slot0 * D;
+    for (int i = threadIdx.x; i < nlc * D; i += kThreads) out[i] = acc[i];
+  }
+#ifdef TMI_MF_PROFILE
   if (threadIdx.x == 0 && m.prof) {
-    for (int i = 0; i < 5; ++i) m.prof[(size_t)item * 8 + i] = tp[i];
-    m.prof[(size_t)item * 8 + 5] = u1 - u0;
+    long long in_loop = 0;
+    for (int i = 0; i < 10; ++i) {
+      m.prof[(size_t)item * 16 + i] = tp[i];
+      in_loop += tp[i];
+    }
+    m.prof[(size_t)item * 16 + 10] = u1 - u0;
+    m.prof[(size_t)item * 16 + 11] = tc - t_begin - in_loop;
+    m.prof[(size_t)item * 16 + 12] = clock64() - t_loop;
   }
 #endif
-  if (direct) return;
-  __syncthreads();  // acc
-  double* out = m.partial + (size_t)slot0 * D;
-  for (int i = threadIdx.x; i < nlc * D; i += kThreads) out[i] = acc[i];
 }
 
 // y = D_c x + the sum of every view's slots (ascending = item order) [+ x . y behind the vector]
