@@ -264,9 +264,6 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
   double (*wpart)[DP][64] = reinterpret_cast<double (*)[DP][64]>(vbuf);
   __shared__ double zs[kWaves][DP][64];
   __shared__ double acc[LCM * D];
-  __shared__ int4 long_run[VB / kLongRun + 2];
-  __shared__ int n_long;
-  if (threadIdx.x == 0) n_long = 0;
   const int item = blockIdx.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 
@@ -367,6 +364,7 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
   constexpr int J1 = RR * kWaves;  // row slots
   constexpr int NLI = sym_size(DP);
   static_assert(VB >= J1 * 64, "the v_i of a unit fit vbuf");
+  static_assert(J1 * 64 <= 2 * kThreads && kWaves == 4, "two runs per thread cover a unit");
 #ifdef TMI_MF_PROFILE
   const long long tc0 = clock64();
 #endif
@@ -412,7 +410,7 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
   auto load_runs = [&](int first) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const int r = min(first + (int)threadIdx.x + q * kThreads, m.n_runs - 1);
+      const int r = min(first + 4 * (lane + 64 * q) + w, m.n_runs - 1);
       ma[q] = m.run_obs_ptr[r];
       mb[q] = m.run_obs_ptr[r + 1];
       ms[q] = m.run_slot[r];
@@ -499,15 +497,34 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
     MF_LAP(2);
     if (w < G) {
       // slice w of a pack: its rows are the slots [w K, w K + K); a cut slice: every slot, the L lanes of the track
-      const int s_lo = lsh ? 0 : w * K, s_hi = lsh ? J1 : w * K + K;
       double wt[DP], zh[DP];
 #pragma unroll
       for (int a = 0; a < DP; ++a) wt[a] = 0.0;
-      for (int sl = s_lo; sl < s_hi; ++sl)
-        for (int q = t; q < 64; q += nt) {
+      if (lsh == 0) {
+        // every slot is read (independent LDS loads), the slots of slice w are added, in slot order
+        const int s_lo = w * K, s_hi = w * K + K;
+        double wp[J1][DP];
 #pragma unroll
-          for (int a = 0; a < DP; ++a) wt[a] += wpart[sl][a][q];
+        for (int sl = 0; sl < J1; ++sl)
+#pragma unroll
+          for (int a = 0; a < DP; ++a) wp[sl][a] = wpart[sl][a][lane];
+#pragma unroll
+        for (int sl = 0; sl < J1; ++sl)
+#pragma unroll
+          for (int a = 0; a < DP; ++a) wt[a] += (sl >= s_lo && sl < s_hi) ? wp[sl][a] : 0.0;
+      } else {
+        for (int q = t; q < 64; q += nt) {
+          double wp[J1][DP];
+#pragma unroll
+          for (int sl = 0; sl < J1; ++sl)
+#pragma unroll
+            for (int a = 0; a < DP; ++a) wp[sl][a] = wpart[sl][a][q];
+#pragma unroll
+          for (int sl = 0; sl < J1; ++sl)
+#pragma unroll
+            for (int a = 0; a < DP; ++a) wt[a] += wp[sl][a];
         }
+      }
       // z = L^-T (L^-1 w)   (Linv planes: sym_idx(a, b), a <= b, holds L^-1(b, a))
 #pragma unroll
       for (int bb = 0; bb < DP; ++bb) {
@@ -547,7 +564,12 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
     MF_LAP(5);
     lds_barrier();  // vbuf
     MF_LAP(6);
-    // a thread per run sums its (consecutive) entries
+    // The unit's runs (at most 2 kThreads: one per observation at worst): run r0 + 4 i + w belongs to thread i of
+    // wavefront w -- consecutive runs are consecutive views, and the views many tracks share (long runs) come in
+    // clusters, so dealing them round keeps the wavefronts even.  A thread sums its run's (consecutive) entries; a run
+    // of more than kLongRun entries (the tracks of a slice share their lowest view: 64) would hold its wavefront for
+    // as many dependent trips, so the wavefront takes those together afterwards: lane g D + a sums component a of
+    // the entries g, g + 64 / D, ..; the partial sums are added in g order.  Fixed orders, no atomics.
     auto put_sum = [&](const double (&sum)[D], int slot) {
       if (direct) {
         double* dst = m.partial + (size_t)slot * D;
@@ -559,49 +581,51 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
         for (int a = 0; a < D; ++a) dst[a] += sum[a];
       }
     };
-    auto take_run = [&](int first, int last, int slot) {
-      const int b = first - o0, e = last - o0;
-      if (e - b > kLongRun) {
-        // a long run (the tracks of a slice share their lowest view: 64 entries) would hold its wavefront for
-        // e - b dependent trips: a whole wavefront takes it after this loop
-        const int i = atomicAdd(&n_long, 1);
-        long_run[i] = make_int4(b, e, slot, 0);
-        return;
+    unsigned long long is_long[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const bool mine = r0 + 4 * (lane + 64 * q) + w < r1;
+      const int b = ma[q] - o0, e = mb[q] - o0;
+      is_long[q] = __ballot(mine && e - b > kLongRun);
+      if (mine && e - b <= kLongRun) {
+        double sum[D];
+#pragma unroll
+        for (int a = 0; a < D; ++a) sum[a] = 0.0;
+        for (int p = b; p < e; ++p) {
+#pragma unroll
+          for (int a = 0; a < D; ++a) sum[a] += vbuf[p * D + a];
+        }
+        put_sum(sum, ms[q]);
       }
-      double sum[D];
-#pragma unroll
-      for (int a = 0; a < D; ++a) sum[a] = 0.0;
-      for (int p = b; p < e; ++p) {
-#pragma unroll
-        for (int a = 0; a < D; ++a) sum[a] += vbuf[p * D + a];
-      }
-      put_sum(sum, slot);
-    };
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-      if (r0 + (int)threadIdx.x + q * kThreads < r1) take_run(ma[q], mb[q], ms[q]);
-    for (int r = r0 + (int)threadIdx.x + 2 * kThreads; r < r1; r += kThreads)
-      take_run(m.run_obs_ptr[r], m.run_obs_ptr[r + 1], m.run_slot[r]);
+    }
     MF_LAP(7);
-    lds_barrier();  // the list of long runs
-    const int nl = n_long;
-    for (int i = w; i < nl; i += kWaves) {
-      const int4 lr = long_run[i];
-      double sum[D];
+    {
+      constexpr int NG = 64 / D;  // entry groups
+      const int g = lane / D, a = lane - g * D;
 #pragma unroll
-      for (int a = 0; a < D; ++a) sum[a] = 0.0;
-      for (int p = lr.x + lane; p < lr.y; p += 64) {
+      for (int q = 0; q < 2; ++q) {
+        unsigned long long todo = is_long[q];
+        while (todo) {
+          const int i = __builtin_ctzll(todo);
+          todo &= todo - 1;
+          const int b = __builtin_amdgcn_readlane(ma[q], i) - o0, e = __builtin_amdgcn_readlane(mb[q], i) - o0;
+          const int slot = __builtin_amdgcn_readlane(ms[q], i);
+          double part = 0.0;
+          if (g < NG)
+            for (int p = b + g; p < e; p += NG) part += vbuf[p * D + a];
+          double tot = part;  // (lanes a < D: group 0's partial)
 #pragma unroll
-        for (int a = 0; a < D; ++a) sum[a] += vbuf[p * D + a];
+          for (int gg = 1; gg < NG; ++gg) tot += __shfl(part, gg * D + a);
+          if (lane < D) {
+            if (direct) m.partial[(size_t)slot * D + a] = tot;
+            else acc[(slot - slot0) * D + a] += tot;
+          }
+        }
       }
-#pragma unroll
-      for (int a = 0; a < D; ++a) sum[a] = wave_sum(sum[a]);  // fixed butterfly: reproducible
-      if (lane == 0) put_sum(sum, lr.z);
     }
     MF_LAP(8);
-    lds_barrier();  // n_long is read, vbuf is free
+    lds_barrier();  // vbuf is free (wpart shares its memory)
     MF_LAP(9);
-    if (threadIdx.x == 0) n_long = 0;
     if (u + 1 < u1) load_runs(r1);  // consumed an iteration from now
     d0 = d1;
     d1 = d2;
