@@ -372,7 +372,7 @@ def main():
         # beside the contract's figure, under its own key: what a matrix-free product has to read in this layout
         lf = matrix_free_layout_floor(n_obs // world, n_cam, n_pts // world, dc, dp)
         e1 = os.environ.get("TMI_BA_MF_ONE_SWEEP")
-        one_sweep = (e1 != "0") and (e1 is not None or n_obs // world >= 1000000)  # engine.hip build_mf_chunks
+        one_sweep = (e1 != "0") and (e1 is not None or n_obs // world >= 500000)  # engine.hip build_mf_chunks
         roofline["kernel"] = ("spmv (one product q = S p; matrix-free in %d of %d timed LM iterations: %s)"
                               % (m["matrix_free"], steps_run,
                                  "mfc::product_kernel + mfc::reduce_kernel, the one-sweep product of mf_chunks.h" if one_sweep

@@ -1174,15 +1174,14 @@ static int build_mf_chunks(tmi_ba_solver* s) {
   using namespace tmi::mfc;
   s->mf_ok = false;
   int rc_early = TMI_BA_OK;
-  // Which product: measured on MI355X (profiles/r04_one_sweep_experiment.md, same-box pairs on venice1778_heavy) the
-  // one-sweep product takes 4-13 % off the LM iteration when a rank holds the whole problem, a half or a quarter of it
-  // (3.80 / 2.20 / 1.24 ms against 4.00 / 2.35 / 1.42) and loses 5 % on an eighth (0.81 against 0.77 ms: 625 k
-  // observations are ~500 work items of ~40 us each, a single round, and the 16- / 64-lane units take ~100 us whatever
-  // the shard).  So: the one-sweep product from a million observations per rank, the two-pass product below;
-  // TMI_BA_MF_ONE_SWEEP=1 / =0 forces either (tests, A/B).
+  // Which product: measured on MI355X (profiles/r04_one_sweep_experiment.md, same-box pairs on venice1778_heavy, ms per
+  // LM iteration, two-pass / one-sweep) a rank that holds the whole problem, a half, a quarter, an eighth of it takes
+  // 3.93 / 3.27, 2.33 / 1.91, 1.41 / 1.23, 0.77 / 0.72.  An eighth is 625 k observations -- ~500 work items, a single
+  // round -- and nothing smaller has been measured, so: the one-sweep product from half a million observations per
+  // rank, the two-pass product below; TMI_BA_MF_ONE_SWEEP=1 / =0 forces either (tests, A/B).
   {
     const char* e = getenv("TMI_BA_MF_ONE_SWEEP");
-    const bool want = e ? atoi(e) != 0 : s->st.No >= 1000000;
+    const bool want = e ? atoi(e) != 0 : s->st.No >= 500000;
     if (!want) return TMI_BA_OK;
   }
   Structure& st = s->st;
@@ -1190,16 +1189,21 @@ static int build_mf_chunks(tmi_ba_solver* s) {
   hipStream_t stream = s->stream;
   if (st.has_shared || st.Nrb == 0 || st.No_pad == 0 || st.nslices == 0) return TMI_BA_OK;
   const int Nrb = st.Nrb, D = st.D;
-  const int nub = 16 * st.n_ultra, nwb = nub + 4 * (st.n_wide - st.n_ultra);
-  const int n_narrow = st.nslices - st.n_wide;
   auto rows_of = [&](int sl) { return (st.slice_ptr[sl + 1] - st.slice_ptr[sl]) >> 6; };
-  if (n_narrow > 0 && rows_of(st.n_wide) > kMaxNarrowK) return TMI_BA_OK;
+  // slices (descending length) with more rows than 64 lanes per track can hold in the row slots: a wavefront per
+  // track, four tracks a unit (they are among the `ultra` slices of track_map); every other slice is a narrow unit
+  // or is cut into narrow units
+  const int max_rows = 64 * kWaves * reg_rows(D);
+  int n_old = 0;
+  while (n_old < st.nslices && rows_of(n_old) > max_rows) ++n_old;
+  if (n_old > st.n_ultra) return TMI_BA_OK;  // (cannot happen: kUltraK <= max_rows)
+  const int nub = 16 * n_old, nwb = nub;
   // narrow units: a slice, or a pack of consecutive slices of the same (small) length whose rows together fill the
   // kWaves * reg_rows(D) row slots of the kernel
   std::vector<int4> unit_desc;  // {first element, rows, rows of one slice | log2 L << 16, first slice}
   {
     const int slots = kWaves * reg_rows(D);
-    for (int sl = st.n_wide; sl < st.nslices;) {
+    for (int sl = n_old; sl < st.nslices;) {
       const int K = rows_of(sl);
       if (K > slots) {
         // a long slice: L pieces of 64 / L tracks, L lanes per track (mf_chunks.h)
@@ -1311,7 +1315,7 @@ static int build_mf_chunks(tmi_ba_solver* s) {
   TMI_HIP(tmp.get(&d_slot_rb, (size_t)n_runs));
   TMI_HIP(tmp.get(&d_slot_key, (size_t)n_runs));
   TMI_HIP(tmp.get(&d_item_slot_ptr, (size_t)n_units + 1));
-  const long long narrow_elems = (long long)st.slice_ptr[st.nslices] - st.slice_ptr[st.n_wide];
+  const long long narrow_elems = (long long)st.slice_ptr[st.nslices] - st.slice_ptr[n_old];
   long long target = std::max<long long>(64, std::min<long long>(4096, narrow_elems / std::max(1, 4 * s->num_cus)));
   if (const char* e = getenv("TMI_BA_MF_ITEM")) target = std::max(64, atoi(e));  // A/B: elements per item
   // narrow items as unit ranges: about `target` elements each, cut where the slice length changes
@@ -1425,7 +1429,7 @@ static int build_mf_chunks(tmi_ba_solver* s) {
 #undef MF_EXCLUSIVE_SUM
   double *p_partial, *p_ut;
   if ((rc = dev_alloc(s, &p_partial, (size_t)n_slots * D))) return rc;
-  if ((rc = dev_alloc(s, &p_ut, (size_t)2 * std::max(st.slice_ptr[st.n_wide], 1)))) return rc;
+  if ((rc = dev_alloc(s, &p_ut, (size_t)2 * std::max(st.slice_ptr[n_old], 1)))) return rc;
   m.unit_desc = d_unit_desc;
   m.item_unit0 = p_item_unit0;
   m.unit_run_ptr = p_unit_run_ptr;

@@ -33,7 +33,6 @@ namespace mfc {
 
 constexpr int kWaves = 4;  // two workgroups per CU (<= 80 KB of LDS each), two wavefronts per SIMD
 constexpr int kThreads = 64 * kWaves;
-constexpr int kMaxNarrowK = 20;               // longest thread-per-track slice (kWideKLarge)
 constexpr int kLongRun = 12;                  // a run with more entries than this is summed by a whole wavefront
 // row slots of a workgroup: kWaves * reg_rows(D); a row slot keeps A, Jp and u of its rows in registers until the
 // track's z is known (see the narrow path of product_kernel for what a unit puts into them)
@@ -362,7 +361,7 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
   //   * a slice of at most that many rows, or a PACK of 2-4 consecutive slices of <= 4 rows (59 % of the slices of the
   //     bench problem): their tiles are consecutive in memory, so a pack is walked like one slice of G K rows whose
   //     row R belongs to the tracks of slice R / K; lane = track, a row slot holds one row;
-  //   * a longer slice (up to kMaxNarrowK rows) is cut into L = 2, 4, .. units of 64 / L tracks: L lanes per track,
+  //   * a longer slice (up to 64 times the row slots) is cut into L = 2, 4, .. 64 units of 64 / L tracks: L lanes per track,
   //     lane = sub * (64 / L) + track, a row slot holds the L rows slot * L + sub.  (Before: the rows beyond the row
   //     slots were demand loads in dependent trips, twice per unit -- 29 % of the observations sit in such slices and
   //     their units took 45 % of the kernel's time.)
@@ -501,8 +500,16 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
       }
       uu[rr][0] = s0;
       uu[rr][1] = s1;
+      double wv[DP];
 #pragma unroll
-      for (int a = 0; a < DP; ++a) wpart[w + rr * kWaves][a][lane] = jr[rr][a].x * s0 + jr[rr][a].y * s1;
+      for (int a = 0; a < DP; ++a) wv[a] = jr[rr][a].x * s0 + jr[rr][a].y * s1;
+      // a cut slice: the L lanes of a track add their rows (a fixed butterfly; every lane ends with the sum)
+      for (int mk = nt; mk < 64; mk <<= 1) {
+#pragma unroll
+        for (int a = 0; a < DP; ++a) wv[a] += __shfl_xor(wv[a], mk, 64);
+      }
+#pragma unroll
+      for (int a = 0; a < DP; ++a) wpart[w + rr * kWaves][a][lane] = wv[a];
     }
     MF_LAP(1);
     lds_barrier();  // wpart (and: the previous unit's run sums have left vbuf, which wpart shares its memory with)
@@ -512,9 +519,10 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
       double wt[DP], zh[DP];
 #pragma unroll
       for (int a = 0; a < DP; ++a) wt[a] = 0.0;
-      if (lsh == 0) {
-        // every slot is read (independent LDS loads), the slots of slice w are added, in slot order
-        const int s_lo = w * K, s_hi = w * K + K;
+      {
+        // every slot is read (independent LDS loads); the slots of slice w of a pack -- of a cut slice: all of them --
+        // are added, in slot order
+        const int s_lo = lsh ? 0 : w * K, s_hi = lsh ? J1 : w * K + K;
         double wp[J1][DP];
 #pragma unroll
         for (int sl = 0; sl < J1; ++sl)
@@ -524,18 +532,6 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
         for (int sl = 0; sl < J1; ++sl)
 #pragma unroll
           for (int a = 0; a < DP; ++a) wt[a] += (sl >= s_lo && sl < s_hi) ? wp[sl][a] : 0.0;
-      } else {
-        for (int q = t; q < 64; q += nt) {
-          double wp[J1][DP];
-#pragma unroll
-          for (int sl = 0; sl < J1; ++sl)
-#pragma unroll
-            for (int a = 0; a < DP; ++a) wp[sl][a] = wpart[sl][a][q];
-#pragma unroll
-          for (int sl = 0; sl < J1; ++sl)
-#pragma unroll
-            for (int a = 0; a < DP; ++a) wt[a] += wp[sl][a];
-        }
       }
       // z = L^-T (L^-1 w)   (Linv planes: sym_idx(a, b), a <= b, holds L^-1(b, a))
 #pragma unroll
