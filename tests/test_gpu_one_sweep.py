@@ -1,9 +1,10 @@
 """-m gpu: the one-sweep matrix-free product (theiasfm_amd/csrc/mf_chunks.h, opt-in through TMI_BA_MF_ONE_SWEEP) against
 the two-pass product it is meant to replace and against the oracle: same operator q = S p (Ceres'
 ImplicitSchurComplement behind ceres::Solve, bundle_adjuster.cc:205), so identical PCG / LM iteration counts and
-results to round-off, over the shapes its work items take -- thread-per-track slices of every length up to the wide
-threshold (register rows and tail rows), 16- and 64-lane tracks (heavy tail), items of one slice and of several,
-constant cameras / tracks, block sizes 6 / 9 / 12 and both point parameterisations."""
+results to round-off, over the shapes its work items take -- packs of short slices, whole slices, slices cut into 2 .. 64
+pieces (heavy tail: up to 400 views per track), tracks of more views than the row slots hold (a wavefront per track),
+items of one unit and of several, constant cameras / tracks, block sizes 6 / 9 / 16 and both point
+parameterisations."""
 import os
 
 import numpy as np
@@ -29,6 +30,24 @@ def solve(prob, one_sweep, **kw):
             os.environ["TMI_BA_MF_ONE_SWEEP"] = old
 
 
+def with_landmarks(prob, n_long, seed):
+    """+ n_long tracks near the middle of the scene that EVERY view sees (observed where the problem's current
+    parameters project them, half a pixel of noise): longer than any row-slot arrangement holds when there are more
+    than 512 views (256 for the 16-wide blocks), i.e. the wavefront-per-track units of mf_chunks.h"""
+    rng = np.random.default_rng(seed)
+    nc, np0, no0 = prob.num_cameras, prob.num_points, prob.num_observations
+    centre = (prob.points[:, :3] / prob.points[:, 3:4]).mean(0)
+    X = np.concatenate([centre + 0.02 * np.abs(centre).max() * rng.standard_normal((n_long, 3)), np.ones((n_long, 1))], 1)
+    prob.points = np.ascontiguousarray(np.concatenate([prob.points, X]))
+    prob.point_constant = np.concatenate([prob.point_constant, np.zeros(n_long, np.uint8)])
+    prob.obs_camera = np.concatenate([prob.obs_camera, np.tile(np.arange(nc, dtype=np.int32), n_long)])
+    prob.obs_point = np.concatenate([prob.obs_point, np.repeat(np.arange(np0, np0 + n_long, dtype=np.int32), nc)])
+    prob.obs_xy = np.ascontiguousarray(np.concatenate([prob.obs_xy, np.zeros((n_long * nc, 2))]))
+    new = np.arange(no0, no0 + n_long * nc)
+    prob.obs_xy[new] = synth.project(prob, new) + 0.5 * rng.standard_normal((new.size, 2))
+    return prob
+
+
 CASES = {
     "ladybug49": lambda: (synth.config("ladybug49"), dict(point_dof=3)),
     "dof4": lambda: (synth.make_problem(40, 6000, 30000, seed=5, scene="ring", spread=0.5), dict(point_dof=4)),
@@ -38,6 +57,14 @@ CASES = {
     "d6_huber": lambda: (synth.make_problem(60, 9000, 50000, seed=9, scene="ring", spread=0.4, intrinsics_to_optimize=abi.INTRINSICS_NONE),
                          dict(point_dof=3, loss_function_type=abi.LOSS_HUBER, robust_loss_width=2.0)),
     # radial-tangential cameras with every intrinsic free but skew / aspect ratio: D = 6 + 8 -> 16
+    # 560 views, six tracks that all of them see (+ the 24-400 view tail): more rows than 64 lanes per track hold
+    "landmarks": lambda: (with_landmarks(synth.make_problem(560, 12000, 70000, seed=13, scene="ring", spread=0.5, heavy_tail=0.01), 6, 14),
+                          dict(point_dof=3)),
+    # 16-wide blocks keep one row per wavefront in registers: the same beyond 256 views
+    "d16_landmarks": lambda: (with_landmarks(synth.make_problem(300, 6000, 36000, seed=15, scene="ring", spread=0.5,
+                                                                models=[(abi.PINHOLE_RADIAL_TANGENTIAL, 1.0)],
+                                                                intrinsics_to_optimize=abi.INTRINSICS_ALL & ~(abi.INTRINSICS_SKEW | abi.INTRINSICS_ASPECT_RATIO)), 5, 16),
+                              dict(point_dof=3)),
     "d16": lambda: (synth.make_problem(30, 4000, 22000, seed=11, scene="ring", spread=0.5, models=[(abi.PINHOLE_RADIAL_TANGENTIAL, 1.0)],
                                        intrinsics_to_optimize=abi.INTRINSICS_ALL & ~(abi.INTRINSICS_SKEW | abi.INTRINSICS_ASPECT_RATIO)),
                     dict(point_dof=4)),
