@@ -101,6 +101,16 @@ struct DeviceView {
   // work arrays
   double* pm_r;
   double* pm_A;
+  // drop_pos (round 4): the three POSITION columns of the camera block are not stored in pm_A (its planes 0..5 are
+  // holes nobody touches).  With every block's position free and no constant point they are, column by column,
+  //   A_pos[a] = -w Jp[a] scale_c[a] / scale_p[a]   (reprojection_error.h: d r / d C = -w d r / d X; the loss
+  // corrector is the same linear map on both), so the consumers form them from the Jp planes they read anyway:
+  // pos_coef[a][track] = -w / scale_p[a] (pos_coef_kernel, after every linearize), the view's scale_c[a] is folded
+  // into the vector a product gathers (xs, pos_scale_kernel) and into the reduce launch.  48 of the 208 plane bytes
+  // per observation less for linearize, point_eliminate, back_substitute and every matrix-free product.
+  int drop_pos;
+  double* pos_coef;  // [3][Np_pad]
+  double* xs;        // [Nrb D] the vector of the running product / back-substitution, position entries times scale_c
   double* pm_Jp;
   double* pm_A1;    // [2 D][No_pad] shared-intrinsics Jacobian columns (has_shared only)
   double* cam_part; // [Ncam_rb][2 D^2 + 3 D] per-view sums for the shared blocks

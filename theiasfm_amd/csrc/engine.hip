@@ -85,6 +85,7 @@ struct Launch {
   void (*pcg_a)(const DeviceView&, hipStream_t, int, int);
   void (*pcg_b2)(const DeviceView&, hipStream_t, const double*, int, int, double*);
   void (*back_substitute)(const DeviceView&, hipStream_t, int, double*, double* sums);
+  void (*pos_coef)(const DeviceView&, hipStream_t, const double* pts);  // drop_pos: after every linearize
   void (*update_points)(const DeviceView&, hipStream_t, int, double*, double* sums);
   void (*update_cameras)(const DeviceView&, hipStream_t, double* out, double* prep_c);
   void (*pcg_init)(const DeviceView&, hipStream_t, const double* b, int nb);
@@ -198,7 +199,16 @@ Launch make_launch(bool fp32) {
   L.mf_product = [](const DeviceView& v, const mfc::View& m, hipStream_t st, RedLayout R, const double* x, double* y,
                     double ir, double lo, double hi, int add_diag, int dot) {
     if (!v.Nrb) return;
-    if (m.n_items) hipLaunchKernelGGL((mfc::product_kernel<D, DP>), dim3(m.n_items), dim3(mfc::kThreads), 0, st, v, m, x);
+    if (v.drop_pos) {
+      // the position columns of the planes are formed from Jp (device_view.h): the product gathers x with the
+      // position entries times the views' column scales, the reduce launch scales the position entries of the sums
+      const int n = v.Nrb * D;
+      hipLaunchKernelGGL((pos_scale_kernel<D>), dim3((n + 255) / 256), dim3(256), 0, st, v, x, v.xs);
+      if (m.n_items)
+        hipLaunchKernelGGL((mfc::product_kernel<D, DP, true>), dim3(m.n_items), dim3(mfc::kThreads), 0, st, v, m, v.xs);
+    } else if (m.n_items) {
+      hipLaunchKernelGGL((mfc::product_kernel<D, DP, false>), dim3(m.n_items), dim3(mfc::kThreads), 0, st, v, m, x);
+    }
     hipLaunchKernelGGL((mfc::reduce_kernel<D>), dim3(8 * ((v.Nrb + 7) / 8)), dim3(256), 0, st, v, m, R, x, y, ir, lo, hi,
                        add_diag, dot);
   };
@@ -209,7 +219,15 @@ Launch make_launch(bool fp32) {
     hipLaunchKernelGGL((pcg_b2_kernel<D>), dim3(nb), dim3(256), 0, st, v, b, mode, nb, partial);
   };
   L.back_substitute = [](const DeviceView& v, hipStream_t st, int nb, double* partial, double* sums) {
+    if (!SH && v.drop_pos && v.Nrb) {
+      const int n = v.Nrb * D;
+      hipLaunchKernelGGL((pos_scale_kernel<D>), dim3((n + 255) / 256), dim3(256), 0, st, v, v.yc, v.xs);
+    }
     hipLaunchKernelGGL((back_substitute_kernel<D, DP, SH>), dim3(nb), dim3(256), 0, st, v, nb, partial, sums);
+  };
+  L.pos_coef = [](const DeviceView& v, hipStream_t st, const double* pts) {
+    if (v.drop_pos && v.Np_pad)
+      hipLaunchKernelGGL((pos_coef_kernel<DP>), dim3((v.Np_pad + 255) / 256), dim3(256), 0, st, v, pts);
   };
   L.update_points = [](const DeviceView& v, hipStream_t st, int nb, double* partial, double* sums) {
     hipLaunchKernelGGL((update_points_kernel<DP>), dim3(nb), dim3(256), 0, st, v, nb, partial, sums);
@@ -1455,7 +1473,7 @@ static int build_mf_chunks(tmi_ba_solver* s) {
   s->mf_ok = true;
   if (getenv("TMI_BA_SETUP_TIMING")) {
     int occ = -1;
-    if (D == 9 && s->DP == 3) hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, mfc::product_kernel<9, 3>, mfc::kThreads, 0);
+    if (D == 9 && s->DP == 3) hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, mfc::product_kernel<9, 3, false>, mfc::kThreads, 0);
     fprintf(stderr, "[tmi_ba setup] one-sweep product: %d units, %d items, %d runs, %d slots (%.1f MB of partials), "
                     "%d workgroups per CU\n", n_units, n_items, n_runs, n_slots, 8e-6 * n_slots * D, occ);
   }
@@ -1920,6 +1938,27 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
     rc = build_mf_chunks(s);
     if (rc) return rc;
   }
+  // drop_pos (device_view.h): the position columns of the A planes formed from Jp instead of stored.  Only where the
+  // identity holds for every observation and every reader of the planes knows it: the one-sweep product is in use (the
+  // two-pass kernels read stored columns), fp64 evaluation (fp32 rounds -w M and M separately), every camera block has
+  // its position free (then its first three columns are the position) and no point is constant (its Jp is stored as
+  // zero).  TMI_BA_DROP_POS=0 keeps the columns (A/B, tests).
+  v.drop_pos = 0;
+  if (s->mf_ok && !st.has_shared && O->residual_precision != 32 && D >= 3 && s->DP >= 3) {
+    const char* e = getenv("TMI_BA_DROP_POS");
+    bool ok = !(e && atoi(e) == 0);
+    for (int rb = 0; rb < st.Nrb && ok; ++rb) {
+      const int c = st.rb_cam[rb];
+      ok = c >= 0 && (st.cam_mask[c] & 7u) == 7u;
+    }
+    for (int lp = 0; lp < st.Np_pad && ok; ++lp) ok = st.pt_const[lp] == 0;
+    if (ok) {
+      if ((rc = dev_alloc(s, &v.pos_coef, (size_t)3 * std::max(st.Np_pad, 1)))) return rc;
+      if ((rc = dev_alloc(s, &v.xs, (size_t)std::max(st.Nrb, 1) * D + 8))) return rc;
+      v.drop_pos = 1;
+    }
+  }
+  if (setup_timing) fprintf(stderr, "[tmi_ba setup] position columns of the A planes: %s\n", v.drop_pos ? "formed from Jp" : "stored");
   if (s->vis_clusters && (rc = build_visibility_clusters(s, P, O->visibility_clustering_type))) return rc;
   if (s->need_slot_track && !s->mf_ok) {
     int* stt;
@@ -2709,6 +2748,7 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
     // cost and sum of squares land in d_sc[0..1] (finished by the kernel's last workgroup)
     Timed t(s, TMI_BA_K_LINEARIZE);
     s->launch.linearize(v, stream, v.prep, lt, lw, nbs, d_sc);
+    s->launch.pos_coef(v, stream, v.pts);  // (drop_pos: -w / scale_p of the point and the scales the planes were taken at)
   };
   linearize();
   // d_sc[0] = cost, d_sc[1] = ss, d_sc[2] = #ranks with an invalid residual
@@ -3859,7 +3899,11 @@ int32_t tmi_ba_solver_evaluate(tmi_ba_solver* s, double* residuals, double* jac_
   prepare_cameras(s, v.ext, v.intr, v.prep);
   hipLaunchKernelGGL(fill_kernel, dim3((unsigned)(((long long)st.Np_pad * DP + 255) / 256 + 1)), dim3(256), 0, stream, v.scale_p, (long long)st.Np_pad * DP, 1.0);
   // poison the residual planes so that invalid observations can be told apart
-  s->launch.linearize(v, stream, v.prep, 0, 1.0, s->nblocks_tracks, nullptr);
+  {
+    DeviceView ve = v;  // (the caller gets every column: stored, not formed from Jp)
+    ve.drop_pos = 0;
+    s->launch.linearize(ve, stream, v.prep, 0, 1.0, s->nblocks_tracks, nullptr);
+  }
   const size_t N = (size_t)st.No_pad;
   std::vector<double> r(residuals ? 2 * N : 0), A(jac_camera ? (size_t)2 * D * N : 0),
       Jp(jac_point ? (size_t)2 * DP * N : 0);

@@ -536,8 +536,10 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
           j0 = sqrt_rho1 * (j0 - asn * r[0] * rtj);
           j1 = sqrt_rho1 * (j1 - asn * r[1] * rtj);
         }
-        __builtin_nontemporal_store(j0 * scl, &v.pm_A[pidx<2 * D>((2 * dst), e)]);
-        __builtin_nontemporal_store(j1 * scl, &v.pm_A[pidx<2 * D>((2 * dst + 1), e)]);
+        if (!(c < 3 && !SH && v.drop_pos)) {  // (drop_pos: the position columns are not stored, device_view.h)
+          __builtin_nontemporal_store(j0 * scl, &v.pm_A[pidx<2 * D>((2 * dst), e)]);
+          __builtin_nontemporal_store(j1 * scl, &v.pm_A[pidx<2 * D>((2 * dst + 1), e)]);
+        }
         ++dst;
       }
     }
@@ -585,6 +587,24 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
     __builtin_nontemporal_store(r[1] * rscale, &v.pm_r[pidx<2>(1, e)]);
   }
   block_sum_finish<2>(acc, v.partial, nblocks, v.ticket + 2 * kTicketStride, sums);
+}
+
+// drop_pos (device_view.h): pos_coef[a][track] = -w / scale_p[a] at the point the planes were linearized at
+template <int DP>
+__global__ __launch_bounds__(256) void pos_coef_kernel(DeviceView v, const double* __restrict__ pts) {
+  const int lp = blockIdx.x * 256 + threadIdx.x;
+  if (lp >= v.Np_pad) return;
+  const double w = pts[(size_t)lp * 4 + 3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) v.pos_coef[(size_t)a * v.Np_pad + lp] = -w / v.scale_p[(size_t)lp * DP + a];
+}
+// ... and xs = x with the position entries of every view block times the block's column scales
+template <int D>
+__global__ __launch_bounds__(256) void pos_scale_kernel(DeviceView v, const double* __restrict__ x, double* __restrict__ xs) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= v.Nrb * D) return;
+  const int a = i % D;
+  xs[i] = a < 3 ? x[i] * v.scale_c[i] : x[i];
 }
 
 // cost only, at a prepared parameter set (kernel class 9): hot loop 1, residual-only.
@@ -878,9 +898,22 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
           Q0[b] = q0;
           Q1[b] = q1;
         }
+        double pc[3] = {0.0, 0.0, 0.0};
+        if (!SH && v.drop_pos) {
+          const int rb = v.obs_rb[e];
+#pragma unroll
+          for (int a = 0; a < 3; ++a) pc[a] = v.pos_coef[(size_t)a * NP + lp] * v.scale_c[(size_t)(rb < 0 ? 0 : rb) * D + a];
+        }
 #pragma unroll
         for (int a = 0; a < D; ++a) {
-          const double a0 = v.pm_A[pidx<2 * D>((2 * a), e)], a1 = v.pm_A[pidx<2 * D>((2 * a + 1), e)];
+          double a0, a1;
+          if (!SH && a < 3 && v.drop_pos) {  // the position columns are formed from Jp (device_view.h)
+            a0 = J0[a < DP ? a : 0] * pc[a < 3 ? a : 0];
+            a1 = J1[a < DP ? a : 0] * pc[a < 3 ? a : 0];
+          } else {
+            a0 = v.pm_A[pidx<2 * D>((2 * a), e)];
+            a1 = v.pm_A[pidx<2 * D>((2 * a + 1), e)];
+          }
           Av[a] = a0;
           Av[D + a] = a1;
 #pragma unroll
@@ -2737,12 +2770,29 @@ __global__ __launch_bounds__(256) void back_substitute_kernel(DeviceView v, int 
         const int cam = SH ? v.obs_cam[e] : 0;
         double u0 = 0.0, u1 = 0.0;
         if (rb >= 0) {
-          const double* yc = v.yc + (size_t)rb * D;
+          if (!SH && v.drop_pos) {
+            // the position columns from Jp (device_view.h); xs = y_c with the position entries times scale_c
+            const double* yc = v.xs + (size_t)rb * D;
 #pragma unroll
-          for (int a = 0; a < D; ++a) {
-            const double ya = yc[a];
-            u0 += v.pm_A[pidx<2 * D>((2 * a), e)] * ya;
-            u1 += v.pm_A[pidx<2 * D>((2 * a + 1), e)] * ya;
+            for (int a = 0; a < D; ++a) {
+              const double ya = yc[a];
+              if (a < 3) {
+                const double t = ya * v.pos_coef[(size_t)a * NP + lp];
+                u0 += v.pm_Jp[pidx<2 * DP>((2 * (a < DP ? a : 0)), e)] * t;
+                u1 += v.pm_Jp[pidx<2 * DP>((2 * (a < DP ? a : 0) + 1), e)] * t;
+              } else {
+                u0 += v.pm_A[pidx<2 * D>((2 * a), e)] * ya;
+                u1 += v.pm_A[pidx<2 * D>((2 * a + 1), e)] * ya;
+              }
+            }
+          } else {
+            const double* yc = v.yc + (size_t)rb * D;
+#pragma unroll
+            for (int a = 0; a < D; ++a) {
+              const double ya = yc[a];
+              u0 += v.pm_A[pidx<2 * D>((2 * a), e)] * ya;
+              u1 += v.pm_A[pidx<2 * D>((2 * a + 1), e)] * ya;
+            }
           }
         }
         if (SH) {

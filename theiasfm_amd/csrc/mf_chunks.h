@@ -260,8 +260,12 @@ __device__ __forceinline__ double2 mf_stream_load(const double2* p) {
   return make_double2(t.x, t.y);
 }
 #define MF_STREAM_LOAD(p) mf_stream_load(p)
-template <int D, int DP>
+// DROP: the position columns of the A planes are not stored (DeviceView::drop_pos); x is then the vector with the position
+// entries of every block already times the block's column scales (pos_scale_kernel), reduce_kernel applies the scales
+// to the position entries of the sums.
+template <int D, int DP, bool DROP>
 __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View m, const double* __restrict__ x) {
+  constexpr int A0 = DROP ? 3 : 0;  // first stored column of the A planes
   constexpr int LCM = lc_max(D);
   constexpr int VB = vb_entries(D);
   constexpr int ROWD = 2 * D * 64;  // doubles of one row (= one 64-observation tile) of the A planes
@@ -290,6 +294,11 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
       double wv[DP];
 #pragma unroll
       for (int a = 0; a < DP; ++a) wv[a] = 0.0;
+      double pcw[3] = {0.0, 0.0, 0.0};
+      if (DROP) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) pcw[a] = v.pos_coef[(size_t)a * v.Np_pad + lp];
+      }
       for (int j = j0; j < k; j += L) {
         const size_t e = base + (size_t)j * 64;
         const int rb = v.obs_rb[e];
@@ -299,17 +308,25 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
         const double* jp = v.pm_Jp + (e >> 6) * (size_t)ROWP + ((e & 63) << 1);
         double u0 = 0.0, u1 = 0.0;
 #pragma unroll
-        for (int a = 0; a < D; ++a) {
+        for (int a = A0; a < D; ++a) {
           const double2 aa = *reinterpret_cast<const double2*>(ap + a * 128);
           const double xa = xc[a];
           u0 += aa.x * xa;
           u1 += aa.y * xa;
         }
+        double2 jj[DP];
 #pragma unroll
-        for (int a = 0; a < DP; ++a) {
-          const double2 jj = *reinterpret_cast<const double2*>(jp + a * 128);
-          wv[a] += jj.x * u0 + jj.y * u1;
+        for (int a = 0; a < DP; ++a) jj[a] = *reinterpret_cast<const double2*>(jp + a * 128);
+        if (DROP) {
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            const double ca = pcw[a] * xc[a];
+            u0 += jj[a < DP ? a : 0].x * ca;
+            u1 += jj[a < DP ? a : 0].y * ca;
+          }
         }
+#pragma unroll
+        for (int a = 0; a < DP; ++a) wv[a] += jj[a].x * u0 + jj[a].y * u1;
         *reinterpret_cast<double2*>(m.ut + 2 * e) = make_double2(u0, u1);
       }
 #pragma unroll
@@ -344,9 +361,19 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
         const double2 t = *reinterpret_cast<const double2*>(m.ut + 2 * e);
         const double* ap = v.pm_A + (e >> 6) * (size_t)ROWD + ((e & 63) << 1);
 #pragma unroll
-        for (int a = 0; a < D; ++a) {
+        for (int a = A0; a < D; ++a) {
           const double2 aa = *reinterpret_cast<const double2*>(ap + a * 128);
           sum[a] += aa.x * t.x + aa.y * t.y;
+        }
+        if (DROP) {
+          // the element's track: slice q.s, column e & 63
+          const double* jp = v.pm_Jp + (e >> 6) * (size_t)ROWP + ((e & 63) << 1);
+          const size_t lpe = (size_t)q.s * 64 + (e & 63);
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            const double2 jj = *reinterpret_cast<const double2*>(jp + (a < DP ? a : 0) * 128);
+            sum[a] += v.pos_coef[(size_t)a * v.Np_pad + lpe] * (jj.x * t.x + jj.y * t.y);
+          }
         }
       }
       double* dst = m.partial + (size_t)m.run_slot[r] * D;
@@ -445,6 +472,7 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
     double2 ar[RR][D], jr[RR][DP];
     double xr[RR][D];
     double uu[RR][2];
+    double pcr[RR][3];  // DROP: -w / scale_p of the row's track
     int pos[RR];
     // ---- the batch of loads
 #pragma unroll
@@ -473,9 +501,19 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
         // streamed once: non-temporal, so that the rows do not push the x blocks (gathered again and again by the
         // units of an item) out of the vector L1
 #pragma unroll
-        for (int a = 0; a < D; ++a) ar[rr][a] = MF_STREAM_LOAD(reinterpret_cast<const double2*>(ap + a * 128));
+        for (int a = A0; a < D; ++a) ar[rr][a] = MF_STREAM_LOAD(reinterpret_cast<const double2*>(ap + a * 128));
 #pragma unroll
         for (int a = 0; a < DP; ++a) jr[rr][a] = MF_STREAM_LOAD(reinterpret_cast<const double2*>(jp + a * 128));
+        if (DROP) {
+          // the row's track: slice R / K of a pack, the piece's own slice otherwise
+          const size_t lpr = (size_t)(d0.w + (lsh ? 0 : min(R / K, G - 1))) * 64 + tl;
+#pragma unroll
+          for (int a = 0; a < 3; ++a) pcr[rr][a] = v.pos_coef[(size_t)a * v.Np_pad + lpr];
+        }
+      }
+      if (DROP && !(R < rows)) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) pcr[rr][a] = 0.0;
       }
     }
     MF_LAP(0);
@@ -489,9 +527,17 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
     for (int rr = 0; rr < RR; ++rr) {
       double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-      for (int a = 0; a < D; ++a) {
+      for (int a = A0; a < D; ++a) {
         s0 += ar[rr][a].x * xr[rr][a];
         s1 += ar[rr][a].y * xr[rr][a];
+      }
+      if (DROP) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const double ca = pcr[rr][a] * xr[rr][a];
+          s0 += jr[rr][a < DP ? a : 0].x * ca;
+          s1 += jr[rr][a < DP ? a : 0].y * ca;
+        }
       }
       if (pos[rr] < 0) {  // no observation here: whatever the loads fetched must not reach the sums
         s0 = s1 = 0.0;
@@ -566,7 +612,12 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
       if (pos[rr] >= 0) {
         double* dst = &vbuf[pos[rr] * D];
 #pragma unroll
-        for (int a = 0; a < D; ++a) dst[a] = ar[rr][a].x * uu[rr][0] + ar[rr][a].y * uu[rr][1];
+        for (int a = A0; a < D; ++a) dst[a] = ar[rr][a].x * uu[rr][0] + ar[rr][a].y * uu[rr][1];
+        if (DROP) {
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+            dst[a] = pcr[rr][a] * (jr[rr][a < DP ? a : 0].x * uu[rr][0] + jr[rr][a < DP ? a : 0].y * uu[rr][1]);
+        }
       }
     }
     MF_LAP(5);
@@ -699,6 +750,8 @@ __global__ __launch_bounds__(256) void reduce_kernel(DeviceView v, View m, RedLa
     double tot = sh[0][a] + sh[1][a] + sh[2][a] + sh[3][a];
     double pr = 0.0;
     if (live) {
+      // (drop_pos: the sums of the position entries still lack the view's column scale, device_view.h)
+      if (v.drop_pos && a < 3) tot *= v.scale_c[(size_t)rb * D + a];
       const double xa = x[(size_t)rb * D + a];
       // the damping (and the identity on padding rows) enters once: on rank 0 when the product is all-reduced
       if (add_diag) {
