@@ -70,12 +70,13 @@ def algorithmic_bytes(cls: str, n_obs: int, n_cam: int, n_pts: int, dc: int, dp:
     return 0
 
 
-def matrix_free_layout_floor(n_obs: int, n_cam: int, n_pts: int, dc: int, dp: int):
+def matrix_free_layout_floor(n_obs: int, n_cam: int, n_pts: int, dc: int, dp: int, stored_dc: int | None = None):
     """Bytes ONE matrix-free product must read in the layout of DESIGN.md section 3 when every stored block is read
     once: the 2 x dc camera and 2 x dp point Jacobian blocks of every observation, its two int32 indices, the
     per-track factor and the vectors.  NOT SURVEY 8(d)'s figure (that one counts S blocks); a different key in the
     bench line."""
-    return n_obs * (16 * (dc + dp) + 8) + 4 * n_cam * 8 * dc + n_pts * 8 * (dp * (dp + 1) // 2)
+    sdc = dc if stored_dc is None else stored_dc  # (round 4: the three position columns are formed from the point block)
+    return n_obs * (16 * (sdc + dp) + 8) + 4 * n_cam * 8 * dc + n_pts * 8 * (dp * (dp + 1) // 2)
 
 
 def engine_source_sha():
@@ -370,9 +371,12 @@ def main():
                     measured="HIP events on the engine's stream inside the timed region")
     if dom["kernel"] == "spmv" and mf_frac > 0.0:
         # beside the contract's figure, under its own key: what a matrix-free product has to read in this layout
-        lf = matrix_free_layout_floor(n_obs // world, n_cam, n_pts // world, dc, dp)
         e1 = os.environ.get("TMI_BA_MF_ONE_SWEEP")
         one_sweep = (e1 != "0") and (e1 is not None or n_obs // world >= 500000)  # engine.hip build_mf_chunks
+        # engine.hip create_impl: with the one-sweep product, every position free and no constant point (the synthetic
+        # workloads) the A planes hold dc - 3 columns
+        drop_pos = one_sweep and os.environ.get("TMI_BA_DROP_POS") != "0"
+        lf = matrix_free_layout_floor(n_obs // world, n_cam, n_pts // world, dc, dp, dc - 3 if drop_pos else dc)
         roofline["kernel"] = ("spmv (one product q = S p; matrix-free in %d of %d timed LM iterations: %s)"
                               % (m["matrix_free"], steps_run,
                                  "mfc::product_kernel + mfc::reduce_kernel, the one-sweep product of mf_chunks.h" if one_sweep
@@ -380,8 +384,9 @@ def main():
         roofline["layout_floor"] = dict(
             bytes_per_launch=int(lf), achieved=round(lf / (dom["avg_us"] * 1e-6) / 1e9, 2),
             frac=round(lf / (dom["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
-            note="matrix-free product, every stored Jacobian block read once (NOT SURVEY 8(d)'s bytes; round 2 "
-                 "quoted this figure as roofline.frac)")
+            note="matrix-free product, every stored Jacobian block read once%s (NOT SURVEY 8(d)'s bytes; round 2 "
+                 "quoted this figure as roofline.frac)" % (" -- the position columns of the camera block are not "
+                                                           "stored" if drop_pos else ""))
     # the other large classes of the same timed region (schur_offdiag was the dominant one until the adaptive
     # operator choice took it out of the short PCG solves): same definition, for comparison across rounds
     roofline["other_classes"] = {

@@ -1939,12 +1939,15 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
     if (rc) return rc;
   }
   // drop_pos (device_view.h): the position columns of the A planes formed from Jp instead of stored.  Only where the
-  // identity holds for every observation and every reader of the planes knows it: the one-sweep product is in use (the
-  // two-pass kernels read stored columns), fp64 evaluation (fp32 rounds -w M and M separately), every camera block has
+  // identity holds for every observation and every reader of the planes knows it: the two-pass matrix-free kernels (which
+  // read stored columns) cannot run, fp64 evaluation (fp32 rounds -w M and M separately), every camera block has
   // its position free (then its first three columns are the position) and no point is constant (its Jp is stored as
   // zero).  TMI_BA_DROP_POS=0 keeps the columns (A/B, tests).
   v.drop_pos = 0;
-  if (s->mf_ok && !st.has_shared && O->residual_precision != 32 && D >= 3 && s->DP >= 3) {
+  // (the two-pass matrix-free kernels are the only other readers of the A planes: fine when they cannot run -- the
+  // one-sweep product is built, or the operator is always the formed S / an exact solver)
+  const bool two_pass_possible = (s->implicit || s->adaptive) && !s->mf_ok;
+  if (!light && !two_pass_possible && !st.has_shared && O->residual_precision != 32 && D >= 3 && s->DP >= 3) {
     const char* e = getenv("TMI_BA_DROP_POS");
     bool ok = !(e && atoi(e) == 0);
     for (int rb = 0; rb < st.Nrb && ok; ++rb) {
