@@ -78,8 +78,9 @@ struct Launch {
   void (*implicit_spmv)(const DeviceView&, hipStream_t, RedLayout, const double*, double*, double*,
                         double*, double, double, double, int, int, int dot);
   // the one-sweep matrix-free product of mf_chunks.h (no shared intrinsics blocks)
+  // xs_ready: DeviceView::xs already holds x with the position entries scaled (pcg_init / pcg_p leave it for cg_p)
   void (*mf_product)(const DeviceView&, const mfc::View&, hipStream_t, RedLayout, const double*, double*, double, double,
-                     double, int, int dot);
+                     double, int, int dot, int xs_ready);
   void (*pcg_step)(const DeviceView&, hipStream_t, const double* b, int it, int nb, double eta, int min_it,
                    int max_it, const double* red8, HostMirror* mirror, unsigned long long seq);
   void (*pcg_a)(const DeviceView&, hipStream_t, int, int);
@@ -197,13 +198,13 @@ Launch make_launch(bool fp32) {
                          y, ir, lo, hi, add_diag);
   };
   L.mf_product = [](const DeviceView& v, const mfc::View& m, hipStream_t st, RedLayout R, const double* x, double* y,
-                    double ir, double lo, double hi, int add_diag, int dot) {
+                    double ir, double lo, double hi, int add_diag, int dot, int xs_ready) {
     if (!v.Nrb) return;
     if (v.drop_pos) {
       // the position columns of the planes are formed from Jp (device_view.h): the product gathers x with the
       // position entries times the views' column scales, the reduce launch scales the position entries of the sums
       const int n = v.Nrb * D;
-      hipLaunchKernelGGL((pos_scale_kernel<D>), dim3((n + 255) / 256), dim3(256), 0, st, v, x, v.xs);
+      if (!xs_ready) hipLaunchKernelGGL((pos_scale_kernel<D>), dim3((n + 255) / 256), dim3(256), 0, st, v, x, v.xs);
       if (m.n_items)
         hipLaunchKernelGGL((mfc::product_kernel<D, DP, true>), dim3(m.n_items), dim3(mfc::kThreads), 0, st, v, m, v.xs);
     } else if (m.n_items) {
@@ -2139,7 +2140,7 @@ static void prepare_cameras(tmi_ba_solver* s, const double* ext, const double* i
 // returns TMI_BA_OK; *usable = 0 for LINEAR_SOLVER_FAILURE
 // q = S x: explicit (symmetric block SpMV on the formed Schur complement) or implicit
 // (two passes over the observations; the reduced vector is all-reduced across ranks)
-static int apply_schur(tmi_ba_solver* s, const double* x, double* y, int dot = 0) {
+static int apply_schur(tmi_ba_solver* s, const double* x, double* y, int dot = 0, int xs_ready = 0) {
   DeviceView& v = s->v;
   const int n = v.Nrb * v.D;
   if (!s->implicit_now) {
@@ -2153,7 +2154,7 @@ static int apply_schur(tmi_ba_solver* s, const double* x, double* y, int dot = 0
     const int add_diag = (s->st.world <= 1 || s->st.rank == 0) ? 1 : 0;
     if (s->mf_ok)
       s->launch.mf_product(v, s->mf, s->stream, s->RL, x, y, s->cur_inv_radius, O->min_lm_diagonal, O->max_lm_diagonal,
-                           add_diag, dot);
+                           add_diag, dot, xs_ready);
     else
       s->launch.implicit_spmv(v, s->stream, s->RL, x, y, s->d_pm_u, s->d_cm_t, s->cur_inv_radius,
                               O->min_lm_diagonal, O->max_lm_diagonal, add_diag, s->nblocks_tracks, dot);
@@ -2323,12 +2324,15 @@ static int solve_reduced_pcg(tmi_ba_solver* s, const tmi_ba_options* O, int* usa
   const bool fused = !s->st.has_shared && !s->cl_active;  // (pcg_step applies the block inverses itself: no clusters)
   const int nbv = (v.Nrb + 3) / 4;
   const int nbs16 = (v.Nrb + kPcgStepThreads / 64 - 1) / (kPcgStepThreads / 64);  // workgroups of pcg_step
+  // drop_pos: pcg_init and pcg_p leave the scaled copy of p the product gathers; the three-kernel path does not
+  bool xs_valid = !s->cl_active;
   int it;
   for (it = 1;; ++it) {
     const bool reset = (it % 10 == 0);  // residual_reset_period
     int rc;
     if (fused && !reset) {
-      if ((rc = apply_schur(s, v.cg_p, v.cg_q, /*dot=*/1))) return rc;
+      if ((rc = apply_schur(s, v.cg_p, v.cg_q, /*dot=*/1, xs_valid ? 1 : 0))) return rc;
+      xs_valid = true;  // (pcg_p below)
       unsigned long long my_seq;
       {
         Timed t(s, TMI_BA_K_PCG_VECTOR);
@@ -2340,8 +2344,9 @@ static int solve_reduced_pcg(tmi_ba_solver* s, const tmi_ba_options* O, int* usa
       if ((rc = wait_mirror(s, it & 1, my_seq))) return rc;
     } else {
       {
-        const int rcs = apply_schur(s, v.cg_p, v.cg_q);
+        const int rcs = apply_schur(s, v.cg_p, v.cg_q, 0, xs_valid ? 1 : 0);
         if (rcs) return rcs;
+        xs_valid = false;  // (pcg_b3 writes p)
       }
       {
         Timed t(s, TMI_BA_K_PCG_VECTOR);

@@ -2547,7 +2547,11 @@ __global__ __launch_bounds__(256) void pcg_p_kernel(DeviceView v, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const double beta = v.scal[SC_RHO] / v.scal[SC_LAST_RHO];
-  v.cg_p[i] = v.cg_z[i] + beta * v.cg_p[i];
+  const double pn = v.cg_z[i] + beta * v.cg_p[i];
+  v.cg_p[i] = pn;
+  // drop_pos: the copy the next product gathers, position entries times the column scales (pos_scale_kernel's job
+  // for any other vector)
+  if (v.drop_pos) v.xs[i] = (i % v.D) < 3 ? pn * v.scale_c[i] : pn;
 }
 
 // Start of a PCG solve in one launch (pcg_begin + the first pcg_a): x = 0, r = b, z = M^-1 b,
@@ -2580,6 +2584,7 @@ __global__ __launch_bounds__(kPcgStepThreads) void pcg_init_kernel(DeviceView v,
     if (lane < D) {
       v.cg_z[i] = z;
       v.cg_p[i] = z;
+      if (v.drop_pos) v.xs[i] = lane < 3 ? z * v.scale_c[i] : z;
       acc = rn * z;
     }
   }
