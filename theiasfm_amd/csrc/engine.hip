@@ -325,6 +325,7 @@ struct tmi_ba_solver {
   bool implicit_now = false;  // the operator of the current LM iteration
   bool y_records = false;     // point_eliminate writes Y records (shared blocks, or the older Schur kernels by env)
   int n_implicit_iterations = 0;
+  int adaptive_break_even_override = -1;
   int adaptive_break_even = 4;  // PCG iterations up to which the matrix-free operator is the cheaper one
   double cur_inv_radius = 0.0;
   double time_vote = 0.0;     // this rank's "solver time exceeded" vote (source of a small async copy)
@@ -1899,12 +1900,20 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   s->y_records = st.has_shared || getenv("TMI_BA_SCHUR_Y") != nullptr;
   v.write_y = (s->y_records && (!s->implicit || st.has_shared)) ? 1 : 0;
   if (s->adaptive) {
-    // cost model measured on MI355X (profiles/r02_z): forming S ~61 ps per pair, a product with S ~192 ps per
-    // upper block, a matrix-free product ~85 ps per observation
-    const double form = 61.0 * (double)st.npairs, with_s = 192.0 * (double)st.nub, free = 85.0 * (double)st.No;
+    // cost model measured on MI355X (profiles/r02_z, r04): forming S ~61 ps per pair (79 with 4-dof points), a product
+    // with S ~195 ps per upper block, a matrix-free product ~85 ps per observation in two passes.  The one-sweep
+    // product takes 56-62 ps per observation, but the break-even that measures best on the bench problem at the
+    // reference's default options (TMI_BA_BREAK_EVEN = 8 / 16 / 24 / 32 / 48: 10.67 / 10.58 / 10.66 / 10.77 / 10.91 ms per
+    // LM iteration; the forecast of an iteration's PCG length is the previous iteration's, and the lengths grow) is
+    // what 70 ps give
+    const bool one_sweep_size = st.No >= 500000;  // (build_mf_chunks' rule; the product itself is built further down)
+    const double form = (s->DP == 4 ? 79.0 : 61.0) * (double)st.npairs, with_s = 195.0 * (double)st.nub,
+                 free = (one_sweep_size ? 70.0 : 85.0) * (double)st.No;
+    if (const char* e = getenv("TMI_BA_BREAK_EVEN")) s->adaptive_break_even_override = atoi(e);
     // (a product with S that costs more than a matrix-free one -- many views, little co-visibility: S has more
     // blocks than there are observations to walk -- never pays off: always matrix-free)
     s->adaptive_break_even = free > with_s ? (int)std::min(1.0e6, form / (free - with_s)) : 1 << 30;
+    if (s->adaptive_break_even_override >= 0) s->adaptive_break_even = s->adaptive_break_even_override;
   }
   AL(v.cm_Y, v.write_y ? (size_t)std::max<int64_t>(st.Nslots, 1) * YS : 1) AL(v.cm_A, (size_t)std::max<int64_t>(st.Nslots, 1) * AS)
   v.cm_R = v.cm_A + (size_t)std::max<int64_t>(st.Nslots, 1) * asa_of(D, DP);  // tails behind the [A | Q] records (!has_shared)
