@@ -8,20 +8,23 @@
 // Rounds 1-3 ran this as two launches -- a track-major pass over the planes (u, zhat) and a camera-major pass over
 // the [A | Q] records (A^T t summed per view) -- so the camera Jacobian blocks crossed HBM twice per product
 // (2.4 GB for 0.83 GB algorithmic at Venice size).  Summing A^T t per VIEW is what forced the second order.  Here
-// a workgroup streams a SELL slice ONCE: the lane that owns an observation keeps its A block in registers until
+// a workgroup streams a UNIT (below) ONCE: the lane that owns an observation keeps its A block in registers until
 // the track's z is known, forms v_i = A_i^T t_i and drops it into LDS at the observation's position in the
-// slice's VIEW order (a static index); one thread per "run" (the observations of the slice that share a view)
+// unit's VIEW order (a static index); one thread per "run" (the observations of the unit that share a view)
 // then sums consecutive LDS entries => a fixed order and no atomics, and adds the run sum into per-view
-// accumulators that stay in LDS while the workgroup walks an ITEM = a range of consecutive slices.  Tracks are ordered by (length, lowest view), so the slices of an
-// item see the same few hundred views; an item leaves one D-vector per distinct view ("slot") in HBM and
-// mfc_reduce sums a view's slots in item order and adds the damping and p.q.  Bytes per observation: the A and Jp
-// planes once (16 (D + DP)), two int32 indices, and ~2 % of partials, against twice the A blocks + a 128-byte
-// line per zhat gather before.
+// accumulators that stay in LDS while the workgroup walks an ITEM = a range of consecutive units.  Tracks are
+// ordered by (length, lowest view), so the units of an item see the same few hundred views; an item leaves one
+// D-vector per distinct view ("slot") in HBM and reduce_kernel sums a view's slots in item order and adds the damping
+// and p.q.  Bytes per observation: the stored columns of the A planes and the Jp planes once (16 (D + DP), 48 less
+// where the position columns are formed from Jp: DeviceView::drop_pos), two int32 indices, and ~10 % of partials,
+// against twice the A blocks + a 128-byte line per zhat gather before.
 //
-// Units: the pieces a workgroup handles between two barriers -- a narrow slice (64 tracks, thread-per-track
-// slices), a quarter of a wide slice (16 tracks, 16 lanes per track) or four tracks of an ultra slice (a wavefront
-// per track), exactly the workgroup shapes of track_map (kernels.h).  Wide / ultra units are items of their own:
-// their rows do not fit LDS, so u / t go through a global scratch and every run writes its slot directly.
+// Units: what a workgroup (kWaves wavefronts x reg_rows(D) row slots) handles between two load batches --
+//   * a SELL slice of at most kWaves reg_rows(D) rows, or a pack of 2-4 consecutive slices of <= 4 rows;
+//   * one of the L = 2, 4, .. 64 pieces a longer slice (up to 64 times that many rows) is cut into: 64 / L tracks,
+//     L lanes per track;
+//   * four tracks of a slice that is longer still: a wavefront per track, u / t through a global scratch, every run
+//     writes its slot directly (an item of its own).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -45,8 +48,8 @@ __host__ __device__ constexpr int vb_entries(int D) { return D <= 9 ? 512 : 256;
 
 struct View {
   int n_items, n_units, n_runs;
-  int nub;  // units [0, nub): four tracks of an ultra slice each
-  int nwb;  // units [nub, nwb): a quarter of a wide slice each; [nwb, n_units): narrow slices
+  int nub;  // units [0, nub): four tracks (a wavefront each) of a slice too long for the row slots
+  int nwb;  // = nub since round 4 (was: + the quarters of the 16-lane slices); [nwb, n_units): narrow units
   const int* item_unit0;     // [n_items + 1] units of an item (wide / ultra: one)
   const int4* unit_desc;     // [n_units - nwb] narrow units: {first element, rows, rows of one slice | log2 L << 16,
                              //  first slice}; L > 1: one of the L pieces (64 / L tracks each) of a long slice
@@ -59,9 +62,9 @@ struct View {
   const int* obs_pos;        // [No_pad] position of the observation in its unit's view order, -1: no view block
   const int* cam_slot_ptr;   // [Nrb + 1] slots of a view block ...
   const int* cam_slots;      // ... ascending (item order)
-  long long* prof;           // TMI_MF_PROFILE builds: per item {cycles of 5 phases, units}
+  long long* prof;           // TMI_MF_PROFILE builds: per item {cycles of 10 phases, units, start-up, write-out}
   double* partial;           // [n_slots][D]
-  double* ut;                // [elements of the wide slices][2]
+  double* ut;                // [elements of the wavefront-per-track slices][2]
 };
 
 struct UnitShape {
