@@ -1450,6 +1450,13 @@ static int build_mf_chunks(tmi_ba_solver* s) {
   double *p_partial, *p_ut;
   if ((rc = dev_alloc(s, &p_partial, (size_t)n_slots * D))) return rc;
   if ((rc = dev_alloc(s, &p_ut, (size_t)2 * std::max(st.slice_ptr[n_old], 1)))) return rc;
+  {
+    int4* p_hdr;
+    if ((rc = dev_alloc(s, &p_hdr, (size_t)n_items * 6))) return rc;
+    hipLaunchKernelGGL(item_hdr_kernel, nb(n_items), dim3(256), 0, stream, n_items, nwb, n_units, p_item_unit0, p_item_slot_ptr,
+                       d_unit_desc, p_unit_run_ptr, p_run_obs_ptr, p_hdr);
+    m.item_hdr = p_hdr;
+  }
   m.unit_desc = d_unit_desc;
   m.item_unit0 = p_item_unit0;
   m.unit_run_ptr = p_unit_run_ptr;

@@ -51,6 +51,7 @@ struct View {
   int nub;  // units [0, nub): four tracks (a wavefront each) of a slice too long for the row slots
   int nwb;  // = nub since round 4 (was: + the quarters of the 16-lane slices); [nwb, n_units): narrow units
   const int* item_unit0;     // [n_items + 1] units of an item (wide / ultra: one)
+  const int4* item_hdr;      // [n_items][6] what a narrow item's prologue needs, in one place (item_hdr_kernel)
   const int4* unit_desc;     // [n_units - nwb] narrow units: {first element, rows, rows of one slice | log2 L << 16,
                              //  first slice}; L > 1: one of the L pieces (64 / L tracks each) of a long slice
   const int* unit_run_ptr;   // [n_units + 1]
@@ -218,6 +219,31 @@ __global__ __launch_bounds__(256) void lower_bound_u32_kernel(const unsigned* __
     else hi = mid;
   }
   out[i] = lo;
+}
+
+// everything the prologue of a narrow item looks up, gathered once: {u0, u1, slot0, #slots}, the descriptors of its
+// first three units, the run ranges of the first three and the observation ranges of the first two -- one
+// dependent round trip at the start of a work item instead of three
+__global__ __launch_bounds__(256) void item_hdr_kernel(int n_items, int nwb, int n_units, const int* __restrict__ item_unit0,
+                                                       const int* __restrict__ item_slot_ptr,
+                                                       const int4* __restrict__ unit_desc,
+                                                       const int* __restrict__ unit_run_ptr,
+                                                       const int* __restrict__ run_obs_ptr, int4* __restrict__ hdr) {
+  const int item = blockIdx.x * 256 + threadIdx.x;
+  if (item >= n_items) return;
+  int4* h = hdr + (size_t)item * 6;
+  const int u0 = item_unit0[item], u1 = item_unit0[item + 1];
+  const int slot0 = item_slot_ptr[item];
+  h[0] = make_int4(u0, u1, slot0, item_slot_ptr[item + 1] - slot0);
+  if (item < nwb) return;
+  const int4* desc = unit_desc - nwb;
+  const int last_u = n_units - 1;
+  h[1] = desc[u0];
+  h[2] = desc[min(u0 + 1, last_u)];
+  h[3] = desc[min(u0 + 2, last_u)];
+  const int r0 = unit_run_ptr[u0], r1 = unit_run_ptr[u0 + 1], r2 = unit_run_ptr[min(u0 + 2, n_units)];
+  h[4] = make_int4(r0, r1, r2, run_obs_ptr[r0]);
+  h[5] = make_int4(run_obs_ptr[r1], 0, 0, 0);
 }
 
 // ---- the product ---------------------------------------------------------------------------------------------
@@ -407,18 +433,18 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
 #ifdef TMI_MF_PROFILE
   const long long tc0 = clock64();
 #endif
-  const int u0 = m.item_unit0[item], u1 = m.item_unit0[item + 1];
-  const int slot0 = m.item_slot_ptr[item];
-  const int nlc = m.item_slot_ptr[item + 1] - slot0;
+  const int4* hdr = m.item_hdr + (size_t)item * 6;
+  const int4 h0 = hdr[0], h4 = hdr[4], h5 = hdr[5];
+  const int u0 = h0.x, u1 = h0.y, slot0 = h0.z, nlc = h0.w;
   // an item of ONE unit has a slot per run: the sums go straight to HBM (and it may see any number of views)
   const bool direct = (u1 - u0) == 1;
   if (!direct)
     for (int i = threadIdx.x; i < nlc * D; i += kThreads) acc[i] = 0.0;
   const int4* desc = m.unit_desc - m.nwb;  // {first element, rows, rows of one slice | log2 L << 16, first slice}
   const int last_u = m.n_units - 1;
-  int4 d0 = desc[u0], d1 = desc[min(u0 + 1, last_u)], d2 = desc[min(u0 + 2, last_u)];
-  int r0 = m.unit_run_ptr[u0], r1 = m.unit_run_ptr[u0 + 1], r2 = m.unit_run_ptr[min(u0 + 2, m.n_units)];
-  int o0 = m.run_obs_ptr[r0], o1 = m.run_obs_ptr[r1];
+  int4 d0 = hdr[1], d1 = hdr[2], d2 = hdr[3];
+  int r0 = h4.x, r1 = h4.y, r2 = h4.z;
+  int o0 = h4.w, o1 = h5.x;
   int nrb[RR], npos[RR];
   auto load_index = [&](int4 d) {
     const int lsh = d.z >> 16, t = lane & ((64 >> lsh) - 1), sub = lane >> (6 - lsh);
