@@ -1451,6 +1451,23 @@ static int build_mf_chunks(tmi_ba_solver* s) {
   if ((rc = dev_alloc(s, &p_partial, (size_t)n_slots * D))) return rc;
   if ((rc = dev_alloc(s, &p_ut, (size_t)2 * std::max(st.slice_ptr[n_old], 1)))) return rc;
   {
+    // launch order: the wavefront-per-track units first (as before), then the narrow items by descending size --
+    // the hardware hands out workgroups in index order, and the largest items (packs of the shortest tracks) used to
+    // come last
+    std::vector<int> order((size_t)n_items);
+    std::vector<long long> elems((size_t)n_items, 0);
+    for (int i = 0; i < n_items; ++i) order[i] = i;
+    for (size_t g = 0; g < groups.size(); ++g)
+      for (int u = groups[g].first; u < groups[g].second; ++u) {
+        const int4& d = unit_desc[(size_t)(u - nwb)];
+        elems[(size_t)nwb + g] += (long long)d.y * (64 >> (d.z >> 16));
+      }
+    std::stable_sort(order.begin() + nwb, order.end(), [&](int a, int b) { return elems[a] > elems[b]; });
+    int* p_order;
+    if ((rc = dev_upload(s, &p_order, order))) return rc;
+    m.item_order = p_order;
+  }
+  {
     int4* p_hdr;
     if ((rc = dev_alloc(s, &p_hdr, (size_t)n_items * 6))) return rc;
     hipLaunchKernelGGL(item_hdr_kernel, nb(n_items), dim3(256), 0, stream, n_items, nwb, n_units, p_item_unit0, p_item_slot_ptr,

@@ -51,6 +51,7 @@ struct View {
   int nub;  // units [0, nub): four tracks (a wavefront each) of a slice too long for the row slots
   int nwb;  // = nub since round 4 (was: + the quarters of the 16-lane slices); [nwb, n_units): narrow units
   const int* item_unit0;     // [n_items + 1] units of an item (wide / ultra: one)
+  const int* item_order;     // [n_items] workgroup b takes item item_order[b]: largest first, so the last round is short
   const int4* item_hdr;      // [n_items][6] what a narrow item's prologue needs, in one place (item_hdr_kernel)
   const int4* unit_desc;     // [n_units - nwb] narrow units: {first element, rows, rows of one slice | log2 L << 16,
                              //  first slice}; L > 1: one of the L pieces (64 / L tracks each) of a long slice
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
   double (*wpart)[DP][64] = reinterpret_cast<double (*)[DP][64]>(vbuf);
   __shared__ double zs[kWaves][DP][64];
   __shared__ double acc[LCM * D];
-  const int item = blockIdx.x;
+  const int item = m.item_order[blockIdx.x];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 
   if (item < m.nwb) {
