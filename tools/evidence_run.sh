@@ -1,7 +1,7 @@
 #!/bin/bash
 # evidence run of a round (on the GPU box, via gpurun): tests, smoke, default bench line, kernel trace, PMC passes,
 # alamo-variant kernel trace, config-5 kernel trace, scale probe.  usage: tools/evidence_run.sh <tag>   (e.g. r03_z)
-T=${1:-r04_d}
+T=${1:-r04_e}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 cd $R
 export TMI_GIT_HEAD=${TMI_GIT_HEAD:-unknown}
