@@ -372,7 +372,7 @@ def main():
     if dom["kernel"] == "spmv" and mf_frac > 0.0:
         # beside the contract's figure, under its own key: what a matrix-free product has to read in this layout
         e1 = os.environ.get("TMI_BA_MF_ONE_SWEEP")
-        one_sweep = (e1 != "0") and (e1 is not None or n_obs // world >= 500000)  # engine.hip build_mf_chunks
+        one_sweep = (e1 != "0") and (e1 is not None or n_obs // world >= 350000)  # engine.hip build_mf_chunks
         # engine.hip create_impl: with the one-sweep product, every position free and no constant point (the synthetic
         # workloads) the A planes hold dc - 3 columns
         drop_pos = one_sweep and os.environ.get("TMI_BA_DROP_POS") != "0"

@@ -107,7 +107,7 @@ def test_one_sweep_product_is_reproducible_to_the_bit():
 @pytest.mark.parametrize("world", [2, 3])
 def test_one_sweep_product_on_sharded_handles(world):
     """Every rank of a sharded solve builds its own units / items / slots from its shard of the slices (the engine
-    switches the one-sweep product on per rank, from half a million observations): `world` handles in threads on the one
+    switches the one-sweep product on per rank, from 350 k observations): `world` handles in threads on the one
     device, the hook summing their buffers where RCCL would -- each rank ends where the single-rank solve ends."""
     import threading
 

@@ -1195,13 +1195,14 @@ static int build_mf_chunks(tmi_ba_solver* s) {
   s->mf_ok = false;
   int rc_early = TMI_BA_OK;
   // Which product: measured on MI355X (profiles/r04_one_sweep_experiment.md, same-box pairs on venice1778_heavy, ms per
-  // LM iteration, two-pass / one-sweep) a rank that holds the whole problem, a half, a quarter, an eighth of it takes
-  // 3.93 / 3.27, 2.33 / 1.91, 1.41 / 1.23, 0.77 / 0.72.  An eighth is 625 k observations -- ~500 work items, a single
-  // round -- and nothing smaller has been measured, so: the one-sweep product from half a million observations per
-  // rank, the two-pass product below; TMI_BA_MF_ONE_SWEEP=1 / =0 forces either (tests, A/B).
+  // LM iteration, two-pass / one-sweep) a rank that holds the whole problem, a half, a quarter, an eighth, a sixteenth
+  // of it takes 3.93 / 2.98, 2.33 / 1.77, 1.41 / 1.16, 0.77 / 0.70, 0.93 / 0.96.  The shards of a sharded handle are
+  // dealt by work, not by observations (the rank with the longest tracks of eight holds ~450 k of 5.0 M), so: the
+  // one-sweep product from 350 k observations per rank, the two-pass product below; TMI_BA_MF_ONE_SWEEP=1 / =0 forces
+  // either (tests, A/B).
   {
     const char* e = getenv("TMI_BA_MF_ONE_SWEEP");
-    const bool want = e ? atoi(e) != 0 : s->st.No >= 500000;
+    const bool want = e ? atoi(e) != 0 : s->st.No >= 350000;
     if (!want) return TMI_BA_OK;
   }
   Structure& st = s->st;
@@ -1930,7 +1931,7 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
     // reference's default options (TMI_BA_BREAK_EVEN = 8 / 16 / 24 / 32 / 48: 10.67 / 10.58 / 10.66 / 10.77 / 10.91 ms per
     // LM iteration; the forecast of an iteration's PCG length is the previous iteration's, and the lengths grow) is
     // what 70 ps give
-    const bool one_sweep_size = st.No >= 500000;  // (build_mf_chunks' rule; the product itself is built further down)
+    const bool one_sweep_size = st.No >= 350000;  // (build_mf_chunks' rule; the product itself is built further down)
     const double form = (s->DP == 4 ? 79.0 : 61.0) * (double)st.npairs, with_s = 195.0 * (double)st.nub,
                  free = (one_sweep_size ? 70.0 : 85.0) * (double)st.No;
     if (const char* e = getenv("TMI_BA_BREAK_EVEN")) s->adaptive_break_even_override = atoi(e);
