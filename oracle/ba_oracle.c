@@ -85,6 +85,9 @@
 #undef ABS
 #undef VAL
 
+/* ORACLE_TIMING=1: wall-clock of the phases of oracle_ba_solve on stderr (where the CPU baseline's time goes) */
+#define OT_LAP(name) do { if (getenv("ORACLE_TIMING")) { const double n_ = now_s(); fprintf(stderr, "[oracle] %-22s %.3f s\n", name, n_ - ot_); ot_ = n_; } } while (0)
+static double now_s(void);
 static double now_s(void) {
   struct timespec ts;
   clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -1759,7 +1762,9 @@ int32_t oracle_ba_solve(tmi_ba_problem* P, const tmi_ba_options* O, tmi_ba_summa
   s->yp = (double*)calloc((size_t)s->Np * dp + 1, sizeof(double));
   for (int i = 0; i < s->nr; ++i) s->scale_c[i] = 1.0;
   for (int64_t i = 0; i < (int64_t)s->Np * dp; ++i) s->scale_p[i] = 1.0;
+  double ot_ = now_s();
   build_structure(s);
+  OT_LAP("build_structure");
   sum->num_reduced_blocks = s->nrb;
   sum->reduced_block_dim = 0;
   for (int b = 0; b < s->nrb; ++b)
@@ -1774,6 +1779,7 @@ int32_t oracle_ba_solve(tmi_ba_problem* P, const tmi_ba_options* O, tmi_ba_summa
   /* ---- iteration zero (TrustRegionMinimizer::IterationZero) ---- */
   double cost, ss;
   int64_t bad = evaluate(s, 1, 0, &cost, &ss);
+  OT_LAP("evaluate (jets)");
   if (bad) {
     sum->status = TMI_BA_ERR_EVALUATION_FAILED;
     snprintf(sum->message, sizeof(sum->message),
@@ -1795,7 +1801,9 @@ int32_t oracle_ba_solve(tmi_ba_problem* P, const tmi_ba_options* O, tmi_ba_summa
     for (int i = 0; i < s->nr; ++i) s->scale_c[i] = 1.0 / (1.0 + sqrt(s->diag_c[i]));
     for (int64_t i = 0; i < (int64_t)s->Np * dp; ++i)
       s->scale_p[i] = 1.0 / (1.0 + sqrt(s->diag_p[i]));
+    OT_LAP("gradient + norms");
     evaluate(s, 1, 1, &cost, &ss);
+    OT_LAP("evaluate (scaled)");
   }
   double x_norm = state_norm(s);
   double radius = O->initial_trust_region_radius;
@@ -1821,12 +1829,17 @@ int32_t oracle_ba_solve(tmi_ba_problem* P, const tmi_ba_options* O, tmi_ba_summa
         break;
       }
       ++iter;
+      ot_ = now_s();
       if (!reuse_diagonal) column_sqnorms(s, s->diag_c, s->diag_p);
+      OT_LAP("column norms");
       int step_ok = build_reduced(s, radius);
+      OT_LAP("build_reduced");
       if (step_ok) step_ok = iterative ? solve_pcg(s) : solve_dense(s);
+      OT_LAP("linear solve");
       double model_cost_change = 0.0;
       if (step_ok) {
         model_cost_change = back_substitute(s);
+        OT_LAP("back_substitute");
         if (!(model_cost_change > 0.0)) step_ok = 0;
       }
       if (!step_ok) {
