@@ -477,6 +477,11 @@ typedef struct {
   int64_t* blk_off;
   int64_t* row_ptr; /* CSR over blocks by block row */
   int64_t* row_blk;
+  /* the observations of every reduced block row (a view's block: the view's observations; a shared intrinsics block:
+   * those of all its views), as sorted positions k, ascending; and the point of every sorted position */
+  int64_t* rb_obs_ptr; /* [nrb + 1] */
+  int64_t* rb_obs;
+  int* k_pt;           /* [No] */
   double* S;
   int64_t S_len;
   double *gc, *rhs, *yc, *yp;
@@ -719,6 +724,29 @@ static void build_structure(ost* s) {
   for (int64_t b = 0; b < s->nblk; ++b) s->row_blk[fill[s->blk_i[b]]++] = b;
   free(fill);
   s->S = (double*)malloc(sizeof(double) * (size_t)s->S_len);
+  /* observations by reduced block row (counting sort over the sorted positions: ascending k within a row) */
+  s->k_pt = (int*)malloc(sizeof(int) * (size_t)(s->No + 1));
+  s->rb_obs_ptr = (int64_t*)calloc((size_t)s->nrb + 2, sizeof(int64_t));
+  int64_t total = 0;
+  for (int p = 0; p < s->Np; ++p)
+    for (int64_t k = s->pt_ptr[p]; k < s->pt_ptr[p + 1]; ++k) {
+      s->k_pt[k] = p;
+      int rb0, n0, rb1, n1;
+      obs_parts(s, s->P->obs_camera[s->order[k]], &rb0, &n0, &rb1, &n1);
+      if (rb0 >= 0) { s->rb_obs_ptr[rb0 + 1]++; ++total; }
+      if (rb1 >= 0) { s->rb_obs_ptr[rb1 + 1]++; ++total; }
+    }
+  for (int i = 0; i < s->nrb; ++i) s->rb_obs_ptr[i + 1] += s->rb_obs_ptr[i];
+  s->rb_obs = (int64_t*)malloc(sizeof(int64_t) * (size_t)(total + 1));
+  int64_t* at = (int64_t*)malloc(sizeof(int64_t) * (size_t)(s->nrb + 1));
+  memcpy(at, s->rb_obs_ptr, sizeof(int64_t) * (size_t)s->nrb);
+  for (int64_t k = 0; k < s->No; ++k) {
+    int rb0, n0, rb1, n1;
+    obs_parts(s, s->P->obs_camera[s->order[k]], &rb0, &n0, &rb1, &n1);
+    if (rb0 >= 0) s->rb_obs[at[rb0]++] = k;
+    if (rb1 >= 0) s->rb_obs[at[rb1]++] = k;
+  }
+  free(at);
 }
 
 /* small SPD inverse via Cholesky (n <= 4).  Returns 0 if not positive definite. */
@@ -805,23 +833,30 @@ static int build_reduced(ost* s, double radius) {
   if (!ok) return 0;
   memset(s->S, 0, sizeof(double) * (size_t)s->S_len);
   memset(s->rhs, 0, sizeof(double) * (size_t)s->nr);
-  /* phase 2: accumulate, each thread owns the block rows bi % T == t */
+  /* phase 2: accumulate, ROW BY ROW: a thread takes a block row, maps the row's columns to its blocks once (no
+   * hashing per update) and walks the row's observations; every update of the row lands in the row's own blocks
+   * (~1 MB: they stay in cache) and in its own slice of rhs.  (Until round 4 every thread walked all the points and
+   * updated the rows it owned through the hash map: 78 % of an LM iteration on the bench problem, ORACLE_TIMING.) */
 #pragma omp parallel
   {
-#ifdef _OPENMP
-    const int T_ = omp_get_num_threads(), t_ = omp_get_thread_num();
-#else
-    const int T_ = 1, t_ = 0;
-#endif
-    for (int p = 0; p < s->Np; ++p) {
-      const int64_t k0 = s->pt_ptr[p], k1 = s->pt_ptr[p + 1];
-      const double* tp = s->tp + (int64_t)p * dp;
-      for (int64_t ki = k0; ki < k1; ++ki) {
+    int64_t* col_blk = (int64_t*)malloc(sizeof(int64_t) * (size_t)(s->nrb + 1));
+    for (int i = 0; i < s->nrb; ++i) col_blk[i] = -1;
+#pragma omp for schedule(dynamic, 1)
+    for (int bi = 0; bi < s->nrb; ++bi) {
+      for (int64_t q = s->row_ptr[bi]; q < s->row_ptr[bi + 1]; ++q) col_blk[s->blk_j[s->row_blk[q]]] = s->row_blk[q];
+      const int ni = s->rb_dim[bi];
+      double* rhs = s->rhs + s->rb_off[bi];
+      for (int64_t qi = s->rb_obs_ptr[bi]; qi < s->rb_obs_ptr[bi + 1]; ++qi) {
+        const int64_t ki = s->rb_obs[qi];
+        const int p = s->k_pt[ki];
+        const int64_t k0 = s->pt_ptr[p], k1 = s->pt_ptr[p + 1];
+        const double* tp = s->tp + (int64_t)p * dp;
         const int cam_i = s->P->obs_camera[s->order[ki]];
         int rb[2], n[2], c0[2];
         obs_parts(s, cam_i, &rb[0], &n[0], &rb[1], &n[1]);
         c0[0] = 0;
         c0[1] = n[0];
+        const int pi = (rb[0] == bi) ? 0 : 1;  /* which part of the observation's camera-side block this row is */
         const double* Ji = s->Jc + 2 * MAXC * ki;
         const double* Jpi = s->Jp + 8 * ki;
         const double* Ei = s->Ep + 8 * ki;
@@ -831,55 +866,52 @@ static int build_reduced(ost* s, double radius) {
           rt[0] -= Jpi[a] * tp[a];
           rt[1] -= Jpi[4 + a] * tp[a];
         }
-        for (int pi = 0; pi < 2; ++pi) {
-          if (rb[pi] < 0 || (rb[pi] % T_) != t_) continue;
-          const int ni = n[pi];
-          const double* Ai0 = Ji + c0[pi];
-          const double* Ai1 = Ji + MAXC + c0[pi];
-          double* rhs = s->rhs + s->rb_off[rb[pi]];
-          for (int a = 0; a < ni; ++a) rhs[a] += Ai0[a] * rt[0] + Ai1[a] * rt[1];
-          /* U: this observation's own blocks (pi, pj) */
-          for (int pj = 0; pj < 2; ++pj) {
-            if (rb[pj] < 0) continue;
-            double* B = s->S + s->blk_off[block_lookup(s, rb[pi], rb[pj])];
-            const int nj = n[pj];
-            const double* Aj0 = Ji + c0[pj];
-            const double* Aj1 = Ji + MAXC + c0[pj];
-            for (int a = 0; a < ni; ++a)
-              for (int b = 0; b < nj; ++b) B[a * nj + b] += Ai0[a] * Aj0[b] + Ai1[a] * Aj1[b];
+        const double* Ai0 = Ji + c0[pi];
+        const double* Ai1 = Ji + MAXC + c0[pi];
+        for (int a = 0; a < ni; ++a) rhs[a] += Ai0[a] * rt[0] + Ai1[a] * rt[1];
+        /* U: this observation's own blocks (pi, pj) */
+        for (int pj = 0; pj < 2; ++pj) {
+          if (rb[pj] < 0) continue;
+          double* B = s->S + s->blk_off[col_blk[rb[pj]]];
+          const int nj = n[pj];
+          const double* Aj0 = Ji + c0[pj];
+          const double* Aj1 = Ji + MAXC + c0[pj];
+          for (int a = 0; a < ni; ++a)
+            for (int b = 0; b < nj; ++b) B[a * nj + b] += Ai0[a] * Aj0[b] + Ai1[a] * Aj1[b];
+        }
+        /* Schur: - A_i^T (E_i Jp_j^T) A_j over every observation j of the track */
+        for (int64_t kj = k0; kj < k1; ++kj) {
+          const int cam_j = s->P->obs_camera[s->order[kj]];
+          int rbj[2], nj_[2], cj0[2];
+          obs_parts(s, cam_j, &rbj[0], &nj_[0], &rbj[1], &nj_[1]);
+          cj0[0] = 0;
+          cj0[1] = nj_[0];
+          const double* Jj = s->Jc + 2 * MAXC * kj;
+          const double* Jpj = s->Jp + 8 * kj;
+          double M[4] = {0, 0, 0, 0};
+          for (int a = 0; a < dp; ++a) {
+            M[0] += Ei[a] * Jpj[a];
+            M[1] += Ei[a] * Jpj[4 + a];
+            M[2] += Ei[4 + a] * Jpj[a];
+            M[3] += Ei[4 + a] * Jpj[4 + a];
           }
-          /* Schur: - A_i^T (E_i Jp_j^T) A_j over every observation j of the track */
-          for (int64_t kj = k0; kj < k1; ++kj) {
-            const int cam_j = s->P->obs_camera[s->order[kj]];
-            int rbj[2], nj_[2], cj0[2];
-            obs_parts(s, cam_j, &rbj[0], &nj_[0], &rbj[1], &nj_[1]);
-            cj0[0] = 0;
-            cj0[1] = nj_[0];
-            const double* Jj = s->Jc + 2 * MAXC * kj;
-            const double* Jpj = s->Jp + 8 * kj;
-            double M[4] = {0, 0, 0, 0};
-            for (int a = 0; a < dp; ++a) {
-              M[0] += Ei[a] * Jpj[a];
-              M[1] += Ei[a] * Jpj[4 + a];
-              M[2] += Ei[4 + a] * Jpj[a];
-              M[3] += Ei[4 + a] * Jpj[4 + a];
-            }
-            for (int pj = 0; pj < 2; ++pj) {
-              if (rbj[pj] < 0) continue;
-              const int nj = nj_[pj];
-              const double* Aj0 = Jj + cj0[pj];
-              const double* Aj1 = Jj + MAXC + cj0[pj];
-              double* B = s->S + s->blk_off[block_lookup(s, rb[pi], rbj[pj])];
-              for (int b = 0; b < nj; ++b) {
-                const double t0 = M[0] * Aj0[b] + M[1] * Aj1[b];
-                const double t1 = M[2] * Aj0[b] + M[3] * Aj1[b];
-                for (int a = 0; a < ni; ++a) B[a * nj + b] -= Ai0[a] * t0 + Ai1[a] * t1;
-              }
+          for (int pj = 0; pj < 2; ++pj) {
+            if (rbj[pj] < 0) continue;
+            const int nj = nj_[pj];
+            const double* Aj0 = Jj + cj0[pj];
+            const double* Aj1 = Jj + MAXC + cj0[pj];
+            double* B = s->S + s->blk_off[col_blk[rbj[pj]]];
+            for (int b = 0; b < nj; ++b) {
+              const double t0 = M[0] * Aj0[b] + M[1] * Aj1[b];
+              const double t1 = M[2] * Aj0[b] + M[3] * Aj1[b];
+              for (int a = 0; a < ni; ++a) B[a * nj + b] -= Ai0[a] * t0 + Ai1[a] * t1;
             }
           }
         }
       }
+      for (int64_t q = s->row_ptr[bi]; q < s->row_ptr[bi + 1]; ++q) col_blk[s->blk_j[s->row_blk[q]]] = -1;
     }
+    free(col_blk);
   }
   /* LM diagonal on the camera blocks */
   for (int b = 0; b < s->nrb; ++b) {
@@ -1432,6 +1464,7 @@ static void free_state(ost* s) {
   free(s->Vinv); free(s->gp); free(s->tp);
   if (s->bmap.keys) hmap_free(&s->bmap);
   free(s->blk_i); free(s->blk_j); free(s->blk_off); free(s->row_ptr); free(s->row_blk);
+  free(s->rb_obs_ptr); free(s->rb_obs); free(s->k_pt);
   free(s->S); free(s->gc); free(s->rhs); free(s->yc); free(s->yp); free(s->dense);
 }
 
