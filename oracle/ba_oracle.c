@@ -622,46 +622,44 @@ static int64_t evaluate(ost* s, int with_jac, int apply_scale, double* cost, dou
   return bad;
 }
 
-/* squared column norms of the current (possibly scaled) Jacobian */
-static void column_sqnorms(ost* s, double* dc, double* dpn) {
-  memset(dc, 0, sizeof(double) * (size_t)s->nr);
-  memset(dpn, 0, sizeof(double) * (size_t)s->Np * s->dp);
-  for (int p = 0; p < s->Np; ++p) {
-    for (int64_t k = s->pt_ptr[p]; k < s->pt_ptr[p + 1]; ++k) {
-      const int cam = s->P->obs_camera[s->order[k]];
+/* Column sums over the observations, camera side: row by row over the row's observations (rb_obs: ascending sorted
+ * position, the order the one serial loop over all observations added them in -- same sums bit for bit, on every
+ * thread count), point side: point by point.  sq = 1: squared column norms of the current (possibly scaled) Jacobian;
+ * sq = 0: the gradient J^T r. */
+static void column_sums(ost* s, int sq, double* dc, double* dpn) {
+#pragma omp parallel for schedule(dynamic, 8)
+  for (int bi = 0; bi < s->nrb; ++bi) {
+    const int ni = s->rb_dim[bi];
+    double* out = dc + s->rb_off[bi];
+    for (int a = 0; a < ni; ++a) out[a] = 0.0;
+    for (int64_t q = s->rb_obs_ptr[bi]; q < s->rb_obs_ptr[bi + 1]; ++q) {
+      const int64_t k = s->rb_obs[q];
       int rb0, n0, rb1, n1;
-      obs_parts(s, cam, &rb0, &n0, &rb1, &n1);
-      const double* Jc = s->Jc + 2 * MAXC * k;
+      obs_parts(s, s->P->obs_camera[s->order[k]], &rb0, &n0, &rb1, &n1);
+      const double* Jc = s->Jc + 2 * MAXC * k + (rb0 == bi ? 0 : n0);
+      const double w0 = sq ? 0.0 : s->r[2 * k], w1 = sq ? 0.0 : s->r[2 * k + 1];
+      for (int a = 0; a < ni; ++a)
+        out[a] += sq ? Jc[a] * Jc[a] + Jc[MAXC + a] * Jc[MAXC + a] : Jc[a] * w0 + Jc[MAXC + a] * w1;
+    }
+  }
+#pragma omp parallel for schedule(dynamic, 1024)
+  for (int p = 0; p < s->Np; ++p) {
+    double* out = dpn + (int64_t)p * s->dp;
+    for (int a = 0; a < s->dp; ++a) out[a] = 0.0;
+    for (int64_t k = s->pt_ptr[p]; k < s->pt_ptr[p + 1]; ++k) {
       const double* Jp = s->Jp + 8 * k;
-      for (int a = 0; a < n0; ++a)
-        dc[s->rb_off[rb0] + a] += Jc[a] * Jc[a] + Jc[MAXC + a] * Jc[MAXC + a];
-      for (int a = 0; a < n1; ++a)
-        dc[s->rb_off[rb1] + a] += Jc[n0 + a] * Jc[n0 + a] + Jc[MAXC + n0 + a] * Jc[MAXC + n0 + a];
+      const double w0 = sq ? 0.0 : s->r[2 * k], w1 = sq ? 0.0 : s->r[2 * k + 1];
       for (int a = 0; a < s->dp; ++a)
-        dpn[(int64_t)p * s->dp + a] += Jp[a] * Jp[a] + Jp[4 + a] * Jp[4 + a];
+        out[a] += sq ? Jp[a] * Jp[a] + Jp[4 + a] * Jp[4 + a] : Jp[a] * w0 + Jp[4 + a] * w1;
     }
   }
 }
 
+/* squared column norms of the current (possibly scaled) Jacobian */
+static void column_sqnorms(ost* s, double* dc, double* dpn) { column_sums(s, 1, dc, dpn); }
+
 /* gradient J^T r (of the current Jacobian) -> gc [nr], gp [Np*dp] */
-static void gradient(ost* s, double* gc, double* gp) {
-  memset(gc, 0, sizeof(double) * (size_t)s->nr);
-  memset(gp, 0, sizeof(double) * (size_t)s->Np * s->dp);
-  for (int p = 0; p < s->Np; ++p) {
-    for (int64_t k = s->pt_ptr[p]; k < s->pt_ptr[p + 1]; ++k) {
-      const int cam = s->P->obs_camera[s->order[k]];
-      int rb0, n0, rb1, n1;
-      obs_parts(s, cam, &rb0, &n0, &rb1, &n1);
-      const double* Jc = s->Jc + 2 * MAXC * k;
-      const double* Jp = s->Jp + 8 * k;
-      const double r0 = s->r[2 * k], r1 = s->r[2 * k + 1];
-      for (int a = 0; a < n0; ++a) gc[s->rb_off[rb0] + a] += Jc[a] * r0 + Jc[MAXC + a] * r1;
-      for (int a = 0; a < n1; ++a)
-        gc[s->rb_off[rb1] + a] += Jc[n0 + a] * r0 + Jc[MAXC + n0 + a] * r1;
-      for (int a = 0; a < s->dp; ++a) gp[(int64_t)p * s->dp + a] += Jp[a] * r0 + Jp[4 + a] * r1;
-    }
-  }
-}
+static void gradient(ost* s, double* gc, double* gp) { column_sums(s, 0, gc, gp); }
 
 static int64_t block_lookup(const ost* s, int bi, int bj) {
   return hmap_get(&s->bmap, ((int64_t)bi << 32) | (int64_t)(uint32_t)bj);
