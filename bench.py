@@ -39,6 +39,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_MFMA_PEAK_TFLOPS = 78.6  # dense fp64 matrix peak of MI355X (product specification; MI355X_MICROARCH.md has no fp64 row)
 
 
 def algorithmic_bytes(cls: str, n_obs: int, n_cam: int, n_pts: int, dc: int, dp: int, nnzb: int, mf_frac: float = 0.0):
@@ -722,6 +723,20 @@ def main():
                 linear_solver=solver_policy(pa.num_cameras)[1],
                 ms_per_step=round(1e3 * ma["elapsed"] / max(ma["steps_run"], 1), 4), steps=ma["steps_run"],
                 value=pa.num_observations * ma["steps_run"] / ma["elapsed"], final_rmse=ma["summary"].final_rmse)
+            # the exact solve's own roofline: the factorisation is compute, not bytes (n^3 / 3 flops + two triangular
+            # solves per launch of the tile-dataflow Cholesky), priced against the dense fp64 MFMA peak
+            ic = abi.KERNEL_CLASS_NAMES.index("cholesky")
+            if ma["launches_p"][ic]:
+                n_s = pa.num_cameras * 9  # (every view has the 9-wide block in this workload)
+                fl = n_s ** 3 / 3.0 + 2.0 * n_s ** 2
+                us = 1e6 * ma["secs_p"][ic] / ma["launches_p"][ic]
+                out["variants"]["alamo570-synthetic"]["roofline"] = dict(
+                    bound="mfma", kernel="cholesky (gather + cdf::chol_dataflow_kernel: factorisation and both substitutions)",
+                    n=n_s, flops_per_launch=fl, avg_us=round(us, 2), launches=int(ma["launches_p"][ic]),
+                    achieved=round(fl / (us * 1e-6) / 1e12, 3), peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=round(fl / (us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 5),
+                    share_of_iteration=round(ma["secs_p"][ic] / max(sum(ma["secs_p"]), 1e-30), 4),
+                    measured="HIP events on the engine's stream, the untimed pass with every class timed")
             # BASELINE config 1 (49 views, 31.8 k observations): DENSE_SCHUR by the reference's policy; a problem
             # this small is bound by launch and read-back latency, not by bytes
             ml = measure("ladybug49", args.steps, args.warmup, False)
