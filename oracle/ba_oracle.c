@@ -482,6 +482,7 @@ typedef struct {
   int64_t* rb_obs_ptr; /* [nrb + 1] */
   int64_t* rb_obs;
   int* k_pt;           /* [No] */
+  int* row_lpt;        /* [nrb] block rows by descending number of observations: the order threads take them in */
   double* S;
   int64_t S_len;
   double *gc, *rhs, *yc, *yp;
@@ -627,8 +628,9 @@ static int64_t evaluate(ost* s, int with_jac, int apply_scale, double* cost, dou
  * thread count), point side: point by point.  sq = 1: squared column norms of the current (possibly scaled) Jacobian;
  * sq = 0: the gradient J^T r. */
 static void column_sums(ost* s, int sq, double* dc, double* dpn) {
-#pragma omp parallel for schedule(dynamic, 8)
-  for (int bi = 0; bi < s->nrb; ++bi) {
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int bq = 0; bq < s->nrb; ++bq) {
+    const int bi = s->row_lpt[bq];
     const int ni = s->rb_dim[bi];
     double* out = dc + s->rb_off[bi];
     for (int a = 0; a < ni; ++a) out[a] = 0.0;
@@ -745,6 +747,28 @@ static void build_structure(ost* s) {
     if (rb1 >= 0) s->rb_obs[at[rb1]++] = k;
   }
   free(at);
+  /* rows by descending work (counting sort on the observation count would do; nrb is small: insertion into buckets
+   * by a simple sort).  With dynamic scheduling the longest rows then start first and the last ones are short. */
+  s->row_lpt = (int*)malloc(sizeof(int) * (size_t)(s->nrb + 1));
+  for (int i = 0; i < s->nrb; ++i) s->row_lpt[i] = i;
+  {
+    /* stable merge sort by descending count (deterministic order for equal counts) */
+    int* tmp = (int*)malloc(sizeof(int) * (size_t)(s->nrb + 1));
+    for (int w = 1; w < s->nrb; w *= 2) {
+      for (int lo = 0; lo < s->nrb; lo += 2 * w) {
+        const int mid = lo + w < s->nrb ? lo + w : s->nrb, hi = lo + 2 * w < s->nrb ? lo + 2 * w : s->nrb;
+        int a = lo, b = mid, o = lo;
+        while (a < mid || b < hi) {
+          const int64_t ca = a < mid ? s->rb_obs_ptr[s->row_lpt[a] + 1] - s->rb_obs_ptr[s->row_lpt[a]] : -1;
+          const int64_t cb = b < hi ? s->rb_obs_ptr[s->row_lpt[b] + 1] - s->rb_obs_ptr[s->row_lpt[b]] : -1;
+          if (b >= hi || (a < mid && ca >= cb)) tmp[o++] = s->row_lpt[a++];
+          else tmp[o++] = s->row_lpt[b++];
+        }
+      }
+      memcpy(s->row_lpt, tmp, sizeof(int) * (size_t)s->nrb);
+    }
+    free(tmp);
+  }
 }
 
 /* small SPD inverse via Cholesky (n <= 4).  Returns 0 if not positive definite. */
@@ -840,7 +864,8 @@ static int build_reduced(ost* s, double radius) {
     int64_t* col_blk = (int64_t*)malloc(sizeof(int64_t) * (size_t)(s->nrb + 1));
     for (int i = 0; i < s->nrb; ++i) col_blk[i] = -1;
 #pragma omp for schedule(dynamic, 1)
-    for (int bi = 0; bi < s->nrb; ++bi) {
+    for (int bq = 0; bq < s->nrb; ++bq) {
+      const int bi = s->row_lpt[bq];
       for (int64_t q = s->row_ptr[bi]; q < s->row_ptr[bi + 1]; ++q) col_blk[s->blk_j[s->row_blk[q]]] = s->row_blk[q];
       const int ni = s->rb_dim[bi];
       double* rhs = s->rhs + s->rb_off[bi];
@@ -1462,7 +1487,7 @@ static void free_state(ost* s) {
   free(s->Vinv); free(s->gp); free(s->tp);
   if (s->bmap.keys) hmap_free(&s->bmap);
   free(s->blk_i); free(s->blk_j); free(s->blk_off); free(s->row_ptr); free(s->row_blk);
-  free(s->rb_obs_ptr); free(s->rb_obs); free(s->k_pt);
+  free(s->rb_obs_ptr); free(s->rb_obs); free(s->k_pt); free(s->row_lpt);
   free(s->S); free(s->gc); free(s->rhs); free(s->yc); free(s->yp); free(s->dense);
 }
 
