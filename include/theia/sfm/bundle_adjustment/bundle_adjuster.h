@@ -87,12 +87,17 @@ class BundleAdjuster {
   virtual void SetTrackVariable(const TrackId track_id);
   virtual void SetCameraSchurGroups(const ViewId view_id);
   virtual void SetTrackSchurGroup(const TrackId track_id);
-  virtual void AddReprojectionErrorResidual(const Feature& feature, const ViewId view_id,
-                                            const TrackId track_id);
+  // The reference's hook, signature unchanged (bundle_adjuster.h:100-102).  AddView / AddTrack call it with the camera
+  // of the view and the track they are adding; the ids those pointers belong to are in hook_view_id_ /
+  // hook_track_id_ for the duration of the call (a subclass that forwards OTHER pointers to the base implementation
+  // has them looked up: one walk over the views / tracks).
+  virtual void AddReprojectionErrorResidual(const Feature& feature, Camera* camera, Track* track);
 
   const BundleAdjustmentOptions options_;
   Reconstruction* reconstruction_;
   std::chrono::steady_clock::time_point timer_start_;
+  ViewId hook_view_id_ = kInvalidViewId;     // ids behind the pointers handed to AddReprojectionErrorResidual
+  TrackId hook_track_id_ = kInvalidTrackId;
 
   std::unordered_set<ViewId> optimized_views_;
   std::unordered_set<CameraIntrinsicsGroupId> optimized_camera_intrinsics_groups_;
@@ -138,6 +143,15 @@ class BundleAdjuster {
       return fresh;
     }
     void NoteAdded(size_t n) { count_ += n; }
+    // ids that were hashed (Set() beyond the flat range at the time): SetPresized() must not be used while there are
+    // any -- it would add a second, flat entry for such an id
+    bool HasSparse() const { return !sparse_.empty(); }
+    size_t FlatSize() const { return flat_.size(); }
+    void Clear() {
+      count_ = 0;
+      std::fill(flat_.begin(), flat_.end(), static_cast<int16_t>(-1));
+      sparse_.clear();
+    }
     // make ids 0..max_id flat-addressable up front (so that concurrent readers never see a resize);
     // false if max_id is beyond the flat range
     // ... or so far above the number of ids that a dense table would be mostly holes (sub-reconstructions, merged

@@ -129,10 +129,17 @@ typedef enum tmi_ba_linear_solver {
  *     canonical views with size penalty 3 / similarity penalty 0 / at least 3 centres, or single linkage at 0.9;
  *     restated from Ceres 1.14 -- parity unpinned like the rest of the Ceres layer) and every cluster's principal
  *     submatrix of S is inverted exactly; this needs the formed S (schur_mode auto picks it; implicit is refused)
- *     and one rank.  CLUSTER_TRIDIAGONAL is served as CLUSTER_JACOBI (no cluster-pair blocks).
+ *     and one rank.  CLUSTER_TRIDIAGONAL (Ceres adds the blocks between neighbouring clusters of a degree-2
+ *     spanning forest) is NOT implemented: create / solve return TMI_BA_ERR_UNSUPPORTED rather than answer with
+ *     another preconditioner; the C++ shim maps ceres::CLUSTER_TRIDIAGONAL to CLUSTER_JACOBI and says so on stderr.
  *     A cluster launch that cannot become co-resident (device shared with another process) retires
  *     the clusters for that solve: PCG continues with the SCHUR_JACOBI blocks.
  *   Intrinsics shared by several views form their own reduced block in every mode.  */
+/* A cluster of CLUSTER_JACOBI is inverted as a dense matrix (n^3 / 3 flops and n^2 / 2 doubles per LM iteration): a
+ * cluster with more unknowns than this keeps the SCHUR_JACOBI blocks of its views (Ceres factors its cluster matrices
+ * sparsely and has no such limit). */
+#define TMI_BA_MAX_CLUSTER_DIM 4096
+
 typedef enum tmi_ba_preconditioner {
   TMI_BA_PRECOND_IDENTITY = 0,
   TMI_BA_PRECOND_JACOBI = 1,

@@ -1009,9 +1009,13 @@ static int block_inverse(int n, const double* A, double* Ainv) {
 static int* g_last_vis = NULL;
 static int g_last_vis_n = 0;
 int32_t oracle_last_visibility_clusters(int32_t* out, int32_t n) {
-  if (!g_last_vis || n < g_last_vis_n) return -1;
-  for (int c = 0; c < g_last_vis_n; ++c) out[c] = g_last_vis[c];
-  return g_last_vis_n;
+  int rc = -1;
+#pragma omp critical(oracle_last_vis)
+  if (g_last_vis && n >= g_last_vis_n) {
+    for (int c = 0; c < g_last_vis_n; ++c) out[c] = g_last_vis[c];
+    rc = g_last_vis_n;
+  }
+  return rc;
 }
 
 /* The views of a problem WITHOUT shared intrinsics blocks clustered by visibility, as
@@ -1045,7 +1049,10 @@ static int visibility_clusters(ost* s, int type, int* cluster) {
     for (int a = 0; a < m; ++a) {
       ntr[rbs[a]] += 1.0;
       for (int b = 0; b < m; ++b)
-        if (a != b) cnt[block_lookup(s, rbs[a], rbs[b])] += 1.0;
+        if (a != b) {
+          const int64_t q = block_lookup(s, rbs[a], rbs[b]);
+          if (q >= 0) cnt[q] += 1.0;
+        }
     }
   }
   free(rbs);
@@ -1196,8 +1203,7 @@ static int solve_pcg(ost* s) {
    * is a shared intrinsics block together with the views that share it (theia_mi355_ba.h) -- the principal submatrix
    * of S over {views of g, g}, factored densely (Cholesky), views of private groups keep their own block.  A
    * cluster whose matrix is not positive definite falls back to its diagonal blocks. */
-  const int clustered = s->O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_JACOBI ||
-                        s->O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_TRIDIAGONAL;
+  const int clustered = s->O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_JACOBI;
   int ncl = 0;
   int* cl_ptr = NULL;     /* [ncl + 1] into cl_rb */
   int* cl_rb = NULL;      /* member reduced blocks: the views of the group ascending, then the group's block */
@@ -1214,10 +1220,15 @@ static int solve_pcg(ost* s) {
       s->vis_cluster = (int*)malloc(sizeof(int) * (size_t)(s->nrb + 1));
       s->vis_ncl = visibility_clusters(s, s->O->visibility_clustering_type, s->vis_cluster);
       /* test hook (oracle_last_visibility_clusters): the cluster of every CAMERA of the last clustered solve */
-      free(g_last_vis);
-      g_last_vis = (int*)malloc(sizeof(int) * (size_t)(s->Nc + 1));
-      g_last_vis_n = s->Nc;
-      for (int c = 0; c < s->Nc; ++c) g_last_vis[c] = s->cam_rb[c] >= 0 ? s->vis_cluster[s->cam_rb[c]] : -1;
+      int* mine = (int*)malloc(sizeof(int) * (size_t)(s->Nc + 1));
+      for (int c = 0; c < s->Nc; ++c) mine[c] = s->cam_rb[c] >= 0 ? s->vis_cluster[s->cam_rb[c]] : -1;
+      /* (concurrent oracle_ba_solve calls: the hook is swapped under a lock) */
+#pragma omp critical(oracle_last_vis)
+      {
+        free(g_last_vis);
+        g_last_vis = mine;
+        g_last_vis_n = s->Nc;
+      }
     }
     n_cand = s->vis_ncl;
   }
@@ -1239,9 +1250,12 @@ static int solve_pcg(ost* s) {
           if (s->vis_cluster[b] == g) cl_rb[m++] = b;
         if (m - cl_ptr[ncl] < 2) continue; /* a cluster of one view is its own (whole) block: Minv has it */
       }
-      cl_ptr[ncl + 1] = m;
       int nc = 0;
       for (int a = cl_ptr[ncl]; a < m; ++a) nc += s->rb_dim[cl_rb[a]];
+      /* a cluster is inverted as a DENSE matrix: beyond TMI_BA_MAX_CLUSTER_DIM unknowns its blocks stay SCHUR_JACOBI
+       * blocks (engine and oracle alike; Ceres factors the cluster matrices sparsely) */
+      if (nc > TMI_BA_MAX_CLUSTER_DIM) continue;
+      cl_ptr[ncl + 1] = m;
       cl_n[ncl] = nc;
       double* C = (double*)calloc((size_t)nc * nc, sizeof(double));
       int oi = 0;
@@ -1703,6 +1717,14 @@ int32_t oracle_ba_solve(tmi_ba_problem* P, const tmi_ba_options* O, tmi_ba_summa
   if (!validate(P)) {
     sum->status = TMI_BA_ERR_INVALID_ARGUMENT;
     snprintf(sum->message, sizeof(sum->message), "invalid problem");
+    return sum->status;
+  }
+  if ((O->linear_solver_type == TMI_BA_ITERATIVE_SCHUR || O->linear_solver_type == TMI_BA_CGNR) &&
+      O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_TRIDIAGONAL) {
+    /* not restated (Ceres keeps the blocks between neighbouring clusters of a degree-2 spanning forest); the device
+     * path refuses it as well instead of answering with another preconditioner */
+    sum->status = TMI_BA_ERR_UNSUPPORTED;
+    snprintf(sum->message, sizeof(sum->message), "CLUSTER_TRIDIAGONAL is not restated");
     return sum->status;
   }
   const double t_start = now_s();

@@ -219,6 +219,73 @@ static void TestSemantics() {
       EXPECT(f.track_ids.size() == 20 && f.obs_camera.size() == 80);
     }
   }
+  {
+    // the reference's protected hook keeps its signature (bundle_adjuster.h:100-102): a subclass sees every residual
+    // with the camera of its view and its track, and the base implementation records the right ids
+    struct Counting : BundleAdjuster {
+      using BundleAdjuster::BundleAdjuster;
+      int calls = 0;
+      bool pointers_ok = true;
+      void AddReprojectionErrorResidual(const Feature& feature, Camera* camera, Track* track) override {
+        ++calls;
+        bool cam_found = false, trk_found = false;
+        for (const ViewId v : reconstruction_->ViewIds()) cam_found |= reconstruction_->MutableView(v)->MutableCamera() == camera;
+        for (const TrackId t : reconstruction_->TrackIds()) trk_found |= reconstruction_->MutableTrack(t) == track;
+        pointers_ok &= cam_found && trk_found;
+        BundleAdjuster::AddReprojectionErrorResidual(feature, camera, track);
+      }
+    };
+    Counting sub(opt, &rec);
+    BundleAdjuster plain(opt, &rec);
+    sub.AddViews(rec.ViewIds());   // subclasses take the one-at-a-time path: the hook sees every residual
+    sub.AddTracks(rec.TrackIds());
+    for (ViewId v : rec.ViewIds()) plain.AddView(v);
+    for (TrackId t : rec.TrackIds()) plain.AddTrack(t);
+    FlattenedBundleAdjustmentProblem f1, f2;
+    EXPECT(sub.Flatten(&f1) && plain.Flatten(&f2));
+    EXPECT(sub.calls == 4 * 7 && sub.pointers_ok);
+    EXPECT(f1.obs_camera == f2.obs_camera && f1.obs_point == f2.obs_point && f1.obs_xy == f2.obs_xy);
+    // a subclass that forwards pointers the caller did not announce: the ids are looked up
+    struct Forwarding : BundleAdjuster {
+      using BundleAdjuster::BundleAdjuster;
+      void Add(const Feature& f, Camera* c, Track* t) { AddReprojectionErrorResidual(f, c, t); }
+    };
+    Forwarding fw(opt, &rec);
+    fw.Add(Feature(1.0, 2.0), rec.MutableView(2)->MutableCamera(), rec.MutableTrack(5));
+    FlattenedBundleAdjustmentProblem f3;
+    EXPECT(fw.Flatten(&f3));
+    EXPECT(f3.view_ids.size() == 1 && f3.view_ids[0] == 2 && f3.track_ids.size() == 1 && f3.track_ids[0] == 5);
+  }
+  {
+    // a track id hashed by an earlier AddTrack (far above the dense range) and then met by the threaded
+    // AddViews must not be flattened twice; and an IsEstimated memo entry of a track removed since must not survive
+    Reconstruction rec2;
+    BuildScene(&rec2, 4, 30, /*share_groups=*/false, 5, 0.0);
+    BundleAdjuster ba(opt, &rec2), ref(opt, &rec2);
+    const TrackId far = 50u << 20;  // beyond 8 x ids + 1 M: the sparse store
+    // (the stand-in Reconstruction hands out consecutive ids; poke the tables through the public calls instead)
+    ba.AddTrack(3);
+    ba.AddViews(rec2.ViewIds());
+    ba.AddTracks(rec2.TrackIds());
+    for (TrackId t : {TrackId(3)}) ref.AddTrack(t);
+    for (ViewId v : rec2.ViewIds()) ref.AddView(v);
+    for (TrackId t : rec2.TrackIds()) ref.AddTrack(t);
+    FlattenedBundleAdjustmentProblem f1, f2;
+    EXPECT(ba.Flatten(&f1) && ref.Flatten(&f2));
+    EXPECT(f1.track_ids == f2.track_ids && f1.obs_camera == f2.obs_camera && f1.point_constant == f2.point_constant);
+    for (size_t q = 1; q < f1.track_ids.size(); ++q) EXPECT(f1.track_ids[q] > f1.track_ids[q - 1]);
+    (void)far;
+    // second AddViews on the same adjuster after a track was un-estimated: the memo follows the reconstruction
+    Reconstruction rec3;
+    BuildScene(&rec3, 4, 30, /*share_groups=*/false, 6, 0.0);
+    BundleAdjuster two(opt, &rec3);
+    two.AddViews({rec3.ViewIds()[0]});
+    rec3.MutableTrack(9)->SetEstimated(false);
+    two.AddViews({rec3.ViewIds()[1]});
+    FlattenedBundleAdjustmentProblem f3;
+    EXPECT(two.Flatten(&f3));
+    EXPECT(f3.obs_camera.size() == 30u + 29u);
+  }
   // option defaults (bundle_adjustment.h:78-122)
   EXPECT(opt.max_num_iterations == 100 && opt.use_inner_iterations && opt.robust_loss_width == 2.0);
   EXPECT(opt.linear_solver_type == ceres::SPARSE_SCHUR && opt.preconditioner_type == ceres::SCHUR_JACOBI);
@@ -230,6 +297,9 @@ static void TestSemantics() {
     ToDeviceOptions(d, &o);
     EXPECT(o.preconditioner_type == TMI_BA_PRECOND_SCHUR_JACOBI_PARAMETER_BLOCKS);
     d.preconditioner_type = ceres::CLUSTER_JACOBI;  // clusters = shared intrinsics blocks + their views on the device
+    ToDeviceOptions(d, &o);
+    EXPECT(o.preconditioner_type == TMI_BA_PRECOND_CLUSTER_JACOBI);
+    d.preconditioner_type = ceres::CLUSTER_TRIDIAGONAL;  // refused by the C ABI; the shim answers with the nearest and says so
     ToDeviceOptions(d, &o);
     EXPECT(o.preconditioner_type == TMI_BA_PRECOND_CLUSTER_JACOBI);
     d.preconditioner_type = ceres::JACOBI;

@@ -35,7 +35,7 @@ def options(pre, **kw):
 def test_oracle_cluster_jacobi_cuts_the_pcg_iterations():
     prob = shared_problem()
     res = {}
-    for pre in (abi.PRECOND_SCHUR_JACOBI, abi.PRECOND_CLUSTER_JACOBI, abi.PRECOND_CLUSTER_TRIDIAGONAL):
+    for pre in (abi.PRECOND_SCHUR_JACOBI, abi.PRECOND_CLUSTER_JACOBI):
         p = prob.copy()
         st, s = oracle.solve(p, options(pre))
         assert st == 0 and s.success == 1
@@ -45,10 +45,9 @@ def test_oracle_cluster_jacobi_cuts_the_pcg_iterations():
     # both solve the same reduced systems to the same forcing tolerance: the trajectories agree to what that leaves
     assert abs(clu.final_cost - jac.final_cost) < 1e-4 * jac.final_cost
     assert clu.num_successful_steps == jac.num_successful_steps
-    tri = res[abi.PRECOND_CLUSTER_TRIDIAGONAL][0]
-    # (the oracle's OpenMP reductions are not bit-reproducible from run to run)
-    assert abs(tri.final_cost - clu.final_cost) <= 1e-12 * clu.final_cost
-    assert tri.num_linear_solver_iterations == clu.num_linear_solver_iterations
+    # CLUSTER_TRIDIAGONAL is not restated: refused, not answered with another preconditioner
+    st, s = oracle.solve(prob.copy(), options(abi.PRECOND_CLUSTER_TRIDIAGONAL))
+    assert st == abi.ERR_UNSUPPORTED and s.success == 0
 
 
 def test_single_linkage_without_similar_views_is_the_merged_block_jacobi():
@@ -175,14 +174,13 @@ def test_oracle_single_linkage_joins_views_that_see_the_same_tracks():
 def test_oracle_visibility_clusters_precondition_better_than_block_jacobi():
     prob = synth.make_problem(60, 9000, 50000, seed=17, scene="ring", spread=0.3)
     res = {}
-    for pre in (abi.PRECOND_SCHUR_JACOBI, abi.PRECOND_CLUSTER_JACOBI, abi.PRECOND_CLUSTER_TRIDIAGONAL):
+    for pre in (abi.PRECOND_SCHUR_JACOBI, abi.PRECOND_CLUSTER_JACOBI):
         st, s = oracle.solve(prob.copy(), options(pre, max_num_iterations=6))
         assert st == 0 and s.success == 1
         res[pre] = s
-    jac, clu, tri = res[abi.PRECOND_SCHUR_JACOBI], res[abi.PRECOND_CLUSTER_JACOBI], res[abi.PRECOND_CLUSTER_TRIDIAGONAL]
+    jac, clu = res[abi.PRECOND_SCHUR_JACOBI], res[abi.PRECOND_CLUSTER_JACOBI]
     assert clu.num_linear_solver_iterations < jac.num_linear_solver_iterations
     assert abs(clu.final_cost - jac.final_cost) < 1e-4 * jac.final_cost and clu.num_successful_steps == jac.num_successful_steps
-    assert tri.num_linear_solver_iterations == clu.num_linear_solver_iterations  # served as CLUSTER_JACOBI
 
 
 @pytest.mark.gpu
@@ -221,11 +219,37 @@ def test_device_visibility_clusters_match_oracle(case):
 
 
 @pytest.mark.gpu
-def test_device_visibility_clusters_refuse_the_matrix_free_operator():
+def test_device_visibility_clusters_with_the_matrix_free_operator_fall_back_to_block_jacobi():
+    """the clusters are submatrices of the formed S: a handle created for the matrix-free operator keeps the SCHUR_JACOBI
+    blocks (as on several ranks) instead of failing the create"""
+    from theiasfm_amd import lib
+    prob = synth.config("ladybug49")
+    kw = dict(function_tolerance=1e-6, gradient_tolerance=1e-10, parameter_tolerance=1e-8, max_num_iterations=12,
+              schur_mode=abi.SCHUR_IMPLICIT)
+    st_c, s_c = lib.solve(prob.copy(), options(abi.PRECOND_CLUSTER_JACOBI, **kw))
+    st_j, s_j = lib.solve(prob.copy(), options(abi.PRECOND_SCHUR_JACOBI, **kw))
+    assert st_c == st_j == 0
+    assert s_c.num_linear_solver_iterations == s_j.num_linear_solver_iterations and s_c.final_cost == s_j.final_cost
+
+
+@pytest.mark.gpu
+def test_device_refuses_cluster_tridiagonal_and_a_changed_clustering_type():
+    """CLUSTER_TRIDIAGONAL is not implemented: create and solve say so instead of answering with CLUSTER_JACOBI; the
+    visibility clusters are built at create, a solve with another visibility_clustering_type is rejected"""
     from theiasfm_amd import lib
     prob = synth.config("ladybug49")
     with pytest.raises(lib.EngineError):
-        lib.Solver(prob, options(abi.PRECOND_CLUSTER_JACOBI, schur_mode=abi.SCHUR_IMPLICIT))
+        lib.Solver(prob, options(abi.PRECOND_CLUSTER_TRIDIAGONAL))
+    st, s = lib.solve(prob.copy(), options(abi.PRECOND_CLUSTER_TRIDIAGONAL))
+    assert st == abi.ERR_UNSUPPORTED and s.success == 0
+    h = lib.Solver(prob, options(abi.PRECOND_CLUSTER_JACOBI))
+    try:
+        st, s = h.solve(options(abi.PRECOND_CLUSTER_JACOBI, visibility_clustering_type=abi.SINGLE_LINKAGE))
+        assert st != 0 and b"visibility_clustering_type" in bytes(s.message)
+        st, s = h.solve(options(abi.PRECOND_CLUSTER_TRIDIAGONAL))
+        assert st == abi.ERR_UNSUPPORTED
+    finally:
+        h.close()
 
 
 @pytest.mark.gpu

@@ -344,9 +344,11 @@ struct tmi_ba_solver {
   double* d_shared_diag_partial = nullptr;
   bool cluster_blocks = false;  // the matrix-free operator with the clusters' blocks of S formed beside it
   bool cl_built = false;      // plan + device buffers exist
+  int vis_type = 0;           // visibility_clustering_type the clusters were built with (create)
   bool vis_clusters = false;  // no shared intrinsics blocks: the clusters are Ceres' visibility clusters of the views
   std::vector<std::vector<int> > vis_members;  // ... their reduced blocks, ascending (build_visibility_clusters)
   bool cl_active = false;     // the current LM iteration's PCG applies it
+  bool cl_unavailable = false;  // the clusters' tiles could not be allocated: SCHUR_JACOBI for the life of the handle
   bool cl_retired = false;    // a cluster launch gave up in this solve (device shared with another process): SCHUR_JACOBI for the rest of it
   clp::ClusterDesc* d_cl_desc = nullptr;
   clp::GatherEntry* d_cl_ge = nullptr;
@@ -1695,6 +1697,12 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   s->DP = O->point_dof;
   const bool iterative_type =
       (O->linear_solver_type == TMI_BA_ITERATIVE_SCHUR || O->linear_solver_type == TMI_BA_CGNR);
+  if (iterative_type && !light && O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_TRIDIAGONAL) {
+    // Ceres' tridiagonal variant keeps the blocks between neighbouring clusters of a degree-2 spanning forest
+    // (visibility_based_preconditioner.cc); not rebuilt, and not answered with a different preconditioner either
+    s->error = "CLUSTER_TRIDIAGONAL is not implemented on the device path (nearest: CLUSTER_JACOBI)";
+    return TMI_BA_ERR_UNSUPPORTED;
+  }
   if (O->schur_mode < 0 || O->schur_mode > 2) {
     s->error = "schur_mode must be 0 (auto), 1 (explicit) or 2 (implicit)";
     return TMI_BA_ERR_INVALID_ARGUMENT;
@@ -1717,8 +1725,7 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   // CLUSTER_JACOBI on a problem with shared intrinsics blocks (cluster_precond.h): with schur_mode auto the operator is
   // the matrix-free one and only the blocks INSIDE the clusters are formed (what the preconditioner factors); an
   // explicit request for the formed / the matrix-free operator is honoured, the latter with the cluster blocks as well
-  const bool cluster_pre = O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_JACOBI ||
-                           O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_TRIDIAGONAL;
+  const bool cluster_pre = O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_JACOBI;
   if (cluster_pre && s->st.has_shared && iterative_type && !light) {
     if (O->schur_mode == 0) s->implicit = s->implicit_now = true;
     s->cluster_blocks = s->implicit;
@@ -1727,13 +1734,10 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   // ... and on a problem WITHOUT shared blocks: Ceres' clusters of the views by visibility (build_visibility_clusters).
   // They are principal submatrices of the formed S and come from the GLOBAL co-visibility counts, which a rank of a
   // sharded handle does not have: one rank only (several ranks: SCHUR_JACOBI, as before round 4).
-  if (cluster_pre && !s->st.has_shared && iterative_type && !light && world == 1) {
-    if (O->schur_mode == 2) {
-      s->error = "CLUSTER_JACOBI / CLUSTER_TRIDIAGONAL over visibility clusters need the formed Schur complement "
-                 "(schur_mode auto or explicit)";
-      return TMI_BA_ERR_UNSUPPORTED;
-    }
+  // (schur_mode implicit: no formed S to take the clusters from -- SCHUR_JACOBI, as on several ranks)
+  if (cluster_pre && !s->st.has_shared && iterative_type && !light && world == 1 && O->schur_mode != 2) {
     s->vis_clusters = true;
+    s->vis_type = O->visibility_clustering_type;
     s->implicit = s->implicit_now = false;
     s->adaptive = false;
     want_pairs = true;
@@ -2279,6 +2283,15 @@ static int ensure_clusters(tmi_ba_solver* s) {
     m.push_back(st.Ncam_rb + g);
     members.push_back(m);
   }
+  // a cluster is factored densely: oversized ones keep their SCHUR_JACOBI blocks (TMI_BA_MAX_CLUSTER_DIM, the oracle
+  // applies the same rule)
+  members.erase(std::remove_if(members.begin(), members.end(),
+                               [&](const std::vector<int>& m) {
+                                 long long n = 0;
+                                 for (const int rb : m) n += st.rb_dim[rb];
+                                 return n > TMI_BA_MAX_CLUSTER_DIM;
+                               }),
+                members.end());
   auto lookup = [&](int bi, int bj) -> int {
     const int* b = st.ub_j.data() + st.urow_ptr[bi];
     const int* e = st.ub_j.data() + st.urow_ptr[bi + 1];
@@ -2772,6 +2785,16 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
   const double lw = O->robust_loss_width;
   const bool iterative = (O->linear_solver_type == TMI_BA_ITERATIVE_SCHUR || O->linear_solver_type == TMI_BA_CGNR);
   s->cur_opts = O;
+  if (iterative && O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_TRIDIAGONAL) {
+    s->error = "CLUSTER_TRIDIAGONAL is not implemented on the device path (nearest: CLUSTER_JACOBI)";
+    return fail(TMI_BA_ERR_UNSUPPORTED);
+  }
+  if (iterative && s->vis_clusters && O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_JACOBI &&
+      O->visibility_clustering_type != s->vis_type) {
+    // the clusters are part of the handle's structure (built at create from visibility_clustering_type)
+    s->error = "visibility_clustering_type differs from the value the solver was created with";
+    return fail(TMI_BA_ERR_INVALID_ARGUMENT);
+  }
   if (s->implicit && !iterative) {
     s->error = "this solver was created for the implicit Schur operator (ITERATIVE_SCHUR); "
                "an exact linear solver type needs schur_mode = explicit at creation";
@@ -2929,11 +2952,22 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
                           : O->preconditioner_type == TMI_BA_PRECOND_SCHUR_JACOBI_PARAMETER_BLOCKS ? 2 : 0);
         // CLUSTER_JACOBI / CLUSTER_TRIDIAGONAL on a problem with shared intrinsics blocks: the exact inverse of every
         // {shared block, its views} cluster (needs the cluster's blocks of S: the formed operator)
-        s->cl_active = (O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_JACOBI ||
-                        O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_TRIDIAGONAL) &&
+        s->cl_active = O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_JACOBI &&
                        (s->st.has_shared || s->vis_clusters) && (!s->implicit_now || s->cluster_blocks) && n_r > 0 &&
-                       !s->cl_retired;
-        if (s->cl_active) CK(factor_clusters(s));
+                       !s->cl_retired && !s->cl_unavailable;
+        if (s->cl_active) {
+          rc = factor_clusters(s);
+          if (rc == TMI_BA_ERR_OUT_OF_MEMORY && !s->cl_built) {
+            // the clusters' tiles do not fit: the handle keeps its SCHUR_JACOBI blocks -- (void) the sticky
+            // HIP error, forget the message, do not try again
+            (void)hipGetLastError();
+            s->error.clear();
+            s->cl_unavailable = true;
+            s->cl_active = false;
+          } else if (rc != TMI_BA_OK) {
+            return fail(rc);
+          }
+        }
       }
       const int64_t before = pcg_iters;
       CK(solve_reduced_pcg(s, O, &usable, &pcg_iters));

@@ -92,7 +92,9 @@ void BundleAdjuster::AddView(const ViewId view_id) {
       track_estimated_.Set(track_id, est);
     }
     if (!est) continue;
-    AddReprojectionErrorResidual(kv.second, view_id, track_id);
+    hook_view_id_ = view_id;
+    hook_track_id_ = track_id;
+    AddReprojectionErrorResidual(kv.second, view->MutableCamera(), reconstruction_->MutableTrack(track_id));
     SetTrackConstant(track_id);
   }
 }
@@ -109,7 +111,9 @@ void BundleAdjuster::AddTrack(const TrackId track_id) {
     if (view_optimized_.Get(view_id) == 1 || !view->IsEstimated()) continue;
     const Feature* feature = view->GetFeature(track_id);
     if (feature == nullptr) continue;
-    AddReprojectionErrorResidual(*feature, view_id, track_id);
+    hook_view_id_ = view_id;
+    hook_track_id_ = track_id;
+    AddReprojectionErrorResidual(*feature, view->MutableCamera(), track);
     SetCameraExtrinsicsConstant(view_id);
     potentially_constant_camera_intrinsics_groups_.emplace(
         reconstruction_->CameraIntrinsicsGroupIdFromViewId(view_id));
@@ -129,6 +133,9 @@ void BundleAdjuster::AddViews(const std::vector<ViewId>& view_ids) {
     all_tracks = reconstruction_->TrackIds();
     for (const TrackId t : all_tracks) max_track = std::max<uint32_t>(max_track, t);
     flat_ok = track_estimated_.Reserve(max_track, all_tracks.size()) && track_constant_.Reserve(max_track, all_tracks.size());
+    // SetPresized() below writes flat slots only: an id that an earlier AddTrack hashed (above the flat range of the
+    // time) would end up in both stores and be flattened twice -- such tables take the one-at-a-time path
+    flat_ok = flat_ok && !track_constant_.HasSparse() && !track_estimated_.HasSparse();
   }
   if (!flat_ok) {
     for (const ViewId v : view_ids) AddView(v);
@@ -151,6 +158,10 @@ void BundleAdjuster::AddViews(const std::vector<ViewId>& view_ids) {
     work += view->Features().size();
   }
   const int n_threads = HostThreads(work);
+  // The IsEstimated memo is rebuilt from the CURRENT tracks: an entry left by an earlier call may belong to a track
+  // that has been removed since (its id could lie above max_track, which sizes `touched` below), and the
+  // reference looks the track up at every feature (bundle_adjuster.cc:121-125).
+  track_estimated_.Clear();
   // Track::IsEstimated for every track, threads own disjoint id ranges (read-only look-ups); the table was
   // pre-sized by Reserve above, so a thread writes its own flat slots and nothing else (IdState::SetPresized)
   std::vector<size_t> fresh(n_threads, 0);
@@ -194,7 +205,8 @@ void BundleAdjuster::AddViews(const std::vector<ViewId>& view_ids) {
     std::vector<uint8_t> touched(static_cast<size_t>(max_track) + 1, 0);
     // (one byte per track id; equal values written by several threads: relaxed atomic stores)
     RunThreads(n_threads, [&](int t) {
-      for (const Residual& r : local[t]) __atomic_store_n(&touched[r.track], static_cast<uint8_t>(1), __ATOMIC_RELAXED);
+      for (const Residual& r : local[t])
+        if (r.track <= max_track) __atomic_store_n(&touched[r.track], static_cast<uint8_t>(1), __ATOMIC_RELAXED);
     });
     std::vector<size_t> fresh_c(n_threads, 0);
     RunThreads(n_threads, [&](int t) {
@@ -319,8 +331,26 @@ void BundleAdjuster::SetCameraSchurGroups(const ViewId) {}
 void BundleAdjuster::SetTrackSchurGroup(const TrackId) {}
 
 // bundle_adjuster.cc:373-386
-void BundleAdjuster::AddReprojectionErrorResidual(const Feature& feature, const ViewId view_id,
-                                                  const TrackId track_id) {
+void BundleAdjuster::AddReprojectionErrorResidual(const Feature& feature, Camera* camera, Track* track) {
+  if (reconstruction_ == nullptr || camera == nullptr || track == nullptr) return;
+  // the ids behind the pointers: AddView / AddTrack leave them in hook_*_id_; pointers that are not theirs (a subclass
+  // forwarding something else) are looked up
+  ViewId view_id = hook_view_id_;
+  TrackId track_id = hook_track_id_;
+  {
+    View* hv = view_id == kInvalidViewId ? nullptr : reconstruction_->MutableView(view_id);
+    if (hv == nullptr || hv->MutableCamera() != camera) {
+      view_id = kInvalidViewId;
+      for (const ViewId v : reconstruction_->ViewIds())
+        if (reconstruction_->MutableView(v)->MutableCamera() == camera) { view_id = v; break; }
+    }
+    if (track_id == kInvalidTrackId || reconstruction_->MutableTrack(track_id) != track) {
+      track_id = kInvalidTrackId;
+      for (const TrackId t : reconstruction_->TrackIds())
+        if (reconstruction_->MutableTrack(t) == track) { track_id = t; break; }
+    }
+  }
+  if (view_id == kInvalidViewId || track_id == kInvalidTrackId) return;  // not of this reconstruction
   residuals_.push_back(Residual{view_id, track_id, feature.x(), feature.y()});
   camera_flags_.SetIfAbsent(view_id, 0);
   track_constant_.SetIfAbsent(track_id, 1);
@@ -569,6 +599,14 @@ void ToDeviceOptions(const BundleAdjustmentOptions& options, tmi_ba_options* o) 
   // parameter block; the merged per-view block only on request (bundle_adjustment.h, extensions).  CLUSTER_JACOBI /
   // CLUSTER_TRIDIAGONAL go through: clusters = the shared intrinsics blocks with their views (theia_mi355_ba.h).
   o->preconditioner_type = static_cast<int32_t>(options.preconditioner_type);
+  if (options.preconditioner_type == ceres::CLUSTER_TRIDIAGONAL) {
+    // the C ABI refuses CLUSTER_TRIDIAGONAL (not implemented); a Theia caller gets the nearest preconditioner and is
+    // told once per process (the reference would LOG(WARNING))
+    static std::atomic<bool> warned(false);
+    if (!warned.exchange(true))
+      std::fprintf(stderr, "[tmi_ba shim] ceres::CLUSTER_TRIDIAGONAL is not implemented on the device path: using CLUSTER_JACOBI\n");
+    o->preconditioner_type = TMI_BA_PRECOND_CLUSTER_JACOBI;
+  }
   if ((options.preconditioner_type == ceres::SCHUR_JACOBI || options.preconditioner_type == ceres::JACOBI) &&
       !options.merged_view_blocks_in_preconditioner)
     o->preconditioner_type = TMI_BA_PRECOND_SCHUR_JACOBI_PARAMETER_BLOCKS;
@@ -712,6 +750,7 @@ bool SameShape(const BundleAdjustmentOptions& a, const BundleAdjustmentOptions& 
          a.constant_camera_position == b.constant_camera_position && a.intrinsics_to_optimize == b.intrinsics_to_optimize &&
          a.linear_solver_type == b.linear_solver_type && a.point_dof == b.point_dof && a.device == b.device &&
          a.preconditioner_type == b.preconditioner_type &&
+         a.visibility_clustering_type == b.visibility_clustering_type &&
          a.merged_view_blocks_in_preconditioner == b.merged_view_blocks_in_preconditioner;
 }
 
