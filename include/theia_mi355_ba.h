@@ -274,7 +274,21 @@ typedef struct tmi_ba_options {
                               intrinsics blocks: how the views are clustered (ceres::
                               VisibilityClusteringType, bundle_adjustment.h:88-89; Theia's default is
                               CANONICAL_VIEWS).  0 = CANONICAL_VIEWS, 1 = SINGLE_LINKAGE.          */
+  double* iteration_trace; /* optional (NULL = none): HOST buffer of iteration_trace_capacity rows of
+                              TMI_BA_TRACE_STRIDE doubles, one row per trust-region iteration (the first
+                              summary.num_iterations rows, fewer if the buffer is shorter):
+                              [0] iteration (1-based), [1] cost at the iteration's linearisation point,
+                              [2] trust-region radius the step was computed with, [3] outcome (1 accepted,
+                              0 rejected, -1 invalid step, 2 parameter tolerance reached, 3 function
+                              tolerance reached -- 2 and 3 drop the candidate), [4] candidate cost (NaN for an
+                              invalid step), [5] model cost change, [6] linear-solver (PCG) iterations of this
+                              iteration, [7] step norm.  What ceres::Solver::Summary::iterations holds; the
+                              reference reads none of it (bundle_adjuster.cc:203-218) -- it exists so that
+                              tests can hold the trust-region trajectory against an independent model
+                              (tests/trajectory_model.py).  On a sharded solve every rank writes the same rows. */
+  int32_t iteration_trace_capacity;
 } tmi_ba_options;
+#define TMI_BA_TRACE_STRIDE 8
 
 /* ---- summary: BundleAdjustmentSummary + device-path extras --------------- */
 /* reference: bundle_adjustment.h:125-133 */

@@ -1908,6 +1908,18 @@ int32_t oracle_ba_solve(tmi_ba_problem* P, const tmi_ba_options* O, tmi_ba_summa
       }
       ++iter;
       ot_ = now_s();
+      const double radius_used = radius;
+      const int64_t pcg_before = s->pcg_iters;
+      /* one row of the optional trace (theia_mi355_ba.h, tmi_ba_options.iteration_trace) */
+#define ORACLE_TRACE(outcome, cand, mcc, step)                                                   \
+      do {                                                                                       \
+        if (O->iteration_trace && iter <= O->iteration_trace_capacity) {                         \
+          double* row_ = O->iteration_trace + (size_t)(iter - 1) * TMI_BA_TRACE_STRIDE;          \
+          row_[0] = iter; row_[1] = cost; row_[2] = radius_used; row_[3] = (outcome);            \
+          row_[4] = (cand); row_[5] = (mcc); row_[6] = (double)(s->pcg_iters - pcg_before);      \
+          row_[7] = (step);                                                                      \
+        }                                                                                        \
+      } while (0)
       if (!reuse_diagonal) column_sqnorms(s, s->diag_c, s->diag_p);
       OT_LAP("column norms");
       int step_ok = build_reduced(s, radius);
@@ -1922,6 +1934,7 @@ int32_t oracle_ba_solve(tmi_ba_problem* P, const tmi_ba_options* O, tmi_ba_summa
       }
       if (!step_ok) {
         /* HandleInvalidStep */
+        ORACLE_TRACE(-1.0, NAN, model_cost_change, 0.0);
         if (++invalid_run >= O->max_num_consecutive_invalid_steps) {
           termination = 2;
           why = "too many consecutive invalid steps";
@@ -2034,6 +2047,7 @@ int32_t oracle_ba_solve(tmi_ba_problem* P, const tmi_ba_options* O, tmi_ba_summa
       /* ParameterToleranceReached */
       const double step_norm = sqrt(step_sq);
       if (step_norm <= O->parameter_tolerance * (x_norm + O->parameter_tolerance)) {
+        ORACLE_TRACE(2.0, cand_cost, model_cost_change, step_norm);
         termination = 0;
         why = "parameter tolerance reached";
         break;
@@ -2041,11 +2055,14 @@ int32_t oracle_ba_solve(tmi_ba_problem* P, const tmi_ba_options* O, tmi_ba_summa
       /* FunctionToleranceReached */
       const double cost_change = cost - cand_cost;
       if (fabs(cost_change) <= O->function_tolerance * cost) {
+        ORACLE_TRACE(3.0, cand_cost, model_cost_change, step_norm);
         termination = 0;
         why = "function tolerance reached";
         break;
       }
       const double relative_decrease = cost_change / model_cost_change;
+      ORACLE_TRACE((inner_useful || relative_decrease > O->min_relative_decrease) ? 1.0 : 0.0, cand_cost,
+                   model_cost_change, step_norm);
       /* IsStepSuccessful: a net decrease through the inner iterations also accepts */
       if (inner_useful || relative_decrease > O->min_relative_decrease) {
         /* HandleSuccessfulStep */

@@ -111,7 +111,12 @@ class COptions(C.Structure):
         ("residual_precision", C.c_int32),
         ("schur_mode", C.c_int32),
         ("visibility_clustering_type", C.c_int32),
+        ("iteration_trace", C.POINTER(C.c_double)),
+        ("iteration_trace_capacity", C.c_int32),
     ]
+
+TRACE_STRIDE = 8
+TRACE_FIELDS = ("iteration", "cost", "radius", "outcome", "candidate_cost", "model_cost_change", "linear_iterations", "step_norm")
 
 
 class CSummary(C.Structure):
@@ -209,6 +214,16 @@ class CSelectSummary(C.Structure):
         ("seconds", C.c_double),
         ("kernel_seconds", C.c_double),
     ]
+
+
+def attach_trace(options: "COptions", capacity: int) -> np.ndarray:
+    """Gives `options` a per-iteration trace buffer (tmi_ba_options.iteration_trace) and returns it as a
+    [capacity, TRACE_STRIDE] array (rows beyond summary.num_iterations stay NaN).  The array owns the memory: keep it
+    alive for as long as `options` is used."""
+    buf = np.full((capacity, TRACE_STRIDE), np.nan)
+    options.iteration_trace = buf.ctypes.data_as(C.POINTER(C.c_double))
+    options.iteration_trace_capacity = capacity
+    return buf
 
 
 def default_options(**overrides) -> COptions:

@@ -1118,6 +1118,8 @@ void tmi_ba_options_init(tmi_ba_options* o) {
   o->residual_precision = 64;
   o->schur_mode = 0;
   o->visibility_clustering_type = 0;
+  o->iteration_trace = nullptr;
+  o->iteration_trace_capacity = 0;
 }
 
 int32_t tmi_ba_intrinsics_size(int32_t model) {
@@ -2916,6 +2918,15 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
     }
     ++iter;
     const double inv_radius = 1.0 / radius;
+    const double radius_used = radius;
+    const int64_t pcg_before = pcg_iters;
+    // one row of the optional trace (theia_mi355_ba.h, tmi_ba_options::iteration_trace)
+    auto trace = [&](double outcome, double cand, double mcc, double step) {
+      if (!O->iteration_trace || iter > O->iteration_trace_capacity) return;
+      double* row = O->iteration_trace + (size_t)(iter - 1) * TMI_BA_TRACE_STRIDE;
+      row[0] = iter; row[1] = cost; row[2] = radius_used; row[3] = outcome; row[4] = cand; row[5] = mcc;
+      row[6] = (double)(pcg_iters - pcg_before); row[7] = step;
+    };
     CKH(hipMemsetAsync(v.flags, 0, FL_COUNT * sizeof(int), stream));
     CKH(hipMemsetAsync(d_sc, 0, 8 * sizeof(double), stream));
     s->cur_inv_radius = inv_radius;
@@ -3085,6 +3096,7 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
     }
     if (!usable) {
       // HandleInvalidStep
+      trace(-1.0, std::nan(""), model_cost_change, 0.0);
       sum->num_unsuccessful_steps++;
       if (++invalid_run >= O->max_num_consecutive_invalid_steps) {
         termination = 2;
@@ -3104,17 +3116,20 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
     if (cand_invalid) cand_cost = 1.7976931348623157e308;
     const double step_norm = std::sqrt(step_sq);
     if (step_norm <= O->parameter_tolerance * (x_norm + O->parameter_tolerance)) {
+      trace(2.0, cand_cost, model_cost_change, step_norm);
       termination = 0;
       why = "parameter tolerance reached";
       break;
     }
     const double cost_change = cost - cand_cost;
     if (std::fabs(cost_change) <= O->function_tolerance * cost) {
+      trace(3.0, cand_cost, model_cost_change, step_norm);
       termination = 0;
       why = "function tolerance reached";
       break;
     }
     const double relative_decrease = cost_change / model_cost_change;
+    trace((inner_useful || relative_decrease > O->min_relative_decrease) ? 1.0 : 0.0, cand_cost, model_cost_change, step_norm);
     if (inner_useful || relative_decrease > O->min_relative_decrease) {  // IsStepSuccessful
       std::swap(v.ext, v.ext_c);
       std::swap(v.intr, v.intr_c);

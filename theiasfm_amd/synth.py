@@ -41,6 +41,9 @@ CONFIG_SIZES = {
     # the same sizes with 0.2 % of the tracks seen by 24..400 views (not a BASELINE config: a stress
     # case for the long-track paths, cf. SURVEY 8d "max k a few hundred")
     "venice1778_heavy": (1778, 993923, 5001946),
+    # the same sizes with SEQUENCE structure (scene "street"): S is a band of ~10 % fill, PCG needs tens of
+    # iterations per LM iteration -- what real collections look like, where the ring scene is a turntable
+    "venice1778_street": (1778, 993923, 5001946),
 }
 
 
@@ -158,6 +161,42 @@ def _visibility(rng, n_cameras, n_points, n_obs, spread, heavy_tail=0.0):
     return cam.astype(np.int32), pt.astype(np.int32), k
 
 
+def _visibility_street(rng, n_cameras, n_points, n_obs, spread, heavy_tail=0.0, max_window=0.14):
+    """Sequence structure: the views of a track are k of the w = m k CONSECUTIVE views around the track's own place on
+    the path (m >= 1, log-normal around `spread` n / k, w capped at max_window n), so two views share tracks only
+    when they are neighbours on the path -- the reduced camera matrix is a band (plus the wrap-around of the closed
+    path), its fill about 2 E[w] / n.  Track lengths: the geometric body of _track_lengths with a short Pareto tail
+    (landmarks seen from up to ~7 % of the path), the shape of the BAL track-length histograms (mode 2, mean ~5,
+    maximum a few hundred).  Returns (camera, point, k, centre view of every track, window of every track)."""
+    k = _track_lengths(rng, n_cameras, n_points, n_obs, 0.0)
+    if heavy_tail > 0.0:
+        long = np.flatnonzero(rng.random(n_points) < heavy_tail)
+        k[long] = np.clip(np.rint(16.0 * (1.0 + rng.pareto(1.6, long.size))), 16, max(int(0.07 * n_cameras), 16)).astype(np.int64)
+        for _ in range(64):  # steer the total back to exactly n_obs on the short tracks
+            diff = int(n_obs - k.sum())
+            if diff == 0:
+                break
+            cand = np.flatnonzero((k < 12) if diff > 0 else ((k > 2) & (k < 12)))
+            pick = rng.choice(cand, size=min(abs(diff), cand.size), replace=False)
+            k[pick] += 1 if diff > 0 else -1
+        if k.sum() != n_obs:
+            raise ValueError("cannot realise the requested observation count")
+    w_cap = max(int(max_window * n_cameras), 2)
+    m = np.maximum(spread * n_cameras / k * rng.lognormal(0.0, 0.5, n_points), 1.0)
+    w = np.minimum(np.maximum(np.rint(m * k).astype(np.int64), k), max(w_cap, int(k.max())))
+    centre = rng.integers(0, n_cameras, n_points)
+    pt = np.repeat(np.arange(n_points, dtype=np.int64), k)
+    first = np.cumsum(k) - k
+    j = np.arange(n_obs, dtype=np.int64) - np.repeat(first, k)
+    # k distinct views out of the window: the j-th of k equal strata of the window, a random view inside the stratum
+    ww, kk = np.repeat(w, k), np.repeat(k, k)
+    lo = (j * ww) // kk
+    hi = np.maximum(((j + 1) * ww) // kk, lo + 1)
+    off = lo + (rng.random(n_obs) * (hi - lo)).astype(np.int64)
+    cam = (np.repeat(centre - w // 2, k) + off) % n_cameras
+    return cam.astype(np.int32), pt.astype(np.int32), k, centre, w
+
+
 # ---- scenes -----------------------------------------------------------------
 def _look_at(C, target, up=np.array([0.0, 1.0, 0.0])):
     z = target - C
@@ -212,6 +251,28 @@ def make_problem(n_cameras: int, n_points: int, n_obs: int, seed: int, *,
         X = radius * 0.3 * rng.uniform(-1, 1, (n_points, 3))
         cam, pt, _ = _visibility(rng, n_cameras, n_points, n_obs, spread, heavy_tail)
         depth = radius
+        f = rng.uniform(600, 900, n_cameras)
+        pp = np.zeros((n_cameras, 2))
+        k1 = rng.uniform(-0.1, 0.0, n_cameras)
+        k2 = rng.uniform(0.0, 0.02, n_cameras)
+    elif scene == "street":
+        # A closed path (a circle whose perimeter is one unit per view) photographed from the inside out: every view
+        # looks away from the centre at facades / landmarks beyond the path, a track sits in front of the middle of
+        # its window of consecutive views at a depth proportional to the window (a wide window = a far landmark), so
+        # every view of the window has it inside a ~100 degree field of view.  Neighbouring views share most tracks,
+        # distant views none: the sequence structure of real collections -- S is a band, and the
+        # chain's long-wavelength bending modes are what PCG with a block-Jacobi preconditioner is slow on.
+        cam, pt, _, centre, w = _visibility_street(rng, n_cameras, n_points, n_obs, spread, heavy_tail)
+        R0 = n_cameras / (2 * np.pi)
+        phi = (np.arange(n_cameras) + rng.uniform(-0.2, 0.2, n_cameras)) * (2 * np.pi / n_cameras)
+        rr = R0 + rng.uniform(-0.3, 0.3, n_cameras)
+        C = np.stack([rr * np.cos(phi), rng.uniform(-0.3, 0.3, n_cameras), rr * np.sin(phi)], 1)
+        outward = np.stack([np.cos(phi), np.zeros(n_cameras), np.sin(phi)], 1)
+        aa = _look_at(C, C + 10.0 * outward + rng.normal(0.0, 0.6, (n_cameras, 3)))
+        z = np.maximum(6.0, 0.55 * w) * rng.uniform(1.0, 1.6, n_points)       # depth beyond the path
+        pphi = (centre + rng.uniform(-0.5, 0.5, n_points)) * (2 * np.pi / n_cameras)
+        X = np.stack([(R0 + z) * np.cos(pphi), z * rng.uniform(-0.35, 0.35, n_points), (R0 + z) * np.sin(pphi)], 1)
+        depth = 12.0
         f = rng.uniform(600, 900, n_cameras)
         pp = np.zeros((n_cameras, 2))
         k1 = rng.uniform(-0.1, 0.0, n_cameras)
@@ -308,10 +369,13 @@ def config(name: str, **kw) -> Problem:
     if name == "tiny":
         return make_problem(nc, npt, nobs, seed=1, scene="allsee", **kw)
     seeds = {"ladybug49": 49, "alamo": 570, "venice1778": 1778, "venice1778_heavy": 1778}
-    spreads = {"ladybug49": 0.35, "alamo": 0.15, "venice1778": 0.12, "venice1778_heavy": 0.12}
+    spreads = {"ladybug49": 0.35, "alamo": 0.15, "venice1778": 0.12, "venice1778_heavy": 0.12, "venice1778_street": 0.025}
     kw.setdefault("spread", spreads[name])
     if name == "venice1778_heavy":
         kw.setdefault("heavy_tail", 0.002)
+    if name == "venice1778_street":
+        kw.setdefault("heavy_tail", 0.002)
+        return make_problem(nc, npt, nobs, seed=1778, scene="street", **kw)
     return make_problem(nc, npt, nobs, seed=seeds[name], scene="ring", **kw)
 
 
