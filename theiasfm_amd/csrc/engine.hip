@@ -28,6 +28,7 @@
 #include "cluster_precond.h"
 #include "kernels.h"
 #include "mf_chunks.h"
+#include "pcg_persist.h"
 #include "track_kernels.h"
 #include "inner_kernels.h"
 #include "two_view_kernels.h"
@@ -90,6 +91,7 @@ struct Launch {
   void (*update_points)(const DeviceView&, hipStream_t, int, double*, double* sums);
   void (*update_cameras)(const DeviceView&, hipStream_t, double* out, double* prep_c);
   void (*pcg_init)(const DeviceView&, hipStream_t, const double* b, int nb);
+  void (*pcg_persistent)(const DeviceView&, hipStream_t, int grid, const ppcg::Args&);
   void (*dense_gather)(const DeviceView&, hipStream_t, const double*, double*, int);
   void (*tile_gather)(const DeviceView&, hipStream_t, const double*, const double*, double*, int);
 };
@@ -243,6 +245,9 @@ Launch make_launch(bool fp32) {
   L.pcg_init = [](const DeviceView& v, hipStream_t st, const double* b, int nb) {
     hipLaunchKernelGGL((pcg_init_kernel<D>), dim3(nb), dim3(kPcgStepThreads), 0, st, v, b, nb);
   };
+  L.pcg_persistent = [](const DeviceView& v, hipStream_t st, int grid, const ppcg::Args& a) {
+    hipLaunchKernelGGL((ppcg::pcg_persistent_kernel<D>), dim3(grid), dim3(ppcg::kThreads), 0, st, v, a);
+  };
   L.tile_gather = [](const DeviceView& v, hipStream_t st, const double* ub, const double* rhs, double* tiles, int n) {
     const long long total = ((long long)v.nub + v.Nrb) * D * D + n;
     if (total)
@@ -348,6 +353,12 @@ struct tmi_ba_solver {
   bool vis_clusters = false;  // no shared intrinsics blocks: the clusters are Ceres' visibility clusters of the views
   std::vector<std::vector<int> > vis_members;  // ... their reduced blocks, ascending (build_visibility_clusters)
   bool cl_active = false;     // the current LM iteration's PCG applies it
+  // persistent PCG on the formed S (pcg_persist.h): buffers made on first use; off after an aborted launch
+  bool ppcg_ready = false, ppcg_off = false;
+  int ppcg_grid = 0;
+  double *d_ppcg_p = nullptr, *d_ppcg_x = nullptr, *d_ppcg_partial = nullptr;
+  int* d_ppcg_bar = nullptr;
+  long long* d_ppcg_prof = nullptr;  // TMI_BA_PPCG_PROF: per-phase ticks of the persistent PCG launch, printed at destroy
   bool cl_unavailable = false;  // the clusters' tiles could not be allocated: SCHUR_JACOBI for the life of the handle
   bool cl_retired = false;    // a cluster launch gave up in this solve (device shared with another process): SCHUR_JACOBI for the rest of it
   clp::ClusterDesc* d_cl_desc = nullptr;
@@ -1152,6 +1163,18 @@ int32_t tmi_ba_intrinsics_constant_mask(int32_t model, int32_t bits, uint8_t* ma
 }
 
 void tmi_ba_solver_destroy(tmi_ba_solver* s) {
+  if (s && s->d_ppcg_prof) {
+    long long h[48];
+    if (hipMemcpy(h, s->d_ppcg_prof, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+      static const char* names[8] = {"A rows", "barrier 1", "B cols + p.q", "reduce p.q", "-", "C update (+ resets)", "reduce Q1 rho", "-"};
+      for (int wg = 0; wg < 3; ++wg) {
+        fprintf(stderr, "[tmi_ba ppcg] %s workgroup, ms:", wg == 0 ? "first" : wg == 1 ? "middle" : "last");
+        for (int i = 0; i < 7; ++i)
+          if (i != 4) fprintf(stderr, " %s %.3f |", names[i], 1e-5 * (double)h[16 * wg + i]);
+        fprintf(stderr, "\n");
+      }
+    }
+  }
 #ifdef TMI_MF_PROFILE
   if (s && s->mf_ok && s->mf.prof) {
     std::vector<long long> h((size_t)s->mf.n_items * 16);
@@ -2349,6 +2372,7 @@ static int apply_clusters(tmi_ba_solver* s, const double* r, double* z) {
   });
 }
 
+static inline double st_nub_bytes(const tmi_ba_solver* s) { return 8.0 * (double)s->st.nub * s->st.D * s->st.D; }
 static int solve_reduced_pcg(tmi_ba_solver* s, const tmi_ba_options* O, int* usable, int64_t* iters) {
   DeviceView& v = s->v;
   const int n = v.Nrb * v.D;
@@ -2371,6 +2395,85 @@ static int solve_reduced_pcg(tmi_ba_solver* s, const tmi_ba_options* O, int* usa
   // the scalars of iteration it are read measured no gain on MI355X -- 5.02 vs 5.04 ms per LM iteration at one GPU,
   // 1.57 vs 1.53 ms for an eighth of the tracks, profiles/r02_g -- and is gone.)
   const bool fused = !s->st.has_shared && !s->cl_active;  // (pcg_step applies the block inverses itself: no clusters)
+  // The formed S: the whole solve as ONE persistent launch (pcg_persist.h) -- no launch, drain or host poll per PCG
+  // iteration.  TMI_BA_PCG_PERSISTENT=0 keeps the launch-per-step loop below (tests hold the two to each other).
+  if (fused && !s->implicit_now && !s->ppcg_off && v.n_spc > 0) {
+    // ... while S is small: the grid of one workgroup per CU keeps ~28 KB per CU in flight, enough for a matrix the
+    // Infinity Cache holds but half the rate of the launch-per-step kernels (whole-chip occupancy) on the 826 MB of the
+    // ring scene (measured: 406 against 235 us per PCG iteration).  TMI_BA_PCG_PERSISTENT=1 forces it, 0 switches it off
+    // (read per solve: tests switch it inside one process).
+    const char* env = getenv("TMI_BA_PCG_PERSISTENT");
+    const bool small_S = (double)st_nub_bytes(s) <= 256.0 * 1024 * 1024;
+    if (env ? env[0] != '0' : small_S) {
+      if (!s->ppcg_ready) {
+        if (!s->num_cus) {
+          hipDeviceProp_t prop;
+          TMI_HIP(hipGetDeviceProperties(&prop, s->device));
+          s->num_cus = prop.multiProcessorCount;
+        }
+        s->ppcg_grid = std::max(1, s->num_cus);
+        int rc;
+        if ((rc = dev_alloc(s, &s->d_ppcg_p, (size_t)2 * n))) return rc;
+        if ((rc = dev_alloc(s, &s->d_ppcg_x, (size_t)n))) return rc;
+        if ((rc = dev_alloc(s, &s->d_ppcg_partial, (size_t)3 * s->ppcg_grid))) return rc;
+        if ((rc = dev_alloc(s, &s->d_ppcg_bar, (size_t)ppcg::kBarInts))) return rc;
+        s->ppcg_ready = true;
+      }
+      int rc0;
+      ppcg::Args a;
+      a.ub = v.red + s->RL.ub;
+      a.b = b;
+      a.pbuf = s->d_ppcg_p;
+      a.xpub = s->d_ppcg_x;
+      a.partial = s->d_ppcg_partial;
+      a.bar = s->d_ppcg_bar;
+      a.ctrl = v.flags + FL_CHOL_ABORT;
+      a.eta = O->eta;
+      a.min_it = O->min_linear_solver_iterations;
+      a.max_it = O->max_linear_solver_iterations;
+      a.red8 = v.red + s->RL.scalars;
+      a.mirror = s->d_mirror;
+      const unsigned long long my_seq = ++s->mirror_seq;
+      a.seq = my_seq;
+      a.prof = nullptr;
+      static const bool want_prof = getenv("TMI_BA_PPCG_PROF") != nullptr;
+      if (want_prof) {
+        if (!s->d_ppcg_prof) {
+          if ((rc0 = dev_alloc(s, &s->d_ppcg_prof, 48))) return rc0;
+          TMI_HIP(hipMemsetAsync(s->d_ppcg_prof, 0, 48 * sizeof(long long), s->stream));
+        }
+        a.prof = s->d_ppcg_prof;
+      }
+      TMI_HIP(hipMemsetAsync(s->d_ppcg_bar, 0, ppcg::kBarInts * sizeof(int), s->stream));
+      int rc;
+      {
+        Timed t(s, TMI_BA_K_SPMV);
+        rc = launch_coresident(s, s->ppcg_grid, [&] { s->launch.pcg_persistent(v, s->stream, s->ppcg_grid, a); });
+      }
+      if (rc) return rc;
+      if ((rc = wait_mirror(s, 0, my_seq))) return rc;
+      if (s->h_flags[FL_CHOL_ABORT]) {
+        // the grid could not become co-resident (another process holds part of the device): launch per step from
+        // here on, this solve included
+        TMI_HIP(hipMemsetAsync(v.flags + FL_CHOL_ABORT, 0, sizeof(int), s->stream));
+        s->ppcg_off = true;
+        return solve_reduced_pcg(s, O, usable, iters);
+      }
+      const int done = (int)s->h_scal[ppcg::SC_PCG_IT];
+      if (done > 1) s->launches[TMI_BA_K_SPMV] += done - 1;  // the class counts products
+      if (s->h_flags[FL_PCG_FAIL]) {
+        *usable = 0;
+      } else if (!(s->h_scal[SC_PQ] > 0.0)) {
+        // LINEAR_SOLVER_NO_CONVERGENCE, x kept
+      } else if ((s->h_scal[SC_ZETA] < O->eta && done >= O->min_linear_solver_iterations) ||
+                 done >= O->max_linear_solver_iterations) {
+      } else if (s->h_scal[SC_RHO_BAD] != 0.0) {
+        *usable = 0;
+      }
+      *iters += done;
+      return TMI_BA_OK;
+    }
+  }
   const int nbv = (v.Nrb + 3) / 4;
   const int nbs16 = (v.Nrb + kPcgStepThreads / 64 - 1) / (kPcgStepThreads / 64);  // workgroups of pcg_step
   // drop_pos: pcg_init and pcg_p leave the scaled copy of p the product gathers; the three-kernel path does not
