@@ -117,6 +117,10 @@ struct DeviceView {
   double* cm_Y;
   double* cm_A;
   double* cm_R;  // tail records {N, r~, r} when there are no shared intrinsics blocks (kernels.h asa_of)
+  // direct_diag (round 5, direct_diag.h): this LM iteration is matrix-free with the one-sweep product, so point_eliminate
+  // writes NO camera-major records; it leaves trk_rec and camera_diag_direct re-evaluates the observations view by view
+  int direct_diag;
+  double* trk_rec;  // [Np_pad][16 (3-dof) | 24 (4-dof)] {X, scale_p, L^-1, t_p}
   double* scale_c;  // [Nrb][D]
   double* scale_cam; // [Nc][16] scale_c expanded to the columns [ext(6) | intr(10)] of every view
                      //   (0 on constant columns): linearize indexes it statically

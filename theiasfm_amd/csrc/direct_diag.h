@@ -1,0 +1,337 @@
+// Camera side of the normal equations WITHOUT camera-major records (round 5).
+//
+// In a matrix-free LM iteration (the one-sweep product of mf_chunks.h) nothing but camera_diag reads the camera-major
+// [A | Q] records + tails that point_eliminate writes: 1.47 GB written and 1.31 GB read back per LM iteration on the
+// Venice-sized problem to obtain 0.77 MB of diagonal blocks, U diagonal, g~ and g_c (profiles/r04_e_summary.md:
+// point_eliminate 493 us, camera_diag 243 us).  The records are a transposition -- per-track data (the factor of
+// V + D_p, t_p) meets per-view sums -- and the transposition is cheaper done on the INPUTS than on the Jacobians:
+//
+//   * point_eliminate (DeviceView::direct_diag) stops after the per-track part and leaves ONE record per track,
+//       trk_rec[lp] = { X (4), L^-1 diag(scale_p) (DP (DP + 1) / 2), scale_p . t_p (DP) }
+//     (the Jacobi scales of the point block folded into the factor: Q = (Jp diag(s)) L^-T = Jp (L^-1 diag(s))^T and
+//     Jp diag(s) t_p = Jp (s . t_p), so the scaled Jp is never formed; s = 0 for a constant point, whose Jp is zero)
+//     -- 128 B for 3-dof points, 192 B for 4-dof -- 1 M tracks = 128 MB, resident in the Infinity Cache;
+//   * camera_diag_direct walks a view's slots (one wavefront per chunk of a view): the pixel and the track of a slot
+//     are static and streamed (20 B per observation), the track's record is gathered, and the observation's residual
+//     and Jacobian blocks are RE-EVALUATED from the view's prepared record, which is wave-uniform here -- no staging of
+//     64 different camera records per trip as in the track-major linearize, the camera-model switch does not diverge
+//     -- followed by the same loss corrector, column scaling and compaction as linearize_kernel, Q = Jp L^-T,
+//     N = I - Q Q^T, r~ = r - Jp t_p and the sums of camera_diag_kernel;
+//   * a chunk leaves its partial sums, camera_diag_direct_reduce adds a view's chunks in chunk order (fixed order:
+//     bit-reproducible) and writes the raw diagonal block, U diagonal, g~ and g_c where camera_diag_kernel does.
+//
+// Reference: this is the f-block diagonal of Ceres' SchurEliminator::Eliminate (called under ceres::Solve,
+// bundle_adjuster.cc:205) for the cost functions of reprojection_error.h:51-95.
+#pragma once
+#include "kernels.h"
+
+namespace tmi {
+namespace ddg {
+
+constexpr int kChunkSlots = 1024;  // slots of a view one wavefront walks (16 trips)
+constexpr int kMaxD = 12;  // (16-wide blocks: S_cc, g~ and g_c do not fit one 16 x 16 accumulator; they keep the records)
+#ifndef TMI_DD_WAVES
+#define TMI_DD_WAVES 2  // wavefronts per SIMD the register allocation of camera_diag_direct must allow
+#endif
+
+__host__ __device__ constexpr int trk_stride(int DP) { return DP == 3 ? 16 : 24; }
+__host__ __device__ constexpr int trk_off_li(int) { return 4; }
+__host__ __device__ constexpr int trk_off_tp(int DP) { return 4 + sym_size(DP); }
+__host__ __device__ constexpr int trk_used(int DP) { return (4 + sym_size(DP) + DP + 1) & ~1; }  // doubles of a record that are read
+__host__ __device__ constexpr int n_acc(int D) { return sym_size(D) + 3 * D; }
+
+struct Plan {
+  int n_chunks;
+  const int* chunk_rb;   // [n_chunks] view block of a chunk
+  const int* chunk_s0;   // [n_chunks + 1] ... its slots [s0, s1)
+  const int* chunk_s1;
+  const int* rb_chunk;   // [Nrb + 1] chunks of a view block
+  const double* cm_xy;   // [Nslots][2] pixel of a slot
+  double* part;          // [n_chunks][n_acc(D)]
+};
+
+// slot -> (track, pixel), built once per structure
+__global__ __launch_bounds__(256) void slot_gather_kernel(DeviceView v, int* __restrict__ slot_track,
+                                                          double* __restrict__ cm_xy) {
+  const TrackMap tm = track_map(v);
+  if (!tm.valid) return;
+  for (int j = tm.j0; j < tm.k; j += tm.jstep) {
+    const size_t e = tm.base + (size_t)j * 64;
+    const int cpos = v.obs_cpos[e];
+    if (cpos >= 0) {
+      slot_track[cpos] = tm.lp;
+      *reinterpret_cast<double2*>(cm_xy + 2 * (size_t)cpos) = *reinterpret_cast<const double2*>(v.obs_xy + 2 * e);
+    }
+  }
+}
+
+// LDS staging of one trip (64 slots) for the matrix cores: per slot the two rows of the compacted camera block A
+// (2 x D) and of B' = [N A | r~ | r] (2 x (D + 2)); pitches are odd so that the per-slot writes (lane = slot) and the
+// per-step operand reads (lane = (k, column)) both spread over the banks
+template <int D>
+struct StageDims {
+  static constexpr int PA = 2 * D + 1;
+  static constexpr int PB = 2 * (D + 2) + 1;
+};
+
+template <int D, int DP>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TMI_DD_WAVES, TMI_DD_WAVES))) void camera_diag_direct_kernel(DeviceView v, Plan pl, const double* __restrict__ prep,
+                                                                int loss_type, double loss_width) {
+  static_assert(D + 2 <= 16, "one 16 x 16 accumulator holds S_cc (D x D), g~ and g_c");
+  constexpr int NS = sym_size(D);
+  constexpr int TR = trk_stride(DP);
+  constexpr int TU = trk_used(DP);
+  constexpr int NA = n_acc(D);
+  constexpr int PA = StageDims<D>::PA, PB = StageDims<D>::PB;
+  __shared__ double As[64 * PA];
+  __shared__ double Bs[64 * PB];
+  __shared__ double Zs[2];
+  const int lane = threadIdx.x;
+  const int ch = blockIdx.x;
+  const int rb = pl.chunk_rb[ch];
+  const int s0 = pl.chunk_s0[ch], s1 = pl.chunk_s1[ch];
+  const int cam = v.rb_cam[rb];
+  const int4 rec = v.cam_rec[cam];
+  const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane(rec.w);
+  const int model = __builtin_amdgcn_readfirstlane(rec.x);
+  // the view's prepared record: a wave-uniform address, so its words arrive through the scalar cache into SGPRs
+  const double* __restrict__ Pl = prep + (size_t)__builtin_amdgcn_readfirstlane(cam) * kPrepStride;
+  // padding columns of the staged blocks stay zero for the whole launch
+  for (int i = lane; i < 64 * PA; i += 64) As[i] = 0.0;
+  for (int i = lane; i < 64 * PB; i += 64) Bs[i] = 0.0;
+  if (lane < 2) Zs[lane] = 0.0;
+  // the matrix-core accumulator: acc[q] = element (row (lane >> 4) + 4 q, column lane & 15) of  sum A^T [N A | r~ | r]
+  v4f64 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};  // (two chains: even / odd steps)
+  double usum = 0.0;  // this lane's share of U_cc (column lane & 15, k = lane >> 4)
+  __syncthreads();
+
+  double* Al = As + lane * PA;
+  double* Bl = Bs + lane * PB;
+  const int ocol = lane & 15, ok4 = lane >> 4;  // operand element of this lane in an MFMA step
+  // lanes whose operand column is padding read a word that stays zero (stride 0) instead of selecting per step
+  const double* opA = ocol < D ? As + (ok4 >> 1) * PA + (ok4 & 1) * D + ocol : Zs;
+  const double* opB = ocol < D + 2 ? Bs + (ok4 >> 1) * PB + (ok4 & 1) * (D + 2) + ocol : Zs;
+  const int strA = ocol < D ? 2 * PA : 0, strB = ocol < D + 2 ? 2 * PB : 0;
+
+  const int trips = (s1 - s0 + 63) >> 6;
+  // software pipeline: the track record of trip t + 1 and the (track, pixel) of trip t + 2 are in flight during trip t
+  int lp_n = -1;
+  double2 xy_n = make_double2(0.0, 0.0);
+  double Tn[TU];
+#pragma unroll
+  for (int i = 0; i < TU; ++i) Tn[i] = 0.0;
+  {
+    const int s = s0 + lane;
+    if (s < s1) {
+      lp_n = v.slot_track[s];
+      xy_n = *reinterpret_cast<const double2*>(pl.cm_xy + 2 * (size_t)s);
+      const double* tr = v.trk_rec + (size_t)lp_n * TR;
+#pragma unroll
+      for (int i = 0; i < TU; i += 2) {
+        const double2 t = *reinterpret_cast<const double2*>(tr + i);
+        Tn[i] = t.x;
+        Tn[i + 1] = t.y;
+      }
+    }
+  }
+  int lp_nn = -1;
+  double2 xy_nn = make_double2(0.0, 0.0);
+  if (trips > 1) {
+    const int s = s0 + 64 + lane;
+    if (s < s1) {
+      lp_nn = v.slot_track[s];
+      xy_nn = *reinterpret_cast<const double2*>(pl.cm_xy + 2 * (size_t)s);
+    }
+  }
+  for (int trip = 0; trip < trips; ++trip) {
+    const bool act = lp_n >= 0;
+    const double2 xy = xy_n;
+    double T[TU];
+#pragma unroll
+    for (int i = 0; i < TU; ++i) T[i] = Tn[i];
+    // next trip's record, the trip after's indices
+    lp_n = lp_nn;
+    xy_n = xy_nn;
+    if (lp_n >= 0) {
+      const double* tr = v.trk_rec + (size_t)lp_n * TR;
+#pragma unroll
+      for (int i = 0; i < TU; i += 2) {
+        const double2 t = *reinterpret_cast<const double2*>(tr + i);
+        Tn[i] = t.x;
+        Tn[i + 1] = t.y;
+      }
+    }
+    lp_nn = -1;
+    {
+      const int s = s0 + (trip + 2) * 64 + lane;
+      if (s < s1) {
+        lp_nn = v.slot_track[s];
+        xy_nn = *reinterpret_cast<const double2*>(pl.cm_xy + 2 * (size_t)s);
+      }
+    }
+    // ---- residual and Jacobian blocks of this lane's observation (linearize_kernel's expressions) ----
+    double r[2] = {0.0, 0.0}, Jext[2][6], Jint[2][10], Jpt[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) Jext[i][j] = 0.0;
+#pragma unroll
+      for (int j = 0; j < 10; ++j) Jint[i][j] = 0.0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Jpt[i][j] = 0.0;
+    }
+    bool ok = false;
+    if (act) ok = reprojection_error_prepared<true, double>(model, Pl, T, xy.x, xy.y, r, Jext, Jint, Jpt);
+    // an observation that does not count (past the chunk, |X - w C|^2 < 1e-8) contributes zero rows
+    const double live = ok ? 1.0 : 0.0;
+    if (!ok) r[0] = r[1] = 0.0;
+    double sqrt_rho1 = 1.0, asn = 0.0, rscale = 1.0;
+    if (loss_type != 0 && ok) {
+      const double sq = r[0] * r[0] + r[1] * r[1];
+      double rho[3];
+      loss_eval(loss_type, loss_width, sq, rho);
+      sqrt_rho1 = sqrt(rho[1]);
+      rscale = sqrt_rho1;
+      if (!(sq == 0.0 || rho[2] <= 0.0)) {
+        const double Dd = 1.0 + 2.0 * sq * rho[2] / rho[1];
+        const double alpha = 1.0 - sqrt(Dd);
+        rscale = sqrt_rho1 / (1.0 - alpha);
+        asn = alpha / sq;
+      }
+    }
+    double J0[DP], J1[DP];
+#pragma unroll
+    for (int a = 0; a < DP; ++a) {
+      double j0 = ok ? Jpt[0][a < 4 ? a : 0] : 0.0, j1 = ok ? Jpt[1][a < 4 ? a : 0] : 0.0;
+      if (loss_type != 0) {
+        const double rtj = j0 * r[0] + j1 * r[1];
+        j0 = sqrt_rho1 * (j0 - asn * r[0] * rtj);
+        j1 = sqrt_rho1 * (j1 - asn * r[1] * rtj);
+      }
+      J0[a] = j0;  // (unscaled: the scales ride in the track's factor)
+      J1[a] = j1;
+    }
+    const double r0 = r[0] * rscale, r1 = r[1] * rscale;
+    // Q = Jp L^-T, N = I - Q Q^T, r~ = r - Jp t_p   (point_eliminate_kernel's second pass)
+    double rt0 = r0, rt1 = r1;
+#pragma unroll
+    for (int a = 0; a < DP; ++a) {
+      rt0 -= J0[a] * T[trk_off_tp(DP) + a];
+      rt1 -= J1[a] * T[trk_off_tp(DP) + a];
+    }
+    double n00 = 1.0, n01 = 0.0, n11 = 1.0;
+#pragma unroll
+    for (int b = 0; b < DP; ++b) {
+      double q0 = 0.0, q1 = 0.0;
+#pragma unroll
+      for (int a = 0; a <= b; ++a) {
+        const double li = T[trk_off_li(DP) + sym_idx(a, b, DP)];  // L^-1 (b, a)
+        q0 += li * J0[a];
+        q1 += li * J1[a];
+      }
+      n00 -= q0 * q0;
+      n01 -= q0 * q1;
+      n11 -= q1 * q1;
+    }
+    // ---- the free columns of [ext(6) | intr(10)], compacted: column dst of the staged A and B' rows ----
+    int dst = 0;  // (wave uniform)
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      if (mask & (1u << c)) {
+        double j0, j1, scl;
+        if (c < 6) {
+          j0 = Jext[0][c < 6 ? c : 0];
+          j1 = Jext[1][c < 6 ? c : 0];
+          scl = c < 3 ? Pl[33 + (c < 3 ? c : 0)] : 1.0;  // (the angle-axis scales are folded into Jl)
+        } else {
+          j0 = Jint[0][c >= 6 ? c - 6 : 0];
+          j1 = Jint[1][c >= 6 ? c - 6 : 0];
+          scl = Pl[36 + (c >= 6 ? c - 6 : 0)];
+        }
+        if (loss_type != 0) {
+          const double rtj = j0 * r[0] + j1 * r[1];
+          j0 = sqrt_rho1 * (j0 - asn * r[0] * rtj);
+          j1 = sqrt_rho1 * (j1 - asn * r[1] * rtj);
+        }
+        j0 = ok ? j0 * scl : 0.0;
+        j1 = ok ? j1 * scl : 0.0;
+        Al[dst] = j0;
+        Al[D + dst] = j1;
+        Bl[dst] = n00 * j0 + n01 * j1;
+        Bl[(D + 2) + dst] = n01 * j0 + n11 * j1;
+        ++dst;
+      }
+    }
+    Bl[D] = rt0 * live;
+    Bl[D + 1] = r0 * live;
+    Bl[(D + 2) + D] = rt1 * live;
+    Bl[(D + 2) + D + 1] = r1 * live;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- sum over the 64 slots on the matrix cores: K = 4 per step = the two rows of two slots ----
+#pragma unroll 8
+    for (int m = 0; m < 32; m += 2) {
+      const double a0 = opA[m * strA], b0 = opB[m * strB];
+      const double a1 = opA[(m + 1) * strA], b1 = opB[(m + 1) * strB];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc2, 0, 0, 0);
+      usum += a0 * a0;
+      usum += a1 * a1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  double* out = pl.part + (size_t)ch * NA;
+  acc += acc2;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = ok4 + 4 * q;
+    if (row < D) {
+      if (ocol < D) {
+        if (row <= ocol) out[sym_idx(row, ocol, D)] = acc[q];
+      } else if (ocol == D) {
+        out[NS + D + row] = acc[q];
+      } else if (ocol == D + 1) {
+        out[NS + 2 * D + row] = acc[q];
+      }
+    }
+  }
+  usum += __shfl_xor(usum, 16, 64);
+  usum += __shfl_xor(usum, 32, 64);
+  if (lane < D) out[NS + lane] = usum;
+}
+
+// a view's chunks summed in chunk order; results where camera_diag_kernel leaves them
+template <int D>
+__global__ __launch_bounds__(64) void camera_diag_direct_reduce_kernel(DeviceView v, RedLayout L, Plan pl) {
+  constexpr int NS = sym_size(D);
+  constexpr int NA = n_acc(D);
+  const int rb = blockIdx.x;
+  const int c0 = pl.rb_chunk[rb], c1 = pl.rb_chunk[rb + 1];
+  double* diag = v.red + L.diag + (size_t)rb * D * D;
+  for (int i = threadIdx.x; i < NA; i += 64) {
+    double t = 0.0;
+    for (int c = c0; c < c1; ++c) t += pl.part[(size_t)c * NA + i];
+    if (i < NS) {
+      int a = 0, rem = i;
+      while (rem >= D - a) {
+        rem -= D - a;
+        ++a;
+      }
+      const int b = a + rem;
+      diag[a * D + b] = t;
+      diag[b * D + a] = t;
+    } else if (i < NS + D) {
+      v.red[L.udiag + (size_t)rb * D + (i - NS)] = t;
+    } else if (i < NS + 2 * D) {
+      v.red[L.gt + (size_t)rb * D + (i - NS - D)] = t;
+    } else {
+      v.red[L.gc + (size_t)rb * D + (i - NS - 2 * D)] = t;
+    }
+  }
+}
+
+}  // namespace ddg
+}  // namespace tmi

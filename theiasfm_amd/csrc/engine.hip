@@ -28,6 +28,7 @@
 #include "cluster_precond.h"
 #include "kernels.h"
 #include "mf_chunks.h"
+#include "direct_diag.h"
 #include "pcg_persist.h"
 #include "track_kernels.h"
 #include "inner_kernels.h"
@@ -68,6 +69,8 @@ struct Launch {
   void (*point_eliminate)(const DeviceView&, hipStream_t, double, double, double, int, double*, double*, double,
                           double*);
   void (*camera_diag)(const DeviceView&, hipStream_t, RedLayout, int, double*);
+  // direct_diag.h: the same sums without camera-major records (matrix-free iterations, no shared intrinsics blocks)
+  void (*camera_diag_direct)(const DeviceView&, hipStream_t, RedLayout, const ddg::Plan&, const double* prep, int, double);
   void (*schur_offdiag)(const DeviceView&, hipStream_t, RedLayout);
   void (*expand_scale)(const DeviceView&, hipStream_t);
   void (*expand)(const DeviceView&, hipStream_t, RedLayout, double, double, double, int want_gmax);
@@ -142,6 +145,14 @@ Launch make_launch(bool fp32) {
       const int ns = v.Nrb - v.Ncam_rb;
       hipLaunchKernelGGL((shared_diag_partial_kernel<D, DP>), dim3(ns * max_chunks), dim3(64), 0, st, v, max_chunks, chunk_partial);
       hipLaunchKernelGGL((shared_diag_reduce_kernel<D>), dim3(ns), dim3(64), 0, st, v, R, max_chunks, chunk_partial);
+    }
+  };
+  L.camera_diag_direct = [](const DeviceView& v, hipStream_t st, RedLayout R, const ddg::Plan& pl, const double* prep, int lt,
+                            double lw) {
+    if constexpr (!SH && D <= ddg::kMaxD) {
+      if (pl.n_chunks)
+        hipLaunchKernelGGL((ddg::camera_diag_direct_kernel<D, DP>), dim3(pl.n_chunks), dim3(64), 0, st, v, pl, prep, lt, lw);
+      if (v.Nrb) hipLaunchKernelGGL((ddg::camera_diag_direct_reduce_kernel<D>), dim3(v.Nrb), dim3(64), 0, st, v, R, pl);
     }
   };
   L.expand_scale = [](const DeviceView& v, hipStream_t st) {
@@ -324,6 +335,8 @@ struct tmi_ba_solver {
   bool need_slot_track = false;
   mfc::View mf = {};          // one-sweep matrix-free product (mf_chunks.h); mf_ok: built and in use
   bool mf_ok = false;
+  ddg::Plan dd = {};          // camera side without camera-major records (direct_diag.h); direct_ok: built
+  bool direct_ok = false;
   bool implicit = false;      // S is never formed (schur_mode)
   bool adaptive = false;      // schur_mode auto on one rank: both operators are resident and every LM iteration
                               // takes the cheaper one for the PCG length it expects (see solve)
@@ -2026,6 +2039,55 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
     }
   }
   if (setup_timing) fprintf(stderr, "[tmi_ba setup] position columns of the A planes: %s\n", v.drop_pos ? "formed from Jp" : "stored");
+  // direct_diag.h: matrix-free iterations of the one-sweep product build the camera side without camera-major records
+  // (TMI_BA_DIRECT_DIAG=0 keeps the records: A/B, tests)
+  s->direct_ok = false;
+  v.direct_diag = 0;
+  {
+    const char* e = getenv("TMI_BA_DIRECT_DIAG");
+    if (s->mf_ok && !st.has_shared && O->residual_precision != 32 && !s->cluster_blocks && st.Nrb > 0 && st.Nslots > 0 && D <= ddg::kMaxD &&
+        !(e && atoi(e) == 0)) {
+      std::vector<int> cp((size_t)st.Nrb + 1);
+      TMI_HIP(hipMemcpyAsync(cp.data(), v.cam_ptr, cp.size() * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+      TMI_HIP(hipStreamSynchronize(s->stream));
+      std::vector<int> crb, cs0, cs1, rbc((size_t)st.Nrb + 1, 0);
+      for (int rb = 0; rb < st.Nrb; ++rb) {
+        rbc[rb] = (int)crb.size();
+        const int n = cp[rb + 1] - cp[rb];
+        if (n <= 0) continue;
+        // equal shares of whole trips
+        const int nch = (n + ddg::kChunkSlots - 1) / ddg::kChunkSlots;
+        const int per = (((n + nch - 1) / nch) + 63) & ~63;
+        for (int b = cp[rb]; b < cp[rb + 1]; b += per) {
+          crb.push_back(rb);
+          cs0.push_back(b);
+          cs1.push_back(std::min(b + per, cp[rb + 1]));
+        }
+      }
+      rbc[st.Nrb] = (int)crb.size();
+      int *p0, *p1, *p2, *p3, *stt;
+      double *xy, *part;
+      if ((rc = dev_upload(s, &p0, crb))) return rc;
+      if ((rc = dev_upload(s, &p1, cs0))) return rc;
+      if ((rc = dev_upload(s, &p2, cs1))) return rc;
+      if ((rc = dev_upload(s, &p3, rbc))) return rc;
+      if ((rc = dev_alloc(s, &xy, (size_t)2 * st.Nslots))) return rc;
+      if ((rc = dev_alloc(s, &part, std::max<size_t>(crb.size(), 1) * ddg::n_acc(D)))) return rc;
+      if ((rc = dev_alloc(s, &v.trk_rec, (size_t)std::max(st.Np_pad, 1) * ddg::trk_stride(s->DP)))) return rc;
+      if ((rc = dev_alloc(s, &stt, (size_t)st.Nslots))) return rc;
+      hipLaunchKernelGGL(ddg::slot_gather_kernel, dim3(s->nblocks_tracks), dim3(256), 0, s->stream, v, stt, xy);
+      v.slot_track = stt;
+      s->dd.n_chunks = (int)crb.size();
+      s->dd.chunk_rb = p0;
+      s->dd.chunk_s0 = p1;
+      s->dd.chunk_s1 = p2;
+      s->dd.rb_chunk = p3;
+      s->dd.cm_xy = xy;
+      s->dd.part = part;
+      s->direct_ok = true;
+    }
+  }
+  if (setup_timing) fprintf(stderr, "[tmi_ba setup] camera side of matrix-free iterations: %s\n", s->direct_ok ? "view by view from the track records (no camera-major records)" : "camera-major records");
   if (s->vis_clusters && (rc = build_visibility_clusters(s, P, O->visibility_clustering_type))) return rc;
   if (s->need_slot_track && !s->mf_ok) {
     int* stt;
@@ -2957,10 +3019,16 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
     }
     {
       Timed t(s, TMI_BA_K_CAMERA_DIAG);
-      s->launch.camera_diag(v, stream, RL, s->shared_diag_chunks, s->d_shared_diag_partial);
-      s->launch.shared_blocks(v, stream, RL);
+      if (v.direct_diag) {
+        s->launch.camera_diag_direct(v, stream, RL, s->dd, v.prep, lt, lw);
+      } else {
+        s->launch.camera_diag(v, stream, RL, s->shared_diag_chunks, s->d_shared_diag_partial);
+        s->launch.shared_blocks(v, stream, RL);
+      }
     }
   };
+  // (direct_diag.h) the pre-pass below only needs the U diagonal: without records whenever the handle can
+  v.direct_diag = (s->direct_ok && iterative) ? 1 : 0;
   if (O->jacobi_scaling) {
     // Jacobi scaling 1 / (1 + ||column||) from the UNSCALED Jacobian at the start point:
     // track columns directly, camera-side columns as the diagonal of J_c^T J_c which a
@@ -3044,6 +3112,7 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
     } else if (s->implicit && iterative) {
       s->n_implicit_iterations++;
     }
+    v.direct_diag = (s->direct_ok && iterative && s->implicit_now && !s->cluster_blocks) ? 1 : 0;
     build_camera_side(inv_radius);
     if (!s->implicit_now || s->cluster_blocks) {
       Timed t(s, TMI_BA_K_SCHUR_OFFDIAG);

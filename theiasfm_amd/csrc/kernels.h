@@ -849,6 +849,27 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
 #pragma unroll
         for (int b = 0; b <= a; ++b) Li_s[a][b] = Li[a][b];
       }
+      if (v.direct_diag && tm.leader) {
+        // direct_diag.h: the camera side re-evaluates the observations view by view and needs, per track,
+        // { X, L^-1 diag(scale_p), scale_p . t_p } in one record (scale 0: constant point, its Jp is zero)
+        constexpr int TRS = DP == 3 ? 16 : 24;
+        double rec[TRS];
+#pragma unroll
+        for (int i = 0; i < TRS; ++i) rec[i] = 0.0;
+        const bool pc = v.pt_const[lp] != 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rec[i] = v.pts[(size_t)lp * 4 + i];
+#pragma unroll
+        for (int a = 0; a < DP; ++a) {
+          const double sa = pc ? 0.0 : v.scale_p[(size_t)lp * DP + a];
+          rec[4 + NS + a] = tp[a] * sa;
+#pragma unroll
+          for (int b = a; b < DP; ++b) rec[4 + sym_idx(a, b, DP)] = Li[b][a] * sa;
+        }
+        double* out = v.trk_rec + (size_t)lp * TRS;
+#pragma unroll
+        for (int i = 0; i < TRS; i += 2) *reinterpret_cast<double2*>(out + i) = make_double2(rec[i], rec[i + 1]);
+      }
     }
     // ---- second pass: Y = A^T (Jp L^-T), r~ = r - Jp t_p into the camera-major records.
     // Each lane builds its record in registers; the wave then stages 32 records at a
@@ -860,7 +881,9 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
     double Yg[SH ? YS : 1];  // running sum of the shared block's Y over the current run
 #pragma unroll
     for (int i = 0; i < (SH ? YS : 1); ++i) Yg[i] = 0.0;
-    for (int trip = 0; trip < tm.trips; ++trip) {
+    // (direct_diag: no camera-major records at all -- nothing but camera_diag would read them in a matrix-free iteration)
+    const int rec_trips = v.direct_diag ? 0 : tm.trips;
+    for (int trip = 0; trip < rec_trips; ++trip) {
       const int j = tm.j0 + trip * tm.jstep;
       const size_t e = base + (size_t)j * 64;
       int cpos = -1, gslot = -1, gflag = 0;
