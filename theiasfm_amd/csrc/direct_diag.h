@@ -30,6 +30,14 @@ namespace ddg {
 
 constexpr int kChunkSlots = 1024;  // slots of a view one wavefront walks (16 trips)
 constexpr int kMaxD = 12;  // (16-wide blocks: S_cc, g~ and g_c do not fit one 16 x 16 accumulator; they keep the records)
+#ifndef TMI_DD_EXP
+#define TMI_DD_EXP 0  // timing experiments (1: no matrix-core loop, 2: track records from a cache-resident window, 3: no evaluation)
+#endif
+#ifdef TMI_DD_PROFILE
+#define DDP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof[i] += t_ - tprev; tprev = t_; }
+#else
+#define DDP(i)
+#endif
 #ifndef TMI_DD_WAVES
 #define TMI_DD_WAVES 2  // wavefronts per SIMD the register allocation of camera_diag_direct must allow
 #endif
@@ -95,7 +103,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TMI_DD_WAVES
   const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane(rec.w);
   const int model = __builtin_amdgcn_readfirstlane(rec.x);
   // the view's prepared record: a wave-uniform address, so its words arrive through the scalar cache into SGPRs
-  const double* __restrict__ Pl = prep + (size_t)__builtin_amdgcn_readfirstlane(cam) * kPrepStride;
+  // (read ONCE, before the loop: behind the LDS fences of a trip the compiler would fetch every word again at its use,
+  // a scalar-cache round trip each, with two wavefronts per SIMD to hide it).  The Jacobi scales of the position and
+  // intrinsics columns [33..45] are not needed here: they are applied to the SUMS by the reduce launch
+  // (S = diag(s) (sum A'^T N A') diag(s) for A = A' diag(s)).
+  double Pl[kPrepStride];
+  {
+    const double* __restrict__ Pg = prep + (size_t)__builtin_amdgcn_readfirstlane(cam) * kPrepStride;
+#pragma unroll
+    for (int i = 0; i < 33; ++i) Pl[i] = Pg[i];
+#pragma unroll
+    for (int i = 33; i < kPrepStride; ++i) Pl[i] = 0.0;
+  }
   // padding columns of the staged blocks stay zero for the whole launch
   for (int i = lane; i < 64 * PA; i += 64) As[i] = 0.0;
   for (int i = lane; i < 64 * PB; i += 64) Bs[i] = 0.0;
@@ -125,7 +144,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TMI_DD_WAVES
     if (s < s1) {
       lp_n = v.slot_track[s];
       xy_n = *reinterpret_cast<const double2*>(pl.cm_xy + 2 * (size_t)s);
-      const double* tr = v.trk_rec + (size_t)lp_n * TR;
+      const double* tr = v.trk_rec + (size_t)(TMI_DD_EXP == 2 ? (lp_n & 1023) : lp_n) * TR;
 #pragma unroll
       for (int i = 0; i < TU; i += 2) {
         const double2 t = *reinterpret_cast<const double2*>(tr + i);
@@ -143,7 +162,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TMI_DD_WAVES
       xy_nn = *reinterpret_cast<const double2*>(pl.cm_xy + 2 * (size_t)s);
     }
   }
+#ifdef TMI_DD_PROFILE
+  unsigned long long prof[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#endif
   for (int trip = 0; trip < trips; ++trip) {
+    DDP(5)
     const bool act = lp_n >= 0;
     const double2 xy = xy_n;
     double T[TU];
@@ -153,7 +177,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TMI_DD_WAVES
     lp_n = lp_nn;
     xy_n = xy_nn;
     if (lp_n >= 0) {
-      const double* tr = v.trk_rec + (size_t)lp_n * TR;
+      const double* tr = v.trk_rec + (size_t)(TMI_DD_EXP == 2 ? (lp_n & 1023) : lp_n) * TR;
 #pragma unroll
       for (int i = 0; i < TU; i += 2) {
         const double2 t = *reinterpret_cast<const double2*>(tr + i);
@@ -169,22 +193,40 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TMI_DD_WAVES
         xy_nn = *reinterpret_cast<const double2*>(pl.cm_xy + 2 * (size_t)s);
       }
     }
+    DDP(0)
     // ---- residual and Jacobian blocks of this lane's observation (linearize_kernel's expressions) ----
-    double r[2] = {0.0, 0.0}, Jext[2][6], Jint[2][10], Jpt[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int j = 0; j < 6; ++j) Jext[i][j] = 0.0;
-#pragma unroll
-      for (int j = 0; j < 10; ++j) Jint[i][j] = 0.0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) Jpt[i][j] = 0.0;
-    }
+    double r[2], Jext[2][6], Jint[2][10], Jpt[2][4];
     bool ok = false;
+#if TMI_DD_EXP == 3
+    ok = act;
+    r[0] = T[0] - xy.x;
+    r[1] = T[1] - xy.y;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { Jext[0][j] = T[j & 3]; Jext[1][j] = T[(j + 1) & 3]; }
+#pragma unroll
+    for (int j = 0; j < 10; ++j) { Jint[0][j] = T[j & 3] * 0.5; Jint[1][j] = T[(j + 1) & 3] * 0.25; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { Jpt[0][j] = T[j]; Jpt[1][j] = T[3 - j]; }
+#else
     if (act) ok = reprojection_error_prepared<true, double>(model, Pl, T, xy.x, xy.y, r, Jext, Jint, Jpt);
-    // an observation that does not count (past the chunk, |X - w C|^2 < 1e-8) contributes zero rows
+#endif
+    DDP(1)
+    // an observation that does not count (past the chunk: the last trip only; |X - w C|^2 < 1e-8) contributes zero rows
     const double live = ok ? 1.0 : 0.0;
-    if (!ok) r[0] = r[1] = 0.0;
+    if (!__all(ok)) {
+      if (!ok) {
+        r[0] = r[1] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+          for (int j = 0; j < 6; ++j) Jext[i][j] = 0.0;
+#pragma unroll
+          for (int j = 0; j < 10; ++j) Jint[i][j] = 0.0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) Jpt[i][j] = 0.0;
+        }
+      }
+    }
     double sqrt_rho1 = 1.0, asn = 0.0, rscale = 1.0;
     if (loss_type != 0 && ok) {
       const double sq = r[0] * r[0] + r[1] * r[1];
@@ -202,7 +244,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TMI_DD_WAVES
     double J0[DP], J1[DP];
 #pragma unroll
     for (int a = 0; a < DP; ++a) {
-      double j0 = ok ? Jpt[0][a < 4 ? a : 0] : 0.0, j1 = ok ? Jpt[1][a < 4 ? a : 0] : 0.0;
+      double j0 = Jpt[0][a < 4 ? a : 0], j1 = Jpt[1][a < 4 ? a : 0];
       if (loss_type != 0) {
         const double rtj = j0 * r[0] + j1 * r[1];
         j0 = sqrt_rho1 * (j0 - asn * r[0] * rtj);
@@ -238,23 +280,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TMI_DD_WAVES
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
       if (mask & (1u << c)) {
-        double j0, j1, scl;
+        double j0, j1;  // (zero where the observation does not count: the blocks were cleared above)
         if (c < 6) {
           j0 = Jext[0][c < 6 ? c : 0];
           j1 = Jext[1][c < 6 ? c : 0];
-          scl = c < 3 ? Pl[33 + (c < 3 ? c : 0)] : 1.0;  // (the angle-axis scales are folded into Jl)
         } else {
           j0 = Jint[0][c >= 6 ? c - 6 : 0];
           j1 = Jint[1][c >= 6 ? c - 6 : 0];
-          scl = Pl[36 + (c >= 6 ? c - 6 : 0)];
         }
         if (loss_type != 0) {
           const double rtj = j0 * r[0] + j1 * r[1];
           j0 = sqrt_rho1 * (j0 - asn * r[0] * rtj);
           j1 = sqrt_rho1 * (j1 - asn * r[1] * rtj);
         }
-        j0 = ok ? j0 * scl : 0.0;
-        j1 = ok ? j1 * scl : 0.0;
         Al[dst] = j0;
         Al[D + dst] = j1;
         Bl[dst] = n00 * j0 + n01 * j1;
@@ -262,6 +300,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TMI_DD_WAVES
         ++dst;
       }
     }
+    DDP(2)
     Bl[D] = rt0 * live;
     Bl[D + 1] = r0 * live;
     Bl[(D + 2) + D] = rt1 * live;
@@ -269,9 +308,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TMI_DD_WAVES
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    DDP(3)
     // ---- sum over the 64 slots on the matrix cores: K = 4 per step = the two rows of two slots ----
 #pragma unroll 8
-    for (int m = 0; m < 32; m += 2) {
+    for (int m = 0; m < (TMI_DD_EXP == 1 ? 0 : 32); m += 2) {
       const double a0 = opA[m * strA], b0 = opB[m * strB];
       const double a1 = opA[(m + 1) * strA], b1 = opB[(m + 1) * strB];
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
@@ -279,10 +319,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TMI_DD_WAVES
       usum += a0 * a0;
       usum += a1 * a1;
     }
+    DDP(4)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
+#ifdef TMI_DD_PROFILE
+  if (lane == 0 && (ch == 7 || ch == pl.n_chunks / 2 || ch == pl.n_chunks - 9))
+    printf("[ddg profile] chunk %d trips %d: cycles per trip: loads %llu | eval %llu | Jp Q N columns %llu | stage + barrier %llu | matrix cores %llu | loop %llu\n",
+           ch, trips, prof[0] / trips, prof[1] / trips, prof[2] / trips, prof[3] / trips, prof[4] / trips, prof[5] / trips);
+#endif
   double* out = pl.part + (size_t)ch * NA;
   acc += acc2;
 #pragma unroll
@@ -311,6 +357,14 @@ __global__ __launch_bounds__(64) void camera_diag_direct_reduce_kernel(DeviceVie
   const int rb = blockIdx.x;
   const int c0 = pl.rb_chunk[rb], c1 = pl.rb_chunk[rb + 1];
   double* diag = v.red + L.diag + (size_t)rb * D * D;
+  // Jacobi scale of a compacted column: the angle-axis columns carry theirs already (folded into Jl of the prepared
+  // record, camera_models.h), position and intrinsics columns take scale_c
+  __shared__ double f[D];
+  if (threadIdx.x < D) {
+    const int c = v.rb_cols[(size_t)rb * D + threadIdx.x];
+    f[threadIdx.x] = (c >= 3 && c < 6) ? 1.0 : (c < 0 ? 0.0 : v.scale_c[(size_t)rb * D + threadIdx.x]);
+  }
+  __syncthreads();
   for (int i = threadIdx.x; i < NA; i += 64) {
     double t = 0.0;
     for (int c = c0; c < c1; ++c) t += pl.part[(size_t)c * NA + i];
@@ -321,14 +375,18 @@ __global__ __launch_bounds__(64) void camera_diag_direct_reduce_kernel(DeviceVie
         ++a;
       }
       const int b = a + rem;
+      t *= f[a] * f[b];
       diag[a * D + b] = t;
       diag[b * D + a] = t;
     } else if (i < NS + D) {
-      v.red[L.udiag + (size_t)rb * D + (i - NS)] = t;
+      const int a = i - NS;
+      v.red[L.udiag + (size_t)rb * D + a] = t * (f[a] * f[a]);
     } else if (i < NS + 2 * D) {
-      v.red[L.gt + (size_t)rb * D + (i - NS - D)] = t;
+      const int a = i - NS - D;
+      v.red[L.gt + (size_t)rb * D + a] = t * f[a];
     } else {
-      v.red[L.gc + (size_t)rb * D + (i - NS - 2 * D)] = t;
+      const int a = i - NS - 2 * D;
+      v.red[L.gc + (size_t)rb * D + a] = t * f[a];
     }
   }
 }

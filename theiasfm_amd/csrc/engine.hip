@@ -134,6 +134,13 @@ Launch make_launch(bool fp32) {
   };
   L.point_eliminate = [](const DeviceView& v, hipStream_t st, double ir, double lo, double hi, int nb,
                          double* pm, double* vote, double gtol, double* gvote) {
+    if constexpr (!SH) {
+      if (v.direct_diag) {
+        hipLaunchKernelGGL((point_eliminate_kernel<D, DP, SH, false>), dim3(nb), dim3(256), 0, st, v, ir, lo, hi, nb, pm,
+                           vote, gtol, gvote);
+        return;
+      }
+    }
     hipLaunchKernelGGL((point_eliminate_kernel<D, DP, SH>), dim3(nb), dim3(256), 0, st, v, ir, lo, hi, nb, pm,
                        vote, gtol, gvote);
   };

@@ -711,7 +711,9 @@ __global__ void camera_scale_finish_kernel(double* scale_c, int n) {
 // SchurEliminator (hot loop 2) restricted to what the camera side needs.
 // partial: [gmax_p] (max) per block.
 // ------------------------------------------------------------------------------
-template <int D, int DP, bool SH>
+// REC = false (direct_diag.h, DeviceView::direct_diag): the per-track part only -- no camera-major records, no LDS
+// staging, a quarter of the registers, so that the sweep over the Jp and r planes runs at full occupancy.
+template <int D, int DP, bool SH, bool REC = true>
 __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, double inv_radius,
                                                               double lm_lo, double lm_hi, int nblocks,
                                                               double* partial_max, double* singular_vote,
@@ -723,8 +725,11 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
                                                           // shared blocks, the one record of as_of otherwise
   constexpr int TO = SH ? 2 * D : ASA;                    // where {N, r~, r} start in it
   constexpr int STP = (YS > AS ? YS : AS) + 2;  // LDS record pitch, +2 doubles: conflict-free b64/b128
-  __shared__ __attribute__((aligned(16))) double stage[kSlicesPerBlock][32][STP];
-  __shared__ int stage_cpos[kSlicesPerBlock][32];
+  __shared__ __attribute__((aligned(16))) double stage[REC ? kSlicesPerBlock : 1][REC ? 32 : 1][REC ? STP : 2];
+  __shared__ int stage_cpos[REC ? kSlicesPerBlock : 1][REC ? 32 : 1];
+  constexpr int TRS = DP == 3 ? 16 : 24;  // doubles of a track record (direct_diag.h, trk_stride)
+  constexpr int TPITCH = TRS + 2;
+  __shared__ __attribute__((aligned(16))) double tstage[REC ? 1 : kSlicesPerBlock][REC ? 2 : 64 * TPITCH];
   const int lane = threadIdx.x & 63;
   const TrackMap tm = track_map(v);
   double gmax = 0.0;
@@ -736,6 +741,9 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
     const size_t NP = (size_t)v.Np_pad;
     bool have_tp = false;
     double tp_s[DP], Li_s[DP][DP];
+    double trec[REC ? 2 : TRS];  // (REC = false) the track's record for the view-by-view camera side
+#pragma unroll
+    for (int i = 0; i < (REC ? 2 : TRS); ++i) trec[i] = 0.0;
     if (k > 0) {
       double V[NS], g[DP];
 #pragma unroll
@@ -849,26 +857,41 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
 #pragma unroll
         for (int b = 0; b <= a; ++b) Li_s[a][b] = Li[a][b];
       }
-      if (v.direct_diag && tm.leader) {
+      if (!REC) {
         // direct_diag.h: the camera side re-evaluates the observations view by view and needs, per track,
         // { X, L^-1 diag(scale_p), scale_p . t_p } in one record (scale 0: constant point, its Jp is zero)
-        constexpr int TRS = DP == 3 ? 16 : 24;
-        double rec[TRS];
-#pragma unroll
-        for (int i = 0; i < TRS; ++i) rec[i] = 0.0;
         const bool pc = v.pt_const[lp] != 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rec[i] = v.pts[(size_t)lp * 4 + i];
+        for (int i = 0; i < 4; ++i) trec[i] = v.pts[(size_t)lp * 4 + i];
 #pragma unroll
         for (int a = 0; a < DP; ++a) {
           const double sa = pc ? 0.0 : v.scale_p[(size_t)lp * DP + a];
-          rec[4 + NS + a] = tp[a] * sa;
+          trec[4 + NS + a] = tp[a] * sa;
 #pragma unroll
-          for (int b = a; b < DP; ++b) rec[4 + sym_idx(a, b, DP)] = Li[b][a] * sa;
+          for (int b = a; b < DP; ++b) trec[4 + sym_idx(a, b, DP)] = Li[b][a] * sa;
         }
+      }
+    }
+    if (!REC) {
+      if (tm.wide == 0) {
+        // a wavefront's 64 records are consecutive in memory: through LDS, so that consecutive lanes store consecutive
+        // 16 bytes (a lane storing its own 128-byte record 16 bytes at a time writes partial sectors)
+        double* ts = &tstage[threadIdx.x >> 6][0];
+#pragma unroll
+        for (int i = 0; i < TRS; i += 2)
+          *reinterpret_cast<double2*>(ts + lane * TPITCH + i) = make_double2(trec[i], trec[i + 1]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double* out = v.trk_rec + (size_t)tm.s * 64 * TRS;
+        for (int c = lane; c < 64 * (TRS / 2); c += 64) {
+          const int rc = c / (TRS / 2), part = c - rc * (TRS / 2);
+          *reinterpret_cast<double2*>(out + (size_t)rc * TRS + 2 * part) = *reinterpret_cast<const double2*>(ts + rc * TPITCH + 2 * part);
+        }
+      } else if (tm.leader && k > 0) {
         double* out = v.trk_rec + (size_t)lp * TRS;
 #pragma unroll
-        for (int i = 0; i < TRS; i += 2) *reinterpret_cast<double2*>(out + i) = make_double2(rec[i], rec[i + 1]);
+        for (int i = 0; i < TRS; i += 2) *reinterpret_cast<double2*>(out + i) = make_double2(trec[i], trec[i + 1]);
       }
     }
     // ---- second pass: Y = A^T (Jp L^-T), r~ = r - Jp t_p into the camera-major records.
@@ -876,13 +899,13 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
     // time in LDS and writes them out with consecutive lanes covering consecutive 16 B,
     // i.e. whole 64-byte sectors per record (scattered 8/16-byte stores cost 2-4x the
     // bytes in HBM write traffic, profiles/r01_a).  The trip count K is wave uniform.
-    double* st = &stage[threadIdx.x >> 6][0][0];
-    int* scp = &stage_cpos[threadIdx.x >> 6][0];
+    double* st = &stage[REC ? threadIdx.x >> 6 : 0][0][0];
+    int* scp = &stage_cpos[REC ? threadIdx.x >> 6 : 0][0];
     double Yg[SH ? YS : 1];  // running sum of the shared block's Y over the current run
 #pragma unroll
     for (int i = 0; i < (SH ? YS : 1); ++i) Yg[i] = 0.0;
     // (direct_diag: no camera-major records at all -- nothing but camera_diag would read them in a matrix-free iteration)
-    const int rec_trips = v.direct_diag ? 0 : tm.trips;
+    const int rec_trips = REC ? tm.trips : 0;
     for (int trip = 0; trip < rec_trips; ++trip) {
       const int j = tm.j0 + trip * tm.jstep;
       const size_t e = base + (size_t)j * 64;
