@@ -73,6 +73,39 @@ __global__ __launch_bounds__(256) void slot_gather_kernel(DeviceView v, int* __r
   }
 }
 
+// The sums run on v_mfma_f64_4x4x4f64: FOUR independent 4 x 4 x 4 products per instruction (16 cycles; the 16 x 16 x 4
+// form takes 64 cycles and a 9 x 11 result would use 99 of its 256 outputs).  Layout found with tools/mfma_probe
+// (lane = 16 g + 4 b + e): block b takes A_b[i = e][k = g] and B_b[k = g][j = e] and holds D_b[i = g][j = e].
+// S_cc is symmetric and g~, g_c sit in the last column block(s), so only the 4 x 4 blocks (I, J >= I) of
+// A^T [N A | r~ | r] are formed: 6 for D = 9, 3 for D = 6, 9 for D = 12.
+__host__ __device__ constexpr int blk_rows(int D) { return (D + 3) / 4; }
+__host__ __device__ constexpr int blk_cols(int D) { return (D + 2 + 3) / 4; }
+__host__ __device__ constexpr int blk_count(int D) {
+  int n = 0;
+  for (int I = 0; I < blk_rows(D); ++I)
+    for (int J = I; J < blk_cols(D); ++J) ++n;
+  return n;
+}
+__host__ __device__ constexpr int blk_I(int t, int D) {
+  int n = 0;
+  for (int I = 0; I < blk_rows(D); ++I)
+    for (int J = I; J < blk_cols(D); ++J) {
+      if (n == t) return I;
+      ++n;
+    }
+  return 0;
+}
+__host__ __device__ constexpr int blk_J(int t, int D) {
+  int n = 0;
+  for (int I = 0; I < blk_rows(D); ++I)
+    for (int J = I; J < blk_cols(D); ++J) {
+      if (n == t) return J;
+      ++n;
+    }
+  return 0;
+}
+__host__ __device__ constexpr int gcd_c(int a, int b) { return b == 0 ? a : gcd_c(b, a % b); }
+
 // LDS staging of one trip (64 slots) for the matrix cores: per slot the two rows of the compacted camera block A
 // (2 x D) and of B' = [N A | r~ | r] (2 x (D + 2)); pitches are odd so that the per-slot writes (lane = slot) and the
 // per-step operand reads (lane = (k, column)) both spread over the banks
@@ -91,9 +124,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TMI_DD_WAVES
   constexpr int TU = trk_used(DP);
   constexpr int NA = n_acc(D);
   constexpr int PA = StageDims<D>::PA, PB = StageDims<D>::PB;
-  __shared__ double As[64 * PA];
-  __shared__ double Bs[64 * PB];
-  __shared__ double Zs[2];
+  __shared__ double Ls[64 * PA + 64 * PB];  // staged A rows | staged B' rows
+  double* const As = Ls;
+  double* const Bs = Ls + 64 * PA;
   const int lane = threadIdx.x;
   const int ch = blockIdx.x;
   const int rb = pl.chunk_rb[ch];
@@ -116,21 +149,42 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TMI_DD_WAVES
     for (int i = 33; i < kPrepStride; ++i) Pl[i] = 0.0;
   }
   // padding columns of the staged blocks stay zero for the whole launch
-  for (int i = lane; i < 64 * PA; i += 64) As[i] = 0.0;
-  for (int i = lane; i < 64 * PB; i += 64) Bs[i] = 0.0;
-  if (lane < 2) Zs[lane] = 0.0;
-  // the matrix-core accumulator: acc[q] = element (row (lane >> 4) + 4 q, column lane & 15) of  sum A^T [N A | r~ | r]
-  v4f64 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};  // (two chains: even / odd steps)
-  double usum = 0.0;  // this lane's share of U_cc (column lane & 15, k = lane >> 4)
+  for (int i = lane; i < 64 * PA + 64 * PB; i += 64) Ls[i] = 0.0;
+  // Work items of a trip = (slot pair p, block t), item w = p NB + t goes to instruction w / 4, block w % 4; the
+  // assignment repeats every PER instructions (SP slot pairs), so a lane keeps PER accumulators: acc[r] is element
+  // (g, e) of block type (4 r + b) % NB, summed over the slot pairs that land there.
+  constexpr int NB = blk_count(D);
+  constexpr int LCM = NB * 4 / gcd_c(NB, 4);
+  constexpr int PER = LCM / 4;   // instructions per period
+  constexpr int SP = LCM / NB;   // slot pairs per period
+  constexpr int NQ = 32 / SP;    // periods per trip
+  static_assert(32 % SP == 0, "a trip is a whole number of periods");
+  double acc[PER], usq[PER];
+  int oA[PER], oB[PER];
+  const int mg = lane >> 4, mb = (lane >> 2) & 3, me = lane & 3;
+#pragma unroll
+  for (int r = 0; r < PER; ++r) {
+    acc[r] = 0.0;
+    usq[r] = 0.0;
+    const int w = 4 * r + mb, p0 = w / NB, t = w - p0 * NB;
+    int I = 0, J = 0;
+#pragma unroll
+    for (int tt = 0; tt < NB; ++tt)
+      if (t == tt) {
+        I = blk_I(tt, D);
+        J = blk_J(tt, D);
+      }
+    const int slot0 = 2 * p0 + (mg >> 1), row = mg & 1;
+    const int ca = 4 * I + me, cb = 4 * J + me;
+    // (an operand column that is padding reads the slot's pad word -- the pitch is one more than the two rows --,
+    // which nobody writes: zero, and every lane steps by the same compile-time stride)
+    oA[r] = slot0 * PA + (ca < D ? row * D + ca : 2 * D);
+    oB[r] = 64 * PA + slot0 * PB + (cb < D + 2 ? row * (D + 2) + cb : 2 * (D + 2));
+  }
   __syncthreads();
 
   double* Al = As + lane * PA;
   double* Bl = Bs + lane * PB;
-  const int ocol = lane & 15, ok4 = lane >> 4;  // operand element of this lane in an MFMA step
-  // lanes whose operand column is padding read a word that stays zero (stride 0) instead of selecting per step
-  const double* opA = ocol < D ? As + (ok4 >> 1) * PA + (ok4 & 1) * D + ocol : Zs;
-  const double* opB = ocol < D + 2 ? Bs + (ok4 >> 1) * PB + (ok4 & 1) * (D + 2) + ocol : Zs;
-  const int strA = ocol < D ? 2 * PA : 0, strB = ocol < D + 2 ? 2 * PB : 0;
 
   const int trips = (s1 - s0 + 63) >> 6;
   // software pipeline: the track record of trip t + 1 and the (track, pixel) of trip t + 2 are in flight during trip t
@@ -310,14 +364,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TMI_DD_WAVES
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     DDP(3)
     // ---- sum over the 64 slots on the matrix cores: K = 4 per step = the two rows of two slots ----
-#pragma unroll 8
-    for (int m = 0; m < (TMI_DD_EXP == 1 ? 0 : 32); m += 2) {
-      const double a0 = opA[m * strA], b0 = opB[m * strB];
-      const double a1 = opA[(m + 1) * strA], b1 = opB[(m + 1) * strB];
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc2, 0, 0, 0);
-      usum += a0 * a0;
-      usum += a1 * a1;
+#pragma unroll
+    for (int q = 0; q < (TMI_DD_EXP == 1 ? 0 : NQ); ++q) {
+      double a[PER], b[PER];
+#pragma unroll
+      for (int r = 0; r < PER; ++r) {
+        a[r] = Ls[oA[r] + q * (2 * SP * PA)];
+        b[r] = Ls[oB[r] + q * (2 * SP * PB)];
+      }
+#pragma unroll
+      for (int r = 0; r < PER; ++r) {
+        acc[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[r], b[r], acc[r], 0, 0, 0);
+        usq[r] += a[r] * a[r];
+      }
     }
     DDP(4)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -329,24 +388,57 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TMI_DD_WAVES
     printf("[ddg profile] chunk %d trips %d: cycles per trip: loads %llu | eval %llu | Jp Q N columns %llu | stage + barrier %llu | matrix cores %llu | loop %llu\n",
            ch, trips, prof[0] / trips, prof[1] / trips, prof[2] / trips, prof[3] / trips, prof[4] / trips, prof[5] / trips);
 #endif
-  double* out = pl.part + (size_t)ch * NA;
-  acc += acc2;
+  // ---- a lane's PER accumulators -> the chunk's NA sums.  Several (r, b) carry the same block type: they are added
+  // in LDS in a fixed order (rounds over r, two sub-rounds over b so that no two lanes of a round share an entry).
+  double* const Out = Ls;  // (the staging area is free now)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int i = lane; i < NA; i += 64) Out[i] = 0.0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int row = ok4 + 4 * q;
+  for (int r = 0; r < PER; ++r) {
+    // U diagonal: sum over k (the four g) of a lane's squares, diagonal block types only
+    double u = usq[r];
+    u += __shfl_xor(u, 16, 64);
+    u += __shfl_xor(u, 32, 64);
+    int bI = 0, bJ = 0;
+    {
+      const int w = 4 * r + mb, t = w % NB;
+#pragma unroll
+      for (int tt = 0; tt < NB; ++tt)
+        if (t == tt) {
+          bI = blk_I(tt, D);
+          bJ = blk_J(tt, D);
+        }
+    }
+    const int row = 4 * bI + mg, col = 4 * bJ + me;
+    int idx = -1;
     if (row < D) {
-      if (ocol < D) {
-        if (row <= ocol) out[sym_idx(row, ocol, D)] = acc[q];
-      } else if (ocol == D) {
-        out[NS + D + row] = acc[q];
-      } else if (ocol == D + 1) {
-        out[NS + 2 * D + row] = acc[q];
+      if (col < D) {
+        if (row <= col) idx = sym_idx(row, col, D);
+      } else if (col == D) {
+        idx = NS + D + row;
+      } else if (col == D + 1) {
+        idx = NS + 2 * D + row;
       }
     }
+    const int uidx = (bI == bJ && mg == 0 && col < D) ? NS + col : -1;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if ((mb < 3) == (half == 0)) {
+        if (idx >= 0) Out[idx] += acc[r];
+        if (uidx >= 0) Out[uidx] += u;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
   }
-  usum += __shfl_xor(usum, 16, 64);
-  usum += __shfl_xor(usum, 32, 64);
-  if (lane < D) out[NS + lane] = usum;
+  double* out = pl.part + (size_t)ch * NA;
+  for (int i = lane; i < NA; i += 64) out[i] = Out[i];
 }
 
 // a view's chunks summed in chunk order; results where camera_diag_kernel leaves them
