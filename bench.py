@@ -372,11 +372,9 @@ def main():
                     measured="HIP events on the engine's stream inside the timed region")
     if dom["kernel"] == "spmv" and mf_frac > 0.0:
         # beside the contract's figure, under its own key: what a matrix-free product has to read in this layout
-        e1 = os.environ.get("TMI_BA_MF_ONE_SWEEP")
-        one_sweep = (e1 != "0") and (e1 is not None or n_obs // world >= 350000)  # engine.hip build_mf_chunks
-        # engine.hip create_impl: with the one-sweep product, every position free and no constant point (the synthetic
-        # workloads) the A planes hold dc - 3 columns
-        drop_pos = one_sweep and os.environ.get("TMI_BA_DROP_POS") != "0"
+        # which product / plane layout THIS handle runs is the engine's answer, not a copy of its rules
+        info = solver.operator_info()
+        one_sweep, drop_pos = info["one_sweep_product"], info["position_columns_formed"]
         lf = matrix_free_layout_floor(n_obs // world, n_cam, n_pts // world, dc, dp, dc - 3 if drop_pos else dc)
         roofline["kernel"] = ("spmv (one product q = S p; matrix-free in %d of %d timed LM iterations: %s)"
                               % (m["matrix_free"], steps_run,
@@ -429,7 +427,11 @@ def main():
                                      "auto on one rank; both resident)"
                                      if (world == 1 and args.schur_mode == "auto" and solver_type == abi.ITERATIVE_SCHUR)
                                      else "explicit block-sparse S") if explicit else "implicit (matrix-free)"),
-                    parallelism=f"tracks sharded x{world}", transport=m["transport"]),
+                    parallelism=f"tracks sharded x{world}", transport=m["transport"],
+                    # what this handle runs (tmi_ba_solver_operator_info): the one-sweep matrix-free product, position
+                    # columns formed from the point block, camera side of matrix-free iterations built view by view
+                    # from one record per track instead of camera-major records (direct_diag.h)
+                    engine_paths=solver.operator_info()),
         lm_iterations_per_sec=steps_run / elapsed,
         pcg_iterations=int(m["pcg"]),
         matrix_free_lm_iterations_in_last_solve=int(s.num_matrix_free_iterations),

@@ -608,6 +608,14 @@ int32_t tmi_ba_adjust_two_views_angular(tmi_ba_two_view_angular_batch* batch, in
  * the definition (engine.hip).  The two builders must agree array for array. */
 int32_t tmi_ba_solver_structure_checksums(tmi_ba_solver* solver, uint64_t out[24]);
 
+/* Which kernels a handle will run -- decided at create from the problem's shape and size (bench.py reports the
+ * bytes of the kernel that ran instead of re-deriving the engine's rules):
+ *   out[0] the one-sweep matrix-free product is built (mf_chunks.h)        out[1] position columns formed from Jp
+ *   out[2] matrix-free LM iterations build the camera side without camera-major records (direct_diag.h)
+ *   out[3] schur_mode auto chooses the operator per LM iteration           out[4] S is never formed (implicit)
+ *   out[5] PCG length up to which the matrix-free operator is taken (auto) out[6], out[7] reserved (0)          */
+int32_t tmi_ba_solver_operator_info(tmi_ba_solver* solver, int32_t out[8]);
+
 /* Host-only: statistics of the static structure the engine would build for
  * rank `rank` of `world` (no GPU needed).  Used by the CPU tests of the track
  * sharding: out[0] tracks owned, out[1] observations owned, out[2] reduced

@@ -17,14 +17,16 @@ from theiasfm_amd import abi, lib, synth
 
 pytestmark = pytest.mark.gpu
 
-ENV = ("TMI_BA_DIRECT_DIAG", "TMI_BA_MF_ONE_SWEEP", "TMI_BA_SETUP_TIMING")
+ENV = ("TMI_BA_DIRECT_DIAG", "TMI_BA_MF_ONE_SWEEP", "TMI_BA_SETUP_TIMING", "TMI_BA_COST_BY_VIEW")
 
 
-def run(prob, direct, **kw):
+def run(prob, direct, cost_by_view=True, **kw):
     saved = {k: os.environ.pop(k, None) for k in ENV}
     try:
         if not direct:
             os.environ["TMI_BA_DIRECT_DIAG"] = "0"
+        if not cost_by_view:
+            os.environ["TMI_BA_COST_BY_VIEW"] = "0"
         os.environ["TMI_BA_MF_ONE_SWEEP"] = "1"  # (the one-sweep product below its size threshold)
         p = prob.copy()
         kw.setdefault("max_num_iterations", 6)
@@ -126,6 +128,35 @@ def test_auto_mode_switches_between_the_paths_per_iteration():
     assert s1.num_iterations == s0.num_iterations
     assert s1.num_linear_solver_iterations == s0.num_linear_solver_iterations
     assert abs(s1.final_cost - s0.final_cost) <= 1e-10 * s0.final_cost
+
+
+@pytest.mark.parametrize("name", ["cauchy_heavy_tail", "mixed_models", "huber_dof4"])
+def test_trial_cost_view_by_view_gives_the_track_major_one(name):
+    # ddg::cost_view_kernel against cost_kernel (TMI_BA_COST_BY_VIEW=0): the same residuals summed in another order
+    make, kw = CASES[name]
+    prob = make()
+    s1, p1 = run(prob, True, True, **kw)
+    s0, p0 = run(prob, True, False, **kw)
+    assert s1.num_iterations == s0.num_iterations and s1.num_successful_steps == s0.num_successful_steps
+    assert s1.num_linear_solver_iterations == s0.num_linear_solver_iterations
+    assert abs(s1.final_cost - s0.final_cost) <= 1e-12 * s0.final_cost
+    assert abs(s1.final_rmse - s0.final_rmse) <= 1e-12 * s0.final_rmse
+
+
+def test_a_fully_constant_camera_keeps_the_track_major_cost():
+    # its observations own no camera-major slot: the view-by-view cost would not see them
+    prob = synth.make_problem(40, 5000, 28000, seed=45, scene="ring", spread=0.5,
+                              intrinsics_to_optimize=abi.INTRINSICS_NONE)
+    prob.camera_flags[7] = abi.CAMERA_POSITION_CONSTANT | abi.CAMERA_ORIENTATION_CONSTANT
+    kw = dict(point_dof=3, **IMPL)
+    s1, p1 = run(prob, True, True, **kw)
+    s0, p0 = run(prob, False, False, **kw)
+    assert s1.num_iterations == s0.num_iterations
+    assert abs(s1.final_cost - s0.final_cost) <= 1e-10 * s0.final_cost
+    from oracle import oracle
+    ref = prob.copy()
+    st, s2 = oracle.solve(ref, abi.default_options(use_inner_iterations=0, max_num_iterations=6, **kw))
+    assert st == 0 and abs(s1.final_cost - s2.final_cost) <= 1e-9 * s2.final_cost
 
 
 def test_run_to_run_bit_identical():

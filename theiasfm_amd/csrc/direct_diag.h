@@ -441,6 +441,93 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TMI_DD_WAVES
   for (int i = lane; i < NA; i += 64) out[i] = Out[i];
 }
 
+// ------------------------------------------------------------------------------
+// Trial cost view by view (kernel class 9): the residual of reprojection_error.h:51-95 at the candidate, summed.
+// The track-major cost_kernel gathers a 192-byte half record of a DIFFERENT camera for each lane of a trip (its time
+// is the L2 gather); here the camera record is wave-uniform (SGPRs), a lane streams its slot's pixel and track index
+// and gathers the 32-byte candidate point.  Needs every observation to own a slot (no fully constant camera).
+// A workgroup = 4 wavefronts = 4 chunks of the plan; sums finished by the last workgroup as in cost_kernel.
+// ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cost_view_kernel(DeviceView v, Plan pl, const double* __restrict__ prep,
+                                                        const double* __restrict__ pts, int loss_type, double loss_width,
+                                                        int flag_slot, int nblocks, double* partial,
+                                                        double* __restrict__ sums, double* __restrict__ flag_dst) {
+  const int lane = threadIdx.x & 63;
+  const int ch = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
+  double acc[2] = {0.0, 0.0};
+  if (ch < pl.n_chunks) {
+    const int rb = pl.chunk_rb[ch];
+    const int s0 = pl.chunk_s0[ch], s1 = pl.chunk_s1[ch];
+    const int cam = __builtin_amdgcn_readfirstlane(v.rb_cam[rb]);
+    const int model = __builtin_amdgcn_readfirstlane(v.cam_rec[cam].x);
+    double P[kPrepCostWords];
+    {
+      const double* __restrict__ Pg = prep + (size_t)cam * kPrepStride;
+#pragma unroll
+      for (int i = 0; i < kPrepCostWords; ++i) P[i] = Pg[i];
+    }
+    const int trips = (s1 - s0 + 63) >> 6;
+    int lp_n = -1, lp_nn = -1;
+    double2 xy_n = make_double2(0.0, 0.0), xy_nn = make_double2(0.0, 0.0);
+    double Xn[4] = {0.0, 0.0, 0.0, 1.0};
+    {
+      const int s = s0 + lane;
+      if (s < s1) {
+        lp_n = v.slot_track[s];
+        xy_n = *reinterpret_cast<const double2*>(pl.cm_xy + 2 * (size_t)s);
+        const double2 a = *reinterpret_cast<const double2*>(pts + (size_t)lp_n * 4);
+        const double2 b = *reinterpret_cast<const double2*>(pts + (size_t)lp_n * 4 + 2);
+        Xn[0] = a.x; Xn[1] = a.y; Xn[2] = b.x; Xn[3] = b.y;
+      }
+      const int s2 = s + 64;
+      if (s2 < s1) {
+        lp_nn = v.slot_track[s2];
+        xy_nn = *reinterpret_cast<const double2*>(pl.cm_xy + 2 * (size_t)s2);
+      }
+    }
+    for (int trip = 0; trip < trips; ++trip) {
+      const bool act = lp_n >= 0;
+      const double2 xy = xy_n;
+      const double X[4] = {Xn[0], Xn[1], Xn[2], Xn[3]};
+      lp_n = lp_nn;
+      xy_n = xy_nn;
+      if (lp_n >= 0) {
+        const double2 a = *reinterpret_cast<const double2*>(pts + (size_t)lp_n * 4);
+        const double2 b = *reinterpret_cast<const double2*>(pts + (size_t)lp_n * 4 + 2);
+        Xn[0] = a.x; Xn[1] = a.y; Xn[2] = b.x; Xn[3] = b.y;
+      }
+      lp_nn = -1;
+      {
+        const int s = s0 + (trip + 2) * 64 + lane;
+        if (s < s1) {
+          lp_nn = v.slot_track[s];
+          xy_nn = *reinterpret_cast<const double2*>(pl.cm_xy + 2 * (size_t)s);
+        }
+      }
+      if (!act) continue;
+      double rr[2];
+      double (*nul6)[6] = nullptr;
+      double Jint[2][10];
+      double (*nul4)[4] = nullptr;
+      const bool ok = reprojection_error_prepared<false, double>(model, P, X, xy.x, xy.y, rr, nul6, Jint, nul4);
+      if (!ok) {
+        st_agent(&v.flags[flag_slot], 1);
+        continue;
+      }
+      const double sq = rr[0] * rr[0] + rr[1] * rr[1];
+      if (loss_type != 0) {
+        double rho[3];
+        loss_eval(loss_type, loss_width, sq, rho);
+        acc[0] += 0.5 * rho[0];
+      } else {
+        acc[0] += 0.5 * sq;
+      }
+      acc[1] += sq;
+    }
+  }
+  block_sum_finish<2>(acc, partial, nblocks, v.ticket + 2 * kTicketStride, sums, v.flags + flag_slot, flag_dst);
+}
+
 // a view's chunks summed in chunk order; results where camera_diag_kernel leaves them
 template <int D>
 __global__ __launch_bounds__(64) void camera_diag_direct_reduce_kernel(DeviceView v, RedLayout L, Plan pl) {

@@ -344,6 +344,7 @@ struct tmi_ba_solver {
   bool mf_ok = false;
   ddg::Plan dd = {};          // camera side without camera-major records (direct_diag.h); direct_ok: built
   bool direct_ok = false;
+  bool cost_by_view = false;   // ... and the trial cost view by view (every observation owns a slot)
   bool implicit = false;      // S is never formed (schur_mode)
   bool adaptive = false;      // schur_mode auto on one rank: both operators are resident and every LM iteration
                               // takes the cheaper one for the PCG length it expects (see solve)
@@ -2092,6 +2093,10 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
       s->dd.cm_xy = xy;
       s->dd.part = part;
       s->direct_ok = true;
+      // the trial cost view by view (ddg::cost_view_kernel): every observation must own a camera-major slot (no fully
+      // constant camera) and the per-workgroup partial sums must fit where cost_kernel leaves its own
+      const char* ec = getenv("TMI_BA_COST_BY_VIEW");
+      s->cost_by_view = st.Nslots == st.No && ((int)crb.size() + 3) / 4 <= nbmax && !(ec && atoi(ec) == 0);
     }
   }
   if (setup_timing) fprintf(stderr, "[tmi_ba setup] camera side of matrix-free iterations: %s\n", s->direct_ok ? "view by view from the track records (no camera-major records)" : "camera-major records");
@@ -3017,6 +3022,16 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
   sum->initial_rmse = n_obs_global > 0 ? std::sqrt(hsc[1] / n_obs_global) : 0.0;
   double final_ss = hsc[1];
 
+  // trial cost at the candidate (prep_c, pts_c): view by view where every observation owns a slot (direct_diag.h)
+  auto trial_cost = [&]() {
+    if (s->cost_by_view) {
+      const int nb = (s->dd.n_chunks + 3) / 4;
+      hipLaunchKernelGGL(ddg::cost_view_kernel, dim3(nb), dim3(256), 0, stream, v, s->dd, v.prep_c, v.pts_c, lt, lw, FL_INVALID,
+                         nb, v.partial, d_sc + 3, d_sc + 5);
+    } else {
+      s->launch.cost(v, stream, v.prep_c, v.pts_c, lt, lw, FL_INVALID, nbs, v.partial, d_sc + 3, d_sc + 5);
+    }
+  };
   // builds the camera side of the normal equations from the current linearisation
   auto build_camera_side = [&](double inv_radius) {
     {
@@ -3213,7 +3228,7 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
         s->launch.update_points(v, stream, nbp, v.partial, d_sc + 1);
         // d_sc: [mcc, step_sq_points, |x+|^2 points, cand_cost, cand_ss, invalid votes, singular
         //        track votes, time-limit votes]
-        s->launch.cost(v, stream, v.prep_c, v.pts_c, lt, lw, FL_INVALID, nbs, v.partial, d_sc + 3, d_sc + 5);
+        trial_cost();
       }
       if (st.world > 1 && now_s() - t_start >= O->max_solver_time_in_seconds) {
         // this rank's clock says the time limit has passed: its vote (the slot is zero otherwise, cleared at the
@@ -3243,7 +3258,7 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
         Timed t(s, TMI_BA_K_UPDATE_COST);
         CKH(hipMemsetAsync(v.flags + FL_INVALID, 0, sizeof(int), stream));
         prepare_cameras(s, v.ext_c, v.intr_c, v.prep_c);  // the sweep moved the candidate cameras
-        s->launch.cost(v, stream, v.prep_c, v.pts_c, lt, lw, FL_INVALID, nbs, v.partial, d_sc + 3, d_sc + 5);
+        trial_cost();
         hipLaunchKernelGGL(diff_sq_kernel, dim3(1), dim3(1024), 0, stream, v.ext, v.ext_c, (long long)6 * st.Nc, v.scal + SC_II_DEXT);
         hipLaunchKernelGGL(diff_sq_kernel, dim3(1), dim3(1024), 0, stream, v.intr, v.intr_c, (long long)s->n_intr, v.scal + SC_II_DINTR);
         // per-track sums go where the trial step left its own: d_sc[1] = |step|^2 over the
@@ -4145,6 +4160,18 @@ int32_t tmi_ba_solver_structure_checksums(tmi_ba_solver* s, uint64_t out[24]) {
   out[21] = (uint64_t)v.n_order;
   out[22] = (uint64_t)v.n_spc;
   out[23] = (uint64_t)st.Nslots;
+  return TMI_BA_OK;
+}
+
+int32_t tmi_ba_solver_operator_info(tmi_ba_solver* s, int32_t out[8]) {
+  if (!s || !out) return TMI_BA_ERR_INVALID_ARGUMENT;
+  for (int i = 0; i < 8; ++i) out[i] = 0;
+  out[0] = s->mf_ok ? 1 : 0;
+  out[1] = s->v.drop_pos ? 1 : 0;
+  out[2] = s->direct_ok ? 1 : 0;
+  out[3] = s->adaptive ? 1 : 0;
+  out[4] = s->implicit ? 1 : 0;
+  out[5] = s->adaptive ? (int32_t)std::min(s->adaptive_break_even, 1 << 30) : 0;
   return TMI_BA_OK;
 }
 

@@ -31,6 +31,7 @@ EXPORTS = (
     "tmi_ba_solver_adjust_tracks", "tmi_ba_adjust_tracks",
     "tmi_ba_solver_select_good_tracks", "tmi_ba_select_good_tracks",
     "tmi_ba_adjust_two_views", "tmi_ba_adjust_two_views_angular", "tmi_ba_solver_structure_checksums",
+    "tmi_ba_solver_operator_info",
 )
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
@@ -121,6 +122,8 @@ def load():
     L.tmi_ba_adjust_two_views_angular.restype = C.c_int32
     L.tmi_ba_solver_structure_checksums.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.tmi_ba_solver_structure_checksums.restype = C.c_int32
+    L.tmi_ba_solver_operator_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    L.tmi_ba_solver_operator_info.restype = C.c_int32
     SS = C.POINTER(abi.CSelectSummary)
     L.tmi_ba_solver_select_good_tracks.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, SS]
@@ -400,6 +403,15 @@ class Solver:
         if st != 0:
             raise EngineError(st, "tmi_ba_solver_structure_checksums")
         return list(out)
+
+    def operator_info(self) -> dict:
+        """Which kernels this handle runs (tmi_ba_solver_operator_info)."""
+        out = (C.c_int32 * 8)()
+        st = self._L.tmi_ba_solver_operator_info(self._h, out)
+        if st != 0:
+            raise EngineError(st, "tmi_ba_solver_operator_info")
+        return dict(one_sweep_product=bool(out[0]), position_columns_formed=bool(out[1]), direct_camera_side=bool(out[2]),
+                    adaptive=bool(out[3]), implicit=bool(out[4]), break_even=int(out[5]))
 
     @property
     def stream(self) -> int:
