@@ -186,7 +186,7 @@ def main():
                     help="skip the lines beside the headline: plain venice1778, inner iterations, end-to-end "
                          "C++ entry point, side kernels")
     ap.add_argument("--cpu-iters", type=int, default=2)
-    ap.add_argument("--transport", default="rccl", choices=["rccl", "torch", "staged"],
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "torch", "staged", "torch_staged"],
                     help="rccl: ncclAllReduce issued by the engine; torch: torch.distributed (nccl) hook; staged: "
                          "gloo through host memory with every rank on GPU 0 -- a functional check of the "
                          "multi-process path on a single-GPU box, not a measurement")
@@ -204,9 +204,11 @@ def main():
     from theiasfm_amd import abi, dist, lib, synth
     import __graft_entry__ as entry
 
-    rank, world, local = dist.init_from_env(backend="gloo" if args.transport == "staged" else None)
-    if args.transport == "staged":
+    one_gpu = args.transport in ("staged", "torch_staged")  # every rank on GPU 0, sums through gloo
+    rank, world, local = dist.init_from_env(backend="gloo" if one_gpu else None)
+    if one_gpu:
         local = 0
+    hook_stats = {}  # calls / bytes of the torch.distributed hook (N > 1 with --transport torch / torch_staged)
     if world != args.gpus:
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with "
@@ -292,10 +294,15 @@ def main():
             if args.transport == "staged":
                 solver.set_allreduce(dist.make_staged_allreduce())
                 transport = "gloo, staged through host memory (functional check only)"
+            elif args.transport == "torch_staged":
+                # the torch.distributed hook itself (aliased device tensors on the engine's stream) with a collective
+                # that works when the ranks share one GPU: what --transport torch runs, minus RCCL
+                solver.set_allreduce(dist.make_device_allreduce(dist.gloo_staged_sum, hook_stats))
+                transport = "torch.distributed hook with a gloo collective staged through host memory (functional check only)"
             elif args.transport == "rccl" and dist.init_native_rccl(solver, rank, world):
                 transport = "rccl (native, ncclAllReduce from the engine)"
             else:
-                solver.set_allreduce(dist.make_device_allreduce())
+                solver.set_allreduce(dist.make_device_allreduce(None, hook_stats))
                 transport = "rccl via torch.distributed hook"
         t_create = time.perf_counter() - t0
         if warmup > 0:
@@ -318,10 +325,16 @@ def main():
         elapsed = time.perf_counter() - t0
         if world > 1:
             torch.distributed.barrier()
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.transport == "staged" else "cuda")
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            elapsed = float(t.item())
+            dev = "cpu" if one_gpu else "cuda"
+            mine = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            torch.distributed.all_gather(every, mine)
+            per_rank_elapsed = [float(x.item()) for x in every]
+            elapsed = max(per_rank_elapsed)
+        else:
+            per_rank_elapsed = [elapsed]
         return dict(prob=prob, prob0=prob0, base=base, solver=solver, transport=transport, t_gen=t_gen, sweeps=run_chunks.sweeps,
+                    per_rank_elapsed=per_rank_elapsed,
                     t_create=t_create, steps_run=done, elapsed=elapsed, summary=s, pcg=pcg, accepted=acc, matrix_free=mf,
                     secs_p=secs_p, launches_p=launches_p, secs_t=secs_t, launches_t=launches_t, dom_idx=dom_idx)
 
@@ -442,6 +455,16 @@ def main():
         roofline=roofline, kernels=kernels,
         kernels_note="per-class table: separate untimed pass of the same iterations with every class timed")
     if allreduce:
+        # what the first real multi-GPU run needs to be read from ONE line: every rank's own time for the same K
+        # iterations (the slowest is the headline), rank 0's time inside the all-reduce callback and its launches from
+        # the pass with every class timed, and -- with the torch.distributed hook -- the hook's own call / byte counts
+        i_ar = abi.KERNEL_CLASS_NAMES.index("allreduce")
+        allreduce["per_rank_ms_per_step"] = [round(1e3 * e / max(steps_run, 1), 4) for e in m["per_rank_elapsed"]]
+        allreduce["rank0_calls_per_lm_iteration_measured"] = round(m["launches_p"][i_ar] / max(steps_run, 1), 2)
+        allreduce["rank0_ms_per_step_in_callback"] = round(1e3 * m["secs_p"][i_ar] / max(steps_run, 1), 4)
+        if hook_stats:
+            allreduce["torch_hook"] = dict(calls=int(hook_stats.get("calls", 0)), bytes=int(hook_stats.get("bytes", 0)),
+                                           note="over warm-up, the profiled pass and the timed region")
         out["allreduce"] = allreduce
     if steps_run != args.steps:
         out["note"] = f"solver stopped after {steps_run} of {args.steps} iterations: {s.message!r}"
@@ -739,6 +762,55 @@ def main():
                     frac=round(fl / (us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 5),
                     share_of_iteration=round(ma["secs_p"][ic] / max(sum(ma["secs_p"]), 1e-30), 4),
                     measured="HIP events on the engine's stream, the untimed pass with every class timed")
+            # ---- Venice sizes with SEQUENCE structure (synth scene "street"): neighbouring views share
+            # most tracks, distant views none -- S is a band (fill below), and PCG with SCHUR_JACOBI needs tens to
+            # hundreds of iterations per LM iteration where the ring scene of the headline needs five.  Headline options,
+            # default tolerances (the solve converges), one solve from the perturbed start.
+            pv = synth.config("venice1778_street")
+            ov = dict(point_dof=3, linear_solver_type=abi.ITERATIVE_SCHUR, use_inner_iterations=0)
+            sv = lib.Solver(pv.copy(), abi.default_options(max_num_iterations=2, **ov), 0, 1)
+            sv.solve(abi.default_options(max_num_iterations=2, **ov))
+            sv.reset()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            st_v, sm_v = sv.solve(abi.default_options(max_num_iterations=30, **ov))
+            torch.cuda.synchronize()
+            t_v = time.perf_counter() - t0
+            sv.reset()
+            _, sm_vp = sv.solve(abi.default_options(max_num_iterations=30, profile_kernels=1, **ov))
+            info_v = sv.operator_info()
+            sv.close()
+            dv = sm_vp.as_dict()
+            nv, pcg_v = int(sm_v.num_iterations), int(sm_v.num_linear_solver_iterations)
+            nnzb_v, dc_v = int(sm_v.num_schur_blocks), int(sm_v.reduced_block_dim)
+            rows_v = []
+            for name, launches, sec in zip(abi.KERNEL_CLASS_NAMES, dv["kernel_launches"], dv["kernel_seconds"]):
+                if launches == 0 or sec <= 0.0:
+                    continue
+                ab = algorithmic_bytes(name, pv.num_observations, pv.num_cameras, pv.num_points, dc_v, 3, nnzb_v, 0.0)
+                rows_v.append(dict(kernel=name, launches=int(launches), ms_per_step=round(1e3 * sec / max(1, nv), 4),
+                                   avg_us=round(1e6 * sec / launches, 2), algorithmic_bytes_per_launch=int(ab),
+                                   achieved_GBs=round(ab / (sec / launches) / 1e9, 2)))
+            dom_v = max(rows_v, key=lambda k: k["ms_per_step"])
+            out["variants"]["venice_like"] = dict(
+                workload="venice1778_street-synthetic", cameras=pv.num_cameras, tracks=pv.num_points,
+                observations=pv.num_observations, schur_blocks_upper=nnzb_v,
+                S_fill=round((2.0 * (nnzb_v - pv.num_cameras) + pv.num_cameras) / float(pv.num_cameras) ** 2, 4),
+                steps=nv, accepted_steps=int(sm_v.num_successful_steps), ms_per_step=round(1e3 * t_v / max(1, nv), 3),
+                solve_ms=round(1e3 * t_v, 2), value=pv.num_observations * nv / t_v, pcg_iterations=pcg_v,
+                pcg_iterations_per_lm_iteration=round(pcg_v / max(1, nv), 1),
+                us_per_pcg_iteration=round(1e6 * t_v / max(1, pcg_v), 1),
+                matrix_free_lm_iterations=int(sm_v.num_matrix_free_iterations), engine_paths=info_v,
+                initial_rmse=sm_v.initial_rmse, final_rmse=sm_v.final_rmse, status=int(st_v),
+                termination=bytes(sm_v.message).split(b"\0")[0].decode(),
+                roofline=dict(bound="hbm", kernel=dom_v["kernel"] + " (with the formed S a whole PCG solve is ONE persistent "
+                              "launch, pcg_persist.h: a 'launch' of this class is one PCG iteration, product + vector part)",
+                              achieved=dom_v["achieved_GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
+                              frac=round(dom_v["achieved_GBs"] / HBM_PEAK_GBS, 5), avg_us=dom_v["avg_us"],
+                              launches=dom_v["launches"], algorithmic_bytes_per_launch=dom_v["algorithmic_bytes_per_launch"],
+                              traffic=None, measured="HIP events on the engine's stream, separate pass with every class timed"),
+                kernels=rows_v,
+                note="what a sequence-structured collection asks of the path: the LM iteration is the PCG loop")
             # BASELINE config 1 (49 views, 31.8 k observations): DENSE_SCHUR by the reference's policy; a problem
             # this small is bound by launch and read-back latency, not by bytes
             ml = measure("ladybug49", args.steps, args.warmup, False)

@@ -91,6 +91,43 @@ def test_config4_venice_iterative_schur_trajectory():
         same_place((st_d, s_d, a), (st_o, s_o, b), scale=100.0)
 
 
+def test_venice_like_street_trajectory():
+    # Venice sizes with SEQUENCE structure (synth scene "street"): S is a band of ~14 % fill, PCG
+    # needs 2, 8, 30, 106, ... iterations per LM iteration with SCHUR_JACOBI -- the persistent PCG launch on the formed
+    # S and the operator choice of schur_mode auto at lengths the ring scene never reaches.  Compared row by row of the
+    # iteration trace (theia_mi355_ba.h, iteration_trace): the same accepted / rejected sequence and radii; a PCG solve
+    # of a hundred iterations stops on Ceres' Q tolerance -- a test on rounded sums -- so its length may differ by one,
+    # and after a hundred CG iterations two correct implementations hold iterates that differ far above round-off (CG
+    # loses orthogonality; both satisfy the same forcing tolerance of 0.1): the candidate cost of such a step agrees to
+    # 3e-8 relative (measured, identical PCG lengths 2 / 8 / 30 / 106).  Rows agree to 1e-9 while every PCG solve so far
+    # was shorter than 50 iterations and of identical length, and to 1e-6 from there on.
+    prob = synth.config("venice1778_street")
+    kw = dict(linear_solver_type=abi.ITERATIVE_SCHUR, point_dof=3, max_num_iterations=4, use_inner_iterations=0)
+    b = prob.copy()
+    oo = abi.default_options(**kw)
+    tr_o = abi.attach_trace(oo, 8)
+    st_o, s_o = oracle_solve(b, oo)
+    assert st_o == 0 and int(s_o.num_linear_solver_iterations) >= 100
+    for mode in (abi.SCHUR_AUTO, abi.SCHUR_IMPLICIT):
+        a = prob.copy()
+        od = abi.default_options(schur_mode=mode, **kw)
+        tr_d = abi.attach_trace(od, 8)
+        st_d, s_d = lib.solve(a, od)
+        assert st_d == 0 and s_d.num_iterations == s_o.num_iterations == 4 and s_d.final_cost < 0.05 * s_d.initial_cost
+        assert s_d.num_successful_steps == s_o.num_successful_steps
+        tol = 1e-9
+        for k in range(4):
+            rd, ro = tr_d[k], tr_o[k]  # [iteration, cost before, radius, outcome, candidate cost, model change, pcg, |step|]
+            assert rd[3] == ro[3] and rd[2] == ro[2], (mode, k, rd, ro)
+            assert abs(rd[1] - ro[1]) <= tol * ro[1], (mode, k, rd[1], ro[1])
+            assert abs(rd[6] - ro[6]) <= 1, (mode, k, rd[6], ro[6])
+            if rd[6] != ro[6] or ro[6] >= 50:
+                tol = 1e-6
+            assert abs(rd[4] - ro[4]) <= tol * ro[4], (mode, k, rd[4], ro[4])
+        assert abs(s_d.final_cost - s_o.final_cost) <= tol * s_o.final_cost
+        assert np.abs(a.extrinsics - b.extrinsics).max() <= 300.0 * (1e-6 if tol == 1e-9 else 1e-4)
+
+
 def test_config4_venice_reference_defaults_trajectory():
     """Config 4 at the REFERENCE-DEFAULT operating point -- what theia::BundleAdjustReconstruction solves when the
     caller changes nothing: Ceres' SCHUR_JACOBI block shape (one block per parameter block, bundle_adjustment.h:87),

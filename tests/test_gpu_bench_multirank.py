@@ -62,6 +62,25 @@ def test_bench_two_ranks_staged_transport(workload, steps):
     assert "allreduce" not in one
 
 
+def test_bench_two_ranks_torch_hook_with_a_gloo_collective():
+    """bench.py --transport torch_staged: dist.make_device_allreduce -- the hook `--transport torch` installs: device
+    pointers aliased through __cuda_array_interface__, one cached tensor per engine buffer, the collective issued under
+    the engine's ExternalStream -- driven end to end by two real processes; only the collective inside it is swapped for
+    one that works with both ranks on cuda:0 (the first RCCL run must not also be the first
+    execution of that code)."""
+    args = ["--workload", "ladybug49", "--steps", "4", "--warmup", "1"]
+    one = run_bench(1, 0, *args)
+    two = run_bench(2, 29621, "--transport", "torch_staged", *args)
+    assert two["n_gpus"] == 2 and "torch.distributed hook" in two["config"]["transport"]
+    assert two["pcg_iterations"] == one["pcg_iterations"] and two["accepted_steps"] == one["accepted_steps"]
+    assert abs(two["final_cost"] - one["final_cost"]) <= 1e-9 * one["final_cost"], (two["final_cost"], one["final_cost"])
+    ar = two["allreduce"]
+    assert len(ar["per_rank_ms_per_step"]) == 2 and all(x > 0 for x in ar["per_rank_ms_per_step"])
+    assert abs(max(ar["per_rank_ms_per_step"]) - two["ms_per_step"]) <= 1e-3 * two["ms_per_step"]
+    assert ar["torch_hook"]["calls"] > 0 and ar["torch_hook"]["bytes"] > 0
+    assert ar["rank0_calls_per_lm_iteration_measured"] >= 2
+
+
 def test_native_rccl_refuses_two_ranks_on_one_device_cleanly():
     """tmi_ba_solver_init_rccl with two ranks that both sit on cuda:0: ncclCommInitRank must come back with an error
     on both (no hang, no crash), the handle stays usable with the staged hook, and dist.init_native_rccl reports False

@@ -1974,22 +1974,6 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   // against the [A | Q] kernel on the same matrix)
   s->y_records = st.has_shared || getenv("TMI_BA_SCHUR_Y") != nullptr;
   v.write_y = (s->y_records && (!s->implicit || st.has_shared)) ? 1 : 0;
-  if (s->adaptive) {
-    // cost model measured on MI355X (profiles/r02_z, r04): forming S ~61 ps per pair (79 with 4-dof points), a product
-    // with S ~195 ps per upper block, a matrix-free product ~85 ps per observation in two passes.  The one-sweep
-    // product takes 56-62 ps per observation, but the break-even that measures best on the bench problem at the
-    // reference's default options (TMI_BA_BREAK_EVEN = 8 / 16 / 24 / 32 / 48: 10.67 / 10.58 / 10.66 / 10.77 / 10.91 ms per
-    // LM iteration; the forecast of an iteration's PCG length is the previous iteration's, and the lengths grow) is
-    // what 70 ps give
-    const bool one_sweep_size = st.No >= 350000;  // (build_mf_chunks' rule; the product itself is built further down)
-    const double form = (s->DP == 4 ? 79.0 : 61.0) * (double)st.npairs, with_s = 195.0 * (double)st.nub,
-                 free = (one_sweep_size ? 70.0 : 85.0) * (double)st.No;
-    if (const char* e = getenv("TMI_BA_BREAK_EVEN")) s->adaptive_break_even_override = atoi(e);
-    // (a product with S that costs more than a matrix-free one -- many views, little co-visibility: S has more
-    // blocks than there are observations to walk -- never pays off: always matrix-free)
-    s->adaptive_break_even = free > with_s ? (int)std::min(1.0e6, form / (free - with_s)) : 1 << 30;
-    if (s->adaptive_break_even_override >= 0) s->adaptive_break_even = s->adaptive_break_even_override;
-  }
   AL(v.cm_Y, v.write_y ? (size_t)std::max<int64_t>(st.Nslots, 1) * YS : 1) AL(v.cm_A, (size_t)std::max<int64_t>(st.Nslots, 1) * AS)
   v.cm_R = v.cm_A + (size_t)std::max<int64_t>(st.Nslots, 1) * asa_of(D, DP);  // tails behind the [A | Q] records (!has_shared)
   AL(v.scale_c, std::max(n_r, 1)) AL(v.scale_p, NP * DP)
@@ -2098,6 +2082,24 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
       const char* ec = getenv("TMI_BA_COST_BY_VIEW");
       s->cost_by_view = st.Nslots == st.No && ((int)crb.size() + 3) / 4 <= nbmax && !(ec && atoi(ec) == 0);
     }
+  }
+  if (s->adaptive) {
+    // Cost model of schur_mode auto, constants measured on MI355X (profiles/r02_z, r04, r05): forming S ~61 ps per pair
+    // (79 with 4-dof points), a product with S ~195 ps per upper block, a matrix-free product ~85 ps per observation in
+    // two passes and 52 (57 with 4-dof points) in one sweep.  An iteration that forms S also writes and reads the
+    // camera-major records, which a matrix-free one with the direct camera side (direct_diag.h) does not: ~80 ps per
+    // observation (point_eliminate 0.41 against 0.11 ms, camera_diag 0.32 against 0.22 ms at Venice size).  Round 4
+    // priced the one-sweep product at 70 ps (what measured best then: TMI_BA_BREAK_EVEN = 8 / 16 / 24 / 32 / 48 gave
+    // 10.67 / 10.58 / 10.66 / 10.77 / 10.91 ms per LM iteration at the reference's default options); with the records
+    // gone from the matrix-free iterations 15 / 32 / 64 / 128 give 9.96 / 9.56 / 9.14 / 9.17 ms.
+    const double form = (s->DP == 4 ? 79.0 : 61.0) * (double)st.npairs + (s->direct_ok ? 80.0 * (double)st.No : 0.0),
+                 with_s = 195.0 * (double)st.nub,
+                 free = (s->mf_ok ? (s->DP == 4 ? 57.0 : 52.0) : 85.0) * (double)st.No;
+    if (const char* e = getenv("TMI_BA_BREAK_EVEN")) s->adaptive_break_even_override = atoi(e);
+    // (a product with S that costs more than a matrix-free one -- many views, little co-visibility: S has more
+    // blocks than there are observations to walk -- never pays off: always matrix-free)
+    s->adaptive_break_even = free > with_s ? (int)std::min(1.0e6, form / (free - with_s)) : 1 << 30;
+    if (s->adaptive_break_even_override >= 0) s->adaptive_break_even = s->adaptive_break_even_override;
   }
   if (setup_timing) fprintf(stderr, "[tmi_ba setup] camera side of matrix-free iterations: %s\n", s->direct_ok ? "view by view from the track records (no camera-major records)" : "camera-major records");
   if (s->vis_clusters && (rc = build_visibility_clusters(s, P, O->visibility_clustering_type))) return rc;

@@ -48,14 +48,23 @@ def init_from_env(backend: str | None = None):
     return rank, world, local
 
 
-def make_device_allreduce():
+def make_device_allreduce(collective=None, stats=None):
     """Hook for lib.Solver.set_allreduce on GPU: RCCL sum over the default group,
-    enqueued on the engine's stream (no host synchronisation)."""
+    enqueued on the engine's stream (no host synchronisation).
+
+    collective: the in-place sum of a device tensor over the group (default: torch.distributed.all_reduce, i.e. RCCL
+    with backend "nccl").  tests/test_gpu_bench_multirank.py passes gloo_staged_sum so that THIS hook -- the pointer
+    aliasing through __cuda_array_interface__, the per-buffer tensor cache, the ExternalStream of the engine -- runs
+    with two real processes on a box whose ranks share one GPU (where RCCL itself cannot).
+    stats: optional dict, counts calls and bytes (bench.py prints them for N > 1)."""
     import torch
     import torch.distributed as dist
 
     streams = {}
     tensors = {}  # the engine's buffers are persistent: alias each (pointer, count) once
+    if collective is None:
+        def collective(t):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
     def hook(ptr: int, count: int, stream: int) -> int:
         if count <= 0:
@@ -69,10 +78,23 @@ def make_device_allreduce():
             ext = torch.cuda.ExternalStream(stream)
             streams[stream] = ext
         with torch.cuda.stream(ext):
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            collective(t)
+        if stats is not None:
+            stats["calls"] = stats.get("calls", 0) + 1
+            stats["bytes"] = stats.get("bytes", 0) + 8 * int(count)
         return 0
 
     return hook
+
+
+def gloo_staged_sum(t):
+    """In-place sum of a device tensor over the default group through host memory (gloo): the collective
+    make_device_allreduce takes when the ranks share one GPU.  Runs under the caller's stream context; the copies
+    order themselves on it."""
+    import torch.distributed as dist
+    h = t.cpu()
+    dist.all_reduce(h, op=dist.ReduceOp.SUM)
+    t.copy_(h)
 
 
 def make_host_allreduce():
