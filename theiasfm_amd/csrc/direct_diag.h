@@ -448,13 +448,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TMI_DD_WAVES
 // and gathers the 32-byte candidate point.  Needs every observation to own a slot (no fully constant camera).
 // A workgroup = 4 wavefronts = 4 chunks of the plan; sums finished by the last workgroup as in cost_kernel.
 // ------------------------------------------------------------------------------
+// warm (Infinity Cache): the trial cost is followed -- when the step is accepted, the usual case -- by linearize, whose
+// 0.8 GB of plane stores leave its own reads (the track-major pixels and camera indices, 20 B per observation) queueing
+// behind a saturated write stream: 350 -> 404 us when nothing had touched them since the last iteration (the track-major
+// cost_kernel used to, as a side effect).  Every wavefront here also reads its share of those two arrays, which this
+// kernel's own gathers leave room for, so that linearize finds them in the memory-side cache.
 __global__ __launch_bounds__(256) void cost_view_kernel(DeviceView v, Plan pl, const double* __restrict__ prep,
                                                         const double* __restrict__ pts, int loss_type, double loss_width,
                                                         int flag_slot, int nblocks, double* partial,
-                                                        double* __restrict__ sums, double* __restrict__ flag_dst) {
+                                                        double* __restrict__ sums, double* __restrict__ flag_dst, int warm) {
   const int lane = threadIdx.x & 63;
   const int ch = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
   double acc[2] = {0.0, 0.0};
+  double wsum = 0.0;
+  if (warm && ch < pl.n_chunks) {
+    // 16-byte pieces of obs_xy (2 doubles per observation) and obs_cam (1 int): this chunk's contiguous share
+    const size_t n16 = (size_t)v.No_pad + (size_t)v.No_pad / 4;
+    const size_t per = (n16 + pl.n_chunks - 1) / pl.n_chunks;
+    const size_t b0 = (size_t)ch * per, b1 = b0 + per < n16 ? b0 + per : n16;
+    const double2* xy16 = reinterpret_cast<const double2*>(v.obs_xy);
+    const double2* cam16 = reinterpret_cast<const double2*>(v.obs_cam);
+    for (size_t i = b0 + lane; i < b1; i += 64) {
+      const double2 t = i < (size_t)v.No_pad ? xy16[i] : cam16[i - (size_t)v.No_pad];
+      wsum += t.x;
+    }
+  }
   if (ch < pl.n_chunks) {
     const int rb = pl.chunk_rb[ch];
     const int s0 = pl.chunk_s0[ch], s1 = pl.chunk_s1[ch];
@@ -525,6 +543,7 @@ __global__ __launch_bounds__(256) void cost_view_kernel(DeviceView v, Plan pl, c
       acc[1] += sq;
     }
   }
+  if (wsum == -1.2345678e300) acc[1] += wsum;  // (never: keeps the warming loads alive)
   block_sum_finish<2>(acc, partial, nblocks, v.ticket + 2 * kTicketStride, sums, v.flags + flag_slot, flag_dst);
 }
 

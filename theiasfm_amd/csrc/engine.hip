@@ -345,6 +345,7 @@ struct tmi_ba_solver {
   ddg::Plan dd = {};          // camera side without camera-major records (direct_diag.h); direct_ok: built
   bool direct_ok = false;
   bool cost_by_view = false;   // ... and the trial cost view by view (every observation owns a slot)
+  bool cost_warm = true;       // ... which also reads linearize's observation stream into the Infinity Cache (TMI_BA_COST_WARM=0: off)
   bool implicit = false;      // S is never formed (schur_mode)
   bool adaptive = false;      // schur_mode auto on one rank: both operators are resident and every LM iteration
                               // takes the cheaper one for the PCG length it expects (see solve)
@@ -2080,6 +2081,7 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
       // the trial cost view by view (ddg::cost_view_kernel): every observation must own a camera-major slot (no fully
       // constant camera) and the per-workgroup partial sums must fit where cost_kernel leaves its own
       const char* ec = getenv("TMI_BA_COST_BY_VIEW");
+      if (const char* ew = getenv("TMI_BA_COST_WARM")) s->cost_warm = atoi(ew) != 0;
       s->cost_by_view = st.Nslots == st.No && ((int)crb.size() + 3) / 4 <= nbmax && !(ec && atoi(ec) == 0);
     }
   }
@@ -3029,7 +3031,7 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
     if (s->cost_by_view) {
       const int nb = (s->dd.n_chunks + 3) / 4;
       hipLaunchKernelGGL(ddg::cost_view_kernel, dim3(nb), dim3(256), 0, stream, v, s->dd, v.prep_c, v.pts_c, lt, lw, FL_INVALID,
-                         nb, v.partial, d_sc + 3, d_sc + 5);
+                         nb, v.partial, d_sc + 3, d_sc + 5, s->cost_warm ? 1 : 0);
     } else {
       s->launch.cost(v, stream, v.prep_c, v.pts_c, lt, lw, FL_INVALID, nbs, v.partial, d_sc + 3, d_sc + 5);
     }

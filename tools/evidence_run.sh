@@ -1,17 +1,13 @@
 #!/bin/bash
 # evidence run of a round (on the GPU box, via gpurun): tests, smoke, default bench line, kernel trace, PMC passes,
 # alamo-variant kernel trace, config-5 kernel trace, scale probe.  usage: tools/evidence_run.sh <tag>   (e.g. r03_z)
-T=${1:-r04_e}
+T=${1:-r05_f}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 cd $R
 export TMI_GIT_HEAD=${TMI_GIT_HEAD:-unknown}
 timeout 2400 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -8 > $O/${T}_pytest.log
 grep -E "passed|failed" $O/${T}_pytest.log
 python -c "import __graft_entry__ as e; e.smoke(); print('smoke ok')" 2>&1 | tail -1
-SECONDS=0
-timeout 900 python bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err
-echo "default bench.py wall: $SECONDS s"
-head -c 300 $O/${T}_bench.json; echo
 cd /tmp && export TMPDIR=/tmp && cd $R
 rm -rf $O/${T}_stats
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_stats -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $O/${T}_stats.log 2>&1
@@ -21,6 +17,12 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python tools/summarize_profile.py $T $O/${T}_stats $O/${T}_pmc_FETCH_SIZE $O/${T}_pmc_WRITE_SIZE > $O/${T}_summary.txt 2>&1
 head -14 $O/${T}_summary.txt
+# the default bench line AFTER the PMC passes: pmc_latest.json now carries this build's stamp, so roofline.traffic is
+# filled (the committed r04 line was taken before the passes and said traffic: null / stale)
+SECONDS=0
+timeout 900 python bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err
+echo "default bench.py wall: $SECONDS s"
+head -c 300 $O/${T}_bench.json; echo
 # the reference-default operating point: kernel trace
 rm -rf $O/${T}_refdef_stats
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_refdef_stats -- python tools/refdef_probe.py 10 refdef_auto > $O/${T}_refdef.log 2>&1

@@ -85,7 +85,10 @@ def main():
               "cost_kernel": "update_cost", "update_points_kernel": "update_cost",
               "update_cameras_kernel": "update_cost", "schur_offdiag_aq_kernel": "schur_offdiag",
               "pcg_step_kernel": "pcg_vector", "pcg_p_kernel": "pcg_vector", "pcg_init_kernel": "pcg_vector",
-              "camera_prepare_kernel": "linearize"}
+              "camera_prepare_kernel": "linearize",
+              # round 5 (direct_diag.h): the camera side and the trial cost view by view
+              "ddg::camera_diag_direct_kernel": "camera_diag", "ddg::camera_diag_direct_reduce_kernel": "camera_diag",
+              "ddg::cost_view_kernel": "update_cost", "pos_coef_kernel": "linearize"}
     classes = {}
     for r in rows:
         base = r["kernel"].split("<")[0]
