@@ -2607,6 +2607,13 @@ static int solve_reduced_pcg(tmi_ba_solver* s, const tmi_ba_options* O, int* usa
       rc = readback(s);
       if (rc) return rc;
     }
+    {
+      static const bool pcg_trace = getenv("TMI_BA_PCG_TRACE") != nullptr;  // (diagnostics: the scalars of every PCG iteration)
+      if (pcg_trace)
+        fprintf(stderr, "[tmi_ba pcg] it %d %s pq %.17g alpha %.17g Q1 %.17g zeta %.17g rho %.17g\n", it,
+                fused && !reset ? "step" : "reset", s->h_scal[SC_PQ], s->h_scal[SC_ALPHA], s->h_scal[SC_Q1], s->h_scal[SC_ZETA],
+                s->h_scal[SC_RHO]);
+    }
     if (s->h_flags[FL_PCG_FAIL]) {
       *usable = 0;
       break;
