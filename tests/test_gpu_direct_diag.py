@@ -195,3 +195,25 @@ def test_the_records_stay_where_something_else_reads_them(capfd):
     assert not _setup_says(prob, capfd, point_dof=3, residual_precision=32, **IMPL)
     # the exact solvers form S
     assert not _setup_says(prob, capfd, point_dof=3, linear_solver_type=abi.DENSE_SCHUR)
+
+
+def test_operator_info_reports_the_paths_of_a_handle():
+    # tmi_ba_solver_operator_info: what bench.py prints as config.engine_paths
+    prob = synth.make_problem(30, 3000, 15000, seed=29, scene="ring", spread=0.5)
+    saved = {k: os.environ.pop(k, None) for k in ENV}
+    os.environ["TMI_BA_MF_ONE_SWEEP"] = "1"
+    try:
+        s = lib.Solver(prob.copy(), abi.default_options(max_num_iterations=1, point_dof=3, **IMPL), 0, 1)
+        info = s.operator_info()
+        s.close()
+        assert info["one_sweep_product"] and info["position_columns_formed"] and info["direct_camera_side"]
+        assert info["implicit"] and not info["adaptive"]
+        s = lib.Solver(prob.copy(), abi.default_options(max_num_iterations=1, point_dof=3, linear_solver_type=abi.DENSE_SCHUR), 0, 1)
+        info = s.operator_info()
+        s.close()
+        assert not info["one_sweep_product"] and not info["direct_camera_side"] and not info["implicit"]
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v

@@ -97,9 +97,12 @@ def main():
     sys.path.insert(0, os.path.dirname(out_dir))
     import bench  # engine_source_sha(): the stamp bench.py checks before quoting these bytes
     if fetch and write:  # only a run with both PMC passes replaces the traffic table
+      # the default workload's table is pmc_latest.json; every other workload keeps its own (bench.py reads the
+      # reference-default one for variants.reference_defaults.roofline.traffic)
+      name = "pmc_latest.json" if workload == "venice1778_heavy" else f"pmc_{workload}.json"
       json.dump(dict(tag=tag, workload=workload, correction="2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes",
                      engine_source_sha=bench.engine_source_sha(), git_head=os.environ.get("TMI_GIT_HEAD"),
-                     classes=classes), open(os.path.join(out_dir, "pmc_latest.json"), "w"), indent=1)
+                     classes=classes), open(os.path.join(out_dir, name), "w"), indent=1)
     print(open(os.path.join(out_dir, f"{tag}_summary.md")).read())
 
 
