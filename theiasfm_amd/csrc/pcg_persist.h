@@ -45,7 +45,8 @@ constexpr int kWaves = 8;
 constexpr int kThreads = 64 * kWaves;
 constexpr int kBarInts = 2 * 8 * 1024;  // the grid barrier's records: two sets of 32 bytes per workgroup (grid <= 1024)
 constexpr int kResetPeriod = 10;  // ConjugateGradientsSolver: residual_reset_period
-constexpr int kDepth = 3;         // trips of S a wavefront keeps in flight
+constexpr int kDepth = 2;         // trips of S a wavefront keeps in flight (same box, street scene, us per PCG iteration:
+                                  // 1: 108.4, 2: 88.2, 3: 94.4, 5: 106.6 -- the loads of a trip live in registers)
 // chunks per wavefront whose header and block columns stay on chip over the solve; entries per lane of the first owned
 // column whose tbuf indices do (both in LDS: the wide blocks leave less of it)
 __host__ __device__ constexpr int chunks_cached(int D) { return D <= 9 ? 3 : 1; }
