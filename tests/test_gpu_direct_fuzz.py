@@ -75,3 +75,55 @@ def test_random_shapes(seed):
     assert np.array_equal(t1[:n, 6], t0[:n, 6]), (t1[:n, 6], t0[:n, 6])  # PCG iterations of every LM iteration
     assert np.abs(t1[:n, 1] - t0[:n, 1]).max() <= 1e-9 * max(t0[0, 1], 1e-30)
     assert abs(s1.final_cost - s0.final_cost) <= 1e-9 * max(s0.final_cost, 1e-30)
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_random_shapes_follow_the_oracle(seed):
+    """The same generator against the ORACLE (default paths of the engine, whatever they are for the shape): exact and
+    iterative reduced solves, row by row of the iteration trace."""
+    from oracle import oracle
+    rng = np.random.default_rng(5000 + seed)
+    n_cam = int(rng.choice([7, 12, 20, 45]))
+    n_pts = int(rng.integers(40 * n_cam, 120 * n_cam))
+    n_obs = int(float(rng.uniform(2.5, min(7.0, 0.8 * n_cam))) * n_pts)
+    models = None
+    if rng.random() < 0.5:
+        pick = rng.choice(len(MODELS), size=int(rng.integers(1, 4)), replace=False)
+        models = [(MODELS[int(i)], 1.0 / len(pick)) for i in pick]
+    prob = synth.make_problem(n_cam, n_pts, n_obs, seed=6000 + seed, scene="ring", spread=float(rng.uniform(0.3, 1.0)),
+                              models=models, intrinsics_to_optimize=int(rng.choice(INTR)))
+    if rng.random() < 0.4:
+        prob.point_constant[rng.choice(prob.num_points, size=max(1, prob.num_points // 50), replace=False)] = 1
+    if rng.random() < 0.4:
+        for c in rng.choice(n_cam, size=max(1, n_cam // 6), replace=False):
+            prob.camera_flags[c] = int(rng.choice([abi.CAMERA_POSITION_CONSTANT, abi.CAMERA_ORIENTATION_CONSTANT]))
+    solver = int(rng.choice([abi.DENSE_SCHUR, abi.SPARSE_SCHUR, abi.ITERATIVE_SCHUR]))
+    kw = dict(point_dof=int(rng.choice([3, 4])), loss_function_type=int(rng.choice(LOSSES)),
+              robust_loss_width=float(rng.uniform(1.0, 4.0)), linear_solver_type=solver, use_inner_iterations=0,
+              max_num_iterations=5)
+    saved = {k: os.environ.pop(k, None) for k in ENV}
+    try:
+        os.environ["TMI_BA_MF_ONE_SWEEP"] = "1"
+        od = abi.default_options(**kw)
+        td = abi.attach_trace(od, 6)
+        a = prob.copy()
+        st_d, s_d = lib.solve(a, od)
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    oo = abi.default_options(**kw)
+    to = abi.attach_trace(oo, 6)
+    b = prob.copy()
+    st_o, s_o = oracle.solve(b, oo)
+    assert st_d == st_o, (st_d, s_d.message, st_o, s_o.message)
+    if st_o != 0:
+        return
+    n = int(s_o.num_iterations)
+    assert s_d.num_iterations == s_o.num_iterations
+    assert np.array_equal(td[:n, 3], to[:n, 3]), (td[:n, 3], to[:n, 3])
+    assert np.array_equal(td[:n, 6], to[:n, 6]), (td[:n, 6], to[:n, 6])
+    tol = 1e-9 if kw["point_dof"] == 3 else 1e-7  # (4-dof points carry an exact gauge direction, DESIGN section 8)
+    assert np.abs(td[:n, 1] - to[:n, 1]).max() <= tol * max(to[0, 1], 1e-30)
+    assert abs(s_d.final_cost - s_o.final_cost) <= tol * max(s_o.final_cost, 1e-30)
