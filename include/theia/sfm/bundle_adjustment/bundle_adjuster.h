@@ -28,14 +28,41 @@ class CameraIntrinsicsModel;
 class Reconstruction;
 class Track;
 
+// Allocator whose value-less construct() default-initialises: vector::resize(n) of a trivial type then allocates
+// without zero-filling.  The per-observation arrays below (and the residual list) are 40-120 MB each at Venice size and
+// are filled by threads right after they are sized: a single-threaded memset of memory that is about to be
+// overwritten cost 15-20 ms per array of the 0.21 s set-up of BundleAdjustReconstruction (tools/e2e_setup_probe.py).
+template <class T>
+struct DefaultInitAllocator : std::allocator<T> {
+  template <class U>
+  struct rebind {
+    using other = DefaultInitAllocator<U>;
+  };
+  DefaultInitAllocator() = default;
+  template <class U>
+  DefaultInitAllocator(const DefaultInitAllocator<U>&) {}
+  template <class U>
+  void construct(U* p) {
+    ::new (static_cast<void*>(p)) U;
+  }
+  template <class U, class... Args>
+  void construct(U* p, Args&&... args) {
+    ::new (static_cast<void*>(p)) U(std::forward<Args>(args)...);
+  }
+};
+template <class T>
+using BulkVector = std::vector<T, DefaultInitAllocator<T>>;
+
 // The flattened problem Optimize() hands to the C ABI (exposed for tests and
 // for callers that want to keep a problem resident with tmi_ba_solver_*).
 struct FlattenedBundleAdjustmentProblem {
   std::vector<ViewId> view_ids;                   // camera index -> ViewId (ascending)
   std::vector<TrackId> track_ids;                 // point index -> TrackId (ascending)
   std::vector<CameraIntrinsicsGroupId> group_ids; // group index -> group id (ascending)
-  std::vector<double> extrinsics, intrinsics, points, obs_xy;
-  std::vector<int32_t> camera_group, group_model, group_offset, obs_camera, obs_point;
+  std::vector<double> extrinsics, intrinsics, points;
+  std::vector<int32_t> camera_group, group_model, group_offset;
+  BulkVector<double> obs_xy;                      // [2 x #observations]   (sized without a fill, see BulkVector)
+  BulkVector<int32_t> obs_camera, obs_point;      // [#observations], ordered by (track, view)
   std::vector<uint8_t> camera_flags, intrinsics_constant, point_constant;
   tmi_ba_problem AsC();
 };
@@ -105,7 +132,7 @@ class BundleAdjuster {
 
   // what the reference keeps inside ceres::Problem
   struct Residual { ViewId view; TrackId track; double x, y; };
-  std::vector<Residual> residuals_;
+  BulkVector<Residual> residuals_;
   // id -> small state, a flat table when the ids are compact (Reconstruction hands them out
   // consecutively) and a hash map otherwise: the reference pays hash look-ups into ceres::Problem
   // per residual (5 M at Venice size); the per-residual path here is one array access.

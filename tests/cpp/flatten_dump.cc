@@ -32,8 +32,8 @@ static T rd(FILE* f) {
   }
   return v;
 }
-template <class T>
-static void wr(FILE* f, const std::vector<T>& v) {
+template <class T, class A>
+static void wr(FILE* f, const std::vector<T, A>& v) {
   if (!v.empty()) fwrite(v.data(), sizeof(T), v.size(), f);
 }
 

@@ -487,7 +487,7 @@ bool BundleAdjuster::Flatten(FlattenedBundleAdjustmentProblem* f) {
     for (int t = 0; t < n_threads; ++t) pool.emplace_back([&, t] { body(t); });
     for (auto& th : pool) th.join();
   };
-  std::vector<Rec> coarse(n);
+  std::unique_ptr<Rec[]> coarse(new Rec[n ? n : 1]);  // (not value-initialised: every slot is written by the scatter below)
   std::vector<size_t> bucket_first(nbuckets + 1, 0);
   {
     std::vector<std::vector<size_t> > cnt(n_threads, std::vector<size_t>(nbuckets, 0));
