@@ -113,6 +113,8 @@ struct DeviceView {
   double* xs;        // [Nrb D] the vector of the running product / back-substitution, position entries times scale_c
   double* pm_Jp;
   double* pm_A1;    // [2 D][No_pad] shared-intrinsics Jacobian columns (has_shared only)
+  int planes_fp32;  // round 5: residual_precision = 32 on a problem with shared intrinsics blocks STORES pm_r / pm_A / pm_A1 /
+                    //   pm_Jp as float (same tile layout in elements; the allocations stay sized for doubles)
   double* cam_part; // [Ncam_rb][2 D^2 + 3 D] per-view sums for the shared blocks
   double* cm_Y;
   double* cm_A;

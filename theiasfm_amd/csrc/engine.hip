@@ -266,6 +266,37 @@ Launch make_launch(bool fp32) {
   L.pcg_persistent = [](const DeviceView& v, hipStream_t st, int grid, const ppcg::Args& a) {
     hipLaunchKernelGGL((ppcg::pcg_persistent_kernel<D>), dim3(grid), dim3(ppcg::kThreads), 0, st, v, a);
   };
+  if constexpr (SH) {
+    if (fp32) {
+      // fp32 evaluation on a problem with shared intrinsics blocks (BASELINE config 5): the per-observation planes are
+      // STORED in fp32 as well (DeviceView::planes_fp32; sums and everything per track / per view stay fp64) -- the
+      // kernels that touch the planes, in their float instantiation
+      L.linearize = [](const DeviceView& v, hipStream_t st, const double* prep, int lt, double lw, int nb, double* sums) {
+        hipLaunchKernelGGL((linearize_kernel<D, DP, SH, float, 2, float>), dim3(nb), dim3(256), 0, st, v, prep, lt, lw, nb, sums);
+      };
+      L.point_scale = [](const DeviceView& v, hipStream_t st, int nb) {
+        hipLaunchKernelGGL((point_scale_kernel<DP, float>), dim3(nb), dim3(256), 0, st, v);
+      };
+      L.point_eliminate = [](const DeviceView& v, hipStream_t st, double ir, double lo, double hi, int nb, double* pm,
+                             double* vote, double gtol, double* gvote) {
+        hipLaunchKernelGGL((point_eliminate_kernel<D, DP, SH, true, float>), dim3(nb), dim3(256), 0, st, v, ir, lo, hi, nb, pm,
+                           vote, gtol, gvote);
+      };
+      L.implicit_spmv = [](const DeviceView& v, hipStream_t st, RedLayout R, const double* x, double* y, double* w1, double* w2,
+                           double ir, double lo, double hi, int add_diag, int nb, int dot) {
+        if (!v.Nrb) return;
+        hipLaunchKernelGGL((implicit_tracks_sq_kernel<D, DP, float>), dim3(nb), dim3(256), 0, st, v, x, w1);
+        hipLaunchKernelGGL((implicit_cameras_sq_kernel<D, DP>), dim3(v.Ncam_rb), dim3(64), 0, st, v, R, x, w1, y,
+                           ir, lo, hi, add_diag, v.cam_part);
+        if (v.Nrb > v.Ncam_rb)
+          hipLaunchKernelGGL((implicit_groups_kernel<D>), dim3(v.Nrb - v.Ncam_rb), dim3(64), 0, st, v, R, x, v.cam_part,
+                             y, ir, lo, hi, add_diag);
+      };
+      L.back_substitute = [](const DeviceView& v, hipStream_t st, int nb, double* partial, double* sums) {
+        hipLaunchKernelGGL((back_substitute_kernel<D, DP, SH, float>), dim3(nb), dim3(256), 0, st, v, nb, partial, sums);
+      };
+    }
+  }
   L.tile_gather = [](const DeviceView& v, hipStream_t st, const double* ub, const double* rhs, double* tiles, int n) {
     const long long total = ((long long)v.nub + v.Nrb) * D * D + n;
     if (total)
@@ -1826,6 +1857,7 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   memset(&v, 0, sizeof(v));
   v.Nc = st.Nc; v.G = st.G; v.Np_pad = st.Np_pad; v.nslices = st.nslices; v.Nrb = st.Nrb;
   v.Ncam_rb = st.Ncam_rb; v.has_shared = st.has_shared ? 1 : 0;
+  v.planes_fp32 = (st.has_shared && O->residual_precision == 32) ? 1 : 0;  // (make_launch picks the float-plane kernels)
   v.D = D; v.DP = DP; v.No_pad = (int)st.No_pad; v.Nslots = (int)st.Nslots;
   v.nub = (int)st.nub; v.nnzb = (int)st.nnzb; v.npairs = st.npairs;
   v.n_order = s->device_structure ? s->n_order_dev : (int)st.ub_order.size();
@@ -4221,6 +4253,15 @@ int32_t tmi_ba_solver_evaluate(tmi_ba_solver* s, double* residuals, double* jac_
   std::vector<double> A1((jac_shared && st.has_shared) ? (size_t)2 * D * N : 0);
   if (!A1.empty()) TMI_HIP(hipMemcpyAsync(A1.data(), v.pm_A1, A1.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
   TMI_HIP(hipStreamSynchronize(stream));
+  if (v.planes_fp32) {
+    // the planes hold floats (same layout in elements)
+    auto widen = [](std::vector<double>& buf) {
+      std::vector<float> f(buf.size());
+      if (!f.empty()) memcpy(f.data(), buf.data(), f.size() * sizeof(float));
+      for (size_t k = 0; k < f.size(); ++k) buf[k] = (double)f[k];
+    };
+    widen(r); widen(A); widen(Jp); widen(A1);
+  }
   for (size_t e = 0; e < N; ++e) {
     const int64_t i = st.obs_orig[e];
     if (i < 0) continue;

@@ -42,6 +42,11 @@ __device__ __forceinline__ void store_nt(double* dst, const double* src) {
 }
 // Inside a tile the two rows of a column (planes 2a and 2a + 1: the u- and v-residual rows of the
 // same Jacobian column) are interleaved per lane, so both come and go in one 16-byte access per lane.
+// store into a plane of storage type PT (write-once data: non-temporal)
+template <typename PT>
+__device__ __forceinline__ void plane_store(double v, PT* p) {
+  __builtin_nontemporal_store((PT)v, p);
+}
 template <int NPL>
 __host__ __device__ __forceinline__ size_t pidx(int plane, size_t e) {
   return (e >> 6) * (size_t)(NPL * 64) + (size_t)(plane >> 1) * 128 + ((e & 63) << 1) + (size_t)(plane & 1);
@@ -403,12 +408,17 @@ __device__ __forceinline__ void stage_camera_records(const double* __restrict__ 
 // stage [Jl scale] -> angle-axis columns, scaling and the plane stores.
 // OCC = minimum workgroups per CU the register allocation must allow (2: 256 registers per
 // lane, a handful of doubles spilled in the rarely taken camera-model branches).
-template <int D, int DP, bool SH, typename RT, int OCC>
+template <int D, int DP, bool SH, typename RT, int OCC, typename PT = double>
 __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const double* __restrict__ prep,
                                                              int loss_type, double loss_width, int nblocks,
                                                              double* __restrict__ sums) {
   __shared__ __attribute__((aligned(16))) double stage[kSlicesPerBlock][64 * kStagePitch];
   const TrackMap tm = track_map(v);
+  PT* const pmR = reinterpret_cast<PT*>(v.pm_r);   // (the planes in their storage type: double, or float with
+  PT* const pmA = reinterpret_cast<PT*>(v.pm_A);   //  fp32 evaluation on shared-intrinsics problems -- DeviceView::planes_fp32)
+  PT* const pmA1 = reinterpret_cast<PT*>(v.pm_A1);
+  PT* const pmJp = reinterpret_cast<PT*>(v.pm_Jp);
+  (void)pmR; (void)pmA; (void)pmA1; (void)pmJp;
   const int lane = threadIdx.x & 63;
   double* st = stage[threadIdx.x >> 6];
   const double* P = st + lane * kStagePitch;
@@ -483,12 +493,12 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
     if (!act) continue;
     if (!ok) {
       v.flags[FL_INVALID] = 1;
-      for (int d = 0; d < 2 * D; ++d) __builtin_nontemporal_store(0.0, &v.pm_A[pidx<2 * D>(d, e)]);
+      for (int d = 0; d < 2 * D; ++d) plane_store<PT>(0.0, &pmA[pidx<2 * D>(d, e)]);
       if (SH)
-        for (int d = 0; d < 2 * D; ++d) __builtin_nontemporal_store(0.0, &v.pm_A1[pidx<2 * D>(d, e)]);
-      for (int d = 0; d < 2 * DP; ++d) __builtin_nontemporal_store(0.0, &v.pm_Jp[pidx<2 * DP>(d, e)]);
-      __builtin_nontemporal_store(0.0, &v.pm_r[pidx<2>(0, e)]);
-      __builtin_nontemporal_store(0.0, &v.pm_r[pidx<2>(1, e)]);
+        for (int d = 0; d < 2 * D; ++d) plane_store<PT>(0.0, &pmA1[pidx<2 * D>(d, e)]);
+      for (int d = 0; d < 2 * DP; ++d) plane_store<PT>(0.0, &pmJp[pidx<2 * DP>(d, e)]);
+      plane_store<PT>(0.0, &pmR[pidx<2>(0, e)]);
+      plane_store<PT>(0.0, &pmR[pidx<2>(1, e)]);
       continue;
     }
     const double sq = r[0] * r[0] + r[1] * r[1];
@@ -537,13 +547,13 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
           j1 = sqrt_rho1 * (j1 - asn * r[1] * rtj);
         }
         if (!(c < 3 && !SH && v.drop_pos)) {  // (drop_pos: the position columns are not stored, device_view.h)
-          __builtin_nontemporal_store(j0 * scl, &v.pm_A[pidx<2 * D>((2 * dst), e)]);
-          __builtin_nontemporal_store(j1 * scl, &v.pm_A[pidx<2 * D>((2 * dst + 1), e)]);
+          plane_store<PT>(j0 * scl, &pmA[pidx<2 * D>((2 * dst), e)]);
+          plane_store<PT>(j1 * scl, &pmA[pidx<2 * D>((2 * dst + 1), e)]);
         }
         ++dst;
       }
     }
-    for (int d = 2 * dst; d < 2 * D; ++d) __builtin_nontemporal_store(0.0, &v.pm_A[pidx<2 * D>(d, e)]);
+    for (int d = 2 * dst; d < 2 * D; ++d) plane_store<PT>(0.0, &pmA[pidx<2 * D>(d, e)]);
     if (SH) {
       // free intrinsics shared between views: their columns go to the group's own block
       const int grb = v.cam_grb[cam];
@@ -560,13 +570,13 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
               j1 = sqrt_rho1 * (j1 - asn * r[1] * rtj);
             }
             const double scl = P[12 + c];
-            __builtin_nontemporal_store(j0 * scl, &v.pm_A1[pidx<2 * D>((2 * dst1), e)]);
-            __builtin_nontemporal_store(j1 * scl, &v.pm_A1[pidx<2 * D>((2 * dst1 + 1), e)]);
+            plane_store<PT>(j0 * scl, &pmA1[pidx<2 * D>((2 * dst1), e)]);
+            plane_store<PT>(j1 * scl, &pmA1[pidx<2 * D>((2 * dst1 + 1), e)]);
             ++dst1;
           }
         }
       }
-      for (int d = 2 * dst1; d < 2 * D; ++d) __builtin_nontemporal_store(0.0, &v.pm_A1[pidx<2 * D>(d, e)]);
+      for (int d = 2 * dst1; d < 2 * D; ++d) plane_store<PT>(0.0, &pmA1[pidx<2 * D>(d, e)]);
     }
 #pragma unroll
     for (int a = 0; a < DP; ++a) {
@@ -580,11 +590,11 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
         j0 = sqrt_rho1 * (j0 - asn * r[0] * rtj);
         j1 = sqrt_rho1 * (j1 - asn * r[1] * rtj);
       }
-      __builtin_nontemporal_store(j0 * sp[a], &v.pm_Jp[pidx<2 * DP>((2 * a), e)]);
-      __builtin_nontemporal_store(j1 * sp[a], &v.pm_Jp[pidx<2 * DP>((2 * a + 1), e)]);
+      plane_store<PT>(j0 * sp[a], &pmJp[pidx<2 * DP>((2 * a), e)]);
+      plane_store<PT>(j1 * sp[a], &pmJp[pidx<2 * DP>((2 * a + 1), e)]);
     }
-    __builtin_nontemporal_store(r[0] * rscale, &v.pm_r[pidx<2>(0, e)]);
-    __builtin_nontemporal_store(r[1] * rscale, &v.pm_r[pidx<2>(1, e)]);
+    plane_store<PT>(r[0] * rscale, &pmR[pidx<2>(0, e)]);
+    plane_store<PT>(r[1] * rscale, &pmR[pidx<2>(1, e)]);
   }
   block_sum_finish<2>(acc, v.partial, nblocks, v.ticket + 2 * kTicketStride, sums);
 }
@@ -670,9 +680,14 @@ __global__ __launch_bounds__(256) void cost_kernel(DeviceView v, const double* _
 // Jacobi scaling (Ceres jacobi_scaling): 1 / (1 + ||column||), computed once
 // from the unscaled Jacobian at the start point.
 // ------------------------------------------------------------------------------
-template <int DP>
+template <int DP, typename PT = double>
 __global__ __launch_bounds__(256) void point_scale_kernel(DeviceView v) {
   const TrackMap tm = track_map(v);
+  PT* const pmR = reinterpret_cast<PT*>(v.pm_r);   // (the planes in their storage type: double, or float with
+  PT* const pmA = reinterpret_cast<PT*>(v.pm_A);   //  fp32 evaluation on shared-intrinsics problems -- DeviceView::planes_fp32)
+  PT* const pmA1 = reinterpret_cast<PT*>(v.pm_A1);
+  PT* const pmJp = reinterpret_cast<PT*>(v.pm_Jp);
+  (void)pmR; (void)pmA; (void)pmA1; (void)pmJp;
   if (!tm.valid) return;
   const int lp = tm.lp;
   const int k = tm.k;
@@ -685,7 +700,7 @@ __global__ __launch_bounds__(256) void point_scale_kernel(DeviceView v) {
     const size_t e = base + (size_t)j * 64;
 #pragma unroll
     for (int a = 0; a < DP; ++a) {
-      const double j0 = v.pm_Jp[pidx<2 * DP>((2 * a), e)], j1 = v.pm_Jp[pidx<2 * DP>((2 * a + 1), e)];
+      const double j0 = pmJp[pidx<2 * DP>((2 * a), e)], j1 = pmJp[pidx<2 * DP>((2 * a + 1), e)];
       n2[a] += j0 * j0 + j1 * j1;
     }
   }
@@ -713,12 +728,17 @@ __global__ void camera_scale_finish_kernel(double* scale_c, int n) {
 // ------------------------------------------------------------------------------
 // REC = false (direct_diag.h, DeviceView::direct_diag): the per-track part only -- no camera-major records, no LDS
 // staging, a quarter of the registers, so that the sweep over the Jp and r planes runs at full occupancy.
-template <int D, int DP, bool SH, bool REC = true>
-__global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, double inv_radius,
+template <int D, int DP, bool SH, bool REC = true, typename PT = double>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void point_eliminate_kernel(DeviceView v, double inv_radius,
                                                               double lm_lo, double lm_hi, int nblocks,
                                                               double* partial_max, double* singular_vote,
                                                               double grad_tol, double* grad_vote) {
   constexpr int NS = sym_size(DP);
+  PT* const pmR = reinterpret_cast<PT*>(v.pm_r);   // (the planes in their storage type: double, or float with
+  PT* const pmA = reinterpret_cast<PT*>(v.pm_A);   //  fp32 evaluation on shared-intrinsics problems -- DeviceView::planes_fp32)
+  PT* const pmA1 = reinterpret_cast<PT*>(v.pm_A1);
+  PT* const pmJp = reinterpret_cast<PT*>(v.pm_Jp);
+  (void)pmR; (void)pmA; (void)pmA1; (void)pmJp;
   constexpr int YS = ys_of(D, DP);
   constexpr int ASA = asa_of(D, DP);
   constexpr int AS = SH ? as_of(D, true) : ASA + kRecTail;  // staged A record: [A rows | Q | pad][N r~ r] without
@@ -755,10 +775,10 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
         double J0[DP], J1[DP];
 #pragma unroll
         for (int a = 0; a < DP; ++a) {
-          J0[a] = v.pm_Jp[pidx<2 * DP>((2 * a), e)];
-          J1[a] = v.pm_Jp[pidx<2 * DP>((2 * a + 1), e)];
+          J0[a] = pmJp[pidx<2 * DP>((2 * a), e)];
+          J1[a] = pmJp[pidx<2 * DP>((2 * a + 1), e)];
         }
-        const double r0 = v.pm_r[pidx<2>(0, e)], r1 = v.pm_r[pidx<2>(1, e)];
+        const double r0 = pmR[pidx<2>(0, e)], r1 = pmR[pidx<2>(1, e)];
 #pragma unroll
         for (int a = 0; a < DP; ++a) {
 #pragma unroll
@@ -922,10 +942,10 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
         double J0[DP], J1[DP], Q0[DP], Q1[DP];
 #pragma unroll
         for (int a = 0; a < DP; ++a) {
-          J0[a] = v.pm_Jp[pidx<2 * DP>((2 * a), e)];
-          J1[a] = v.pm_Jp[pidx<2 * DP>((2 * a + 1), e)];
+          J0[a] = pmJp[pidx<2 * DP>((2 * a), e)];
+          J1[a] = pmJp[pidx<2 * DP>((2 * a + 1), e)];
         }
-        const double r0 = v.pm_r[pidx<2>(0, e)], r1 = v.pm_r[pidx<2>(1, e)];
+        const double r0 = pmR[pidx<2>(0, e)], r1 = pmR[pidx<2>(1, e)];
         double rt0 = r0, rt1 = r1;
 #pragma unroll
         for (int a = 0; a < DP; ++a) {
@@ -957,8 +977,8 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
             a0 = J0[a < DP ? a : 0] * pc[a < 3 ? a : 0];
             a1 = J1[a < DP ? a : 0] * pc[a < 3 ? a : 0];
           } else {
-            a0 = v.pm_A[pidx<2 * D>((2 * a), e)];
-            a1 = v.pm_A[pidx<2 * D>((2 * a + 1), e)];
+            a0 = pmA[pidx<2 * D>((2 * a), e)];
+            a1 = pmA[pidx<2 * D>((2 * a + 1), e)];
           }
           Av[a] = a0;
           Av[D + a] = a1;
@@ -1014,8 +1034,8 @@ __global__ __launch_bounds__(256) void point_eliminate_kernel(DeviceView v, doub
           for (int a = 0; a < D; ++a) {
             double a0 = 0.0, a1 = 0.0;
             if (gslot >= 0) {
-              a0 = v.pm_A1[pidx<2 * D>((2 * a), e)];
-              a1 = v.pm_A1[pidx<2 * D>((2 * a + 1), e)];
+              a0 = pmA1[pidx<2 * D>((2 * a), e)];
+              a1 = pmA1[pidx<2 * D>((2 * a + 1), e)];
             }
             Av[sh_off_a1(D) + a] = a0;
             Av[sh_off_a1(D) + D + a] = a1;
@@ -1987,10 +2007,15 @@ __global__ __launch_bounds__(256) void spmv_cols_kernel(DeviceView v, const doub
 // scattered 16-byte t records): u_i = A_i x_c(i) + A1_i x_g(i) with x_g the view's shared block, zhat as below; the
 // cameras pass recomputes u_i from its record (which carries A, A1 and Q) and leaves the view's partial of the shared
 // block for implicit_groups to add up in the block's view order.
-template <int D, int DP>
+template <int D, int DP, typename PT = double>
 __global__ __launch_bounds__(256) void implicit_tracks_sq_kernel(DeviceView v, const double* __restrict__ x,
                                                                  double* __restrict__ zhat) {
   const TrackMap tm = track_map(v);
+  PT* const pmR = reinterpret_cast<PT*>(v.pm_r);   // (the planes in their storage type: double, or float with
+  PT* const pmA = reinterpret_cast<PT*>(v.pm_A);   //  fp32 evaluation on shared-intrinsics problems -- DeviceView::planes_fp32)
+  PT* const pmA1 = reinterpret_cast<PT*>(v.pm_A1);
+  PT* const pmJp = reinterpret_cast<PT*>(v.pm_Jp);
+  (void)pmR; (void)pmA; (void)pmA1; (void)pmJp;
   if (!tm.valid) return;
   const int lp = tm.lp;
   const int k = tm.k;
@@ -2013,8 +2038,8 @@ __global__ __launch_bounds__(256) void implicit_tracks_sq_kernel(DeviceView v, c
 #pragma unroll
       for (int a = 0; a < D; ++a) {
         const double xa = xc[a];
-        u0 += v.pm_A[pidx<2 * D>((2 * a), e)] * xa;
-        u1 += v.pm_A[pidx<2 * D>((2 * a + 1), e)] * xa;
+        u0 += pmA[pidx<2 * D>((2 * a), e)] * xa;
+        u1 += pmA[pidx<2 * D>((2 * a + 1), e)] * xa;
       }
     }
     if (grb >= 0) {
@@ -2022,13 +2047,13 @@ __global__ __launch_bounds__(256) void implicit_tracks_sq_kernel(DeviceView v, c
 #pragma unroll
       for (int a = 0; a < D; ++a) {
         const double xa = xg[a];
-        u0 += v.pm_A1[pidx<2 * D>((2 * a), e)] * xa;
-        u1 += v.pm_A1[pidx<2 * D>((2 * a + 1), e)] * xa;
+        u0 += pmA1[pidx<2 * D>((2 * a), e)] * xa;
+        u1 += pmA1[pidx<2 * D>((2 * a + 1), e)] * xa;
       }
     }
 #pragma unroll
     for (int a = 0; a < DP; ++a)
-      w[a] += v.pm_Jp[pidx<2 * DP>((2 * a), e)] * u0 + v.pm_Jp[pidx<2 * DP>((2 * a + 1), e)] * u1;
+      w[a] += pmJp[pidx<2 * DP>((2 * a), e)] * u0 + pmJp[pidx<2 * DP>((2 * a + 1), e)] * u1;
   }
 #pragma unroll
   for (int a = 0; a < DP; ++a) w[a] = group_sum(w[a], tm.wide);
@@ -2796,10 +2821,15 @@ __global__ __launch_bounds__(256) void cross_add_kernel(DeviceView v, RedLayout 
 // -- g_p and the undamped V = sum Jp^T Jp are point_eliminate's, sum Jp^T u is g_p - w -- so the
 // second sweep (u written and read back, Jp and r read again) is not needed.
 // ------------------------------------------------------------------------------
-template <int D, int DP, bool SH>
+template <int D, int DP, bool SH, typename PT = double>
 __global__ __launch_bounds__(256) void back_substitute_kernel(DeviceView v, int nblocks, double* partial,
                                                               double* __restrict__ sums) {
   constexpr int NS = sym_size(DP);
+  PT* const pmR = reinterpret_cast<PT*>(v.pm_r);   // (the planes in their storage type: double, or float with
+  PT* const pmA = reinterpret_cast<PT*>(v.pm_A);   //  fp32 evaluation on shared-intrinsics problems -- DeviceView::planes_fp32)
+  PT* const pmA1 = reinterpret_cast<PT*>(v.pm_A1);
+  PT* const pmJp = reinterpret_cast<PT*>(v.pm_Jp);
+  (void)pmR; (void)pmA; (void)pmA1; (void)pmJp;
   const TrackMap tm = track_map(v);
   double acc[1] = {0.0};
   if (tm.valid) {
@@ -2829,11 +2859,11 @@ __global__ __launch_bounds__(256) void back_substitute_kernel(DeviceView v, int 
               const double ya = yc[a];
               if (a < 3) {
                 const double t = ya * v.pos_coef[(size_t)a * NP + lp];
-                u0 += v.pm_Jp[pidx<2 * DP>((2 * (a < DP ? a : 0)), e)] * t;
-                u1 += v.pm_Jp[pidx<2 * DP>((2 * (a < DP ? a : 0) + 1), e)] * t;
+                u0 += pmJp[pidx<2 * DP>((2 * (a < DP ? a : 0)), e)] * t;
+                u1 += pmJp[pidx<2 * DP>((2 * (a < DP ? a : 0) + 1), e)] * t;
               } else {
-                u0 += v.pm_A[pidx<2 * D>((2 * a), e)] * ya;
-                u1 += v.pm_A[pidx<2 * D>((2 * a + 1), e)] * ya;
+                u0 += pmA[pidx<2 * D>((2 * a), e)] * ya;
+                u1 += pmA[pidx<2 * D>((2 * a + 1), e)] * ya;
               }
             }
           } else {
@@ -2841,8 +2871,8 @@ __global__ __launch_bounds__(256) void back_substitute_kernel(DeviceView v, int 
 #pragma unroll
             for (int a = 0; a < D; ++a) {
               const double ya = yc[a];
-              u0 += v.pm_A[pidx<2 * D>((2 * a), e)] * ya;
-              u1 += v.pm_A[pidx<2 * D>((2 * a + 1), e)] * ya;
+              u0 += pmA[pidx<2 * D>((2 * a), e)] * ya;
+              u1 += pmA[pidx<2 * D>((2 * a + 1), e)] * ya;
             }
           }
         }
@@ -2853,16 +2883,16 @@ __global__ __launch_bounds__(256) void back_substitute_kernel(DeviceView v, int 
 #pragma unroll
             for (int a = 0; a < D; ++a) {
               const double ya = yg[a];
-              u0 += v.pm_A1[pidx<2 * D>((2 * a), e)] * ya;
-              u1 += v.pm_A1[pidx<2 * D>((2 * a + 1), e)] * ya;
+              u0 += pmA1[pidx<2 * D>((2 * a), e)] * ya;
+              u1 += pmA1[pidx<2 * D>((2 * a + 1), e)] * ya;
             }
           }
         }
-        ur += u0 * v.pm_r[pidx<2>(0, e)] + u1 * v.pm_r[pidx<2>(1, e)];
+        ur += u0 * pmR[pidx<2>(0, e)] + u1 * pmR[pidx<2>(1, e)];
         uu += u0 * u0 + u1 * u1;
 #pragma unroll
         for (int a = 0; a < DP; ++a)
-          w[a] -= v.pm_Jp[pidx<2 * DP>((2 * a), e)] * u0 + v.pm_Jp[pidx<2 * DP>((2 * a + 1), e)] * u1;
+          w[a] -= pmJp[pidx<2 * DP>((2 * a), e)] * u0 + pmJp[pidx<2 * DP>((2 * a + 1), e)] * u1;
       }
       acc[0] = ur - 0.5 * uu;
 #pragma unroll
