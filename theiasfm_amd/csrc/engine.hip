@@ -286,7 +286,7 @@ Launch make_launch(bool fp32) {
                            double ir, double lo, double hi, int add_diag, int nb, int dot) {
         if (!v.Nrb) return;
         hipLaunchKernelGGL((implicit_tracks_sq_kernel<D, DP, float>), dim3(nb), dim3(256), 0, st, v, x, w1);
-        hipLaunchKernelGGL((implicit_cameras_sq_kernel<D, DP>), dim3(v.Ncam_rb), dim3(64), 0, st, v, R, x, w1, y,
+        hipLaunchKernelGGL((implicit_cameras_sq_kernel<D, DP, float>), dim3(v.Ncam_rb), dim3(64), 0, st, v, R, x, w1, y,
                            ir, lo, hi, add_diag, v.cam_part);
         if (v.Nrb > v.Ncam_rb)
           hipLaunchKernelGGL((implicit_groups_kernel<D>), dim3(v.Nrb - v.Ncam_rb), dim3(64), 0, st, v, R, x, v.cam_part,
@@ -295,6 +295,22 @@ Launch make_launch(bool fp32) {
       L.back_substitute = [](const DeviceView& v, hipStream_t st, int nb, double* partial, double* sums) {
         hipLaunchKernelGGL((back_substitute_kernel<D, DP, SH, float>), dim3(nb), dim3(256), 0, st, v, nb, partial, sums);
       };
+      // ... and the [A | Q | r~ | r | A1] records (cm_A) are fp32 too: their writer is point_eliminate above, their readers
+      L.shared_blocks = [](const DeviceView& v, hipStream_t st, RedLayout R) {
+        if (v.Nrb == v.Ncam_rb) return;
+        hipLaunchKernelGGL((camera_group_partials_kernel<D, DP, float>), dim3(v.Ncam_rb), dim3(64), 0, st, v);
+        hipLaunchKernelGGL((group_reduce_kernel<D>), dim3(v.Nrb - v.Ncam_rb), dim3(256), 0, st, v, R);
+      };
+      L.camera_diag = [](const DeviceView& v, hipStream_t st, RedLayout R, int max_chunks, double* chunk_partial) {
+        const bool chunked = max_chunks > 0 && v.Nrb > v.Ncam_rb;
+        if (v.Nrb) hipLaunchKernelGGL((camera_diag_kernel<D, DP, SH, float>), dim3(v.Nrb), dim3(64), 0, st, v, R, chunked ? 1 : 0);
+        if (chunked) {
+          const int ns = v.Nrb - v.Ncam_rb;
+          hipLaunchKernelGGL((shared_diag_partial_kernel<D, DP>), dim3(ns * max_chunks), dim3(64), 0, st, v, max_chunks, chunk_partial);
+          hipLaunchKernelGGL((shared_diag_reduce_kernel<D>), dim3(ns), dim3(64), 0, st, v, R, max_chunks, chunk_partial);
+        }
+      };
+
     }
   }
   L.tile_gather = [](const DeviceView& v, hipStream_t st, const double* ub, const double* rhs, double* tiles, int n) {

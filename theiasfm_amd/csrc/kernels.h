@@ -47,6 +47,26 @@ template <typename PT>
 __device__ __forceinline__ void plane_store(double v, PT* p) {
   __builtin_nontemporal_store((PT)v, p);
 }
+// camera-major records in their storage type (double, or float with fp32 evaluation on shared-intrinsics problems --
+// DeviceView::planes_fp32): two consecutive words of a record, widened
+typedef float nt_float2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 rec_ld2(const double* p) { return *reinterpret_cast<const double2*>(p); }
+__device__ __forceinline__ double2 rec_ld2(const float* p) {
+  const float2 t = *reinterpret_cast<const float2*>(p);
+  return make_double2((double)t.x, (double)t.y);
+}
+// ... and the staged (fp64, LDS) pair `src` stored non-temporally at words [idx, idx + 2) of the record array `base`
+template <typename RS>
+__device__ __forceinline__ void rec_store2_nt(double* base, size_t idx, const double* src) {
+  if constexpr (sizeof(RS) == 8) {
+    store_nt(base + idx, src);
+  } else {
+    nt_float2 f;
+    f.x = (float)src[0];
+    f.y = (float)src[1];
+    __builtin_nontemporal_store(f, reinterpret_cast<nt_float2*>(reinterpret_cast<float*>(base) + idx));
+  }
+}
 template <int NPL>
 __host__ __device__ __forceinline__ size_t pidx(int plane, size_t e) {
   return (e >> 6) * (size_t)(NPL * 64) + (size_t)(plane >> 1) * 128 + ((e & 63) << 1) + (size_t)(plane & 1);
@@ -1086,7 +1106,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
             const int rec = c / (AS / 2), part = c - rec * (AS / 2);
             const int cp = scp[rec];
             if (cp >= 0)
-              store_nt(v.cm_A + (size_t)cp * AS + 2 * part, st + rec * STP + 2 * part);
+              rec_store2_nt<PT>(v.cm_A, (size_t)cp * AS + 2 * part, st + rec * STP + 2 * part);  // (SH: PT is the records' type too)
           }
         } else {
           // [A rows | Q] (whole sectors) and the tail
@@ -1231,7 +1251,7 @@ __global__ __launch_bounds__(64) void shared_diag_reduce_kernel(DeviceView v, Re
     }
 }
 
-template <int D, int DP, bool SH>
+template <int D, int DP, bool SH, typename RS = double>
 __global__ __launch_bounds__(64) void camera_diag_kernel(DeviceView v, RedLayout L, int shared_elsewhere) {
   constexpr int NS = sym_size(D);
   constexpr int AS = as_of(D, SH);
@@ -1271,17 +1291,17 @@ __global__ __launch_bounds__(64) void camera_diag_kernel(DeviceView v, RedLayout
     double rec[2 * D + 8];
     if (SH) {
       // [A rows | Q | r~ | r | ...]: N = I - Q Q^T is formed here, the tail goes where the other layout has it
-      const double* arec = v.cm_A + (size_t)s * AS;
+      const RS* arec = reinterpret_cast<const RS*>(v.cm_A) + (size_t)s * AS;
       double w12[12];
 #pragma unroll
       for (int i = 0; i < 2 * D; i += 2) {
-        const double2 t = *reinterpret_cast<const double2*>(arec + i);
+        const double2 t = rec_ld2(arec + i);
         rec[i] = t.x;
         rec[i + 1] = t.y;
       }
 #pragma unroll
       for (int i = 0; i < 12; i += 2) {
-        const double2 t = *reinterpret_cast<const double2*>(arec + 2 * D + i);
+        const double2 t = rec_ld2(arec + 2 * D + i);
         w12[i] = t.x;
         w12[i + 1] = t.y;
       }
@@ -2224,7 +2244,7 @@ __global__ __launch_bounds__(64) void implicit_cameras_q_kernel(DeviceView v, Re
 }
 
 // cameras pass with shared intrinsics blocks: one wave per VIEW block (shared blocks: implicit_groups_kernel)
-template <int D, int DP>
+template <int D, int DP, typename RS = double>
 __global__ __launch_bounds__(64) void implicit_cameras_sq_kernel(DeviceView v, RedLayout L,
                                                                  const double* __restrict__ x,
                                                                  const double* __restrict__ zhat,
@@ -2244,11 +2264,11 @@ __global__ __launch_bounds__(64) void implicit_cameras_sq_kernel(DeviceView v, R
     acc[a] = acc1[a] = 0.0;
   }
   for (int s = v.cam_ptr[rb] + threadIdx.x; s < v.cam_ptr[rb + 1]; s += 64) {
-    const double* arec = v.cm_A + (size_t)s * AS;
+    const RS* arec = reinterpret_cast<const RS*>(v.cm_A) + (size_t)s * AS;
     double rec[4 * D + 12];
 #pragma unroll
     for (int i = 0; i < 4 * D + 12; i += 2) {
-      const double2 t = *reinterpret_cast<const double2*>(arec + i);
+      const double2 t = rec_ld2(arec + i);
       rec[i] = t.x;
       rec[i + 1] = t.y;
     }
@@ -2698,7 +2718,7 @@ __global__ __launch_bounds__(kPcgStepThreads) void pcg_init_kernel(DeviceView v,
 //   `red` (fixed order), cross_add puts C into the (view, shared block) upper block.
 // cam_part[view block] = [C (D^2) | G (D^2) | gt (D) | gc (D) | ud (D)]
 // ------------------------------------------------------------------------------
-template <int D, int DP>
+template <int D, int DP, typename RS = double>
 __global__ __launch_bounds__(64) void camera_group_partials_kernel(DeviceView v) {
   constexpr int AS = as_of(D, true);
   const int rb = blockIdx.x;
@@ -2712,7 +2732,7 @@ __global__ __launch_bounds__(64) void camera_group_partials_kernel(DeviceView v)
 #pragma unroll
       for (int b = 0; b < D; ++b) C[a][b] = 0.0;
     for (int s = v.cam_ptr[rb] + threadIdx.x; s < v.cam_ptr[rb + 1]; s += 64) {
-      const double* rec = v.cm_A + (size_t)s * AS;
+      const RS* rec = reinterpret_cast<const RS*>(v.cm_A) + (size_t)s * AS;
       double A0[2][D], A1[2][D];
 #pragma unroll
       for (int a = 0; a < D; ++a) {
@@ -2741,7 +2761,7 @@ __global__ __launch_bounds__(64) void camera_group_partials_kernel(DeviceView v)
 #pragma unroll
     for (int a = 0; a < D; ++a) gt[a] = gc[a] = ud[a] = 0.0;
     for (int s = v.cam_ptr[rb] + threadIdx.x; s < v.cam_ptr[rb + 1]; s += 64) {
-      const double* rec = v.cm_A + (size_t)s * AS;
+      const RS* rec = reinterpret_cast<const RS*>(v.cm_A) + (size_t)s * AS;
       double A1[2][D];
 #pragma unroll
       for (int a = 0; a < D; ++a) {
