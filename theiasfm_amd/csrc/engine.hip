@@ -818,7 +818,7 @@ static int build_structure_device(tmi_ba_solver* s, const tmi_ba_problem* P, boo
         const int idx = gs * 64 + t;
         if (idx < n_active) {
           const double k = klen[order[idx]];
-          w += 0.5 * k * (k - 1.0) + 5.0 * k;
+          w += want_pairs ? 0.5 * k * (k - 1.0) + 5.0 * k : k + 0.5;  // (structure.cpp: observations when S is not formed)
         }
       }
       int best = 0;

@@ -329,7 +329,16 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, 
   // Deal the slices (already in descending track-length order) to the ranks by
   // longest-processing-time-first on the estimated work of a slice:
   //   Schur pairs k(k-1)/2  +  5 per observation (the per-observation kernels cost
-  //   about 5x a pair; profiles/r01_a).  Deterministic: ties go to the lowest rank.
+  //   about 5x a pair; profiles/r01_a) when S is formed; with the matrix-free operator -- the default
+  //   on several ranks -- there are no pairs and the work of a track is its observations (+ 1/2 for
+  //   the per-track records): the pair rule left rank 0 of 8 with 228 k of the 5.0 M observations of
+  //   venice1778_heavy (the 400-view tracks) and the other seven with 580-706 k (round 5; rank 0 then
+  //   also fell below the size from which the one-sweep product is built).  With observation counts
+  //   every rank holds 625 k; rank 0 -- the slice of the very longest tracks -- still takes 0.87 ms per
+  //   LM iteration against 0.78 ms for rank 7 (tools/scale_probe.py times first and last rank):
+  //   weighting tracks of 16+ views 1.5x moved 85 k observations off rank 0 and changed nothing, its
+  //   time is the pace of its 400-view tracks, which no dealing of whole tracks can split.
+  //   Deterministic: ties go to the lowest rank.  (engine.hip, build_structure_device: the same rule.)
   std::vector<int> slice_rank(gslices, 0);
   {
     std::vector<double> load(world, 0.0);
@@ -339,7 +348,7 @@ int build_structure(const tmi_ba_problem* P, int rank, int world, Structure* S, 
         const int idx = gs * 64 + t;
         if (idx < n_active) {
           const double k = klen[order[idx]];
-          w += 0.5 * k * (k - 1.0) + 5.0 * k;
+          w += (want_pairs_mode == 1) ? 0.5 * k * (k - 1.0) + 5.0 * k : k + 0.5;
         }
       }
       int best = 0;
