@@ -48,6 +48,8 @@ struct DefaultInitAllocator : std::allocator<T> {
   // big blocks: 2 MB aligned and advised as transparent huge pages -- the arrays are written once, front to back, right
   // after they are sized, and with 4 KB pages that first touch is ~30 000 page faults per 120 MB array
   T* allocate(std::size_t n) {
+    // (n * sizeof(T) and the rounding below must not wrap: what std::allocator::allocate checks -- ADVICE r5)
+    if (n > (static_cast<std::size_t>(-1) - kHugeAlign) / sizeof(T)) throw std::bad_array_new_length();
     const std::size_t bytes = n * sizeof(T);
     if (bytes >= kHugeFrom) {
       const std::size_t rounded = (bytes + kHugeAlign - 1) / kHugeAlign * kHugeAlign;
@@ -141,7 +143,9 @@ class BundleAdjuster {
   // The reference's hook, signature unchanged (bundle_adjuster.h:100-102).  AddView / AddTrack call it with the camera
   // of the view and the track they are adding; the ids those pointers belong to are in hook_view_id_ /
   // hook_track_id_ for the duration of the call (a subclass that forwards OTHER pointers to the base implementation
-  // has them looked up: one walk over the views / tracks).
+  // has them looked up in pointer -> id maps built at the first miss; a pointer that is not of this reconstruction
+  // drops the residual with one warning per BundleAdjuster).  The bulk AddViews / AddTracks take the one-at-a-time
+  // path -- and so call this hook per residual -- whenever the dynamic type is not BundleAdjuster itself.
   virtual void AddReprojectionErrorResidual(const Feature& feature, Camera* camera, Track* track);
 
   const BundleAdjustmentOptions options_;
@@ -149,6 +153,9 @@ class BundleAdjuster {
   std::chrono::steady_clock::time_point timer_start_;
   ViewId hook_view_id_ = kInvalidViewId;     // ids behind the pointers handed to AddReprojectionErrorResidual
   TrackId hook_track_id_ = kInvalidTrackId;
+  std::unordered_map<const Camera*, ViewId> camera_to_view_;  // built at the first pointer the hook ids do not explain
+  std::unordered_map<const Track*, TrackId> track_to_id_;
+  bool warned_foreign_residual_ = false;
 
   std::unordered_set<ViewId> optimized_views_;
   std::unordered_set<CameraIntrinsicsGroupId> optimized_camera_intrinsics_groups_;

@@ -84,6 +84,13 @@ struct BundleAdjustmentSummary {
   double final_cost = 0.0;
   double setup_time_in_seconds = 0.0;
   double solve_time_in_seconds = 0.0;
+  // Extensions (behind the reference's five fields, bundle_adjustment.h:124-133).  The preconditioner PCG ran with,
+  // as a ceres::PreconditionerType, and whether it differs from what BundleAdjustmentOptions asked for:
+  // ceres::CLUSTER_TRIDIAGONAL is not implemented on the device path and is served by CLUSTER_JACOBI; CLUSTER_JACOBI
+  // on a handle without clusters (several ranks, clusters that do not fit) keeps the SCHUR_JACOBI blocks;
+  // ceres::JACOBI runs as SCHUR_JACOBI.  (Exact linear solvers: IDENTITY, not substituted.)
+  ceres::PreconditionerType effective_preconditioner_type = ceres::IDENTITY;
+  bool preconditioner_substituted = false;
 };
 
 // Extensions: the resident session BundleAdjustReconstruction keeps (one per process; it holds the problem's HBM).

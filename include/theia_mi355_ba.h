@@ -128,10 +128,11 @@ typedef enum tmi_ba_linear_solver {
  *     edge weights |tracks seen by both| / sqrt(|tracks of a| |tracks of b|) over the parameter blocks, then
  *     canonical views with size penalty 3 / similarity penalty 0 / at least 3 centres, or single linkage at 0.9;
  *     restated from Ceres 1.14 -- parity unpinned like the rest of the Ceres layer) and every cluster's principal
- *     submatrix of S is inverted exactly; this needs the formed S (schur_mode auto picks it; implicit is refused)
- *     and one rank.  CLUSTER_TRIDIAGONAL (Ceres adds the blocks between neighbouring clusters of a degree-2
+ *     submatrix of S is inverted exactly; this needs the formed S (schur_mode auto picks it; with schur_mode implicit, or on several ranks,
+ *     the solve keeps the SCHUR_JACOBI blocks and says so in tmi_ba_summary.effective_preconditioner_type).  CLUSTER_TRIDIAGONAL (Ceres adds the blocks between neighbouring clusters of a degree-2
  *     spanning forest) is NOT implemented: create / solve return TMI_BA_ERR_UNSUPPORTED rather than answer with
- *     another preconditioner; the C++ shim maps ceres::CLUSTER_TRIDIAGONAL to CLUSTER_JACOBI and says so on stderr.
+ *     another preconditioner; the C++ shim maps ceres::CLUSTER_TRIDIAGONAL to CLUSTER_JACOBI and reports the
+ *     substitution in BundleAdjustmentSummary (preconditioner_substituted / effective_preconditioner_type).
  *     A cluster launch that cannot become co-resident (device shared with another process) retires
  *     the clusters for that solve: PCG continues with the SCHUR_JACOBI blocks.
  *   Intrinsics shared by several views form their own reduced block in every mode.  */
@@ -322,6 +323,12 @@ typedef struct tmi_ba_summary {
   int64_t kernel_launches[TMI_BA_NUM_KERNEL_CLASSES];
   double kernel_seconds[TMI_BA_NUM_KERNEL_CLASSES];
   char message[192];
+  /* the preconditioner PCG actually ran with in the last LM iteration (tmi_ba_preconditioner_type; 0 for the exact
+   * solvers): differs from options.preconditioner_type where the header above says a request is served by another
+   * one -- CLUSTER_JACOBI without usable clusters (several ranks, schur_mode implicit without shared blocks, a
+   * cluster launch that could not become co-resident, clusters that do not fit) keeps its SCHUR_JACOBI blocks,
+   * JACOBI runs as SCHUR_JACOBI.  A caller can tell which trajectory it got. */
+  int32_t effective_preconditioner_type;
 } tmi_ba_summary;
 
 typedef enum tmi_ba_kernel_class {
@@ -613,7 +620,9 @@ int32_t tmi_ba_solver_structure_checksums(tmi_ba_solver* solver, uint64_t out[24
  *   out[0] the one-sweep matrix-free product is built (mf_chunks.h)        out[1] position columns formed from Jp
  *   out[2] matrix-free LM iterations build the camera side without camera-major records (direct_diag.h)
  *   out[3] schur_mode auto chooses the operator per LM iteration           out[4] S is never formed (implicit)
- *   out[5] PCG length up to which the matrix-free operator is taken (auto) out[6], out[7] reserved (0)          */
+ *   out[5] PCG length up to which the matrix-free operator is taken (auto)
+ *   out[6] the handle holds clusters for CLUSTER_JACOBI (0: such a request keeps the SCHUR_JACOBI blocks, and
+ *          tmi_ba_summary.effective_preconditioner_type says so)            out[7] reserved (0)                   */
 int32_t tmi_ba_solver_operator_info(tmi_ba_solver* solver, int32_t out[8]);
 
 /* Host-only: statistics of the static structure the engine would build for
@@ -626,6 +635,12 @@ int32_t tmi_ba_solver_operator_info(tmi_ba_solver* solver, int32_t out[8]);
  * owned pairs of a (slot independent) pair key.  Returns a tmi_ba_status. */
 int32_t tmi_ba_structure_stats(const tmi_ba_problem* problem, int32_t rank, int32_t world,
                                int64_t out[12]);
+/* The same for the dealing a handle actually uses: slices go to the ranks longest-work-first, and "work" is Schur
+ * pairs + 5 x observations where the handle forms S (forms_S = 1: schur_mode explicit, exact solvers -- what
+ * tmi_ba_structure_stats reports) but the track's observations where the operator is matrix-free (forms_S = 0: the
+ * default of a solve on several ranks, schur_mode auto / implicit). */
+int32_t tmi_ba_structure_stats_for(const tmi_ba_problem* problem, int32_t rank, int32_t world, int32_t forms_S,
+                                   int64_t out[12]);
 
 #ifdef __cplusplus
 } /* extern "C" */

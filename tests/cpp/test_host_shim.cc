@@ -341,6 +341,27 @@ static void TestGpu() {
     const BundleAdjustmentSummary s2 = BundleAdjustReconstruction(opt, &rec);
     EXPECT(s2.success && s2.final_cost <= s2.initial_cost * (1 + 1e-12));
     EXPECT(std::fabs(s2.initial_cost - s.final_cost) < 1e-9 * s.final_cost);
+    // exact solver (the default SPARSE_SCHUR): no preconditioner ran, nothing substituted
+    EXPECT(!s.preconditioner_substituted && s.effective_preconditioner_type == ceres::IDENTITY);
+  }
+  {
+    // which preconditioner ran is part of the summary: ceres::CLUSTER_TRIDIAGONAL is served by CLUSTER_JACOBI (or by
+    // SCHUR_JACOBI where the handle has no clusters) and the caller is told; SCHUR_JACOBI is served as asked
+    Reconstruction rec;
+    BuildScene(&rec, 8, 300, /*share_groups=*/true, 13, 0.3);
+    BundleAdjustmentOptions opt;
+    opt.linear_solver_type = ceres::ITERATIVE_SCHUR;
+    opt.max_num_iterations = 4;
+    opt.preconditioner_type = ceres::CLUSTER_TRIDIAGONAL;
+    const BundleAdjustmentSummary st = BundleAdjustReconstruction(opt, &rec);
+    EXPECT(st.success && st.preconditioner_substituted);
+    EXPECT(st.effective_preconditioner_type == ceres::CLUSTER_JACOBI || st.effective_preconditioner_type == ceres::SCHUR_JACOBI);
+    opt.preconditioner_type = ceres::SCHUR_JACOBI;
+    const BundleAdjustmentSummary sj = BundleAdjustReconstruction(opt, &rec);
+    EXPECT(sj.success && !sj.preconditioner_substituted && sj.effective_preconditioner_type == ceres::SCHUR_JACOBI);
+    std::printf("preconditioner report: CLUSTER_TRIDIAGONAL -> %d (substituted %d), SCHUR_JACOBI -> %d (substituted %d)\n",
+                (int)st.effective_preconditioner_type, (int)st.preconditioner_substituted, (int)sj.effective_preconditioner_type,
+                (int)sj.preconditioner_substituted);
   }
   {
     // partial BA with anchors + shared constant intrinsics + Huber loss

@@ -230,6 +230,15 @@ def test_device_visibility_clusters_with_the_matrix_free_operator_fall_back_to_b
     st_j, s_j = lib.solve(prob.copy(), options(abi.PRECOND_SCHUR_JACOBI, **kw))
     assert st_c == st_j == 0
     assert s_c.num_linear_solver_iterations == s_j.num_linear_solver_iterations and s_c.final_cost == s_j.final_cost
+    # ... and the caller is told which preconditioner it got: the summary names the one that ran
+    assert s_c.effective_preconditioner_type == abi.PRECOND_SCHUR_JACOBI == s_j.effective_preconditioner_type
+    st_e, s_e = lib.solve(prob.copy(), options(abi.PRECOND_CLUSTER_JACOBI, max_num_iterations=3))  # schur_mode explicit
+    assert st_e == 0 and s_e.effective_preconditioner_type == abi.PRECOND_CLUSTER_JACOBI
+    st_p, s_p = lib.solve(prob.copy(), options(abi.PRECOND_SCHUR_JACOBI_PARAMETER_BLOCKS, max_num_iterations=3))
+    assert st_p == 0 and s_p.effective_preconditioner_type == abi.PRECOND_SCHUR_JACOBI_PARAMETER_BLOCKS
+    st_x, s_x = lib.solve(prob.copy(), abi.default_options(linear_solver_type=abi.DENSE_SCHUR, point_dof=3, use_inner_iterations=0,
+                                                           max_num_iterations=3))
+    assert st_x == 0 and s_x.effective_preconditioner_type == 0  # exact solver: no preconditioner ran
 
 
 @pytest.mark.gpu

@@ -45,6 +45,27 @@ def test_shards_partition_tracks_observations_and_pairs(world):
     assert work.max() / work.mean() < 1.15
 
 
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_matrix_free_dealing_balances_observations(world):
+    """The default operator on several ranks is matrix-free, and its slices are dealt by observations (structure.cpp;
+    ADVICE r5: the statistics call used to describe the pair-weighted dealing only).  A heavy-tailed problem is where the
+    two rules differ: the rank that holds the longest tracks gets few observations under the pair rule."""
+    prob = synth.make_problem(80, 8000, 44000, seed=21, scene="ring", spread=0.4, heavy_tail=0.02)
+    one = lib.structure_stats(prob, 0, 1, forms_S=False)
+    mf = [lib.structure_stats(prob, r, world, forms_S=False) for r in range(world)]
+    ex = [lib.structure_stats(prob, r, world, forms_S=True) for r in range(world)]
+    for parts in (mf, ex):  # both dealings partition the tracks and observations of the problem
+        for k in ("tracks", "observations", "observation_checksum"):
+            assert sum(p[k] for p in parts) == one[k], k
+        for p in parts:
+            assert p["reduced_blocks"] == one["reduced_blocks"] and p["block_dim"] == one["block_dim"]
+    obs_mf = np.array([p["observations"] for p in mf], dtype=float)
+    obs_ex = np.array([p["observations"] for p in ex], dtype=float)
+    assert obs_mf.max() / obs_mf.mean() < 1.05 and obs_mf.min() / obs_mf.mean() > 0.95
+    # ... which the pair-weighted dealing does not give on this problem (its balance is pairs + 5 x observations)
+    assert obs_ex.min() / obs_ex.mean() < obs_mf.min() / obs_mf.mean()
+
+
 def test_structure_rejects_bad_input():
     prob = synth.config("tiny")
     bad = prob.copy()

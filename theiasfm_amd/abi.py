@@ -143,6 +143,7 @@ class CSummary(C.Structure):
         ("kernel_launches", C.c_int64 * NUM_KERNEL_CLASSES),
         ("kernel_seconds", C.c_double * NUM_KERNEL_CLASSES),
         ("message", C.c_char * 192),
+        ("effective_preconditioner_type", C.c_int32),
     ]
 
     def as_dict(self) -> dict:

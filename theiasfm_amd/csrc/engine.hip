@@ -2538,11 +2538,15 @@ static int solve_reduced_pcg(tmi_ba_solver* s, const tmi_ba_options* O, int* usa
           s->num_cus = prop.multiProcessorCount;
         }
         s->ppcg_grid = std::max(1, s->num_cus);
-        int rc;
-        if ((rc = dev_alloc(s, &s->d_ppcg_p, (size_t)2 * n))) return rc;
-        if ((rc = dev_alloc(s, &s->d_ppcg_x, (size_t)n))) return rc;
-        if ((rc = dev_alloc(s, &s->d_ppcg_partial, (size_t)3 * s->ppcg_grid))) return rc;
-        if ((rc = dev_alloc(s, &s->d_ppcg_bar, (size_t)ppcg::kBarInts))) return rc;
+        // the persistent launch is an optimisation: if its (small) buffers cannot be had, the solve continues on the
+        // launch-per-step loop below instead of failing -- clear the sticky HIP error and the message
+        if (dev_alloc(s, &s->d_ppcg_p, (size_t)2 * n) || dev_alloc(s, &s->d_ppcg_x, (size_t)n) ||
+            dev_alloc(s, &s->d_ppcg_partial, (size_t)3 * s->ppcg_grid) || dev_alloc(s, &s->d_ppcg_bar, (size_t)ppcg::kBarInts)) {
+          (void)hipGetLastError();
+          s->error.clear();
+          s->ppcg_off = true;
+          return solve_reduced_pcg(s, O, usable, iters);
+        }
         s->ppcg_ready = true;
       }
       int rc0;
@@ -3236,6 +3240,13 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
       const int64_t before = pcg_iters;
       CK(solve_reduced_pcg(s, O, &usable, &pcg_iters));
       last_pcg_len = (int)(pcg_iters - before);
+      // what this iteration's PCG ran with (tmi_ba_summary::effective_preconditioner_type): the clusters only while
+      // they are active (cl_active is cleared when a cluster launch retires them mid-solve), JACOBI as SCHUR_JACOBI
+      sum->effective_preconditioner_type =
+          s->cl_active ? TMI_BA_PRECOND_CLUSTER_JACOBI
+          : O->preconditioner_type == TMI_BA_PRECOND_IDENTITY ? TMI_BA_PRECOND_IDENTITY
+          : O->preconditioner_type == TMI_BA_PRECOND_SCHUR_JACOBI_PARAMETER_BLOCKS ? TMI_BA_PRECOND_SCHUR_JACOBI_PARAMETER_BLOCKS
+                                                                                    : TMI_BA_PRECOND_SCHUR_JACOBI;
     } else {
       CK(solve_reduced_dense(s, &usable));
     }
@@ -4154,9 +4165,16 @@ int32_t tmi_ba_adjust_two_views(tmi_ba_two_view_batch* Bh, int32_t point_dof, in
 }
 
 int32_t tmi_ba_structure_stats(const tmi_ba_problem* P, int32_t rank, int32_t world, int64_t out[12]) {
+  return tmi_ba_structure_stats_for(P, rank, world, /*forms_S=*/1, out);
+}
+
+int32_t tmi_ba_structure_stats_for(const tmi_ba_problem* P, int32_t rank, int32_t world, int32_t forms_S, int64_t out[12]) {
   if (!P || !out) return TMI_BA_ERR_INVALID_ARGUMENT;
   Structure st;
-  const int rc = build_structure(P, rank, world, &st);
+  // the dealing of the slices depends on what the handle will do with them (structure.cpp): work = Schur pairs +
+  // 5 x observations where S is formed (want_pairs_mode 1), observations where the operator is matrix-free -- the
+  // default of a sharded solve (want_pairs_mode 0)
+  const int rc = build_structure(P, rank, world, &st, forms_S ? 1 : 0);
   if (rc != TMI_BA_OK) return rc;
   out[0] = st.Np; out[1] = st.No; out[2] = st.Nrb; out[3] = st.D; out[4] = st.nub;
   out[5] = st.nnzb; out[6] = st.npairs; out[8] = st.nslices; out[9] = st.No_pad;
@@ -4231,6 +4249,9 @@ int32_t tmi_ba_solver_operator_info(tmi_ba_solver* s, int32_t out[8]) {
   out[3] = s->adaptive ? 1 : 0;
   out[4] = s->implicit ? 1 : 0;
   out[5] = s->adaptive ? (int32_t)std::min(s->adaptive_break_even, 1 << 30) : 0;
+  // can this handle serve CLUSTER_JACOBI with clusters (shared-intrinsics clusters, or visibility clusters built at create)?
+  // 0: a CLUSTER_JACOBI request keeps the SCHUR_JACOBI blocks (tmi_ba_summary::effective_preconditioner_type says so per solve)
+  out[6] = ((s->st.has_shared || s->vis_clusters) && !s->cl_unavailable) ? 1 : 0;
   return TMI_BA_OK;
 }
 

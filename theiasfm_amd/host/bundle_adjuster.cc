@@ -338,19 +338,31 @@ void BundleAdjuster::AddReprojectionErrorResidual(const Feature& feature, Camera
   ViewId view_id = hook_view_id_;
   TrackId track_id = hook_track_id_;
   {
+    // (a miss builds the pointer -> id maps ONCE: a subclass that forwards its own pointers for every residual would
+    // otherwise pay a scan of all views and tracks per residual -- ADVICE r5)
     View* hv = view_id == kInvalidViewId ? nullptr : reconstruction_->MutableView(view_id);
     if (hv == nullptr || hv->MutableCamera() != camera) {
-      view_id = kInvalidViewId;
-      for (const ViewId v : reconstruction_->ViewIds())
-        if (reconstruction_->MutableView(v)->MutableCamera() == camera) { view_id = v; break; }
+      if (camera_to_view_.empty())
+        for (const ViewId v : reconstruction_->ViewIds()) camera_to_view_.emplace(reconstruction_->MutableView(v)->MutableCamera(), v);
+      const auto it = camera_to_view_.find(camera);
+      view_id = it == camera_to_view_.end() ? kInvalidViewId : it->second;
     }
     if (track_id == kInvalidTrackId || reconstruction_->MutableTrack(track_id) != track) {
-      track_id = kInvalidTrackId;
-      for (const TrackId t : reconstruction_->TrackIds())
-        if (reconstruction_->MutableTrack(t) == track) { track_id = t; break; }
+      if (track_to_id_.empty())
+        for (const TrackId t : reconstruction_->TrackIds()) track_to_id_.emplace(reconstruction_->MutableTrack(t), t);
+      const auto it = track_to_id_.find(track);
+      track_id = it == track_to_id_.end() ? kInvalidTrackId : it->second;
     }
   }
-  if (view_id == kInvalidViewId || track_id == kInvalidTrackId) return;  // not of this reconstruction
+  if (view_id == kInvalidViewId || track_id == kInvalidTrackId) {
+    // not of this reconstruction: the residual cannot be flattened (the reference would hand Ceres the raw pointers)
+    if (!warned_foreign_residual_) {
+      warned_foreign_residual_ = true;
+      std::fprintf(stderr, "[tmi_ba shim] AddReprojectionErrorResidual: camera / track pointer does not belong to the "
+                           "reconstruction being adjusted; residual dropped (reported once per BundleAdjuster)\n");
+    }
+    return;
+  }
   residuals_.push_back(Residual{view_id, track_id, feature.x(), feature.y()});
   camera_flags_.SetIfAbsent(view_id, 0);
   track_constant_.SetIfAbsent(track_id, 1);
@@ -600,8 +612,9 @@ void ToDeviceOptions(const BundleAdjustmentOptions& options, tmi_ba_options* o) 
   // CLUSTER_TRIDIAGONAL go through: clusters = the shared intrinsics blocks with their views (theia_mi355_ba.h).
   o->preconditioner_type = static_cast<int32_t>(options.preconditioner_type);
   if (options.preconditioner_type == ceres::CLUSTER_TRIDIAGONAL) {
-    // the C ABI refuses CLUSTER_TRIDIAGONAL (not implemented); a Theia caller gets the nearest preconditioner and is
-    // told once per process (the reference would LOG(WARNING))
+    // the C ABI refuses CLUSTER_TRIDIAGONAL (not implemented); a Theia caller gets the nearest preconditioner, is told
+    // once per process (the reference would LOG(WARNING)) and finds the substitution in every summary
+    // (BundleAdjustmentSummary::preconditioner_substituted / effective_preconditioner_type, FillPreconditionerReport)
     static std::atomic<bool> warned(false);
     if (!warned.exchange(true))
       std::fprintf(stderr, "[tmi_ba shim] ceres::CLUSTER_TRIDIAGONAL is not implemented on the device path: using CLUSTER_JACOBI\n");
@@ -622,6 +635,23 @@ void ToDeviceOptions(const BundleAdjustmentOptions& options, tmi_ba_options* o) 
   o->point_dof = options.point_dof;
   o->device = options.device;
   o->visibility_clustering_type = static_cast<int32_t>(options.visibility_clustering_type);  // bundle_adjuster.cc:61
+}
+
+// which preconditioner ran (tmi_ba_summary::effective_preconditioner_type) in ceres' enumerators, against the request
+void FillPreconditionerReport(const BundleAdjustmentOptions& options, const tmi_ba_summary& device, BundleAdjustmentSummary* summary) {
+  const bool iterative = options.linear_solver_type == ceres::ITERATIVE_SCHUR || options.linear_solver_type == ceres::CGNR;
+  if (!iterative || device.num_linear_solver_iterations == 0) {
+    summary->effective_preconditioner_type = iterative ? options.preconditioner_type : ceres::IDENTITY;
+    summary->preconditioner_substituted = iterative && options.preconditioner_type == ceres::CLUSTER_TRIDIAGONAL;
+    if (summary->preconditioner_substituted) summary->effective_preconditioner_type = ceres::CLUSTER_JACOBI;
+    return;
+  }
+  switch (device.effective_preconditioner_type) {
+    case TMI_BA_PRECOND_IDENTITY: summary->effective_preconditioner_type = ceres::IDENTITY; break;
+    case TMI_BA_PRECOND_CLUSTER_JACOBI: summary->effective_preconditioner_type = ceres::CLUSTER_JACOBI; break;
+    default: summary->effective_preconditioner_type = ceres::SCHUR_JACOBI; break;  // either block shape
+  }
+  summary->preconditioner_substituted = summary->effective_preconditioner_type != options.preconditioner_type;
 }
 
 // bundle_adjuster.cc:182-221
@@ -686,6 +716,7 @@ BundleAdjustmentSummary BundleAdjuster::OptimizeResident(FlattenedBundleAdjustme
   summary.final_cost = device_summary_.final_cost;
   summary.setup_time_in_seconds = internal_setup_time + device_summary_.setup_time_in_seconds;
   summary.solve_time_in_seconds = device_summary_.solve_time_in_seconds;
+  FillPreconditionerReport(options_, device_summary_, &summary);
   if (options_.verbose)
     std::fprintf(stderr, "[theia::BundleAdjuster] %s: cost %.9e -> %.9e, %d iterations, rmse %.6f px\n",
                  device_summary_.message, summary.initial_cost, summary.final_cost,
@@ -845,6 +876,7 @@ BundleAdjustmentSummary RunSession(ResidentSession* s, const BundleAdjustmentOpt
   summary.final_cost = ds.final_cost;
   summary.setup_time_in_seconds = setup;  // gather + upload (the handle's own figure is its create call, long past)
   summary.solve_time_in_seconds = ds.solve_time_in_seconds;
+  FillPreconditionerReport(options, ds, &summary);
   if (options.verbose)
     std::fprintf(stderr, "[theia::BundleAdjustReconstruction, resident session] %s: cost %.9e -> %.9e, %d iterations\n",
                  ds.message, summary.initial_cost, summary.final_cost, ds.num_iterations);

@@ -25,7 +25,7 @@ EXPORTS = (
     "tmi_ba_intrinsics_size", "tmi_ba_intrinsics_constant_mask", "tmi_ba_solve",
     "tmi_ba_solver_create", "tmi_ba_solver_set_allreduce", "tmi_ba_solver_solve",
     "tmi_ba_solver_reset", "tmi_ba_solver_set_parameters", "tmi_ba_solver_download", "tmi_ba_solver_stream",
-    "tmi_ba_solver_destroy", "tmi_ba_solver_evaluate", "tmi_ba_structure_stats",
+    "tmi_ba_solver_destroy", "tmi_ba_solver_evaluate", "tmi_ba_structure_stats", "tmi_ba_structure_stats_for",
     "tmi_ba_rccl_unique_id", "tmi_ba_solver_init_rccl", "tmi_ba_solver_debug_allreduce",
     "tmi_ba_solver_filter_outlier_tracks", "tmi_ba_filter_outlier_tracks",
     "tmi_ba_solver_adjust_tracks", "tmi_ba_adjust_tracks",
@@ -101,6 +101,8 @@ def load():
     L.tmi_ba_solver_debug_allreduce.restype = C.c_int32
     L.tmi_ba_structure_stats.argtypes = [P, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]
     L.tmi_ba_structure_stats.restype = C.c_int32
+    L.tmi_ba_structure_stats_for.argtypes = [P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]
+    L.tmi_ba_structure_stats_for.restype = C.c_int32
     FS, TS = C.POINTER(abi.CFilterSummary), C.POINTER(abi.CTrackBatchSummary)
     L.tmi_ba_solver_filter_outlier_tracks.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p,
                                                       C.c_void_p, FS]
@@ -140,12 +142,13 @@ STRUCTURE_STAT_NAMES = ("tracks", "observations", "reduced_blocks", "block_dim",
                         "observation_checksum", "pair_checksum")
 
 
-def structure_stats(problem: abi.Problem, rank: int = 0, world: int = 1) -> dict:
-    """Host-only statistics of the static structure for one rank (no GPU)."""
+def structure_stats(problem: abi.Problem, rank: int = 0, world: int = 1, forms_S: bool = True) -> dict:
+    """Host-only statistics of the static structure for one rank (no GPU).  forms_S=False: the dealing of a handle whose
+    operator is matrix-free (the default on several ranks) -- slices balanced by observations, not by Schur pairs."""
     L = load()
     cp = problem.as_c()
     out = (C.c_int64 * 12)()
-    st = L.tmi_ba_structure_stats(C.byref(cp), rank, world, out)
+    st = L.tmi_ba_structure_stats_for(C.byref(cp), rank, world, 1 if forms_S else 0, out)
     if st != 0:
         raise EngineError(st, "tmi_ba_structure_stats")
     return dict(zip(STRUCTURE_STAT_NAMES, list(out)))
