@@ -128,11 +128,20 @@ typedef enum tmi_ba_linear_solver {
  *     edge weights |tracks seen by both| / sqrt(|tracks of a| |tracks of b|) over the parameter blocks, then
  *     canonical views with size penalty 3 / similarity penalty 0 / at least 3 centres, or single linkage at 0.9;
  *     restated from Ceres 1.14 -- parity unpinned like the rest of the Ceres layer) and every cluster's principal
- *     submatrix of S is inverted exactly; this needs the formed S (schur_mode auto picks it; with schur_mode implicit, or on several ranks,
- *     the solve keeps the SCHUR_JACOBI blocks and says so in tmi_ba_summary.effective_preconditioner_type).  CLUSTER_TRIDIAGONAL (Ceres adds the blocks between neighbouring clusters of a degree-2
- *     spanning forest) is NOT implemented: create / solve return TMI_BA_ERR_UNSUPPORTED rather than answer with
- *     another preconditioner; the C++ shim maps ceres::CLUSTER_TRIDIAGONAL to CLUSTER_JACOBI and reports the
- *     substitution in BundleAdjustmentSummary (preconditioner_substituted / effective_preconditioner_type).
+ *     submatrix of S is inverted exactly; this needs the formed S (schur_mode auto picks it; with schur_mode
+ *     implicit, or on several ranks, the solve keeps the SCHUR_JACOBI blocks and says so in
+ *     tmi_ba_summary.effective_preconditioner_type).
+ *     CLUSTER_TRIDIAGONAL (round 6, cluster_chains.h): Ceres' tridiagonal variant also keeps the blocks between clusters that are neighbours in a degree-2 maximum spanning forest of the cluster graph (vertices: the
+ *     clusters above plus every other reduced block as a cluster of its own; edge weight: the number of non-constant
+ *     tracks both clusters see; edges taken in decreasing order of (weight, lower end, higher end) unless an end has two
+ *     edges already or the ends are connected).  The forest's components are paths; every path is factored exactly as
+ *     a block-tridiagonal matrix (a dense factor whose tiles outside the band stay zero: a path is cut where it would
+ *     pass TMI_BA_MAX_CLUSTER_DIM unknowns).  Dropping the other blocks can cost positive definiteness: as in Ceres the
+ *     off-diagonal cluster-pair cells are then halved and the factorisation repeated once; a second failure fails the
+ *     linear solve (an invalid LM step).  Needs the formed S and one rank -- schur_mode auto forms S, schur_mode implicit
+ *     and sharded solves keep the SCHUR_JACOBI blocks (effective_preconditioner_type says so).  A handle serves the
+ *     preconditioner it was created for (the chains are part of its structure).  Restated from Ceres 1.14
+ *     (visibility_based_preconditioner.cc, graph_algorithms.h); parity unpinned like the rest of the Ceres layer.
  *     A cluster launch that cannot become co-resident (device shared with another process) retires
  *     the clusters for that solve: PCG continues with the SCHUR_JACOBI blocks.
  *   Intrinsics shared by several views form their own reduced block in every mode.  */

@@ -492,6 +492,13 @@ typedef struct {
    * computed at the first PCG solve (visibility_clusters) */
   int* vis_cluster;
   int vis_ncl;
+  /* CLUSTER_TRIDIAGONAL: the segments (chains of clusters along the degree-2 maximum spanning forest of the cluster
+   * graph), computed at the first PCG solve (tridiagonal_segments): members of segment c are tri_rb[tri_ptr[c] ..
+   * tri_ptr[c + 1]), tri_ord = the position of the member's cluster in its segment */
+  int tri_nseg;
+  int* tri_ptr;
+  int* tri_rb;
+  int* tri_ord;
 } ost;
 
 static int obs_parts(const ost* s, int c, int* rb0, int* n0, int* rb1, int* n1) {
@@ -1008,6 +1015,23 @@ static int block_inverse(int n, const double* A, double* Ainv) {
 
 static int* g_last_vis = NULL;
 static int g_last_vis_n = 0;
+/* test hook of CLUSTER_TRIDIAGONAL: segment and position of its cluster inside the segment, per camera (-1: the view
+ * block is in no segment), of the last solve that built them */
+static int* g_last_tri = NULL; /* [2 * n]: segment, ordinal */
+static int g_last_tri_n = 0;
+int32_t oracle_last_tridiagonal_segments(int32_t* segment, int32_t* ordinal, int32_t n) {
+  int rc = -1;
+#pragma omp critical(oracle_last_vis)
+  if (g_last_tri && n >= g_last_tri_n) {
+    for (int c = 0; c < g_last_tri_n; ++c) {
+      segment[c] = g_last_tri[2 * c];
+      ordinal[c] = g_last_tri[2 * c + 1];
+    }
+    rc = g_last_tri_n;
+  }
+  return rc;
+}
+
 int32_t oracle_last_visibility_clusters(int32_t* out, int32_t n) {
   int rc = -1;
 #pragma omp critical(oracle_last_vis)
@@ -1163,6 +1187,226 @@ static int visibility_clusters(ost* s, int type, int* cluster) {
   return ncl;
 }
 
+/* CLUSTER_TRIDIAGONAL (ceres::CLUSTER_TRIDIAGONAL, bundle_adjustment.h:86-89; the reference only passes the enum on,
+ * bundle_adjuster.cc:59-63 -- Ceres 1.14 visibility_based_preconditioner.cc ComputeClusterTridiagonalSparsity /
+ * CreateClusterGraph / graph_algorithms.h Degree2MaximumSpanningForest restated; PARITY UNPINNED like the rest of the
+ * Ceres layer).  Where CLUSTER_JACOBI keeps the cluster pairs (i, i), the tridiagonal variant also keeps the pairs
+ * (i, j) that are edges of a degree-2 maximum spanning forest of the cluster graph:
+ *   vertices  the clusters of CLUSTER_JACOBI -- with shared intrinsics blocks {shared block, its views}, otherwise the
+ *             visibility clusters -- and every reduced block outside them as a cluster of its own; numbered by their
+ *             lowest reduced block;
+ *   edges     between two clusters that see a common (non-constant) track, weight = the number of such tracks;
+ *   forest    the edges in decreasing order of (weight, lower vertex, higher vertex) -- Ceres sorts the pairs
+ *             <weight, <v1, v2>> with reverse iterators --, an edge is taken unless one of its ends has two edges
+ *             already or both ends are connected already.
+ * The components of the forest are paths; the preconditioner of a path is its block-tridiagonal matrix (the clusters'
+ * principal submatrices of S and the blocks of S between neighbours on the path), factored exactly.  A path is walked
+ * from its end with the lower cluster number; it is cut where the next cluster would take the matrix beyond
+ * TMI_BA_MAX_CLUSTER_DIM unknowns (a dense factor here, a sparse one in Ceres -- engine and oracle cut alike), a
+ * cluster that alone is beyond it keeps its SCHUR_JACOBI blocks, and a segment that is one single reduced block IS
+ * its SCHUR_JACOBI block. */
+static void tridiagonal_segments(ost* s, int have_shared) {
+  const int n = s->nrb;
+  int* cl_of = (int*)malloc(sizeof(int) * (size_t)(n + 1));
+  for (int b = 0; b < n; ++b) cl_of[b] = -1;
+  int ncl = 0;
+  if (have_shared) {
+    for (int g = 0; g < s->G; ++g) {
+      if (s->grp_rb[g] < 0) continue;
+      for (int c = 0; c < s->Nc; ++c)
+        if (s->P->camera_group[c] == g && s->cam_rb[c] >= 0) cl_of[s->cam_rb[c]] = ncl;
+      cl_of[s->grp_rb[g]] = ncl;
+      ++ncl;
+    }
+  } else {
+    for (int b = 0; b < n; ++b)
+      if (s->vis_cluster[b] >= 0) {
+        cl_of[b] = s->vis_cluster[b];
+        if (cl_of[b] + 1 > ncl) ncl = cl_of[b] + 1;
+      }
+  }
+  for (int b = 0; b < n; ++b)
+    if (cl_of[b] < 0) cl_of[b] = ncl++;
+  /* number the clusters by their lowest reduced block (empty ids of the visibility clustering drop out) */
+  {
+    int* lowest = (int*)malloc(sizeof(int) * (size_t)(ncl + 1));
+    int* renum = (int*)malloc(sizeof(int) * (size_t)(ncl + 1));
+    for (int c = 0; c < ncl; ++c) lowest[c] = renum[c] = -1;
+    int m = 0;
+    for (int b = 0; b < n; ++b)
+      if (lowest[cl_of[b]] < 0) {
+        lowest[cl_of[b]] = b;
+        renum[cl_of[b]] = m++;
+      }
+    for (int b = 0; b < n; ++b) cl_of[b] = renum[cl_of[b]];
+    ncl = m;
+    free(lowest);
+    free(renum);
+  }
+  int* cdim = (int*)calloc((size_t)ncl + 1, sizeof(int));
+  for (int b = 0; b < n; ++b) cdim[cl_of[b]] += s->rb_dim[b];
+  /* weights: tracks seen from both clusters */
+  double* W = (double*)calloc((size_t)ncl * ncl + 1, sizeof(double));
+  {
+    int* seen = (int*)malloc(sizeof(int) * (size_t)(s->Nc + 2));
+    for (int p = 0; p < s->Np; ++p) {
+      if (s->P->point_constant && s->P->point_constant[p]) continue;
+      int m = 0;
+      for (int64_t k = s->pt_ptr[p]; k < s->pt_ptr[p + 1]; ++k) {
+        const int rb = s->cam_rb[s->P->obs_camera[s->order[k]]];
+        if (rb < 0) continue;
+        const int c = cl_of[rb];
+        int dup = 0;
+        for (int a = 0; a < m; ++a)
+          if (seen[a] == c) dup = 1;
+        if (!dup) seen[m++] = c;
+      }
+      for (int a = 0; a < m; ++a)
+        for (int b = 0; b < m; ++b)
+          if (seen[a] < seen[b]) W[(int64_t)seen[a] * ncl + seen[b]] += 1.0;
+    }
+    free(seen);
+  }
+  /* edges, sorted: weight descending, then (a, b) descending */
+  int64_t ne = 0;
+  for (int64_t i = 0; i < (int64_t)ncl * ncl; ++i)
+    if (W[i] > 0.0) ++ne;
+  int* ea = (int*)malloc(sizeof(int) * (size_t)(ne + 1));
+  int* eb = (int*)malloc(sizeof(int) * (size_t)(ne + 1));
+  {
+    int64_t k = 0;
+    for (int a = 0; a < ncl; ++a)
+      for (int b = a + 1; b < ncl; ++b)
+        if (W[(int64_t)a * ncl + b] > 0.0) {
+          ea[k] = a;
+          eb[k] = b;
+          ++k;
+        }
+    /* insertion sort is quadratic: a simple merge-free heap sort on the index instead */
+    int64_t* idx = (int64_t*)malloc(sizeof(int64_t) * (size_t)(ne + 1));
+    for (int64_t i = 0; i < ne; ++i) idx[i] = i;
+#define TRI_BEFORE(x, y)                                                                                   \
+  (W[(int64_t)ea[x] * ncl + eb[x]] != W[(int64_t)ea[y] * ncl + eb[y]]                                      \
+       ? W[(int64_t)ea[x] * ncl + eb[x]] > W[(int64_t)ea[y] * ncl + eb[y]]                                 \
+       : (ea[x] != ea[y] ? ea[x] > ea[y] : eb[x] > eb[y]))
+    /* heap sort: idx ends in "before" order */
+    for (int64_t start = ne / 2 - 1; start >= 0; --start) {
+      int64_t root = start;
+      for (;;) {
+        int64_t child = 2 * root + 1;
+        if (child >= ne) break;
+        if (child + 1 < ne && TRI_BEFORE(idx[child], idx[child + 1])) ++child; /* the LATER one is the larger heap key */
+        if (TRI_BEFORE(idx[root], idx[child])) {
+          const int64_t t = idx[root]; idx[root] = idx[child]; idx[child] = t;
+          root = child;
+        } else {
+          break;
+        }
+      }
+    }
+    for (int64_t end = ne - 1; end > 0; --end) {
+      { const int64_t t = idx[0]; idx[0] = idx[end]; idx[end] = t; }
+      int64_t root = 0;
+      for (;;) {
+        int64_t child = 2 * root + 1;
+        if (child >= end) break;
+        if (child + 1 < end && TRI_BEFORE(idx[child], idx[child + 1])) ++child;
+        if (TRI_BEFORE(idx[root], idx[child])) {
+          const int64_t t = idx[root]; idx[root] = idx[child]; idx[child] = t;
+          root = child;
+        } else {
+          break;
+        }
+      }
+    }
+#undef TRI_BEFORE
+    /* forest */
+    int* deg = (int*)calloc((size_t)ncl + 1, sizeof(int));
+    int* nb = (int*)malloc(sizeof(int) * (size_t)(2 * ncl + 2));
+    int* parent = (int*)malloc(sizeof(int) * (size_t)(ncl + 1));
+    for (int c = 0; c < ncl; ++c) parent[c] = c;
+    for (int64_t q = 0; q < ne; ++q) {
+      const int a = ea[idx[q]], b = eb[idx[q]];
+      if (deg[a] == 2 || deg[b] == 2) continue;
+      int ra = a, rb2 = b;
+      while (parent[ra] != ra) ra = parent[ra];
+      while (parent[rb2] != rb2) rb2 = parent[rb2];
+      if (ra == rb2) continue;
+      nb[2 * a + deg[a]++] = b;
+      nb[2 * b + deg[b]++] = a;
+      if (rb2 < ra) { const int t = ra; ra = rb2; rb2 = t; }
+      parent[rb2] = ra;
+    }
+    /* paths, from the end with the lower number; segments */
+    int* visited = (int*)calloc((size_t)ncl + 1, sizeof(int));
+    int* path = (int*)malloc(sizeof(int) * (size_t)(ncl + 1));
+    s->tri_ptr = (int*)calloc((size_t)ncl + 2, sizeof(int));
+    s->tri_rb = (int*)malloc(sizeof(int) * (size_t)(n + 1));
+    s->tri_ord = (int*)malloc(sizeof(int) * (size_t)(n + 1));
+    s->tri_nseg = 0;
+    for (int c0 = 0; c0 < ncl; ++c0) {
+      if (visited[c0] || deg[c0] == 2) continue;
+      int len = 0, prev = -1, cur = c0;
+      while (cur >= 0) {
+        visited[cur] = 1;
+        path[len++] = cur;
+        int next = -1;
+        for (int k = 0; k < deg[cur]; ++k)
+          if (nb[2 * cur + k] != prev) next = nb[2 * cur + k];
+        prev = cur;
+        cur = next;
+      }
+      /* cut into segments */
+      int i = 0;
+      while (i < len) {
+        if (cdim[path[i]] > TMI_BA_MAX_CLUSTER_DIM) { ++i; continue; } /* keeps its SCHUR_JACOBI blocks */
+        int j = i, dim = 0;
+        while (j < len && cdim[path[j]] <= TMI_BA_MAX_CLUSTER_DIM && dim + cdim[path[j]] <= TMI_BA_MAX_CLUSTER_DIM) dim += cdim[path[j++]];
+        /* members: cluster by cluster, reduced blocks ascending */
+        int m = s->tri_ptr[s->tri_nseg];
+        const int m0 = m;
+        for (int q = i; q < j; ++q)
+          for (int b = 0; b < n; ++b)
+            if (cl_of[b] == path[q]) {
+              s->tri_rb[m] = b;
+              s->tri_ord[m] = q - i;
+              ++m;
+            }
+        if (m - m0 >= 2) { /* a single reduced block is its own SCHUR_JACOBI block */
+          s->tri_ptr[s->tri_nseg + 1] = m;
+          s->tri_nseg++;
+        }
+        i = j;
+      }
+    }
+    free(visited); free(path); free(deg); free(nb); free(parent); free(idx);
+  }
+  free(ea); free(eb); free(W); free(cdim); free(cl_of);
+  {
+    int* mine = (int*)malloc(sizeof(int) * (size_t)(2 * s->Nc + 2));
+    int* seg_of = (int*)malloc(sizeof(int) * (size_t)(n + 1));
+    int* ord_of = (int*)malloc(sizeof(int) * (size_t)(n + 1));
+    for (int b = 0; b < n; ++b) seg_of[b] = ord_of[b] = -1;
+    for (int g = 0; g < s->tri_nseg; ++g)
+      for (int a = s->tri_ptr[g]; a < s->tri_ptr[g + 1]; ++a) {
+        seg_of[s->tri_rb[a]] = g;
+        ord_of[s->tri_rb[a]] = s->tri_ord[a];
+      }
+    for (int c = 0; c < s->Nc; ++c) {
+      mine[2 * c] = s->cam_rb[c] >= 0 ? seg_of[s->cam_rb[c]] : -1;
+      mine[2 * c + 1] = s->cam_rb[c] >= 0 ? ord_of[s->cam_rb[c]] : -1;
+    }
+    free(seg_of);
+    free(ord_of);
+#pragma omp critical(oracle_last_vis)
+    {
+      free(g_last_tri);
+      g_last_tri = mine;
+      g_last_tri_n = s->Nc;
+    }
+  }
+}
+
 /* ceres/conjugate_gradients_solver.cc (Ceres 1.14) restated, applied to the
  * explicit reduced system with the SCHUR_JACOBI preconditioner (inverse of
  * the diagonal blocks of S).  r_tolerance = -1, q_tolerance = eta
@@ -1203,7 +1447,8 @@ static int solve_pcg(ost* s) {
    * is a shared intrinsics block together with the views that share it (theia_mi355_ba.h) -- the principal submatrix
    * of S over {views of g, g}, factored densely (Cholesky), views of private groups keep their own block.  A
    * cluster whose matrix is not positive definite falls back to its diagonal blocks. */
-  const int clustered = s->O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_JACOBI;
+  const int tri = s->O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_TRIDIAGONAL;
+  const int clustered = s->O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_JACOBI || tri;
   int ncl = 0;
   int* cl_ptr = NULL;     /* [ncl + 1] into cl_rb */
   int* cl_rb = NULL;      /* member reduced blocks: the views of the group ascending, then the group's block */
@@ -1232,7 +1477,22 @@ static int solve_pcg(ost* s) {
     }
     n_cand = s->vis_ncl;
   }
+  /* CLUSTER_TRIDIAGONAL: the "clusters" factored below are the segments of tridiagonal_segments -- chains of clusters
+   * with the blocks of S between neighbours.  Dropping blocks can cost positive definiteness: Ceres then halves every
+   * off-diagonal cluster-pair cell and factors once more (VisibilityBasedPreconditioner::UpdateImpl /
+   * ScaleOffDiagonalCells); a second failure fails the preconditioner update and with it the linear solve. */
+  if (tri) {
+    if (!s->tri_ptr) tridiagonal_segments(s, have_shared);
+    n_cand = s->tri_nseg;
+  }
+  int* cl_ord = NULL;
+  int tri_attempt = 0;
+  double off_scale = 1.0;
+  /* (test hooks shared with the engine: the factors of the two attempts, tests/test_cluster_jacobi.py) */
+  if (tri && getenv("TMI_BA_TEST_TRI_SCALE0")) off_scale = atof(getenv("TMI_BA_TEST_TRI_SCALE0"));
+tri_again:
   if (clustered) {
+    if (tri) cl_ord = (int*)malloc(sizeof(int) * (size_t)(s->Nc + s->G + 1));
     cl_ptr = (int*)calloc((size_t)n_cand + 2, sizeof(int));
     cl_rb = (int*)malloc(sizeof(int) * (size_t)(s->Nc + s->G + 1));
     cl_ok = (int*)calloc((size_t)n_cand + 1, sizeof(int));
@@ -1240,7 +1500,12 @@ static int solve_pcg(ost* s) {
     cl_n = (int*)calloc((size_t)n_cand + 1, sizeof(int));
     for (int g = 0; g < n_cand; ++g) {
       int m = cl_ptr[ncl];
-      if (have_shared) {
+      if (tri) {
+        for (int a = s->tri_ptr[g]; a < s->tri_ptr[g + 1]; ++a) {
+          cl_ord[m] = s->tri_ord[a];
+          cl_rb[m++] = s->tri_rb[a];
+        }
+      } else if (have_shared) {
         if (s->grp_rb[g] < 0) continue;
         for (int c = 0; c < s->Nc; ++c)
           if (s->P->camera_group[c] == g && s->cam_rb[c] >= 0) cl_rb[m++] = s->cam_rb[c];
@@ -1265,10 +1530,13 @@ static int solve_pcg(ost* s) {
         for (int bb = cl_ptr[ncl]; bb <= a; ++bb) {
           const int bj = cl_rb[bb], nj = s->rb_dim[bj];
           const int64_t q = block_lookup(s, bi, bj);
-          if (q >= 0) {
+          /* (tridiagonal: the blocks inside a cluster and between neighbouring clusters of the chain only) */
+          const int dord = tri ? cl_ord[a] - cl_ord[bb] : 0;
+          if (q >= 0 && dord >= -1 && dord <= 1) {
             const double* B = s->S + s->blk_off[q];
+            const double sc = dord != 0 ? off_scale : 1.0;
             for (int i = 0; i < ni; ++i)
-              for (int j = 0; j < nj; ++j) C[(int64_t)(oi + i) * nc + oj + j] = B[i * nj + j];
+              for (int j = 0; j < nj; ++j) C[(int64_t)(oi + i) * nc + oj + j] = sc * B[i * nj + j];
           }
           oj += nj;
         }
@@ -1293,6 +1561,26 @@ static int solve_pcg(ost* s) {
       cl_ok[ncl] = pd;
       cl_L[ncl] = C;
       ++ncl;
+    }
+  }
+  if (tri) {
+    int all_pd = 1;
+    for (int c = 0; c < ncl; ++c)
+      if (!cl_ok[c]) all_pd = 0;
+    if (!all_pd) {
+      for (int c = 0; c < ncl; ++c) free(cl_L[c]);
+      free(cl_ptr); free(cl_rb); free(cl_ok); free(cl_L); free(cl_n); free(cl_ord);
+      cl_ptr = cl_rb = cl_ok = cl_n = cl_ord = NULL;
+      cl_L = NULL;
+      ncl = 0;
+      if (tri_attempt == 0) {
+        tri_attempt = 1;
+        off_scale = getenv("TMI_BA_TEST_TRI_SCALE1") ? atof(getenv("TMI_BA_TEST_TRI_SCALE1")) : 0.5;
+        goto tri_again;
+      }
+      free(r);
+      free(Minv);
+      return 0; /* "Preconditioner update failed.": LINEAR_SOLVER_FAILURE, the step is invalid */
     }
   }
   const double* bref = s->rhs;
@@ -1380,7 +1668,7 @@ static int solve_pcg(ost* s) {
   free(r);
   free(Minv);
   for (int c = 0; c < ncl; ++c) free(cl_L[c]);
-  free(cl_ptr); free(cl_rb); free(cl_ok); free(cl_L); free(cl_n);
+  free(cl_ptr); free(cl_rb); free(cl_ok); free(cl_L); free(cl_n); free(cl_ord);
   return ok;
 }
 
@@ -1495,6 +1783,7 @@ static void free_state(ost* s) {
   free(s->ext); free(s->intr); free(s->pts);
   free(s->n_ext); free(s->ext_idx); free(s->n_intr); free(s->intr_idx); free(s->grp_private);
   free(s->rb_dim); free(s->rb_off); free(s->rb_split); free(s->cam_rb); free(s->grp_rb); free(s->vis_cluster);
+  free(s->tri_ptr); free(s->tri_rb); free(s->tri_ord);
   free(s->order); free(s->pt_ptr);
   free(s->r); free(s->Jc); free(s->Jp); free(s->Ep);
   free(s->scale_c); free(s->scale_p); free(s->diag_c); free(s->diag_p);
@@ -1717,14 +2006,6 @@ int32_t oracle_ba_solve(tmi_ba_problem* P, const tmi_ba_options* O, tmi_ba_summa
   if (!validate(P)) {
     sum->status = TMI_BA_ERR_INVALID_ARGUMENT;
     snprintf(sum->message, sizeof(sum->message), "invalid problem");
-    return sum->status;
-  }
-  if ((O->linear_solver_type == TMI_BA_ITERATIVE_SCHUR || O->linear_solver_type == TMI_BA_CGNR) &&
-      O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_TRIDIAGONAL) {
-    /* not restated (Ceres keeps the blocks between neighbouring clusters of a degree-2 spanning forest); the device
-     * path refuses it as well instead of answering with another preconditioner */
-    sum->status = TMI_BA_ERR_UNSUPPORTED;
-    snprintf(sum->message, sizeof(sum->message), "CLUSTER_TRIDIAGONAL is not restated");
     return sum->status;
   }
   const double t_start = now_s();

@@ -138,6 +138,9 @@ int32_t oracle_angular_epipolar_error(const double* rotation, const double* posi
 /* test hook: the visibility cluster (CLUSTER_JACOBI without shared intrinsics blocks) of every camera in the last
  * oracle_ba_solve that built them; returns the number of cameras or -1 */
 int32_t oracle_last_visibility_clusters(int32_t* out, int32_t n);
+/* test hook of CLUSTER_TRIDIAGONAL: per camera the segment (chain of clusters along the degree-2 maximum spanning forest
+ * of the cluster graph) its view block belongs to and the position of its cluster in that chain, -1: in no segment */
+int32_t oracle_last_tridiagonal_segments(int32_t* segment, int32_t* ordinal, int32_t n);
 int32_t oracle_num_threads(void);
 /* OpenMP threads used by the calls that follow (bench.py: single-thread baseline). */
 void oracle_set_num_threads(int32_t n);

@@ -104,6 +104,18 @@ def last_visibility_clusters(num_cameras: int) -> np.ndarray:
     return out
 
 
+def last_tridiagonal_segments(num_cameras: int):
+    """(segment, position of the view's cluster in the segment) of every camera in the last CLUSTER_TRIDIAGONAL solve"""
+    seg = np.full(num_cameras, -2, dtype=np.int32)
+    pos = np.full(num_cameras, -2, dtype=np.int32)
+    L = lib()
+    L.oracle_last_tridiagonal_segments.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    L.oracle_last_tridiagonal_segments.restype = C.c_int32
+    n = L.oracle_last_tridiagonal_segments(seg.ctypes.data, pos.ctypes.data, num_cameras)
+    assert n == num_cameras, n
+    return seg, pos
+
+
 def inner_sweep(problem: abi.Problem, options: abi.COptions):
     """One coordinate-descent sweep (Ceres inner iterations) in place."""
     cp = problem.as_c()

@@ -299,9 +299,9 @@ static void TestSemantics() {
     d.preconditioner_type = ceres::CLUSTER_JACOBI;  // clusters = shared intrinsics blocks + their views on the device
     ToDeviceOptions(d, &o);
     EXPECT(o.preconditioner_type == TMI_BA_PRECOND_CLUSTER_JACOBI);
-    d.preconditioner_type = ceres::CLUSTER_TRIDIAGONAL;  // refused by the C ABI; the shim answers with the nearest and says so
+    d.preconditioner_type = ceres::CLUSTER_TRIDIAGONAL;  // round 6: implemented (cluster_chains.h), passed through
     ToDeviceOptions(d, &o);
-    EXPECT(o.preconditioner_type == TMI_BA_PRECOND_CLUSTER_JACOBI);
+    EXPECT(o.preconditioner_type == TMI_BA_PRECOND_CLUSTER_TRIDIAGONAL);
     d.preconditioner_type = ceres::JACOBI;
     ToDeviceOptions(d, &o);
     EXPECT(o.preconditioner_type == TMI_BA_PRECOND_SCHUR_JACOBI_PARAMETER_BLOCKS);
@@ -345,8 +345,8 @@ static void TestGpu() {
     EXPECT(!s.preconditioner_substituted && s.effective_preconditioner_type == ceres::IDENTITY);
   }
   {
-    // which preconditioner ran is part of the summary: ceres::CLUSTER_TRIDIAGONAL is served by CLUSTER_JACOBI (or by
-    // SCHUR_JACOBI where the handle has no clusters) and the caller is told; SCHUR_JACOBI is served as asked
+    // which preconditioner ran is part of the summary: ceres::CLUSTER_TRIDIAGONAL and SCHUR_JACOBI are served as asked
+    // on one rank with the formed S (the shim's default); ceres::JACOBI runs as SCHUR_JACOBI and the caller is told
     Reconstruction rec;
     BuildScene(&rec, 8, 300, /*share_groups=*/true, 13, 0.3);
     BundleAdjustmentOptions opt;
@@ -354,11 +354,13 @@ static void TestGpu() {
     opt.max_num_iterations = 4;
     opt.preconditioner_type = ceres::CLUSTER_TRIDIAGONAL;
     const BundleAdjustmentSummary st = BundleAdjustReconstruction(opt, &rec);
-    EXPECT(st.success && st.preconditioner_substituted);
-    EXPECT(st.effective_preconditioner_type == ceres::CLUSTER_JACOBI || st.effective_preconditioner_type == ceres::SCHUR_JACOBI);
+    EXPECT(st.success && !st.preconditioner_substituted && st.effective_preconditioner_type == ceres::CLUSTER_TRIDIAGONAL);
     opt.preconditioner_type = ceres::SCHUR_JACOBI;
     const BundleAdjustmentSummary sj = BundleAdjustReconstruction(opt, &rec);
     EXPECT(sj.success && !sj.preconditioner_substituted && sj.effective_preconditioner_type == ceres::SCHUR_JACOBI);
+    opt.preconditioner_type = ceres::JACOBI;
+    const BundleAdjustmentSummary sjj = BundleAdjustReconstruction(opt, &rec);
+    EXPECT(sjj.success && sjj.preconditioner_substituted && sjj.effective_preconditioner_type == ceres::SCHUR_JACOBI);
     std::printf("preconditioner report: CLUSTER_TRIDIAGONAL -> %d (substituted %d), SCHUR_JACOBI -> %d (substituted %d)\n",
                 (int)st.effective_preconditioner_type, (int)st.preconditioner_substituted, (int)sj.effective_preconditioner_type,
                 (int)sj.preconditioner_substituted);

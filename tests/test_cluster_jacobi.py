@@ -45,9 +45,12 @@ def test_oracle_cluster_jacobi_cuts_the_pcg_iterations():
     # both solve the same reduced systems to the same forcing tolerance: the trajectories agree to what that leaves
     assert abs(clu.final_cost - jac.final_cost) < 1e-4 * jac.final_cost
     assert clu.num_successful_steps == jac.num_successful_steps
-    # CLUSTER_TRIDIAGONAL is not restated: refused, not answered with another preconditioner
-    st, s = oracle.solve(prob.copy(), options(abi.PRECOND_CLUSTER_TRIDIAGONAL))
-    assert st == abi.ERR_UNSUPPORTED and s.success == 0
+    # CLUSTER_TRIDIAGONAL (round 6): the clusters plus the blocks between neighbours of the spanning forest -- at least
+    # as good a preconditioner on this problem, the same minimum
+    st, tri = oracle.solve(prob.copy(), options(abi.PRECOND_CLUSTER_TRIDIAGONAL))
+    assert st == 0 and tri.success == 1
+    assert tri.num_linear_solver_iterations <= clu.num_linear_solver_iterations + 2
+    assert abs(tri.final_cost - jac.final_cost) < 1e-4 * jac.final_cost and tri.num_successful_steps == jac.num_successful_steps
 
 
 def test_single_linkage_without_similar_views_is_the_merged_block_jacobi():
@@ -242,23 +245,201 @@ def test_device_visibility_clusters_with_the_matrix_free_operator_fall_back_to_b
 
 
 @pytest.mark.gpu
-def test_device_refuses_cluster_tridiagonal_and_a_changed_clustering_type():
-    """CLUSTER_TRIDIAGONAL is not implemented: create and solve say so instead of answering with CLUSTER_JACOBI; the
-    visibility clusters are built at create, a solve with another visibility_clustering_type is rejected"""
+def test_device_rejects_a_changed_clustering_type_and_the_other_cluster_preconditioner():
+    """the visibility clusters -- and for CLUSTER_TRIDIAGONAL the chains of clusters -- are built at create: a solve with
+    another visibility_clustering_type, or with the other one of the two cluster preconditioners, is rejected"""
     from theiasfm_amd import lib
     prob = synth.config("ladybug49")
-    with pytest.raises(lib.EngineError):
-        lib.Solver(prob, options(abi.PRECOND_CLUSTER_TRIDIAGONAL))
-    st, s = lib.solve(prob.copy(), options(abi.PRECOND_CLUSTER_TRIDIAGONAL))
-    assert st == abi.ERR_UNSUPPORTED and s.success == 0
     h = lib.Solver(prob, options(abi.PRECOND_CLUSTER_JACOBI))
     try:
         st, s = h.solve(options(abi.PRECOND_CLUSTER_JACOBI, visibility_clustering_type=abi.SINGLE_LINKAGE))
         assert st != 0 and b"visibility_clustering_type" in bytes(s.message)
         st, s = h.solve(options(abi.PRECOND_CLUSTER_TRIDIAGONAL))
-        assert st == abi.ERR_UNSUPPORTED
+        assert st == abi.ERR_INVALID_ARGUMENT and b"created for the other one" in bytes(s.message)
     finally:
         h.close()
+    h = lib.Solver(prob, options(abi.PRECOND_CLUSTER_TRIDIAGONAL))
+    try:
+        st, s = h.solve(options(abi.PRECOND_CLUSTER_JACOBI))
+        assert st == abi.ERR_INVALID_ARGUMENT
+        st, s = h.solve(options(abi.PRECOND_CLUSTER_TRIDIAGONAL, max_num_iterations=2))
+        assert st == 0 and s.effective_preconditioner_type == abi.PRECOND_CLUSTER_TRIDIAGONAL
+    finally:
+        h.close()
+
+
+# ---- CLUSTER_TRIDIAGONAL (cluster_chains.h; oracle: tridiagonal_segments) -----------------------------------------------
+def literal_tridiagonal_segments(prob, cluster_of_cam):
+    """Ceres 1.14's ComputeClusterTridiagonalSparsity on the clusters handed in, written from its sources as published
+    (visibility_based_preconditioner.cc: CreateClusterGraph -- edge weight = number of e-blocks both clusters see --,
+    graph_algorithms.h: Degree2MaximumSpanningForest -- pairs <weight, <v1, v2>> sorted with reverse iterators, an edge
+    is skipped when an end has degree 2 or the ends are connected) plus this repository's conventions: clusters numbered
+    by their lowest camera, paths walked from their lower-numbered end.  Returns {camera: (segment, position)}."""
+    cams = [c for c in range(prob.num_cameras) if cluster_of_cam[c] >= -1 and prob.camera_flags[c] != (abi.CAMERA_POSITION_CONSTANT | abi.CAMERA_ORIENTATION_CONSTANT)]
+    raw = {}
+    nxt = max([cluster_of_cam[c] for c in cams] + [-1]) + 1
+    for c in cams:
+        if cluster_of_cam[c] >= 0:
+            raw[c] = int(cluster_of_cam[c])
+        else:
+            raw[c] = nxt
+            nxt += 1
+    renum = {}
+    for c in cams:
+        renum.setdefault(raw[c], len(renum))
+    cl = {c: renum[raw[c]] for c in cams}
+    ncl = len(renum)
+    seen = [set() for _ in range(ncl)]
+    for cam, pt in zip(prob.obs_camera.tolist(), prob.obs_point.tolist()):
+        if cam in cl and not prob.point_constant[pt]:
+            seen[cl[cam]].add(pt)
+    edges = []
+    for a in range(ncl):
+        for b in range(a + 1, ncl):
+            w = len(seen[a] & seen[b])
+            if w > 0:
+                edges.append((float(w), (a, b)))
+    edges.sort(reverse=True)
+    deg = [0] * ncl
+    nb = [[] for _ in range(ncl)]
+    comp = list(range(ncl))
+
+    def find(a):
+        while comp[a] != a:
+            a = comp[a]
+        return a
+    for _, (a, b) in edges:
+        if deg[a] == 2 or deg[b] == 2 or find(a) == find(b):
+            continue
+        nb[a].append(b)
+        nb[b].append(a)
+        deg[a] += 1
+        deg[b] += 1
+        ra, rb = sorted((find(a), find(b)))
+        comp[rb] = ra
+    out, visited, seg = {}, [False] * ncl, 0
+    for c0 in range(ncl):
+        if visited[c0] or deg[c0] == 2:
+            continue
+        path, prev, cur = [], -1, c0
+        while cur >= 0:
+            visited[cur] = True
+            path.append(cur)
+            nx = [x for x in nb[cur] if x != prev]
+            prev, cur = cur, (nx[0] if nx else -1)
+        members = [(c, q) for q, k in enumerate(path) for c in cams if cl[c] == k]
+        if len(members) >= 2:
+            for c, q in members:
+                out[c] = (seg, q)
+            seg += 1
+    return out
+
+
+@pytest.mark.parametrize("name", ["ladybug49", "ring150", "constant_blocks"])
+def test_oracle_tridiagonal_segments_are_the_literal_algorithm(name):
+    if name == "ladybug49":
+        prob = synth.config("ladybug49")
+    elif name == "ring150":
+        prob = synth.make_problem(150, 6000, 30000, seed=29, scene="ring", spread=0.15)
+    else:
+        prob = synth.make_problem(20, 1500, 7000, seed=23, scene="ring", spread=0.6)
+        prob.camera_flags[3] = abi.CAMERA_POSITION_CONSTANT | abi.CAMERA_ORIENTATION_CONSTANT
+        prob.set_intrinsics_to_optimize(abi.INTRINSICS_NONE)
+        prob.point_constant[::4] = 1
+    st, s = oracle.solve(prob.copy(), options(abi.PRECOND_CLUSTER_TRIDIAGONAL, max_num_iterations=1))
+    assert st == 0 and s.success == 1
+    clusters = oracle.last_visibility_clusters(prob.num_cameras)
+    seg, pos = oracle.last_tridiagonal_segments(prob.num_cameras)
+    want = literal_tridiagonal_segments(prob, clusters)
+    got = {c: (int(seg[c]), int(pos[c])) for c in range(prob.num_cameras) if seg[c] >= 0}
+    assert got == want
+    n_clusters = len(set(int(x) for x in clusters if x >= 0))
+    assert n_clusters >= 3 and max(p for _, p in want.values()) >= 1  # a chain of several clusters exists
+
+
+def test_oracle_tridiagonal_of_two_clusters_is_the_exact_inverse():
+    """two shared intrinsics groups that hold every view: the chain of the two clusters with the blocks between them is S
+    itself, so the preconditioned system is the identity and conjugate gradients stops at its second iteration"""
+    prob = shared_problem(n_views=20, groups=(10, 10), seed=11, per_view=400)
+    assert len(set(prob.camera_group.tolist())) == 2
+    st, s = oracle.solve(prob.copy(), options(abi.PRECOND_CLUSTER_TRIDIAGONAL, max_num_iterations=5))
+    assert st == 0 and s.success == 1
+    assert s.num_linear_solver_iterations <= 2 * s.num_iterations
+    st, j = oracle.solve(prob.copy(), options(abi.PRECOND_CLUSTER_JACOBI, max_num_iterations=5))
+    assert st == 0 and j.num_linear_solver_iterations > s.num_linear_solver_iterations
+    assert abs(s.final_cost - j.final_cost) < 1e-4 * j.final_cost
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["ladybug49", "ring150_huber_dof4", "shared_mixed_sizes", "shared_two_groups", "auto_mode"])
+def test_device_cluster_tridiagonal_matches_oracle(case):
+    from theiasfm_amd import lib
+    kw = dict(function_tolerance=1e-6, gradient_tolerance=1e-10, parameter_tolerance=1e-8, max_num_iterations=10)
+    if case == "ladybug49":
+        prob = synth.config("ladybug49")
+    elif case == "ring150_huber_dof4":
+        prob = synth.make_problem(150, 24000, 130000, seed=29, scene="ring", spread=0.3)
+        kw.update(loss_function_type=abi.LOSS_HUBER, robust_loss_width=3.0, point_dof=4)
+    elif case == "shared_mixed_sizes":
+        prob = shared_problem()
+    elif case == "shared_two_groups":
+        prob = shared_problem(n_views=20, groups=(10, 10), seed=11, per_view=400)
+    else:
+        prob = shared_problem(n_views=40, groups=(2, 9), seed=3)
+        kw.update(schur_mode=abi.SCHUR_AUTO)  # auto must form S: the chains need the blocks between clusters
+    a, b = prob.copy(), prob.copy()
+    st_d, s_d = lib.solve(a, options(abi.PRECOND_CLUSTER_TRIDIAGONAL, **kw))
+    st_o, s_o = oracle.solve(b, options(abi.PRECOND_CLUSTER_TRIDIAGONAL, **kw))
+    assert st_d == st_o == 0 and s_d.success == s_o.success == 1
+    assert s_d.effective_preconditioner_type == abi.PRECOND_CLUSTER_TRIDIAGONAL
+    assert s_d.num_iterations == s_o.num_iterations and s_d.num_successful_steps == s_o.num_successful_steps
+    assert s_d.num_linear_solver_iterations == s_o.num_linear_solver_iterations
+    assert abs(s_d.final_cost - s_o.final_cost) <= 1e-9 * s_o.final_cost
+    if case == "shared_two_groups":
+        assert s_d.num_linear_solver_iterations <= 2 * s_d.num_iterations
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", ["retry", "failure"])
+def test_device_cluster_tridiagonal_retry_and_failure_follow_the_oracle(path, monkeypatch):
+    """Dropping the blocks between distant clusters can cost positive definiteness; Ceres then halves the off-diagonal
+    cluster-pair cells and factors again, and a second failure fails the linear solve (the LM step is invalid).  The two
+    attempts' factors are test hooks on both sides: 8 x the off-diagonal cells makes the chain matrix indefinite."""
+    from theiasfm_amd import lib
+    prob = shared_problem(n_views=40, groups=(2, 9), seed=3)
+    kw = dict(max_num_iterations=6)
+    ref = oracle.solve(prob.copy(), options(abi.PRECOND_CLUSTER_TRIDIAGONAL, **kw))[1]
+    monkeypatch.setenv("TMI_BA_TEST_TRI_SCALE0", "8.0")
+    if path == "failure":
+        monkeypatch.setenv("TMI_BA_TEST_TRI_SCALE1", "8.0")
+    st_o, s_o = oracle.solve(prob.copy(), options(abi.PRECOND_CLUSTER_TRIDIAGONAL, **kw))
+    st_d, s_d = lib.solve(prob.copy(), options(abi.PRECOND_CLUSTER_TRIDIAGONAL, **kw))
+    assert s_d.num_iterations == s_o.num_iterations and s_d.num_successful_steps == s_o.num_successful_steps
+    assert s_d.num_linear_solver_iterations == s_o.num_linear_solver_iterations
+    if path == "retry":
+        # the halved cells are a different (weaker) preconditioner than the unscaled ones: same minimum, another count
+        assert st_d == st_o == 0 and s_d.success == s_o.success == 1
+        assert abs(s_d.final_cost - s_o.final_cost) <= 1e-9 * s_o.final_cost
+        assert s_o.num_linear_solver_iterations != ref.num_linear_solver_iterations
+    else:
+        # every linear solve fails: five invalid steps in a row end the solve (Ceres: max_num_consecutive_invalid_steps)
+        assert s_d.success == s_o.success == 0 and s_d.num_successful_steps == 0 and s_d.num_linear_solver_iterations == 0
+        assert abs(s_d.final_cost - s_d.initial_cost) <= 1e-12 * s_d.initial_cost  # nothing moved
+        assert abs(s_o.final_cost - s_o.initial_cost) <= 1e-12 * s_o.initial_cost
+        assert abs(s_d.final_cost - s_o.final_cost) <= 1e-12 * s_o.final_cost
+
+
+@pytest.mark.gpu
+def test_device_cluster_tridiagonal_without_the_formed_S_keeps_block_jacobi():
+    """schur_mode implicit (and several ranks): no blocks between clusters to take -- the SCHUR_JACOBI blocks, and the
+    summary says so"""
+    from theiasfm_amd import lib
+    prob = synth.config("ladybug49")
+    kw = dict(max_num_iterations=6, schur_mode=abi.SCHUR_IMPLICIT)
+    st_t, s_t = lib.solve(prob.copy(), options(abi.PRECOND_CLUSTER_TRIDIAGONAL, **kw))
+    st_j, s_j = lib.solve(prob.copy(), options(abi.PRECOND_SCHUR_JACOBI, **kw))
+    assert st_t == st_j == 0 and s_t.effective_preconditioner_type == abi.PRECOND_SCHUR_JACOBI
+    assert s_t.num_linear_solver_iterations == s_j.num_linear_solver_iterations and s_t.final_cost == s_j.final_cost
 
 
 @pytest.mark.gpu

@@ -25,7 +25,7 @@ LOSS_TRIVIAL, LOSS_HUBER, LOSS_SOFTLONE, LOSS_CAUCHY, LOSS_ARCTAN, LOSS_TUKEY = 
 
 DENSE_QR, DENSE_SCHUR, SPARSE_SCHUR, ITERATIVE_SCHUR, CGNR = 1, 3, 4, 5, 6
 PRECOND_IDENTITY, PRECOND_JACOBI, PRECOND_SCHUR_JACOBI = 0, 1, 2
-PRECOND_CLUSTER_JACOBI, PRECOND_CLUSTER_TRIDIAGONAL = 3, 4  # clusters = shared intrinsics block + its views; TRIDIAGONAL: refused (ERR_UNSUPPORTED)
+PRECOND_CLUSTER_JACOBI, PRECOND_CLUSTER_TRIDIAGONAL = 3, 4  # clusters = shared intrinsics block + its views (or visibility clusters); TRIDIAGONAL: + the blocks between neighbours of the degree-2 spanning forest
 PRECOND_SCHUR_JACOBI_PARAMETER_BLOCKS = 18  # Ceres's own block shape (6x6 + NxN per view)
 SCHUR_AUTO, SCHUR_EXPLICIT, SCHUR_IMPLICIT = 0, 1, 2
 CANONICAL_VIEWS, SINGLE_LINKAGE = 0, 1  # ceres::VisibilityClusteringType
@@ -51,6 +51,7 @@ KERNEL_CLASS_NAMES = (
     "allreduce",
 )
 
+ERR_INVALID_ARGUMENT = 1
 ERR_UNSUPPORTED = 5
 
 STATUS_NAMES = {

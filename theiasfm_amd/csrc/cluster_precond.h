@@ -46,6 +46,9 @@ struct GatherEntry {
   int i0, j0;        // local offsets (row block a >= column block b)
   int ni, nj;        // true dimensions
   int src;           // >= 0: upper block of S (stored as its transpose); < 0: diagonal block -1 - rb
+  int offdiag;       // CLUSTER_TRIDIAGONAL: the block couples two NEIGHBOURING clusters of a chain (scaled by off_scale)
+  int tr;            // the upper block is S(row part, column part) itself (the row member is the LOWER reduced block:
+                     // only in the chains of CLUSTER_TRIDIAGONAL, whose members are not ascending)
 };
 
 template <int D>
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(256) void cluster_gather_kernel(const GatherEntry* 
                                                              const ClusterDesc* __restrict__ desc,
                                                              const double* __restrict__ ub,
                                                              const double* __restrict__ Sdiag,
-                                                             double* __restrict__ tiles) {
+                                                             double* __restrict__ tiles, double off_scale) {
   const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (e >= n_entries) return;
   const GatherEntry g = ge[e];
@@ -63,7 +66,9 @@ __global__ __launch_bounds__(256) void cluster_gather_kernel(const GatherEntry* 
     const int i = w / g.nj, j = w - i * g.nj;
     double val;
     if (g.src >= 0) {
-      val = ub[(size_t)g.src * D * D + j * D + i];  // the upper block holds S(column part, row part)
+      val = g.tr ? ub[(size_t)g.src * D * D + i * D + j]
+                 : ub[(size_t)g.src * D * D + j * D + i];  // the upper block holds S(column part, row part)
+      if (g.offdiag) val *= off_scale;
     } else {
       if (j > i) continue;
       val = Sdiag[(size_t)(-1 - g.src) * D * D + i * D + j];
@@ -289,9 +294,11 @@ struct Plan {
 
 // members[c] = the reduced blocks of cluster c in ascending order (views, then the shared block); rb_dim = true
 // dimensions; ub_lookup(bi, bj) = index of the upper block (bi < bj) or -1
+// ordinal (CLUSTER_TRIDIAGONAL, cluster_chains.h): position of every member's cluster in its chain -- only the blocks
+// inside a cluster and between neighbouring clusters are gathered, everything else of the chain's matrix stays zero
 template <class Lookup>
 inline Plan make_plan(const std::vector<std::vector<int> >& members, const std::vector<int>& rb_dim, int D,
-                      Lookup ub_lookup, int num_cus) {
+                      Lookup ub_lookup, int num_cus, const std::vector<std::vector<int> >* ordinal = nullptr) {
   Plan p;
   p.ncl = (int)members.size();
   p.desc.resize(p.ncl);
@@ -331,10 +338,21 @@ inline Plan make_plan(const std::vector<std::vector<int> >& members, const std::
         g.ni = rb_dim[members[c][a]];
         g.nj = rb_dim[members[c][b]];
         if (g.ni == 0 || g.nj == 0) continue;
+        g.offdiag = 0;
+        if (ordinal) {
+          const int dord = (*ordinal)[c][a] - (*ordinal)[c][b];
+          if (dord < -1 || dord > 1) continue;
+          g.offdiag = dord != 0 ? 1 : 0;
+        }
+        g.tr = 0;
         if (a == b) {
           g.src = -1 - members[c][a];
-        } else {
+        } else if (members[c][b] < members[c][a]) {
           g.src = ub_lookup(members[c][b], members[c][a]);
+          if (g.src < 0) continue;
+        } else {
+          g.src = ub_lookup(members[c][a], members[c][b]);
+          g.tr = 1;
           if (g.src < 0) continue;
         }
         p.entries.push_back(g);

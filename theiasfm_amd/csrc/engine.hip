@@ -25,6 +25,7 @@
 #include "../../include/theia_mi355_ba.h"
 #include "dense_cholesky.h"
 #include "dense_cholesky_df.h"
+#include "cluster_chains.h"
 #include "cluster_precond.h"
 #include "kernels.h"
 #include "mf_chunks.h"
@@ -75,7 +76,7 @@ struct Launch {
   void (*expand_scale)(const DeviceView&, hipStream_t);
   void (*expand)(const DeviceView&, hipStream_t, RedLayout, double, double, double, int want_gmax);
   void (*precond)(const DeviceView&, hipStream_t, int);
-  void (*cluster_gather)(hipStream_t, const clp::GatherEntry*, int, const clp::ClusterDesc*, const double*, const double*, double*);
+  void (*cluster_gather)(hipStream_t, const clp::GatherEntry*, int, const clp::ClusterDesc*, const double*, const double*, double*, double);
   void (*cluster_rz)(const DeviceView&, hipStream_t, int, double*);
   // dot: the product kernel also leaves x . y at y[Nrb D]
   void (*spmv)(const DeviceView&, hipStream_t, const double*, const double*, double*, int dot);
@@ -179,8 +180,8 @@ Launch make_launch(bool fp32) {
                          lo, hi, want_gmax);
   };
   L.cluster_gather = [](hipStream_t st, const clp::GatherEntry* ge, int n, const clp::ClusterDesc* desc, const double* ub,
-                        const double* Sdiag, double* tiles) {
-    if (n) hipLaunchKernelGGL((clp::cluster_gather_kernel<D>), dim3((n + 3) / 4), dim3(256), 0, st, ge, n, desc, ub, Sdiag, tiles);
+                        const double* Sdiag, double* tiles, double off_scale) {
+    if (n) hipLaunchKernelGGL((clp::cluster_gather_kernel<D>), dim3((n + 3) / 4), dim3(256), 0, st, ge, n, desc, ub, Sdiag, tiles, off_scale);
   };
   L.cluster_rz = [](const DeviceView& v, hipStream_t st, int nb, double* partial) {
     hipLaunchKernelGGL((clp::cluster_rz_kernel<D>), dim3(nb), dim3(256), 0, st, v, nb, partial);
@@ -421,6 +422,12 @@ struct tmi_ba_solver {
   int vis_type = 0;           // visibility_clustering_type the clusters were built with (create)
   bool vis_clusters = false;  // no shared intrinsics blocks: the clusters are Ceres' visibility clusters of the views
   std::vector<std::vector<int> > vis_members;  // ... their reduced blocks, ascending (build_visibility_clusters)
+  std::vector<int> vis_cluster_of_rb;          // ... and the cluster of every reduced block (-1: none), singletons included
+  // CLUSTER_TRIDIAGONAL (cluster_chains.h): the handle's "clusters" are chains of clusters with the blocks of S between
+  // neighbours; built at create, factored with a retry (off-diagonal cells halved) as Ceres does
+  bool tri = false;
+  chains::Segments tri_seg;
+  bool cl_failed = false;  // the last factorisation of a tridiagonal handle failed twice: the linear solve fails
   bool cl_active = false;     // the current LM iteration's PCG applies it
   // persistent PCG on the formed S (pcg_persist.h): buffers made on first use; off after an aborted launch
   bool ppcg_ready = false, ppcg_off = false;
@@ -1742,6 +1749,7 @@ static int build_visibility_clusters(tmi_ba_solver* s, const tmi_ba_problem* P, 
     }
     if (ncl == 0) ncl = 1;
   }
+  s->vis_cluster_of_rb = cluster;
   std::vector<std::vector<int> > members((size_t)ncl);
   for (int i = 0; i < Nrb; ++i)
     if (cluster[i] >= 0) members[cluster[i]].push_back(i);  // ascending
@@ -1791,12 +1799,6 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   s->DP = O->point_dof;
   const bool iterative_type =
       (O->linear_solver_type == TMI_BA_ITERATIVE_SCHUR || O->linear_solver_type == TMI_BA_CGNR);
-  if (iterative_type && !light && O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_TRIDIAGONAL) {
-    // Ceres' tridiagonal variant keeps the blocks between neighbouring clusters of a degree-2 spanning forest
-    // (visibility_based_preconditioner.cc); not rebuilt, and not answered with a different preconditioner either
-    s->error = "CLUSTER_TRIDIAGONAL is not implemented on the device path (nearest: CLUSTER_JACOBI)";
-    return TMI_BA_ERR_UNSUPPORTED;
-  }
   if (O->schur_mode < 0 || O->schur_mode > 2) {
     s->error = "schur_mode must be 0 (auto), 1 (explicit) or 2 (implicit)";
     return TMI_BA_ERR_INVALID_ARGUMENT;
@@ -1819,8 +1821,18 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   // CLUSTER_JACOBI on a problem with shared intrinsics blocks (cluster_precond.h): with schur_mode auto the operator is
   // the matrix-free one and only the blocks INSIDE the clusters are formed (what the preconditioner factors); an
   // explicit request for the formed / the matrix-free operator is honoured, the latter with the cluster blocks as well
-  const bool cluster_pre = O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_JACOBI;
-  if (cluster_pre && s->st.has_shared && iterative_type && !light) {
+  // CLUSTER_TRIDIAGONAL (cluster_chains.h) also needs the blocks BETWEEN neighbouring clusters: the formed S, on one
+  // rank (the cluster graph counts tracks globally).  With schur_mode implicit or on several ranks the handle keeps its
+  // SCHUR_JACOBI blocks, like CLUSTER_JACOBI without shared blocks (tmi_ba_summary::effective_preconditioner_type).
+  const bool tri_pre = O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_TRIDIAGONAL && iterative_type && !light;
+  s->tri = tri_pre && world == 1 && O->schur_mode != 2;
+  const bool cluster_pre = O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_JACOBI || s->tri;
+  if (s->tri && s->st.has_shared) {
+    s->implicit = s->implicit_now = false;
+    s->adaptive = false;
+    s->cluster_blocks = false;
+    want_pairs = true;
+  } else if (cluster_pre && s->st.has_shared && iterative_type && !light) {
     if (O->schur_mode == 0) s->implicit = s->implicit_now = true;
     s->cluster_blocks = s->implicit;
     want_pairs = !s->implicit;
@@ -2153,6 +2165,33 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   }
   if (setup_timing) fprintf(stderr, "[tmi_ba setup] camera side of matrix-free iterations: %s\n", s->direct_ok ? "view by view from the track records (no camera-major records)" : "camera-major records");
   if (s->vis_clusters && (rc = build_visibility_clusters(s, P, O->visibility_clustering_type))) return rc;
+  if (s->tri) {
+    // base clusters: the ones CLUSTER_JACOBI would use on this problem; everything else is a cluster of its own
+    std::vector<int> cl_of((size_t)st.Nrb, -1);
+    if (st.has_shared) {
+      for (int g = 0; g < st.Nrb - st.Ncam_rb; ++g) {
+        for (int k = st.grp_cam_ptr[g]; k < st.grp_cam_ptr[g + 1]; ++k) {
+          const int rb = st.cam_rb[st.grp_cams[k]];
+          if (rb >= 0) cl_of[rb] = g;
+        }
+        cl_of[st.Ncam_rb + g] = g;
+      }
+    } else {
+      cl_of = s->vis_cluster_of_rb;
+      cl_of.resize((size_t)st.Nrb, -1);
+    }
+    s->tri_seg = chains::build(cl_of, st.rb_dim, P->num_observations, P->obs_camera, st.cam_rb, P->obs_point, P->num_points,
+                               P->point_constant, TMI_BA_MAX_CLUSTER_DIM);
+    if (setup_timing) {
+      size_t big = 0, most = 0;
+      for (size_t c = 0; c < s->tri_seg.members.size(); ++c) {
+        big = std::max(big, s->tri_seg.members[c].size());
+        most = std::max<size_t>(most, (size_t)s->tri_seg.ordinal[c].back() + 1);
+      }
+      fprintf(stderr, "[tmi_ba setup] CLUSTER_TRIDIAGONAL: %zu segments, the largest %zu reduced blocks, the longest %zu clusters\n",
+              s->tri_seg.members.size(), big, most);
+    }
+  }
   if (s->need_slot_track && !s->mf_ok) {
     int* stt;
     if ((rc = dev_alloc(s, &stt, (size_t)std::max<int64_t>(st.Nslots, 1)))) return rc;
@@ -2426,8 +2465,8 @@ static int ensure_clusters(tmi_ba_solver* s) {
     TMI_HIP(hipGetDeviceProperties(&prop, s->device));
     s->num_cus = prop.multiProcessorCount;
   }
-  std::vector<std::vector<int> > members = s->vis_members;  // (empty unless vis_clusters)
-  for (int g = 0; g < st.Nrb - st.Ncam_rb && !s->vis_clusters; ++g) {
+  std::vector<std::vector<int> > members = s->tri ? s->tri_seg.members : s->vis_members;  // (empty unless vis_clusters / tri)
+  for (int g = 0; g < st.Nrb - st.Ncam_rb && !s->vis_clusters && !s->tri; ++g) {
     std::vector<int> m;
     for (int k = st.grp_cam_ptr[g]; k < st.grp_cam_ptr[g + 1]; ++k) m.push_back(st.cam_rb[st.grp_cams[k]]);
     std::sort(m.begin(), m.end());
@@ -2449,7 +2488,8 @@ static int ensure_clusters(tmi_ba_solver* s) {
     const int* it = std::lower_bound(b, e, bj);
     return (it != e && *it == bj) ? (int)(it - st.ub_j.data()) : -1;
   };
-  s->cl_plan = clp::make_plan(members, st.rb_dim, st.D, lookup, s->num_cus);
+  // (tridiagonal: only the blocks inside a cluster and between neighbours of the chain are gathered, the latter marked)
+  s->cl_plan = clp::make_plan(members, st.rb_dim, st.D, lookup, s->num_cus, s->tri ? &s->tri_seg.ordinal : nullptr);
   const clp::Plan& p = s->cl_plan;
   int rc;
   if ((rc = dev_upload(s, &s->d_cl_desc, p.desc))) return rc;
@@ -2473,18 +2513,39 @@ static int factor_clusters(tmi_ba_solver* s) {
   const clp::Plan& p = s->cl_plan;
   if (p.ncl == 0) return TMI_BA_OK;
   DeviceView& v = s->v;
-  TMI_HIP(hipMemsetAsync(s->d_cl_tiles, 0, (size_t)p.n_tiles * cdf::TILE * sizeof(double), s->stream));
-  TMI_HIP(hipMemsetAsync(s->d_cl_bad, 0, (size_t)p.ncl * sizeof(int), s->stream));
-  s->launch.cluster_gather(s->stream, s->d_cl_ge, (int)p.entries.size(), s->d_cl_desc, v.red + s->RL.ub, v.Sdiag, s->d_cl_tiles);
-  if (s->cl_epoch >= 0x7ffffff0) {  // flags compare against the epoch: start over long before it wraps (as df_epoch)
-    TMI_HIP(hipMemsetAsync(s->d_cl_flags, 0, (size_t)std::max(p.n_flags, 1) * sizeof(int), s->stream));
-    s->cl_epoch = 0;
+  s->cl_failed = false;
+  // CLUSTER_TRIDIAGONAL: a chain's matrix lacks the blocks between clusters that are not neighbours, which can cost
+  // positive definiteness.  Ceres (VisibilityBasedPreconditioner::UpdateImpl) then halves every off-diagonal
+  // cluster-pair cell and factors once more; a second failure fails the preconditioner update and the linear solve.
+  for (int attempt = 0; attempt < (s->tri ? 2 : 1); ++attempt) {
+    TMI_HIP(hipMemsetAsync(s->d_cl_tiles, 0, (size_t)p.n_tiles * cdf::TILE * sizeof(double), s->stream));
+    TMI_HIP(hipMemsetAsync(s->d_cl_bad, 0, (size_t)p.ncl * sizeof(int), s->stream));
+    // (test hooks, read by the oracle as well: TMI_BA_TEST_TRI_SCALE0 / _SCALE1 replace the factors 1 and 1/2 of the two
+    // attempts, so that tests/test_cluster_jacobi.py can drive the retry and the failure path on both sides)
+    double off_scale = attempt ? 0.5 : 1.0;
+    if (const char* e = getenv(attempt ? "TMI_BA_TEST_TRI_SCALE1" : "TMI_BA_TEST_TRI_SCALE0")) off_scale = atof(e);
+    s->launch.cluster_gather(s->stream, s->d_cl_ge, (int)p.entries.size(), s->d_cl_desc, v.red + s->RL.ub, v.Sdiag, s->d_cl_tiles,
+                             off_scale);
+    if (s->cl_epoch >= 0x7ffffff0) {  // flags compare against the epoch: start over long before it wraps (as df_epoch)
+      TMI_HIP(hipMemsetAsync(s->d_cl_flags, 0, (size_t)std::max(p.n_flags, 1) * sizeof(int), s->stream));
+      s->cl_epoch = 0;
+    }
+    const int epoch = ++s->cl_epoch;
+    rc = launch_coresident(s, p.grid, [&] {
+      hipLaunchKernelGGL(clp::cluster_factor_kernel, dim3(p.grid), dim3(256), 0, s->stream, s->d_cl_desc, p.ncl, s->d_cl_tiles,
+                         s->d_cl_linv, s->d_cl_flags, epoch, v.flags + FL_CHOL_ABORT, s->d_cl_bad);
+    });
+    if (rc || !s->tri) return rc;
+    // (one small read-back per LM iteration: the retry is a host decision, as in Ceres)
+    std::vector<int> bad((size_t)p.ncl);
+    TMI_HIP(hipMemcpyAsync(bad.data(), s->d_cl_bad, (size_t)p.ncl * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    TMI_HIP(hipStreamSynchronize(s->stream));
+    bool any = false;
+    for (const int b : bad) any = any || b != 0;
+    if (!any) return TMI_BA_OK;
   }
-  const int epoch = ++s->cl_epoch;
-  return launch_coresident(s, p.grid, [&] {
-    hipLaunchKernelGGL(clp::cluster_factor_kernel, dim3(p.grid), dim3(256), 0, s->stream, s->d_cl_desc, p.ncl, s->d_cl_tiles,
-                       s->d_cl_linv, s->d_cl_flags, epoch, v.flags + FL_CHOL_ABORT, s->d_cl_bad);
-  });
+  s->cl_failed = true;  // "Preconditioner update failed.": LINEAR_SOLVER_FAILURE, the step is invalid
+  return TMI_BA_OK;
 }
 
 // z <- C^-1 r on the clustered entries (the others keep their block-Jacobi values)
@@ -3027,11 +3088,15 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
   const double lw = O->robust_loss_width;
   const bool iterative = (O->linear_solver_type == TMI_BA_ITERATIVE_SCHUR || O->linear_solver_type == TMI_BA_CGNR);
   s->cur_opts = O;
-  if (iterative && O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_TRIDIAGONAL) {
-    s->error = "CLUSTER_TRIDIAGONAL is not implemented on the device path (nearest: CLUSTER_JACOBI)";
-    return fail(TMI_BA_ERR_UNSUPPORTED);
+  if (iterative && (s->st.has_shared || s->vis_clusters) &&
+      ((s->tri && O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_JACOBI) ||
+       (!s->tri && O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_TRIDIAGONAL && st.world == 1 && !s->implicit))) {
+    // the clusters (CLUSTER_JACOBI) or chains of clusters (CLUSTER_TRIDIAGONAL) are part of the handle's structure
+    s->error = "CLUSTER_JACOBI / CLUSTER_TRIDIAGONAL: the solver was created for the other one";
+    return fail(TMI_BA_ERR_INVALID_ARGUMENT);
   }
-  if (iterative && s->vis_clusters && O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_JACOBI &&
+  if (iterative && s->vis_clusters &&
+      (O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_JACOBI || O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_TRIDIAGONAL) &&
       O->visibility_clustering_type != s->vis_type) {
     // the clusters are part of the handle's structure (built at create from visibility_clustering_type)
     s->error = "visibility_clustering_type differs from the value the solver was created with";
@@ -3220,7 +3285,8 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
                           : O->preconditioner_type == TMI_BA_PRECOND_SCHUR_JACOBI_PARAMETER_BLOCKS ? 2 : 0);
         // CLUSTER_JACOBI / CLUSTER_TRIDIAGONAL on a problem with shared intrinsics blocks: the exact inverse of every
         // {shared block, its views} cluster (needs the cluster's blocks of S: the formed operator)
-        s->cl_active = O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_JACOBI &&
+        s->cl_active = (s->tri ? O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_TRIDIAGONAL
+                               : O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_JACOBI) &&
                        (s->st.has_shared || s->vis_clusters) && (!s->implicit_now || s->cluster_blocks) && n_r > 0 &&
                        !s->cl_retired && !s->cl_unavailable;
         if (s->cl_active) {
@@ -3238,12 +3304,16 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
         }
       }
       const int64_t before = pcg_iters;
-      CK(solve_reduced_pcg(s, O, &usable, &pcg_iters));
+      if (s->cl_active && s->cl_failed) {
+        usable = 0;  // the tridiagonal preconditioner could not be factored, scaled or not: the linear solve fails (Ceres)
+      } else {
+        CK(solve_reduced_pcg(s, O, &usable, &pcg_iters));
+      }
       last_pcg_len = (int)(pcg_iters - before);
       // what this iteration's PCG ran with (tmi_ba_summary::effective_preconditioner_type): the clusters only while
       // they are active (cl_active is cleared when a cluster launch retires them mid-solve), JACOBI as SCHUR_JACOBI
       sum->effective_preconditioner_type =
-          s->cl_active ? TMI_BA_PRECOND_CLUSTER_JACOBI
+          s->cl_active ? (s->tri ? TMI_BA_PRECOND_CLUSTER_TRIDIAGONAL : TMI_BA_PRECOND_CLUSTER_JACOBI)
           : O->preconditioner_type == TMI_BA_PRECOND_IDENTITY ? TMI_BA_PRECOND_IDENTITY
           : O->preconditioner_type == TMI_BA_PRECOND_SCHUR_JACOBI_PARAMETER_BLOCKS ? TMI_BA_PRECOND_SCHUR_JACOBI_PARAMETER_BLOCKS
                                                                                     : TMI_BA_PRECOND_SCHUR_JACOBI;

@@ -609,17 +609,9 @@ void ToDeviceOptions(const BundleAdjustmentOptions& options, tmi_ba_options* o) 
   o->linear_solver_type = ToAbiSolver(options.linear_solver_type);
   // ceres::SCHUR_JACOBI (and JACOBI, which the device path maps onto it) -> Ceres' own block shape, one block per
   // parameter block; the merged per-view block only on request (bundle_adjustment.h, extensions).  CLUSTER_JACOBI /
-  // CLUSTER_TRIDIAGONAL go through: clusters = the shared intrinsics blocks with their views (theia_mi355_ba.h).
+  // CLUSTER_TRIDIAGONAL go through (theia_mi355_ba.h: clusters = the shared intrinsics blocks with their views, or the
+  // visibility clusters; the tridiagonal variant adds the blocks between neighbours of the degree-2 spanning forest).
   o->preconditioner_type = static_cast<int32_t>(options.preconditioner_type);
-  if (options.preconditioner_type == ceres::CLUSTER_TRIDIAGONAL) {
-    // the C ABI refuses CLUSTER_TRIDIAGONAL (not implemented); a Theia caller gets the nearest preconditioner, is told
-    // once per process (the reference would LOG(WARNING)) and finds the substitution in every summary
-    // (BundleAdjustmentSummary::preconditioner_substituted / effective_preconditioner_type, FillPreconditionerReport)
-    static std::atomic<bool> warned(false);
-    if (!warned.exchange(true))
-      std::fprintf(stderr, "[tmi_ba shim] ceres::CLUSTER_TRIDIAGONAL is not implemented on the device path: using CLUSTER_JACOBI\n");
-    o->preconditioner_type = TMI_BA_PRECOND_CLUSTER_JACOBI;
-  }
   if ((options.preconditioner_type == ceres::SCHUR_JACOBI || options.preconditioner_type == ceres::JACOBI) &&
       !options.merged_view_blocks_in_preconditioner)
     o->preconditioner_type = TMI_BA_PRECOND_SCHUR_JACOBI_PARAMETER_BLOCKS;
@@ -642,13 +634,13 @@ void FillPreconditionerReport(const BundleAdjustmentOptions& options, const tmi_
   const bool iterative = options.linear_solver_type == ceres::ITERATIVE_SCHUR || options.linear_solver_type == ceres::CGNR;
   if (!iterative || device.num_linear_solver_iterations == 0) {
     summary->effective_preconditioner_type = iterative ? options.preconditioner_type : ceres::IDENTITY;
-    summary->preconditioner_substituted = iterative && options.preconditioner_type == ceres::CLUSTER_TRIDIAGONAL;
-    if (summary->preconditioner_substituted) summary->effective_preconditioner_type = ceres::CLUSTER_JACOBI;
+    summary->preconditioner_substituted = false;
     return;
   }
   switch (device.effective_preconditioner_type) {
     case TMI_BA_PRECOND_IDENTITY: summary->effective_preconditioner_type = ceres::IDENTITY; break;
     case TMI_BA_PRECOND_CLUSTER_JACOBI: summary->effective_preconditioner_type = ceres::CLUSTER_JACOBI; break;
+    case TMI_BA_PRECOND_CLUSTER_TRIDIAGONAL: summary->effective_preconditioner_type = ceres::CLUSTER_TRIDIAGONAL; break;
     default: summary->effective_preconditioner_type = ceres::SCHUR_JACOBI; break;  // either block shape
   }
   summary->preconditioner_substituted = summary->effective_preconditioner_type != options.preconditioner_type;
