@@ -26,6 +26,10 @@ namespace tmi {
 // SpMV rows pass: a wave streams kSpmvTrips trips of 64 / D upper blocks (its chunk);
 // shared by the host work list (structure.cpp) and the kernel (kernels.h)
 constexpr int kSpmvTrips = 8;
+// free columns of [extrinsics (bits 0-5) | intrinsics in model order (bits 6-15)] for a PINHOLE view under the reference's
+// default intrinsics_to_optimize = FOCAL_LENGTH | RADIAL_DISTORTION (bundle_adjustment.h:95; pinhole_camera_model.h:86-94:
+// f = intrinsic 0, k1 = 5, k2 = 6): what BAL problems and an unchanged Theia caller have for every view
+constexpr unsigned kPinholeDefaultMask = 0x3Fu | (1u << 6) | (1u << 11) | (1u << 12);
 // per-track kernels: slices whose longest track has at least this many observations are run
 // with 16 lanes per track (kernels.h, track_map); the larger value applies when a rank holds
 // >= 5000 slices (structure.cpp)
@@ -68,6 +72,7 @@ struct DeviceView {
                           //   (matrix-free product without shared blocks; null otherwise)
   const int* cam_grp;
   const int4* cam_rec;         // [Nc] {camera model, intrinsics offset, #intrinsics, free-column mask}
+  int uniform_pinhole_default; // every camera: PINHOLE, free columns = extrinsics + f + k1 + k2 (kPinholeDefaultMask)
   const int* cam_rb;
   const unsigned* cam_mask;
   const int* grp_model;

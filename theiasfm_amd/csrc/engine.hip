@@ -113,6 +113,15 @@ Launch make_launch(bool fp32) {
     };
   } else {
     L.linearize = [](const DeviceView& v, hipStream_t st, const double* prep, int lt, double lw, int nb, double* sums) {
+      if constexpr (!SH && D == 9) {
+        // every camera a PINHOLE with extrinsics + focal length + two radial terms free (the BAL / reference default,
+        // bundle_adjustment.h:95) and no robust loss: the specialised body (kernels.h, UMODEL / UMASK)
+        if (v.uniform_pinhole_default && lt == 0) {
+          hipLaunchKernelGGL((linearize_kernel<D, DP, SH, double, 2, double, 0, kPinholeDefaultMask>), dim3(nb), dim3(256), 0, st, v, prep,
+                             lt, lw, nb, sums);
+          return;
+        }
+      }
       hipLaunchKernelGGL((linearize_kernel<D, DP, SH, double, 2>), dim3(nb), dim3(256), 0, st, v, prep, lt, lw, nb, sums);
     };
     L.cost = [](const DeviceView& v, hipStream_t st, const double* prep, const double* p, int lt, double lw, int fl,
@@ -1251,6 +1260,17 @@ void tmi_ba_solver_destroy(tmi_ba_solver* s) {
       }
     }
   }
+#ifdef TMI_LIN_PROFILE
+  {
+    unsigned long long h[8] = {0};
+    hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lin_prof), sizeof(h)) == hipSuccess && h[5]) {
+      const double t = (double)h[5];
+      fprintf(stderr, "[linearize profile] per wave-trip (cycles): loads %.0f | stage A %.0f | eval A %.0f | stage B %.0f | columns + stores %.0f  (wave-trips %.0f, waves %.0f)\n",
+              h[0] / t, h[1] / t, h[2] / t, h[3] / t, h[4] / t, t, (double)h[6]);
+    }
+  }
+#endif
 #ifdef TMI_MF_PROFILE
   if (s && s->mf_ok && s->mf.prof) {
     std::vector<long long> h((size_t)s->mf.n_items * 16);
@@ -1976,6 +1996,11 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
       int4* pr;
       if ((rc = dev_upload(s, &pr, rec))) return rc;
       v.cam_rec = pr;
+      // one camera model and one free-column mask for the whole problem?  (the specialised linearize, kernels.h)
+      bool uni = st.Nc > 0 && !st.has_shared;
+      for (int c = 0; c < st.Nc && uni; ++c) uni = rec[c].x == TMI_BA_PINHOLE && (unsigned)rec[c].w == kPinholeDefaultMask;
+      if (const char* e = getenv("TMI_BA_LINEARIZE_GENERIC")) uni = uni && atoi(e) == 0;  // A/B, tests
+      v.uniform_pinhole_default = uni ? 1 : 0;
     }
     if ((rc = dev_upload(s, &pu, st.grp_mask))) return rc; v.grp_mask = pu;
     if ((rc = dev_upload(s, &pc, st.obs_gflag))) return rc; v.obs_gflag = pc;

@@ -402,20 +402,43 @@ constexpr int kStagePitch = kStageWords + 2; // +2 doubles: conflict-free 16-byt
 
 // lane l wants words [off, off + kStageWords) of record idx (idx < 0: nothing); on return
 // st[l * kStagePitch + i] holds word off + i of lane l's record.  Wave-collective.
+template <int NB = 2>
 __device__ __forceinline__ void stage_camera_records(const double* __restrict__ prep, int off, int idx,
                                                      double* st, int lane) {
   constexpr int CH = kStageWords / 2;
   // the previous contents may still be being read by other lanes of this wave
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
+  // Every chunk is loaded UNCONDITIONALLY (a lane without a record fetches record 0; nobody reads what it stages) and
+  // all loads of a batch are issued before the first LDS store.  With the load inside `if (id >= 0)` every chunk was
+  // a basic block of its own -- global_load, s_waitcnt vmcnt(0), ds_write, twelve times per staging: 24 dependent
+  // memory round trips per trip of linearize (round 6: in-kernel phase counters put 44 k of a trip's 54 k cycles
+  // into the two stagings, 1.5 k into the evaluation).  Two batches of CH / 2 keep the transient registers at 24.
+  constexpr int PER = CH / NB;
+  static_assert(CH % NB == 0 && (PER == 6 || PER == 12), "batches");
 #pragma unroll
-  for (int it = 0; it < CH; ++it) {
-    const int f = it * 64 + lane;
-    const int rec = f / CH, part = f - rec * CH;
-    const int id = __shfl(idx, rec, 64);
-    if (id >= 0) {
-      const double2 t = *reinterpret_cast<const double2*>(prep + (size_t)id * kPrepStride + off + 2 * part);
-      *reinterpret_cast<double2*>(st + rec * kStagePitch + 2 * part) = t;
+  for (int bt = 0; bt < NB; ++bt) {
+    double2 t[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int f = (bt * PER + q) * 64 + lane;
+      const int rec = f / CH, part = f - rec * CH;
+      const int id = max(__shfl(idx, rec, 64), 0);
+      t[q] = *reinterpret_cast<const double2*>(prep + (size_t)id * kPrepStride + off + 2 * part);
+    }
+    // (left alone, the compiler sinks every load back to its store -- the kernel is at the register limit: ONE empty
+    // asm statement that names all six values keeps the batch together: they must all be in registers there)
+    // ("memory": the loads of the second half of a 12-chunk batch stay in front of it too)
+    asm volatile("" : "+v"(t[0].x), "+v"(t[0].y), "+v"(t[1].x), "+v"(t[1].y), "+v"(t[2].x), "+v"(t[2].y), "+v"(t[3].x),
+                      "+v"(t[3].y), "+v"(t[4].x), "+v"(t[4].y), "+v"(t[5].x), "+v"(t[5].y) : : "memory");
+    if constexpr (PER == 12)
+      asm volatile("" : "+v"(t[6].x), "+v"(t[6].y), "+v"(t[7].x), "+v"(t[7].y), "+v"(t[8].x), "+v"(t[8].y), "+v"(t[9].x),
+                        "+v"(t[9].y), "+v"(t[10].x), "+v"(t[10].y), "+v"(t[11].x), "+v"(t[11].y));
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int f = (bt * PER + q) * 64 + lane;
+      const int rec = f / CH, part = f - rec * CH;
+      *reinterpret_cast<double2*>(st + rec * kStagePitch + 2 * part) = t[q];
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -428,10 +451,21 @@ __device__ __forceinline__ void stage_camera_records(const double* __restrict__ 
 // stage [Jl scale] -> angle-axis columns, scaling and the plane stores.
 // OCC = minimum workgroups per CU the register allocation must allow (2: 256 registers per
 // lane, a handful of doubles spilled in the rarely taken camera-model branches).
-template <int D, int DP, bool SH, typename RT, int OCC, typename PT = double>
+#ifdef TMI_LIN_PROFILE
+__device__ unsigned long long g_lin_prof[8];
+#define LIN_LAP(i) do { const long long n_ = clock64(); lp_[i] += n_ - lt_; lt_ = n_; } while (0)
+#else
+#define LIN_LAP(i)
+#endif
+// UMODEL >= 0: every camera of the problem has camera model UMODEL and the free-column mask UMASK (the engine checks
+// at create): the model switch and the column compaction fold at compile time, the intrinsics columns nobody stores are
+// never formed and the per-observation gather of cam_rec goes -- ~100 registers less than the generic body.
+template <int D, int DP, bool SH, typename RT, int OCC, typename PT = double, int UMODEL = -1, unsigned UMASK = 0u>
 __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const double* __restrict__ prep,
-                                                             int loss_type, double loss_width, int nblocks,
+                                                             int loss_type_arg, double loss_width, int nblocks,
                                                              double* __restrict__ sums) {
+  // (the specialised instantiation is also the TRIVIAL-loss one: the engine launches it for loss_type 0 only)
+  const int loss_type = UMODEL >= 0 ? 0 : loss_type_arg;
   __shared__ __attribute__((aligned(16))) double stage[kSlicesPerBlock][64 * kStagePitch];
   const TrackMap tm = track_map(v);
   PT* const pmR = reinterpret_cast<PT*>(v.pm_r);   // (the planes in their storage type: double, or float with
@@ -458,6 +492,10 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
     for (int a = 0; a < DP; ++a) sp[a] = v.scale_p[(size_t)lp * DP + a];
   }
   int cam_next = (tm.j0 < k) ? v.obs_cam[tm.base + (size_t)tm.j0 * 64] : -1;
+#ifdef TMI_LIN_PROFILE
+  long long lp_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long lt_ = clock64();
+#endif
   for (int trip = 0; trip < tm.trips; ++trip) {
     const int j = tm.j0 + trip * tm.jstep;
     const bool act = j < k;
@@ -467,12 +505,18 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
     int4 rec = make_int4(0, 0, 0, 0);
     double fx = 0.0, fy = 0.0;
     if (act) {
-      rec = v.cam_rec[cam];
+      if (UMODEL < 0) rec = v.cam_rec[cam];
       const double2 f2 = *reinterpret_cast<const double2*>(v.obs_xy + 2 * e);
       fx = f2.x;
       fy = f2.y;
     }
+    if (UMODEL >= 0) {
+      rec.x = UMODEL;
+      rec.w = (int)UMASK;
+    }
+    LIN_LAP(0);
     stage_camera_records(prep, 0, cam, st, lane);
+    LIN_LAP(1);
     // ---- phase A: value, dp/dq, dp/dK; M = dp/dq R; c = p x dp/dq ----
     bool ok = false;
     RT Jint[2][10], M[2][3], cx[2][3], Jp3[2];
@@ -508,7 +552,9 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
         }
       }
     }
+    LIN_LAP(2);
     stage_camera_records(prep, kStageWords, cam, st, lane);
+    LIN_LAP(3);
     // ---- phase B: P[0..8] = Jl diag(scale_w), P[9..11] = position scales, P[12..21] = intrinsics scales
     if (!act) continue;
     if (!ok) {
@@ -615,7 +661,15 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
     }
     plane_store<PT>(r[0] * rscale, &pmR[pidx<2>(0, e)]);
     plane_store<PT>(r[1] * rscale, &pmR[pidx<2>(1, e)]);
+    LIN_LAP(4);
   }
+#ifdef TMI_LIN_PROFILE
+  if ((threadIdx.x & 63) == 0) {
+    for (int i = 0; i < 5; ++i) atomicAdd(&g_lin_prof[i], (unsigned long long)lp_[i]);
+    atomicAdd(&g_lin_prof[5], (unsigned long long)tm.trips);
+    atomicAdd(&g_lin_prof[6], 1ull);
+  }
+#endif
   block_sum_finish<2>(acc, v.partial, nblocks, v.ticket + 2 * kTicketStride, sums);
 }
 

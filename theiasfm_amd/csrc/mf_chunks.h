@@ -762,11 +762,26 @@ __global__ __launch_bounds__(256) void reduce_kernel(DeviceView v, View m, RedLa
 #pragma unroll
   for (int a = 0; a < D; ++a) a9[a] = 0.0;
   if (live) {
+    // a slot is D doubles at an 8-byte aligned address: fetched 16 bytes at a time, the slot index of the thread's next
+    // trip already in flight (the two loads of a trip are dependent; a view has ~3 trips per thread)
     const int k1 = m.cam_slot_ptr[rb + 1];
-    for (int k = m.cam_slot_ptr[rb] + (int)threadIdx.x; k < k1; k += 256) {
-      const double* p = m.partial + (size_t)m.cam_slots[k] * D;
+    int k = m.cam_slot_ptr[rb] + (int)threadIdx.x;
+    int slot = k < k1 ? m.cam_slots[k] : 0;
+    while (k < k1) {
+      const double* p = m.partial + (size_t)slot * D;
+      const int kn = k + 256;
+      if (kn < k1) slot = m.cam_slots[kn];
+      double t[D];
 #pragma unroll
-      for (int a = 0; a < D; ++a) a9[a] += p[a];
+      for (int a = 0; a + 1 < D; a += 2) {
+        const double2_a8 t2 = *reinterpret_cast<const double2_a8*>(p + a);
+        t[a] = t2.x;
+        t[a + 1] = t2.y;
+      }
+      if (D & 1) t[D - 1] = p[D - 1];
+#pragma unroll
+      for (int a = 0; a < D; ++a) a9[a] += t[a];
+      k = kn;
     }
   }
 #pragma unroll
