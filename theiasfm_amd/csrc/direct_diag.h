@@ -115,9 +115,12 @@ struct StageDims {
   static constexpr int PB = 2 * (D + 2) + 1;
 };
 
-template <int D, int DP>
+// UMODEL >= 0 (as linearize_kernel's): every camera is of model UMODEL with the free-column mask UMASK and the loss is
+// TRIVIAL -- the model switch, the column compaction and the corrector fold at compile time
+template <int D, int DP, int UMODEL = -1, unsigned UMASK = 0u>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TMI_DD_WAVES, TMI_DD_WAVES))) void camera_diag_direct_kernel(DeviceView v, Plan pl, const double* __restrict__ prep,
-                                                                int loss_type, double loss_width) {
+                                                                int loss_type_arg, double loss_width) {
+  const int loss_type = UMODEL >= 0 ? 0 : loss_type_arg;
   static_assert(D + 2 <= 16, "one 16 x 16 accumulator holds S_cc (D x D), g~ and g_c");
   constexpr int NS = sym_size(D);
   constexpr int TR = trk_stride(DP);
@@ -133,8 +136,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TMI_DD_WAVES
   const int s0 = pl.chunk_s0[ch], s1 = pl.chunk_s1[ch];
   const int cam = v.rb_cam[rb];
   const int4 rec = v.cam_rec[cam];
-  const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane(rec.w);
-  const int model = __builtin_amdgcn_readfirstlane(rec.x);
+  const unsigned mask = UMODEL >= 0 ? UMASK : (unsigned)__builtin_amdgcn_readfirstlane(rec.w);
+  const int model = UMODEL >= 0 ? UMODEL : __builtin_amdgcn_readfirstlane(rec.x);
   // the view's prepared record: a wave-uniform address, so its words arrive through the scalar cache into SGPRs
   // (read ONCE, before the loop: behind the LDS fences of a trip the compiler would fetch every word again at its use,
   // a scalar-cache round trip each, with two wavefronts per SIMD to hide it).  The Jacobi scales of the position and

@@ -167,8 +167,18 @@ Launch make_launch(bool fp32) {
   L.camera_diag_direct = [](const DeviceView& v, hipStream_t st, RedLayout R, const ddg::Plan& pl, const double* prep, int lt,
                             double lw) {
     if constexpr (!SH && D <= ddg::kMaxD) {
-      if (pl.n_chunks)
-        hipLaunchKernelGGL((ddg::camera_diag_direct_kernel<D, DP>), dim3(pl.n_chunks), dim3(64), 0, st, v, pl, prep, lt, lw);
+      if (pl.n_chunks) {
+        bool special = false;
+        if constexpr (D == 9) {
+          if (v.uniform_pinhole_default && lt == 0) {  // (as linearize: every camera PINHOLE / default mask, no robust loss)
+            hipLaunchKernelGGL((ddg::camera_diag_direct_kernel<D, DP, 0, kPinholeDefaultMask>), dim3(pl.n_chunks), dim3(64), 0, st, v, pl,
+                               prep, lt, lw);
+            special = true;
+          }
+        }
+        if (!special)
+          hipLaunchKernelGGL((ddg::camera_diag_direct_kernel<D, DP>), dim3(pl.n_chunks), dim3(64), 0, st, v, pl, prep, lt, lw);
+      }
       if (v.Nrb) hipLaunchKernelGGL((ddg::camera_diag_direct_reduce_kernel<D>), dim3(v.Nrb), dim3(64), 0, st, v, R, pl);
     }
   };
