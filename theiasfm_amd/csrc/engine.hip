@@ -117,8 +117,12 @@ Launch make_launch(bool fp32) {
         // every camera a PINHOLE with extrinsics + focal length + two radial terms free (the BAL / reference default,
         // bundle_adjustment.h:95) and no robust loss: the specialised body (kernels.h, UMODEL / UMASK)
         if (v.uniform_pinhole_default && lt == 0) {
-          hipLaunchKernelGGL((linearize_kernel<D, DP, SH, double, 2, double, 0, kPinholeDefaultMask>), dim3(nb), dim3(256), 0, st, v, prep,
-                             lt, lw, nb, sums);
+          if (v.drop_pos)
+            hipLaunchKernelGGL((linearize_kernel<D, DP, SH, double, 2, double, 0, kPinholeDefaultMask, true>), dim3(nb), dim3(256), 0, st, v,
+                               prep, lt, lw, nb, sums);
+          else
+            hipLaunchKernelGGL((linearize_kernel<D, DP, SH, double, 2, double, 0, kPinholeDefaultMask, false>), dim3(nb), dim3(256), 0, st, v,
+                               prep, lt, lw, nb, sums);
           return;
         }
       }

@@ -460,7 +460,10 @@ __device__ unsigned long long g_lin_prof[8];
 // UMODEL >= 0: every camera of the problem has camera model UMODEL and the free-column mask UMASK (the engine checks
 // at create): the model switch and the column compaction fold at compile time, the intrinsics columns nobody stores are
 // never formed and the per-observation gather of cam_rec goes -- ~100 registers less than the generic body.
-template <int D, int DP, bool SH, typename RT, int OCC, typename PT = double, int UMODEL = -1, unsigned UMASK = 0u>
+// UDROP: the handle does not store the position columns (DeviceView::drop_pos is set): known at compile time, M is dead
+// once the point block is out.
+template <int D, int DP, bool SH, typename RT, int OCC, typename PT = double, int UMODEL = -1, unsigned UMASK = 0u,
+          bool UDROP = false>
 __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const double* __restrict__ prep,
                                                              int loss_type_arg, double loss_width, int nblocks,
                                                              double* __restrict__ sums) {
@@ -552,6 +555,46 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
         }
       }
     }
+    // The loss corrector and the planes that need nothing of the second half record -- the point block and the residual --
+    // go out BEFORE it is staged: M then dies here where the position columns are not stored (UDROP), and fewer values
+    // cross the staging (round 6).
+    double sqrt_rho1 = 1.0, asn = 0.0, rscale = 1.0;
+    if (act && ok) {
+      const double sq = r[0] * r[0] + r[1] * r[1];
+      if (loss_type != 0) {
+        double rho[3];
+        loss_eval(loss_type, loss_width, sq, rho);
+        acc[0] += 0.5 * rho[0];
+        sqrt_rho1 = sqrt(rho[1]);
+        rscale = sqrt_rho1;
+        if (!(sq == 0.0 || rho[2] <= 0.0)) {
+          const double Dd = 1.0 + 2.0 * sq * rho[2] / rho[1];
+          const double alpha = 1.0 - sqrt(Dd);
+          rscale = sqrt_rho1 / (1.0 - alpha);
+          asn = alpha / sq;
+        }
+      } else {
+        acc[0] += 0.5 * sq;
+      }
+      acc[1] += sq;
+#pragma unroll
+      for (int a = 0; a < DP; ++a) {
+        double j0 = 0.0, j1 = 0.0;
+        if (!pconst) {
+          j0 = (a < 3) ? (double)M[0][a < 3 ? a : 0] : (double)Jp3[0];
+          j1 = (a < 3) ? (double)M[1][a < 3 ? a : 0] : (double)Jp3[1];
+        }
+        if (loss_type != 0) {
+          const double rtj = j0 * r[0] + j1 * r[1];
+          j0 = sqrt_rho1 * (j0 - asn * r[0] * rtj);
+          j1 = sqrt_rho1 * (j1 - asn * r[1] * rtj);
+        }
+        plane_store<PT>(j0 * sp[a], &pmJp[pidx<2 * DP>((2 * a), e)]);
+        plane_store<PT>(j1 * sp[a], &pmJp[pidx<2 * DP>((2 * a + 1), e)]);
+      }
+      plane_store<PT>(r[0] * rscale, &pmR[pidx<2>(0, e)]);
+      plane_store<PT>(r[1] * rscale, &pmR[pidx<2>(1, e)]);
+    }
     LIN_LAP(2);
     stage_camera_records(prep, kStageWords, cam, st, lane);
     LIN_LAP(3);
@@ -567,24 +610,6 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
       plane_store<PT>(0.0, &pmR[pidx<2>(1, e)]);
       continue;
     }
-    const double sq = r[0] * r[0] + r[1] * r[1];
-    double sqrt_rho1 = 1.0, asn = 0.0, rscale = 1.0;
-    if (loss_type != 0) {
-      double rho[3];
-      loss_eval(loss_type, loss_width, sq, rho);
-      acc[0] += 0.5 * rho[0];
-      sqrt_rho1 = sqrt(rho[1]);
-      rscale = sqrt_rho1;
-      if (!(sq == 0.0 || rho[2] <= 0.0)) {
-        const double Dd = 1.0 + 2.0 * sq * rho[2] / rho[1];
-        const double alpha = 1.0 - sqrt(Dd);
-        rscale = sqrt_rho1 / (1.0 - alpha);
-        asn = alpha / sq;
-      }
-    } else {
-      acc[0] += 0.5 * sq;
-    }
-    acc[1] += sq;
     const double wneg = -X[3];
     const unsigned mask = (unsigned)rec.w;
     // reduced camera block: free columns of [ext(6) | intr(10)], compacted
@@ -612,7 +637,7 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
           j0 = sqrt_rho1 * (j0 - asn * r[0] * rtj);
           j1 = sqrt_rho1 * (j1 - asn * r[1] * rtj);
         }
-        if (!(c < 3 && !SH && v.drop_pos)) {  // (drop_pos: the position columns are not stored, device_view.h)
+        if (!(c < 3 && !SH && (UDROP || v.drop_pos))) {  // (drop_pos: the position columns are not stored, device_view.h)
           plane_store<PT>(j0 * scl, &pmA[pidx<2 * D>((2 * dst), e)]);
           plane_store<PT>(j1 * scl, &pmA[pidx<2 * D>((2 * dst + 1), e)]);
         }
@@ -644,23 +669,6 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
       }
       for (int d = 2 * dst1; d < 2 * D; ++d) plane_store<PT>(0.0, &pmA1[pidx<2 * D>(d, e)]);
     }
-#pragma unroll
-    for (int a = 0; a < DP; ++a) {
-      double j0 = 0.0, j1 = 0.0;
-      if (!pconst) {
-        j0 = (a < 3) ? (double)M[0][a < 3 ? a : 0] : (double)Jp3[0];
-        j1 = (a < 3) ? (double)M[1][a < 3 ? a : 0] : (double)Jp3[1];
-      }
-      if (loss_type != 0) {
-        const double rtj = j0 * r[0] + j1 * r[1];
-        j0 = sqrt_rho1 * (j0 - asn * r[0] * rtj);
-        j1 = sqrt_rho1 * (j1 - asn * r[1] * rtj);
-      }
-      plane_store<PT>(j0 * sp[a], &pmJp[pidx<2 * DP>((2 * a), e)]);
-      plane_store<PT>(j1 * sp[a], &pmJp[pidx<2 * DP>((2 * a + 1), e)]);
-    }
-    plane_store<PT>(r[0] * rscale, &pmR[pidx<2>(0, e)]);
-    plane_store<PT>(r[1] * rscale, &pmR[pidx<2>(1, e)]);
     LIN_LAP(4);
   }
 #ifdef TMI_LIN_PROFILE
