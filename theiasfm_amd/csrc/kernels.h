@@ -195,22 +195,24 @@ struct TrackMap {
   bool leader, valid;
 };
 
-__device__ __forceinline__ TrackMap track_map(const DeviceView& v) {
+// (bid, tid): the workgroup and thread of the 256-thread launch the mapping was made for -- a kernel with another launch
+// shape (back_substitute_lds_kernel) walks the same virtual workgroups
+__device__ __forceinline__ TrackMap track_map_at(const DeviceView& v, int bid, int tid) {
   TrackMap m;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = tid & 63, w = tid >> 6;
   const int nub = 16 * v.n_ultra;
   const int nwb = nub + 4 * (v.n_wide - v.n_ultra);
   int t;
-  if ((int)blockIdx.x < nub) {
+  if (bid < nub) {
     m.wide = 2;
-    m.s = blockIdx.x >> 4;
-    t = 4 * (blockIdx.x & 15) + w;
+    m.s = bid >> 4;
+    t = 4 * (bid & 15) + w;
     m.j0 = lane;
     m.jstep = 64;
     m.leader = lane == 0;
-  } else if ((int)blockIdx.x < nwb) {
+  } else if (bid < nwb) {
     m.wide = 1;
-    const int bw = (int)blockIdx.x - nub;
+    const int bw = bid - nub;
     m.s = v.n_ultra + (bw >> 2);
     t = 16 * (bw & 3) + 4 * w + (lane >> 4);
     m.j0 = lane & (kWideLanes - 1);
@@ -218,7 +220,7 @@ __device__ __forceinline__ TrackMap track_map(const DeviceView& v) {
     m.leader = m.j0 == 0;
   } else {
     m.wide = 0;
-    m.s = v.n_wide + ((int)blockIdx.x - nwb) * kSlicesPerBlock + w;
+    m.s = v.n_wide + (bid - nwb) * kSlicesPerBlock + w;
     t = lane;
     m.j0 = 0;
     m.jstep = 1;
@@ -238,6 +240,7 @@ __device__ __forceinline__ TrackMap track_map(const DeviceView& v) {
   }
   return m;
 }
+__device__ __forceinline__ TrackMap track_map(const DeviceView& v) { return track_map_at(v, (int)blockIdx.x, (int)threadIdx.x); }
 
 // sum over the 16 lanes that share a track (identity for thread-per-track slices); every lane
 // of the group receives the total; fixed butterfly => reproducible
@@ -2924,6 +2927,11 @@ __global__ __launch_bounds__(256) void back_substitute_kernel(DeviceView v, int 
 #pragma unroll
       for (int a = 0; a < DP; ++a) w[a] = tm.leader ? v.gp[(size_t)a * NP + lp] : 0.0;
       double ur = 0.0, uu = 0.0;
+      double pc[3] = {0.0, 0.0, 0.0};  // drop_pos: -w / scale_p of this track (device_view.h)
+      if (!SH && v.drop_pos) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) pc[a] = v.pos_coef[(size_t)a * NP + lp];
+      }
       // (the block index of the next observation is in flight while this one is processed)
       int rb_next = (tm.j0 < k) ? v.obs_rb[base + (size_t)tm.j0 * 64] : -1;
       for (int j = tm.j0; j < k; j += tm.jstep) {
@@ -2935,12 +2943,22 @@ __global__ __launch_bounds__(256) void back_substitute_kernel(DeviceView v, int 
         if (rb >= 0) {
           if (!SH && v.drop_pos) {
             // the position columns from Jp (device_view.h); xs = y_c with the position entries times scale_c
-            const double* yc = v.xs + (size_t)rb * D;
+            // (the view's block of y_c: D doubles at an 8-byte aligned address, gathered 16 bytes at a time -- five
+            // instructions of 64 different lines instead of nine)
+            const double* ycp = v.xs + (size_t)rb * D;
+            double yv[D];
+#pragma unroll
+            for (int a = 0; a + 1 < D; a += 2) {
+              const double2_a8 t2 = *reinterpret_cast<const double2_a8*>(ycp + a);
+              yv[a] = t2.x;
+              yv[a + 1] = t2.y;
+            }
+            if (D & 1) yv[D - 1] = ycp[D - 1];
 #pragma unroll
             for (int a = 0; a < D; ++a) {
-              const double ya = yc[a];
+              const double ya = yv[a];
               if (a < 3) {
-                const double t = ya * v.pos_coef[(size_t)a * NP + lp];
+                const double t = ya * pc[a];
                 u0 += pmJp[pidx<2 * DP>((2 * (a < DP ? a : 0)), e)] * t;
                 u1 += pmJp[pidx<2 * DP>((2 * (a < DP ? a : 0) + 1), e)] * t;
               } else {

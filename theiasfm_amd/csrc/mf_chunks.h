@@ -42,7 +42,10 @@ constexpr int kLongRun = 12;                  // a run with more entries than th
 __host__ __device__ constexpr int reg_rows(int D) { return D <= 9 ? 2 : 1; }
 // distinct views an item of SEVERAL slices may see (its accumulators); an item of one slice writes its run sums
 // straight to its slots and has no limit
-__host__ __device__ constexpr int lc_max(int D) { return D <= 6 ? 704 : D <= 9 ? 472 : D <= 12 ? 352 : 264; }
+#ifndef TMI_LCM9
+#define TMI_LCM9 472  // (A/B builds: -DTMI_LCM9=<views>)
+#endif
+__host__ __device__ constexpr int lc_max(int D) { return D <= 6 ? 704 : D <= 9 ? TMI_LCM9 : D <= 12 ? 352 : 264; }
 // v_i per round: at least the kWaves * reg_rows(D) rows a pack keeps in registers
 __host__ __device__ constexpr int vb_entries(int D) { return D <= 9 ? 512 : 256; }
 
