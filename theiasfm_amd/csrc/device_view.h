@@ -207,6 +207,7 @@ enum {
   SC_II_DEXT = 18,  // inner iterations: |x - candidate|^2 over extrinsics / intrinsics,
   SC_II_DINTR = 19,
   SC_II_XC = 22,    //   |candidate|^2 over the non-constant camera blocks
+  SC_PCG_STOP = 24, // pcg_step: its stopping test held (what DeviceView::pcg_done says, for the host)
   SC_COUNT = 32
 };
 // DeviceView::flags

@@ -592,5 +592,220 @@ __global__ __launch_bounds__(64) void camera_diag_direct_reduce_kernel(DeviceVie
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Round 6: the per-block tail of the normal equations and the start of PCG in ONE launch.  Until then four launches --
+// camera_diag_direct_reduce, finish_diag, precond_invert, pcg_init -- of ~6-10 us each plus the ~5 us of idle device
+// between two dependent launches, for 1 778 blocks of 81 doubles (profiles/r06_a_gaps.md).  One wavefront per reduced
+// block, everything block-local stays in LDS / registers:
+//   (DIRECT: camera_diag_direct ran, one rank) the block's chunk partials summed in chunk order -> raw diagonal block,
+//       U diagonal, g~, g_c in `red`, exactly as camera_diag_direct_reduce_kernel leaves them;
+//   diagonal block of S = raw + clamp(U_aa) / radius -> Sdiag (finish_diag_kernel), max |g_c / scale| for the gradient test;
+//   SCHUR_JACOBI inverse of the block -> Minv (precond_invert_kernel; mode 0 merged block, 1 identity, 2 parameter blocks);
+//   start of PCG (pcg_init_kernel): x = 0, r = b = g~, z = M^-1 r, p = z (+ the scaled copy the product gathers),
+//       rho = r . z.
+// rho and max |g_c| are finished by the last workgroup (one ticket, fence-free hand-over of kernels.h).
+// Not used with the cluster preconditioners (their factorisation sits between precond and pcg_init) nor by the exact
+// solvers (no preconditioner): those keep the separate launches.
+// ------------------------------------------------------------------------------------------------------------------
+template <int D, bool DIRECT>
+__global__ __launch_bounds__(64) void camera_finish_kernel(DeviceView v, RedLayout L, Plan pl, double inv_radius, double lm_lo,
+                                                           double lm_hi, int want_gmax, int mode) {
+  constexpr int NS = sym_size(D);
+  constexpr int NA = n_acc(D);
+  __shared__ double Sraw[D * D];
+  __shared__ double M[D * D];
+  __shared__ double ud[D], gt[D], gc[D], f[D];
+  __shared__ int bad;
+  __shared__ int cf_last;
+  const int rb = blockIdx.x;
+  const int t = threadIdx.x;
+  const int nb = (int)gridDim.x;
+  const signed char* cols = v.rb_cols + (size_t)rb * D;
+  if (t == 0) bad = 0;
+  if (DIRECT) {
+    const int c0 = pl.rb_chunk[rb], c1 = pl.rb_chunk[rb + 1];
+    if (t < D) {
+      const int c = cols[t];
+      f[t] = (c >= 3 && c < 6) ? 1.0 : (c < 0 ? 0.0 : v.scale_c[(size_t)rb * D + t]);
+    }
+    __syncthreads();
+    double* diag = v.red + L.diag + (size_t)rb * D * D;
+    for (int i = t; i < NA; i += 64) {
+      double s = 0.0;
+      for (int c = c0; c < c1; ++c) s += pl.part[(size_t)c * NA + i];
+      if (i < NS) {
+        int a = 0, rem = i;
+        while (rem >= D - a) {
+          rem -= D - a;
+          ++a;
+        }
+        const int b = a + rem;
+        s *= f[a] * f[b];
+        diag[a * D + b] = s;
+        diag[b * D + a] = s;
+        Sraw[a * D + b] = s;
+        Sraw[b * D + a] = s;
+      } else if (i < NS + D) {
+        const int a = i - NS;
+        s *= f[a] * f[a];
+        v.red[L.udiag + (size_t)rb * D + a] = s;
+        ud[a] = s;
+      } else if (i < NS + 2 * D) {
+        const int a = i - NS - D;
+        s *= f[a];
+        v.red[L.gt + (size_t)rb * D + a] = s;
+        gt[a] = s;
+      } else {
+        const int a = i - NS - 2 * D;
+        s *= f[a];
+        v.red[L.gc + (size_t)rb * D + a] = s;
+        gc[a] = s;
+      }
+    }
+  } else {
+    for (int e = t; e < D * D; e += 64) Sraw[e] = v.red[L.diag + (size_t)rb * D * D + e];
+    if (t < D) {
+      ud[t] = v.red[L.udiag + (size_t)rb * D + t];
+      gt[t] = v.red[L.gt + (size_t)rb * D + t];
+      gc[t] = v.red[L.gc + (size_t)rb * D + t];
+    }
+  }
+  __syncthreads();
+  // ---- finish_diag: the block of S, the preconditioner's input (mode 2: cross terms of a view dropped) ----
+  for (int e = t; e < D * D; e += 64) {
+    const int a = e / D, b = e - a * D;
+    double val = Sraw[e];
+    if (a == b) {
+      if (cols[a] < 0)
+        val = 1.0;
+      else
+        val += fmin(fmax(ud[a], lm_lo), lm_hi) * inv_radius;
+    }
+    v.Sdiag[(size_t)rb * D * D + e] = val;
+    if (mode == 2) {
+      const int ci = cols[a], cj = cols[b];
+      if (ci >= 0 && cj >= 0 && ((ci < 6) != (cj < 6))) val = 0.0;
+    }
+    M[e] = val;
+  }
+  double gm = 0.0;
+  if (want_gmax && t < D && cols[t] >= 0) gm = fabs(gc[t] / v.scale_c[(size_t)rb * D + t]);
+  gm = wave_max(gm);
+  __syncthreads();
+  // ---- precond_invert: M <- (L L^T)^-1 of the block (identity for mode 1) ----
+  double* out = v.Minv + (size_t)rb * D * D;
+  if (mode == 1) {
+    for (int e = t; e < D * D; e += 64) {
+      const double one = (e / D == e % D) ? 1.0 : 0.0;
+      out[e] = one;
+      M[e] = one;
+    }
+    __syncthreads();
+  } else {
+    for (int j = 0; j < D; ++j) {
+      if (t == 0) {
+        const double d = M[j * D + j];
+        if (!(d > 0.0)) {
+          bad = 1;
+          M[j * D + j] = 1.0;
+        } else {
+          M[j * D + j] = sqrt(d);
+        }
+      }
+      __syncthreads();
+      if (t > j && t < D) M[t * D + j] /= M[j * D + j];
+      __syncthreads();
+      for (int e = t; e < D * D; e += 64) {
+        const int i = e / D, m = e - i * D;
+        if (m > j && m <= i) M[e] -= M[i * D + j] * M[m * D + j];
+      }
+      __syncthreads();
+    }
+    double y[D];
+    if (t < D) {
+      // column t of (L L^T)^-1
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        double s = (i == t) ? 1.0 : 0.0;
+        for (int m = 0; m < i; ++m) s -= M[i * D + m] * y[m];
+        y[i] = s / M[i * D + i];
+      }
+#pragma unroll
+      for (int i = D - 1; i >= 0; --i) {
+        double s = y[i];
+        for (int m = i + 1; m < D; ++m) s -= M[m * D + i] * y[m];
+        y[i] = s / M[i * D + i];
+      }
+#pragma unroll
+      for (int i = 0; i < D; ++i) out[i * D + t] = y[i];
+    }
+    __syncthreads();  // (every lane is done with the factor)
+    if (t < D) {
+#pragma unroll
+      for (int i = 0; i < D; ++i) M[i * D + t] = y[i];
+    }
+    __syncthreads();
+    if (t == 0 && bad) v.flags[FL_SINGULAR_BLOCK] = 1;
+  }
+  // ---- pcg_init: x = 0, r = b, z = M^-1 b, p = z ----
+  double acc = 0.0;
+  if (t < D) {
+    const size_t i = (size_t)rb * D + t;
+    const double rn = gt[t];
+    double z = 0.0;
+#pragma unroll
+    for (int c = 0; c < D; ++c) z += M[t * D + c] * gt[c];
+    v.yc[i] = 0.0;
+    v.cg_r[i] = rn;
+    v.cg_z[i] = z;
+    v.cg_p[i] = z;
+    if (v.drop_pos) v.xs[i] = t < 3 ? z * v.scale_c[i] : z;
+    acc = rn * z;
+  }
+  acc = wave_sum(acc);
+  if (t == 0) {
+    st_agent(&v.dotbuf[rb], acc);
+    st_agent(&v.partial[rb], gm);
+    cf_last = take_ticket(v.ticket + 1 * kTicketStride, nb) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!cf_last) return;
+  // rho in pcg_init_kernel's summation order (workgroups of kPcgStepThreads / 64 blocks added in block order, then that
+  // kernel's 1024-leaf tree), so that this launch and the separate ones give the same bits
+  __shared__ double tree[kPcgStepThreads];
+  constexpr int W16 = kPcgStepThreads / 64;
+  const int nb16 = (nb + W16 - 1) / W16;
+  for (int i = t; i < kPcgStepThreads; i += 64) {
+    double l0 = 0.0;
+    for (int g = i; g < nb16; g += kPcgStepThreads) {
+      double tt = 0.0;
+#pragma unroll
+      for (int k = 0; k < W16; ++k) {
+        const int rbk = g * W16 + k;
+        tt += rbk < nb ? ld_agent(&v.dotbuf[rbk]) : 0.0;
+      }
+      l0 += tt;
+    }
+    tree[i] = l0;
+  }
+  double g0 = 0.0;
+  for (int i = t; i < nb; i += 64) g0 = fmax(g0, ld_agent(&v.partial[i]));
+  g0 = wave_max(g0);
+  __syncthreads();
+  for (int o = kPcgStepThreads / 2; o > 0; o >>= 1) {
+    for (int i = t; i < o; i += 64) tree[i] += tree[i + o];
+    __syncthreads();
+  }
+  const double r0 = tree[0];
+  if (t == 0) {
+    v.scal[SC_LAST_RHO] = 1.0;
+    v.scal[SC_RHO] = r0;
+    v.scal[SC_Q0] = 0.0;
+    v.flags[FL_PCG_FAIL] = (r0 == 0.0 || !isfinite(r0)) ? 1 : 0;
+    *v.pcg_done = 0;
+    if (want_gmax) v.scal[SC_GMAX] = g0;
+  }
+}
+
 }  // namespace ddg
 }  // namespace tmi

@@ -10,6 +10,7 @@
 // handful of scalars read back once per iteration (once per PCG iteration
 // inside the linear solve).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <dlfcn.h>
 
 #include <algorithm>
@@ -71,7 +72,12 @@ struct Launch {
                           double*);
   void (*camera_diag)(const DeviceView&, hipStream_t, RedLayout, int, double*);
   // direct_diag.h: the same sums without camera-major records (matrix-free iterations, no shared intrinsics blocks)
-  void (*camera_diag_direct)(const DeviceView&, hipStream_t, RedLayout, const ddg::Plan&, const double* prep, int, double);
+  void (*camera_diag_direct)(const DeviceView&, hipStream_t, RedLayout, const ddg::Plan&, const double* prep, int, double,
+                             int skip_reduce);
+  // direct_diag.h, camera_finish_kernel: [the chunk sums of camera_diag_direct ->] diagonal blocks + LM diagonal ->
+  // SCHUR_JACOBI inverses -> start of PCG, one launch
+  void (*camera_finish)(const DeviceView&, hipStream_t, RedLayout, const ddg::Plan&, double, double, double, int want_gmax,
+                        int mode, int direct);
   void (*schur_offdiag)(const DeviceView&, hipStream_t, RedLayout);
   void (*expand_scale)(const DeviceView&, hipStream_t);
   void (*expand)(const DeviceView&, hipStream_t, RedLayout, double, double, double, int want_gmax);
@@ -84,15 +90,14 @@ struct Launch {
                         double*, double, double, double, int, int, int dot);
   // the one-sweep matrix-free product of mf_chunks.h (no shared intrinsics blocks)
   // xs_ready: DeviceView::xs already holds x with the position entries scaled (pcg_init / pcg_p leave it for cg_p)
+  // ev_a / ev_b (may be null): HIP events that take the start of the first and the end of the last kernel of the product
   void (*mf_product)(const DeviceView&, const mfc::View&, hipStream_t, RedLayout, const double*, double*, double, double,
-                     double, int, int dot, int xs_ready);
+                     double, int, int dot, int xs_ready, hipEvent_t ev_a, hipEvent_t ev_b, const int* guard);
   void (*pcg_step)(const DeviceView&, hipStream_t, const double* b, int it, int nb, double eta, int min_it,
-                   int max_it, const double* red8, HostMirror* mirror, unsigned long long seq);
+                   int max_it, const double* red8, HostMirror* mirror, unsigned long long seq, const int* guard);
   void (*pcg_a)(const DeviceView&, hipStream_t, int, int);
   void (*pcg_b2)(const DeviceView&, hipStream_t, const double*, int, int, double*);
   void (*back_substitute)(const DeviceView&, hipStream_t, int, double*, double* sums);
-  void (*pos_coef)(const DeviceView&, hipStream_t, const double* pts);  // drop_pos: after every linearize
-  void (*update_points)(const DeviceView&, hipStream_t, int, double*, double* sums);
   void (*update_cameras)(const DeviceView&, hipStream_t, double* out, double* prep_c);
   void (*pcg_init)(const DeviceView&, hipStream_t, const double* b, int nb);
   void (*pcg_persistent)(const DeviceView&, hipStream_t, int grid, const ppcg::Args&);
@@ -169,7 +174,7 @@ Launch make_launch(bool fp32) {
     }
   };
   L.camera_diag_direct = [](const DeviceView& v, hipStream_t st, RedLayout R, const ddg::Plan& pl, const double* prep, int lt,
-                            double lw) {
+                            double lw, int skip_reduce) {
     if constexpr (!SH && D <= ddg::kMaxD) {
       if (pl.n_chunks) {
         bool special = false;
@@ -183,8 +188,21 @@ Launch make_launch(bool fp32) {
         if (!special)
           hipLaunchKernelGGL((ddg::camera_diag_direct_kernel<D, DP>), dim3(pl.n_chunks), dim3(64), 0, st, v, pl, prep, lt, lw);
       }
-      if (v.Nrb) hipLaunchKernelGGL((ddg::camera_diag_direct_reduce_kernel<D>), dim3(v.Nrb), dim3(64), 0, st, v, R, pl);
+      // (skip_reduce: camera_finish sums the chunks itself)
+      if (v.Nrb && !skip_reduce)
+        hipLaunchKernelGGL((ddg::camera_diag_direct_reduce_kernel<D>), dim3(v.Nrb), dim3(64), 0, st, v, R, pl);
     }
+  };
+  L.camera_finish = [](const DeviceView& v, hipStream_t st, RedLayout R, const ddg::Plan& pl, double ir, double lo, double hi,
+                       int want_gmax, int mode, int direct) {
+    if (!v.Nrb) return;
+    if constexpr (!SH && D <= ddg::kMaxD) {
+      if (direct) {
+        hipLaunchKernelGGL((ddg::camera_finish_kernel<D, true>), dim3(v.Nrb), dim3(64), 0, st, v, R, pl, ir, lo, hi, want_gmax, mode);
+        return;
+      }
+    }
+    hipLaunchKernelGGL((ddg::camera_finish_kernel<D, false>), dim3(v.Nrb), dim3(64), 0, st, v, R, pl, ir, lo, hi, want_gmax, mode);
   };
   L.expand_scale = [](const DeviceView& v, hipStream_t st) {
     if (v.Nc) hipLaunchKernelGGL((expand_camera_scale_kernel<D>), dim3((v.Nc + 255) / 256), dim3(256), 0, st, v);
@@ -218,9 +236,9 @@ Launch make_launch(bool fp32) {
     hipLaunchKernelGGL((spmv_cols_kernel<D>), dim3(v.Nrb), dim3(256), 0, st, v, x, y, dot);
   };
   L.pcg_step = [](const DeviceView& v, hipStream_t st, const double* b, int it, int nb, double eta, int min_it,
-                  int max_it, const double* red8, HostMirror* mirror, unsigned long long seq) {
+                  int max_it, const double* red8, HostMirror* mirror, unsigned long long seq, const int* guard) {
     hipLaunchKernelGGL((pcg_step_kernel<D>), dim3(nb), dim3(kPcgStepThreads), 0, st, v, b, it, nb, eta, min_it,
-                       max_it, red8, mirror, seq);
+                       max_it, red8, mirror, seq, guard);
   };
   L.implicit_spmv = [](const DeviceView& v, hipStream_t st, RedLayout R, const double* x, double* y,
                        double* w1, double* w2, double ir, double lo, double hi, int add_diag, int nb, int dot) {
@@ -241,21 +259,25 @@ Launch make_launch(bool fp32) {
       hipLaunchKernelGGL((implicit_groups_kernel<D>), dim3(v.Nrb - v.Ncam_rb), dim3(64), 0, st, v, R, x, v.cam_part,
                          y, ir, lo, hi, add_diag);
   };
-  L.mf_product = [](const DeviceView& v, const mfc::View& m, hipStream_t st, RedLayout R, const double* x, double* y,
-                    double ir, double lo, double hi, int add_diag, int dot, int xs_ready) {
+  L.mf_product = [](const DeviceView& v, const mfc::View& m0, hipStream_t st, RedLayout R, const double* x, double* y,
+                    double ir, double lo, double hi, int add_diag, int dot, int xs_ready, hipEvent_t ev_a, hipEvent_t ev_b,
+                    const int* guard) {
     if (!v.Nrb) return;
+    mfc::View m = m0;
+    m.guard = guard;
     if (v.drop_pos) {
       // the position columns of the planes are formed from Jp (device_view.h): the product gathers x with the
       // position entries times the views' column scales, the reduce launch scales the position entries of the sums
       const int n = v.Nrb * D;
       if (!xs_ready) hipLaunchKernelGGL((pos_scale_kernel<D>), dim3((n + 255) / 256), dim3(256), 0, st, v, x, v.xs);
       if (m.n_items)
-        hipLaunchKernelGGL((mfc::product_kernel<D, DP, true>), dim3(m.n_items), dim3(mfc::kThreads), 0, st, v, m, v.xs);
+        hipExtLaunchKernelGGL((mfc::product_kernel<D, DP, true>), dim3(m.n_items), dim3(mfc::kThreads), 0, st, ev_a, nullptr, 0, v, m,
+                              (const double*)v.xs);
     } else if (m.n_items) {
-      hipLaunchKernelGGL((mfc::product_kernel<D, DP, false>), dim3(m.n_items), dim3(mfc::kThreads), 0, st, v, m, x);
+      hipExtLaunchKernelGGL((mfc::product_kernel<D, DP, false>), dim3(m.n_items), dim3(mfc::kThreads), 0, st, ev_a, nullptr, 0, v, m, x);
     }
-    hipLaunchKernelGGL((mfc::reduce_kernel<D>), dim3(8 * ((v.Nrb + 7) / 8)), dim3(256), 0, st, v, m, R, x, y, ir, lo, hi,
-                       add_diag, dot);
+    hipExtLaunchKernelGGL((mfc::reduce_kernel<D>), dim3(8 * ((v.Nrb + 7) / 8)), dim3(256), 0, st, m.n_items ? nullptr : ev_a, ev_b, 0,
+                          v, m, R, x, y, ir, lo, hi, add_diag, dot);
   };
   L.pcg_a = [](const DeviceView& v, hipStream_t st, int n, int it) {
     hipLaunchKernelGGL((pcg_a_kernel<D>), dim3(1), dim3(1024), 0, st, v, n, it);
@@ -264,18 +286,9 @@ Launch make_launch(bool fp32) {
     hipLaunchKernelGGL((pcg_b2_kernel<D>), dim3(nb), dim3(256), 0, st, v, b, mode, nb, partial);
   };
   L.back_substitute = [](const DeviceView& v, hipStream_t st, int nb, double* partial, double* sums) {
-    if (!SH && v.drop_pos && v.Nrb) {
-      const int n = v.Nrb * D;
-      hipLaunchKernelGGL((pos_scale_kernel<D>), dim3((n + 255) / 256), dim3(256), 0, st, v, v.yc, v.xs);
-    }
+    // (drop_pos: the scaled copy of y_c the kernel gathers is update_cameras' -- the engine launches that one first;
+    //  the candidate points and their step / norm sums come out of this launch too: no update_points launch)
     hipLaunchKernelGGL((back_substitute_kernel<D, DP, SH>), dim3(nb), dim3(256), 0, st, v, nb, partial, sums);
-  };
-  L.pos_coef = [](const DeviceView& v, hipStream_t st, const double* pts) {
-    if (v.drop_pos && v.Np_pad)
-      hipLaunchKernelGGL((pos_coef_kernel<DP>), dim3((v.Np_pad + 255) / 256), dim3(256), 0, st, v, pts);
-  };
-  L.update_points = [](const DeviceView& v, hipStream_t st, int nb, double* partial, double* sums) {
-    hipLaunchKernelGGL((update_points_kernel<DP>), dim3(nb), dim3(256), 0, st, v, nb, partial, sums);
   };
   L.update_cameras = [](const DeviceView& v, hipStream_t st, double* out, double* prep_c) {
     const int n = v.Nc + (SH ? v.Nrb - v.Ncam_rb : 0);
@@ -371,6 +384,12 @@ using namespace tmi;
 // ---- the opaque solver ----------------------------------------------------------
 namespace tmi {
 static_assert(SC_COUNT == 32 && FL_COUNT == 8, "HostMirror layout (device_view.h)");
+// top of an LM iteration: the device flags and the eight all-reduced scalars start at zero (one launch; two fill commands before)
+__global__ void iteration_begin_kernel(int* __restrict__ flags, double* __restrict__ sc8) {
+  const int t = threadIdx.x;
+  if (t < FL_COUNT) flags[t] = 0;
+  if (t < 8) sc8[t] = 0.0;
+}
 __global__ void publish_kernel(const double* __restrict__ scal, const double* __restrict__ red8,
                                const int* __restrict__ flags, HostMirror* m, unsigned long long seq) {
   const int t = threadIdx.x;  // 64 threads
@@ -415,6 +434,14 @@ struct tmi_ba_solver {
   bool mf_ok = false;
   ddg::Plan dd = {};          // camera side without camera-major records (direct_diag.h); direct_ok: built
   bool direct_ok = false;
+  // camera_finish_kernel (direct_diag.h) instead of the separate reduce / finish_diag / precond / pcg_init launches;
+  // TMI_BA_FUSED_FINISH=0 keeps the separate launches (tests hold the two to each other)
+  bool fuse_finish_ok = true;
+  // the product class hands its HIP events to the launches (Timed, attach); TMI_BA_ATTACH_EVENTS=0 records them on the stream
+  bool attach_events = true;
+  // PCG: the next iteration is enqueued before the host has read the current one's stopping test (solve_reduced_pcg);
+  // TMI_BA_PCG_SPECULATE=0 switches it off
+  bool pcg_speculate = true;
   bool cost_by_view = false;   // ... and the trial cost view by view (every observation owns a slot)
   bool cost_warm = true;       // ... which also reads linearize's observation stream into the Infinity Cache (TMI_BA_COST_WARM=0: off)
   bool implicit = false;      // S is never formed (schur_mode)
@@ -550,12 +577,17 @@ int dev_upload(tmi_ba_solver* s, T** p, const std::vector<T>& h) {
   return TMI_BA_OK;
 }
 
+// HIP events around the launches of one kernel class.  attach = true: the events are not recorded here (a record is a
+// barrier packet of its own on the stream: ~7 us of idle device per record, 2.7 % of the headline iteration with the two
+// records per product) but handed to the launches -- hipExtLaunchKernelGGL takes the start time of the first kernel
+// and the end time of the last one from the dispatch packets' own completion signals (start() / stop()).
 struct Timed {
   tmi_ba_solver* s;
   int cls;
   bool on;
+  bool attached;
   tmi_ba_solver::Ev* ev = nullptr;
-  Timed(tmi_ba_solver* s_, int cls_) : s(s_), cls(cls_) {
+  Timed(tmi_ba_solver* s_, int cls_, bool attach = false) : s(s_), cls(cls_), attached(attach) {
     s->launches[cls]++;
     on = (s->prof_mask >> cls) & 1u;
     if (on) {
@@ -568,11 +600,13 @@ struct Timed {
       }
       ev = &s->events[s->ev_used++];
       ev->cls = cls;
-      hipEventRecord(ev->a, s->stream);
+      if (!attached) hipEventRecord(ev->a, s->stream);
     }
   }
+  hipEvent_t start() const { return on && attached ? ev->a : nullptr; }
+  hipEvent_t stop() const { return on && attached ? ev->b : nullptr; }
   ~Timed() {
-    if (on) hipEventRecord(ev->b, s->stream);
+    if (on && !attached) hipEventRecord(ev->b, s->stream);
   }
 };
 
@@ -2134,6 +2168,14 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   // direct_diag.h: matrix-free iterations of the one-sweep product build the camera side without camera-major records
   // (TMI_BA_DIRECT_DIAG=0 keeps the records: A/B, tests)
   s->direct_ok = false;
+  {
+    const char* env = getenv("TMI_BA_FUSED_FINISH");
+    s->fuse_finish_ok = !(env && env[0] == '0');
+    env = getenv("TMI_BA_ATTACH_EVENTS");
+    s->attach_events = !(env && env[0] == '0');
+    env = getenv("TMI_BA_PCG_SPECULATE");
+    s->pcg_speculate = !(env && env[0] == '0');
+  }
   v.direct_diag = 0;
   {
     const char* e = getenv("TMI_BA_DIRECT_DIAG");
@@ -2407,7 +2449,7 @@ static void prepare_cameras(tmi_ba_solver* s, const double* ext, const double* i
 // returns TMI_BA_OK; *usable = 0 for LINEAR_SOLVER_FAILURE
 // q = S x: explicit (symmetric block SpMV on the formed Schur complement) or implicit
 // (two passes over the observations; the reduced vector is all-reduced across ranks)
-static int apply_schur(tmi_ba_solver* s, const double* x, double* y, int dot = 0, int xs_ready = 0) {
+static int apply_schur(tmi_ba_solver* s, const double* x, double* y, int dot = 0, int xs_ready = 0, const int* guard = nullptr) {
   DeviceView& v = s->v;
   const int n = v.Nrb * v.D;
   if (!s->implicit_now) {
@@ -2416,12 +2458,12 @@ static int apply_schur(tmi_ba_solver* s, const double* x, double* y, int dot = 0
     return TMI_BA_OK;
   }
   {
-    Timed t(s, TMI_BA_K_SPMV);
+    Timed t(s, TMI_BA_K_SPMV, /*attach=*/s->mf_ok && s->attach_events);
     const tmi_ba_options* O = s->cur_opts;
     const int add_diag = (s->st.world <= 1 || s->st.rank == 0) ? 1 : 0;
     if (s->mf_ok)
       s->launch.mf_product(v, s->mf, s->stream, s->RL, x, y, s->cur_inv_radius, O->min_lm_diagonal, O->max_lm_diagonal,
-                           add_diag, dot, xs_ready);
+                           add_diag, dot, xs_ready, t.start(), t.stop(), guard);
     else
       s->launch.implicit_spmv(v, s->stream, s->RL, x, y, s->d_pm_u, s->d_cm_t, s->cur_inv_radius,
                               O->min_lm_diagonal, O->max_lm_diagonal, add_diag, s->nblocks_tracks, dot);
@@ -2599,13 +2641,13 @@ static int apply_clusters(tmi_ba_solver* s, const double* r, double* z) {
 }
 
 static inline double st_nub_bytes(const tmi_ba_solver* s) { return 8.0 * (double)s->st.nub * s->st.D * s->st.D; }
-static int solve_reduced_pcg(tmi_ba_solver* s, const tmi_ba_options* O, int* usable, int64_t* iters) {
+static int solve_reduced_pcg(tmi_ba_solver* s, const tmi_ba_options* O, int* usable, int64_t* iters, bool init_done = false) {
   DeviceView& v = s->v;
   const int n = v.Nrb * v.D;
   const double* b = v.red + s->RL.gt;
   *usable = 1;
   if (n == 0) return TMI_BA_OK;
-  {
+  if (!init_done) {  // (init_done: camera_finish left x, r, z, p and rho)
     // x = 0, r = b, z = M^-1 b, p = z, rho: one multi-workgroup launch
     Timed t(s, TMI_BA_K_PCG_VECTOR);
     s->launch.pcg_init(v, s->stream, b, (v.Nrb + kPcgStepThreads / 64 - 1) / (kPcgStepThreads / 64));
@@ -2615,8 +2657,8 @@ static int solve_reduced_pcg(tmi_ba_solver* s, const tmi_ba_options* O, int* usa
       hipLaunchKernelGGL(clp::cluster_init_fix_kernel, dim3(1), dim3(1024), 0, s->stream, v, n);
     }
   }
-  // Fused path (no shared intrinsics blocks): an iteration is  product (+ p.q) -> [all-reduce] -> pcg_step -> pcg_p,
-  // four launches and one poll of the host mirror.  Every tenth iteration recomputes the residual
+  // Fused path (no shared intrinsics blocks): an iteration is  product (+ p.q) -> [all-reduce] -> pcg_step (whose last
+  // workgroup also forms p for the next product), three launches and one poll of the host mirror.  Every tenth iteration recomputes the residual
   // (residual_reset_period) through the three-kernel path below.  (Enqueueing iteration it + 1 speculatively before
   // the scalars of iteration it are read measured no gain on MI355X -- 5.02 vs 5.04 ms per LM iteration at one GPU,
   // 1.57 vs 1.53 ms for an eighth of the tracks, profiles/r02_g -- and is gone.)
@@ -2708,20 +2750,49 @@ static int solve_reduced_pcg(tmi_ba_solver* s, const tmi_ba_options* O, int* usa
   const int nbs16 = (v.Nrb + kPcgStepThreads / 64 - 1) / (kPcgStepThreads / 64);  // workgroups of pcg_step
   // drop_pos: pcg_init and pcg_p leave the scaled copy of p the product gathers; the three-kernel path does not
   bool xs_valid = !s->cl_active;
+  // One fused iteration: product (+ p.q) -> [all-reduce] -> pcg_step, which publishes to slot (it & 1) of the host mirror.
+  // guard != null: the kernels return at once when the previous step's stopping test held (DeviceView::pcg_done).
+  auto enqueue_step = [&](int it_, const int* guard, unsigned long long* seq_out) -> int {
+    const int rcs = apply_schur(s, v.cg_p, v.cg_q, /*dot=*/1, xs_valid ? 1 : 0, guard);
+    if (rcs) return rcs;
+    xs_valid = true;  // (pcg_step leaves the scaled copy of the next p)
+    Timed t(s, TMI_BA_K_PCG_VECTOR);
+    *seq_out = ++s->mirror_seq;
+    s->launch.pcg_step(v, s->stream, b, it_, nbs16, O->eta, O->min_linear_solver_iterations, O->max_linear_solver_iterations,
+                       v.red + s->RL.scalars, s->d_mirror + (it_ & 1), *seq_out, guard);
+    return TMI_BA_OK;
+  };
+  // Round 6: iteration it + 1 is enqueued BEFORE the host reads the scalars of iteration it.  The host's round trip
+  // (mirror write over PCIe, poll, three launches) left the device idle for ~20 us after every pcg_step
+  // (profiles/r06_a_gaps.md); now it sits behind the next product, and a solve that has stopped costs three launches
+  // that return at once -- while the host is on that same round trip.  (Round 2 measured no gain from this: an LM
+  // iteration took 5 ms then and every PCG iteration was four launches and a poll.)  Only with the one-sweep product
+  // (its kernels carry the guard) and never across a residual-reset iteration (another launch sequence).
+  const bool speculate = fused && s->pcg_speculate && s->implicit_now && s->mf_ok;
+  bool pending = false;  // iteration `it` is already enqueued (speculatively, during iteration it - 1)
+  unsigned long long pending_seq = 0;
+  size_t spec_ev_mark = 0;
+  long long spec_launches[TMI_BA_NUM_KERNEL_CLASSES];
+  // a speculative iteration that found PCG stopped did nothing: its launches and event pairs do not count
+  auto void_speculation = [&]() {
+    if (!pending) return;
+    for (size_t i = spec_ev_mark; i < s->ev_used; ++i) s->events[i].cls = -1;
+    for (int c = 0; c < TMI_BA_NUM_KERNEL_CLASSES; ++c) s->launches[c] = spec_launches[c];
+    pending = false;
+  };
   int it;
   for (it = 1;; ++it) {
     const bool reset = (it % 10 == 0);  // residual_reset_period
     int rc;
     if (fused && !reset) {
-      if ((rc = apply_schur(s, v.cg_p, v.cg_q, /*dot=*/1, xs_valid ? 1 : 0))) return rc;
-      xs_valid = true;  // (pcg_p below)
-      unsigned long long my_seq;
-      {
-        Timed t(s, TMI_BA_K_PCG_VECTOR);
-        my_seq = ++s->mirror_seq;
-        s->launch.pcg_step(v, s->stream, b, it, nbs16, O->eta, O->min_linear_solver_iterations,
-                           O->max_linear_solver_iterations, v.red + s->RL.scalars, s->d_mirror + (it & 1), my_seq);
-        hipLaunchKernelGGL(pcg_p_kernel, dim3((n + 255) / 256), dim3(256), 0, s->stream, v, n);
+      unsigned long long my_seq = pending_seq;
+      if (!pending && (rc = enqueue_step(it, nullptr, &my_seq))) return rc;
+      pending = false;
+      if (speculate && (it + 1) % 10 != 0 && it + 1 <= O->max_linear_solver_iterations) {
+        spec_ev_mark = s->ev_used;
+        for (int c = 0; c < TMI_BA_NUM_KERNEL_CLASSES; ++c) spec_launches[c] = s->launches[c];
+        if ((rc = enqueue_step(it + 1, v.pcg_done, &pending_seq))) return rc;
+        pending = true;
       }
       if ((rc = wait_mirror(s, it & 1, my_seq))) return rc;
     } else {
@@ -2770,6 +2841,13 @@ static int solve_reduced_pcg(tmi_ba_solver* s, const tmi_ba_options* O, int* usa
       *usable = 0;
       break;
     }
+    if (pending && s->h_scal[SC_PCG_STOP] != 0.0 && (s->h_scal[SC_PQ] > 0.0) &&
+        !((s->h_scal[SC_ZETA] < O->eta && it >= O->min_linear_solver_iterations) || it >= O->max_linear_solver_iterations ||
+          s->h_scal[SC_RHO_BAD] != 0.0)) {
+      // pcg_step's stopping test and the host's below are the same rules; should they ever disagree (p.q = +inf), the
+      // device's answer stands: the speculative step has already returned without publishing
+      break;
+    }
     if (s->cl_active && s->h_flags[FL_CHOL_ABORT]) {
       // A dataflow launch of the cluster preconditioner could not become co-resident (another process holds part of
       // the device) and gave up: nothing it produced is to be trusted.  As the exact solver does (solve_reduced_dense),
@@ -2790,6 +2868,7 @@ static int solve_reduced_pcg(tmi_ba_solver* s, const tmi_ba_options* O, int* usa
       break;
     }
   }
+  void_speculation();
   *iters += it;
   return TMI_BA_OK;
 }
@@ -3158,8 +3237,8 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
   auto linearize = [&]() {
     // cost and sum of squares land in d_sc[0..1] (finished by the kernel's last workgroup)
     Timed t(s, TMI_BA_K_LINEARIZE);
+    // (drop_pos: the kernel also leaves -w / scale_p of every track, at the point and the scales the planes are taken at)
     s->launch.linearize(v, stream, v.prep, lt, lw, nbs, d_sc);
-    s->launch.pos_coef(v, stream, v.pts);  // (drop_pos: -w / scale_p of the point and the scales the planes were taken at)
   };
   linearize();
   // d_sc[0] = cost, d_sc[1] = ss, d_sc[2] = #ranks with an invalid residual
@@ -3200,7 +3279,7 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
     }
   };
   // builds the camera side of the normal equations from the current linearisation
-  auto build_camera_side = [&](double inv_radius) {
+  auto build_camera_side = [&](double inv_radius, bool skip_direct_reduce = false) {
     {
       Timed t(s, TMI_BA_K_POINT_ELIMINATE);
       s->launch.point_eliminate(v, stream, inv_radius, O->min_lm_diagonal, O->max_lm_diagonal, nbs,
@@ -3209,7 +3288,7 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
     {
       Timed t(s, TMI_BA_K_CAMERA_DIAG);
       if (v.direct_diag) {
-        s->launch.camera_diag_direct(v, stream, RL, s->dd, v.prep, lt, lw);
+        s->launch.camera_diag_direct(v, stream, RL, s->dd, v.prep, lt, lw, skip_direct_reduce ? 1 : 0);
       } else {
         s->launch.camera_diag(v, stream, RL, s->shared_diag_chunks, s->d_shared_diag_partial);
         s->launch.shared_blocks(v, stream, RL);
@@ -3287,8 +3366,7 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
       row[0] = iter; row[1] = cost; row[2] = radius_used; row[3] = outcome; row[4] = cand; row[5] = mcc;
       row[6] = (double)(pcg_iters - pcg_before); row[7] = step;
     };
-    CKH(hipMemsetAsync(v.flags, 0, FL_COUNT * sizeof(int), stream));
-    CKH(hipMemsetAsync(d_sc, 0, 8 * sizeof(double), stream));
+    hipLaunchKernelGGL(iteration_begin_kernel, dim3(1), dim3(64), 0, stream, v.flags, d_sc);  // flags = 0, d_sc[0..7] = 0
     s->cur_inv_radius = inv_radius;
     if (s->adaptive && iterative && !s->st.has_shared) {
       // Forming S pays off after adaptive_break_even products (set at create from the sizes): short PCG
@@ -3302,14 +3380,28 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
       s->n_implicit_iterations++;
     }
     v.direct_diag = (s->direct_ok && iterative && s->implicit_now && !s->cluster_blocks) ? 1 : 0;
-    build_camera_side(inv_radius);
+    // one launch for [chunk sums ->] diagonal blocks -> block inverses -> start of PCG (direct_diag.h, camera_finish_kernel)
+    // wherever no cluster factorisation sits between the preconditioner blocks and PCG's first residual
+    const bool cluster_handle = s->st.has_shared || s->vis_clusters;
+    const bool cluster_precond = O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_JACOBI ||
+                                 O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_TRIDIAGONAL;
+    const bool fuse_finish = s->fuse_finish_ok && iterative && n_r > 0 && !(cluster_handle && cluster_precond);
+    const bool fuse_direct = fuse_finish && v.direct_diag && st.world == 1;
+    build_camera_side(inv_radius, fuse_direct);
     if (!s->implicit_now || s->cluster_blocks) {
       Timed t(s, TMI_BA_K_SCHUR_OFFDIAG);
       s->launch.schur_offdiag(v, stream, RL);
       s->launch.cross_add(v, stream, RL);
     }
     CK(do_allreduce(s, v.red, RL.total));  // d_sc[6] carries the singular-track votes
-    {
+    const int precond_mode = O->preconditioner_type == TMI_BA_PRECOND_IDENTITY ? 1
+                             : O->preconditioner_type == TMI_BA_PRECOND_SCHUR_JACOBI_PARAMETER_BLOCKS ? 2 : 0;
+    if (fuse_finish) {
+      Timed t(s, TMI_BA_K_PRECONDITIONER);
+      s->launch.camera_finish(v, stream, RL, s->dd, inv_radius, O->min_lm_diagonal, O->max_lm_diagonal,
+                              need_gradient_check ? 1 : 0, precond_mode, fuse_direct ? 1 : 0);
+      s->cl_active = false;
+    } else {
       // diagonal blocks + LM diagonal; with the gradient test pending also max |g_c / scale|
       // (max |g_p / scale| was finished by point_eliminate's last workgroup)
       Timed t(s, TMI_BA_K_REDUCE);
@@ -3317,11 +3409,9 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
     }
     int usable = 1;
     if (iterative) {
-      {
+      if (!fuse_finish) {
         Timed t(s, TMI_BA_K_PRECONDITIONER);
-        s->launch.precond(v, stream,
-                          O->preconditioner_type == TMI_BA_PRECOND_IDENTITY ? 1
-                          : O->preconditioner_type == TMI_BA_PRECOND_SCHUR_JACOBI_PARAMETER_BLOCKS ? 2 : 0);
+        s->launch.precond(v, stream, precond_mode);
         // CLUSTER_JACOBI / CLUSTER_TRIDIAGONAL on a problem with shared intrinsics blocks: the exact inverse of every
         // {shared block, its views} cluster (needs the cluster's blocks of S: the formed operator)
         s->cl_active = (s->tri ? O->preconditioner_type == TMI_BA_PRECOND_CLUSTER_TRIDIAGONAL
@@ -3346,7 +3436,7 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
       if (s->cl_active && s->cl_failed) {
         usable = 0;  // the tridiagonal preconditioner could not be factored, scaled or not: the linear solve fails (Ceres)
       } else {
-        CK(solve_reduced_pcg(s, O, &usable, &pcg_iters));
+        CK(solve_reduced_pcg(s, O, &usable, &pcg_iters, fuse_finish));
       }
       last_pcg_len = (int)(pcg_iters - before);
       // what this iteration's PCG ran with (tmi_ba_summary::effective_preconditioner_type): the clusters only while
@@ -3398,13 +3488,17 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
     bool cand_invalid = false;
     if (usable) {
       {
+        // candidate cameras + their prepared records (+ the scaled copy of y_c back_substitute gathers: first)
+        Timed t(s, TMI_BA_K_UPDATE_COST);
+        s->launch.update_cameras(v, stream, v.scal + SC_STEP_SQ, v.prep_c);
+      }
+      {
+        // y_p, the model cost change, the candidate points and their share of |step|^2, |x+|^2: d_sc[0..2]
         Timed t(s, TMI_BA_K_BACK_SUBSTITUTE);
         s->launch.back_substitute(v, stream, nbs, v.partial, d_sc + 0);
       }
       {
         Timed t(s, TMI_BA_K_UPDATE_COST);
-        s->launch.update_cameras(v, stream, v.scal + SC_STEP_SQ, v.prep_c);  // candidate cameras + their prepared records
-        s->launch.update_points(v, stream, nbp, v.partial, d_sc + 1);
         // d_sc: [mcc, step_sq_points, |x+|^2 points, cand_cost, cand_ss, invalid votes, singular
         //        track votes, time-limit votes]
         trial_cost();
@@ -3547,6 +3641,7 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
   for (int c = 0; c < TMI_BA_NUM_KERNEL_CLASSES; ++c) sum->kernel_launches[c] = s->launches[c];
   for (size_t i = 0; i < s->ev_used; ++i) {
     float ms = 0.f;
+    if (s->events[i].cls < 0) continue;  // (a speculative PCG iteration that found the solve stopped)
     if (hipEventElapsedTime(&ms, s->events[i].a, s->events[i].b) == hipSuccess)
       sum->kernel_seconds[s->events[i].cls] += 1e-3 * ms;
   }

@@ -496,6 +496,12 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
     pconst = v.pt_const[lp] != 0;
 #pragma unroll
     for (int a = 0; a < DP; ++a) sp[a] = v.scale_p[(size_t)lp * DP + a];
+    // drop_pos (device_view.h): pos_coef[a][track] = -w / scale_p[a] at the point and the scales these planes are taken at
+    // (round 6: was a launch of its own after every linearize)
+    if (!SH && (UDROP || v.drop_pos) && tm.leader) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) v.pos_coef[(size_t)a * v.Np_pad + lp] = -X[3] / sp[a];
+    }
   }
   int cam_next = (tm.j0 < k) ? v.obs_cam[tm.base + (size_t)tm.j0 * 64] : -1;
 #ifdef TMI_LIN_PROFILE
@@ -684,16 +690,8 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
   block_sum_finish<2>(acc, v.partial, nblocks, v.ticket + 2 * kTicketStride, sums);
 }
 
-// drop_pos (device_view.h): pos_coef[a][track] = -w / scale_p[a] at the point the planes were linearized at
-template <int DP>
-__global__ __launch_bounds__(256) void pos_coef_kernel(DeviceView v, const double* __restrict__ pts) {
-  const int lp = blockIdx.x * 256 + threadIdx.x;
-  if (lp >= v.Np_pad) return;
-  const double w = pts[(size_t)lp * 4 + 3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) v.pos_coef[(size_t)a * v.Np_pad + lp] = -w / v.scale_p[(size_t)lp * DP + a];
-}
-// ... and xs = x with the position entries of every view block times the block's column scales
+// drop_pos: xs = x with the position entries of every view block times the block's column scales (device_view.h)
+
 template <int D>
 __global__ __launch_bounds__(256) void pos_scale_kernel(DeviceView v, const double* __restrict__ x, double* __restrict__ xs) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -2575,21 +2573,26 @@ __global__ __launch_bounds__(1024) void pcg_b3_kernel(DeviceView v, int n, int i
 // kernel delivered p.q behind the product vector): pcg_step -- every workgroup forms alpha itself,
 // updates x, r and z = M^-1 r of its blocks and hands over its partial sums of Q1 and rho'; the last
 // workgroup to arrive finishes the sums in a fixed order, does the scalar recurrences, decides
-// whether PCG stops (so that kernels enqueued speculatively for the next iteration return at once)
-// and publishes the scalars to the host mirror -- then pcg_p: p = z + beta p (a vector that
-// crosses workgroups must cross a kernel boundary, see the hand-over note at the top).
+// whether PCG stops, forms p = z + beta p for the next product (round 6: until then a launch of its own, pcg_p --
+// z is handed over like the partial sums: agent-scope stores by the workgroups that form it, agent-scope loads by the
+// last one, see the hand-over note at the top; p and its scaled copy then cross the kernel boundary to the product)
+// and publishes the scalars to the host mirror.
 constexpr int kPcgStepThreads = 1024;
 template <int D>
 __global__ __launch_bounds__(kPcgStepThreads) void pcg_step_kernel(DeviceView v, const double* __restrict__ b, int it,
                                                        int nblocks, double eta, int min_it, int max_it,
                                                        const double* __restrict__ red8, HostMirror* mirror,
-                                                       unsigned long long seq) {
+                                                       unsigned long long seq, const int* guard) {
   constexpr int T = kPcgStepThreads, W = T / 64;
+  // (guard: a step enqueued before the host had read the previous one's stopping test -- nothing to do once that held)
+  if (guard && *guard) return;
   __shared__ double sh[2][T];
   __shared__ double shw[2][W];
   __shared__ double pub[SC_COUNT];
   __shared__ int pubf[FL_COUNT];
   __shared__ int last;
+  __shared__ double beta_sh;
+  __shared__ int stop_sh;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int rb = blockIdx.x * W + wv;
   const int n = v.Nrb * D;
@@ -2616,7 +2619,7 @@ __global__ __launch_bounds__(kPcgStepThreads) void pcg_step_kernel(DeviceView v,
       if (lane < D) z += M[c] * rc;
     }
     if (lane < D) {
-      v.cg_z[i] = z;
+      st_agent(&v.cg_z[i], z);  // (read by the last workgroup below)
       acc[1] = rn * z;
     }
   }
@@ -2685,29 +2688,29 @@ __global__ __launch_bounds__(kPcgStepThreads) void pcg_step_kernel(DeviceView v,
     // the host's stopping rules (solve_reduced_pcg): pcg_p, enqueued behind this kernel, has nothing to do once they hold
     const bool stop = pubf[FL_PCG_FAIL] != 0 || !ok || (zeta < eta && it >= min_it) || it >= max_it || rho_bad != 0.0;
     *v.pcg_done = stop ? 1 : 0;
+    set(SC_PCG_STOP, stop ? 1.0 : 0.0);
+    stop_sh = stop ? 1 : 0;
+    beta_sh = ok ? rho_new / rho : 0.0;
   }
   __syncthreads();
-  // publish (what publish_kernel does)
   const int t = threadIdx.x;
+  if (!stop_sh) {
+    // p = z + beta p, beta = rho' / rho, and (drop_pos) the copy the next product gathers: position entries times the
+    // column scales (pos_scale_kernel's job for any other vector)
+    const double beta = beta_sh;
+    for (int i = t; i < n; i += T) {
+      const double pn = ld_agent(&v.cg_z[i]) + beta * v.cg_p[i];
+      v.cg_p[i] = pn;
+      if (v.drop_pos) v.xs[i] = (i % D) < 3 ? pn * v.scale_c[i] : pn;
+    }
+  }
+  // publish (what publish_kernel does)
   if (t < SC_COUNT) mirror->scal[t] = pub[t];
   if (t < 8) mirror->red[t] = red8[t];
   if (t < FL_COUNT) mirror->flags[t] = pubf[t];
   __threadfence_system();
   __syncthreads();
   if (t == 0) __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// p = z + beta p, beta = rho / last_rho (both left by pcg_step); nothing if PCG has stopped
-__global__ __launch_bounds__(256) void pcg_p_kernel(DeviceView v, int n) {
-  if (*v.pcg_done) return;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const double beta = v.scal[SC_RHO] / v.scal[SC_LAST_RHO];
-  const double pn = v.cg_z[i] + beta * v.cg_p[i];
-  v.cg_p[i] = pn;
-  // drop_pos: the copy the next product gathers, position entries times the column scales (pos_scale_kernel's job
-  // for any other vector)
-  if (v.drop_pos) v.xs[i] = (i % v.D) < 3 ? pn * v.scale_c[i] : pn;
 }
 
 // Start of a PCG solve in one launch (pcg_begin + the first pcg_a): x = 0, r = b, z = M^-1 b,
@@ -2916,12 +2919,15 @@ __global__ __launch_bounds__(256) void back_substitute_kernel(DeviceView v, int 
   PT* const pmJp = reinterpret_cast<PT*>(v.pm_Jp);
   (void)pmR; (void)pmA; (void)pmA1; (void)pmJp;
   const TrackMap tm = track_map(v);
-  double acc[1] = {0.0};
+  double acc[3] = {0.0, 0.0, 0.0};
   if (tm.valid) {
     const int lp = tm.lp;
     const int k = tm.k;
     const size_t base = tm.base;
     const size_t NP = (size_t)v.Np_pad;
+    double ypv[DP];
+#pragma unroll
+    for (int a = 0; a < DP; ++a) ypv[a] = 0.0;
     if (k > 0) {
       double w[DP];
 #pragma unroll
@@ -3010,6 +3016,7 @@ __global__ __launch_bounds__(256) void back_substitute_kernel(DeviceView v, int 
 #pragma unroll
           for (int b = 0; b < DP; ++b) t += Vi[a <= b ? sym_idx(a, b, DP) : sym_idx(b, a, DP)] * w[b];
           yp[a] = t;
+          ypv[a] = t;
           v.yp[(size_t)a * NP + lp] = t;
         }
         double lin = 0.0, quad = 0.0;
@@ -3025,38 +3032,36 @@ __global__ __launch_bounds__(256) void back_substitute_kernel(DeviceView v, int 
         acc[0] += lin - 0.5 * quad;
       }
     }
+    if (tm.leader) {
+      // the candidate point x - scale .* y on the free coordinates and the tracks' share of |step|^2 and |x+|^2
+      // (round 6: update_points_kernel's job, here where y_p is in registers -- one launch and a sweep over
+      // y_p / the points less per LM iteration; a track without observations or a constant point is copied)
+      const bool live = k > 0 && !v.pt_const[lp];
+      const double2 x01 = *reinterpret_cast<const double2*>(v.pts + (size_t)lp * 4);
+      const double2 x23 = *reinterpret_cast<const double2*>(v.pts + (size_t)lp * 4 + 2);
+      double x[4] = {x01.x, x01.y, x23.x, x23.y};
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        if (live && a < DP) {
+          const double d = -ypv[a < DP ? a : 0] * v.scale_p[(size_t)lp * DP + (a < DP ? a : 0)];
+          x[a] += d;
+          acc[1] += d * d;
+        }
+        if (live) acc[2] += x[a] * x[a];
+      }
+      *reinterpret_cast<double2*>(v.pts_c + (size_t)lp * 4) = make_double2(x[0], x[1]);
+      *reinterpret_cast<double2*>(v.pts_c + (size_t)lp * 4 + 2) = make_double2(x[2], x[3]);
+    }
   }
-  block_sum_finish<1>(acc, partial, nblocks, v.ticket + 2 * kTicketStride, sums);
+  // sums[0] = model cost change, sums[1] = |step|^2 over the points, sums[2] = |x+|^2 over the points
+  block_sum_finish<3>(acc, partial, nblocks, v.ticket + 2 * kTicketStride, sums);
 }
 
 // ------------------------------------------------------------------------------
 // update (kernel class 9): candidate = x - scale .* y on the free coordinates.
-// Points: one thread per track, partial sums [step^2, |x+|^2] for the tracks.
-// Cameras: single workgroup (the camera part is replicated on every rank).
+// Points: by back_substitute_kernel, where y_p is in registers (partial sums [step^2, |x+|^2] for the tracks).
+// Cameras: update_cameras_kernel (the camera part is replicated on every rank).
 // ------------------------------------------------------------------------------
-template <int DP>
-__global__ __launch_bounds__(256) void update_points_kernel(DeviceView v, int nblocks, double* partial,
-                                                            double* __restrict__ sums) {
-  const int lp = blockIdx.x * 256 + threadIdx.x;
-  double acc[2] = {0.0, 0.0};
-  if (lp < v.Np_pad) {
-    const size_t NP = (size_t)v.Np_pad;
-    const bool live = v.pt_k[lp] > 0 && !v.pt_const[lp];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      double x = v.pts[(size_t)lp * 4 + a];
-      if (live && a < DP) {
-        const double d = -v.yp[(size_t)a * NP + lp] * v.scale_p[(size_t)lp * DP + a];
-        x += d;
-        acc[0] += d * d;
-      }
-      v.pts_c[(size_t)lp * 4 + a] = x;
-      if (live) acc[1] += x * x;
-    }
-  }
-  block_sum_finish<2>(acc, partial, nblocks, v.ticket + 2 * kTicketStride, sums);
-}
-
 // |x|^2 over the live tracks of a parameter set
 __global__ __launch_bounds__(256) void points_norm_kernel(DeviceView v, const double* __restrict__ pts,
                                                           int nblocks, double* partial,
@@ -3130,6 +3135,16 @@ __global__ __launch_bounds__(256) void update_cameras_kernel(DeviceView v, doubl
         for (int j = 0; j < 10; ++j) xn += K[j] * K[j];
     }
     if (!SH) prepare_camera_record(e, K, rec.z, v.scale_cam + (size_t)c * 16, prep_c + (size_t)c * kPrepStride);
+    if (!SH && v.drop_pos && rb >= 0) {
+      // drop_pos: the copy of y_c back_substitute gathers, position entries times the column scales (round 6:
+      // pos_scale_kernel's job -- this launch runs BEFORE back_substitute and owns the view's block anyway)
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        const size_t i = (size_t)rb * D + a;
+        const double y = v.yc[i];
+        v.xs[i] = a < 3 ? y * v.scale_c[i] : y;
+      }
+    }
   } else if (SH && c < v.Nc + n_groups_sh) {
     const int grb = v.Ncam_rb + (c - v.Nc);
     const int g = v.rb_grp[grb];

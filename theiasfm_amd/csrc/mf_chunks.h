@@ -70,6 +70,8 @@ struct View {
   long long* prof;           // TMI_MF_PROFILE builds: per item {cycles of 10 phases, units, start-up, write-out}
   double* partial;           // [n_slots][D]
   double* ut;                // [elements of the wavefront-per-track slices][2]
+  const int* guard;          // null, or DeviceView::pcg_done: a product enqueued ahead of PCG's stopping test returns at once
+                             // when the test held (engine.hip, solve_reduced_pcg)
 };
 
 struct UnitShape {
@@ -310,6 +312,7 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
   double (*wpart)[DP][64] = reinterpret_cast<double (*)[DP][64]>(vbuf);
   __shared__ double zs[kWaves][DP][64];
   __shared__ double acc[LCM * D];
+  if (m.guard && *m.guard) return;
   const int item = m.item_order[blockIdx.x];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 
@@ -757,6 +760,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(DeviceView v, View m, RedLa
                                                      double lm_hi, int add_diag, int dot) {
   __shared__ double sh[4][D];
   __shared__ double prod[D];
+  if (m.guard && *m.guard) return;
   const int chunk = ((int)gridDim.x) >> 3;
   const int rb = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
   const bool live = rb < v.Nrb;  // the padding workgroups still take part in the dot product's ticket
