@@ -2768,7 +2768,8 @@ static int solve_reduced_pcg(tmi_ba_solver* s, const tmi_ba_options* O, int* usa
   // that return at once -- while the host is on that same round trip.  (Round 2 measured no gain from this: an LM
   // iteration took 5 ms then and every PCG iteration was four launches and a poll.)  Only with the one-sweep product
   // (its kernels carry the guard) and never across a residual-reset iteration (another launch sequence).
-  const bool speculate = fused && s->pcg_speculate && s->implicit_now && s->mf_ok;
+  // One rank only: a collective enqueued ahead cannot be skipped, a stopped solve would pay one more all-reduce.
+  const bool speculate = fused && s->pcg_speculate && s->implicit_now && s->mf_ok && s->st.world == 1;
   bool pending = false;  // iteration `it` is already enqueued (speculatively, during iteration it - 1)
   unsigned long long pending_seq = 0;
   size_t spec_ev_mark = 0;

@@ -32,6 +32,10 @@
 #include "kernels.h"
 
 namespace tmi {
+#ifndef TMI_MF_ABL
+#define TMI_MF_ABL 0  // timing experiments, results wrong by construction (bit 0: no run sums, 1: x gathers from eight cached
+                      // blocks, 2: the v_i not stored to LDS, 3: no slot write-out); profiles/r06_product_experiments.md
+#endif
 namespace mfc {
 
 constexpr int kWaves = 4;  // two workgroups per CU (<= 80 KB of LDS each), two wavefronts per SIMD
@@ -524,7 +528,11 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
       for (int a = 0; a < DP; ++a) jr[rr][a] = make_double2(0.0, 0.0);
       if (R < rows) {
         // the view's block of x: D doubles at an 8-byte aligned address, fetched 16 bytes at a time
+#if TMI_MF_ABL & 2
+        const double* xc = x + (size_t)(lane & 7) * D;  // (timing experiment: eight cache-resident blocks)
+#else
         const double* xc = x + (size_t)max(nrb[rr], 0) * D;
+#endif
 #pragma unroll
         for (int a = 0; a + 1 < D; a += 2) {
           const double2_a8 t2 = *reinterpret_cast<const double2_a8*>(xc + a);
@@ -645,7 +653,11 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
         uu[rr][0] -= jr[rr][a].x * za;
         uu[rr][1] -= jr[rr][a].y * za;
       }
+#if TMI_MF_ABL & 4
+      if (pos[rr] >= 0 && uu[rr][0] == 1.2345e301) {  // (timing experiment: the v_i are formed but not stored)
+#else
       if (pos[rr] >= 0) {
+#endif
         double* dst = &vbuf[pos[rr] * D];
 #pragma unroll
         for (int a = A0; a < D; ++a) dst[a] = ar[rr][a].x * uu[rr][0] + ar[rr][a].y * uu[rr][1];
@@ -682,7 +694,12 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
       const bool mine = r0 + 4 * (lane + 64 * q) + w < r1;
       const int b = ma[q] - o0, e = mb[q] - o0;
       is_long[q] = __ballot(mine && e - b > kLongRun);
+#if TMI_MF_ABL & 1
+      is_long[q] = 0;  // (timing experiment: no run sums at all)
+      if (false) {
+#else
       if (mine && e - b <= kLongRun) {
+#endif
         double sum[D];
 #pragma unroll
         for (int a = 0; a < D; ++a) sum[a] = 0.0;
@@ -734,7 +751,11 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
 #ifdef TMI_MF_PROFILE
   const long long t_loop = clock64();
 #endif
+#if TMI_MF_ABL & 8
+  if (!direct && x[0] == 1.2345e301) {  // (timing experiment: the item's slots are not written)
+#else
   if (!direct) {
+#endif
     __syncthreads();  // acc
     double* out = m.partial + (size_t)slot0 * D;
     for (int i = threadIdx.x; i < nlc * D; i += kThreads) out[i] = acc[i];
