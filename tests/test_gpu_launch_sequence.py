@@ -7,6 +7,9 @@ src/theia/sfm/bundle_adjustment/bundle_adjuster.cc:205) from ~36 to ~27:
   (TMI_BA_FUSED_FINISH=0 keeps the separate launches),
 * PCG's next iteration is enqueued before the host has read the current one's stopping test, its kernels return at once
   when the test held (TMI_BA_PCG_SPECULATE=0: the host reads first),
+* the start of a solve writes no planes before their Jacobi scales are known: a norms-only `linearize` (cost + the point
+  columns' scales) and `camera_diag_direct` on records that carry the points alone replace linearize + point_scale +
+  point_eliminate (TMI_BA_FAST_START=0: the three-pass start),
 * `pcg_step`'s last workgroup forms p (was `pcg_p`), `back_substitute` writes the candidate points (was `update_points`),
   `linearize` leaves the position coefficients (was `pos_coef`), `update_cameras` the scaled copy of y_c (was `pos_scale`).
 
@@ -23,15 +26,16 @@ from theiasfm_amd import abi, lib, synth
 
 pytestmark = pytest.mark.gpu
 
-ENV = ("TMI_BA_FUSED_FINISH", "TMI_BA_PCG_SPECULATE", "TMI_BA_MF_ONE_SWEEP", "TMI_BA_ATTACH_EVENTS")
+ENV = ("TMI_BA_FUSED_FINISH", "TMI_BA_PCG_SPECULATE", "TMI_BA_MF_ONE_SWEEP", "TMI_BA_ATTACH_EVENTS", "TMI_BA_FAST_START")
 
 
-def run(prob, fused, speculate, attach=True, profile=0, **kw):
+def run(prob, fused, speculate, attach=True, profile=0, fast_start=True, **kw):
     saved = {k: os.environ.pop(k, None) for k in ENV}
     try:
         os.environ["TMI_BA_FUSED_FINISH"] = "1" if fused else "0"
         os.environ["TMI_BA_PCG_SPECULATE"] = "1" if speculate else "0"
         os.environ["TMI_BA_ATTACH_EVENTS"] = "1" if attach else "0"
+        os.environ["TMI_BA_FAST_START"] = "1" if fast_start else "0"
         os.environ["TMI_BA_MF_ONE_SWEEP"] = "1"  # (the one-sweep product below its size threshold: its kernels carry the guard)
         p = prob.copy()
         kw.setdefault("max_num_iterations", 8)
@@ -117,3 +121,26 @@ def test_voided_speculation_is_not_counted():
     # the attached events leave out the two barrier packets: never longer than the recorded ones by more than noise
     assert b.kernel_seconds[spmv] < 1.5 * a.kernel_seconds[spmv] + 1e-4
     assert b.kernel_seconds[spmv] > 0.3 * a.kernel_seconds[spmv]
+
+
+@pytest.mark.parametrize("name", ["matrix_free_dof3", "matrix_free_dof4_parameter_blocks", "matrix_free_identity_cauchy", "auto",
+                                  "rejected_steps"])
+def test_fast_start_gives_the_same_bits(name):
+    """the norms-only first pass sums what point_scale summed, in its order; the U diagonal comes out of the same kernel:
+    scale_p, scale_c and with them the whole trajectory are the three-pass start's, bit for bit"""
+    make, kw = CASES[name]
+    prob = make()
+    same_bits(run(prob, True, True, fast_start=False, **dict(kw)), run(prob, True, True, fast_start=True, **dict(kw)))
+
+
+def test_fast_start_mixed_models_and_constant_blocks():
+    """the generic body of the norms-only pass (camera-model switch, column masks), constant points, a constant position"""
+    prob = synth.make_problem(48, 6000, 36000, seed=33, scene="ring", spread=0.5,
+                              models=[(abi.PINHOLE, 0.2), (abi.PINHOLE_RADIAL_TANGENTIAL, 0.2), (abi.FISHEYE, 0.2), (abi.FOV, 0.2),
+                                      (abi.DIVISION_UNDISTORTION, 0.2)],
+                              intrinsics_to_optimize=abi.INTRINSICS_FOCAL_LENGTH | abi.INTRINSICS_PRINCIPAL_POINTS)
+    prob.point_constant[5] = 1
+    prob.point_constant[77] = 1
+    prob.camera_flags[3] = abi.CAMERA_ORIENTATION_CONSTANT
+    kw = dict(point_dof=3, loss_function_type=abi.LOSS_SOFTLONE, robust_loss_width=2.0, **IMPL)
+    same_bits(run(prob, True, True, fast_start=False, **dict(kw)), run(prob, True, True, fast_start=True, **dict(kw)))

@@ -73,6 +73,23 @@ __global__ __launch_bounds__(256) void slot_gather_kernel(DeviceView v, int* __r
   }
 }
 
+// Start of a solve (round 6): the Jacobi scales of the camera columns need the U diagonal of the UNSCALED Jacobian, i.e.
+// camera_diag_direct before any track has been eliminated -- its records then carry the point only (L^-1 = 0: Q = 0,
+// N = I; what the launch leaves besides the U diagonal is not used).  Replaces a point_eliminate pass over planes that
+// the norms-only linearize (kernels.h, NORMS) no longer writes.
+template <int DP>
+__global__ __launch_bounds__(256) void track_records_points_only_kernel(DeviceView v, const double* __restrict__ pts) {
+  constexpr int TR = trk_stride(DP);
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // one 16-byte piece of a record per thread
+  const long long n = (long long)v.Np_pad * (TR / 2);
+  if (i >= n) return;
+  const long long lp = i / (TR / 2);
+  const int part = (int)(i - lp * (TR / 2));
+  double2 val = make_double2(0.0, 0.0);
+  if (part < 2) val = *reinterpret_cast<const double2*>(pts + lp * 4 + 2 * part);
+  *reinterpret_cast<double2*>(v.trk_rec + lp * TR + 2 * part) = val;
+}
+
 // The sums run on v_mfma_f64_4x4x4f64: FOUR independent 4 x 4 x 4 products per instruction (16 cycles; the 16 x 16 x 4
 // form takes 64 cycles and a 9 x 11 result would use 99 of its 256 outputs).  Layout found with tools/mfma_probe
 // (lane = 16 g + 4 b + e): block b takes A_b[i = e][k = g] and B_b[k = g][j = e] and holds D_b[i = g][j = e].

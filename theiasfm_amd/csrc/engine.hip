@@ -62,7 +62,9 @@ static double now_s() {
 struct Launch {
   // evaluation at a parameter set through its prepared camera records; `sums` / `flag_dst`:
   // where the kernel's last workgroup leaves the grid-wide sums / the invalid-residual vote
-  void (*linearize)(const DeviceView&, hipStream_t, const double* prep, int, double, int, double* sums);
+  // norms != 0 (fp64 evaluation only): no planes; cost sums and scale_p from the unscaled column norms (kernels.h, NORMS)
+  void (*linearize)(const DeviceView&, hipStream_t, const double* prep, int, double, int, double* sums, int norms);
+  void (*track_records_points_only)(const DeviceView&, hipStream_t, const double* pts);
   void (*cost)(const DeviceView&, hipStream_t, const double* prep, const double* pts, int, double, int, int,
                double* partial, double* sums, double* flag_dst);
   void (*point_scale)(const DeviceView&, hipStream_t, int);
@@ -109,7 +111,7 @@ template <int D, int DP, bool SH>
 Launch make_launch(bool fp32) {
   Launch L;
   if (fp32) {
-    L.linearize = [](const DeviceView& v, hipStream_t st, const double* prep, int lt, double lw, int nb, double* sums) {
+    L.linearize = [](const DeviceView& v, hipStream_t st, const double* prep, int lt, double lw, int nb, double* sums, int) {
       hipLaunchKernelGGL((linearize_kernel<D, DP, SH, float, 2>), dim3(nb), dim3(256), 0, st, v, prep, lt, lw, nb, sums);
     };
     L.cost = [](const DeviceView& v, hipStream_t st, const double* prep, const double* p, int lt, double lw, int fl,
@@ -117,7 +119,24 @@ Launch make_launch(bool fp32) {
       hipLaunchKernelGGL((cost_kernel<DP, float>), dim3(nb), dim3(256), 0, st, v, prep, p, lt, lw, fl, nb, partial, sums, flag_dst);
     };
   } else {
-    L.linearize = [](const DeviceView& v, hipStream_t st, const double* prep, int lt, double lw, int nb, double* sums) {
+    L.linearize = [](const DeviceView& v, hipStream_t st, const double* prep, int lt, double lw, int nb, double* sums, int norms) {
+      if constexpr (!SH) {
+        if (norms) {
+          // start of a solve: cost + the Jacobi scales of the point columns, no planes (kernels.h, NORMS)
+          bool special = false;
+          if constexpr (D == 9) {
+            if (v.uniform_pinhole_default && lt == 0) {
+              hipLaunchKernelGGL((linearize_kernel<D, DP, SH, double, 2, double, 0, kPinholeDefaultMask, true, true>), dim3(nb), dim3(256),
+                                 0, st, v, prep, lt, lw, nb, sums);
+              special = true;
+            }
+          }
+          if (!special)
+            hipLaunchKernelGGL((linearize_kernel<D, DP, SH, double, 2, double, -1, 0u, false, true>), dim3(nb), dim3(256), 0, st, v,
+                               prep, lt, lw, nb, sums);
+          return;
+        }
+      }
       if constexpr (!SH && D == 9) {
         // every camera a PINHOLE with extrinsics + focal length + two radial terms free (the BAL / reference default,
         // bundle_adjustment.h:95) and no robust loss: the specialised body (kernels.h, UMODEL / UMASK)
@@ -140,6 +159,11 @@ Launch make_launch(bool fp32) {
   }
   L.point_scale = [](const DeviceView& v, hipStream_t st, int nb) {
     hipLaunchKernelGGL((point_scale_kernel<DP>), dim3(nb), dim3(256), 0, st, v);
+  };
+  L.track_records_points_only = [](const DeviceView& v, hipStream_t st, const double* pts) {
+    const long long n = (long long)v.Np_pad * (ddg::trk_stride(DP) / 2);
+    if (n && v.trk_rec)
+      hipLaunchKernelGGL((ddg::track_records_points_only_kernel<DP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, v, pts);
   };
   L.shared_blocks = [](const DeviceView& v, hipStream_t st, RedLayout R) {
     if (!SH || v.Nrb == v.Ncam_rb) return;
@@ -308,7 +332,7 @@ Launch make_launch(bool fp32) {
       // fp32 evaluation on a problem with shared intrinsics blocks (BASELINE config 5): the per-observation planes are
       // STORED in fp32 as well (DeviceView::planes_fp32; sums and everything per track / per view stay fp64) -- the
       // kernels that touch the planes, in their float instantiation
-      L.linearize = [](const DeviceView& v, hipStream_t st, const double* prep, int lt, double lw, int nb, double* sums) {
+      L.linearize = [](const DeviceView& v, hipStream_t st, const double* prep, int lt, double lw, int nb, double* sums, int) {
         hipLaunchKernelGGL((linearize_kernel<D, DP, SH, float, 2, float>), dim3(nb), dim3(256), 0, st, v, prep, lt, lw, nb, sums);
       };
       L.point_scale = [](const DeviceView& v, hipStream_t st, int nb) {
@@ -442,6 +466,7 @@ struct tmi_ba_solver {
   // PCG: the next iteration is enqueued before the host has read the current one's stopping test (solve_reduced_pcg);
   // TMI_BA_PCG_SPECULATE=0 switches it off
   bool pcg_speculate = true;
+  bool fast_start_ok = true;  // TMI_BA_FAST_START=0: linearize + point_scale + point_eliminate before the scaled linearize
   bool cost_by_view = false;   // ... and the trial cost view by view (every observation owns a slot)
   bool cost_warm = true;       // ... which also reads linearize's observation stream into the Infinity Cache (TMI_BA_COST_WARM=0: off)
   bool implicit = false;      // S is never formed (schur_mode)
@@ -2175,6 +2200,8 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
     s->attach_events = !(env && env[0] == '0');
     env = getenv("TMI_BA_PCG_SPECULATE");
     s->pcg_speculate = !(env && env[0] == '0');
+    env = getenv("TMI_BA_FAST_START");
+    s->fast_start_ok = !(env && env[0] == '0');
   }
   v.direct_diag = 0;
   {
@@ -3235,13 +3262,20 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
   s->launch.expand_scale(v, stream);
   prepare_cameras(s, v.ext, v.intr, v.prep);
   hipLaunchKernelGGL(fill_kernel, dim3((unsigned)(((long long)st.Np_pad * s->DP + 255) / 256 + 1)), dim3(256), 0, stream, v.scale_p, (long long)st.Np_pad * s->DP, 1.0);
-  auto linearize = [&]() {
+  auto linearize = [&](bool norms_only = false) {
     // cost and sum of squares land in d_sc[0..1] (finished by the kernel's last workgroup)
     Timed t(s, TMI_BA_K_LINEARIZE);
     // (drop_pos: the kernel also leaves -w / scale_p of every track, at the point and the scales the planes are taken at)
-    s->launch.linearize(v, stream, v.prep, lt, lw, nbs, d_sc);
+    s->launch.linearize(v, stream, v.prep, lt, lw, nbs, d_sc, norms_only ? 1 : 0);
   };
-  linearize();
+  // (direct_diag.h) the pre-pass below only needs the U diagonal: without records whenever the handle can
+  v.direct_diag = (s->direct_ok && iterative) ? 1 : 0;
+  // Round 6: where the camera side is built view by view (no camera-major records) the start of a solve writes no
+  // planes before their Jacobi scales are known: the first pass is the norms-only linearize (cost + scale_p), the
+  // U diagonal comes from camera_diag_direct on records that carry the points alone -- instead of a full linearize,
+  // point_scale and point_eliminate (0.9 -> 0.6 ms at Venice size).  TMI_BA_FAST_START=0: the three-pass start.
+  const bool fast_start = O->jacobi_scaling && v.direct_diag && s->fast_start_ok;  // (direct_ok implies fp64 evaluation)
+  linearize(fast_start);
   // d_sc[0] = cost, d_sc[1] = ss, d_sc[2] = #ranks with an invalid residual
   hipLaunchKernelGGL(flag_to_scalar_kernel, dim3(1), dim3(64), 0, stream, v.flags + FL_INVALID, d_sc + 2);
   CK(do_allreduce(s, d_sc, 8));
@@ -3296,17 +3330,22 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
       }
     }
   };
-  // (direct_diag.h) the pre-pass below only needs the U diagonal: without records whenever the handle can
-  v.direct_diag = (s->direct_ok && iterative) ? 1 : 0;
   if (O->jacobi_scaling) {
     // Jacobi scaling 1 / (1 + ||column||) from the UNSCALED Jacobian at the start point:
     // track columns directly, camera-side columns as the diagonal of J_c^T J_c which a
     // first pass of point_eliminate + camera_diag leaves in `red` (udiag).
-    {
-      Timed t(s, TMI_BA_K_REDUCE);
-      s->launch.point_scale(v, stream, nbs);
+    if (fast_start) {
+      // (scale_p is the norms-only linearize's; records = the points alone)
+      Timed t(s, TMI_BA_K_CAMERA_DIAG);
+      s->launch.track_records_points_only(v, stream, v.pts);
+      s->launch.camera_diag_direct(v, stream, RL, s->dd, v.prep, lt, lw, 0);
+    } else {
+      {
+        Timed t(s, TMI_BA_K_REDUCE);
+        s->launch.point_scale(v, stream, nbs);
+      }
+      build_camera_side(1.0);
     }
-    build_camera_side(1.0);
     CK(do_allreduce(s, v.red + RL.udiag, n_r));
     {
       Timed t(s, TMI_BA_K_REDUCE);
@@ -4484,7 +4523,7 @@ int32_t tmi_ba_solver_evaluate(tmi_ba_solver* s, double* residuals, double* jac_
   {
     DeviceView ve = v;  // (the caller gets every column: stored, not formed from Jp)
     ve.drop_pos = 0;
-    s->launch.linearize(ve, stream, v.prep, 0, 1.0, s->nblocks_tracks, nullptr);
+    s->launch.linearize(ve, stream, v.prep, 0, 1.0, s->nblocks_tracks, nullptr, 0);
   }
   const size_t N = (size_t)st.No_pad;
   std::vector<double> r(residuals ? 2 * N : 0), A(jac_camera ? (size_t)2 * D * N : 0),

@@ -465,8 +465,12 @@ __device__ unsigned long long g_lin_prof[8];
 // never formed and the per-observation gather of cam_rec goes -- ~100 registers less than the generic body.
 // UDROP: the handle does not store the position columns (DeviceView::drop_pos is set): known at compile time, M is dead
 // once the point block is out.
+// NORMS (round 6): the start of a solve needs the cost and the squared column norms of the UNSCALED Jacobian (Ceres'
+// jacobi_scaling, 1 / (1 + ||column||)) before the planes can be written with their scales: this instantiation stores no
+// plane at all -- it sums the point block's column norms per track and leaves scale_p itself (point_scale_kernel's job,
+// same sums in the same order), never stages the second half record, and takes a third of the time of the full pass.
 template <int D, int DP, bool SH, typename RT, int OCC, typename PT = double, int UMODEL = -1, unsigned UMASK = 0u,
-          bool UDROP = false>
+          bool UDROP = false, bool NORMS = false>
 __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const double* __restrict__ prep,
                                                              int loss_type_arg, double loss_width, int nblocks,
                                                              double* __restrict__ sums) {
@@ -483,6 +487,12 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
   double* st = stage[threadIdx.x >> 6];
   const double* P = st + lane * kStagePitch;
   double acc[2] = {0.0, 0.0};
+  auto PST = [&](double val, PT* ptr) {
+    if constexpr (!NORMS) plane_store<PT>(val, ptr);
+  };
+  double n2[DP];  // NORMS: squared norms of the point block's columns over the track's observations
+#pragma unroll
+  for (int a = 0; a < DP; ++a) n2[a] = 0.0;
   const int lp = tm.lp;
   const int k = tm.k;  // 0 for padding tracks and beyond the last slice
   double X[4] = {0.0, 0.0, 0.0, 1.0};
@@ -495,10 +505,10 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
     for (int i = 0; i < 4; ++i) X[i] = v.pts[(size_t)lp * 4 + i];
     pconst = v.pt_const[lp] != 0;
 #pragma unroll
-    for (int a = 0; a < DP; ++a) sp[a] = v.scale_p[(size_t)lp * DP + a];
+    for (int a = 0; a < DP; ++a) sp[a] = NORMS ? 1.0 : v.scale_p[(size_t)lp * DP + a];
     // drop_pos (device_view.h): pos_coef[a][track] = -w / scale_p[a] at the point and the scales these planes are taken at
     // (round 6: was a launch of its own after every linearize)
-    if (!SH && (UDROP || v.drop_pos) && tm.leader) {
+    if (!NORMS && !SH && (UDROP || v.drop_pos) && tm.leader) {
 #pragma unroll
       for (int a = 0; a < 3; ++a) v.pos_coef[(size_t)a * v.Np_pad + lp] = -X[3] / sp[a];
     }
@@ -598,25 +608,33 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
           j0 = sqrt_rho1 * (j0 - asn * r[0] * rtj);
           j1 = sqrt_rho1 * (j1 - asn * r[1] * rtj);
         }
-        plane_store<PT>(j0 * sp[a], &pmJp[pidx<2 * DP>((2 * a), e)]);
-        plane_store<PT>(j1 * sp[a], &pmJp[pidx<2 * DP>((2 * a + 1), e)]);
+        PST(j0 * sp[a], &pmJp[pidx<2 * DP>((2 * a), e)]);
+        PST(j1 * sp[a], &pmJp[pidx<2 * DP>((2 * a + 1), e)]);
+        if constexpr (NORMS) {
+          const double s0 = j0 * sp[a], s1 = j1 * sp[a];  // (what point_scale_kernel reads back from the planes)
+          n2[a] += s0 * s0 + s1 * s1;
+        }
       }
-      plane_store<PT>(r[0] * rscale, &pmR[pidx<2>(0, e)]);
-      plane_store<PT>(r[1] * rscale, &pmR[pidx<2>(1, e)]);
+      PST(r[0] * rscale, &pmR[pidx<2>(0, e)]);
+      PST(r[1] * rscale, &pmR[pidx<2>(1, e)]);
     }
     LIN_LAP(2);
+    if constexpr (NORMS) {
+      if (act && !ok) v.flags[FL_INVALID] = 1;
+      continue;  // nothing of the camera block is stored: no second half record
+    }
     stage_camera_records(prep, kStageWords, cam, st, lane);
     LIN_LAP(3);
     // ---- phase B: P[0..8] = Jl diag(scale_w), P[9..11] = position scales, P[12..21] = intrinsics scales
     if (!act) continue;
     if (!ok) {
       v.flags[FL_INVALID] = 1;
-      for (int d = 0; d < 2 * D; ++d) plane_store<PT>(0.0, &pmA[pidx<2 * D>(d, e)]);
+      for (int d = 0; d < 2 * D; ++d) PST(0.0, &pmA[pidx<2 * D>(d, e)]);
       if (SH)
-        for (int d = 0; d < 2 * D; ++d) plane_store<PT>(0.0, &pmA1[pidx<2 * D>(d, e)]);
-      for (int d = 0; d < 2 * DP; ++d) plane_store<PT>(0.0, &pmJp[pidx<2 * DP>(d, e)]);
-      plane_store<PT>(0.0, &pmR[pidx<2>(0, e)]);
-      plane_store<PT>(0.0, &pmR[pidx<2>(1, e)]);
+        for (int d = 0; d < 2 * D; ++d) PST(0.0, &pmA1[pidx<2 * D>(d, e)]);
+      for (int d = 0; d < 2 * DP; ++d) PST(0.0, &pmJp[pidx<2 * DP>(d, e)]);
+      PST(0.0, &pmR[pidx<2>(0, e)]);
+      PST(0.0, &pmR[pidx<2>(1, e)]);
       continue;
     }
     const double wneg = -X[3];
@@ -647,13 +665,13 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
           j1 = sqrt_rho1 * (j1 - asn * r[1] * rtj);
         }
         if (!(c < 3 && !SH && (UDROP || v.drop_pos))) {  // (drop_pos: the position columns are not stored, device_view.h)
-          plane_store<PT>(j0 * scl, &pmA[pidx<2 * D>((2 * dst), e)]);
-          plane_store<PT>(j1 * scl, &pmA[pidx<2 * D>((2 * dst + 1), e)]);
+          PST(j0 * scl, &pmA[pidx<2 * D>((2 * dst), e)]);
+          PST(j1 * scl, &pmA[pidx<2 * D>((2 * dst + 1), e)]);
         }
         ++dst;
       }
     }
-    for (int d = 2 * dst; d < 2 * D; ++d) plane_store<PT>(0.0, &pmA[pidx<2 * D>(d, e)]);
+    for (int d = 2 * dst; d < 2 * D; ++d) PST(0.0, &pmA[pidx<2 * D>(d, e)]);
     if (SH) {
       // free intrinsics shared between views: their columns go to the group's own block
       const int grb = v.cam_grb[cam];
@@ -670,13 +688,13 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
               j1 = sqrt_rho1 * (j1 - asn * r[1] * rtj);
             }
             const double scl = P[12 + c];
-            plane_store<PT>(j0 * scl, &pmA1[pidx<2 * D>((2 * dst1), e)]);
-            plane_store<PT>(j1 * scl, &pmA1[pidx<2 * D>((2 * dst1 + 1), e)]);
+            PST(j0 * scl, &pmA1[pidx<2 * D>((2 * dst1), e)]);
+            PST(j1 * scl, &pmA1[pidx<2 * D>((2 * dst1 + 1), e)]);
             ++dst1;
           }
         }
       }
-      for (int d = 2 * dst1; d < 2 * D; ++d) plane_store<PT>(0.0, &pmA1[pidx<2 * D>(d, e)]);
+      for (int d = 2 * dst1; d < 2 * D; ++d) PST(0.0, &pmA1[pidx<2 * D>(d, e)]);
     }
     LIN_LAP(4);
   }
@@ -687,6 +705,13 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
     atomicAdd(&g_lin_prof[6], 1ull);
   }
 #endif
+  if constexpr (NORMS) {
+#pragma unroll
+    for (int a = 0; a < DP; ++a) {
+      const double t = group_sum(n2[a], tm.wide);
+      if (tm.valid && tm.leader) v.scale_p[(size_t)lp * DP + a] = 1.0 / (1.0 + sqrt(t));
+    }
+  }
   block_sum_finish<2>(acc, v.partial, nblocks, v.ticket + 2 * kTicketStride, sums);
 }
 
