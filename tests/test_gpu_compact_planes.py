@@ -1,0 +1,164 @@
+"""-m gpu: compact planes (device_view.h, DeviceView::compact) against the stored camera block.
+
+On the all-PINHOLE / default-mask / TRIVIAL-loss problem (every BAL problem, an unchanged Theia caller:
+bundle_adjustment.h:95, pinhole_camera_model.h:86-94) with unit aspect ratio and zero skew, the 2 x 9 camera block of
+ReprojectionError (reprojection_error.h:51-95) is a function of the point block, the normalised image point, the track and
+the view; matrix-free iterations then store p_n (16 bytes) instead of the block (96 bytes) and the product / back-substitution
+gather a transformed view vector.  TMI_BA_COMPACT_PLANES=0 keeps the stored block.
+
+The two are the same operator evaluated in another order: identical LM / PCG iteration counts, costs and parameters to
+round-off -- over both point parameterisations, long tracks (16 and 64 lanes per track, wavefront-per-track units), a view
+with zero rotation (the first-order branch of AngleAxisRotatePoint), both SCHUR_JACOBI shapes, inner iterations, the
+adaptive operator (an iteration that forms S re-linearizes with the full planes) and a sharded solve; and problems the
+compact form does not cover (robust loss, aspect ratio != 1, another mask) must not take it."""
+import os
+
+import numpy as np
+import pytest
+
+from theiasfm_amd import abi, lib, synth
+
+pytestmark = pytest.mark.gpu
+
+IMPL = dict(linear_solver_type=abi.ITERATIVE_SCHUR, schur_mode=abi.SCHUR_IMPLICIT)
+
+
+def run(prob, compact, **kw):
+    saved = {k: os.environ.pop(k, None) for k in ("TMI_BA_COMPACT_PLANES", "TMI_BA_MF_ONE_SWEEP")}
+    try:
+        os.environ["TMI_BA_COMPACT_PLANES"] = "1" if compact else "0"
+        os.environ["TMI_BA_MF_ONE_SWEEP"] = "1"  # (the one-sweep product below its size threshold)
+        p = prob.copy()
+        kw.setdefault("max_num_iterations", 8)
+        o = abi.default_options(use_inner_iterations=kw.pop("use_inner_iterations", 0), profile_kernels=1, **kw)
+        trace = abi.attach_trace(o, kw["max_num_iterations"])
+        st, s = lib.solve(p, o)
+        assert st == 0, s.message
+        return s, p, trace
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+
+
+def same_trajectory(a, b, rtol=1e-7, trace_rtol=1e-8, atol=1e-9):
+    sa, pa, ta = a
+    sb, pb, tb = b
+    assert sa.num_iterations == sb.num_iterations
+    assert sa.num_successful_steps == sb.num_successful_steps and sa.num_unsuccessful_steps == sb.num_unsuccessful_steps
+    assert sa.num_linear_solver_iterations == sb.num_linear_solver_iterations
+    assert sa.termination == sb.termination
+    assert abs(sa.final_cost - sb.final_cost) <= 1e-10 * abs(sa.final_cost)
+    n = sa.num_iterations
+    assert np.array_equal(ta[:n, 3], tb[:n, 3]) and np.array_equal(ta[:n, 6], tb[:n, 6])
+    ok = np.isfinite(ta[:n]) & np.isfinite(tb[:n])
+    np.testing.assert_allclose(ta[:n][ok], tb[:n][ok], rtol=trace_rtol, atol=0)
+    # (parameters: PCG stops at eta = 0.1, so a round-off difference in the operator moves an iterate by ~1e-9 of its
+    #  size -- more along the scale gauge of homogeneous points; the costs above agree to 1e-10)
+    np.testing.assert_allclose(pa.points, pb.points, rtol=rtol, atol=atol)
+    np.testing.assert_allclose(pa.extrinsics, pb.extrinsics, rtol=rtol, atol=atol)
+    np.testing.assert_allclose(pa.intrinsics, pb.intrinsics, rtol=rtol, atol=atol)
+
+
+def lin_us(s):
+    i = abi.KERNEL_CLASS_NAMES.index("linearize")
+    return s.kernel_seconds[i] / max(s.kernel_launches[i], 1)
+
+
+def zero_rotation_view(prob):
+    """view 0 with the identity rotation: theta^2 <= DBL_EPSILON takes the first-order branch (R = I, Jl = I)"""
+    prob.extrinsics[0, 3:6] = 0.0
+    sel = np.flatnonzero(prob.obs_camera == 0)
+    prob.obs_xy[sel] = synth.project(prob, sel) + 0.3
+    return prob
+
+
+CASES = {
+    "dof3": (lambda: synth.make_problem(60, 9000, 50000, seed=41, scene="ring", spread=0.4), dict(point_dof=3, **IMPL)),
+    "dof4_parameter_blocks": (lambda: synth.make_problem(60, 9000, 50000, seed=43, scene="ring", spread=0.4),
+                              dict(point_dof=4, preconditioner_type=abi.PRECOND_SCHUR_JACOBI_PARAMETER_BLOCKS, **IMPL)),
+    "heavy_tail": (lambda: synth.make_problem(320, 30000, 190000, seed=7, scene="ring", spread=0.6, heavy_tail=0.01),
+                   dict(point_dof=3, max_num_iterations=6, **IMPL)),
+    "heavy_tail_dof4": (lambda: synth.make_problem(320, 30000, 190000, seed=8, scene="ring", spread=0.6, heavy_tail=0.01),
+                        dict(point_dof=4, max_num_iterations=5, **IMPL)),
+    "zero_rotation_view": (lambda: zero_rotation_view(synth.make_problem(40, 6000, 32000, seed=45, scene="ring", spread=0.5)),
+                           dict(point_dof=3, **IMPL)),
+    "identity_preconditioner": (lambda: synth.make_problem(40, 6000, 32000, seed=46, scene="ring", spread=0.5),
+                                dict(point_dof=3, preconditioner_type=abi.PRECOND_IDENTITY, **IMPL)),
+    "inner_iterations": (lambda: synth.make_problem(40, 5000, 28000, seed=57, scene="ring", spread=0.5),
+                         dict(point_dof=4, use_inner_iterations=1, max_num_iterations=5, **IMPL)),
+    "rejected_steps": (lambda: synth.make_problem(40, 5000, 28000, seed=55, scene="ring", spread=0.5),
+                       dict(point_dof=3, initial_trust_region_radius=1e12, max_num_iterations=10, **IMPL)),
+    "auto": (lambda: synth.make_problem(50, 7000, 40000, seed=49, scene="ring", spread=0.5),
+             dict(point_dof=3, linear_solver_type=abi.ITERATIVE_SCHUR, schur_mode=abi.SCHUR_AUTO)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_compact_planes_walk_the_same_trajectory(name):
+    make, kw = CASES[name]
+    prob = make()
+    a = run(prob, False, **dict(kw))
+    b = run(prob, True, **dict(kw))
+    assert a[0].num_linear_solver_iterations > 0
+    # (IDENTITY: PCG on the unpreconditioned reduced system amplifies round-off in the operator by its condition number;
+    #  the model cost change and step norm of the late iterations then agree to ~1e-5, the costs still to 1e-10)
+    loose = kw.get("preconditioner_type") == abi.PRECOND_IDENTITY
+    same_trajectory(a, b, rtol=1e-4 if loose else 1e-7, trace_rtol=1e-3 if loose else 1e-8, atol=1e-5 if loose else 1e-9)
+
+
+def test_landmark_tracks_take_the_wavefront_per_track_units():
+    """tracks that every one of 560 views sees: the product's wide path (u and t through the global scratch)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("one_sweep_cases", os.path.join(os.path.dirname(__file__), "test_gpu_one_sweep.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    with_landmarks = mod.with_landmarks
+    prob = with_landmarks(synth.make_problem(560, 12000, 70000, seed=13, scene="ring", spread=0.5, heavy_tail=0.01), 6, 14)
+    kw = dict(point_dof=3, max_num_iterations=5, **IMPL)
+    same_trajectory(run(prob, False, **dict(kw)), run(prob, True, **dict(kw)))
+
+
+def test_compact_planes_are_taken_and_cheaper_to_write():
+    """the specialised linearize stores 80 instead of 160 bytes per observation"""
+    prob = synth.make_problem(200, 60000, 400000, seed=3, scene="ring", spread=0.4)
+    kw = dict(point_dof=3, max_num_iterations=4, **IMPL)
+    a = run(prob, False, **dict(kw))[0]
+    b = run(prob, True, **dict(kw))[0]
+    assert lin_us(b) < 0.95 * lin_us(a)
+
+
+@pytest.mark.parametrize("name", ["huber", "aspect_ratio", "mask", "radtan"])
+def test_problems_outside_the_compact_form_keep_the_full_planes(name):
+    """the switch must change nothing -- bit for bit -- where the compact form does not apply"""
+    kw = dict(point_dof=3, **IMPL)
+    if name == "huber":
+        prob = synth.make_problem(40, 6000, 32000, seed=61, scene="ring", spread=0.5, heavy_tail=0.01)
+        kw.update(loss_function_type=abi.LOSS_HUBER, robust_loss_width=2.0)
+    elif name == "aspect_ratio":
+        prob = synth.make_problem(40, 6000, 32000, seed=62, scene="ring", spread=0.5)
+        prob.intrinsics[1] = 1.02  # the first view's aspect ratio (constant under the default mask)
+        sel = np.flatnonzero(prob.obs_camera == 0)
+        prob.obs_xy[sel] = synth.project(prob, sel) + 0.3
+    elif name == "mask":
+        prob = synth.make_problem(40, 6000, 32000, seed=63, scene="ring", spread=0.5,
+                                  intrinsics_to_optimize=abi.INTRINSICS_FOCAL_LENGTH | abi.INTRINSICS_PRINCIPAL_POINTS)
+    else:
+        prob = synth.make_problem(30, 4000, 22000, seed=64, scene="ring", spread=0.5, models=[(abi.PINHOLE_RADIAL_TANGENTIAL, 1.0)])
+    a = run(prob, False, **dict(kw))
+    b = run(prob, True, **dict(kw))
+    assert a[0].final_cost == b[0].final_cost and np.array_equal(a[2], b[2], equal_nan=True)
+    assert np.array_equal(a[1].points, b[1].points) and np.array_equal(a[1].extrinsics, b[1].extrinsics)
+
+
+def test_skewed_view_keeps_the_full_planes_and_matches_the_oracle_minimum():
+    """skew != 0 on one view: the handle must fall back (a compact evaluation would drop the skew term of the k1, k2 columns)"""
+    prob = synth.make_problem(30, 4000, 22000, seed=65, scene="ring", spread=0.5)
+    prob.intrinsics[2] = 0.01 * prob.intrinsics[0]
+    sel = np.flatnonzero(prob.obs_camera == 0)
+    prob.obs_xy[sel] = synth.project(prob, sel) + 0.3
+    kw = dict(point_dof=3, **IMPL)
+    a = run(prob, False, **dict(kw))
+    b = run(prob, True, **dict(kw))
+    assert a[0].final_cost == b[0].final_cost and np.array_equal(a[1].points, b[1].points)

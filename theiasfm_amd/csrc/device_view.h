@@ -116,6 +116,21 @@ struct DeviceView {
   int drop_pos;
   double* pos_coef;  // [3][Np_pad]
   double* xs;        // [Nrb D] the vector of the running product / back-substitution, position entries times scale_c
+  // compact (round 6, last session): on the all-PINHOLE / default-mask / TRIVIAL-loss problem with unit aspect ratio and
+  // zero skew the 2 x 9 camera block is a function of the point block Jp (2 x 3, stored anyway), the normalised image
+  // point p_n (2 doubles), the track's X and the VIEW's R, C, Jl, f, k1, k2 and column scales:
+  //   A_pos  = -w Jp' S_pos                      Jp' = Jp diag(1 / scale_p) = d r / d X[0:3]     (drop_pos, above)
+  //   A_rot  = -Jp' [X - w C]x R^T Jl S_rot      (d q / d w_k = Jl[:,k] x q, q = R (X - w C): camera_models.h)
+  //   A_int  = p_n [dist s_f, f r^2 s_k1, f r^4 s_k2],  r^2 = |p_n|^2, dist = 1 + k1 r^2 + k2 r^4
+  // so pm_A holds ONE 16-byte plane pair (p_n) instead of six, the product / back-substitution gather a TRANSFORMED
+  // view vector [kappa | eta | a0 a1 a2] (compact_forward, kernels.h) instead of [s_pos x_pos | x_rot | x_int] and form
+  //   A x = Jp' (eta x X - w kappa) + p_n (a0 + a1 r^2 + a2 r^4),
+  // and A^T t is accumulated per view as moments [-w h | X x h | (p_n . t)(1, r^2, r^4)], h = Jp'^T t, which
+  // reduce_kernel maps back (compact_backward).  80 of the 160 plane bytes per observation less for linearize,
+  // back_substitute and every matrix-free product.  Set per linearize by the engine (solve); 0: the full planes.
+  int compact;
+  double* cp_trk;   // [7][Np_pad] planes X0 X1 X2 w 1/scale_p[0..2] of the linearisation the planes belong to (linearize)
+  double* xz;       // [Nrb D] the transformed z of a PCG step (pcg_step: xs <- xz + beta xs)
   double* pm_Jp;
   double* pm_A1;    // [2 D][No_pad] shared-intrinsics Jacobian columns (has_shared only)
   int planes_fp32;  // round 5: residual_precision = 32 on a problem with shared intrinsics blocks STORES pm_r / pm_A / pm_A1 /

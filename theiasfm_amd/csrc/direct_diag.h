@@ -766,6 +766,9 @@ __global__ __launch_bounds__(64) void camera_finish_kernel(DeviceView v, RedLayo
   }
   // ---- pcg_init: x = 0, r = b, z = M^-1 b, p = z ----
   double acc = 0.0;
+  double zc = 0.0;
+  bool cpx = false;
+  if constexpr (D == 9) cpx = v.compact != 0;
   if (t < D) {
     const size_t i = (size_t)rb * D + t;
     const double rn = gt[t];
@@ -776,8 +779,12 @@ __global__ __launch_bounds__(64) void camera_finish_kernel(DeviceView v, RedLayo
     v.cg_r[i] = rn;
     v.cg_z[i] = z;
     v.cg_p[i] = z;
-    if (v.drop_pos) v.xs[i] = t < 3 ? z * v.scale_c[i] : z;
+    if (v.drop_pos && !cpx) v.xs[i] = t < 3 ? z * v.scale_c[i] : z;
     acc = rn * z;
+    zc = z;
+  }
+  if constexpr (D == 9) {
+    if (cpx) compact_forward_wave(v, rb, zc, t, v.xs);  // compact planes: the transformed block of p (kernels.h)
   }
   acc = wave_sum(acc);
   if (t == 0) {

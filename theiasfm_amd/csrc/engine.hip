@@ -40,6 +40,9 @@
 #include <hipcub/hipcub.hpp>
 #include "structure.h"
 
+#ifndef TMI_LIN_OCC
+#define TMI_LIN_OCC 2  // workgroups per CU the specialised linearize is compiled for (A/B builds: -DTMI_LIN_OCC=3)
+#endif
 namespace tmi {
 
 static double now_s() {
@@ -141,8 +144,11 @@ Launch make_launch(bool fp32) {
         // every camera a PINHOLE with extrinsics + focal length + two radial terms free (the BAL / reference default,
         // bundle_adjustment.h:95) and no robust loss: the specialised body (kernels.h, UMODEL / UMASK)
         if (v.uniform_pinhole_default && lt == 0) {
-          if (v.drop_pos)
-            hipLaunchKernelGGL((linearize_kernel<D, DP, SH, double, 2, double, 0, kPinholeDefaultMask, true>), dim3(nb), dim3(256), 0, st, v,
+          if (v.drop_pos && v.compact)  // compact planes (device_view.h): p_n instead of the camera block
+            hipLaunchKernelGGL((linearize_kernel<D, DP, SH, double, TMI_LIN_OCC, double, 0, kPinholeDefaultMask, true, false, true>), dim3(nb),
+                               dim3(256), 0, st, v, prep, lt, lw, nb, sums);
+          else if (v.drop_pos)
+            hipLaunchKernelGGL((linearize_kernel<D, DP, SH, double, TMI_LIN_OCC, double, 0, kPinholeDefaultMask, true>), dim3(nb), dim3(256), 0, st, v,
                                prep, lt, lw, nb, sums);
           else
             hipLaunchKernelGGL((linearize_kernel<D, DP, SH, double, 2, double, 0, kPinholeDefaultMask, false>), dim3(nb), dim3(256), 0, st, v,
@@ -294,7 +300,15 @@ Launch make_launch(bool fp32) {
       // position entries times the views' column scales, the reduce launch scales the position entries of the sums
       const int n = v.Nrb * D;
       if (!xs_ready) hipLaunchKernelGGL((pos_scale_kernel<D>), dim3((n + 255) / 256), dim3(256), 0, st, v, x, v.xs);
-      if (m.n_items)
+      bool cp_done = false;
+      if constexpr (D == 9) {
+        if (m.n_items && v.compact) {
+          hipExtLaunchKernelGGL((mfc::product_kernel<D, DP, true, true>), dim3(m.n_items), dim3(mfc::kThreads), 0, st, ev_a, nullptr, 0, v,
+                                m, (const double*)v.xs);
+          cp_done = true;
+        }
+      }
+      if (m.n_items && !cp_done)
         hipExtLaunchKernelGGL((mfc::product_kernel<D, DP, true>), dim3(m.n_items), dim3(mfc::kThreads), 0, st, ev_a, nullptr, 0, v, m,
                               (const double*)v.xs);
     } else if (m.n_items) {
@@ -448,6 +462,7 @@ struct tmi_ba_solver {
   int* h_flags = nullptr;     // = h_mirror->flags
   // initial parameters (for reset) in device order, on the host and resident in HBM
   std::vector<double> ext0, intr0, pts0;
+  std::vector<int> grp_off_h;  // [G + 1] offsets of the groups' intrinsics in intr0
   double *d_ext0 = nullptr, *d_intr0 = nullptr, *d_pts0 = nullptr;
   int n_intr = 0;
   // extra device arrays not in the view
@@ -467,6 +482,7 @@ struct tmi_ba_solver {
   // TMI_BA_PCG_SPECULATE=0 switches it off
   bool pcg_speculate = true;
   bool fast_start_ok = true;  // TMI_BA_FAST_START=0: linearize + point_scale + point_eliminate before the scaled linearize
+  bool compact_env = true;    // TMI_BA_COMPACT_PLANES=0: always the full planes (device_view.h, DeviceView::compact)
   bool cost_by_view = false;   // ... and the trial cost view by view (every observation owns a slot)
   bool cost_warm = true;       // ... which also reads linearize's observation stream into the Infinity Cache (TMI_BA_COST_WARM=0: off)
   bool implicit = false;      // S is never formed (schur_mode)
@@ -2018,6 +2034,7 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
   std::vector<int> cam_grp(P->camera_group, P->camera_group + st.Nc);
   std::vector<int> grp_model(P->group_model, P->group_model + st.G);
   std::vector<int> grp_off(P->group_offset, P->group_offset + st.G + 1);
+  s->grp_off_h = grp_off;
   std::vector<signed char> rb_cols(st.rb_cols.begin(), st.rb_cols.end());
   std::vector<long long> pair_ptr(st.pair_ptr.begin(), st.pair_ptr.end());
   {
@@ -2185,7 +2202,9 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
     for (int lp = 0; lp < st.Np_pad && ok; ++lp) ok = st.pt_const[lp] == 0;
     if (ok) {
       if ((rc = dev_alloc(s, &v.pos_coef, (size_t)3 * std::max(st.Np_pad, 1)))) return rc;
+      if ((rc = dev_alloc(s, &v.cp_trk, (size_t)7 * std::max(st.Np_pad, 1)))) return rc;
       if ((rc = dev_alloc(s, &v.xs, (size_t)std::max(st.Nrb, 1) * D + 8))) return rc;
+      if ((rc = dev_alloc(s, &v.xz, (size_t)std::max(st.Nrb, 1) * D + 8))) return rc;
       v.drop_pos = 1;
     }
   }
@@ -2202,6 +2221,8 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
     s->pcg_speculate = !(env && env[0] == '0');
     env = getenv("TMI_BA_FAST_START");
     s->fast_start_ok = !(env && env[0] == '0');
+    env = getenv("TMI_BA_COMPACT_PLANES");
+    s->compact_env = !(env && env[0] == '0');
   }
   v.direct_diag = 0;
   {
@@ -2983,6 +3004,8 @@ static int ensure_inner(tmi_ba_solver* s) {
   // sort of the layout's elements by camera (within a view: ascending element, as the host loop
   // it replaces produced), the view pointers by binary search, the track of every element alongside
   int *d_vo_ptr, *d_vo_e, *d_vo_lp;
+  double* d_vo_xy;  // the pixels in the same order: streamed by inner_eval (a 16-byte gather by element costs a 128-byte line)
+  if ((rc = dev_alloc(s, &d_vo_xy, 2 * (size_t)std::max<int64_t>(st.No_pad, 1)))) return rc;
   if ((rc = dev_alloc(s, &d_vo_ptr, (size_t)st.Nc + 2))) return rc;
   if ((rc = dev_alloc(s, &d_vo_e, (size_t)std::max<int64_t>(st.No_pad, 1)))) return rc;
   if ((rc = dev_alloc(s, &d_vo_lp, (size_t)std::max<int64_t>(st.No_pad, 1)))) return rc;
@@ -3013,6 +3036,8 @@ static int ensure_inner(tmi_ba_solver* s) {
       TMI_HIP(hipcub::DeviceRadixSort::SortPairs(cub_tmp, bytes, d_key_in, d_key_out, d_val_in, d_vo_e, (int)st.No_pad, 0, bits, stream));
       hipLaunchKernelGGL(gather_int_kernel, dim3((unsigned)((st.No_pad + 255) / 256)), dim3(256), 0, stream, d_vo_e,
                          (long long)st.No_pad, d_elem_lp, d_vo_lp);
+      hipLaunchKernelGGL(gather_double2_kernel, dim3((unsigned)((st.No_pad + 255) / 256)), dim3(256), 0, stream, d_vo_e,
+                         (long long)st.No_pad, reinterpret_cast<const double2*>(s->v.obs_xy), reinterpret_cast<double2*>(d_vo_xy));
     }
     hipLaunchKernelGGL((lower_bound_kernel<unsigned, int>), dim3((st.Nc + 1 + 255) / 256), dim3(256), 0, stream, d_key_out,
                        (long long)st.No_pad, (long long)st.Nc, d_vo_ptr);
@@ -3075,7 +3100,7 @@ static int ensure_inner(tmi_ba_solver* s) {
     if ((rc = dev_upload(s, &pc, bcols))) return rc; S.blk_cols = pc;
     if ((rc = dev_upload(s, &pi, bparam))) return rc; S.blk_param = pi;
     if ((rc = dev_upload(s, &pi, bsize))) return rc; S.blk_size = pi;
-    S.vo_ptr = d_vo_ptr; S.vo_e = d_vo_e; S.vo_lp = d_vo_lp;
+    S.vo_ptr = d_vo_ptr; S.vo_e = d_vo_e; S.vo_lp = d_vo_lp; S.vo_xy = d_vo_xy;
     const size_t nx = kind == 0 ? (size_t)6 * std::max(st.Nc, 1) : (size_t)std::max(s->n_intr, 1);
     if ((rc = dev_alloc(s, &I.x0[kind], nx))) return rc;
     if ((rc = dev_alloc(s, &I.xc[kind], nx))) return rc;
@@ -3262,7 +3287,25 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
   s->launch.expand_scale(v, stream);
   prepare_cameras(s, v.ext, v.intr, v.prep);
   hipLaunchKernelGGL(fill_kernel, dim3((unsigned)(((long long)st.Np_pad * s->DP + 255) / 256 + 1)), dim3(256), 0, stream, v.scale_p, (long long)st.Np_pad * s->DP, 1.0);
-  auto linearize = [&](bool norms_only = false) {
+  // Compact planes (device_view.h): p_n instead of the stored camera block wherever every consumer of the planes forms
+  // A x / A^T t from Jp, p_n, the track and the view -- the all-PINHOLE / default-mask / TRIVIAL-loss problem without
+  // stored position columns, unit aspect ratio and zero skew (constant under that mask: read from the parameters the
+  // solve starts from), matrix-free iterations of the one-sweep product whose camera side is built view by view
+  // (no kernel reads the A planes then but the product and back_substitute).  Decided per linearize from the operator
+  // the next LM iteration is expected to run; an iteration that forms S after all re-linearizes with the full planes.
+  bool compact_possible = s->compact_env && v.drop_pos && v.uniform_pinhole_default && s->mf_ok && s->direct_ok && D == 9 && lt == 0 &&
+                          iterative && !s->cluster_blocks && v.cp_trk != nullptr && !v.planes_fp32;
+  if (compact_possible) {
+    compact_possible = (int)s->grp_off_h.size() == st.G + 1;
+    for (int g = 0; g < st.G && compact_possible; ++g) {
+      const double* K = s->intr0.data() + s->grp_off_h[g];
+      compact_possible = s->grp_off_h[g + 1] - s->grp_off_h[g] >= 7 && K[1] == 1.0 && K[2] == 0.0;
+    }
+  }
+  int last_pcg_len = 0;  // PCG iterations of the previous LM iteration (0: none yet)
+  auto linearize = [&](bool norms_only = false, bool full_planes = false) {
+    if (!norms_only)
+      v.compact = (!full_planes && compact_possible && (s->implicit || (s->adaptive && last_pcg_len <= s->adaptive_break_even))) ? 1 : 0;
     // cost and sum of squares land in d_sc[0..1] (finished by the kernel's last workgroup)
     Timed t(s, TMI_BA_K_LINEARIZE);
     // (drop_pos: the kernel also leaves -w / scale_p of every track, at the point and the scales the planes are taken at)
@@ -3275,7 +3318,9 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
   // U diagonal comes from camera_diag_direct on records that carry the points alone -- instead of a full linearize,
   // point_scale and point_eliminate (0.9 -> 0.6 ms at Venice size).  TMI_BA_FAST_START=0: the three-pass start.
   const bool fast_start = O->jacobi_scaling && v.direct_diag && s->fast_start_ok;  // (direct_ok implies fp64 evaluation)
-  linearize(fast_start);
+  // (the unscaled first pass of the three-pass start keeps the full planes: its point columns are what point_scale sums,
+  //  and the norms-only pass is held to that instantiation bit for bit -- tests/test_gpu_launch_sequence.py)
+  linearize(fast_start, /*full_planes=*/O->jacobi_scaling != 0);
   // d_sc[0] = cost, d_sc[1] = ss, d_sc[2] = #ranks with an invalid residual
   hipLaunchKernelGGL(flag_to_scalar_kernel, dim3(1), dim3(64), 0, stream, v.flags + FL_INVALID, d_sc + 2);
   CK(do_allreduce(s, d_sc, 8));
@@ -3381,7 +3426,6 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
   const char* why = "maximum number of iterations reached";
   int64_t pcg_iters = 0;
   s->n_implicit_iterations = 0;
-  int last_pcg_len = 0;  // PCG iterations of the previous LM iteration (0: none yet)
   bool need_gradient_check = true;  // after the first build and after every accepted step
   bool inner_enabled = O->use_inner_iterations != 0;
   bool time_up = false;
@@ -3420,6 +3464,12 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
       s->n_implicit_iterations++;
     }
     v.direct_diag = (s->direct_ok && iterative && s->implicit_now && !s->cluster_blocks) ? 1 : 0;
+    if (v.compact && !v.direct_diag) {
+      // this iteration forms S (records from the full camera block): the linearisation again, with the full planes
+      compact_possible = false;
+      linearize();
+      hipLaunchKernelGGL(iteration_begin_kernel, dim3(1), dim3(64), 0, stream, v.flags, d_sc);
+    }
     // one launch for [chunk sums ->] diagonal blocks -> block inverses -> start of PCG (direct_diag.h, camera_finish_kernel)
     // wherever no cluster factorisation sits between the preconditioner blocks and PCG's first residual
     const bool cluster_handle = s->st.has_shared || s->vis_clusters;
@@ -4523,6 +4573,8 @@ int32_t tmi_ba_solver_evaluate(tmi_ba_solver* s, double* residuals, double* jac_
   {
     DeviceView ve = v;  // (the caller gets every column: stored, not formed from Jp)
     ve.drop_pos = 0;
+    ve.compact = 0;
+    v.compact = 0;  // (the planes now hold the full blocks)
     s->launch.linearize(ve, stream, v.prep, 0, 1.0, s->nblocks_tracks, nullptr, 0);
   }
   const size_t N = (size_t)st.No_pad;

@@ -49,6 +49,7 @@ struct InnerSet {
   const int* vo_ptr;       // [Nc+1]
   const int* vo_e;         // element in the track-major layout (pixel, camera)
   const int* vo_lp;        // padded track index (point)
+  const double* vo_xy;     // [.][2] the pixel, in the same order (streamed; obs_xy[vo_e] is a 16-byte gather per observation)
   // parameters: x lives in the candidate arrays of the outer loop (ext_c / intr_c / pts_c)
   double* x;               // ext_c (kind 0) or intr_c (kind 1)
   double* xc;              // candidate of the sub-problems, same indexing
@@ -115,14 +116,16 @@ __global__ __launch_bounds__(256) void inner_eval_kernel(DeviceView v, InnerSet 
   for (int i = 0; i < NV; ++i) acc[i] = 0.0;
   bool bad = false;
   for (int q = S.vo_ptr[cam] + threadIdx.x; q < S.vo_ptr[cam + 1]; q += 256) {
-    const int e = S.vo_e[q];
     const int lp = S.vo_lp[q];
+    const double2 xy = *reinterpret_cast<const double2*>(S.vo_xy + 2 * (size_t)q);
     double X[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) X[i] = v.pts_c[(size_t)lp * 4 + i];
+    {
+      const double2 a = *reinterpret_cast<const double2*>(v.pts_c + (size_t)lp * 4);
+      const double2 b = *reinterpret_cast<const double2*>(v.pts_c + (size_t)lp * 4 + 2);
+      X[0] = a.x; X[1] = a.y; X[2] = b.x; X[3] = b.y;
+    }
     double r[2], Jext[2][6], Jint[2][10], Jpt[2][4];
-    const bool ok = reprojection_error_prepared<JAC, double>(model, Pcam, X, v.obs_xy[2 * (size_t)e],
-                                                             v.obs_xy[2 * (size_t)e + 1], r, Jext, Jint, Jpt);
+    const bool ok = reprojection_error_prepared<JAC, double>(model, Pcam, X, xy.x, xy.y, r, Jext, Jint, Jpt);
     if (!ok) {
       bad = true;
       continue;

@@ -449,6 +449,101 @@ __device__ __forceinline__ void stage_camera_records(const double* __restrict__ 
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ---- compact planes (device_view.h, DeviceView::compact): the per-view maps between a view's block of a reduced
+// vector and what the product / back-substitution gather, and between the per-view moment sums and the block of A^T t.
+// P = the view's prepared record (camera_models.h: R [0..8], C [9..11], K [12..21], Jl diag(s_rot) [24..32],
+// s_pos [33..35], intrinsics scales [36..45]; PINHOLE: f = K[0], k1 = K[5], k2 = K[6]).
+//   forward:  x = [x_pos | x_rot | x_f x_k1 x_k2]  ->  g = [kappa | eta | a0 a1 a2]
+//     eta = R^T Jl_s x_rot, kappa = eta x C + s_pos .* x_pos,
+//     a0 = s_f x_f, a1 = k1 a0 + f s_k1 x_k1, a2 = k2 a0 + f s_k2 x_k2
+//   (first-order branch of AngleAxisRotatePoint, theta^2 <= DBL_EPSILON: R = I + [w]x is not orthogonal and the executed
+//    derivative takes a instead of q; R^T for R^-1 is then off by O(|w|) <= 1.5e-8 relative -- exact for w = 0)
+__device__ __forceinline__ void compact_forward(const double* __restrict__ P, const double (&x)[9], double (&g)[9]) {
+  double xi[3], eta[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) xi[i] = P[24 + 3 * i] * x[3] + P[24 + 3 * i + 1] * x[4] + P[24 + 3 * i + 2] * x[5];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) eta[a] = P[a] * xi[0] + P[3 + a] * xi[1] + P[6 + a] * xi[2];
+  const double C0 = P[9], C1 = P[10], C2 = P[11];
+  g[0] = eta[1] * C2 - eta[2] * C1 + P[33] * x[0];
+  g[1] = eta[2] * C0 - eta[0] * C2 + P[34] * x[1];
+  g[2] = eta[0] * C1 - eta[1] * C0 + P[35] * x[2];
+  g[3] = eta[0];
+  g[4] = eta[1];
+  g[5] = eta[2];
+  const double f = P[12], k1 = P[17], k2 = P[18];
+  const double a0 = P[36] * x[6];
+  g[6] = a0;
+  g[7] = k1 * a0 + f * (P[41] * x[7]);
+  g[8] = k2 * a0 + f * (P[42] * x[8]);
+}
+//   backward: s = per-view sums [sum -w h | sum X x h | sum (p_n . t) (1, r^2, r^4)], h = Jp'^T t  ->  y = A^T t summed
+//     y_pos = s_pos .* s[0..2]   (reduce_kernel's drop_pos line),  y_rot = Jl_s^T R (s[3..5] + C x s[0..2]),
+//     y_f = s_f (m0 + k1 m1 + k2 m2), y_k1 = s_k1 f m1, y_k2 = s_k2 f m2.   Component a only (one thread per component).
+__device__ __forceinline__ double compact_backward(const double* __restrict__ P, const double (&s)[9], int a) {
+  if (a < 3) return s[a];  // (the caller applies scale_c: the same line as for the full planes)
+  const double f = P[12], k1 = P[17], k2 = P[18];
+  if (a == 6) return P[36] * (s[6] + k1 * s[7] + k2 * s[8]);
+  if (a == 7) return P[41] * (f * s[7]);
+  if (a == 8) return P[42] * (f * s[8]);
+  const double C0 = P[9], C1 = P[10], C2 = P[11];
+  const double v0 = s[3] + (C1 * s[2] - C2 * s[1]);
+  const double v1 = s[4] + (C2 * s[0] - C0 * s[2]);
+  const double v2 = s[5] + (C0 * s[1] - C1 * s[0]);
+  const int k = a - 3;
+  double y = 0.0;
+#pragma unroll
+  for (int m = 0; m < 3; ++m) y += P[24 + 3 * m + k] * (P[3 * m] * v0 + P[3 * m + 1] * v1 + P[3 * m + 2] * v2);
+  return y;
+}
+// A x of one observation from the gathered g, the track's {X, w, 1 / scale_p} and the observation's Jp (interleaved
+// rows) and p_n
+__device__ __forceinline__ void compact_ax(const double (&g)[9], const double (&X)[4], const double (&isp)[3],
+                                           const double2 (&jp)[3], double2 pn, double& u0, double& u1) {
+  const double w = X[3];
+  const double c0 = (g[4] * X[2] - g[5] * X[1] - w * g[0]) * isp[0];
+  const double c1 = (g[5] * X[0] - g[3] * X[2] - w * g[1]) * isp[1];
+  const double c2 = (g[3] * X[1] - g[4] * X[0] - w * g[2]) * isp[2];
+  const double r2 = pn.x * pn.x + pn.y * pn.y;
+  const double pr = g[6] + r2 * (g[7] + r2 * g[8]);
+  u0 = jp[0].x * c0 + jp[1].x * c1 + jp[2].x * c2 + pn.x * pr;
+  u1 = jp[0].y * c0 + jp[1].y * c1 + jp[2].y * c2 + pn.y * pr;
+}
+// the nine moment contributions of one observation: [-w h | X x h | (p_n . t) (1, r^2, r^4)], h = Jp'^T t
+__device__ __forceinline__ void compact_at(const double (&X)[4], const double (&isp)[3], const double2 (&jp)[3], double2 pn,
+                                           double t0, double t1, double (&o)[9]) {
+  const double h0 = isp[0] * (jp[0].x * t0 + jp[0].y * t1);
+  const double h1 = isp[1] * (jp[1].x * t0 + jp[1].y * t1);
+  const double h2 = isp[2] * (jp[2].x * t0 + jp[2].y * t1);
+  const double w = X[3];
+  o[0] = -w * h0;
+  o[1] = -w * h1;
+  o[2] = -w * h2;
+  o[3] = X[1] * h2 - X[2] * h1;
+  o[4] = X[2] * h0 - X[0] * h2;
+  o[5] = X[0] * h1 - X[1] * h0;
+  const double r2 = pn.x * pn.x + pn.y * pn.y;
+  const double pt = pn.x * t0 + pn.y * t1;
+  o[6] = pt;
+  o[7] = r2 * pt;
+  o[8] = r2 * r2 * pt;
+}
+
+// the transformed block of view block rb of x into xs (one thread)
+__device__ __forceinline__ void compact_forward_view(const DeviceView& v, int rb, const double (&xv)[9], double* __restrict__ xs) {
+  double g[9];
+  compact_forward(v.prep + (size_t)v.rb_cam[rb] * kPrepStride, xv, g);
+#pragma unroll
+  for (int a = 0; a < 9; ++a) st_agent(&xs[(size_t)rb * 9 + a], g[a]);  // (pcg_step's last workgroup reads xz: agent scope)
+}
+// ... where lane a < 9 of a wavefront holds component a of the block (every lane of the wavefront calls)
+__device__ __forceinline__ void compact_forward_wave(const DeviceView& v, int rb, double val, int lane, double* __restrict__ xs) {
+  double xv[9];
+#pragma unroll
+  for (int a = 0; a < 9; ++a) xv[a] = __shfl(val, a, 64);
+  if (lane == 0) compact_forward_view(v, rb, xv, xs);
+}
+
 // linearize (kernel class 0).
 // Per trip: stage [R C K flag] -> value, projection Jacobian, M = dp/dq R, c = p x dp/dq;
 // stage [Jl scale] -> angle-axis columns, scaling and the plane stores.
@@ -469,8 +564,10 @@ __device__ unsigned long long g_lin_prof[8];
 // jacobi_scaling, 1 / (1 + ||column||)) before the planes can be written with their scales: this instantiation stores no
 // plane at all -- it sums the point block's column norms per track and leaves scale_p itself (point_scale_kernel's job,
 // same sums in the same order), never stages the second half record, and takes a third of the time of the full pass.
+// COMPACT (device_view.h): the specialised instantiation stores p_n instead of the camera block -- the second half record
+// is never staged, no column of A is formed -- and leaves the track's {X, w, 1 / scale_p} for the consumers.
 template <int D, int DP, bool SH, typename RT, int OCC, typename PT = double, int UMODEL = -1, unsigned UMASK = 0u,
-          bool UDROP = false, bool NORMS = false>
+          bool UDROP = false, bool NORMS = false, bool COMPACT = false>
 __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const double* __restrict__ prep,
                                                              int loss_type_arg, double loss_width, int nblocks,
                                                              double* __restrict__ sums) {
@@ -512,6 +609,15 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
 #pragma unroll
       for (int a = 0; a < 3; ++a) v.pos_coef[(size_t)a * v.Np_pad + lp] = -X[3] / sp[a];
     }
+    if constexpr (COMPACT) {
+      if (tm.leader) {
+        const size_t NPc = (size_t)v.Np_pad;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) v.cp_trk[(size_t)a * NPc + lp] = X[a];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) v.cp_trk[(size_t)(4 + a) * NPc + lp] = 1.0 / sp[a];
+      }
+    }
   }
   int cam_next = (tm.j0 < k) ? v.obs_cam[tm.base + (size_t)tm.j0 * 64] : -1;
 #ifdef TMI_LIN_PROFILE
@@ -543,6 +649,7 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
     bool ok = false;
     RT Jint[2][10], M[2][3], cx[2][3], Jp3[2];
     double r[2] = {0.0, 0.0};
+    double pn0 = 0.0, pn1 = 0.0;  // COMPACT: the normalised image point
     if (act) {
       const double wd = X[3];
       const double ad[3] = {X[0] - wd * P[9], X[1] - wd * P[10], X[2] - wd * P[11]};
@@ -560,6 +667,10 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
         project<true, RT>(rec.x, Kt, q, px, dpdq, Jint);
         r[0] = (double)(RT)((double)px[0] - fx);
         r[1] = (double)(RT)((double)px[1] - fy);
+        if constexpr (COMPACT) {
+          pn0 = (double)q[0] / (double)q[2];
+          pn1 = (double)q[1] / (double)q[2];
+        }
         const bool small = P[22] != 0.0;
         const RT p[3] = {small ? a[0] : q[0], small ? a[1] : q[1], small ? a[2] : q[2]};
 #pragma unroll
@@ -622,6 +733,20 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
     if constexpr (NORMS) {
       if (act && !ok) v.flags[FL_INVALID] = 1;
       continue;  // nothing of the camera block is stored: no second half record
+    }
+    if constexpr (COMPACT) {
+      // the camera block is p_n (one plane pair of pm_A): no second half record either
+      if (act) {
+        if (!ok) {
+          v.flags[FL_INVALID] = 1;
+          for (int d = 0; d < 2 * DP; ++d) PST(0.0, &pmJp[pidx<2 * DP>(d, e)]);
+          PST(0.0, &pmR[pidx<2>(0, e)]);
+          PST(0.0, &pmR[pidx<2>(1, e)]);
+        }
+        PST(ok ? pn0 : 0.0, &pmA[pidx<2>(0, e)]);
+        PST(ok ? pn1 : 0.0, &pmA[pidx<2>(1, e)]);
+      }
+      continue;
     }
     stage_camera_records(prep, kStageWords, cam, st, lane);
     LIN_LAP(3);
@@ -720,6 +845,17 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
 template <int D>
 __global__ __launch_bounds__(256) void pos_scale_kernel(DeviceView v, const double* __restrict__ x, double* __restrict__ xs) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  if constexpr (D == 9) {
+    if (v.compact) {  // compact planes: the transformed blocks, a thread per view
+      if (i < v.Nrb) {
+        double xv[9];
+#pragma unroll
+        for (int a = 0; a < 9; ++a) xv[a] = x[(size_t)i * 9 + a];
+        compact_forward_view(v, i, xv, xs);
+      }
+      return;
+    }
+  }
   if (i >= v.Nrb * D) return;
   const int a = i % D;
   xs[i] = a < 3 ? x[i] * v.scale_c[i] : x[i];
@@ -2647,6 +2783,11 @@ __global__ __launch_bounds__(kPcgStepThreads) void pcg_step_kernel(DeviceView v,
       st_agent(&v.cg_z[i], z);  // (read by the last workgroup below)
       acc[1] = rn * z;
     }
+    if constexpr (D == 9) {
+      // compact planes: the transformed block of z, by the wavefront that formed it -- the map is linear, so the last
+      // workgroup gets the transformed p = z + beta p as xz + beta xs, element by element (like p itself)
+      if (v.compact) compact_forward_wave(v, rb, z, lane, v.xz);
+    }
   }
   {
     const double s0 = wave_sum(acc[0]), s1 = wave_sum(acc[1]);
@@ -2723,10 +2864,13 @@ __global__ __launch_bounds__(kPcgStepThreads) void pcg_step_kernel(DeviceView v,
     // p = z + beta p, beta = rho' / rho, and (drop_pos) the copy the next product gathers: position entries times the
     // column scales (pos_scale_kernel's job for any other vector)
     const double beta = beta_sh;
+    bool cpx = false;
+    if constexpr (D == 9) cpx = v.compact != 0;
     for (int i = t; i < n; i += T) {
       const double pn = ld_agent(&v.cg_z[i]) + beta * v.cg_p[i];
       v.cg_p[i] = pn;
-      if (v.drop_pos) v.xs[i] = (i % D) < 3 ? pn * v.scale_c[i] : pn;
+      if (cpx) v.xs[i] = ld_agent(&v.xz[i]) + beta * v.xs[i];  // (compact planes: xs = the transformed p, see above)
+      else if (v.drop_pos) v.xs[i] = (i % D) < 3 ? pn * v.scale_c[i] : pn;
     }
   }
   // publish (what publish_kernel does)
@@ -2765,11 +2909,16 @@ __global__ __launch_bounds__(kPcgStepThreads) void pcg_init_kernel(DeviceView v,
       const double rc = __shfl(rn, c, 64);
       if (lane < D) z += M[c] * rc;
     }
+    bool cpx = false;
+    if constexpr (D == 9) cpx = v.compact != 0;
     if (lane < D) {
       v.cg_z[i] = z;
       v.cg_p[i] = z;
-      if (v.drop_pos) v.xs[i] = lane < 3 ? z * v.scale_c[i] : z;
+      if (v.drop_pos && !cpx) v.xs[i] = lane < 3 ? z * v.scale_c[i] : z;
       acc = rn * z;
+    }
+    if constexpr (D == 9) {
+      if (cpx) compact_forward_wave(v, rb, z, lane, v.xs);
     }
   }
   const double s0 = wave_sum(acc);
@@ -2963,6 +3112,18 @@ __global__ __launch_bounds__(256) void back_substitute_kernel(DeviceView v, int 
 #pragma unroll
         for (int a = 0; a < 3; ++a) pc[a] = v.pos_coef[(size_t)a * NP + lp];
       }
+      // compact planes (device_view.h): the track's {X, w} and 1 / scale_p of the linearisation
+      double Xt[4] = {0.0, 0.0, 0.0, 0.0}, ispt[3] = {0.0, 0.0, 0.0};
+      bool cpx = false;
+      if constexpr (!SH && D == 9) {
+        if (v.compact) {
+          cpx = true;
+#pragma unroll
+          for (int a = 0; a < 4; ++a) Xt[a] = v.cp_trk[(size_t)a * NP + lp];
+#pragma unroll
+          for (int a = 0; a < 3; ++a) ispt[a] = v.cp_trk[(size_t)(4 + a) * NP + lp];
+        }
+      }
       // (the block index of the next observation is in flight while this one is processed)
       int rb_next = (tm.j0 < k) ? v.obs_rb[base + (size_t)tm.j0 * 64] : -1;
       for (int j = tm.j0; j < k; j += tm.jstep) {
@@ -2985,8 +3146,18 @@ __global__ __launch_bounds__(256) void back_substitute_kernel(DeviceView v, int 
               yv[a + 1] = t2.y;
             }
             if (D & 1) yv[D - 1] = ycp[D - 1];
+            if constexpr (!SH && D == 9) {
+              if (cpx) {
+                // xs = the transformed block of y_c (update_cameras): A y_c from Jp, p_n and the track
+                const double2 j3[3] = {make_double2((double)pmJp[pidx<2 * DP>(0, e)], (double)pmJp[pidx<2 * DP>(1, e)]),
+                                       make_double2((double)pmJp[pidx<2 * DP>(2, e)], (double)pmJp[pidx<2 * DP>(3, e)]),
+                                       make_double2((double)pmJp[pidx<2 * DP>(4, e)], (double)pmJp[pidx<2 * DP>(5, e)])};
+                const double2 pn = make_double2((double)pmA[pidx<2>(0, e)], (double)pmA[pidx<2>(1, e)]);
+                compact_ax(yv, Xt, ispt, j3, pn, u0, u1);
+              }
+            }
 #pragma unroll
-            for (int a = 0; a < D; ++a) {
+            for (int a = 0; a < D && !cpx; ++a) {
               const double ya = yv[a];
               if (a < 3) {
                 const double t = ya * pc[a];
@@ -3163,11 +3334,21 @@ __global__ __launch_bounds__(256) void update_cameras_kernel(DeviceView v, doubl
     if (!SH && v.drop_pos && rb >= 0) {
       // drop_pos: the copy of y_c back_substitute gathers, position entries times the column scales (round 6:
       // pos_scale_kernel's job -- this launch runs BEFORE back_substitute and owns the view's block anyway)
+      bool cpx = false;
+      if constexpr (D == 9) {
+        if (v.compact) {  // compact planes: the transformed block (at the linearisation's record, v.prep)
+          double yv[9];
+#pragma unroll
+          for (int a = 0; a < 9; ++a) yv[a] = v.yc[(size_t)rb * 9 + a];
+          compact_forward_view(v, rb, yv, v.xs);
+          cpx = true;
+        }
+      }
 #pragma unroll
       for (int a = 0; a < D; ++a) {
         const size_t i = (size_t)rb * D + a;
         const double y = v.yc[i];
-        v.xs[i] = a < 3 ? y * v.scale_c[i] : y;
+        if (!cpx) v.xs[i] = a < 3 ? y * v.scale_c[i] : y;
       }
     }
   } else if (SH && c < v.Nc + n_groups_sh) {

@@ -302,8 +302,12 @@ __device__ __forceinline__ double2 mf_stream_load(const double2* p) {
 // DROP: the position columns of the A planes are not stored (DeviceView::drop_pos); x is then the vector with the position
 // entries of every block already times the block's column scales (pos_scale_kernel), reduce_kernel applies the scales
 // to the position entries of the sums.
-template <int D, int DP, bool DROP>
+// CP: compact planes (device_view.h, DeviceView::compact): pm_A holds p_n alone, x is the transformed vector
+// [kappa | eta | a0 a1 a2] of every view (compact_forward), the sums are the moments compact_backward maps back
+// (reduce_kernel).  Same units, runs, slots and summation orders as the full planes.
+template <int D, int DP, bool DROP, bool CP = false>
 __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View m, const double* __restrict__ x) {
+  static_assert(!CP || (DROP && D == 9), "compact planes: the 9-wide PINHOLE block without stored position columns");
   constexpr int A0 = DROP ? 3 : 0;  // first stored column of the A planes
   constexpr int LCM = lc_max(D);
   constexpr int VB = vb_entries(D);
@@ -335,9 +339,16 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
 #pragma unroll
       for (int a = 0; a < DP; ++a) wv[a] = 0.0;
       double pcw[3] = {0.0, 0.0, 0.0};
-      if (DROP) {
+      if (DROP && !CP) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) pcw[a] = v.pos_coef[(size_t)a * v.Np_pad + lp];
+      }
+      double Xw[4] = {0.0, 0.0, 0.0, 0.0}, ispw[3] = {0.0, 0.0, 0.0};
+      if (CP) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) Xw[a] = v.cp_trk[(size_t)a * v.Np_pad + lp];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) ispw[a] = v.cp_trk[(size_t)(4 + a) * v.Np_pad + lp];
       }
       for (int j = j0; j < k; j += L) {
         const size_t e = base + (size_t)j * 64;
@@ -347,17 +358,26 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
         const double* ap = v.pm_A + (e >> 6) * (size_t)ROWD + ((e & 63) << 1);
         const double* jp = v.pm_Jp + (e >> 6) * (size_t)ROWP + ((e & 63) << 1);
         double u0 = 0.0, u1 = 0.0;
+        if (!CP) {
 #pragma unroll
-        for (int a = A0; a < D; ++a) {
-          const double2 aa = *reinterpret_cast<const double2*>(ap + a * 128);
-          const double xa = xc[a];
-          u0 += aa.x * xa;
-          u1 += aa.y * xa;
+          for (int a = A0; a < D; ++a) {
+            const double2 aa = *reinterpret_cast<const double2*>(ap + a * 128);
+            const double xa = xc[a];
+            u0 += aa.x * xa;
+            u1 += aa.y * xa;
+          }
         }
         double2 jj[DP];
 #pragma unroll
         for (int a = 0; a < DP; ++a) jj[a] = *reinterpret_cast<const double2*>(jp + a * 128);
-        if (DROP) {
+        if constexpr (CP) {
+          double g[9];
+#pragma unroll
+          for (int a = 0; a < 9; ++a) g[a] = xc[a];
+          const double2 pn = *reinterpret_cast<const double2*>(v.pm_A + (e >> 6) * (size_t)128 + ((e & 63) << 1));
+          const double2 j3[3] = {jj[0], jj[1], jj[2]};
+          compact_ax(g, Xw, ispw, j3, pn, u0, u1);
+        } else if (DROP) {
 #pragma unroll
           for (int a = 0; a < 3; ++a) {
             const double ca = pcw[a] * xc[a];
@@ -400,12 +420,29 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
         const size_t e = (size_t)m.run_obs[o];
         const double2 t = *reinterpret_cast<const double2*>(m.ut + 2 * e);
         const double* ap = v.pm_A + (e >> 6) * (size_t)ROWD + ((e & 63) << 1);
+        if (!CP) {
 #pragma unroll
-        for (int a = A0; a < D; ++a) {
-          const double2 aa = *reinterpret_cast<const double2*>(ap + a * 128);
-          sum[a] += aa.x * t.x + aa.y * t.y;
+          for (int a = A0; a < D; ++a) {
+            const double2 aa = *reinterpret_cast<const double2*>(ap + a * 128);
+            sum[a] += aa.x * t.x + aa.y * t.y;
+          }
         }
-        if (DROP) {
+        if constexpr (CP) {
+          const double* jp = v.pm_Jp + (e >> 6) * (size_t)ROWP + ((e & 63) << 1);
+          const size_t lpe = (size_t)q.s * 64 + (e & 63);
+          double Xe[4], ispe[3];
+#pragma unroll
+          for (int a = 0; a < 4; ++a) Xe[a] = v.cp_trk[(size_t)a * v.Np_pad + lpe];
+#pragma unroll
+          for (int a = 0; a < 3; ++a) ispe[a] = v.cp_trk[(size_t)(4 + a) * v.Np_pad + lpe];
+          const double2 j3[3] = {*reinterpret_cast<const double2*>(jp), *reinterpret_cast<const double2*>(jp + 128),
+                                 *reinterpret_cast<const double2*>(jp + 256)};
+          const double2 pn = *reinterpret_cast<const double2*>(v.pm_A + (e >> 6) * (size_t)128 + ((e & 63) << 1));
+          double o[9];
+          compact_at(Xe, ispe, j3, pn, t.x, t.y, o);
+#pragma unroll
+          for (int a = 0; a < 9; ++a) sum[a] += o[a];
+        } else if (DROP) {
           // the element's track: slice q.s, column e & 63
           const double* jp = v.pm_Jp + (e >> 6) * (size_t)ROWP + ((e & 63) << 1);
           const size_t lpe = (size_t)q.s * 64 + (e & 63);
@@ -513,6 +550,8 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
     double xr[RR][D];
     double uu[RR][2];
     double pcr[RR][3];  // DROP: -w / scale_p of the row's track
+    double2 pnr[RR];    // CP: p_n of the row's observation, {X, w} and 1 / scale_p of its track
+    double Xr[RR][4], ispr[RR][3];
     int pos[RR];
     // ---- the batch of loads
 #pragma unroll
@@ -544,20 +583,38 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
         const double* jp = v.pm_Jp + (tile0 + R) * ROWP + 2 * tl;
         // streamed once: non-temporal, so that the rows do not push the x blocks (gathered again and again by the
         // units of an item) out of the vector L1
+        if (!CP) {
 #pragma unroll
-        for (int a = A0; a < D; ++a) ar[rr][a] = MF_STREAM_LOAD(reinterpret_cast<const double2*>(ap + a * 128));
+          for (int a = A0; a < D; ++a) ar[rr][a] = MF_STREAM_LOAD(reinterpret_cast<const double2*>(ap + a * 128));
+        } else {
+          pnr[rr] = MF_STREAM_LOAD(reinterpret_cast<const double2*>(v.pm_A + (tile0 + R) * (size_t)128 + 2 * tl));
+        }
 #pragma unroll
         for (int a = 0; a < DP; ++a) jr[rr][a] = MF_STREAM_LOAD(reinterpret_cast<const double2*>(jp + a * 128));
         if (DROP) {
           // the row's track: slice R / K of a pack, the piece's own slice otherwise
           const size_t lpr = (size_t)(d0.w + (lsh ? 0 : min(R / K, G - 1))) * 64 + tl;
+          if (!CP) {
 #pragma unroll
-          for (int a = 0; a < 3; ++a) pcr[rr][a] = v.pos_coef[(size_t)a * v.Np_pad + lpr];
+            for (int a = 0; a < 3; ++a) pcr[rr][a] = v.pos_coef[(size_t)a * v.Np_pad + lpr];
+          } else {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) Xr[rr][a] = v.cp_trk[(size_t)a * v.Np_pad + lpr];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) ispr[rr][a] = v.cp_trk[(size_t)(4 + a) * v.Np_pad + lpr];
+          }
         }
       }
       if (DROP && !(R < rows)) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) pcr[rr][a] = 0.0;
+        if (CP) {
+          pnr[rr] = make_double2(0.0, 0.0);
+#pragma unroll
+          for (int a = 0; a < 4; ++a) Xr[rr][a] = 0.0;
+#pragma unroll
+          for (int a = 0; a < 3; ++a) ispr[rr][a] = 0.0;
+        }
       }
     }
     MF_LAP(0);
@@ -570,12 +627,17 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
 #pragma unroll
     for (int rr = 0; rr < RR; ++rr) {
       double s0 = 0.0, s1 = 0.0;
+      if (!CP) {
 #pragma unroll
-      for (int a = A0; a < D; ++a) {
-        s0 += ar[rr][a].x * xr[rr][a];
-        s1 += ar[rr][a].y * xr[rr][a];
+        for (int a = A0; a < D; ++a) {
+          s0 += ar[rr][a].x * xr[rr][a];
+          s1 += ar[rr][a].y * xr[rr][a];
+        }
       }
-      if (DROP) {
+      if constexpr (CP) {
+        const double2 j3[3] = {jr[rr][0], jr[rr][1], jr[rr][2]};
+        compact_ax(xr[rr], Xr[rr], ispr[rr], j3, pnr[rr], s0, s1);
+      } else if (DROP) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
           const double ca = pcr[rr][a] * xr[rr][a];
@@ -659,9 +721,17 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
       if (pos[rr] >= 0) {
 #endif
         double* dst = &vbuf[pos[rr] * D];
+        if (!CP) {
 #pragma unroll
-        for (int a = A0; a < D; ++a) dst[a] = ar[rr][a].x * uu[rr][0] + ar[rr][a].y * uu[rr][1];
-        if (DROP) {
+          for (int a = A0; a < D; ++a) dst[a] = ar[rr][a].x * uu[rr][0] + ar[rr][a].y * uu[rr][1];
+        }
+        if constexpr (CP) {
+          const double2 j3[3] = {jr[rr][0], jr[rr][1], jr[rr][2]};
+          double o[9];
+          compact_at(Xr[rr], ispr[rr], j3, pnr[rr], uu[rr][0], uu[rr][1], o);
+#pragma unroll
+          for (int a = 0; a < 9; ++a) dst[a] = o[a];
+        } else if (DROP) {
 #pragma unroll
           for (int a = 0; a < 3; ++a)
             dst[a] = pcr[rr][a] * (jr[rr][a < DP ? a : 0].x * uu[rr][0] + jr[rr][a < DP ? a : 0].y * uu[rr][1]);
@@ -790,26 +860,33 @@ __global__ __launch_bounds__(256) void reduce_kernel(DeviceView v, View m, RedLa
 #pragma unroll
   for (int a = 0; a < D; ++a) a9[a] = 0.0;
   if (live) {
-    // a slot is D doubles at an 8-byte aligned address: fetched 16 bytes at a time, the slot index of the thread's next
-    // trip already in flight (the two loads of a trip are dependent; a view has ~3 trips per thread)
+    // a slot is D doubles at an 8-byte aligned address, fetched 16 bytes at a time.  A view has ~3 slots per thread: the
+    // indices of four trips are loaded as one batch and their slots as a second one (two memory round trips where the
+    // trip-by-trip loop had one per trip; every load unconditional, the index clamped, so that no s_waitcnt sits between
+    // them), summed in trip order: the same sums in the same order
     const int k1 = m.cam_slot_ptr[rb + 1];
-    int k = m.cam_slot_ptr[rb] + (int)threadIdx.x;
-    int slot = k < k1 ? m.cam_slots[k] : 0;
-    while (k < k1) {
-      const double* p = m.partial + (size_t)slot * D;
-      const int kn = k + 256;
-      if (kn < k1) slot = m.cam_slots[kn];
-      double t[D];
+    for (int k = m.cam_slot_ptr[rb] + (int)threadIdx.x; k < k1; k += 4 * 256) {
+      int slot[4];
 #pragma unroll
-      for (int a = 0; a + 1 < D; a += 2) {
-        const double2_a8 t2 = *reinterpret_cast<const double2_a8*>(p + a);
-        t[a] = t2.x;
-        t[a + 1] = t2.y;
+      for (int q = 0; q < 4; ++q) slot[q] = m.cam_slots[min(k + 256 * q, k1 - 1)];
+      double t[4][D];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double* p = m.partial + (size_t)slot[q] * D;
+#pragma unroll
+        for (int a = 0; a + 1 < D; a += 2) {
+          const double2_a8 t2 = *reinterpret_cast<const double2_a8*>(p + a);
+          t[q][a] = t2.x;
+          t[q][a + 1] = t2.y;
+        }
+        if (D & 1) t[q][D - 1] = p[D - 1];
       }
-      if (D & 1) t[D - 1] = p[D - 1];
 #pragma unroll
-      for (int a = 0; a < D; ++a) a9[a] += t[a];
-      k = kn;
+      for (int q = 0; q < 4; ++q) {
+        const bool on = k + 256 * q < k1;
+#pragma unroll
+        for (int a = 0; a < D; ++a) a9[a] = on ? a9[a] + t[q][a] : a9[a];
+      }
     }
   }
 #pragma unroll
@@ -822,6 +899,15 @@ __global__ __launch_bounds__(256) void reduce_kernel(DeviceView v, View m, RedLa
     const int a = threadIdx.x;
     double tot = sh[0][a] + sh[1][a] + sh[2][a] + sh[3][a];
     double pr = 0.0;
+    if constexpr (D == 9) {
+      if (live && v.compact) {
+        // compact planes: the sums are the view's moments; component a of A^T t from all nine (compact_backward)
+        double raw[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) raw[c] = sh[0][c] + sh[1][c] + sh[2][c] + sh[3][c];
+        tot = compact_backward(v.prep + (size_t)v.rb_cam[rb] * kPrepStride, raw, a);
+      }
+    }
     if (live) {
       // (drop_pos: the sums of the position entries still lack the view's column scale, device_view.h)
       if (v.drop_pos && a < 3) tot *= v.scale_c[(size_t)rb * D + a];

@@ -402,5 +402,11 @@ __global__ __launch_bounds__(256) void gather_int_kernel(const int* __restrict__
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i < n) dst[i] = src[idx[i]];
 }
+// 16-byte records (the pixel of a layout element)
+__global__ __launch_bounds__(256) void gather_double2_kernel(const int* __restrict__ idx, long long n,
+                                                             const double2* __restrict__ src, double2* __restrict__ dst) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
+}
 
 }  // namespace tmi
