@@ -129,6 +129,8 @@ struct DeviceView {
   // reduce_kernel maps back (compact_backward).  80 of the 160 plane bytes per observation less for linearize,
   // back_substitute and every matrix-free product.  Set per linearize by the engine (solve); 0: the full planes.
   int compact;
+  int sums_ready;   // Vraw / gp already hold this linearisation's V = sum Jp^T Jp and g_p (the compact linearize): point_eliminate
+                    //   (REC = false) loads them instead of sweeping the Jp and r planes
   double* cp_trk;   // [7][Np_pad] planes X0 X1 X2 w 1/scale_p[0..2] of the linearisation the planes belong to (linearize)
   double* xz;       // [Nrb D] the transformed z of a PCG step (pcg_step: xs <- xz + beta xs)
   double* pm_Jp;

@@ -483,6 +483,7 @@ struct tmi_ba_solver {
   bool pcg_speculate = true;
   bool fast_start_ok = true;  // TMI_BA_FAST_START=0: linearize + point_scale + point_eliminate before the scaled linearize
   bool compact_env = true;    // TMI_BA_COMPACT_PLANES=0: always the full planes (device_view.h, DeviceView::compact)
+  bool fuse_sums = true;      // TMI_BA_FUSE_TRACK_SUMS=0: point_eliminate sweeps the planes for V and g_p as before
   bool cost_by_view = false;   // ... and the trial cost view by view (every observation owns a slot)
   bool cost_warm = true;       // ... which also reads linearize's observation stream into the Infinity Cache (TMI_BA_COST_WARM=0: off)
   bool implicit = false;      // S is never formed (schur_mode)
@@ -2223,6 +2224,8 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
     s->fast_start_ok = !(env && env[0] == '0');
     env = getenv("TMI_BA_COMPACT_PLANES");
     s->compact_env = !(env && env[0] == '0');
+    env = getenv("TMI_BA_FUSE_TRACK_SUMS");
+    s->fuse_sums = !(env && env[0] == '0');
   }
   v.direct_diag = 0;
   {
@@ -3306,6 +3309,7 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
   auto linearize = [&](bool norms_only = false, bool full_planes = false) {
     if (!norms_only)
       v.compact = (!full_planes && compact_possible && (s->implicit || (s->adaptive && last_pcg_len <= s->adaptive_break_even))) ? 1 : 0;
+    if (!norms_only) v.sums_ready = (v.compact && s->fuse_sums) ? 1 : 0;  // (the compact instantiation also leaves V and g_p)
     // cost and sum of squares land in d_sc[0..1] (finished by the kernel's last workgroup)
     Timed t(s, TMI_BA_K_LINEARIZE);
     // (drop_pos: the kernel also leaves -w / scale_p of every track, at the point and the scales the planes are taken at)
@@ -4575,6 +4579,7 @@ int32_t tmi_ba_solver_evaluate(tmi_ba_solver* s, double* residuals, double* jac_
     ve.drop_pos = 0;
     ve.compact = 0;
     v.compact = 0;  // (the planes now hold the full blocks)
+    v.sums_ready = 0;
     s->launch.linearize(ve, stream, v.prep, 0, 1.0, s->nblocks_tracks, nullptr, 0);
   }
   const size_t N = (size_t)st.No_pad;

@@ -537,11 +537,19 @@ __device__ __forceinline__ void compact_forward_view(const DeviceView& v, int rb
   for (int a = 0; a < 9; ++a) st_agent(&xs[(size_t)rb * 9 + a], g[a]);  // (pcg_step's last workgroup reads xz: agent scope)
 }
 // ... where lane a < 9 of a wavefront holds component a of the block (every lane of the wavefront calls)
+// (lanes 0..8 each form the block -- the loads of the record are the same addresses, broadcast -- and store their own entry)
 __device__ __forceinline__ void compact_forward_wave(const DeviceView& v, int rb, double val, int lane, double* __restrict__ xs) {
   double xv[9];
 #pragma unroll
   for (int a = 0; a < 9; ++a) xv[a] = __shfl(val, a, 64);
-  if (lane == 0) compact_forward_view(v, rb, xv, xs);
+  if (lane < 9) {
+    double g[9];
+    compact_forward(v.prep + (size_t)v.rb_cam[rb] * kPrepStride, xv, g);
+    double mine = g[0];
+#pragma unroll
+    for (int a = 1; a < 9; ++a) mine = (lane == a) ? g[a] : mine;
+    st_agent(&xs[(size_t)rb * 9 + lane], mine);
+  }
 }
 
 // linearize (kernel class 0).
@@ -590,6 +598,13 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
   double n2[DP];  // NORMS: squared norms of the point block's columns over the track's observations
 #pragma unroll
   for (int a = 0; a < DP; ++a) n2[a] = 0.0;
+  // COMPACT: V = sum Jp^T Jp and g_p = sum Jp^T r of the track, in point_eliminate's order -- that kernel then skips its
+  // sweep over the Jp and r planes (DeviceView::sums_ready)
+  double Vt[sym_size(DP)], gt[DP];
+#pragma unroll
+  for (int i = 0; i < sym_size(DP); ++i) Vt[i] = 0.0;
+#pragma unroll
+  for (int a = 0; a < DP; ++a) gt[a] = 0.0;
   const int lp = tm.lp;
   const int k = tm.k;  // 0 for padding tracks and beyond the last slice
   double X[4] = {0.0, 0.0, 0.0, 1.0};
@@ -707,6 +722,7 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
         acc[0] += 0.5 * sq;
       }
       acc[1] += sq;
+      double Js0[DP], Js1[DP];  // COMPACT: the stored (scaled) point block
 #pragma unroll
       for (int a = 0; a < DP; ++a) {
         double j0 = 0.0, j1 = 0.0;
@@ -725,9 +741,22 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
           const double s0 = j0 * sp[a], s1 = j1 * sp[a];  // (what point_scale_kernel reads back from the planes)
           n2[a] += s0 * s0 + s1 * s1;
         }
+        if constexpr (COMPACT) {
+          Js0[a] = j0 * sp[a];
+          Js1[a] = j1 * sp[a];
+        }
       }
       PST(r[0] * rscale, &pmR[pidx<2>(0, e)]);
       PST(r[1] * rscale, &pmR[pidx<2>(1, e)]);
+      if constexpr (COMPACT) {
+        const double r0s = r[0] * rscale, r1s = r[1] * rscale;
+#pragma unroll
+        for (int a = 0; a < DP; ++a) {
+#pragma unroll
+          for (int b = a; b < DP; ++b) Vt[sym_idx(a, b, DP)] += Js0[a] * Js0[b] + Js1[a] * Js1[b];
+          gt[a] += Js0[a] * r0s + Js1[a] * r1s;
+        }
+      }
     }
     LIN_LAP(2);
     if constexpr (NORMS) {
@@ -835,6 +864,19 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
     for (int a = 0; a < DP; ++a) {
       const double t = group_sum(n2[a], tm.wide);
       if (tm.valid && tm.leader) v.scale_p[(size_t)lp * DP + a] = 1.0 / (1.0 + sqrt(t));
+    }
+  }
+  if constexpr (COMPACT) {
+    const size_t NPc = (size_t)v.Np_pad;
+#pragma unroll
+    for (int i = 0; i < sym_size(DP); ++i) {
+      const double t = group_sum(Vt[i], tm.wide);
+      if (tm.valid && tm.leader && k > 0) v.Vraw[(size_t)i * NPc + lp] = t;
+    }
+#pragma unroll
+    for (int a = 0; a < DP; ++a) {
+      const double t = group_sum(gt[a], tm.wide);
+      if (tm.valid && tm.leader && k > 0) v.gp[(size_t)a * NPc + lp] = t;
     }
   }
   block_sum_finish<2>(acc, v.partial, nblocks, v.ticket + 2 * kTicketStride, sums);
@@ -1014,7 +1056,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
       for (int i = 0; i < NS; ++i) V[i] = 0.0;
 #pragma unroll
       for (int a = 0; a < DP; ++a) g[a] = 0.0;
-      for (int j = tm.j0; j < k; j += tm.jstep) {
+      const bool ready = !REC && v.sums_ready;  // (the compact linearize left V and g_p: no sweep over the planes)
+      for (int j = tm.j0; j < k && !ready; j += tm.jstep) {
         const size_t e = base + (size_t)j * 64;
         double J0[DP], J1[DP];
 #pragma unroll
@@ -1036,6 +1079,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
       for (int i = 0; i < NS; ++i) V[i] = group_sum(V[i], tm.wide);
 #pragma unroll
       for (int a = 0; a < DP; ++a) g[a] = group_sum(g[a], tm.wide);
+      if (ready) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) V[i] = v.Vraw[(size_t)i * NP + lp];
+#pragma unroll
+        for (int a = 0; a < DP; ++a) g[a] = v.gp[(size_t)a * NP + lp];
+      }
       // the undamped V = Jp^T Jp is kept for the model cost change (back_substitute_kernel)
       if (tm.leader) {
 #pragma unroll
