@@ -388,7 +388,9 @@ def main():
         # which product / plane layout THIS handle runs is the engine's answer, not a copy of its rules
         info = solver.operator_info()
         one_sweep, drop_pos = info["one_sweep_product"], info["position_columns_formed"]
-        lf = matrix_free_layout_floor(n_obs // world, n_cam, n_pts // world, dc, dp, dc - 3 if drop_pos else dc)
+        compact = info.get("compact_planes", False)
+        # (compact planes: the camera block is ONE 16-byte pair per observation -- the normalised image point)
+        lf = matrix_free_layout_floor(n_obs // world, n_cam, n_pts // world, dc, dp, 1 if compact else (dc - 3 if drop_pos else dc))
         roofline["kernel"] = ("spmv (one product q = S p; matrix-free in %d of %d timed LM iterations: %s)"
                               % (m["matrix_free"], steps_run,
                                  "mfc::product_kernel + mfc::reduce_kernel, the one-sweep product of mf_chunks.h" if one_sweep
@@ -397,8 +399,12 @@ def main():
             bytes_per_launch=int(lf), achieved=round(lf / (dom["avg_us"] * 1e-6) / 1e9, 2),
             frac=round(lf / (dom["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
             note="matrix-free product, every stored Jacobian block read once%s (NOT SURVEY 8(d)'s bytes; round 2 "
-                 "quoted this figure as roofline.frac)" % (" -- the position columns of the camera block are not "
+                 "quoted this figure as roofline.frac)" % (" -- compact planes: the camera block is formed from the point "
+                                                           "block, the normalised image point (the one stored pair), the "
+                                                           "track and the view" if compact else
+                                                           " -- the position columns of the camera block are not "
                                                            "stored" if drop_pos else ""))
+        roofline["compact_planes"] = bool(compact)
     # the other large classes of the same timed region (schur_offdiag was the dominant one until the adaptive
     # operator choice took it out of the short PCG solves): same definition, for comparison across rounds
     roofline["other_classes"] = {

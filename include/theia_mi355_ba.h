@@ -631,7 +631,10 @@ int32_t tmi_ba_solver_structure_checksums(tmi_ba_solver* solver, uint64_t out[24
  *   out[3] schur_mode auto chooses the operator per LM iteration           out[4] S is never formed (implicit)
  *   out[5] PCG length up to which the matrix-free operator is taken (auto)
  *   out[6] the handle holds clusters for CLUSTER_JACOBI (0: such a request keeps the SCHUR_JACOBI blocks, and
- *          tmi_ba_summary.effective_preconditioner_type says so)            out[7] reserved (0)                   */
+ *          tmi_ba_summary.effective_preconditioner_type says so)
+ *   out[7] the planes of the handle's last linearisation are COMPACT: on the all-PINHOLE / default-mask / TRIVIAL-loss
+ *          problem with unit aspect ratio and zero skew the camera block is formed from the point block, the normalised
+ *          image point, the track and the view instead of stored (TMI_BA_COMPACT_PLANES=0 switches it off)              */
 int32_t tmi_ba_solver_operator_info(tmi_ba_solver* solver, int32_t out[8]);
 
 /* Host-only: statistics of the static structure the engine would build for

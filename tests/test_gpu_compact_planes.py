@@ -162,3 +162,29 @@ def test_skewed_view_keeps_the_full_planes_and_matches_the_oracle_minimum():
     a = run(prob, False, **dict(kw))
     b = run(prob, True, **dict(kw))
     assert a[0].final_cost == b[0].final_cost and np.array_equal(a[1].points, b[1].points)
+
+
+@pytest.mark.parametrize("compact", [False, True])
+def test_operator_info_reports_the_plane_layout(compact):
+    """tmi_ba_solver_operator_info out[7]: the planes of the handle's last linearisation (bench.py's layout floor reads it)"""
+    prob = synth.make_problem(40, 6000, 32000, seed=71, scene="ring", spread=0.5)
+    saved = {k: os.environ.pop(k, None) for k in ("TMI_BA_COMPACT_PLANES", "TMI_BA_MF_ONE_SWEEP")}
+    try:
+        os.environ["TMI_BA_COMPACT_PLANES"] = "1" if compact else "0"
+        os.environ["TMI_BA_MF_ONE_SWEEP"] = "1"
+        o = abi.default_options(max_num_iterations=3, use_inner_iterations=0, point_dof=3, **IMPL)
+        s = lib.Solver(prob.copy(), o, 0, 1)
+        try:
+            st, sm = s.solve(o)
+            assert st == 0, sm.message
+            assert s.operator_info()["compact_planes"] == compact
+            # the Jacobian the caller can ask for is always the full one, and asking resets the flag
+            s.evaluate(3)
+            assert s.operator_info()["compact_planes"] is False
+        finally:
+            s.close()
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v

@@ -4550,6 +4550,8 @@ int32_t tmi_ba_solver_operator_info(tmi_ba_solver* s, int32_t out[8]) {
   // can this handle serve CLUSTER_JACOBI with clusters (shared-intrinsics clusters, or visibility clusters built at create)?
   // 0: a CLUSTER_JACOBI request keeps the SCHUR_JACOBI blocks (tmi_ba_summary::effective_preconditioner_type says so per solve)
   out[6] = ((s->st.has_shared || s->vis_clusters) && !s->cl_unavailable) ? 1 : 0;
+  // the planes of the LAST linearisation are compact (device_view.h): p_n instead of the stored camera block
+  out[7] = s->v.compact ? 1 : 0;
   return TMI_BA_OK;
 }
 

@@ -414,7 +414,8 @@ class Solver:
         if st != 0:
             raise EngineError(st, "tmi_ba_solver_operator_info")
         return dict(one_sweep_product=bool(out[0]), position_columns_formed=bool(out[1]), direct_camera_side=bool(out[2]),
-                    adaptive=bool(out[3]), implicit=bool(out[4]), break_even=int(out[5]))
+                    adaptive=bool(out[3]), implicit=bool(out[4]), break_even=int(out[5]), cluster_handle=bool(out[6]),
+                    compact_planes=bool(out[7]))
 
     @property
     def stream(self) -> int:
