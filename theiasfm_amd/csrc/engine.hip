@@ -40,6 +40,9 @@
 #include <hipcub/hipcub.hpp>
 #include "structure.h"
 
+#ifndef TMI_LIN_OCC_COMPACT
+#define TMI_LIN_OCC_COMPACT 3  // ... and its compact instantiation (45 KB of LDS: three workgroups fit a CU)
+#endif
 #ifndef TMI_LIN_OCC
 #define TMI_LIN_OCC 2  // workgroups per CU the specialised linearize is compiled for (A/B builds: -DTMI_LIN_OCC=3)
 #endif
@@ -145,7 +148,7 @@ Launch make_launch(bool fp32) {
         // bundle_adjustment.h:95) and no robust loss: the specialised body (kernels.h, UMODEL / UMASK)
         if (v.uniform_pinhole_default && lt == 0) {
           if (v.drop_pos && v.compact)  // compact planes (device_view.h): p_n instead of the camera block
-            hipLaunchKernelGGL((linearize_kernel<D, DP, SH, double, TMI_LIN_OCC, double, 0, kPinholeDefaultMask, true, false, true>), dim3(nb),
+            hipLaunchKernelGGL((linearize_kernel<D, DP, SH, double, TMI_LIN_OCC_COMPACT, double, 0, kPinholeDefaultMask, true, false, true>), dim3(nb),
                                dim3(256), 0, st, v, prep, lt, lw, nb, sums);
           else if (v.drop_pos)
             hipLaunchKernelGGL((linearize_kernel<D, DP, SH, double, TMI_LIN_OCC, double, 0, kPinholeDefaultMask, true>), dim3(nb), dim3(256), 0, st, v,

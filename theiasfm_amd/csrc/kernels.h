@@ -405,10 +405,12 @@ constexpr int kStagePitch = kStageWords + 2; // +2 doubles: conflict-free 16-byt
 
 // lane l wants words [off, off + kStageWords) of record idx (idx < 0: nothing); on return
 // st[l * kStagePitch + i] holds word off + i of lane l's record.  Wave-collective.
-template <int NB = 2>
+// WORDS: doubles staged per record (default: the half record), the LDS pitch is WORDS + 2
+template <int NB = 2, int WORDS = kStageWords>
 __device__ __forceinline__ void stage_camera_records(const double* __restrict__ prep, int off, int idx,
                                                      double* st, int lane) {
-  constexpr int CH = kStageWords / 2;
+  constexpr int CH = WORDS / 2;
+  constexpr int kStagePitch = WORDS + 2;  // (shadows the default pitch)
   // the previous contents may still be being read by other lanes of this wave
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -418,7 +420,7 @@ __device__ __forceinline__ void stage_camera_records(const double* __restrict__ 
   // memory round trips per trip of linearize (round 6: in-kernel phase counters put 44 k of a trip's 54 k cycles
   // into the two stagings, 1.5 k into the evaluation).  Two batches of CH / 2 keep the transient registers at 24.
   constexpr int PER = CH / NB;
-  static_assert(CH % NB == 0 && (PER == 6 || PER == 12), "batches");
+  static_assert(CH % NB == 0 && (PER == 5 || PER == 6 || PER == 12), "batches");
 #pragma unroll
   for (int bt = 0; bt < NB; ++bt) {
     double2 t[PER];
@@ -432,8 +434,12 @@ __device__ __forceinline__ void stage_camera_records(const double* __restrict__ 
     // (left alone, the compiler sinks every load back to its store -- the kernel is at the register limit: ONE empty
     // asm statement that names all six values keeps the batch together: they must all be in registers there)
     // ("memory": the loads of the second half of a 12-chunk batch stay in front of it too)
-    asm volatile("" : "+v"(t[0].x), "+v"(t[0].y), "+v"(t[1].x), "+v"(t[1].y), "+v"(t[2].x), "+v"(t[2].y), "+v"(t[3].x),
-                      "+v"(t[3].y), "+v"(t[4].x), "+v"(t[4].y), "+v"(t[5].x), "+v"(t[5].y) : : "memory");
+    if constexpr (PER == 5)
+      asm volatile("" : "+v"(t[0].x), "+v"(t[0].y), "+v"(t[1].x), "+v"(t[1].y), "+v"(t[2].x), "+v"(t[2].y), "+v"(t[3].x),
+                        "+v"(t[3].y), "+v"(t[4].x), "+v"(t[4].y) : : "memory");
+    else
+      asm volatile("" : "+v"(t[0].x), "+v"(t[0].y), "+v"(t[1].x), "+v"(t[1].y), "+v"(t[2].x), "+v"(t[2].y), "+v"(t[3].x),
+                        "+v"(t[3].y), "+v"(t[4].x), "+v"(t[4].y), "+v"(t[PER > 5 ? 5 : 0].x), "+v"(t[PER > 5 ? 5 : 0].y) : : "memory");
     if constexpr (PER == 12)
       asm volatile("" : "+v"(t[6].x), "+v"(t[6].y), "+v"(t[7].x), "+v"(t[7].y), "+v"(t[8].x), "+v"(t[8].y), "+v"(t[9].x),
                         "+v"(t[9].y), "+v"(t[10].x), "+v"(t[10].y), "+v"(t[11].x), "+v"(t[11].y));
@@ -581,6 +587,10 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
                                                              double* __restrict__ sums) {
   // (the specialised instantiation is also the TRIVIAL-loss one: the engine launches it for loss_type 0 only)
   const int loss_type = UMODEL >= 0 ? 0 : loss_type_arg;
+  // COMPACT: R, C, f, the principal point, k1, k2 are words 0..18 of the record -- 20 staged words, 45 instead of 53 KB of
+  // LDS: a third workgroup fits a CU
+  constexpr int SW = COMPACT ? 20 : kStageWords;
+  constexpr int kStagePitch = SW + 2;  // (shadows the default pitch)
   __shared__ __attribute__((aligned(16))) double stage[kSlicesPerBlock][64 * kStagePitch];
   const TrackMap tm = track_map(v);
   PT* const pmR = reinterpret_cast<PT*>(v.pm_r);   // (the planes in their storage type: double, or float with
@@ -658,7 +668,7 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
       rec.w = (int)UMASK;
     }
     LIN_LAP(0);
-    stage_camera_records(prep, 0, cam, st, lane);
+    stage_camera_records<2, SW>(prep, 0, cam, st, lane);
     LIN_LAP(1);
     // ---- phase A: value, dp/dq, dp/dK; M = dp/dq R; c = p x dp/dq ----
     bool ok = false;
@@ -677,7 +687,7 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
           q[i] = (RT)P[3 * i] * a[0] + (RT)P[3 * i + 1] * a[1] + (RT)P[3 * i + 2] * a[2];
         RT Kt[10];
 #pragma unroll
-        for (int i = 0; i < 10; ++i) Kt[i] = (RT)P[12 + i];
+        for (int i = 0; i < 10; ++i) Kt[i] = (12 + i < SW) ? (RT)P[12 + i] : (RT)0.0;  // (COMPACT stages 20 words: PINHOLE has 7)
         RT dpdq[2][3], px[2];
         project<true, RT>(rec.x, Kt, q, px, dpdq, Jint);
         r[0] = (double)(RT)((double)px[0] - fx);
@@ -686,7 +696,7 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
           pn0 = (double)q[0] / (double)q[2];
           pn1 = (double)q[1] / (double)q[2];
         }
-        const bool small = P[22] != 0.0;
+        const bool small = COMPACT ? false : P[COMPACT ? 0 : 22] != 0.0;  // (only the rotation columns need it: not formed when COMPACT)
         const RT p[3] = {small ? a[0] : q[0], small ? a[1] : q[1], small ? a[2] : q[2]};
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -1086,7 +1096,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
         for (int a = 0; a < DP; ++a) g[a] = v.gp[(size_t)a * NP + lp];
       }
       // the undamped V = Jp^T Jp is kept for the model cost change (back_substitute_kernel)
-      if (tm.leader) {
+      if (tm.leader && !ready) {
 #pragma unroll
         for (int i = 0; i < NS; ++i) v.Vraw[(size_t)i * NP + lp] = V[i];
       }
@@ -1097,7 +1107,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
       for (int a = 0; a < DP; ++a) {
         const double d = V[sym_idx(a, a, DP)];
         V[sym_idx(a, a, DP)] = d + fmin(fmax(d, lm_lo), lm_hi) * inv_radius;
-        if (tm.leader) v.gp[(size_t)a * NP + lp] = g[a];
+        if (tm.leader && !ready) v.gp[(size_t)a * NP + lp] = g[a];
         gmax = fmax(gmax, fabs(g[a] / v.scale_p[(size_t)lp * DP + a]));
       }
 #pragma unroll
