@@ -860,33 +860,27 @@ __global__ __launch_bounds__(256) void reduce_kernel(DeviceView v, View m, RedLa
 #pragma unroll
   for (int a = 0; a < D; ++a) a9[a] = 0.0;
   if (live) {
-    // a slot is D doubles at an 8-byte aligned address, fetched 16 bytes at a time.  A view has ~3 slots per thread: the
-    // indices of four trips are loaded as one batch and their slots as a second one (two memory round trips where the
-    // trip-by-trip loop had one per trip; every load unconditional, the index clamped, so that no s_waitcnt sits between
-    // them), summed in trip order: the same sums in the same order
+    // a slot is D doubles at an 8-byte aligned address: fetched 16 bytes at a time, the slot index of the thread's next
+    // trip already in flight (the two loads of a trip are dependent; a view has ~3 trips per thread).  (Round 6 measured a
+    // variant with the indices and the slots of four trips loaded as two batches: 42 us against 32, not kept.)
     const int k1 = m.cam_slot_ptr[rb + 1];
-    for (int k = m.cam_slot_ptr[rb] + (int)threadIdx.x; k < k1; k += 4 * 256) {
-      int slot[4];
+    int k = m.cam_slot_ptr[rb] + (int)threadIdx.x;
+    int slot = k < k1 ? m.cam_slots[k] : 0;
+    while (k < k1) {
+      const double* p = m.partial + (size_t)slot * D;
+      const int kn = k + 256;
+      if (kn < k1) slot = m.cam_slots[kn];
+      double t[D];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) slot[q] = m.cam_slots[min(k + 256 * q, k1 - 1)];
-      double t[4][D];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const double* p = m.partial + (size_t)slot[q] * D;
-#pragma unroll
-        for (int a = 0; a + 1 < D; a += 2) {
-          const double2_a8 t2 = *reinterpret_cast<const double2_a8*>(p + a);
-          t[q][a] = t2.x;
-          t[q][a + 1] = t2.y;
-        }
-        if (D & 1) t[q][D - 1] = p[D - 1];
+      for (int a = 0; a + 1 < D; a += 2) {
+        const double2_a8 t2 = *reinterpret_cast<const double2_a8*>(p + a);
+        t[a] = t2.x;
+        t[a + 1] = t2.y;
       }
+      if (D & 1) t[D - 1] = p[D - 1];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const bool on = k + 256 * q < k1;
-#pragma unroll
-        for (int a = 0; a < D; ++a) a9[a] = on ? a9[a] + t[q][a] : a9[a];
-      }
+      for (int a = 0; a < D; ++a) a9[a] += t[a];
+      k = kn;
     }
   }
 #pragma unroll
