@@ -2227,6 +2227,8 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
     s->fast_start_ok = !(env && env[0] == '0');
     env = getenv("TMI_BA_COMPACT_PLANES");
     s->compact_env = !(env && env[0] == '0');
+    env = getenv("TMI_BA_PCG_SPREAD");
+    v.pcg_spread = (env && env[0] == '0') ? 0 : 1;
     env = getenv("TMI_BA_FUSE_TRACK_SUMS");
     s->fuse_sums = !(env && env[0] == '0');
   }

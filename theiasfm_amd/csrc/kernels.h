@@ -543,19 +543,24 @@ __device__ __forceinline__ void compact_forward_view(const DeviceView& v, int rb
   for (int a = 0; a < 9; ++a) st_agent(&xs[(size_t)rb * 9 + a], g[a]);  // (pcg_step's last workgroup reads xz: agent scope)
 }
 // ... where lane a < 9 of a wavefront holds component a of the block (every lane of the wavefront calls)
-// (lanes 0..8 each form the block -- the loads of the record are the same addresses, broadcast -- and store their own entry)
-__device__ __forceinline__ void compact_forward_wave(const DeviceView& v, int rb, double val, int lane, double* __restrict__ xs) {
+// (lanes 0..8 each form the block -- the loads of the record are the same addresses, broadcast -- and keep their own entry)
+__device__ __forceinline__ double compact_forward_wave_value(const DeviceView& v, int rb, double val, int lane) {
   double xv[9];
 #pragma unroll
   for (int a = 0; a < 9; ++a) xv[a] = __shfl(val, a, 64);
+  double mine = 0.0;
   if (lane < 9) {
     double g[9];
     compact_forward(v.prep + (size_t)v.rb_cam[rb] * kPrepStride, xv, g);
-    double mine = g[0];
+    mine = g[0];
 #pragma unroll
     for (int a = 1; a < 9; ++a) mine = (lane == a) ? g[a] : mine;
-    st_agent(&xs[(size_t)rb * 9 + lane], mine);
   }
+  return mine;
+}
+__device__ __forceinline__ void compact_forward_wave(const DeviceView& v, int rb, double val, int lane, double* __restrict__ xs) {
+  const double mine = compact_forward_wave_value(v, rb, val, lane);
+  if (lane < 9) st_agent(&xs[(size_t)rb * 9 + lane], mine);
 }
 
 // linearize (kernel class 0).
@@ -2821,17 +2826,21 @@ __global__ __launch_bounds__(kPcgStepThreads) void pcg_step_kernel(DeviceView v,
   const double rho = v.scal[SC_RHO];
   const double alpha = rho / pq;
   double acc[2] = {0.0, 0.0};
+  // (pcg_spread: every workgroup forms the next p of its own blocks once the last one has published beta -- it keeps
+  //  p, z and the transformed z of its blocks in registers)
+  const bool spread = v.pcg_spread != 0;
+  double z = 0.0, gz = 0.0, p_old = 0.0;
   if (rb < v.Nrb && ok) {
     const int i = rb * D + lane;
     double rn = 0.0;
     if (lane < D) {
-      const double x = v.yc[i] + alpha * v.cg_p[i];
+      p_old = v.cg_p[i];
+      const double x = v.yc[i] + alpha * p_old;
       v.yc[i] = x;
       rn = v.cg_r[i] - alpha * v.cg_q[i];
       v.cg_r[i] = rn;
       acc[0] = -x * (b[i] + rn);
     }
-    double z = 0.0;
     const double* M = v.Minv + (size_t)rb * D * D + (lane < D ? lane : 0) * D;
 #pragma unroll
     for (int c = 0; c < D; ++c) {
@@ -2843,9 +2852,12 @@ __global__ __launch_bounds__(kPcgStepThreads) void pcg_step_kernel(DeviceView v,
       acc[1] = rn * z;
     }
     if constexpr (D == 9) {
-      // compact planes: the transformed block of z, by the wavefront that formed it -- the map is linear, so the last
-      // workgroup gets the transformed p = z + beta p as xz + beta xs, element by element (like p itself)
-      if (v.compact) compact_forward_wave(v, rb, z, lane, v.xz);
+      // compact planes: the transformed block of z, by the wavefront that formed it -- the map is linear, so the
+      // transformed p = z + beta p is xz + beta xs, element by element (like p itself)
+      if (v.compact) {
+        gz = compact_forward_wave_value(v, rb, z, lane);
+        if (!spread && lane < 9) st_agent(&v.xz[(size_t)rb * 9 + lane], gz);
+      }
     }
   }
   {
@@ -2868,7 +2880,40 @@ __global__ __launch_bounds__(kPcgStepThreads) void pcg_step_kernel(DeviceView v,
     }
     __syncthreads();
   }
-  if (!last) return;
+  // the next p of this workgroup's blocks, beta in hand: p = z + beta p and the copy the next product gathers
+  auto form_p = [&](double beta) {
+    if (rb < v.Nrb && lane < D) {
+      const int i = rb * D + lane;
+      const double pn = z + beta * p_old;
+      v.cg_p[i] = pn;
+      bool cpx = false;
+      if constexpr (D == 9) cpx = v.compact != 0;
+      if (cpx) v.xs[i] = gz + beta * v.xs[i];
+      else if (v.drop_pos) v.xs[i] = lane < 3 ? pn * v.scale_c[i] : pn;
+    }
+  };
+  unsigned long long* const beta_seq = reinterpret_cast<unsigned long long*>(&v.scal[SC_BETA_SEQ]);
+  if (!last) {
+    if (!spread || !ok) return;
+    // wait for the last workgroup's beta (all workgroups of this launch are resident: nblocks << CUs; the wait is bounded,
+    // a launch that cannot see the answer fails the linear solve instead of hanging)
+    if (threadIdx.x == 0) {
+      int state = -1;
+      for (unsigned spin = 0; spin < (1u << 24); ++spin) {
+        if (__hip_atomic_load(beta_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == seq) {
+          state = ld_agent(&v.scal[SC_BETA_STOP]) != 0.0 ? 1 : 0;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (state < 0) v.flags[FL_PCG_FAIL] = 1;
+      stop_sh = state != 0 ? 1 : 0;
+      beta_sh = state == 0 ? ld_agent(&v.scal[SC_BETA]) : 0.0;
+    }
+    __syncthreads();
+    if (!stop_sh) form_p(beta_sh);
+    return;
+  }
   double l0 = 0.0, l1 = 0.0;
   for (int i = threadIdx.x; i < nblocks; i += T) {
     l0 += ld_agent(&v.partial[i]);
@@ -2916,10 +2961,18 @@ __global__ __launch_bounds__(kPcgStepThreads) void pcg_step_kernel(DeviceView v,
     set(SC_PCG_STOP, stop ? 1.0 : 0.0);
     stop_sh = stop ? 1 : 0;
     beta_sh = ok ? rho_new / rho : 0.0;
+    if (spread && ok) {
+      // hand beta (or the stop) to the waiting workgroups: values first, then the sequence number they poll
+      st_agent(&v.scal[SC_BETA], beta_sh);
+      st_agent(&v.scal[SC_BETA_STOP], stop ? 1.0 : 0.0);
+      __hip_atomic_store(beta_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   __syncthreads();
   const int t = threadIdx.x;
-  if (!stop_sh) {
+  if (!stop_sh && spread) {
+    form_p(beta_sh);
+  } else if (!stop_sh) {
     // p = z + beta p, beta = rho' / rho, and (drop_pos) the copy the next product gathers: position entries times the
     // column scales (pos_scale_kernel's job for any other vector)
     const double beta = beta_sh;
