@@ -174,8 +174,6 @@ struct DeviceView {
   double* dotbuf;   // [Nrb] per-block partial dot products of the product kernels
   int* ticket;      // [4][kTicketStride] arrival counters of the "last workgroup finishes the reduction" kernels
   int* pcg_done;    // set by pcg_step once PCG has stopped: pcg_p, enqueued behind it, returns at once
-  int pcg_spread;   // pcg_step: every workgroup forms p = z + beta p of its own blocks after waiting for the last workgroup's
-                    //   beta (0: the last workgroup forms all of p; TMI_BA_PCG_SPREAD=0)
 };
 
 // host-visible copy of the device scalars (pinned, mapped, coherent memory): published by a
@@ -227,9 +225,6 @@ enum {
   SC_II_DINTR = 19,
   SC_II_XC = 22,    //   |candidate|^2 over the non-constant camera blocks
   SC_PCG_STOP = 24, // pcg_step: its stopping test held (what DeviceView::pcg_done says, for the host)
-  SC_BETA = 25,     // pcg_step (pcg_spread): beta, whether PCG stopped, and the launch's sequence number (bits of a
-  SC_BETA_STOP = 26, //   64-bit integer) -- the hand-over from the last workgroup to the others
-  SC_BETA_SEQ = 27,
   SC_COUNT = 32
 };
 // DeviceView::flags

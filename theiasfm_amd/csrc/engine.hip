@@ -2227,8 +2227,6 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
     s->fast_start_ok = !(env && env[0] == '0');
     env = getenv("TMI_BA_COMPACT_PLANES");
     s->compact_env = !(env && env[0] == '0');
-    env = getenv("TMI_BA_PCG_SPREAD");
-    v.pcg_spread = (env && env[0] == '0') ? 0 : 1;
     env = getenv("TMI_BA_FUSE_TRACK_SUMS");
     s->fuse_sums = !(env && env[0] == '0');
   }
@@ -3162,20 +3160,30 @@ static int run_inner_sweep(tmi_ba_solver* s, const tmi_ba_options* O) {
       {
         Timed t(s, TMI_BA_K_LINEARIZE);
         TMI_HIP(hipMemsetAsync(S.part, 0, part_bytes, stream));
-        if (kind == 0)
-          hipLaunchKernelGGL((inner_eval_kernel<0, true>), dim3(st.Nc), dim3(256), 0, stream, v, S);
-        else
-          hipLaunchKernelGGL((inner_eval_kernel<1, true>), dim3(st.Nc), dim3(256), 0, stream, v, S);
+        // (one camera model for the whole problem: the instantiation without the model switch, inner_kernels.h)
+        const bool uni = v.uniform_pinhole_default != 0;
+        if (kind == 0) {
+          if (uni) hipLaunchKernelGGL((inner_eval_kernel<0, true, 0>), dim3(st.Nc), dim3(256), 0, stream, v, S);
+          else hipLaunchKernelGGL((inner_eval_kernel<0, true>), dim3(st.Nc), dim3(256), 0, stream, v, S);
+        } else {
+          if (uni) hipLaunchKernelGGL((inner_eval_kernel<1, true, 0>), dim3(st.Nc), dim3(256), 0, stream, v, S);
+          else hipLaunchKernelGGL((inner_eval_kernel<1, true>), dim3(st.Nc), dim3(256), 0, stream, v, S);
+        }
       }
       if ((rc = do_allreduce(s, S.part, (int64_t)st.Nc * kInnerPart))) return rc;
       {
         Timed t(s, TMI_BA_K_LINEARIZE);
         hipLaunchKernelGGL(inner_step_kernel, dim3(S.nblocks), dim3(64), 0, stream, S);
         TMI_HIP(hipMemsetAsync(S.part, 0, part_bytes, stream));
-        if (kind == 0)
-          hipLaunchKernelGGL((inner_eval_kernel<0, false>), dim3(st.Nc), dim3(256), 0, stream, v, S);
-        else
-          hipLaunchKernelGGL((inner_eval_kernel<1, false>), dim3(st.Nc), dim3(256), 0, stream, v, S);
+        // (one camera model for the whole problem: the instantiation without the model switch, inner_kernels.h)
+        const bool uni = v.uniform_pinhole_default != 0;
+        if (kind == 0) {
+          if (uni) hipLaunchKernelGGL((inner_eval_kernel<0, false, 0>), dim3(st.Nc), dim3(256), 0, stream, v, S);
+          else hipLaunchKernelGGL((inner_eval_kernel<0, false>), dim3(st.Nc), dim3(256), 0, stream, v, S);
+        } else {
+          if (uni) hipLaunchKernelGGL((inner_eval_kernel<1, false, 0>), dim3(st.Nc), dim3(256), 0, stream, v, S);
+          else hipLaunchKernelGGL((inner_eval_kernel<1, false>), dim3(st.Nc), dim3(256), 0, stream, v, S);
+        }
       }
       if ((rc = do_allreduce(s, S.part, (int64_t)st.Nc * kInnerPart))) return rc;
       TMI_HIP(hipMemsetAsync(I.d_active, 0, sizeof(int), stream));

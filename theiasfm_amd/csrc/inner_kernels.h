@@ -70,7 +70,9 @@ enum { ISD_COST = 0, ISD_RADIUS = 1, ISD_DF = 2, ISD_XNORM = 3, ISD_MCC = 4, ISD
 enum { ISI_ITER = 0, ISI_INVALID = 1, ISI_DONE = 2, ISI_NEED_LIN = 3, ISI_TERM = 4, ISI_FRESH = 5 };
 
 // ---- evaluation: one workgroup per view ----------------------------------------------
-template <int KIND, bool JAC>
+// UMODEL >= 0: every camera of the problem has this camera model (DeviceView::uniform_pinhole_default: PINHOLE) -- the
+// five-way model switch folds at compile time; the generic Jacobian passes need all 256 registers (one wavefront per SIMD)
+template <int KIND, bool JAC, int UMODEL = -1>
 __global__ __launch_bounds__(256) void inner_eval_kernel(DeviceView v, InnerSet S) {
   constexpr int NMAX = KIND == 0 ? 6 : kInnerMaxN;
   constexpr int NSX = NMAX * (NMAX + 1) / 2;
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(256) void inner_eval_kernel(DeviceView v, InnerSet 
   if (!JAC && !(S.st_d[b * 8 + ISD_MCC] > 0.0)) return;  // the step was invalid: no candidate
   const int n = S.blk_n[b];
   const int grp = v.cam_grp[cam];
-  const int model = v.grp_model[grp];
+  const int model = UMODEL >= 0 ? UMODEL : v.grp_model[grp];
   const int nk = v.grp_off[grp + 1] - v.grp_off[grp];
   // the block's parameters come from x (linearisation point) or xc (candidate); everything
   // else from the outer candidate arrays

@@ -2826,16 +2826,12 @@ __global__ __launch_bounds__(kPcgStepThreads) void pcg_step_kernel(DeviceView v,
   const double rho = v.scal[SC_RHO];
   const double alpha = rho / pq;
   double acc[2] = {0.0, 0.0};
-  // (pcg_spread: every workgroup forms the next p of its own blocks once the last one has published beta -- it keeps
-  //  p, z and the transformed z of its blocks in registers)
-  const bool spread = v.pcg_spread != 0;
-  double z = 0.0, gz = 0.0, p_old = 0.0;
   if (rb < v.Nrb && ok) {
     const int i = rb * D + lane;
     double rn = 0.0;
+    double z = 0.0;
     if (lane < D) {
-      p_old = v.cg_p[i];
-      const double x = v.yc[i] + alpha * p_old;
+      const double x = v.yc[i] + alpha * v.cg_p[i];
       v.yc[i] = x;
       rn = v.cg_r[i] - alpha * v.cg_q[i];
       v.cg_r[i] = rn;
@@ -2854,10 +2850,7 @@ __global__ __launch_bounds__(kPcgStepThreads) void pcg_step_kernel(DeviceView v,
     if constexpr (D == 9) {
       // compact planes: the transformed block of z, by the wavefront that formed it -- the map is linear, so the
       // transformed p = z + beta p is xz + beta xs, element by element (like p itself)
-      if (v.compact) {
-        gz = compact_forward_wave_value(v, rb, z, lane);
-        if (!spread && lane < 9) st_agent(&v.xz[(size_t)rb * 9 + lane], gz);
-      }
+      if (v.compact) compact_forward_wave(v, rb, z, lane, v.xz);
     }
   }
   {
@@ -2880,40 +2873,7 @@ __global__ __launch_bounds__(kPcgStepThreads) void pcg_step_kernel(DeviceView v,
     }
     __syncthreads();
   }
-  // the next p of this workgroup's blocks, beta in hand: p = z + beta p and the copy the next product gathers
-  auto form_p = [&](double beta) {
-    if (rb < v.Nrb && lane < D) {
-      const int i = rb * D + lane;
-      const double pn = z + beta * p_old;
-      v.cg_p[i] = pn;
-      bool cpx = false;
-      if constexpr (D == 9) cpx = v.compact != 0;
-      if (cpx) v.xs[i] = gz + beta * v.xs[i];
-      else if (v.drop_pos) v.xs[i] = lane < 3 ? pn * v.scale_c[i] : pn;
-    }
-  };
-  unsigned long long* const beta_seq = reinterpret_cast<unsigned long long*>(&v.scal[SC_BETA_SEQ]);
-  if (!last) {
-    if (!spread || !ok) return;
-    // wait for the last workgroup's beta (all workgroups of this launch are resident: nblocks << CUs; the wait is bounded,
-    // a launch that cannot see the answer fails the linear solve instead of hanging)
-    if (threadIdx.x == 0) {
-      int state = -1;
-      for (unsigned spin = 0; spin < (1u << 24); ++spin) {
-        if (__hip_atomic_load(beta_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == seq) {
-          state = ld_agent(&v.scal[SC_BETA_STOP]) != 0.0 ? 1 : 0;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(2);
-      }
-      if (state < 0) v.flags[FL_PCG_FAIL] = 1;
-      stop_sh = state != 0 ? 1 : 0;
-      beta_sh = state == 0 ? ld_agent(&v.scal[SC_BETA]) : 0.0;
-    }
-    __syncthreads();
-    if (!stop_sh) form_p(beta_sh);
-    return;
-  }
+  if (!last) return;
   double l0 = 0.0, l1 = 0.0;
   for (int i = threadIdx.x; i < nblocks; i += T) {
     l0 += ld_agent(&v.partial[i]);
@@ -2961,28 +2921,40 @@ __global__ __launch_bounds__(kPcgStepThreads) void pcg_step_kernel(DeviceView v,
     set(SC_PCG_STOP, stop ? 1.0 : 0.0);
     stop_sh = stop ? 1 : 0;
     beta_sh = ok ? rho_new / rho : 0.0;
-    if (spread && ok) {
-      // hand beta (or the stop) to the waiting workgroups: values first, then the sequence number they poll
-      st_agent(&v.scal[SC_BETA], beta_sh);
-      st_agent(&v.scal[SC_BETA_STOP], stop ? 1.0 : 0.0);
-      __hip_atomic_store(beta_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
   }
   __syncthreads();
   const int t = threadIdx.x;
-  if (!stop_sh && spread) {
-    form_p(beta_sh);
-  } else if (!stop_sh) {
+  if (!stop_sh) {
     // p = z + beta p, beta = rho' / rho, and (drop_pos) the copy the next product gathers: position entries times the
-    // column scales (pos_scale_kernel's job for any other vector)
+    // column scales (pos_scale_kernel's job for any other vector).  Eight elements per thread and trip, every load of a
+    // trip issued before the first use: the agent-scope loads of z cost a round trip to the L2 each, and the element-by-
+    // element loop paid sixteen of them one after the other (31 -> 27 us per PCG iteration at Venice size).
+    // (Measured and NOT kept: every workgroup forming the p of its own blocks after a bounded wait for the last
+    //  workgroup's beta -- 26 us, but launches of several handles sharing a device can fill it with waiting workgroups.)
     const double beta = beta_sh;
     bool cpx = false;
     if constexpr (D == 9) cpx = v.compact != 0;
-    for (int i = t; i < n; i += T) {
-      const double pn = ld_agent(&v.cg_z[i]) + beta * v.cg_p[i];
-      v.cg_p[i] = pn;
-      if (cpx) v.xs[i] = ld_agent(&v.xz[i]) + beta * v.xs[i];  // (compact planes: xs = the transformed p, see above)
-      else if (v.drop_pos) v.xs[i] = (i % D) < 3 ? pn * v.scale_c[i] : pn;
+    constexpr int U = 8;
+    for (int i0 = t; i0 < n; i0 += U * T) {
+      double zz[U], pp[U], gg[U], xx[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = min(i0 + u * T, n - 1);
+        zz[u] = ld_agent(&v.cg_z[i]);
+        pp[u] = v.cg_p[i];
+        gg[u] = cpx ? ld_agent(&v.xz[i]) : 0.0;
+        xx[u] = cpx ? v.xs[i] : (v.drop_pos ? v.scale_c[i] : 0.0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * T;
+        if (i < n) {
+          const double pn = zz[u] + beta * pp[u];
+          v.cg_p[i] = pn;
+          if (cpx) v.xs[i] = gg[u] + beta * xx[u];  // (compact planes: xs = the transformed p, see above)
+          else if (v.drop_pos) v.xs[i] = (i % D) < 3 ? pn * xx[u] : pn;
+        }
+      }
     }
   }
   // publish (what publish_kernel does)
