@@ -635,7 +635,8 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
     for (int a = 0; a < DP; ++a) sp[a] = NORMS ? 1.0 : v.scale_p[(size_t)lp * DP + a];
     // drop_pos (device_view.h): pos_coef[a][track] = -w / scale_p[a] at the point and the scales these planes are taken at
     // (round 6: was a launch of its own after every linearize)
-    if (!NORMS && !SH && (UDROP || v.drop_pos) && tm.leader) {
+    // (COMPACT: no consumer of these planes reads pos_coef -- they take {X, w, 1 / scale_p} below)
+    if (!NORMS && !COMPACT && !SH && (UDROP || v.drop_pos) && tm.leader) {
 #pragma unroll
       for (int a = 0; a < 3; ++a) v.pos_coef[(size_t)a * v.Np_pad + lp] = -X[3] / sp[a];
     }
@@ -3192,7 +3193,7 @@ __global__ __launch_bounds__(256) void back_substitute_kernel(DeviceView v, int 
       for (int a = 0; a < DP; ++a) w[a] = tm.leader ? v.gp[(size_t)a * NP + lp] : 0.0;
       double ur = 0.0, uu = 0.0;
       double pc[3] = {0.0, 0.0, 0.0};  // drop_pos: -w / scale_p of this track (device_view.h)
-      if (!SH && v.drop_pos) {
+      if (!SH && v.drop_pos && !v.compact) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) pc[a] = v.pos_coef[(size_t)a * NP + lp];
       }

@@ -50,5 +50,5 @@ head -12 $O/${T}_config5_summary.txt
 tail -1 $O/${T}_config5.log | cut -c1-400
 mkdir -p $O/profiles_out && cp profiles/${T}_* profiles/pmc_latest.json profiles/pmc_venice1778_heavy_reference_defaults.json $O/profiles_out/ 2>/dev/null
 find $O/${T}_stats $O/${T}_pmc_FETCH_SIZE $O/${T}_pmc_WRITE_SIZE $O/${T}_alamo_stats $O/${T}_config5_stats $O/${T}_refdef_stats $O/${T}_refdef_pmc_FETCH_SIZE $O/${T}_refdef_pmc_WRITE_SIZE $O/${T}_config5_pmc_FETCH_SIZE $O/${T}_config5_pmc_WRITE_SIZE -type f -size +4M -delete
-TMI_PROBE_PROFILE=0 python tools/scale_probe.py 1 2 4 8 > $O/${T}_scale_probe.jsonl 2> $O/${T}_scale_probe.err
+TMI_PROBE_PROFILE=0 timeout 600 python tools/scale_probe.py 1 2 4 8 > $O/${T}_scale_probe.jsonl 2> $O/${T}_scale_probe.err
 cut -c1-200 $O/${T}_scale_probe.jsonl
