@@ -3166,7 +3166,7 @@ static int run_inner_sweep(tmi_ba_solver* s, const tmi_ba_options* O) {
           if (uni) hipLaunchKernelGGL((inner_eval_kernel<0, true, 0>), dim3(st.Nc), dim3(256), 0, stream, v, S);
           else hipLaunchKernelGGL((inner_eval_kernel<0, true>), dim3(st.Nc), dim3(256), 0, stream, v, S);
         } else {
-          if (uni) hipLaunchKernelGGL((inner_eval_kernel<1, true, 0>), dim3(st.Nc), dim3(256), 0, stream, v, S);
+          if (uni) hipLaunchKernelGGL((inner_eval_kernel<1, true, 0, 3>), dim3(st.Nc), dim3(256), 0, stream, v, S);  // (f, k1, k2)
           else hipLaunchKernelGGL((inner_eval_kernel<1, true>), dim3(st.Nc), dim3(256), 0, stream, v, S);
         }
       }
@@ -3218,8 +3218,15 @@ static int run_inner_sweep(tmi_ba_solver* s, const tmi_ba_options* O) {
     vc.pts = v.pts_c;
     Timed t(s, TMI_BA_K_LINEARIZE);
     prepare_cameras(s, v.ext_c, v.intr_c, v.prep_c);  // the two view sets moved the candidate cameras
-    if (s->DP == 3)
+    // (one camera model for the whole problem: the instantiation without the model switch, track_kernels.h)
+    if (s->DP == 3 && v.uniform_pinhole_default)
+      hipLaunchKernelGGL((track_lm_kernel<3, 0>), dim3(s->nblocks_tracks), dim3(256), 0, stream, vc, v.prep_c, A, s->d_trk_term,
+                         s->d_trk_iter, s->d_trk_c0, s->d_trk_c1);
+    else if (s->DP == 3)
       hipLaunchKernelGGL(track_lm_kernel<3>, dim3(s->nblocks_tracks), dim3(256), 0, stream, vc, v.prep_c, A, s->d_trk_term,
+                         s->d_trk_iter, s->d_trk_c0, s->d_trk_c1);
+    else if (v.uniform_pinhole_default)
+      hipLaunchKernelGGL((track_lm_kernel<4, 0>), dim3(s->nblocks_tracks), dim3(256), 0, stream, vc, v.prep_c, A, s->d_trk_term,
                          s->d_trk_iter, s->d_trk_c0, s->d_trk_c1);
     else
       hipLaunchKernelGGL(track_lm_kernel<4>, dim3(s->nblocks_tracks), dim3(256), 0, stream, vc, v.prep_c, A, s->d_trk_term,
@@ -3933,8 +3940,14 @@ int32_t tmi_ba_solver_adjust_tracks(tmi_ba_solver* s, const tmi_ba_options* O, i
   TMI_HIP(hipEventRecord(ea, s->stream));
   prepare_cameras(s, s->v.ext, s->v.intr, s->v.prep);  // (inside the timed region: part of the call's device work)
   if (st.nslices > 0) {
-    if (s->DP == 3)
+    if (s->DP == 3 && s->v.uniform_pinhole_default)
+      hipLaunchKernelGGL((track_lm_kernel<3, 0>), dim3(s->nblocks_tracks), dim3(256), 0, s->stream, s->v, s->v.prep, A,
+                         s->d_trk_term, s->d_trk_iter, s->d_trk_c0, s->d_trk_c1);
+    else if (s->DP == 3)
       hipLaunchKernelGGL(track_lm_kernel<3>, dim3(s->nblocks_tracks), dim3(256), 0, s->stream, s->v, s->v.prep, A,
+                         s->d_trk_term, s->d_trk_iter, s->d_trk_c0, s->d_trk_c1);
+    else if (s->v.uniform_pinhole_default)
+      hipLaunchKernelGGL((track_lm_kernel<4, 0>), dim3(s->nblocks_tracks), dim3(256), 0, s->stream, s->v, s->v.prep, A,
                          s->d_trk_term, s->d_trk_iter, s->d_trk_c0, s->d_trk_c1);
     else
       hipLaunchKernelGGL(track_lm_kernel<4>, dim3(s->nblocks_tracks), dim3(256), 0, s->stream, s->v, s->v.prep, A,

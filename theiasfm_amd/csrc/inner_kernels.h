@@ -72,9 +72,11 @@ enum { ISI_ITER = 0, ISI_INVALID = 1, ISI_DONE = 2, ISI_NEED_LIN = 3, ISI_TERM =
 // ---- evaluation: one workgroup per view ----------------------------------------------
 // UMODEL >= 0: every camera of the problem has this camera model (DeviceView::uniform_pinhole_default: PINHOLE) -- the
 // five-way model switch folds at compile time; the generic Jacobian passes need all 256 registers (one wavefront per SIMD)
-template <int KIND, bool JAC, int UMODEL = -1>
+// NFREE > 0: no block of the set has more free coordinates (the default mask of a PINHOLE view frees f, k1, k2: 3 -- ten
+// accumulators per thread instead of 66 in the intrinsics Jacobian pass)
+template <int KIND, bool JAC, int UMODEL = -1, int NFREE = 0>
 __global__ __launch_bounds__(256) void inner_eval_kernel(DeviceView v, InnerSet S) {
-  constexpr int NMAX = KIND == 0 ? 6 : kInnerMaxN;
+  constexpr int NMAX = NFREE > 0 ? NFREE : (KIND == 0 ? 6 : kInnerMaxN);
   constexpr int NSX = NMAX * (NMAX + 1) / 2;
   constexpr int NV = JAC ? 1 + NMAX + NSX : 1;
   const int cam = blockIdx.x;

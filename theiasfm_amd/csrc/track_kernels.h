@@ -158,7 +158,9 @@ struct TrackLmArgs {
 // iteration.  tm: thread per track, or 16 lanes per track on the long slices (kernels.h track_map) --
 // the sums are then finished over the 16 lanes with a fixed butterfly and every lane of the group holds
 // the same totals, so the trust-region loop below runs replicated and never diverges inside a group.
-template <int DP>
+// UMODEL >= 0: every camera of the problem has this camera model -- the five-way model switch folds (the generic
+// track_lm_kernel needs all 256 registers: one wavefront per SIMD) and the per-observation gather of cam_rec goes
+template <int DP, int UMODEL = -1>
 __device__ __forceinline__ bool track_linearize(const DeviceView& v, const double* __restrict__ prep,
                                                 const TrackMap& tm, const double X[4], const double sp[DP],
                                                 int loss_type, double loss_width, double V0[sym_size(DP)],
@@ -175,7 +177,7 @@ __device__ __forceinline__ bool track_linearize(const DeviceView& v, const doubl
     const int cam = v.obs_cam[e];
     const double* P = prep + (size_t)cam * kPrepStride;
     double r[2], Jext[2][6], Jint[2][10], Jpt[2][4];
-    const bool ok = reprojection_error_prepared<true, double>(v.cam_rec[cam].x, P, X, v.obs_xy[2 * e],
+    const bool ok = reprojection_error_prepared<true, double>(UMODEL >= 0 ? UMODEL : v.cam_rec[cam].x, P, X, v.obs_xy[2 * e],
                                                               v.obs_xy[2 * e + 1], r, Jext, Jint, Jpt);
     if (!ok) {
       bad = 1.0;
@@ -226,6 +228,7 @@ __device__ __forceinline__ bool track_linearize(const DeviceView& v, const doubl
   return group_sum(bad, tm.wide) == 0.0;
 }
 
+template <int UMODEL = -1>
 __device__ __forceinline__ bool track_cost(const DeviceView& v, const double* __restrict__ prep, const TrackMap& tm,
                                            const double X[4], int loss_type, double loss_width, double* cost) {
   double c = 0.0;
@@ -238,7 +241,7 @@ __device__ __forceinline__ bool track_cost(const DeviceView& v, const double* __
     double (*nul6)[6] = nullptr;
     double Jint[2][10];
     double (*nul4)[4] = nullptr;
-    const bool ok = reprojection_error_prepared<false, double>(v.cam_rec[cam].x, P, X, v.obs_xy[2 * e],
+    const bool ok = reprojection_error_prepared<false, double>(UMODEL >= 0 ? UMODEL : v.cam_rec[cam].x, P, X, v.obs_xy[2 * e],
                                                                v.obs_xy[2 * e + 1], r, nul6, Jint, nul4);
     if (!ok) {
       bad = 1.0;
@@ -263,7 +266,7 @@ __device__ __forceinline__ bool track_cost(const DeviceView& v, const double* __
 // IsSolutionUsable, bundle_adjuster.cc:213-216).  The trust-region loop is the one the
 // full solver runs (engine.hip / Ceres 1.14 TrustRegionMinimizer) with an empty camera
 // side: the step is -(V + D)^-1 g on the track's own 2k x DP Jacobian.
-template <int DP>
+template <int DP, int UMODEL = -1>
 __global__ __launch_bounds__(256) void track_lm_kernel(DeviceView v, const double* __restrict__ prep, TrackLmArgs A,
                                                        signed char* __restrict__ termination,
                                                        int* __restrict__ iterations,
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(256) void track_lm_kernel(DeviceView v, const doubl
   for (int a = 0; a < DP; ++a) sp[a] = 1.0;
   double V0[NS], g[DP], cost;
   // iteration zero
-  bool ok = track_linearize<DP>(v, prep, tm, X, sp, A.loss_type, A.loss_width, V0, g, &cost);
+  bool ok = track_linearize<DP, UMODEL>(v, prep, tm, X, sp, A.loss_type, A.loss_width, V0, g, &cost);
   if (tm.leader) initial_cost[lp] = cost;
   if (!ok) {
     if (tm.leader) {
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(256) void track_lm_kernel(DeviceView v, const doubl
   if (A.jacobi_scaling) {
 #pragma unroll
     for (int a = 0; a < DP; ++a) sp[a] = 1.0 / (1.0 + sqrt(V0[sym_idx(a, a, DP)]));
-    track_linearize<DP>(v, prep, tm, X, sp, A.loss_type, A.loss_width, V0, g, &cost);
+    track_linearize<DP, UMODEL>(v, prep, tm, X, sp, A.loss_type, A.loss_width, V0, g, &cost);
   }
   double x_norm = sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2] + X[3] * X[3]);
   double radius = A.initial_radius, decrease_factor = 2.0;
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(256) void track_lm_kernel(DeviceView v, const doubl
         step_sq += d * d;
       }
       double cand_cost;
-      if (!track_cost(v, prep, tm, Xc, A.loss_type, A.loss_width, &cand_cost)) cand_cost = 1.7976931348623157e308;
+      if (!track_cost<UMODEL>(v, prep, tm, Xc, A.loss_type, A.loss_width, &cand_cost)) cand_cost = 1.7976931348623157e308;
       if (sqrt(step_sq) <= A.parameter_tolerance * (x_norm + A.parameter_tolerance)) {
         term = 0;
         break;
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(256) void track_lm_kernel(DeviceView v, const doubl
 #pragma unroll
         for (int i = 0; i < 4; ++i) X[i] = Xc[i];
         x_norm = sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2] + X[3] * X[3]);
-        track_linearize<DP>(v, prep, tm, X, sp, A.loss_type, A.loss_width, V0, g, &cost);
+        track_linearize<DP, UMODEL>(v, prep, tm, X, sp, A.loss_type, A.loss_width, V0, g, &cost);
         gmax = 0.0;
 #pragma unroll
         for (int a = 0; a < DP; ++a) gmax = fmax(gmax, fabs(g[a] / sp[a]));
