@@ -74,7 +74,18 @@ def zero_rotation_view(prob):
     return prob
 
 
+def tiny_rotation_view(prob):
+    """view 0 with 0 < |w| <= 1.5e-8: the first-order branch with R = I + [w]x NOT orthogonal -- the one place where the
+    compact rotation columns differ from the stored ones (by O(|w|) relative)"""
+    prob.extrinsics[0, 3:6] = [1e-9, -2e-9, 1.5e-9]
+    sel = np.flatnonzero(prob.obs_camera == 0)
+    prob.obs_xy[sel] = synth.project(prob, sel) + 0.3
+    return prob
+
+
 CASES = {
+    "tiny_rotation_view": (lambda: tiny_rotation_view(synth.make_problem(40, 6000, 32000, seed=47, scene="ring", spread=0.5)),
+                           dict(point_dof=3, **IMPL)),
     "dof3": (lambda: synth.make_problem(60, 9000, 50000, seed=41, scene="ring", spread=0.4), dict(point_dof=3, **IMPL)),
     "dof4_parameter_blocks": (lambda: synth.make_problem(60, 9000, 50000, seed=43, scene="ring", spread=0.4),
                               dict(point_dof=4, preconditioner_type=abi.PRECOND_SCHUR_JACOBI_PARAMETER_BLOCKS, **IMPL)),
