@@ -199,3 +199,24 @@ def test_operator_info_reports_the_plane_layout(compact):
             os.environ.pop(k, None)
             if v is not None:
                 os.environ[k] = v
+
+
+def test_an_iteration_that_forms_S_relinearizes_with_the_full_planes():
+    """schur_mode auto with a low break-even (TMI_BA_BREAK_EVEN): the first LM iterations are matrix-free on compact planes,
+    a later one forms S -- its records need the stored camera block, so the engine linearises again with the full planes
+    (engine.hip, `v.compact && !v.direct_diag`); same trajectory as the run that never used compact planes"""
+    prob = synth.make_problem(50, 7000, 40000, seed=49, scene="ring", spread=0.5)
+    kw = dict(point_dof=3, linear_solver_type=abi.ITERATIVE_SCHUR, schur_mode=abi.SCHUR_AUTO, max_num_iterations=6,
+              function_tolerance=-1.0, gradient_tolerance=-1.0, parameter_tolerance=-1.0)  # (six: before the iterates are round-off)
+    saved = os.environ.pop("TMI_BA_BREAK_EVEN", None)
+    try:
+        os.environ["TMI_BA_BREAK_EVEN"] = "2"
+        a = run(prob, False, **dict(kw))
+        b = run(prob, True, **dict(kw))
+    finally:
+        os.environ.pop("TMI_BA_BREAK_EVEN", None)
+        if saved is not None:
+            os.environ["TMI_BA_BREAK_EVEN"] = saved
+    mf = b[0].num_matrix_free_iterations
+    assert 0 < mf < b[0].num_iterations, (mf, b[0].num_iterations)  # both operators ran
+    same_trajectory(a, b)
