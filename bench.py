@@ -92,6 +92,36 @@ def engine_source_sha():
     return h.hexdigest()[:16]
 
 
+def parse_setup_phases(stderr_text: str) -> dict:
+    """The LAST repeat's '[tmi_ba shim] <phase> <s> s' / '[tmi_ba setup...] <phase> <s> s' lines of tools/e2e_bench run
+    with TMI_BA_SETUP_TIMING=1, as {phase: seconds} plus three sums: the walk of the reference's containers
+    (AddViews / AddTracks), the flat tables the shim builds from them, and tmi_ba_solver_create (upload + device
+    structure build + work arrays)."""
+    import re
+    runs, cur = [], None
+    for line in stderr_text.splitlines():
+        m = re.match(r"\[tmi_ba (shim|setup|setup/device)\]\s+(.*?)\s+([0-9.]+) s\b", line)
+        if not m:
+            continue
+        name = ("device: " if m.group(1) != "shim" else "shim: ") + m.group(2).strip().rstrip(":")
+        if name == "shim: AddViews: feature tables":
+            cur = {}
+            runs.append(cur)
+        if cur is not None:
+            cur[name] = float(m.group(3))
+    if not runs:
+        return {}
+    last = runs[-1]
+    walk = last.get("shim: AddViews: total", 0.0) + last.get("shim: AddTracks", 0.0)
+    tables = sum(last.get(k, 0.0) for k in ("shim: id tables", "shim: parameters", "shim: order: histogram",
+                                            "shim: order: coarse scatter", "shim: order: output alloc", "shim: order: buckets",
+                                            "shim: observation order"))
+    create = last.get("device: create total (incl. upload)", 0.0)
+    return dict(phases=last, host_walk_of_reference_containers=round(walk, 4), host_flat_tables=round(tables, 4),
+                solver_create_upload_and_device_build=round(create, 4),
+                device_structure_build=round(last.get("device: structure total", 0.0), 4))
+
+
 def ceres_probe():
     """SURVEY 8(d) CPU-baseline plan, step 1: is a real Ceres / Eigen / TheiaSfM on this box?  (If so,
     tools/ceres_golden_main.cc can be built against it and `kind` becomes "reference"; otherwise the port.)"""
@@ -597,6 +627,15 @@ def main():
                         e2e[key] = json.loads(p.stdout.strip().splitlines()[-1])
                     except (ValueError, IndexError):
                         e2e[key] = dict(error=(p.stderr or p.stdout)[-400:], returncode=p.returncode)
+                # where the set-up of the drop-in call goes -- the phases the shim and
+                # tmi_ba_solver_create print with TMI_BA_SETUP_TIMING (second repeat of one more run: the first call of a
+                # process also loads the code objects), grouped host walk / host tables / device build
+                try:
+                    p = subprocess.run([exe, path, str(args.solve_length), "0", "2", "1"], capture_output=True, text=True,
+                                       timeout=900, env=dict(os.environ, TMI_BA_SETUP_TIMING="1"))
+                    e2e["setup_phases_seconds"] = parse_setup_phases(p.stderr)
+                except Exception as ex:  # noqa: BLE001  (diagnostics only)
+                    e2e["setup_phases_seconds"] = dict(error=str(ex)[:200])
                 out["end_to_end"] = e2e
         if solver is None:
             solver = lib.Solver(prob0.copy(), abi.default_options(max_num_iterations=1, **base), 0, 1)
