@@ -368,7 +368,18 @@ def main():
                     t_create=t_create, steps_run=done, elapsed=elapsed, summary=s, pcg=pcg, accepted=acc, matrix_free=mf,
                     secs_p=secs_p, launches_p=launches_p, secs_t=secs_t, launches_t=launches_t, dom_idx=dom_idx)
 
-    m = measure(args.workload, args.steps, args.warmup, True)
+    # One retry, visible in the line: if the headline solve FAILS on one rank with the compact planes (DESIGN.md section 3;
+    # seen once in this round on one box of the pool, never reproduced: profiles/r06_product_experiments.md), the run is
+    # repeated with the stored camera block and the line says so -- a failed solve is never reported as a number.
+    compact_retry = None
+    try:
+        m = measure(args.workload, args.steps, args.warmup, True)
+    except RuntimeError as ex:
+        if world != 1 or os.environ.get("TMI_BA_COMPACT_PLANES") == "0" or "solve failed" not in str(ex):
+            raise
+        compact_retry = str(ex)[:300]
+        os.environ["TMI_BA_COMPACT_PLANES"] = "0"
+        m = measure(args.workload, args.steps, args.warmup, True)
     solver, s, prob, prob0, base = m["solver"], m["summary"], m["prob"], m["prob0"], m["base"]
     steps_run, elapsed = m["steps_run"], m["elapsed"]
     n_obs, n_cam, n_pts = prob.num_observations, prob.num_cameras, prob.num_points
@@ -460,6 +471,7 @@ def main():
         allreduce = None
 
     out = dict(
+        **({"solve_failed_with_compact_planes_and_was_repeated_with_the_stored_block": compact_retry} if compact_retry else {}),
         metric="ba_observations_per_sec", value=n_obs * steps_run / elapsed, unit="observations/s",
         n_gpus=world, steps=steps_run, warmup=args.warmup, ms_per_step=1e3 * elapsed / max(steps_run, 1),
         higher_is_better=True, scaling="strong", vs_baseline=None,
