@@ -134,10 +134,11 @@ struct StageDims {
 
 // UMODEL >= 0 (as linearize_kernel's): every camera is of model UMODEL with the free-column mask UMASK and the loss is
 // TRIVIAL -- the model switch, the column compaction and the corrector fold at compile time
-template <int D, int DP, int UMODEL = -1, unsigned UMASK = 0u>
+// (ULOSS: the specialised body with the loss corrector left in, as linearize_kernel's)
+template <int D, int DP, int UMODEL = -1, unsigned UMASK = 0u, bool ULOSS = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TMI_DD_WAVES, TMI_DD_WAVES))) void camera_diag_direct_kernel(DeviceView v, Plan pl, const double* __restrict__ prep,
                                                                 int loss_type_arg, double loss_width) {
-  const int loss_type = UMODEL >= 0 ? 0 : loss_type_arg;
+  const int loss_type = (UMODEL >= 0 && !ULOSS) ? 0 : loss_type_arg;
   static_assert(D + 2 <= 16, "one 16 x 16 accumulator holds S_cc (D x D), g~ and g_c");
   constexpr int NS = sym_size(D);
   constexpr int TR = trk_stride(DP);

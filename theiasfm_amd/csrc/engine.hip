@@ -135,6 +135,10 @@ Launch make_launch(bool fp32) {
               hipLaunchKernelGGL((linearize_kernel<D, DP, SH, double, 2, double, 0, kPinholeDefaultMask, true, true>), dim3(nb), dim3(256),
                                  0, st, v, prep, lt, lw, nb, sums);
               special = true;
+            } else if (v.uniform_pinhole_default) {  // (a robust loss: the specialised body with the corrector left in)
+              hipLaunchKernelGGL((linearize_kernel<D, DP, SH, double, 2, double, 0, kPinholeDefaultMask, true, true, false, true>), dim3(nb),
+                                 dim3(256), 0, st, v, prep, lt, lw, nb, sums);
+              special = true;
             }
           }
           if (!special)
@@ -156,6 +160,18 @@ Launch make_launch(bool fp32) {
           else
             hipLaunchKernelGGL((linearize_kernel<D, DP, SH, double, 2, double, 0, kPinholeDefaultMask, false>), dim3(nb), dim3(256), 0, st, v,
                                prep, lt, lw, nb, sums);
+          return;
+        }
+        // ... with a robust loss (the reference's application flags: HUBER): the same bodies with the corrector left in;
+        // compact planes then hold [C p_n | r^2 .] per observation (DeviceView::compact == 2)
+        if (v.uniform_pinhole_default && v.drop_pos) {
+          if (v.compact)
+            // (two workgroups per CU: with the corrector the body spills at the 168 registers three would allow)
+            hipLaunchKernelGGL((linearize_kernel<D, DP, SH, double, TMI_LIN_OCC, double, 0, kPinholeDefaultMask, true, false, true, true>),
+                               dim3(nb), dim3(256), 0, st, v, prep, lt, lw, nb, sums);
+          else
+            hipLaunchKernelGGL((linearize_kernel<D, DP, SH, double, TMI_LIN_OCC, double, 0, kPinholeDefaultMask, true, false, false, true>),
+                               dim3(nb), dim3(256), 0, st, v, prep, lt, lw, nb, sums);
           return;
         }
       }
@@ -215,6 +231,10 @@ Launch make_launch(bool fp32) {
           if (v.uniform_pinhole_default && lt == 0) {  // (as linearize: every camera PINHOLE / default mask, no robust loss)
             hipLaunchKernelGGL((ddg::camera_diag_direct_kernel<D, DP, 0, kPinholeDefaultMask>), dim3(pl.n_chunks), dim3(64), 0, st, v, pl,
                                prep, lt, lw);
+            special = true;
+          } else if (v.uniform_pinhole_default) {  // ... with a robust loss: the same body, corrector left in
+            hipLaunchKernelGGL((ddg::camera_diag_direct_kernel<D, DP, 0, kPinholeDefaultMask, true>), dim3(pl.n_chunks), dim3(64), 0, st,
+                               v, pl, prep, lt, lw);
             special = true;
           }
         }
@@ -305,8 +325,12 @@ Launch make_launch(bool fp32) {
       if (!xs_ready) hipLaunchKernelGGL((pos_scale_kernel<D>), dim3((n + 255) / 256), dim3(256), 0, st, v, x, v.xs);
       bool cp_done = false;
       if constexpr (D == 9) {
-        if (m.n_items && v.compact) {
-          hipExtLaunchKernelGGL((mfc::product_kernel<D, DP, true, true>), dim3(m.n_items), dim3(mfc::kThreads), 0, st, ev_a, nullptr, 0, v,
+        if (m.n_items && v.compact == 2) {
+          hipExtLaunchKernelGGL((mfc::product_kernel<D, DP, true, 2>), dim3(m.n_items), dim3(mfc::kThreads), 0, st, ev_a, nullptr, 0, v,
+                                m, (const double*)v.xs);
+          cp_done = true;
+        } else if (m.n_items && v.compact) {
+          hipExtLaunchKernelGGL((mfc::product_kernel<D, DP, true, 1>), dim3(m.n_items), dim3(mfc::kThreads), 0, st, ev_a, nullptr, 0, v,
                                 m, (const double*)v.xs);
           cp_done = true;
         }
@@ -487,6 +511,7 @@ struct tmi_ba_solver {
   bool fast_start_ok = true;  // TMI_BA_FAST_START=0: linearize + point_scale + point_eliminate before the scaled linearize
   bool compact_env = true;    // TMI_BA_COMPACT_PLANES=0: always the full planes (device_view.h, DeviceView::compact)
   bool fuse_sums = true;      // TMI_BA_FUSE_TRACK_SUMS=0: point_eliminate sweeps the planes for V and g_p as before
+  bool compact_robust = true; // TMI_BA_COMPACT_ROBUST=0: compact planes for the TRIVIAL loss only
   bool cost_by_view = false;   // ... and the trial cost view by view (every observation owns a slot)
   bool cost_warm = true;       // ... which also reads linearize's observation stream into the Infinity Cache (TMI_BA_COST_WARM=0: off)
   bool implicit = false;      // S is never formed (schur_mode)
@@ -2229,6 +2254,8 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
     s->compact_env = !(env && env[0] == '0');
     env = getenv("TMI_BA_FUSE_TRACK_SUMS");
     s->fuse_sums = !(env && env[0] == '0');
+    env = getenv("TMI_BA_COMPACT_ROBUST");
+    s->compact_robust = !(env && env[0] == '0');
   }
   v.direct_diag = 0;
   {
@@ -3316,8 +3343,8 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
   // solve starts from), matrix-free iterations of the one-sweep product whose camera side is built view by view
   // (no kernel reads the A planes then but the product and back_substitute).  Decided per linearize from the operator
   // the next LM iteration is expected to run; an iteration that forms S after all re-linearizes with the full planes.
-  bool compact_possible = s->compact_env && v.drop_pos && v.uniform_pinhole_default && s->mf_ok && s->direct_ok && D == 9 && lt == 0 &&
-                          iterative && !s->cluster_blocks && v.cp_trk != nullptr && !v.planes_fp32;
+  bool compact_possible = s->compact_env && v.drop_pos && v.uniform_pinhole_default && s->mf_ok && s->direct_ok && D == 9 &&
+                          (lt == 0 || s->compact_robust) && iterative && !s->cluster_blocks && v.cp_trk != nullptr && !v.planes_fp32;
   if (compact_possible) {
     compact_possible = (int)s->grp_off_h.size() == st.G + 1;
     for (int g = 0; g < st.G && compact_possible; ++g) {
@@ -3328,7 +3355,9 @@ int32_t tmi_ba_solver_solve(tmi_ba_solver* s, const tmi_ba_options* O, tmi_ba_su
   int last_pcg_len = 0;  // PCG iterations of the previous LM iteration (0: none yet)
   auto linearize = [&](bool norms_only = false, bool full_planes = false) {
     if (!norms_only)
-      v.compact = (!full_planes && compact_possible && (s->implicit || (s->adaptive && last_pcg_len <= s->adaptive_break_even))) ? 1 : 0;
+      v.compact = (!full_planes && compact_possible && (s->implicit || (s->adaptive && last_pcg_len <= s->adaptive_break_even)))
+                      ? (lt == 0 ? 1 : 2)  // (2: a robust loss -- the planes hold the corrected point and r^2)
+                      : 0;
     if (!norms_only) v.sums_ready = (v.compact && s->fuse_sums) ? 1 : 0;  // (the compact instantiation also leaves V and g_p)
     // cost and sum of squares land in d_sc[0..1] (finished by the kernel's last workgroup)
     Timed t(s, TMI_BA_K_LINEARIZE);

@@ -504,20 +504,23 @@ __device__ __forceinline__ double compact_backward(const double* __restrict__ P,
 }
 // A x of one observation from the gathered g, the track's {X, w, 1 / scale_p} and the observation's Jp (interleaved
 // rows) and p_n
+// (a robust loss -- DeviceView::compact == 2 -- multiplies every column pair of the block by the observation's 2 x 2
+//  corrector C: Jp is stored corrected anyway, pn is then C p_n, and r^2 = |p_n|^2 of the UNcorrected point comes from
+//  its own plane: r2 >= 0; r2 < 0 means "take |pn|^2", the TRIVIAL loss)
 __device__ __forceinline__ void compact_ax(const double (&g)[9], const double (&X)[4], const double (&isp)[3],
-                                           const double2 (&jp)[3], double2 pn, double& u0, double& u1) {
+                                           const double2 (&jp)[3], double2 pn, double& u0, double& u1, double r2_in = -1.0) {
   const double w = X[3];
   const double c0 = (g[4] * X[2] - g[5] * X[1] - w * g[0]) * isp[0];
   const double c1 = (g[5] * X[0] - g[3] * X[2] - w * g[1]) * isp[1];
   const double c2 = (g[3] * X[1] - g[4] * X[0] - w * g[2]) * isp[2];
-  const double r2 = pn.x * pn.x + pn.y * pn.y;
+  const double r2 = r2_in >= 0.0 ? r2_in : pn.x * pn.x + pn.y * pn.y;
   const double pr = g[6] + r2 * (g[7] + r2 * g[8]);
   u0 = jp[0].x * c0 + jp[1].x * c1 + jp[2].x * c2 + pn.x * pr;
   u1 = jp[0].y * c0 + jp[1].y * c1 + jp[2].y * c2 + pn.y * pr;
 }
 // the nine moment contributions of one observation: [-w h | X x h | (p_n . t) (1, r^2, r^4)], h = Jp'^T t
 __device__ __forceinline__ void compact_at(const double (&X)[4], const double (&isp)[3], const double2 (&jp)[3], double2 pn,
-                                           double t0, double t1, double (&o)[9]) {
+                                           double t0, double t1, double (&o)[9], double r2_in = -1.0) {
   const double h0 = isp[0] * (jp[0].x * t0 + jp[0].y * t1);
   const double h1 = isp[1] * (jp[1].x * t0 + jp[1].y * t1);
   const double h2 = isp[2] * (jp[2].x * t0 + jp[2].y * t1);
@@ -528,7 +531,7 @@ __device__ __forceinline__ void compact_at(const double (&X)[4], const double (&
   o[3] = X[1] * h2 - X[2] * h1;
   o[4] = X[2] * h0 - X[0] * h2;
   o[5] = X[0] * h1 - X[1] * h0;
-  const double r2 = pn.x * pn.x + pn.y * pn.y;
+  const double r2 = r2_in >= 0.0 ? r2_in : pn.x * pn.x + pn.y * pn.y;
   const double pt = pn.x * t0 + pn.y * t1;
   o[6] = pt;
   o[7] = r2 * pt;
@@ -586,12 +589,13 @@ __device__ unsigned long long g_lin_prof[8];
 // COMPACT (device_view.h): the specialised instantiation stores p_n instead of the camera block -- the second half record
 // is never staged, no column of A is formed -- and leaves the track's {X, w, 1 / scale_p} for the consumers.
 template <int D, int DP, bool SH, typename RT, int OCC, typename PT = double, int UMODEL = -1, unsigned UMASK = 0u,
-          bool UDROP = false, bool NORMS = false, bool COMPACT = false>
+          bool UDROP = false, bool NORMS = false, bool COMPACT = false, bool ULOSS = false>
 __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const double* __restrict__ prep,
                                                              int loss_type_arg, double loss_width, int nblocks,
                                                              double* __restrict__ sums) {
-  // (the specialised instantiation is also the TRIVIAL-loss one: the engine launches it for loss_type 0 only)
-  const int loss_type = UMODEL >= 0 ? 0 : loss_type_arg;
+  // (the specialised instantiation folds the TRIVIAL loss unless ULOSS: the reference's application flags ask for HUBER,
+  //  applications/build_reconstruction_flags.txt:117 -- the same bodies with the corrector left in)
+  const int loss_type = (UMODEL >= 0 && !ULOSS) ? 0 : loss_type_arg;
   // COMPACT: R, C, f, the principal point, k1, k2 are words 0..18 of the record -- 20 staged words, 45 instead of 53 KB of
   // LDS: a third workgroup fits a CU
   constexpr int SW = COMPACT ? 20 : kStageWords;
@@ -788,8 +792,23 @@ __global__ __launch_bounds__(256, OCC) void linearize_kernel(DeviceView v, const
           PST(0.0, &pmR[pidx<2>(0, e)]);
           PST(0.0, &pmR[pidx<2>(1, e)]);
         }
-        PST(ok ? pn0 : 0.0, &pmA[pidx<2>(0, e)]);
-        PST(ok ? pn1 : 0.0, &pmA[pidx<2>(1, e)]);
+        if constexpr (ULOSS) {
+          // a robust loss: the corrected point C p_n (C = sqrt(rho') (I - alpha r r^T / |r|^2), as on every column pair)
+          // and, in a second pair, r^2 of the uncorrected one
+          double q0 = pn0, q1 = pn1;
+          if (loss_type != 0) {
+            const double rtj = q0 * r[0] + q1 * r[1];
+            q0 = sqrt_rho1 * (q0 - asn * r[0] * rtj);
+            q1 = sqrt_rho1 * (q1 - asn * r[1] * rtj);
+          }
+          PST(ok ? q0 : 0.0, &pmA[pidx<4>(0, e)]);
+          PST(ok ? q1 : 0.0, &pmA[pidx<4>(1, e)]);
+          PST(ok ? pn0 * pn0 + pn1 * pn1 : 0.0, &pmA[pidx<4>(2, e)]);
+          PST(0.0, &pmA[pidx<4>(3, e)]);
+        } else {
+          PST(ok ? pn0 : 0.0, &pmA[pidx<2>(0, e)]);
+          PST(ok ? pn1 : 0.0, &pmA[pidx<2>(1, e)]);
+        }
       }
       continue;
     }
@@ -3237,8 +3256,13 @@ __global__ __launch_bounds__(256) void back_substitute_kernel(DeviceView v, int 
                 const double2 j3[3] = {make_double2((double)pmJp[pidx<2 * DP>(0, e)], (double)pmJp[pidx<2 * DP>(1, e)]),
                                        make_double2((double)pmJp[pidx<2 * DP>(2, e)], (double)pmJp[pidx<2 * DP>(3, e)]),
                                        make_double2((double)pmJp[pidx<2 * DP>(4, e)], (double)pmJp[pidx<2 * DP>(5, e)])};
-                const double2 pn = make_double2((double)pmA[pidx<2>(0, e)], (double)pmA[pidx<2>(1, e)]);
-                compact_ax(yv, Xt, ispt, j3, pn, u0, u1);
+                if (v.compact == 2) {  // a robust loss: [C p_n | r^2 .] per observation
+                  const double2 pn = make_double2((double)pmA[pidx<4>(0, e)], (double)pmA[pidx<4>(1, e)]);
+                  compact_ax(yv, Xt, ispt, j3, pn, u0, u1, (double)pmA[pidx<4>(2, e)]);
+                } else {
+                  const double2 pn = make_double2((double)pmA[pidx<2>(0, e)], (double)pmA[pidx<2>(1, e)]);
+                  compact_ax(yv, Xt, ispt, j3, pn, u0, u1);
+                }
               }
             }
 #pragma unroll

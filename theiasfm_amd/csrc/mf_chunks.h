@@ -305,9 +305,11 @@ __device__ __forceinline__ double2 mf_stream_load(const double2* p) {
 // CP: compact planes (device_view.h, DeviceView::compact): pm_A holds p_n alone, x is the transformed vector
 // [kappa | eta | a0 a1 a2] of every view (compact_forward), the sums are the moments compact_backward maps back
 // (reduce_kernel).  Same units, runs, slots and summation orders as the full planes.
-template <int D, int DP, bool DROP, bool CP = false>
+// (CP == 2: a robust loss -- pm_A holds [C p_n | r^2 .] per observation, 32 bytes)
+template <int D, int DP, bool DROP, int CP = 0>
 __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View m, const double* __restrict__ x) {
   static_assert(!CP || (DROP && D == 9), "compact planes: the 9-wide PINHOLE block without stored position columns");
+  constexpr size_t CPT = CP == 2 ? 256 : 128;  // doubles of a 64-observation tile of the compact pm_A
   constexpr int A0 = DROP ? 3 : 0;  // first stored column of the A planes
   constexpr int LCM = lc_max(D);
   constexpr int VB = vb_entries(D);
@@ -374,9 +376,11 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
           double g[9];
 #pragma unroll
           for (int a = 0; a < 9; ++a) g[a] = xc[a];
-          const double2 pn = *reinterpret_cast<const double2*>(v.pm_A + (e >> 6) * (size_t)128 + ((e & 63) << 1));
+          const double* cpa = v.pm_A + (e >> 6) * CPT + ((e & 63) << 1);
+          const double2 pn = *reinterpret_cast<const double2*>(cpa);
+          const double r2 = CP == 2 ? cpa[128] : -1.0;
           const double2 j3[3] = {jj[0], jj[1], jj[2]};
-          compact_ax(g, Xw, ispw, j3, pn, u0, u1);
+          compact_ax(g, Xw, ispw, j3, pn, u0, u1, r2);
         } else if (DROP) {
 #pragma unroll
           for (int a = 0; a < 3; ++a) {
@@ -437,9 +441,11 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
           for (int a = 0; a < 3; ++a) ispe[a] = v.cp_trk[(size_t)(4 + a) * v.Np_pad + lpe];
           const double2 j3[3] = {*reinterpret_cast<const double2*>(jp), *reinterpret_cast<const double2*>(jp + 128),
                                  *reinterpret_cast<const double2*>(jp + 256)};
-          const double2 pn = *reinterpret_cast<const double2*>(v.pm_A + (e >> 6) * (size_t)128 + ((e & 63) << 1));
+          const double* cpa = v.pm_A + (e >> 6) * CPT + ((e & 63) << 1);
+          const double2 pn = *reinterpret_cast<const double2*>(cpa);
+          const double r2 = CP == 2 ? cpa[128] : -1.0;
           double o[9];
-          compact_at(Xe, ispe, j3, pn, t.x, t.y, o);
+          compact_at(Xe, ispe, j3, pn, t.x, t.y, o, r2);
 #pragma unroll
           for (int a = 0; a < 9; ++a) sum[a] += o[a];
         } else if (DROP) {
@@ -551,6 +557,7 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
     double uu[RR][2];
     double pcr[RR][3];  // DROP: -w / scale_p of the row's track
     double2 pnr[RR];    // CP: p_n of the row's observation, {X, w} and 1 / scale_p of its track
+    double r2r[RR];     // CP == 2: r^2 of the uncorrected point (-1: take |p_n|^2)
     double Xr[RR][4], ispr[RR][3];
     int pos[RR];
     // ---- the batch of loads
@@ -587,7 +594,8 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
 #pragma unroll
           for (int a = A0; a < D; ++a) ar[rr][a] = MF_STREAM_LOAD(reinterpret_cast<const double2*>(ap + a * 128));
         } else {
-          pnr[rr] = MF_STREAM_LOAD(reinterpret_cast<const double2*>(v.pm_A + (tile0 + R) * (size_t)128 + 2 * tl));
+          pnr[rr] = MF_STREAM_LOAD(reinterpret_cast<const double2*>(v.pm_A + (tile0 + R) * CPT + 2 * tl));
+          if (CP == 2) r2r[rr] = MF_STREAM_LOAD(reinterpret_cast<const double2*>(v.pm_A + (tile0 + R) * CPT + 128 + 2 * tl)).x;
         }
 #pragma unroll
         for (int a = 0; a < DP; ++a) jr[rr][a] = MF_STREAM_LOAD(reinterpret_cast<const double2*>(jp + a * 128));
@@ -610,6 +618,7 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
         for (int a = 0; a < 3; ++a) pcr[rr][a] = 0.0;
         if (CP) {
           pnr[rr] = make_double2(0.0, 0.0);
+          r2r[rr] = 0.0;
 #pragma unroll
           for (int a = 0; a < 4; ++a) Xr[rr][a] = 0.0;
 #pragma unroll
@@ -636,7 +645,7 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
       }
       if constexpr (CP) {
         const double2 j3[3] = {jr[rr][0], jr[rr][1], jr[rr][2]};
-        compact_ax(xr[rr], Xr[rr], ispr[rr], j3, pnr[rr], s0, s1);
+        compact_ax(xr[rr], Xr[rr], ispr[rr], j3, pnr[rr], s0, s1, CP == 2 ? r2r[rr] : -1.0);
       } else if (DROP) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -728,7 +737,7 @@ __global__ __launch_bounds__(kThreads, 2) void product_kernel(DeviceView v, View
         if constexpr (CP) {
           const double2 j3[3] = {jr[rr][0], jr[rr][1], jr[rr][2]};
           double o[9];
-          compact_at(Xr[rr], ispr[rr], j3, pnr[rr], uu[rr][0], uu[rr][1], o);
+          compact_at(Xr[rr], ispr[rr], j3, pnr[rr], uu[rr][0], uu[rr][1], o, CP == 2 ? r2r[rr] : -1.0);
 #pragma unroll
           for (int a = 0; a < 9; ++a) dst[a] = o[a];
         } else if (DROP) {
