@@ -48,15 +48,15 @@ def compact_forward(P, x):
     return np.concatenate([kappa, eta, [a0, P["k1"] * a0 + P["f"] * P["s_k1"] * x[7], P["k2"] * a0 + P["f"] * P["s_k2"] * x[8]]])
 
 
-def compact_ax(g, X, isp, Jp_st, pn):
+def compact_ax(g, X, isp, Jp_st, pn, r2=None):
     c = (np.cross(g[3:6], X[:3]) - X[3] * g[0:3]) * isp
-    r2 = pn @ pn
+    r2 = pn @ pn if r2 is None else r2
     return Jp_st @ c + pn * (g[6] + r2 * (g[7] + r2 * g[8]))
 
 
-def compact_at(X, isp, Jp_st, pn, t):
+def compact_at(X, isp, Jp_st, pn, t, r2=None):
     h = isp * (Jp_st.T @ t)
-    r2, pt = pn @ pn, pn @ t
+    r2, pt = (pn @ pn if r2 is None else r2), pn @ t
     return np.concatenate([-X[3] * h, np.cross(X[:3], h), [pt, r2 * pt, r2 * r2 * pt]])
 
 
@@ -156,3 +156,26 @@ def test_the_maps_are_adjoint(scene):
         lhs += compact_ax(compact_forward(P, x), prob.points[p], isp, Jp, pn) @ t
         mom += compact_at(prob.points[p], isp, Jp, pn, t)
     assert abs(lhs - x @ compact_backward(P, mom)) <= 1e-10 * max(1.0, abs(lhs))
+
+
+def test_a_robust_loss_corrects_the_point_block_and_the_stored_pair(scene):
+    """Ceres' corrector multiplies every column pair of an observation by one 2 x 2 matrix C: with Jp and p_n corrected and
+    r^2 of the UNcorrected point handed over separately (DeviceView::compact == 2) the compact maps give C A x and (C A)^T t"""
+    prob, J = scene
+    rng = np.random.default_rng(13)
+    s_c = 1.0 / (1.0 + rng.uniform(0.0, 50.0, size=(prob.num_cameras, 9)))
+    s_p = 1.0 / (1.0 + rng.uniform(0.0, 50.0, size=(prob.num_points, 3)))
+    for o in range(0, prob.num_observations, 7):
+        c, p = prob.obs_camera[o], prob.obs_point[o]
+        A, Jp = full_block(J[o])
+        r = rng.standard_normal(2)
+        C = 0.8 * (np.eye(2) - 0.3 * np.outer(r, r) / (r @ r))  # sqrt(rho') (I - alpha r r^T / |r|^2)
+        A_s, Jp_st = C @ (A * s_c[c][None, :]), C @ (Jp * s_p[p][None, :])
+        pn = normalised_point(prob, o)
+        X, isp = prob.points[p], 1.0 / s_p[p]
+        P = view_record(prob, c, s_c[c])
+        x, t = rng.standard_normal(9), rng.standard_normal(2)
+        u = compact_ax(compact_forward(P, x), X, isp, Jp_st, C @ pn, r2=pn @ pn)
+        np.testing.assert_allclose(u, A_s @ x, rtol=0, atol=1e-10 * np.abs(A_s).max() * np.abs(x).max())
+        y = compact_backward(P, compact_at(X, isp, Jp_st, C @ pn, t, r2=pn @ pn))
+        np.testing.assert_allclose(y, A_s.T @ t, rtol=0, atol=1e-10 * max(1.0, np.abs(A_s).max()))
