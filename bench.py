@@ -908,6 +908,21 @@ def main():
             out["variants"]["venice1778_heavy_point_dof4-synthetic"] = dict(
                 steps=int(sm4.num_iterations), ms_per_step=round(1e3 * sm4.solve_time_in_seconds / max(1, sm4.num_iterations), 3),
                 pcg_iterations=int(sm4.num_linear_solver_iterations), final_rmse=sm4.final_rmse)
+            # the reference's APPLICATION loss: HUBER of width 10 (applications/build_reconstruction_flags.txt:117-121) on the
+            # headline problem and options -- the specialised bodies with the corrector left in and compact planes holding
+            # the corrected point plus r^2; round 5 and before: the generic bodies
+            oh = dict(point_dof=3, linear_solver_type=abi.ITERATIVE_SCHUR, use_inner_iterations=0, loss_function_type=abi.LOSS_HUBER,
+                      robust_loss_width=10.0, function_tolerance=-1.0, gradient_tolerance=-1.0, parameter_tolerance=-1.0)
+            sh = lib.Solver(prob0.copy(), abi.default_options(max_num_iterations=2, **oh))
+            sh.solve(abi.default_options(max_num_iterations=2, **oh))
+            sh.reset()
+            _, smh = sh.solve(abi.default_options(max_num_iterations=10, **oh))
+            compact_h = sh.operator_info().get("compact_planes", False)
+            sh.close()
+            out["variants"]["venice1778_heavy_huber10-synthetic"] = dict(
+                steps=int(smh.num_iterations), ms_per_step=round(1e3 * smh.solve_time_in_seconds / max(1, smh.num_iterations), 3),
+                pcg_iterations=int(smh.num_linear_solver_iterations), final_rmse=smh.final_rmse, compact_planes=bool(compact_h),
+                loss="HUBER", robust_loss_width=10.0)
             # BASELINE config 5 at Venice size (synth.config5): mixed camera models, intrinsics shared by 33 groups of 2-200
             # views, fp32 residual evaluation (fp64 accumulation); CLUSTER_JACOBI over {shared block, its views} with the
             # matrix-free operator (schur_mode auto), and SCHUR_JACOBI -- round 2's operating point -- beside it
