@@ -225,3 +225,37 @@ def test_an_iteration_that_forms_S_relinearizes_with_the_full_planes():
     mf = b[0].num_matrix_free_iterations
     assert 0 < mf < b[0].num_iterations, (mf, b[0].num_iterations)  # both operators ran
     same_trajectory(a, b)
+
+
+def with_constant_views(prob, every):
+    """every `every`-th view constant altogether (extrinsics and its private intrinsics): the views outside the subset of
+    BundleAdjustPartialReconstruction (bundle_adjuster.cc:141-180) -- they have no block in the reduced system"""
+    for c in range(0, prob.num_cameras, every):
+        prob.camera_flags[c] = abi.CAMERA_POSITION_CONSTANT | abi.CAMERA_ORIENTATION_CONSTANT
+        g = prob.camera_group[c]
+        prob.intrinsics_constant[prob.group_offset[g]:prob.group_offset[g + 1]] = 1
+    return prob
+
+
+@pytest.mark.parametrize("dof", [3, 4])
+def test_partial_adjustment_with_constant_views_takes_the_compact_planes(dof):
+    """a third of the views constant: the specialised bodies and the compact planes serve the free ones (the constant
+    views' observations still feed the point side); same trajectory as the stored block, same minimum as the oracle"""
+    from oracle import oracle
+    prob = with_constant_views(synth.make_problem(60, 9000, 50000, seed=81, scene="ring", spread=0.4), 3)
+    kw = dict(point_dof=dof, max_num_iterations=6, **IMPL)
+    a = run(prob, False, **dict(kw))
+    b = run(prob, True, **dict(kw))
+    same_trajectory(a, b)
+    saved = os.environ.pop("TMI_BA_COMPACT_PLANES", None)
+    o = abi.default_options(use_inner_iterations=0, **kw)
+    ref = prob.copy()
+    st_o, s_o = oracle.solve(ref, o)
+    assert st_o == 0
+    assert abs(b[0].final_cost - s_o.final_cost) <= 1e-9 * s_o.final_cost
+    assert b[0].num_iterations == s_o.num_iterations and b[0].num_linear_solver_iterations == s_o.num_linear_solver_iterations
+    # the constant views did not move
+    fixed = np.arange(0, prob.num_cameras, 3)
+    assert np.array_equal(b[1].extrinsics[fixed], prob.extrinsics[fixed])
+    if saved is not None:
+        os.environ["TMI_BA_COMPACT_PLANES"] = saved

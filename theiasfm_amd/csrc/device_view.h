@@ -72,7 +72,8 @@ struct DeviceView {
                           //   (matrix-free product without shared blocks; null otherwise)
   const int* cam_grp;
   const int4* cam_rec;         // [Nc] {camera model, intrinsics offset, #intrinsics, free-column mask}
-  int uniform_pinhole_default; // every camera: PINHOLE, free columns = extrinsics + f + k1 + k2 (kPinholeDefaultMask)
+  int uniform_pinhole_default; // every camera: PINHOLE, free columns = extrinsics + f + k1 + k2 (kPinholeDefaultMask) -- or
+                               //   none at all (a constant view has no block)
   const int* cam_rb;
   const unsigned* cam_mask;
   const int* grp_model;

@@ -2116,8 +2116,16 @@ static int create_impl(tmi_ba_solver* s, const tmi_ba_problem* P, const tmi_ba_o
       if ((rc = dev_upload(s, &pr, rec))) return rc;
       v.cam_rec = pr;
       // one camera model and one free-column mask for the whole problem?  (the specialised linearize, kernels.h)
+      // (a view that is constant altogether -- mask 0, no block: the views outside the subset of
+      //  BundleAdjustPartialReconstruction, bundle_adjuster.cc:141-180 -- does not break the uniformity: its observations
+      //  are evaluated with the same model and nobody reads a camera block of theirs)
       bool uni = st.Nc > 0 && !st.has_shared;
-      for (int c = 0; c < st.Nc && uni; ++c) uni = rec[c].x == TMI_BA_PINHOLE && (unsigned)rec[c].w == kPinholeDefaultMask;
+      bool any_free = false;
+      for (int c = 0; c < st.Nc && uni; ++c) {
+        uni = rec[c].x == TMI_BA_PINHOLE && ((unsigned)rec[c].w == kPinholeDefaultMask || rec[c].w == 0);
+        any_free = any_free || rec[c].w != 0;
+      }
+      uni = uni && any_free;
       if (const char* e = getenv("TMI_BA_LINEARIZE_GENERIC")) uni = uni && atoi(e) == 0;  // A/B, tests
       v.uniform_pinhole_default = uni ? 1 : 0;
     }
